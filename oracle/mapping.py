@@ -1,0 +1,96 @@
+"""Oracle (NumPy, CPU): QAM constellation, mapper and LLR demapper.
+
+TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  Restates ``mapping.py`` of the
+reference (paths relative to /root/reference/src/sionna/phy):
+
+* pam_gray / qam               mapping.py:15-118
+* Mapper.call                  mapping.py:497-519
+* Demapper.call                mapping.py:664-691
+* SymbolLogits2LLRs            mapping.py:880-967  (app = logsumexp, maxlog = max)
+
+The demapper formula is pinned by the reference's own NumPy test
+(test/unit/mapping/test_mapping.py:175-199): scipy ``logsumexp`` over the point sets
+C_{i,1} / C_{i,0}, atol 1e-5.
+"""
+import numpy as np
+
+
+def pam_gray(b):
+    """mapping.py:15-42"""
+    if len(b) > 1:
+        return (1 - 2 * b[0]) * (2 ** len(b[1:]) - pam_gray(b[1:]))
+    return 1 - 2 * b[0]
+
+
+def qam(num_bits_per_symbol, normalize=True, dtype=np.complex64):
+    """mapping.py:44-118"""
+    if num_bits_per_symbol % 2 != 0 or num_bits_per_symbol <= 0:
+        raise ValueError("num_bits_per_symbol must be a multiple of 2")
+    rdtype = np.float32 if dtype == np.complex64 else np.float64
+    c = np.zeros([2 ** num_bits_per_symbol], dtype=dtype)
+    for i in range(2 ** num_bits_per_symbol):
+        b = np.array(list(np.binary_repr(i, num_bits_per_symbol)), dtype=np.int32)
+        c[i] = pam_gray(b[0::2]) + 1j * pam_gray(b[1::2])
+    if normalize:
+        n = num_bits_per_symbol // 2
+        qam_var = 1 / (2 ** (n - 2)) * np.sum(
+            np.linspace(1, 2 ** n - 1, 2 ** (n - 1), dtype=rdtype) ** 2)
+        c /= np.sqrt(qam_var)
+    return c
+
+
+def mapper(bits, points):
+    """mapping.py:497-519: [...,n] 0/1 -> [...,n/m] symbols (MSB first)."""
+    m = int(np.log2(len(points)))
+    bits = np.asarray(bits).astype(np.int32)
+    b = bits.reshape(bits.shape[:-1] + (bits.shape[-1] // m, m))
+    idx = np.sum(b << np.arange(m - 1, -1, -1, dtype=np.int32), axis=-1)
+    return points[idx]
+
+
+def _bit_sets(m):
+    """mapping.py:888-901: indices of the points whose i-th label bit is 0 / 1."""
+    num_points = 2 ** m
+    a = np.zeros([num_points, m], np.int32)
+    for i in range(num_points):
+        a[i, :] = np.array(list(np.binary_repr(i, m)), dtype=np.int32)
+    c0 = np.zeros([num_points // 2, m], np.int64)
+    c1 = np.zeros([num_points // 2, m], np.int64)
+    for i in range(m):
+        c0[:, i] = np.where(a[:, i] == 0)[0]
+        c1[:, i] = np.where(a[:, i] == 1)[0]
+    return c0, c1
+
+
+def _logsumexp(x, axis):
+    mx = np.max(x, axis=axis, keepdims=True)
+    mx = np.where(np.isfinite(mx), mx, 0)
+    return (np.log(np.sum(np.exp(x - mx), axis=axis, keepdims=True)) + mx).squeeze(axis)
+
+
+def demapper(y, no, points, method="app", hard_out=False):
+    """mapping.py:664-691 + 927-967 (no prior).  y: [...,S] complex; no scalar or [...,S].
+
+    Returns logits log p(b=1)/p(b=0), shape [..., S*m], symbol-major then bit index.
+    """
+    rdtype = np.float32 if y.dtype == np.complex64 else np.float64
+    m = int(np.log2(len(points)))
+    c0, c1 = _bit_sets(m)
+    sq = np.abs(y[..., None] - points.astype(y.dtype)) ** 2          # [...,S,2^m]
+    no = np.asarray(no, rdtype)
+    if no.ndim > 0:
+        no = np.broadcast_to(no, y.shape)
+    no = np.maximum(no[..., None], np.finfo(rdtype).tiny)
+    expo = (-sq / no).astype(rdtype)
+    e0 = expo[..., c0]                                               # [...,S,2^m/2,m]
+    e1 = expo[..., c1]
+    if method == "app":
+        llr = _logsumexp(e1, axis=-2) - _logsumexp(e0, axis=-2)
+    elif method == "maxlog":
+        llr = np.max(e1, axis=-2) - np.max(e0, axis=-2)
+    else:
+        raise AssertionError("Unknown demapping method")
+    llr = llr.reshape(y.shape[:-1] + (y.shape[-1] * m,)).astype(rdtype)
+    if hard_out:
+        return (llr > 0).astype(rdtype)
+    return llr
