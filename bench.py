@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Headline benchmark: codeword-decodes/sec, 5G LDPC BG1 n=8448 rate 1/3, BP 20 iterations
+(BASELINE.json metric, config C2; C3 = the same sharded over ranks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--cn-update minsum|boxplus-phi|...]
+
+One step = one pass of the decoder hot path over one resident batch: LDPC5GDecoder.call on a
+[B, 8448] float32 LLR tensor that is already in HBM (generated untimed by the library's own
+chain: BinarySource -> LDPC5GEncoder -> 64-QAM Mapper -> AWGN -> app Demapper), followed by
+the error count against the transmitted bits and, for N > 1 ranks, the RCCL all-reduce of the
+four int64 counters (the only collective of the path; ranks are otherwise independent ->
+weak scaling, B codewords per GPU).  Rank 0 prints ONE JSON line.
+
+`roofline`  : dominant kernel of the timed step, ALGORITHMIC bytes B_msg (SURVEY 8d:
+              13,684,736 B per C2 decode) / its average duration measured here with HIP events
+              on the launch stream; peak = 8 TB/s HBM3E.  For the on-chip min-sum engine the
+              message traffic never reaches HBM, so frac may exceed 1 - `compulsory_io_gbps`
+              (4n+4k bytes per decode) is the traffic that really crosses HBM.
+`cpu_baseline`: oracle/ldpc_bp.c (plain-C restatement of the reference algorithm, OpenMP over
+              codewords, all host cores) on a bounded sample of the same LLRs, rank 0, N=1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K_INFO, N_CW, M_BITS, BG = 2816, 8448, 6, "bg1"
+N_VN, N_CN, N_EDGES = 8704, 5888, 40448
+HBM_PEAK_GBPS = 8000.0
+
+
+def b_msg(num_iter, k_out):
+    """algorithmic bytes per decode of the HBM-resident formulation."""
+    return num_iter * (16 * N_EDGES + 4 * N_VN) + 4 * N_CW + 4 * k_out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536, help="codewords per GPU")
+    ap.add_argument("--num-iter", type=int, default=20)
+    ap.add_argument("--cn-update", default="minsum", choices=["minsum", "offset-minsum", "boxplus-phi", "boxplus"])
+    ap.add_argument("--engine", default="auto", choices=["auto", "generic"],
+                    help="generic forces the HBM-resident decoder also for min-sum")
+    ap.add_argument("--ebno-db", type=float, default=4.5)
+    ap.add_argument("--also", default="boxplus-phi", help="second CN rule timed with fewer steps ('' = none)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="codewords for the CPU baseline (0 = auto)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs a torch.distributed.run launch", file=sys.stderr)
+            sys.exit(2)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    dev = _ffi.device()
+    phy.config.seed = 20250923
+
+    B, k, n, m = args.batch, K_INFO, N_CW, M_BITS
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=BG)
+    src, mapper, awgn = phy.mapping.BinarySource(), phy.mapping.Mapper("qam", m), phy.channel.AWGN()
+    demap = phy.mapping.Demapper("app", "qam", m)
+    no = phy.utils.ebnodb2no(args.ebno_db, m, k / n)
+
+    def make_dec(cn):
+        d = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=args.num_iter, hard_out=True, return_infobits=True)
+        if args.engine == "generic":
+            d._onchip_ok = False
+        return d
+
+    # ---- synthetic batch, resident in HBM before the timed region
+    t0 = time.perf_counter()
+    u = src([B, k])
+    llr = demap(awgn(mapper(enc(u)), no), no)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+
+    counters = torch.zeros(4, dtype=torch.int64, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(dec):
+        u_hat = dec(llr)
+        phy.utils.metrics.count_errors_into(u, u_hat, counters[:2])
+        counters[2] += u.numel()
+        counters[3] += B
+        if world > 1:
+            red = counters.clone()
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            return red
+        return counters
+
+    def run(dec, steps, warmup):
+        for _ in range(warmup):
+            step(dec)
+        counters.zero_()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t_start = time.perf_counter()
+        for i in range(steps):
+            # HIP events on the launch stream bracket the decoder kernels only
+            ev[i][0].record()
+            u_hat = dec(llr)
+            ev[i][1].record()
+            phy.utils.metrics.count_errors_into(u, u_hat, counters[:2])
+            counters[2] += u.numel()
+            counters[3] += B
+            if world > 1:
+                red = counters.clone()
+                dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        barrier()
+        t_wall = time.perf_counter() - t_start
+        t = torch.tensor([t_wall], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dec_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        c = counters.clone()
+        if world > 1:
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        c = c.cpu().numpy()
+        return float(t.item()), dec_ms, c
+
+    dec = make_dec(args.cn_update)
+    t_wall, dec_ms, c = run(dec, args.steps, args.warmup)
+    onchip = bool(dec._onchip_ok and dec._cn_mode in (2, 3))
+    total_cw = B * world * args.steps
+    value = total_cw / t_wall
+    bytes_alg = b_msg(args.num_iter, k) * B
+    achieved = bytes_alg / (dec_ms * 1e-3) / 1e9
+    kernel = "ldpc5g_decode_kernel (on-chip, LDS-resident min-sum)" if onchip else \
+             "cn_pass_kernel + vn_pass_kernel (HBM-resident, 2 launches per iteration)"
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": kernel,
+                "algorithmic_bytes_per_decode": b_msg(args.num_iter, k),
+                "decoder_ms_per_launch_set": round(dec_ms, 3),
+                "compulsory_io_gbps": round((4 * n + 4 * k) * B / (dec_ms * 1e-3) / 1e9, 1)}
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(prof):                      # PMC-derived HBM bytes per launch, if recorded
+        try:
+            with open(prof) as f:
+                tr = json.load(f)
+            key = f"{args.cn_update}:{'onchip' if onchip else 'generic'}:B{B}"
+            roofline["traffic"] = tr.get(key)
+        except Exception:  # pylint: disable=broad-except
+            pass
+    if onchip:
+        roofline["note"] = ("messages stay in LDS: frac is relative to the HBM-resident formulation's "
+                            "algorithmic bytes and may exceed 1; real HBM traffic = compulsory_io")
+
+    out = {
+        "metric": "codeword-decodes/sec (n=8448, BP iters=20)", "value": round(value, 1),
+        "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(t_wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "C2: 5G LDPC BG1 k=2816 n=8448 (rate 1/3, Z=128), 64-QAM AWGN LLRs, flooding BP "
+                               f"{args.num_iter} iterations, batch {B} per GPU",
+                   "cn_update": args.cn_update, "engine": "on-chip" if onchip else "generic-hbm",
+                   "batch_per_gpu": B, "ebno_db": args.ebno_db, "parallelism": f"dp{world}"},
+        "ber": float(c[0] / max(c[2], 1)), "bler": float(c[1] / max(c[3], 1)),
+        "input_generation_s": round(t_gen, 3),
+        "roofline": roofline,
+    }
+
+    if args.also and args.also != args.cn_update:
+        dec2 = make_dec(args.also)
+        steps2 = max(2, args.steps // 3)
+        t2, ms2, c2 = run(dec2, steps2, 1)
+        on2 = bool(dec2._onchip_ok and dec2._cn_mode in (2, 3))
+        ach2 = bytes_alg / (ms2 * 1e-3) / 1e9
+        out["also"] = {"cn_update": args.also, "engine": "on-chip" if on2 else "generic-hbm",
+                       "value": round(B * world * steps2 / t2, 1), "unit": "codewords/s",
+                       "decoder_ms": round(ms2, 3), "ber": float(c2[0] / max(c2[2], 1)),
+                       "bler": float(c2[1] / max(c2[3], 1)),
+                       "roofline": {"bound": "hbm", "achieved": round(ach2, 1), "peak": HBM_PEAK_GBPS,
+                                    "unit": "GB/s", "frac": round(ach2 / HBM_PEAK_GBPS, 4)}}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cbind, ldpc_bp as obp
+        from oracle.ldpc5g import LDPC5GCode
+        odec = obp.LDPC5GDecoder(LDPC5GCode(k, n, m, BG), cn_update=args.cn_update, num_iter=args.num_iter)
+        cores = cbind.num_threads()
+        sample = llr[:min(B, 4 * cores)].cpu().numpy()
+        l5 = odec.rate_recover(sample)
+        t0 = time.perf_counter()
+        cbind.bp_decode(odec, l5)
+        t_probe = max(time.perf_counter() - t0, 1e-3)
+        ns = args.cpu_sample or int(min(B, max(4 * cores, 15.0 / (t_probe / len(l5)))))
+        ns = max(cores, ns // cores * cores)
+        sample = llr[:ns].cpu().numpy()
+        l5 = odec.rate_recover(sample)
+        t0 = time.perf_counter()
+        ref = cbind.bp_decode(odec, l5)
+        t_cpu = time.perf_counter() - t0
+        agree = float(np.mean(ref[:, :k] == dec(llr[:ns]).cpu().numpy()))
+        out["cpu_baseline"] = {"value": round(ns / t_cpu, 2), "unit": "codewords/s", "cores": cores,
+                               "kind": "port",
+                               "sample": f"{ns} codewords of the same C2 LLR batch, oracle/ldpc_bp.c "
+                                         f"({args.cn_update}, {args.num_iter} iterations, OpenMP over codewords), "
+                                         f"{t_cpu:.1f} s",
+                               "hard_decision_agreement_with_gpu": agree}
+        out["speedup_vs_cpu_baseline"] = round(value / (ns / t_cpu), 1)
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

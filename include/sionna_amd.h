@@ -1,0 +1,163 @@
+/*
+ * sionna_amd.h - C-ABI of the MI355X (gfx950) hot-path library  libsionna_amd.so
+ *
+ * This is the drop-in boundary of the build: every entry point below replaces one
+ * chain of TensorFlow ops of the reference (NVlabs/sionna v1.2.1, paths relative to
+ * src/sionna/phy/).  The reference has NO native code and no FFI of its own
+ * (SURVEY.md section 0, fact 1), so the functions are what a ctypes / pybind11 binding
+ * inside the reference's Block.call() methods would bind.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only; no torch / TF types.
+ *  - All data pointers are DEVICE pointers (HBM) unless the parameter is documented as
+ *    "host".  The caller owns every buffer, including the workspace (query its size
+ *    with the matching *_workspace_bytes call).  The library owns only opaque handles.
+ *  - Tensors are batch-first, row-major, exactly like the reference API
+ *    (bits = float32 0.0/1.0, LLRs = logits log p(1)/p(0), symbols = interleaved
+ *    complex64).
+ *  - Every launch is asynchronous on the caller's stream (hipStream_t passed as void*;
+ *    NULL = default stream).  Functions are re-entrant per (handle, stream).
+ *  - Return value: 0 = OK, negative = error (samd_last_error() gives a thread-local
+ *    message).  Nothing throws across the ABI.
+ */
+#ifndef SIONNA_AMD_H
+#define SIONNA_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAMD_OK 0
+#define SAMD_ERR_INVALID (-1)
+#define SAMD_ERR_HIP (-2)
+#define SAMD_ERR_UNSUPPORTED (-3)
+#define SAMD_ERR_WORKSPACE (-4)
+
+/* check-node update rules of LDPCBPDecoder(cn_update=...)  fec/ldpc/decoding.py:295-312 */
+#define SAMD_CN_BOXPLUS 0        /* cn_update_tanh          decoding.py:955-1043  */
+#define SAMD_CN_BOXPLUS_PHI 1    /* cn_update_phi (default) decoding.py:1045-1166 */
+#define SAMD_CN_MINSUM 2         /* cn_update_minsum        decoding.py:911-953   */
+#define SAMD_CN_OFFSET_MINSUM 3  /* cn_update_offset_minsum decoding.py:755-909   */
+
+const char* samd_last_error(void);
+int samd_version(void);
+/* number of visible HIP devices, or a negative error */
+int samd_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Generic LDPC flooding BP decoder (any parity-check matrix).
+ * Replaces LDPCBPDecoder.call + _bp_iter      fec/ldpc/decoding.py:544-637, 416-524
+ *          vn_update_sum                      fec/ldpc/decoding.py:681-732
+ *          cn_update_{tanh,phi,minsum,offset_minsum}  decoding.py:755-1166
+ * ---------------------------------------------------------------------------------- */
+typedef struct samd_ldpc_graph samd_ldpc_graph_t;
+
+/* Edge list in VN-major order (ascending VN, ascending CN inside a VN) - the edge order
+ * of decoding.py:282-288 with a stable sort.  cn_idx / vn_idx: HOST int32[num_edges]. */
+int samd_ldpc_graph_create(const int32_t* cn_idx, const int32_t* vn_idx, int num_edges,
+                           int num_cn, int num_vn, samd_ldpc_graph_t** out);
+void samd_ldpc_graph_destroy(samd_ldpc_graph_t* g);
+
+size_t samd_ldpc_bp_workspace_bytes(const samd_ldpc_graph_t* g, int batch);
+
+/* llr_in  [batch, num_vn] logits (clipped to +-llr_max inside, decoding.py:552-554)
+ * out     [batch, out_cols]: columns 0..out_cols-1 of x_hat (out_cols <= num_vn);
+ *         hard_out=1 -> 0/1 with "0 >= LLR_internal -> 1" (decoding.py:623), else logits
+ * state   nullable [num_edges, batch] v2c messages in logit sign (IDD state,
+ *         decoding.py:569-573, 636): read when state_in!=0, written when state_out!=0
+ * offset  only used by SAMD_CN_OFFSET_MINSUM (reference default 0.5)                  */
+int samd_ldpc_bp_decode_f32(const samd_ldpc_graph_t* g, const float* llr_in, float* out,
+                            int out_cols, float* state, int state_in, int state_out,
+                            int batch, int num_iter, int cn_mode, float llr_max,
+                            float offset, int hard_out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * 5G-NR LDPC (quasi-cyclic) code handle: encoder, rate matching / recovery, decoder.
+ * Replaces LDPC5GEncoder.__init__/call   fec/ldpc/encoding.py:61-137, 599-668
+ *          LDPC5GDecoder.__init__/call   fec/ldpc/decoding.py:1302-1403, 1427-1536
+ * The handle stores the base-graph entries (38.212 Tab. 5.3.2-2/-3 for the chosen
+ * i_LS) - rows/cols/shifts: HOST int16[num_entries], raw shift values (mod Z applied
+ * inside, encoding.py:343-346).  num_bits_per_symbol = 0 disables the 38.212 5.4.2.2
+ * output interleaver (encoding.py:196-246).  nb_pruned = pruned trailing rows/columns
+ * of the PCM used by the DECODER (decoding.py:1344-1373; 0 = unpruned).
+ * ---------------------------------------------------------------------------------- */
+typedef struct samd_ldpc5g samd_ldpc5g_t;
+
+int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int16_t* cols,
+                       const int16_t* shifts, int num_entries, int k, int n,
+                       int num_bits_per_symbol, int nb_pruned, samd_ldpc5g_t** out);
+void samd_ldpc5g_destroy(samd_ldpc5g_t* h);
+
+/* bits [batch,k] float32 0/1 -> out [batch,n] float32 0/1 (encode + rate-match +
+ * interleave), bit-exact with u*G mod 2 of the reference's golden matrices. */
+int samd_ldpc5g_encode_f32(const samd_ldpc5g_t* h, const float* bits, float* out,
+                           int batch, void* stream);
+
+/* Rate recovery only (decoding.py:1431-1475): llr [batch,n] -> out [batch,N_vn] logits,
+ * N_vn = n_ldpc - nb_pruned; filler positions = -llr_max, punctured = 0. */
+int samd_ldpc5g_rate_recover_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
+                                 int batch, float llr_max, void* stream);
+
+/* Decoder output mapping (decoding.py:1486-1536): x_hat [batch,N_vn] -> out [batch,n]
+ * (drop filler, drop first 2Z, keep n, re-interleave). */
+int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const float* x_hat,
+                                     float* out, int batch, void* stream);
+
+size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode);
+
+/* Whole LDPC5GDecoder.call on chip: rate recovery + num_iter flooding BP iterations +
+ * output mapping in ONE kernel, one codeword per workgroup, messages resident in LDS
+ * (min-sum family: compressed check-node state).  cn_mode must be SAMD_CN_MINSUM or
+ * SAMD_CN_OFFSET_MINSUM; returns SAMD_ERR_UNSUPPORTED when the code does not fit in
+ * LDS (caller then uses rate_recover + samd_ldpc_bp_decode_f32 + extract).
+ * llr [batch,n] logits -> out [batch,k] (return_infobits=1) or [batch,n] (=0). */
+int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
+                           int batch, int num_iter, int cn_mode, float llr_max,
+                           float offset, int hard_out, int return_infobits,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Mapping.  points: DEVICE complex64[2^m] (interleaved re,im), label of point i = binary
+ * representation of i, MSB first (mapping.py:486-514).
+ * ---------------------------------------------------------------------------------- */
+/* Mapper.call mapping.py:497-519: bits [num_symbols*m] -> symbols [num_symbols] */
+int samd_qam_map_c64(const float* bits, const float* points, int m, int64_t num_symbols,
+                     float* out_symbols, void* stream);
+
+/* Demapper.call + SymbolLogits2LLRs.call (no prior)  mapping.py:664-691, 927-967.
+ * y [num_symbols] complex64; no: scalar (no_len=1, DEVICE pointer) or per symbol
+ * (no_len=num_symbols); method 0 = "app" (logsumexp), 1 = "maxlog";
+ * out [num_symbols*m] logits (or hard decisions llr>0 when hard_out, misc.py:270). */
+int samd_qam_demap_f32(const float* y, const float* no, int64_t no_len, const float* points,
+                       int m, int64_t num_symbols, int method, int hard_out, float* out,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Random sources and AWGN.  Counter-based Philox4x32-10 stream keyed by (seed, call);
+ * executable specification: oracle/utils.py.
+ * ---------------------------------------------------------------------------------- */
+/* BinarySource.call mapping.py:1350-1352: out[n] float32 in {0,1} */
+int samd_binary_source_f32(uint64_t seed, uint64_t call, int64_t n, float* out, void* stream);
+
+/* AWGN.call channel/awgn.py:63-78 + complex_normal utils/misc.py:19-54:
+ * y = x + sqrt(no) * CN(0,1); x,y complex64[n]; no DEVICE scalar (no_len=1) or [n]. */
+int samd_awgn_c64(const float* x, const float* no, int64_t no_len, uint64_t seed,
+                  uint64_t call, int64_t n, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Error counting  utils/metrics.py:94-144 (count_errors, count_block_errors).
+ * b, b_hat [num_blocks, block_len] float32; counters: DEVICE int64[2], ADDED to:
+ * counters[0] += #(b != b_hat), counters[1] += #blocks with any mismatch.
+ * soft!=0 applies hard_decisions (llr > 0, misc.py:270) to b_hat first.
+ * ---------------------------------------------------------------------------------- */
+int samd_count_errors_f32(const float* b, const float* b_hat, int64_t num_blocks,
+                          int64_t block_len, int soft, int64_t* counters, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIONNA_AMD_H */

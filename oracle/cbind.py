@@ -1,0 +1,52 @@
+"""ctypes binding of oracle/ldpc_bp.c (test infrastructure, see oracle/__init__.py)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle_ldpc.so")
+_lib = None
+
+CN_MODES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2, "min": 2, "offset-minsum": 3}
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "ldpc_bp.c")):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.oracle_ldpc_bp_decode.restype = C.c_int
+        _lib.oracle_ldpc_bp_decode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                               C.c_int, C.c_int]
+        _lib.oracle_num_threads.restype = C.c_int
+    return _lib
+
+
+def bp_decode(dec, llr, num_iter=None, hard_out=None, offset=0.5, nthreads=0):
+    """Run the C oracle on the graph of ``dec`` (an oracle.ldpc_bp.LDPCBPDecoder).
+    llr [B, N_vn] logits -> [B, N_vn]."""
+    llr = np.ascontiguousarray(llr, np.float32)
+    assert llr.ndim == 2 and llr.shape[1] == dec.num_vns
+    cn = np.ascontiguousarray(dec.cn_idx, np.int32)
+    vn = np.ascontiguousarray(dec.vn_idx, np.int32)
+    out = np.empty_like(llr)
+    mode = CN_MODES[[k for k, v in __import__("oracle.ldpc_bp", fromlist=["_CN"])._CN.items()
+                     if v is dec._cn_update][0]]
+    rc = lib().oracle_ldpc_bp_decode(dec.num_edges, dec.num_cns, dec.num_vns, cn.ctypes.data, vn.ctypes.data,
+                                     llr.ctypes.data, out.ctypes.data, llr.shape[0],
+                                     dec.num_iter if num_iter is None else num_iter, mode, float(dec.llr_max),
+                                     float(offset), int(dec.hard_out if hard_out is None else hard_out), nthreads)
+    assert rc == 0
+    return out
+
+
+def num_threads():
+    return lib().oracle_num_threads()

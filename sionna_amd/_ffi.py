@@ -1,0 +1,139 @@
+"""ctypes binding of the C-ABI (include/sionna_amd.h) and device/stream plumbing.
+
+PyTorch is used only as the carrier of device memory and streams: every call passes raw
+``data_ptr()`` addresses and the current HIP stream handle to ``libsionna_amd.so``.
+There is NO CPU fallback: if the library is missing or no GPU is visible, compute calls
+raise immediately.
+"""
+import ctypes as C
+import os
+import re
+
+import torch  # imported first so that libamdhip64 is resolved once, process-wide
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsionna_amd.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "sionna_amd.h")
+
+OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
+CN_MODES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2, "min": 2, "offset-minsum": 3}
+
+_lib = None
+
+_vp, _i32, _i64, _u64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_SIGNATURES = {
+    "samd_last_error": (C.c_char_p, []),
+    "samd_version": (_i32, []),
+    "samd_device_count": (_i32, []),
+    "samd_ldpc_graph_create": (_i32, [_vp, _vp, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "samd_ldpc_graph_destroy": (None, [_vp]),
+    "samd_ldpc_bp_workspace_bytes": (_sz, [_vp, _i32]),
+    "samd_ldpc_bp_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
+                                       _i32, _vp, _sz, _vp]),
+    "samd_ldpc5g_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
+    "samd_ldpc5g_destroy": (None, [_vp]),
+    "samd_ldpc5g_encode_f32": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "samd_ldpc5g_rate_recover_f32": (_i32, [_vp, _vp, _vp, _i32, _f32, _vp]),
+    "samd_ldpc5g_extract_codeword_f32": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "samd_ldpc5g_decode_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "samd_ldpc5g_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, _sz, _vp]),
+    "samd_qam_map_c64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "samd_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "samd_binary_source_f32": (_i32, [_u64, _u64, _i64, _vp, _vp]),
+    "samd_awgn_c64": (_i32, [_vp, _vp, _i64, _u64, _u64, _i64, _vp, _vp]),
+    "samd_count_errors_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+}
+
+
+def declared_symbols():
+    """Names of all functions declared in include/sionna_amd.h."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(samd_[a-z0-9_]+)\s*\(", src)))
+
+
+class SamdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libsionna_amd.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C sionna_amd/csrc` (there is no CPU fallback).")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc == OK:
+        return
+    msg = lib().samd_last_error().decode()
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(f"{what}: {msg}")
+    if rc == ERR_INVALID:
+        raise ValueError(f"{what}: {msg}")
+    raise SamdError(f"{what}: error {rc}: {msg}")
+
+
+_device = None
+
+
+def device():
+    """The compute device of this process: cuda:LOCAL_RANK.  Fails loudly without a GPU."""
+    global _device
+    if _device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("sionna_amd needs a HIP device (MI355X); none is visible and there is "
+                               "no CPU fallback.")
+        idx = int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count()
+        torch.cuda.set_device(idx)
+        _device = torch.device("cuda", idx)
+    return _device
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def to_device(x, dtype):
+    """numpy / python / torch -> contiguous device tensor of ``dtype``."""
+    import numpy as np
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if t.dtype != dtype or t.device != device():
+        t = t.to(device=device(), dtype=dtype)
+    return t.contiguous()
+
+
+class Workspace:
+    """Grow-only scratch buffer owned by a block (the C-ABI never allocates)."""
+
+    def __init__(self):
+        self._buf = None
+
+    def get(self, nbytes):
+        if nbytes == 0:
+            return None, 0
+        if self._buf is None or self._buf.numel() < nbytes:
+            self._buf = None
+            self._buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device())
+        return self._buf, self._buf.numel()

@@ -1,0 +1,134 @@
+// QAM / arbitrary-constellation mapper and LLR demapper.
+//
+// Replaces (reference src/sionna/phy/mapping.py):
+//   Mapper.call                      :497-519   bits -> integer label (MSB first) -> LUT
+//   Demapper.call                    :664-691   exponents = -|y-c|^2 / max(no, tiny)
+//   SymbolLogits2LLRs.call           :927-967   LLR_i = reduce_{c in C_i,1} - reduce_{c in C_i,0}
+//                                               reduce = logsumexp ("app") | max ("maxlog")
+//
+// MI355X design: both are pure streaming kernels (8 B in, 4m B out per symbol).  The
+// reference materialises a [..., S, 2^m] distance tensor plus two [..., S, 2^m/2, m]
+// gathers in HBM (23.6 GB each at config C2); here one lane owns one symbol, the 2^m
+// exponents never leave registers/LDS and the constellation is an LDS-resident LUT.
+// Within a wave the m LLRs of a symbol are written as m consecutive floats per lane, i.e.
+// each store instruction covers a contiguous 64*m*4-byte span across the wave.
+#include "common.h"
+
+namespace samd {
+
+constexpr int kMaxBits = 10;  // up to 1024 points
+
+__global__ __launch_bounds__(256) void qam_map_kernel(const float* __restrict__ bits,
+                                                      const float2* __restrict__ points, int m,
+                                                      int64_t num_symbols, float2* __restrict__ out) {
+  extern __shared__ float2 lut[];
+  for (int i = threadIdx.x; i < (1 << m); i += blockDim.x) lut[i] = points[i];
+  __syncthreads();
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < num_symbols;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    const float* b = bits + s * m;
+    int idx = 0;
+    for (int i = 0; i < m; ++i) idx = (idx << 1) | ((int)b[i] & 1);   // mapping.py:507-511
+    out[s] = lut[idx];
+  }
+}
+
+// Generic demapper: literal per-set reduction with the set's own maximum subtracted
+// (tf.reduce_logsumexp semantics).  M is the compile-time number of label bits.
+template <int M, bool MAXLOG>
+__global__ __launch_bounds__(256) void demap_kernel(const float2* __restrict__ y, const float* __restrict__ no,
+                                                    int64_t no_len, const float2* __restrict__ points,
+                                                    int64_t num_symbols, int hard_out, float* __restrict__ out) {
+  constexpr int P = 1 << M;
+  __shared__ float2 lut[P];
+  for (int i = threadIdx.x; i < P; i += blockDim.x) lut[i] = points[i];
+  __syncthreads();
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < num_symbols;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    const float2 ys = y[s];
+    const float n0 = fmaxf(no_len == 1 ? no[0] : no[s], 1.17549435e-38f);   // finfo(float32).tiny
+    // pass 1: per (bit, value) maximum of the exponents
+    float mx[M][2];
+#pragma unroll
+    for (int i = 0; i < M; ++i) { mx[i][0] = -INFINITY; mx[i][1] = -INFINITY; }
+    for (int c = 0; c < P; ++c) {
+      const float dr = ys.x - lut[c].x, di = ys.y - lut[c].y;
+      // |y-c|^2 (mapping.py:672 forms it as abs()**2; the direct sum of squares is the same
+      // quantity without the sqrt round trip)
+      const float e = -(dr * dr + di * di) / n0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const int bit = (c >> (M - 1 - i)) & 1;            // label bit i, MSB first
+        if (bit) mx[i][1] = fmaxf(mx[i][1], e); else mx[i][0] = fmaxf(mx[i][0], e);
+      }
+    }
+    float llr[M];
+    if constexpr (MAXLOG) {
+#pragma unroll
+      for (int i = 0; i < M; ++i) llr[i] = mx[i][1] - mx[i][0];
+    } else {
+      float sm[M][2];
+#pragma unroll
+      for (int i = 0; i < M; ++i) { sm[i][0] = 0.f; sm[i][1] = 0.f; }
+      for (int c = 0; c < P; ++c) {
+        const float dr = ys.x - lut[c].x, di = ys.y - lut[c].y;
+        const float e = -(dr * dr + di * di) / n0;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          const int bit = (c >> (M - 1 - i)) & 1;
+          if (bit) sm[i][1] += expf(e - mx[i][1]); else sm[i][0] += expf(e - mx[i][0]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i) llr[i] = (logf(sm[i][1]) + mx[i][1]) - (logf(sm[i][0]) + mx[i][0]);
+    }
+    float* o = out + s * M;
+#pragma unroll
+    for (int i = 0; i < M; ++i) o[i] = hard_out ? (llr[i] > 0.f ? 1.f : 0.f) : llr[i];
+  }
+}
+
+template <bool MAXLOG>
+static int launch_demap(int m, dim3 grid, hipStream_t st, const float2* y, const float* no, int64_t no_len,
+                        const float2* pts, int64_t ns, int hard, float* out) {
+#define SAMD_DM(M) case M: hipLaunchKernelGGL((demap_kernel<M, MAXLOG>), grid, dim3(256), 0, st, y, no, no_len, pts, ns, hard, out); break
+  switch (m) {
+    SAMD_DM(1); SAMD_DM(2); SAMD_DM(3); SAMD_DM(4); SAMD_DM(5); SAMD_DM(6); SAMD_DM(7); SAMD_DM(8); SAMD_DM(9); SAMD_DM(10);
+    default: set_error("num_bits_per_symbol must be in 1..10"); return SAMD_ERR_UNSUPPORTED;
+  }
+#undef SAMD_DM
+  return SAMD_OK;
+}
+
+}  // namespace samd
+
+using namespace samd;
+
+static inline int grid_for(int64_t n, int block) {
+  const int64_t g = (n + block - 1) / block;
+  return (int)std::min<int64_t>(std::max<int64_t>(g, 1), 256 * 32);
+}
+
+extern "C" int samd_qam_map_c64(const float* bits, const float* points, int m, int64_t num_symbols,
+                                float* out_symbols, void* stream) {
+  SAMD_REQUIRE(bits && points && out_symbols, "null argument");
+  SAMD_REQUIRE(m >= 1 && m <= kMaxBits && num_symbols >= 0, "bad m / num_symbols");
+  if (num_symbols == 0) return SAMD_OK;
+  hipLaunchKernelGGL(qam_map_kernel, dim3(grid_for(num_symbols, 256)), dim3(256), sizeof(float2) << m,
+                     (hipStream_t)stream, bits, (const float2*)points, m, num_symbols, (float2*)out_symbols);
+  return launch_status();
+}
+
+extern "C" int samd_qam_demap_f32(const float* y, const float* no, int64_t no_len, const float* points, int m,
+                                  int64_t num_symbols, int method, int hard_out, float* out, void* stream) {
+  SAMD_REQUIRE(y && no && points && out, "null argument");
+  SAMD_REQUIRE(num_symbols >= 0 && (no_len == 1 || no_len == num_symbols), "no must be scalar or per symbol");
+  SAMD_REQUIRE(method == 0 || method == 1, "method must be 0 (app) or 1 (maxlog)");
+  if (num_symbols == 0) return SAMD_OK;
+  const dim3 grid(grid_for(num_symbols, 256));
+  int rc = method == 1
+               ? launch_demap<true>(m, grid, (hipStream_t)stream, (const float2*)y, no, no_len, (const float2*)points, num_symbols, hard_out, out)
+               : launch_demap<false>(m, grid, (hipStream_t)stream, (const float2*)y, no, no_len, (const float2*)points, num_symbols, hard_out, out);
+  if (rc != SAMD_OK) return rc;
+  return launch_status();
+}

@@ -1,0 +1,30 @@
+"""AWGN channel - mirror of reference src/sionna/phy/channel/awgn.py:10-78."""
+import torch
+
+from ... import _ffi
+from ..block import Block
+from ..config import config
+
+
+class AWGN(Block):
+    """``AWGN()(x, no)``: y = x + sqrt(no) * CN(0,1); ``no`` scalar or broadcastable to x."""
+
+    def __init__(self, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+
+    def call(self, x, no):
+        self._require_single()
+        x = _ffi.to_device(x, torch.complex64)
+        no = _ffi.to_device(no, torch.float32)
+        if no.numel() == 1:
+            no = no.reshape(1)
+        else:
+            # awgn.py:70-76: no is expanded to the rank of x from the right
+            while no.dim() < x.dim():
+                no = no.unsqueeze(-1)
+            no = torch.broadcast_to(no, x.shape).contiguous()
+        y = torch.empty_like(x)
+        rng = config.rng
+        _ffi.check(_ffi.lib().samd_awgn_c64(_ffi.ptr(x), _ffi.ptr(no), no.numel(), rng.seed, rng.next_call(),
+                                            x.numel(), _ffi.ptr(y), _ffi.stream()), "AWGN")
+        return y

@@ -1,0 +1,2 @@
+"""Forward error correction blocks of the hot path (LDPC 5G; Polar/CRC follow)."""
+from . import ldpc

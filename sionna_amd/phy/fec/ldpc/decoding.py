@@ -1,0 +1,330 @@
+"""LDPC belief-propagation decoders - host-side mirror of
+``sionna.phy.fec.ldpc.LDPCBPDecoder`` / ``LDPC5GDecoder``
+(reference src/sionna/phy/fec/ldpc/decoding.py:13-637, 1169-1536).
+
+Two HIP engines sit behind the same Block API:
+
+* generic (any parity-check matrix, all four check-node rules, IDD state in/out):
+  ``samd_ldpc_bp_decode_f32`` - messages HBM-resident, batch-last, two fused passes per
+  iteration (csrc/ldpc_bp_generic.hip);
+* 5G on-chip (min-sum family on a 5G code that fits in LDS): ``samd_ldpc5g_decode_f32`` -
+  rate recovery + all iterations + output mapping in one kernel (csrc/ldpc5g.hip).
+
+Both use the arithmetic and summation order of oracle/ldpc_bp.py.  Python callables for
+node updates, message callbacks and non-flooding schedules have no HIP path and raise
+``NotImplementedError`` (there is deliberately no CPU fallback).
+"""
+import ctypes as C
+import types
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from .... import _ffi
+from ...block import Block
+from .encoding import LDPC5GEncoder
+
+# workspace cap of one generic-decoder launch; larger batches are processed in slices
+_MAX_WORKSPACE_BYTES = 48 << 30
+
+
+class LDPCBPDecoder(Block):
+    # pylint: disable=line-too-long
+    """``LDPCBPDecoder(pcm, cn_update="boxplus-phi", vn_update="sum", cn_schedule="flooding",
+    hard_out=True, num_iter=20, llr_max=20., v2c_callbacks=None, c2v_callbacks=None,
+    return_state=False, precision=None)`` (reference decoding.py:175-345).
+
+    ``call(llr_ch, /, *, num_iter=None, msg_v2c=None)``: ``llr_ch`` [..., n] logits;
+    returns hard bits / soft logits [..., n] and, with ``return_state``, the v2c messages
+    [num_edges, batch] (edge order: VN-major, ascending CN inside a VN).
+    """
+
+    def __init__(self, pcm, cn_update="boxplus-phi", vn_update="sum", cn_schedule="flooding",
+                 hard_out=True, num_iter=20, llr_max=20., v2c_callbacks=None, c2v_callbacks=None,
+                 return_state=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        if not isinstance(hard_out, bool):
+            raise TypeError("hard_out must be bool.")
+        if not isinstance(num_iter, int):
+            raise TypeError("num_iter must be int.")
+        if num_iter < 0:
+            raise ValueError("num_iter cannot be negative.")
+        if not isinstance(return_state, bool):
+            raise TypeError("return_state must be bool.")
+        if isinstance(pcm, np.ndarray):
+            if not np.array_equal(pcm, pcm.astype(bool)):
+                raise ValueError("PC matrix must be binary.")
+        elif isinstance(pcm, (sp.csr_matrix, sp.csc_matrix)):
+            if not np.array_equal(pcm.data, pcm.data.astype(bool)):
+                raise ValueError("PC matrix must be binary.")
+        else:
+            raise TypeError("Unsupported dtype of pcm.")
+        if "cn_type" in kwargs:
+            raise TypeError("'cn_type' is deprecated; use 'cn_update' instead.")
+        if not isinstance(llr_max, (int, float)):
+            raise TypeError("llr_max must be int or float.")
+
+        self._pcm = pcm
+        self._hard_out = hard_out
+        self._num_iter = num_iter
+        self._return_state = return_state
+        self._num_cns, self._num_vns = pcm.shape
+        self._llr_max = float(llr_max)
+
+        for name, cbs in (("v2c_callbacks", v2c_callbacks), ("c2v_callbacks", c2v_callbacks)):
+            if cbs is None or (isinstance(cbs, (list, tuple)) and len(cbs) == 0):
+                continue
+            if isinstance(cbs, (list, tuple, types.FunctionType)):
+                raise NotImplementedError(f"{name}: message callbacks have no HIP path")
+            raise TypeError(f"{name} must be a list of callables.")
+
+        if isinstance(cn_schedule, str) and cn_schedule == "flooding":
+            self._scheduling = "flooding"
+        elif isinstance(cn_schedule, (np.ndarray, torch.Tensor)):
+            sched = np.asarray(cn_schedule.cpu() if isinstance(cn_schedule, torch.Tensor) else cn_schedule)
+            if sched.ndim != 2:
+                raise ValueError("cn_schedule must be of rank 2.")
+            if sched.max() >= self._num_cns:
+                raise ValueError("cn_schedule can only contain values smaller number_cns.")
+            if sched.min() < 0:
+                raise ValueError("cn_schedule cannot contain negative values.")
+            raise NotImplementedError("custom / layered cn_schedule has no HIP path yet (flooding only)")
+        else:
+            raise ValueError("cn_schedule can be 'flooding' or an array of ints.")
+
+        if cn_update in _ffi.CN_MODES:
+            self._cn_mode = _ffi.CN_MODES[cn_update]
+        elif cn_update == "identity" or isinstance(cn_update, types.FunctionType):
+            raise NotImplementedError("custom / identity cn_update functions have no HIP path")
+        else:
+            raise TypeError("Provided cn_update not supported.")
+        self._cn_update_name = cn_update
+        if vn_update == "sum":
+            pass
+        elif vn_update == "identity" or isinstance(vn_update, types.FunctionType):
+            raise NotImplementedError("custom / identity vn_update functions have no HIP path")
+        else:
+            raise TypeError("Provided vn_update not supported.")
+        self._offset = 0.5                       # reference default of cn_update_offset_minsum
+
+        # graph: VN-major edge list, ascending CN inside a VN (decoding.py:277-292, stable order)
+        coo = sp.coo_matrix(pcm)
+        nz = coo.data != 0
+        cn_idx, vn_idx = coo.row[nz].astype(np.int64), coo.col[nz].astype(np.int64)
+        order = np.lexsort((cn_idx, vn_idx))
+        self._cn_idx = np.ascontiguousarray(cn_idx[order], dtype=np.int32)
+        self._vn_idx = np.ascontiguousarray(vn_idx[order], dtype=np.int32)
+        self._num_edges = len(self._vn_idx)
+        self._graph = None
+        self._ws = _ffi.Workspace()
+
+    # ------------------------------------------------------------ properties (decoding.py:351-410)
+    pcm = property(lambda self: self._pcm)
+    num_cns = property(lambda self: self._num_cns)
+    num_vns = property(lambda self: self._num_vns)
+    n = property(lambda self: self._num_vns)
+    num_edges = property(lambda self: self._num_edges)
+    return_state = property(lambda self: self._return_state)
+
+    @property
+    def coderate(self):
+        return (self._num_vns - self._num_cns) / self._num_vns
+
+    @property
+    def num_iter(self):
+        return self._num_iter
+
+    @num_iter.setter
+    def num_iter(self, num_iter):
+        if not isinstance(num_iter, int):
+            raise TypeError("num_iter must be int.")
+        if num_iter < 0:
+            raise ValueError("num_iter cannot be negative.")
+        self._num_iter = num_iter
+
+    @property
+    def llr_max(self):
+        return self._llr_max
+
+    @llr_max.setter
+    def llr_max(self, value):
+        if value < 0:
+            raise ValueError("llr_max cannot be negative.")
+        self._llr_max = float(value)
+
+    # ------------------------------------------------------------ engine
+    def _graph_handle(self):
+        if self._graph is None:
+            h = C.c_void_p()
+            _ffi.device()
+            _ffi.check(_ffi.lib().samd_ldpc_graph_create(
+                self._cn_idx.ctypes.data_as(C.c_void_p), self._vn_idx.ctypes.data_as(C.c_void_p),
+                self._num_edges, self._num_cns, self._num_vns, C.byref(h)), "samd_ldpc_graph_create")
+            self._graph = h
+        return self._graph
+
+    def __del__(self):
+        try:
+            if self._graph is not None:
+                _ffi.lib().samd_ldpc_graph_destroy(self._graph)
+        except Exception:  # pylint: disable=broad-except
+            pass
+
+    def _decode_2d(self, llr, out_cols, num_iter, msg_v2c, hard_out=None):
+        """llr [B, N_vn] device float32 -> (x_hat [B, out_cols], state or None)."""
+        lib, g = _ffi.lib(), self._graph_handle()
+        hard = self._hard_out if hard_out is None else hard_out
+        batch = llr.shape[0]
+        out = torch.empty((batch, out_cols), dtype=torch.float32, device=llr.device)
+        want_state = self._return_state
+        state = None
+        if msg_v2c is not None:
+            state = _ffi.to_device(msg_v2c, torch.float32)
+            if tuple(state.shape) != (self._num_edges, batch):
+                raise ValueError("msg_v2c must have shape [num_edges, batch_size]")
+            state = state.clone() if want_state else state
+        elif want_state:
+            state = torch.empty((self._num_edges, batch), dtype=torch.float32, device=llr.device)
+        if batch == 0:
+            return out, state
+        per_cw = lib.samd_ldpc_bp_workspace_bytes(g, 64) // 64
+        step = batch
+        if state is None and per_cw * batch > _MAX_WORKSPACE_BYTES:
+            step = max(64, (_MAX_WORKSPACE_BYTES // per_cw) // 64 * 64)
+        for b0 in range(0, batch, step):
+            nb = min(step, batch - b0)
+            need = lib.samd_ldpc_bp_workspace_bytes(g, nb)
+            ws, ws_bytes = self._ws.get(need)
+            _ffi.check(lib.samd_ldpc_bp_decode_f32(
+                g, _ffi.ptr(llr[b0:b0 + nb]), _ffi.ptr(out[b0:b0 + nb]), out_cols, _ffi.ptr(state),
+                int(msg_v2c is not None), int(want_state), nb, int(num_iter), self._cn_mode,
+                self._llr_max, self._offset, int(bool(hard)), _ffi.ptr(ws), ws_bytes, _ffi.stream()),
+                "LDPCBPDecoder")
+        return out, (state if want_state else None)
+
+    # ------------------------------------------------------------ Block interface
+    def build(self, input_shape, **kwargs):
+        assert input_shape[-1] == self._num_vns, "Last dimension must be of length n."
+
+    def call(self, llr_ch, /, *, num_iter=None, msg_v2c=None):
+        self._require_single()
+        if num_iter is None:
+            num_iter = self._num_iter
+        llr_ch = _ffi.to_device(llr_ch, torch.float32)
+        assert llr_ch.shape[-1] == self._num_vns, "Last dimension must be of length n."
+        shape = tuple(llr_ch.shape)
+        x, state = self._decode_2d(llr_ch.reshape(-1, self._num_vns), self._num_vns, num_iter, msg_v2c)
+        x = x.reshape(shape)
+        return (x, state) if self._return_state else x
+
+
+class LDPC5GDecoder(LDPCBPDecoder):
+    # pylint: disable=line-too-long
+    """``LDPC5GDecoder(encoder, cn_update="boxplus-phi", vn_update="sum", cn_schedule="flooding",
+    hard_out=True, return_infobits=True, num_iter=20, llr_max=20., v2c_callbacks=None,
+    c2v_callbacks=None, prune_pcm=True, return_state=False, precision=None)``
+    (reference decoding.py:1302-1403); ``call(llr_ch[..., n])`` -> [..., k] or [..., n]."""
+
+    def __init__(self, encoder, cn_update="boxplus-phi", vn_update="sum", cn_schedule="flooding",
+                 hard_out=True, return_infobits=True, num_iter=20, llr_max=20., v2c_callbacks=None,
+                 c2v_callbacks=None, prune_pcm=True, return_state=False, precision=None, **kwargs):
+        if not isinstance(encoder, LDPC5GEncoder):
+            raise TypeError("encoder must be of class LDPC5GEncoder.")
+        self._encoder = encoder
+        if not isinstance(return_infobits, bool):
+            raise TypeError("return_info must be bool.")
+        self._return_infobits = return_infobits
+        if not isinstance(return_state, bool):
+            raise TypeError("return_state must be bool.")
+        if "cn_type" in kwargs:
+            raise TypeError("'cn_type' is deprecated; use 'cn_update' instead.")
+        if not isinstance(prune_pcm, bool):
+            raise TypeError("prune_pcm must be bool.")
+        self._prune_pcm = prune_pcm
+        pcm = encoder.pcm
+        k_filler = encoder.k_ldpc - encoder.k
+        nb_punc_bits = (encoder.n_ldpc - k_filler) - encoder.n - 2 * encoder.z
+        if prune_pcm:
+            # trailing degree-1 VNs that are punctured never contribute (decoding.py:1337-1378)
+            dv = np.diff(sp.csc_matrix(pcm).indptr)
+            tail = np.nonzero(dv[::-1] != 1)[0]
+            last_pos = encoder.n_ldpc - (int(tail[0]) if len(tail) else encoder.n_ldpc - 1)
+            last_pos = max(last_pos, 1)
+            if cn_schedule == "layered":
+                nb_punc_bits = int(np.floor(nb_punc_bits / encoder.z) * encoder.z)
+            self._n_pruned = int(max(last_pos, encoder.n_ldpc - nb_punc_bits))
+            self._nb_pruned_nodes = encoder.n_ldpc - self._n_pruned
+            if self._nb_pruned_nodes < 0:
+                raise ArithmeticError("Internal error: number of pruned nodes must be positive.")
+            if self._nb_pruned_nodes > 0:
+                pcm = pcm[:-self._nb_pruned_nodes, :-self._nb_pruned_nodes]
+        else:
+            self._nb_pruned_nodes = 0
+            self._n_pruned = encoder.n_ldpc
+        if cn_schedule == "layered":
+            raise NotImplementedError("layered scheduling has no HIP path yet (flooding only)")
+        super().__init__(sp.csr_matrix(pcm), cn_update=cn_update, vn_update=vn_update,
+                         cn_schedule=cn_schedule, hard_out=hard_out, num_iter=num_iter, llr_max=llr_max,
+                         v2c_callbacks=v2c_callbacks, c2v_callbacks=c2v_callbacks,
+                         return_state=return_state, precision=precision, **kwargs)
+        self._onchip_ok = True
+
+    encoder = property(lambda self: self._encoder)
+
+    def build(self, input_shape, **kwargs):
+        if input_shape[-1] != self._encoder.n:
+            raise ValueError("Last dimension must be of length n.")
+
+    def _try_onchip(self, llr2d, num_iter):
+        """Whole decode in one kernel when the code fits in LDS (min-sum family)."""
+        enc = self._encoder
+        out_cols = enc.k if self._return_infobits else enc.n
+        out = torch.empty((llr2d.shape[0], out_cols), dtype=torch.float32, device=llr2d.device)
+        rc = _ffi.lib().samd_ldpc5g_decode_f32(
+            enc._handle(self._nb_pruned_nodes), _ffi.ptr(llr2d), _ffi.ptr(out), llr2d.shape[0], int(num_iter),
+            self._cn_mode, self._llr_max, self._offset, int(self._hard_out), int(self._return_infobits),
+            None, 0, _ffi.stream())
+        if rc == _ffi.ERR_UNSUPPORTED:
+            self._onchip_ok = False
+            return None
+        _ffi.check(rc, "LDPC5GDecoder(on-chip)")
+        return out
+
+    def call(self, llr_ch, /, *, num_iter=None, msg_v2c=None):
+        self._require_single()
+        enc = self._encoder
+        if num_iter is None:
+            num_iter = self._num_iter
+        llr_ch = _ffi.to_device(llr_ch, torch.float32)
+        if llr_ch.shape[-1] != enc.n:
+            raise ValueError("Last dimension must be of length n.")
+        shape = tuple(llr_ch.shape)
+        llr2d = llr_ch.reshape(-1, enc.n)
+        batch = llr2d.shape[0]
+        out_shape = shape[:-1] + ((enc.k,) if self._return_infobits else (enc.n,))
+
+        use_onchip = (self._onchip_ok and self._cn_mode in (2, 3) and not self._return_state
+                      and msg_v2c is None and batch > 0)
+        if use_onchip:
+            out = self._try_onchip(llr2d, num_iter)
+            if out is not None:
+                return out.reshape(out_shape)
+
+        # generic engine: rate recovery -> BP -> output mapping (decoding.py:1431-1536)
+        h = enc._handle(self._nb_pruned_nodes)
+        llr_5g = torch.empty((batch, self._num_vns), dtype=torch.float32, device=llr2d.device)
+        if batch > 0:
+            _ffi.check(_ffi.lib().samd_ldpc5g_rate_recover_f32(h, _ffi.ptr(llr2d), _ffi.ptr(llr_5g), batch,
+                                                               self._llr_max, _ffi.stream()), "rate_recover")
+        if self._return_infobits:
+            x, state = self._decode_2d(llr_5g, enc.k, num_iter, msg_v2c)
+            res = x.reshape(out_shape)
+        else:
+            x, state = self._decode_2d(llr_5g, self._num_vns, num_iter, msg_v2c)
+            res = torch.empty((batch, enc.n), dtype=torch.float32, device=llr2d.device)
+            if batch > 0:
+                _ffi.check(_ffi.lib().samd_ldpc5g_extract_codeword_f32(h, _ffi.ptr(x), _ffi.ptr(res), batch,
+                                                                       _ffi.stream()), "extract_codeword")
+            res = res.reshape(out_shape)
+        return (res, state) if self._return_state else res

@@ -1,0 +1,269 @@
+"""Constellations, mapper, demapper and the binary source - host-side mirror of
+``sionna.phy.mapping`` (reference src/sionna/phy/mapping.py) for the hot path.
+
+Constellation tables are built on the host with NumPy (init time); Mapper / Demapper /
+BinarySource call the HIP kernels in ``csrc/mapping.hip`` / ``csrc/channel.hip`` through
+the C-ABI.  Out of scope: SymbolDemapper, LLRs2SymbolLogits,
+SymbolLogits2Moments, QAM2PAM, PAM sources, demapping with priors.
+"""
+import numpy as np
+import torch
+
+from .. import _ffi
+from .block import Block
+from .config import config, dtypes, PhiloxGenerator
+
+
+def _gray_pam_levels(num_bits):
+    """Gray-labelled PAM level for every label 0..2^num_bits-1 (MSB first).
+
+    Closed iteration of the recursion of 38.211 Sec. 5.1 (reference mapping.py:15-42):
+    the last bit b gives 1-2b; prepending bit b maps v -> (1-2b) * (2^j - v), j = number of
+    bits already consumed.
+    """
+    labels = np.arange(2 ** num_bits)
+    bits = (labels[:, None] >> np.arange(num_bits - 1, -1, -1)) & 1      # [2^nb, nb], MSB first
+    v = 1 - 2 * bits[:, -1]
+    for j in range(1, num_bits):
+        v = (1 - 2 * bits[:, num_bits - 1 - j]) * (2 ** j - v)
+    return v
+
+
+def pam_gray(b):
+    """PAM level of the bit vector ``b`` (reference mapping.py:15-42)."""
+    b = np.asarray(b, dtype=np.int64)
+    label = int(np.sum(b << np.arange(len(b) - 1, -1, -1)))
+    return int(_gray_pam_levels(len(b))[label])
+
+
+def _precision_dtypes(precision):
+    p = config.precision if precision is None else precision
+    return dtypes[p]["np"]["rdtype"], dtypes[p]["np"]["cdtype"]
+
+
+def qam(num_bits_per_symbol, normalize=True, precision=None):
+    """QAM constellation, label of point i = binary representation of i; even label bits
+    drive the real axis, odd ones the imaginary axis (reference mapping.py:44-118)."""
+    if num_bits_per_symbol % 2 != 0 or num_bits_per_symbol <= 0:
+        raise ValueError("num_bits_per_symbol must be a multiple of 2")
+    assert isinstance(normalize, bool), "normalize must be boolean"
+    rdtype, cdtype = _precision_dtypes(precision)
+    m = int(num_bits_per_symbol)
+    n = m // 2
+    idx = np.arange(2 ** m)
+    bits = (idx[:, None] >> np.arange(m - 1, -1, -1)) & 1
+    w = 1 << np.arange(n - 1, -1, -1)
+    lev = _gray_pam_levels(n)
+    c = (lev[bits[:, 0::2] @ w] + 1j * lev[bits[:, 1::2] @ w]).astype(cdtype)
+    if normalize:
+        qam_var = 1 / (2 ** (n - 2)) * np.sum(np.linspace(1, 2 ** n - 1, 2 ** (n - 1), dtype=rdtype) ** 2)
+        c /= np.sqrt(qam_var)
+    return c
+
+
+def pam(num_bits_per_symbol, normalize=True, precision=None):
+    """PAM constellation (reference mapping.py:120-193)."""
+    if num_bits_per_symbol <= 0:
+        raise ValueError("num_bits_per_symbol must be positive")
+    assert isinstance(normalize, bool), "normalize must be boolean"
+    rdtype, cdtype = _precision_dtypes(precision)
+    n = int(num_bits_per_symbol)
+    c = _gray_pam_levels(n).astype(cdtype)
+    if normalize:
+        pam_var = 1 / (2 ** (n - 1)) * np.sum(np.linspace(1, 2 ** n - 1, 2 ** (n - 1), dtype=rdtype) ** 2)
+        c /= np.sqrt(pam_var)
+    return c
+
+
+class Constellation(Block):
+    """reference mapping.py:195-420"""
+
+    def __init__(self, constellation_type, num_bits_per_symbol, points=None, normalize=False,
+                 center=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        if constellation_type not in ("qam", "pam", "custom"):
+            raise ValueError(f"Wrong `constellation_type` {constellation_type}")
+        self._constellation_type = constellation_type
+        if num_bits_per_symbol is None:
+            raise ValueError("No value for `num_bits_per_symbol`")
+        n = num_bits_per_symbol
+        if (n <= 0) or (n % 1 != 0):
+            raise ValueError("`num_bits_per_symbol` must be a positive integer")
+        if constellation_type == "qam" and n % 2 != 0:
+            raise ValueError("`num_bits_per_symbol` must be a positive integer multiple of 2")
+        self._num_bits_per_symbol = int(n)
+        self._num_points = 2 ** self._num_bits_per_symbol
+        self.normalize = normalize
+        self.center = center
+        if points is not None and constellation_type != "custom":
+            raise ValueError("`points` can only be provided for `constellation_type`='custom'")
+        if points is None and constellation_type == "custom":
+            raise ValueError("You must provide a value for `points`")
+        self._points = None
+        self._dev = None
+        if constellation_type == "qam":
+            points = qam(self._num_bits_per_symbol, normalize=True, precision=self.precision)
+        elif constellation_type == "pam":
+            points = pam(self._num_bits_per_symbol, normalize=True, precision=self.precision)
+        self.points = points
+
+    constellation_type = property(lambda self: self._constellation_type)
+    num_bits_per_symbol = property(lambda self: self._num_bits_per_symbol)
+    num_points = property(lambda self: self._num_points)
+
+    @property
+    def normalize(self):
+        return self._normalize
+
+    @normalize.setter
+    def normalize(self, value):
+        assert isinstance(value, bool), "`normalize` must be boolean"
+        self._normalize = value
+        self._dev = None
+
+    @property
+    def center(self):
+        return self._center
+
+    @center.setter
+    def center(self, value):
+        assert isinstance(value, bool), "`center` must be boolean"
+        self._center = value
+        self._dev = None
+
+    @property
+    def points(self):
+        """[2**num_bits_per_symbol] complex ndarray (host copy)."""
+        return self._points
+
+    @points.setter
+    def points(self, v):
+        if self._points is not None and self._constellation_type != "custom":
+            raise ValueError("`points` can only be modified for custom constellations")
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        v = np.asarray(v)
+        if v.shape != (2 ** self._num_bits_per_symbol,):
+            raise ValueError("`points` must have shape [2**num_bits_per_symbol]")
+        self._points = v.astype(dtypes[self.precision]["np"]["cdtype"])
+        self._dev = None
+
+    def _host_points(self):
+        x = self._points
+        if self._constellation_type == "custom":
+            if self._center:
+                x = x - np.mean(x)
+            if self._normalize:
+                x = x / np.sqrt(np.mean(np.abs(x) ** 2)).astype(x.real.dtype)
+        return x.astype(self._points.dtype)
+
+    def device_points(self):
+        """Device copy (complex64) used by the kernels; rebuilt after a setter call."""
+        if self._dev is None:
+            self._dev = _ffi.to_device(self._host_points().astype(np.complex64), torch.complex64)
+        return self._dev
+
+    def __call__(self):
+        return self.call()
+
+    def call(self):
+        """(Possibly) centred and normalised constellation points."""
+        return self._host_points()
+
+    @staticmethod
+    def check_or_create(*, constellation_type=None, num_bits_per_symbol=None, constellation=None,
+                        precision=None):
+        if isinstance(constellation, Constellation):
+            return constellation
+        if constellation_type in ["qam", "pam"]:
+            return Constellation(constellation_type, num_bits_per_symbol, precision=precision)
+        raise ValueError("You must provide a valid `constellation`")
+
+
+class Mapper(Block):
+    """bits [..., n] -> symbols [..., n/num_bits_per_symbol] (reference mapping.py:422-519)."""
+
+    def __init__(self, constellation_type=None, num_bits_per_symbol=None, constellation=None,
+                 return_indices=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+        self._return_indices = return_indices
+
+    constellation = property(lambda self: self._constellation)
+
+    def call(self, bits):
+        self._require_single()
+        m = self._constellation.num_bits_per_symbol
+        bits = _ffi.to_device(bits, torch.float32)
+        if bits.shape[-1] % m != 0:
+            raise ValueError("last dimension must be a multiple of num_bits_per_symbol")
+        out_shape = tuple(bits.shape[:-1]) + (bits.shape[-1] // m,)
+        x = torch.empty(out_shape, dtype=torch.complex64, device=bits.device)
+        ns = x.numel()
+        _ffi.check(_ffi.lib().samd_qam_map_c64(_ffi.ptr(bits), _ffi.ptr(self._constellation.device_points()),
+                                               m, ns, _ffi.ptr(x), _ffi.stream()), "Mapper")
+        if self._return_indices:
+            w = (1 << torch.arange(m - 1, -1, -1, device=bits.device)).to(torch.int32)
+            ind = (bits.reshape(out_shape + (m,)).to(torch.int32) * w).sum(-1).to(torch.int32)
+            return x, ind
+        return x
+
+
+class Demapper(Block):
+    """LLRs (logits) for every bit of every received symbol (reference mapping.py:521-691,
+    794-967).  ``call(y, no, prior=None)``; priors are not supported on the HIP path."""
+
+    def __init__(self, demapping_method, constellation_type=None, num_bits_per_symbol=None,
+                 constellation=None, hard_out=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        assert demapping_method in ("app", "maxlog"), "Unknown demapping method"
+        self._method = demapping_method
+        self._hard_out = hard_out
+        self._constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+
+    constellation = property(lambda self: self._constellation)
+
+    def call(self, y, no, prior=None):
+        self._require_single()
+        if prior is not None:
+            raise NotImplementedError("Demapper: prior information is outside the MI355X hot path")
+        m = self._constellation.num_bits_per_symbol
+        y = _ffi.to_device(y, torch.complex64)
+        no = _ffi.to_device(no, torch.float32)
+        if no.numel() == 1:
+            no = no.reshape(1)
+        else:
+            no = torch.broadcast_to(no, y.shape).contiguous()
+        out = torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] * m,), dtype=torch.float32, device=y.device)
+        _ffi.check(_ffi.lib().samd_qam_demap_f32(
+            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points()), m,
+            y.numel(), 0 if self._method == "app" else 1, int(bool(self._hard_out)), _ffi.ptr(out),
+            _ffi.stream()), "Demapper")
+        return out
+
+
+class BinarySource(Block):
+    """Random bits as float (reference mapping.py:1317-1352) on the device Philox stream."""
+
+    def __init__(self, precision=None, seed=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._seed = seed
+        self._rng = PhiloxGenerator(seed) if seed is not None else None
+
+    def __call__(self, inputs):          # the argument is a shape, not a tensor
+        return super().__call__(tuple(int(s) for s in np.asarray(inputs).reshape(-1)))
+
+    def _convert_to_tensor(self, v):
+        return v
+
+    def call(self, inputs):
+        self._require_single()
+        rng = self._rng if self._rng is not None else config.rng
+        out = torch.empty(tuple(inputs), dtype=torch.float32, device=_ffi.device())
+        _ffi.check(_ffi.lib().samd_binary_source_f32(rng.seed, rng.next_call(), out.numel(), _ffi.ptr(out),
+                                                     _ffi.stream()), "BinarySource")
+        return out

@@ -1,0 +1,3 @@
+"""Utilities of the hot path (mirror of ``sionna.phy.utils``)."""
+from .metrics import count_errors, count_block_errors, compute_ber, compute_bler
+from .misc import ebnodb2no, hard_decisions, complex_normal, sim_ber, get_throughput

@@ -1,0 +1,336 @@
+"""GPU parity tests: the HIP path (through the C-ABI, via the sionna.phy-style blocks) against
+the CPU oracle on the same seeded inputs, against the committed golden fixtures, and - at
+BASELINE.json's full sizes - through size-independent properties.
+
+Bars (BASELINE.json north_star): bit-exact for encoder / interleaver / hard decisions /
+counters / random bit stream and for the whole min-sum decoder (defined summation order);
+<= 1e-5 relative (+ small absolute floor, stated per test) for LLRs of the demapper and
+the boxplus decoders.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.ldpc5g import LDPC5GCode
+from oracle import ldpc_bp as obp, mapping as omap, utils as outil, cbind
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def phy():
+    import sionna_amd.phy as p
+    from sionna_amd import _ffi
+    _ffi.device()
+    return p
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ RNG / sources / AWGN
+def test_binary_source_bit_exact(phy):
+    phy.config.seed = 1234
+    src = phy.mapping.BinarySource()
+    for call, shape in enumerate([(7,), (3, 1001), (64, 2816)]):
+        got = _np(src(shape))
+        ref = outil.random_bits(1234, call, int(np.prod(shape))).reshape(shape)
+        assert np.array_equal(got, ref)
+    assert abs(float(got.mean()) - 0.5) < 0.01
+
+
+def test_awgn_matches_stream_spec(phy):
+    phy.config.seed = 77
+    x = (np.arange(10001) % 7 - 3 + 1j * (np.arange(10001) % 5 - 2)).astype(np.complex64)
+    y = _np(phy.channel.AWGN()(x, 0.37))
+    ref = outil.awgn(x, 0.37, 77, 0)
+    assert np.allclose(y, ref, rtol=1e-5, atol=2e-6)
+    no = np.linspace(0.01, 2, x.size).astype(np.float32)
+    y2 = _np(phy.channel.AWGN()(x, no))
+    assert np.allclose(y2, outil.awgn(x, no, 77, 1), rtol=1e-5, atol=2e-6)
+    # statistics of the noise itself
+    w = _np(phy.utils.complex_normal([200000], 2.0))
+    assert abs(np.var(w) - 2.0) < 0.03 and abs(np.mean(w)) < 0.01
+
+
+# ------------------------------------------------------------------ mapper / demapper
+@pytest.mark.parametrize("m", [2, 4, 6, 8])
+def test_mapper_bit_exact(phy, m):
+    rng = np.random.default_rng(m)
+    bits = rng.integers(0, 2, (5, 24 * m)).astype(np.float32)
+    x = _np(phy.mapping.Mapper("qam", m)(bits))
+    assert np.array_equal(x, omap.mapper(bits, omap.qam(m)))
+
+
+@pytest.mark.parametrize("m", [2, 4, 6])
+@pytest.mark.parametrize("method", ["app", "maxlog"])
+def test_demapper_vs_oracle(phy, m, method):
+    rng = np.random.default_rng(10 + m)
+    pts = omap.qam(m)
+    y = (pts[rng.integers(0, 2 ** m, (4, 300))]
+         + (rng.normal(size=(4, 300)) + 1j * rng.normal(size=(4, 300))) * 0.3).astype(np.complex64)
+    for no in (np.float32(0.2), rng.uniform(0.01, 100, size=(4, 300)).astype(np.float32)):
+        llr = _np(phy.mapping.Demapper(method, "qam", m)(y, no))
+        ref64 = omap.demapper(y.astype(np.complex128), np.asarray(no, np.float64), pts.astype(np.complex128), method)
+        # north-star bar: 1e-5 relative; the float32 reference itself carries ~1e-6 * |exponent|
+        assert np.allclose(llr, ref64, rtol=1e-5, atol=1e-4 * max(1.0, float(np.max(np.abs(ref64))) * 1e-2))
+        hard = _np(phy.mapping.Demapper(method, "qam", m, hard_out=True)(y, no))
+        sure = np.abs(ref64) > 1e-3
+        assert np.array_equal(hard[sure], (ref64 > 0).astype(np.float32)[sure])
+
+
+# ------------------------------------------------------------------ encoder
+G = np.load(os.path.join(GOLD, "ldpc_enc_golden.npz"))
+
+
+@pytest.mark.parametrize("k,n", [tuple(int(v) for v in p) for p in G["params"]])
+def test_encoder_golden(phy, k, n):
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    u = np.unpackbits(G[f"u_{k}_{n}"], axis=1)[:, :k].astype(np.float32)
+    c_ref = np.unpackbits(G[f"c_{k}_{n}"], axis=1)[:, :n].astype(np.float32)
+    assert np.array_equal(_np(enc(u)), c_ref)
+
+
+@pytest.mark.parametrize("k,n,bg,m", [(1024, 2048, "bg1", None), (2816, 8448, "bg1", 6), (200, 600, None, 2),
+                                      (3840, 4800, "bg2", 4)])
+def test_encoder_vs_oracle_interleaved(phy, k, n, bg, m):
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    u = np.random.default_rng(k).integers(0, 2, (2, 5, k)).astype(np.float32)   # multi-dim batch
+    assert np.array_equal(_np(enc(u)), LDPC5GCode(k, n, m, bg).encode(u))
+
+
+# ------------------------------------------------------------------ generic BP decoder
+def _example_pcm(i):
+    ex = np.load(os.path.join(GOLD, "example_pcms.npz"))
+    pcm = np.zeros(tuple(ex[f"shape_{i}"]), np.float32)
+    pcm[ex[f"rc_{i}"][0], ex[f"rc_{i}"][1]] = 1
+    return pcm
+
+
+def _close(a, b, what):
+    """1e-5 relative with an absolute floor of 1e-4 (LLRs are bounded by llr_max=20)."""
+    ok = np.isclose(a, b, rtol=1e-5, atol=1e-4)
+    assert ok.mean() > 0.999, f"{what}: {1 - ok.mean():.2e} of the outputs outside tolerance, max {np.max(np.abs(a - b))}"
+
+
+@pytest.mark.parametrize("pcm_id", [0, 1, 3, 4])
+@pytest.mark.parametrize("cn", ["minsum", "offset-minsum", "boxplus-phi", "boxplus"])
+def test_generic_decoder_vs_oracle(phy, pcm_id, cn):
+    pcm = _example_pcm(pcm_id)
+    rng = np.random.default_rng(pcm_id)
+    llr = rng.normal(loc=-1.2, scale=2.5, size=(37, pcm.shape[1])).astype(np.float32)
+    llr[0, :3] = 0.0
+    llr[1] = np.round(llr[1])                       # ties / duplicate minima
+    for it in (0, 1, 5):
+        dec = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=cn, hard_out=False, num_iter=it, return_state=True)
+        x, st = dec(llr)
+        ref = obp.LDPCBPDecoder(pcm, cn_update=cn, hard_out=False, num_iter=it, return_state=True)
+        xr, sr = ref.decode(llr)
+        if cn in ("minsum", "offset-minsum"):
+            assert np.array_equal(_np(x), xr) and np.array_equal(_np(st), sr), f"{cn} it={it}"
+        else:
+            _close(_np(x), xr, f"{cn} it={it} x_hat")
+            _close(_np(st), sr, f"{cn} it={it} state")
+    hard = _np(phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=cn, num_iter=5)(llr))
+    sure = np.abs(xr) > 1e-3
+    assert np.array_equal(hard[sure], (xr > 0).astype(np.float32)[sure])        # logits>0 <=> bit 1
+    assert set(np.unique(hard)) <= {0.0, 1.0}
+
+
+def test_generic_decoder_state_passing(phy):
+    # decoding.py:569-573/636: 2 x 3 iterations with state == 6 iterations
+    pcm = _example_pcm(3)
+    llr = np.random.default_rng(3).normal(loc=-1, scale=2, size=(9, pcm.shape[1])).astype(np.float32)
+    d3 = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update="minsum", hard_out=False, num_iter=3, return_state=True)
+    d6 = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update="minsum", hard_out=False, num_iter=6, return_state=True)
+    _, st = d3(llr)
+    x2, st2 = d3(llr, msg_v2c=st)
+    x6, st6 = d6(llr)
+    assert np.array_equal(_np(x2), _np(x6)) and np.array_equal(_np(st2), _np(st6))
+
+
+def test_generic_decoder_invariants(phy):
+    pcm = _example_pcm(3)
+    for cn in ("minsum", "offset-minsum", "boxplus-phi", "boxplus"):
+        dec = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=cn, hard_out=False, num_iter=5, return_state=True)
+        x, st = dec(np.zeros((4, pcm.shape[1]), np.float32))
+        assert float(x.abs().max()) == 0 and float(st.abs().max()) == 0        # all-erasure
+        x, st = dec(np.random.default_rng(0).normal(scale=50, size=(8, pcm.shape[1])).astype(np.float32))
+        assert float(x.abs().max()) <= 20 and float(st.abs().max()) <= 20
+
+
+def test_big_degree_fallback(phy):
+    # dense parity-check matrix: CN degree 48, VN degree ~12 -> re-read kernels
+    rng = np.random.default_rng(5)
+    pcm = (rng.random((16, 64)) < 0.75).astype(np.float32)
+    pcm[:, 0] = 1
+    llr = rng.normal(loc=-0.5, scale=3, size=(10, 64)).astype(np.float32)
+    for cn in ("minsum", "boxplus-phi"):
+        x = _np(phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=cn, hard_out=False, num_iter=3)(llr))
+        xr = obp.LDPCBPDecoder(pcm, cn_update=cn, hard_out=False, num_iter=3).decode(llr)
+        if cn == "minsum":
+            assert np.array_equal(x, xr)
+        else:
+            _close(x, xr, "bigdeg phi")
+
+
+# ------------------------------------------------------------------ 5G decoder (both engines)
+CODES5G = [(64, 128, None, None), (200, 600, None, 2), (1024, 2048, "bg1", None), (500, 1000, None, 4),
+           (2816, 8448, "bg1", 6)]
+
+
+def _noisy_llr(code, batch, seed, sigma=0.8):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 2, (batch, code.k)).astype(np.float32)
+    c = code.encode(u)
+    y = (2 * c - 1) + sigma * rng.normal(size=c.shape)
+    return u, c, (2 * y / sigma ** 2).astype(np.float32)
+
+
+@pytest.mark.parametrize("k,n,bg,m", CODES5G)
+@pytest.mark.parametrize("cn", ["minsum", "offset-minsum"])
+def test_5g_minsum_bit_exact_both_engines(phy, k, n, bg, m, cn):
+    code = LDPC5GCode(k, n, m, bg)
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    u, c, llr = _noisy_llr(code, 13, k + n)
+    llr[0, :7] = 0
+    llr[1] = np.round(llr[1])
+    for it, infobits in ((0, False), (1, False), (7, True), (20, False)):
+        odec = obp.LDPC5GDecoder(code, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=it)
+        l5 = odec.rate_recover(llr)
+        xr = cbind.bp_decode(odec, l5, num_iter=it, hard_out=0)
+        ref = xr[:, :k] if infobits else None
+        if not infobits:      # map like decoding.py:1506-1531
+            x_nf = np.concatenate([xr[:, :k], xr[:, code.k_ldpc:]], axis=1)
+            ref = x_nf[:, 2 * code.z:2 * code.z + n]
+            if m is not None:
+                ref = ref[:, code.out_int]
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=it)
+        got_onchip = _np(dec(llr))
+        assert dec._onchip_ok, "on-chip engine should accept this code"
+        assert np.array_equal(got_onchip, ref), f"on-chip {cn} it={it}"
+        dec._onchip_ok = False                                  # force the HBM-resident engine
+        got_generic = _np(dec(llr))
+        assert np.array_equal(got_generic, ref), f"generic {cn} it={it}"
+    hard = _np(phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn)(llr))
+    odec = obp.LDPC5GDecoder(code, cn_update=cn, hard_out=True, num_iter=20)
+    assert np.array_equal(hard, cbind.bp_decode(odec, odec.rate_recover(llr))[:, :k])
+
+
+@pytest.mark.parametrize("k,n,bg,m", CODES5G)
+@pytest.mark.parametrize("cn", ["boxplus-phi", "boxplus"])
+def test_5g_boxplus_vs_oracle(phy, k, n, bg, m, cn):
+    code = LDPC5GCode(k, n, m, bg)
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    u, c, llr = _noisy_llr(code, 8, k, sigma=0.55)
+    for it in (1, 10):
+        odec = obp.LDPC5GDecoder(code, cn_update=cn, hard_out=False, return_infobits=True, num_iter=it)
+        ref = odec.decode5g(llr)
+        got = _np(phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, num_iter=it)(llr))
+        _close(got, ref, f"{cn} it={it}")
+    assert np.array_equal(_np(phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, return_infobits=False)(llr)), c)
+
+
+def test_5g_large_z_falls_back_to_generic(phy):
+    # Z=384: does not fit in LDS -> generic engine, still bit-exact
+    k, n = 8448, 12354
+    code = LDPC5GCode(k, n)
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    u, c, llr = _noisy_llr(code, 3, 1, sigma=0.5)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=5)
+    odec = obp.LDPC5GDecoder(code, cn_update="minsum", hard_out=False, num_iter=5)
+    got = _np(dec(llr))
+    assert not dec._onchip_ok
+    assert np.array_equal(got, cbind.bp_decode(odec, odec.rate_recover(llr))[:, :k])
+
+
+# ------------------------------------------------------------------ metrics + sim_ber + chain
+def test_count_errors(phy):
+    rng = np.random.default_rng(0)
+    b = rng.integers(0, 2, (1000, 257)).astype(np.float32)
+    bh = b.copy()
+    flip = rng.random(b.shape) < 0.001
+    bh[flip] = 1 - bh[flip]
+    assert int(phy.utils.count_errors(torch.tensor(b).cuda(), torch.tensor(bh).cuda())) == int(flip.sum())
+    assert int(phy.utils.count_block_errors(torch.tensor(b).cuda(), torch.tensor(bh).cuda())) == int(flip.any(1).sum())
+
+
+def _chain(phy, k, n, m, bg, cn, num_iter):
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=num_iter)
+    src, mapper, awgn = phy.mapping.BinarySource(), phy.mapping.Mapper("qam", m), phy.channel.AWGN()
+    demap = phy.mapping.Demapper("app", "qam", m)
+
+    def mc_fun(batch_size, ebno_db):
+        no = phy.utils.ebnodb2no(ebno_db, m, k / n)
+        u = src([batch_size, k])
+        llr = demap(awgn(mapper(enc(u)), no), no)
+        return u, dec(llr)
+    return mc_fun
+
+
+def test_c1_chain_matches_oracle_on_same_noise(phy):
+    """Config C1 (QPSK, BG1 k=1024 n=2048, BP-10 boxplus-phi, B=32): whole chain on the GPU vs
+    the oracle chain on the SAME Philox noise: identical bit errors up to LLR ties."""
+    k, n, m = 1024, 2048, 2
+    code = LDPC5GCode(k, n, m, "bg1")
+    pts = omap.qam(m)
+    for seed, ebno in ((1, 0.0), (2, 1.5), (3, 3.0)):
+        phy.config.seed = seed
+        u, u_hat = _chain(phy, k, n, m, "bg1", "boxplus-phi", 10)(32, ebno)
+        no = outil.ebnodb2no(ebno, m, k / n)
+        uo = outil.random_bits(seed, 0, 32 * k).reshape(32, k)
+        assert np.array_equal(_np(u), uo)
+        y = outil.awgn(omap.mapper(code.encode(uo), pts), no, seed, 1)
+        llr = omap.demapper(y, no, pts, "app")
+        ref = obp.LDPC5GDecoder(code, num_iter=10).decode5g(llr)
+        mism = np.mean(_np(u_hat) != ref)
+        assert mism < 2e-3, f"seed {seed}: {mism}"
+        assert abs(np.mean(_np(u_hat) != uo) - np.mean(ref != uo)) < 2e-3
+
+
+def test_sim_ber_runs_and_stops(phy):
+    phy.config.seed = 5
+    ber, bler = phy.utils.sim_ber(_chain(phy, 200, 400, 2, None, "minsum", 10), np.array([0., 3., 6., 9.]),
+                                  batch_size=200, max_mc_iter=3, num_target_block_errors=50, verbose=False)
+    ber = ber.numpy()
+    assert ber[0] > 0.05 and ber[-1] == 0 and np.all(np.diff(ber) <= 1e-9)
+
+
+# ------------------------------------------------------------------ full-size properties (C2)
+def test_c2_full_batch_properties(phy):
+    """BASELINE config C2 at a large batch: size-independent properties."""
+    k, n, m = 2816, 8448, 6
+    B = 4096
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
+    phy.config.seed = 9
+    src = phy.mapping.BinarySource()
+    u1, u2 = src([B, k]), src([B, k])
+    c1, c2 = enc(u1), enc(u2)
+    # linearity over GF(2)
+    c12 = enc(((u1 + u2) % 2))
+    assert torch.equal(c12, (c1 + c2) % 2)
+    # noiseless round trip through mapper / demapper / both decoder engines
+    mapper, demap = phy.mapping.Mapper("qam", m), phy.mapping.Demapper("app", "qam", m)
+    llr = demap(mapper(c1), 0.05)
+    assert torch.equal(hard := (llr > 0).float(), c1), "demapper hard decisions must reproduce the codeword"
+    for cn in ("minsum", "boxplus-phi"):
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=20)
+        assert torch.equal(dec(llr).as_subclass(torch.Tensor), u1.as_subclass(torch.Tensor))
+    # erasures: puncture 25 % of the LLRs, decoder still recovers (rate 1/3)
+    mask = (torch.rand_like(llr) < 0.25)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=20)
+    u_hat = dec(torch.where(mask, torch.zeros_like(llr), llr))
+    assert float((u_hat != u1).float().mean()) < 1e-4
+    # on-chip == generic on the full batch
+    dec2 = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=5, hard_out=False)
+    noisy = llr * 0.05 + torch.randn_like(llr)
+    a = dec2(noisy)
+    dec2._onchip_ok = False
+    b = dec2(noisy)
+    assert torch.equal(a.as_subclass(torch.Tensor), b.as_subclass(torch.Tensor))
