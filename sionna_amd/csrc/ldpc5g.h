@@ -1,0 +1,81 @@
+// Shared declarations of the 5G-NR QC-LDPC kernels (handle layout, rate-matching index maps).
+#pragma once
+#include "common.h"
+#include <utility>
+#include <vector>
+
+struct samd_ldpc5g {
+  int bg = 0, z = 0, k = 0, n = 0, m_int = 0, nb_pruned = 0;
+  int mb = 0, nb = 0, k_b = 0, k_ldpc = 0, n_ldpc = 0, n_vn = 0, n_cn = 0;
+  int s_a = 0, s_b = 0;  // shifts of the core entries P_A, P_B (encoding.py:476-481)
+  int nnz = 0, max_dc = 0, max_dv = 0;
+  // base graph, CSR by row (entries ascending column) - device
+  int32_t* row_ptr = nullptr;  // [mb+1]
+  int32_t* row_ent = nullptr;  // [nnz]  col | shift<<16   (shift already mod Z)
+  // base graph, CSC by column (entries ascending row) - device
+  int32_t* col_ptr = nullptr;  // [nb+1]
+  int32_t* col_ent = nullptr;  // [nnz]  row | shift<<8 | pos<<20  (pos = index of the edge inside its row)
+  // work items for the decoder, longest first: (index | chunk<<16)
+  int32_t* cn_items = nullptr; int n_cn_items = 0;
+  int32_t* vn_items = nullptr; int n_vn_items = 0;
+  // ---- tables of the statically scheduled on-chip decoder (csrc/ldpc5g_onchip.hip)
+  int v2_ok = 0;               // all row degrees have an unrolled instantiation
+  int ncu = 0, nbu = 0;        // base rows / columns that hold at least one un-pruned node
+  int32_t* row_pad = nullptr;  // [mb*20]  (c*z) | shift<<16, entries ascending column
+  int32_t* row_deg = nullptr;  // [mb]
+  int32_t* col_pad = nullptr;  // [nb*32]  (r*z) | shift<<16 | pos<<25, padded with the zero dummy CN block
+  int32_t* col_cls = nullptr;  // [nb]     unrolled class size (>= column degree)
+  int32_t* cn_sched_ptr = nullptr; int32_t* cn_sched = nullptr;   // per-wave item lists (LPT balanced)
+  int32_t* vn_sched_ptr = nullptr; int32_t* vn_sched = nullptr;
+};
+
+namespace samd {
+constexpr int kRowStride = 20;   // max row degree of BG1 is 19
+constexpr int kColStride = 32;   // max column degree of BG1 is 30
+constexpr int kDecWaves = 16;    // 1024-thread workgroup
+// build the v2 tables (host); defined in ldpc5g_onchip.hip
+int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
+void free_onchip_tables(samd_ldpc5g* h);
+int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                     float llr_max, float offset, int hard_out, int return_infobits, hipStream_t st);
+}
+
+namespace samd {
+
+// ------------------------------------------------------------------ index maps (shared)
+struct RateMatch {
+  int k, n, z, k_ldpc, n_vn, m_int;
+};
+
+// position t of c_short / x_short (before the output interleaver) for output index o
+// (encoding.py:238-244: out[o] = c_short[perm[o]], perm[i + j*m] = i*(n/m) + j)
+__device__ __forceinline__ int out_to_short(const RateMatch& p, int o) {
+  if (p.m_int <= 0) return o;
+  const int i = o % p.m_int, j = o / p.m_int;
+  return i * (p.n / p.m_int) + j;
+}
+// index into the full (filler-including) codeword for position t of c_short
+// (encoding.py:645-655 / decoding.py:1508-1521)
+__device__ __forceinline__ int short_to_full(const RateMatch& p, int t) {
+  const int u = t + 2 * p.z;
+  return u < p.k ? u : u + (p.k_ldpc - p.k);
+}
+// rate recovery (decoding.py:1438-1475): value for VN v given the received llr row
+__device__ __forceinline__ float recover_llr(const RateMatch& p, const float* __restrict__ llr_row, int v,
+                                             float llr_max) {
+  int u;
+  if (v < p.k) u = v;
+  else if (v < p.k_ldpc) return -llr_max;          // filler bits: logit -llr_max
+  else u = v - (p.k_ldpc - p.k);
+  const int t = u - 2 * p.z;
+  if (t < 0 || t >= p.n) return 0.f;               // punctured
+  int o = t;
+  if (p.m_int > 0) {                               // out_int_inv[t]
+    const int q = p.n / p.m_int;
+    o = (t / q) + (t % q) * p.m_int;
+  }
+  return llr_row[o];
+}
+
+
+}  // namespace samd

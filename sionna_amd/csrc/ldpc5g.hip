@@ -23,62 +23,13 @@
 //     The arithmetic and its order are those of oracle/ldpc_bp.py, so results are
 //     bit-identical to the HBM-resident generic decoder.
 #include "common.h"
-
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
-struct samd_ldpc5g {
-  int bg = 0, z = 0, k = 0, n = 0, m_int = 0, nb_pruned = 0;
-  int mb = 0, nb = 0, k_b = 0, k_ldpc = 0, n_ldpc = 0, n_vn = 0, n_cn = 0;
-  int s_a = 0, s_b = 0;  // shifts of the core entries P_A, P_B (encoding.py:476-481)
-  int nnz = 0, max_dc = 0, max_dv = 0;
-  // base graph, CSR by row (entries ascending column) - device
-  int32_t* row_ptr = nullptr;  // [mb+1]
-  int32_t* row_ent = nullptr;  // [nnz]  col | shift<<16   (shift already mod Z)
-  // base graph, CSC by column (entries ascending row) - device
-  int32_t* col_ptr = nullptr;  // [nb+1]
-  int32_t* col_ent = nullptr;  // [nnz]  row | shift<<8 | pos<<20  (pos = index of the edge inside its row)
-  // work items for the decoder, longest first: (index | chunk<<16)
-  int32_t* cn_items = nullptr; int n_cn_items = 0;
-  int32_t* vn_items = nullptr; int n_vn_items = 0;
-};
+#include "ldpc5g.h"
 
 namespace samd {
-
-// ------------------------------------------------------------------ index maps (shared)
-struct RateMatch {
-  int k, n, z, k_ldpc, n_vn, m_int;
-};
-
-// position t of c_short / x_short (before the output interleaver) for output index o
-// (encoding.py:238-244: out[o] = c_short[perm[o]], perm[i + j*m] = i*(n/m) + j)
-__device__ __forceinline__ int out_to_short(const RateMatch& p, int o) {
-  if (p.m_int <= 0) return o;
-  const int i = o % p.m_int, j = o / p.m_int;
-  return i * (p.n / p.m_int) + j;
-}
-// index into the full (filler-including) codeword for position t of c_short
-// (encoding.py:645-655 / decoding.py:1508-1521)
-__device__ __forceinline__ int short_to_full(const RateMatch& p, int t) {
-  const int u = t + 2 * p.z;
-  return u < p.k ? u : u + (p.k_ldpc - p.k);
-}
-// rate recovery (decoding.py:1438-1475): value for VN v given the received llr row
-__device__ __forceinline__ float recover_llr(const RateMatch& p, const float* __restrict__ llr_row, int v,
-                                             float llr_max) {
-  int u;
-  if (v < p.k) u = v;
-  else if (v < p.k_ldpc) return -llr_max;          // filler bits: logit -llr_max
-  else u = v - (p.k_ldpc - p.k);
-  const int t = u - 2 * p.z;
-  if (t < 0 || t >= p.n) return 0.f;               // punctured
-  int o = t;
-  if (p.m_int > 0) {                               // out_int_inv[t]
-    const int q = p.n / p.m_int;
-    o = (t / q) + (t % q) * p.m_int;
-  }
-  return llr_row[o];
-}
 
 // ------------------------------------------------------------------ encoder
 __global__ __launch_bounds__(256) void ldpc5g_encode_kernel(
@@ -360,6 +311,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   if (rc == SAMD_OK) rc = upload(&h->col_ent, col_ent.data(), col_ent.size());
   if (rc == SAMD_OK) rc = upload(&h->cn_items, cn_items.data(), cn_items.size());
   if (rc == SAMD_OK) rc = upload(&h->vn_items, vn_items.data(), vn_items.size());
+  if (rc == SAMD_OK) rc = build_onchip_tables(h, by_row);
   if (rc != SAMD_OK) { samd_ldpc5g_destroy(h); return rc; }
   *out = h;
   return SAMD_OK;
@@ -369,6 +321,7 @@ extern "C" void samd_ldpc5g_destroy(samd_ldpc5g_t* h) {
   if (!h) return;
   (void)hipFree(h->row_ptr); (void)hipFree(h->row_ent); (void)hipFree(h->col_ptr); (void)hipFree(h->col_ent);
   (void)hipFree(h->cn_items); (void)hipFree(h->vn_items);
+  free_onchip_tables(h);
   delete h;
 }
 
@@ -424,9 +377,17 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   const size_t lds = decode_lds_bytes(h);
   // the count-based duplicate-minimum test equals the reference's 1e5-sentinel sum test only
   // while node_degree * 2 * llr_max stays below the sentinel (decoding.py:865-872)
-  if (lds > 160 * 1024 || h->max_dc > 27 || !(llr_max >= 0.f) ||
-      (double)h->max_dc * 2.0 * (double)llr_max >= 99999.0) {
+  if (h->max_dc > 27 || !(llr_max >= 0.f) || (double)h->max_dc * 2.0 * (double)llr_max >= 99999.0) {
     set_error("code / llr_max outside the on-chip decoder's envelope");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  if (h->v2_ok && !getenv("SAMD_ONCHIP_V1")) {   // statically scheduled, unrolled engine
+    const int rc = launch_onchip_v2(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out,
+                                    return_infobits, (hipStream_t)stream);
+    if (rc != SAMD_ERR_UNSUPPORTED) return rc;
+  }
+  if (lds > 160 * 1024) {
+    set_error("code does not fit in LDS");
     return SAMD_ERR_UNSUPPORTED;
   }
   const bool off = (cn_mode == SAMD_CN_OFFSET_MINSUM);

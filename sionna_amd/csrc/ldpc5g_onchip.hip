@@ -1,0 +1,303 @@
+// On-chip flooding min-sum decoder for 5G-NR LDPC codes, statically scheduled and fully
+// unrolled ("v2" of the engine in ldpc5g.hip; same algorithm, same arithmetic, same results).
+//
+// Replaces LDPC5GDecoder.call = rate recovery + LDPCBPDecoder._bp_iter x num_iter +
+// cn_update_(offset_)minsum + vn_update_sum + output mapping
+// (reference src/sionna/phy/fec/ldpc/decoding.py:1427-1536, 416-524, 681-953).
+//
+// Why a second engine: the first one walks a base-graph row with a rolled loop - one scalar
+// table load, one LDS read and one dependent min-update per trip - so every wave sits in
+// LDS/scalar latency (measured 97 ms per 65536 C2 decodes).  Here
+//   * every base row / column is processed by a function instantiated for its exact degree
+//     (rows: 3..10 and 19 - all degrees of BG1/BG2; columns: padded to a few classes with a
+//     zero "dummy check node"), so the table entries arrive as wide scalar loads, all LDS
+//     reads of a node are issued back to back and the arithmetic is straight-line;
+//   * the (row, 64-lane chunk) and (column, chunk) work items are assigned to the 16 waves
+//     of the workgroup on the host (longest-processing-time first) - no atomics, no
+//     divergence: all lanes of a wave share (c, shift) in SGPRs and differ only in z;
+//   * the two smallest magnitudes are tracked with v_min/v_med3, the sign bits are spliced
+//     in with v_bfi: ~15 VALU per edge in the CN phase, ~11 in the VN phase.
+// LDS per codeword: xt[nbu*Z] + llr[nbu*Z] floats, check-node state float2 m12[(ncu+1)*Z]
+// + uint pk[(ncu+1)*Z] (the extra block is the dummy CN): 141.8 KB for C2 -> 1 workgroup
+// (16 waves) per CU.
+#include "ldpc5g.h"
+
+#include <algorithm>
+#include <numeric>
+
+namespace samd {
+
+__device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
+__device__ __forceinline__ float u2f(unsigned x) { return __uint_as_float(x); }
+__device__ __forceinline__ unsigned bfi(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
+
+// ---- one check node per lane: row of exact degree D
+template <int D, bool OFFSET>
+__device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned zz, unsigned z, int cn,
+                                       const float* __restrict__ xt, float2* __restrict__ m12,
+                                       unsigned* __restrict__ pk, float llr_max, float offset) {
+  int e[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) e[i] = ent[i];
+  float x[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    unsigned zi = zz + (unsigned)(e[i] >> 16);
+    zi = min(zi, zi - z);                                   // (zz + s) mod Z
+    x[i] = xt[(unsigned)(e[i] & 0xFFFF) + zi];
+  }
+  const float2 om = m12[cn];
+  const unsigned opk = pk[cn];
+  const int oidx = (int)(opk & 31u);
+  float min1 = INFINITY, min2 = INFINITY;
+  int idx = 0;
+  unsigned neg = 0;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    // previous c2v of this edge from the compressed state, then v2c = clip(x_tot - c2v)
+    const float mag = (i == oidx) ? om.y : om.x;
+    const float c2v = u2f(bfi(0x80000000u, opk << (26 - i), f2u(mag)));
+    const float v2c = clampf(-1.f * c2v + x[i], -llr_max, llr_max);
+    neg |= (v2c < 0.f ? 1u : 0u) << i;                      // sign(+-0) := +1
+    const float a = fabsf(v2c);
+    idx = (a < min1) ? i : idx;
+    min2 = __builtin_amdgcn_fmed3f(min1, min2, a);          // second smallest, with multiplicity
+    min1 = fminf(min1, a);
+  }
+  // unique minimum <=> min2 > min1; (min2 - min1) + min1 is the reference's arithmetic (:863)
+  const float min_e = (min2 > min1) ? ((min2 - min1) + min1) : min1;
+  float a1 = min1, a2 = min_e;
+  if constexpr (OFFSET) { a1 -= offset; a2 -= offset; }
+  a1 = fminf(fmaxf(a1, 0.f), llr_max);
+  a2 = fminf(fmaxf(a2, 0.f), llr_max);
+  const unsigned all = (1u << D) - 1u;
+  const unsigned sgn = (__popc(neg) & 1) ? (~neg & all) : neg;
+  m12[cn] = make_float2(a1, a2);
+  pk[cn] = (unsigned)idx | (sgn << 5);
+}
+
+// ---- one variable node per lane: column class of D slots (real edges first, then dummies)
+template <int D>
+__device__ __forceinline__ void vn_col(const int32_t* __restrict__ ent, unsigned zz, unsigned z, int vn,
+                                       float* __restrict__ xt, const float* __restrict__ llr,
+                                       const float2* __restrict__ m12, const unsigned* __restrict__ pk) {
+  int e[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) e[i] = ent[i];
+  float2 m[D];
+  unsigned q[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    unsigned zi = zz - (unsigned)((e[i] >> 16) & 0x1FF);
+    zi = min(zi, zi + z);                                   // (zz - s) mod Z
+    const unsigned cn = (unsigned)(e[i] & 0x7FFF) + zi;
+    m[i] = m12[cn];
+    q[i] = pk[cn];
+  }
+  float x = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const unsigned pos = (unsigned)e[i] >> 25;
+    const float mag = ((q[i] & 31u) == pos) ? m[i].y : m[i].x;
+    x += u2f(bfi(0x80000000u, q[i] << (26u - pos), f2u(mag)));    // ascending CN = edge order
+  }
+  xt[vn] = x + llr[vn];                                     // unclipped x_tot (decoding.py:716)
+}
+
+template <bool OFFSET>
+__global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
+    const float* __restrict__ llr_in, float* __restrict__ out, RateMatch p, int n_cn, int ncu, int nbu, int batch,
+    int num_iter, float llr_max, float offset, int hard_out, int return_infobits,
+    const int32_t* __restrict__ row_pad, const int32_t* __restrict__ row_deg, const int32_t* __restrict__ col_pad,
+    const int32_t* __restrict__ col_cls, const int32_t* __restrict__ cn_sched_ptr,
+    const int32_t* __restrict__ cn_sched, const int32_t* __restrict__ vn_sched_ptr,
+    const int32_t* __restrict__ vn_sched) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = kDecWaves * 64;
+  const unsigned z = (unsigned)p.z;
+  const int n_vn = p.n_vn;
+  const int nx = nbu * (int)z, ns = (ncu + 1) * (int)z;
+  float* xt = smem;
+  float* llr = xt + nx;
+  float2* m12 = reinterpret_cast<float2*>(llr + nx);
+  unsigned* pk = reinterpret_cast<unsigned*>(m12 + ns);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = cn_sched_ptr[w], c1 = cn_sched_ptr[w + 1];
+  const int v0 = vn_sched_ptr[w], v1 = vn_sched_ptr[w + 1];
+
+  for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+    const float* row = llr_in + (size_t)b * p.n;
+    for (int v = tid; v < nx; v += NT) {
+      // decoding.py:552-565: clip, then logits -> LLR
+      const float l = (v < n_vn) ? -1.f * clampf(recover_llr(p, row, v, llr_max), -llr_max, llr_max) : 0.f;
+      llr[v] = l;
+      xt[v] = l;
+    }
+    for (int c = tid; c < ns; c += NT) { m12[c] = make_float2(0.f, 0.f); pk[c] = 0u; }
+    __syncthreads();
+
+    for (int it = 0; it < num_iter; ++it) {
+      for (int t = c0; t < c1; ++t) {
+        const int desc = __builtin_amdgcn_readfirstlane(cn_sched[t]);
+        const int r = desc & 0xFF;
+        const unsigned zz = (unsigned)((desc >> 8) * 64 + lane);
+        const int cn = r * (int)z + (int)zz;
+        const int32_t* ent = row_pad + r * kRowStride;
+        if (zz < z && cn < n_cn) {
+#define SAMD_CN(D) case D: cn_row<D, OFFSET>(ent, zz, z, cn, xt, m12, pk, llr_max, offset); break
+          switch (__builtin_amdgcn_readfirstlane(row_deg[r])) {
+            SAMD_CN(3); SAMD_CN(4); SAMD_CN(5); SAMD_CN(6); SAMD_CN(7); SAMD_CN(8); SAMD_CN(9); SAMD_CN(10); SAMD_CN(19);
+            default: break;
+          }
+#undef SAMD_CN
+        }
+      }
+      __syncthreads();
+      for (int t = v0; t < v1; ++t) {
+        const int desc = __builtin_amdgcn_readfirstlane(vn_sched[t]);
+        const int c = desc & 0xFF;
+        const unsigned zz = (unsigned)((desc >> 8) * 64 + lane);
+        const int vn = c * (int)z + (int)zz;
+        const int32_t* ent = col_pad + c * kColStride;
+        if (zz < z && vn < n_vn) {
+#define SAMD_VN(D) case D: vn_col<D>(ent, zz, z, vn, xt, llr, m12, pk); break
+          switch (__builtin_amdgcn_readfirstlane(col_cls[c])) {
+            SAMD_VN(1); SAMD_VN(4); SAMD_VN(5); SAMD_VN(6); SAMD_VN(7); SAMD_VN(8); SAMD_VN(9); SAMD_VN(10);
+            SAMD_VN(12); SAMD_VN(14); SAMD_VN(16); SAMD_VN(24); SAMD_VN(30);
+            default: break;
+          }
+#undef SAMD_VN
+        }
+      }
+      __syncthreads();
+    }
+    // ---------------- output (decoding.py:620-626, 1486-1531)
+    if (return_infobits) {
+      float* o = out + (size_t)b * p.k;
+      for (int v = tid; v < p.k; v += NT) {
+        const float x = clampf(xt[v], -llr_max, llr_max);
+        o[v] = hard_out ? ((0.f >= x) ? 1.f : 0.f) : -1.f * x;
+      }
+    } else {
+      float* o = out + (size_t)b * p.n;
+      for (int i = tid; i < p.n; i += NT) {
+        const float x = clampf(xt[short_to_full(p, out_to_short(p, i))], -llr_max, llr_max);
+        o[i] = hard_out ? ((0.f >= x) ? 1.f : 0.f) : -1.f * x;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static const int kCnDegrees[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
+static const int kVnClasses[] = {1, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 24, 30};
+
+// longest-processing-time-first assignment of items to the waves of the workgroup
+static void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, std::vector<int32_t>* ptr,
+                         std::vector<int32_t>* list) {
+  std::vector<size_t> order(items.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].first > items[b].first; });
+  std::vector<std::vector<int32_t>> per(kDecWaves);
+  std::vector<long> load(kDecWaves, 0);
+  for (size_t i : order) {
+    const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    per[w].push_back(items[i].second);
+    load[w] += items[i].first + 3;                       // + fixed per-item overhead
+  }
+  ptr->assign(1, 0);
+  list->clear();
+  for (int w = 0; w < kDecWaves; ++w) {
+    list->insert(list->end(), per[w].begin(), per[w].end());
+    ptr->push_back((int32_t)list->size());
+  }
+}
+
+int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row) {
+  const int z = h->z;
+  h->ncu = (h->n_cn + z - 1) / z;
+  h->nbu = (h->n_vn + z - 1) / z;
+  bool ok = h->mb <= 255 && h->nb <= 255 && h->ncu * z + z <= 0x7FFF && h->nbu * z <= 0xFFFF;
+  std::vector<int32_t> row_pad((size_t)h->mb * kRowStride, 0), row_deg(h->mb, 0);
+  std::vector<std::vector<int32_t>> cols(h->nb);
+  for (int r = 0; r < h->mb && ok; ++r) {
+    const int d = (int)by_row[r].size();
+    row_deg[r] = d;
+    if (r < h->ncu && std::find(std::begin(kCnDegrees), std::end(kCnDegrees), d) == std::end(kCnDegrees)) ok = false;
+    if (d > kRowStride) { ok = false; break; }
+    for (int i = 0; i < d; ++i) {
+      const int c = by_row[r][i].first, s = by_row[r][i].second;
+      row_pad[(size_t)r * kRowStride + i] = (c * z) | (s << 16);
+      if (r < h->ncu) cols[c].push_back((r * z) | (s << 16) | (i << 25));   // rows ascending
+    }
+  }
+  std::vector<int32_t> col_pad((size_t)h->nb * kColStride, 0), col_cls(h->nb, 1);
+  for (int c = 0; c < h->nb && ok; ++c) {
+    const int d = (int)cols[c].size();
+    int cls = -1;
+    for (int k : kVnClasses) if (k >= d) { cls = k; break; }
+    if (cls < 0 || cls > kColStride) { ok = false; break; }
+    col_cls[c] = cls;
+    for (int i = 0; i < kColStride; ++i)
+      col_pad[(size_t)c * kColStride + i] = i < d ? cols[c][i] : (h->ncu * z);   // dummy CN block, s = pos = 0
+  }
+  h->v2_ok = ok ? 1 : 0;
+  if (!ok) return SAMD_OK;
+  const int chunks = (z + 63) / 64;
+  std::vector<std::pair<int, int32_t>> ci, vi;
+  for (int r = 0; r < h->ncu; ++r)
+    for (int q = 0; q < chunks; ++q)
+      if (r * z + q * 64 < h->n_cn) ci.push_back({row_deg[r], r | (q << 8)});
+  for (int c = 0; c < h->nbu; ++c)
+    for (int q = 0; q < chunks; ++q)
+      if (c * z + q * 64 < h->n_vn) vi.push_back({col_cls[c], c | (q << 8)});
+  std::vector<int32_t> cp, cl, vp, vl;
+  lpt_schedule(ci, &cp, &cl);
+  lpt_schedule(vi, &vp, &vl);
+  int rc = upload(&h->row_pad, row_pad.data(), row_pad.size());
+  if (rc == SAMD_OK) rc = upload(&h->row_deg, row_deg.data(), row_deg.size());
+  if (rc == SAMD_OK) rc = upload(&h->col_pad, col_pad.data(), col_pad.size());
+  if (rc == SAMD_OK) rc = upload(&h->col_cls, col_cls.data(), col_cls.size());
+  if (rc == SAMD_OK) rc = upload(&h->cn_sched_ptr, cp.data(), cp.size());
+  if (rc == SAMD_OK) rc = upload(&h->cn_sched, cl.data(), cl.size());
+  if (rc == SAMD_OK) rc = upload(&h->vn_sched_ptr, vp.data(), vp.size());
+  if (rc == SAMD_OK) rc = upload(&h->vn_sched, vl.data(), vl.size());
+  return rc;
+}
+
+void free_onchip_tables(samd_ldpc5g* h) {
+  (void)hipFree(h->row_pad); (void)hipFree(h->row_deg); (void)hipFree(h->col_pad); (void)hipFree(h->col_cls);
+  (void)hipFree(h->cn_sched_ptr); (void)hipFree(h->cn_sched); (void)hipFree(h->vn_sched_ptr); (void)hipFree(h->vn_sched);
+}
+
+int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                     float llr_max, float offset, int hard_out, int return_infobits, hipStream_t st) {
+  const size_t lds = ((size_t)2 * h->nbu + (size_t)3 * (h->ncu + 1)) * h->z * 4;
+  if (lds > 160 * 1024) {
+    set_error("code does not fit in LDS");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  const bool off = (cn_mode == SAMD_CN_OFFSET_MINSUM);
+  const void* fn = off ? (const void*)ldpc5g_decode_v2_kernel<true> : (const void*)ldpc5g_decode_v2_kernel<false>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[off]) {
+    SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[off] = true;
+  }
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t per_cu = std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
+  const int grid = (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+#define SAMD_V2_ARGS llr, out, rm, h->n_cn, h->ncu, h->nbu, batch, num_iter, llr_max, (off ? offset : 0.f), hard_out, \
+                     return_infobits, h->row_pad, h->row_deg, h->col_pad, h->col_cls, h->cn_sched_ptr, h->cn_sched,  \
+                     h->vn_sched_ptr, h->vn_sched
+  if (off) hipLaunchKernelGGL(ldpc5g_decode_v2_kernel<true>, dim3(grid), dim3(kDecWaves * 64), lds, st, SAMD_V2_ARGS);
+  else hipLaunchKernelGGL(ldpc5g_decode_v2_kernel<false>, dim3(grid), dim3(kDecWaves * 64), lds, st, SAMD_V2_ARGS);
+#undef SAMD_V2_ARGS
+  return launch_status();
+}
+
+}  // namespace samd

@@ -21,6 +21,7 @@
 //    node's edges in edge order (VN-major edge numbering, ascending CN inside a VN /
 //    ascending VN inside a CN); the library is compiled with -ffp-contract=off.
 #include "common.h"
+#include "accurate_math.h"
 
 #include <vector>
 
@@ -43,9 +44,18 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 __device__ __forceinline__ float sign_nz(float x) { return x < 0.f ? -1.f : 1.f; }  // sign(0) := +1
 __device__ __forceinline__ float sgn3(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
-__device__ __forceinline__ float phi_f32(float x) {
-  // decoding.py:1110-1120, literal form
+// phi of the boxplus-phi rule, literal float32 form of decoding.py:1110-1120.
+// The upper clip 16.635532 ~ ln 2^24 is where e^x + 1 and e^x - 1 round to neighbouring
+// floats: with correctly rounded exp/log (glibc, NumPy, Eigen) the difference of the logs
+// is exactly 0 there - the reference's own test demands it ("all-erasure -> zeros",
+// test_ldpc_decoding.py:279-291) - but the device libm is a 1-2 ulp approximation and
+// returned 5.7e-6.  The saturated point is therefore pinned to the correctly rounded
+// value; everywhere else the float32 device functions are used (accurate_math.h keeps the
+// float64 evaluation that was measured 1.75x slower on the whole decoder for no gain in
+// agreement with the oracle - DESIGN.md "phi conditioning").
+__device__ __forceinline__ float phi_fast_f32(float x) {
   x = clampf(x, 8.5e-8f, 16.635532f);
+  if (x == 16.635532f) return 0.f;
   const float e = expf(x);
   return logf(e + 1.f) - logf(e - 1.f);
 }
@@ -93,14 +103,14 @@ __device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr
       if (i < d) {
         sgn[i] = sign_nz(v[i]);
         node_sign *= sgn[i];
-        v[i] = phi_f32(fabsf(v[i]));
+        v[i] = phi_fast_f32(fabsf(v[i]));
         sum += v[i];
       }
 #pragma unroll
     for (int i = 0; i < MAXD; ++i)
       if (i < d) {
         const float e = -1.f * v[i] + sum;
-        v[i] = clampf((sgn[i] * node_sign) * phi_f32(e), -llr_max, llr_max);
+        v[i] = clampf((sgn[i] * node_sign) * phi_fast_f32(e), -llr_max, llr_max);
       }
   } else {  // SAMD_CN_BOXPLUS (tanh), decoding.py:1000-1042
     float prod = 1.f;
@@ -201,12 +211,12 @@ __global__ __launch_bounds__(256) void cn_pass_bigdeg_kernel(
     for (int i = 0; i < d; ++i) {
       const float x = load(i);
       node_sign *= sign_nz(x);
-      sum += phi_f32(fabsf(x));
+      sum += phi_fast_f32(fabsf(x));
     }
     for (int i = 0; i < d; ++i) {
       const float x = load(i);
-      const float e = -1.f * phi_f32(fabsf(x)) + sum;
-      msg[(size_t)cn_edge[e0 + i] * stride + b] = clampf((sign_nz(x) * node_sign) * phi_f32(e), -llr_max, llr_max);
+      const float e = -1.f * phi_fast_f32(fabsf(x)) + sum;
+      msg[(size_t)cn_edge[e0 + i] * stride + b] = clampf((sign_nz(x) * node_sign) * phi_fast_f32(e), -llr_max, llr_max);
     }
   } else {
     float prod = 1.f;
