@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--engine", default="auto", choices=["auto", "generic"],
                     help="generic forces the HBM-resident decoder also for min-sum")
     ap.add_argument("--ebno-db", type=float, default=4.5)
-    ap.add_argument("--also", default="boxplus-phi", help="second CN rule timed with fewer steps ('' = none)")
+    ap.add_argument("--also", default="boxplus-phi", help="second CN rule timed with fewer steps ('none' disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="codewords for the CPU baseline (0 = auto)")
     args = ap.parse_args()
@@ -101,16 +101,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step(dec):
+    def step(dec, ev=None):
+        if ev is not None:
+            ev[0].record()          # HIP events on the launch stream bracket the decoder kernels only
         u_hat = dec(llr)
+        if ev is not None:
+            ev[1].record()
         phy.utils.metrics.count_errors_into(u, u_hat, counters[:2])
         counters[2] += u.numel()
         counters[3] += B
-        if world > 1:
+        if world > 1:               # the path's only collective: 4 x int64 error counters (RCCL)
             red = counters.clone()
             dist.all_reduce(red, op=dist.ReduceOp.SUM)
-            return red
-        return counters
 
     def run(dec, steps, warmup):
         for _ in range(warmup):
@@ -120,16 +122,7 @@ def main():
         barrier()
         t_start = time.perf_counter()
         for i in range(steps):
-            # HIP events on the launch stream bracket the decoder kernels only
-            ev[i][0].record()
-            u_hat = dec(llr)
-            ev[i][1].record()
-            phy.utils.metrics.count_errors_into(u, u_hat, counters[:2])
-            counters[2] += u.numel()
-            counters[3] += B
-            if world > 1:
-                red = counters.clone()
-                dist.all_reduce(red, op=dist.ReduceOp.SUM)
+            step(dec, ev[i])
         barrier()
         t_wall = time.perf_counter() - t_start
         t = torch.tensor([t_wall], dtype=torch.float64, device=dev)
@@ -183,7 +176,7 @@ def main():
         "roofline": roofline,
     }
 
-    if args.also and args.also != args.cn_update:
+    if args.also and args.also != "none" and args.also != args.cn_update:
         dec2 = make_dec(args.also)
         steps2 = max(2, args.steps // 3)
         t2, ms2, c2 = run(dec2, steps2, 1)

@@ -136,6 +136,14 @@ int samd_qam_demap_f32(const float* y, const float* no, int64_t no_len, const fl
                        int m, int64_t num_symbols, int method, int hard_out, float* out,
                        void* stream);
 
+/* Same contract for a SQUARE QAM constellation whose label interleaves the bits of two
+ * identical PAM axes (qam() of mapping.py:44-118: even label bits -> real axis, odd ->
+ * imaginary): the per-bit sums factorise per axis, so only the 2^(m/2) PAM levels are needed.
+ * levels: DEVICE float[2^(m/2)], level of the PAM label j (MSB first), already normalised. */
+int samd_square_qam_demap_f32(const float* y, const float* no, int64_t no_len, const float* levels,
+                              int m, int64_t num_symbols, int method, int hard_out, float* out,
+                              void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Random sources and AWGN.  Counter-based Philox4x32-10 stream keyed by (seed, call);
  * executable specification: oracle/utils.py.

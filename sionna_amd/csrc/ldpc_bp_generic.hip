@@ -55,9 +55,9 @@ __device__ __forceinline__ float sgn3(float x) { return x > 0.f ? 1.f : (x < 0.f
 // agreement with the oracle - DESIGN.md "phi conditioning").
 __device__ __forceinline__ float phi_fast_f32(float x) {
   x = clampf(x, 8.5e-8f, 16.635532f);
-  if (x == 16.635532f) return 0.f;
   const float e = expf(x);
-  return logf(e + 1.f) - logf(e - 1.f);
+  const float r = logf(e + 1.f) - logf(e - 1.f);
+  return (x == 16.635532f) ? 0.f : r;                    // select, not a branch
 }
 
 // ---- check-node update on one batch column; v[0..d) in CN edge order, in place.

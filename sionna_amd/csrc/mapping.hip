@@ -88,6 +88,69 @@ __global__ __launch_bounds__(256) void demap_kernel(const float2* __restrict__ y
   }
 }
 
+// Square-QAM demapper.  For a QAM constellation whose label interleaves the bits of two
+// identical Gray-PAM axes (reference mapping.py:108-111: even label bits -> real axis, odd
+// -> imaginary), the sum over the 2^(m-1) points of C_{i,b} factorises into (sum over the
+// PAM levels with bit b on the bit's own axis) x (sum over ALL levels of the other axis);
+// the second factor is common to C_{i,1} and C_{i,0} and cancels in the LLR.  The kernel
+// therefore evaluates 2 x 2^(m/2) one-dimensional exponents per symbol instead of 2^m
+// two-dimensional ones (64-QAM: 16 distances and 48 exp instead of 64 and 768), which turns
+// the demapper from exp-bound into the streaming kernel it should be.  Same per-set
+// max-shifted logsumexp as the generic kernel; the cancellation is exact in real
+// arithmetic, so the result differs from the reference's 2-D evaluation only by float32
+// rounding (checked against the float64 oracle to the 1e-5 bar).
+template <int NB, bool MAXLOG>
+__global__ __launch_bounds__(256) void demap_square_qam_kernel(const float2* __restrict__ y,
+                                                               const float* __restrict__ no, int64_t no_len,
+                                                               const float* __restrict__ levels,
+                                                               int64_t num_symbols, int hard_out,
+                                                               float* __restrict__ out) {
+  constexpr int L = 1 << NB;               // PAM levels per axis
+  __shared__ float lev[L];
+  if (threadIdx.x < L) lev[threadIdx.x] = levels[threadIdx.x];
+  __syncthreads();
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < num_symbols;
+       s += (int64_t)gridDim.x * blockDim.x) {
+    const float2 ys = y[s];
+    const float n0 = fmaxf(no_len == 1 ? no[0] : no[s], 1.17549435e-38f);
+    float llr[2 * NB];
+#pragma unroll
+    for (int ax = 0; ax < 2; ++ax) {
+      const float ya = ax == 0 ? ys.x : ys.y;
+      float e[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) { const float d = ya - lev[j]; e[j] = -(d * d) / n0; }
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        float mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          if ((j >> (NB - 1 - t)) & 1) mx1 = fmaxf(mx1, e[j]); else mx0 = fmaxf(mx0, e[j]);
+        }
+        float r;
+        if constexpr (MAXLOG) {
+          r = mx1 - mx0;
+        } else {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < L; ++j) {
+            if ((j >> (NB - 1 - t)) & 1) s1 += expf(e[j] - mx1); else s0 += expf(e[j] - mx0);
+          }
+          r = (logf(s1) + mx1) - (logf(s0) + mx0);
+        }
+        llr[2 * t + ax] = r;
+      }
+    }
+    float* o = out + s * (2 * NB);
+#pragma unroll
+    for (int i = 0; i < 2 * NB; i += 2) {
+      float2 v = make_float2(llr[i], llr[i + 1]);
+      if (hard_out) v = make_float2(v.x > 0.f ? 1.f : 0.f, v.y > 0.f ? 1.f : 0.f);
+      *reinterpret_cast<float2*>(o + i) = v;              // 8 NB bytes per symbol: 8-byte aligned
+    }
+  }
+}
+
 template <bool MAXLOG>
 static int launch_demap(int m, dim3 grid, hipStream_t st, const float2* y, const float* no, int64_t no_len,
                         const float2* pts, int64_t ns, int hard, float* out) {
@@ -116,6 +179,26 @@ extern "C" int samd_qam_map_c64(const float* bits, const float* points, int m, i
   if (num_symbols == 0) return SAMD_OK;
   hipLaunchKernelGGL(qam_map_kernel, dim3(grid_for(num_symbols, 256)), dim3(256), sizeof(float2) << m,
                      (hipStream_t)stream, bits, (const float2*)points, m, num_symbols, (float2*)out_symbols);
+  return launch_status();
+}
+
+extern "C" int samd_square_qam_demap_f32(const float* y, const float* no, int64_t no_len, const float* levels,
+                                         int m, int64_t num_symbols, int method, int hard_out, float* out,
+                                         void* stream) {
+  SAMD_REQUIRE(y && no && levels && out, "null argument");
+  SAMD_REQUIRE(num_symbols >= 0 && (no_len == 1 || no_len == num_symbols), "no must be scalar or per symbol");
+  SAMD_REQUIRE(method == 0 || method == 1, "method must be 0 (app) or 1 (maxlog)");
+  SAMD_REQUIRE(m >= 2 && m <= 10 && m % 2 == 0, "square QAM needs an even m in 2..10");
+  if (num_symbols == 0) return SAMD_OK;
+  const dim3 grid(grid_for(num_symbols, 256));
+  hipStream_t st = (hipStream_t)stream;
+#define SAMD_SQ(NB)                                                                                              \
+  case NB:                                                                                                       \
+    if (method == 1) hipLaunchKernelGGL((demap_square_qam_kernel<NB, true>), grid, dim3(256), 0, st, (const float2*)y, no, no_len, levels, num_symbols, hard_out, out); \
+    else hipLaunchKernelGGL((demap_square_qam_kernel<NB, false>), grid, dim3(256), 0, st, (const float2*)y, no, no_len, levels, num_symbols, hard_out, out); \
+    break
+  switch (m / 2) { SAMD_SQ(1); SAMD_SQ(2); SAMD_SQ(3); SAMD_SQ(4); SAMD_SQ(5); }
+#undef SAMD_SQ
   return launch_status();
 }
 

@@ -157,6 +157,28 @@ class Constellation(Block):
                 x = x / np.sqrt(np.mean(np.abs(x) ** 2)).astype(x.real.dtype)
         return x.astype(self._points.dtype)
 
+    def pam_levels(self):
+        """Device float32[2^(m/2)] PAM levels if the constellation is a square QAM whose label
+        interleaves two identical PAM axes (true for ``qam()``), else None."""
+        if getattr(self, "_pam_valid", False) and self._dev is not None:
+            return self._pam_dev
+        self._pam_dev, self._pam_valid = None, True
+        m = self._num_bits_per_symbol
+        if m % 2 != 0:
+            return None
+        pts = self._host_points().astype(np.complex64)
+        nb = m // 2
+        idx = np.arange(2 ** m)
+        bits = (idx[:, None] >> np.arange(m - 1, -1, -1)) & 1
+        w = 1 << np.arange(nb - 1, -1, -1)
+        li, lq = bits[:, 0::2] @ w, bits[:, 1::2] @ w
+        lev = np.zeros(2 ** nb, np.float32)
+        lev[li] = pts.real                       # level of each I label (last write wins; checked below)
+        self.device_points()                     # (re)creates _dev, the cache-validity marker
+        if np.array_equal(lev[li], pts.real) and np.array_equal(lev[lq], pts.imag):
+            self._pam_dev = _ffi.to_device(lev, torch.float32)
+        return self._pam_dev
+
     def device_points(self):
         """Device copy (complex64) used by the kernels; rebuilt after a setter call."""
         if self._dev is None:
@@ -221,6 +243,9 @@ class Demapper(Block):
         assert demapping_method in ("app", "maxlog"), "Unknown demapping method"
         self._method = demapping_method
         self._hard_out = hard_out
+        # square-QAM fast path (per-axis evaluation); `separable=False` forces the generic
+        # 2^m-point kernel (used by the tests to cross-check the two)
+        self._separable = bool(kwargs.get("separable", True))
         self._constellation = Constellation.check_or_create(
             constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
             constellation=constellation, precision=precision)
@@ -239,6 +264,13 @@ class Demapper(Block):
         else:
             no = torch.broadcast_to(no, y.shape).contiguous()
         out = torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] * m,), dtype=torch.float32, device=y.device)
+        lev = self._constellation.pam_levels() if self._separable else None
+        if lev is not None:
+            _ffi.check(_ffi.lib().samd_square_qam_demap_f32(
+                _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(lev), m, y.numel(),
+                0 if self._method == "app" else 1, int(bool(self._hard_out)), _ffi.ptr(out), _ffi.stream()),
+                "Demapper")
+            return out
         _ffi.check(_ffi.lib().samd_qam_demap_f32(
             _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points()), m,
             y.numel(), 0 if self._method == "app" else 1, int(bool(self._hard_out)), _ffi.ptr(out),
