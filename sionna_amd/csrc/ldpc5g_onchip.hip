@@ -30,81 +30,100 @@ namespace samd {
 __device__ __forceinline__ unsigned f2u(float x) { return __float_as_uint(x); }
 __device__ __forceinline__ float u2f(unsigned x) { return __uint_as_float(x); }
 __device__ __forceinline__ unsigned bfi(unsigned mask, unsigned a, unsigned b) { return (a & mask) | (b & ~mask); }
+__device__ __forceinline__ float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
-// ---- one check node per lane: row of exact degree D
-template <int D, bool OFFSET>
-__device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned zz, unsigned z, int cn,
-                                       const float* __restrict__ xt, float2* __restrict__ m12,
-                                       unsigned* __restrict__ pk, float llr_max, float offset) {
+// Instruction selection follows the measured gfx950 issue rates (tools/ubench/valu_rate.hip):
+// v_add/v_sub/v_and/v_fma and v_cmp+v_cndmask run at the full rate, v_min/v_max/v_med3, shifts,
+// v_bfi and v_alignbit at half rate.  All LDS addressing is done in BYTES (no scaling shifts),
+// the modulo of the cyclic shift is an AND when Z is a power of two, the per-edge sign bits are
+// kept MSB-first so that "next edge" is one add (w += w) and collecting them is one
+// v_alignbit per edge.
+//
+// Check-node state: m12[cn] = (M1, M2) magnitudes after offset and clip; pk[cn] = position of
+// the unique minimum (bits 0-4) | sign of the c2v of edge i at bit 31-i.
+
+// (zz4 + s4) mod 4Z  /  (zz4 - s4) mod 4Z on byte offsets; zw = 4Z-1 (POW2) or 4Z
+template <bool POW2>
+__device__ __forceinline__ unsigned wrap_add(unsigned zz4, unsigned s4, unsigned zw) {
+  const unsigned t = zz4 + s4;
+  return POW2 ? (t & zw) : min(t, t - zw);
+}
+template <bool POW2>
+__device__ __forceinline__ unsigned wrap_sub(unsigned zz4, unsigned s4, unsigned zw) {
+  const unsigned t = zz4 - s4;
+  return POW2 ? (t & zw) : min(t, t + zw);
+}
+
+// ---- one check node per lane: row of exact degree D.  ent[i] = (c*Z*4) | (shift*4 << 18)
+template <int D, bool OFFSET, bool POW2>
+__device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned zz4, unsigned zw, unsigned cn4,
+                                       const char* __restrict__ xt_b, char* __restrict__ m12_b,
+                                       char* __restrict__ pk_b, float llr_max, float offset) {
   int e[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) e[i] = ent[i];
   float x[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    unsigned zi = zz + (unsigned)(e[i] >> 16);
-    zi = min(zi, zi - z);                                   // (zz + s) mod Z
-    x[i] = xt[(unsigned)(e[i] & 0xFFFF) + zi];
-  }
-  const float2 om = m12[cn];
-  const unsigned opk = pk[cn];
-  const int oidx = (int)(opk & 31u);
-  float min1 = INFINITY, min2 = INFINITY;
-  int idx = 0;
-  unsigned neg = 0;
+  for (int i = 0; i < D; ++i)
+    x[i] = *reinterpret_cast<const float*>(xt_b + (unsigned)(e[i] & 0x3FFFF) + wrap_add<POW2>(zz4, (unsigned)e[i] >> 18, zw));
+  const float2 om = *reinterpret_cast<const float2*>(m12_b + 2 * cn4);
+  unsigned w = *reinterpret_cast<const unsigned*>(pk_b + cn4);
+  const unsigned oidx = w & 31u;
+  float m1s = INFINITY, min2 = INFINITY;                    // m1s: the minimum WITH its sign (|.| is free)
+  unsigned idx = 0, neg = 0;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     // previous c2v of this edge from the compressed state, then v2c = clip(x_tot - c2v)
-    const float mag = (i == oidx) ? om.y : om.x;
-    const float c2v = u2f(bfi(0x80000000u, opk << (26 - i), f2u(mag)));
-    const float v2c = clampf(-1.f * c2v + x[i], -llr_max, llr_max);
-    neg |= (v2c < 0.f ? 1u : 0u) << i;                      // sign(+-0) := +1
-    const float a = fabsf(v2c);
-    idx = (a < min1) ? i : idx;
-    min2 = __builtin_amdgcn_fmed3f(min1, min2, a);          // second smallest, with multiplicity
-    min1 = fminf(min1, a);
+    const float mag = (oidx == (unsigned)i) ? om.y : om.x;
+    const float c2v = u2f((w & 0x80000000u) | f2u(mag));          // mag >= 0: one v_and_or
+    asm("v_add_u32 %0, %1, %1" : "=v"(w) : "v"(w));         // w += w at the full VALU rate (not a shift)
+    const float v2c = med3(x[i] - c2v, -llr_max, llr_max);
+    neg = __builtin_amdgcn_alignbit(neg, f2u(v2c), 31);     // (neg << 1) | sign(v2c); v2c is never -0
+    const bool lt = fabsf(v2c) < fabsf(m1s);
+    idx = lt ? (unsigned)i : idx;
+    min2 = med3(fabsf(m1s), min2, fabsf(v2c));              // second smallest, with multiplicity
+    m1s = lt ? v2c : m1s;
   }
+  const float min1 = fabsf(m1s);
   // unique minimum <=> min2 > min1; (min2 - min1) + min1 is the reference's arithmetic (:863)
   const float min_e = (min2 > min1) ? ((min2 - min1) + min1) : min1;
   float a1 = min1, a2 = min_e;
   if constexpr (OFFSET) { a1 -= offset; a2 -= offset; }
-  a1 = fminf(fmaxf(a1, 0.f), llr_max);
-  a2 = fminf(fmaxf(a2, 0.f), llr_max);
+  a1 = med3(a1, 0.f, llr_max);
+  a2 = med3(a2, 0.f, llr_max);
+  // neg holds sign(v2c_i) at bit D-1-i; own sign x node sign, then MSB-first
   const unsigned all = (1u << D) - 1u;
-  const unsigned sgn = (__popc(neg) & 1) ? (~neg & all) : neg;
-  m12[cn] = make_float2(a1, a2);
-  pk[cn] = (unsigned)idx | (sgn << 5);
+  neg = (__popc(neg) & 1) ? (neg ^ all) : neg;
+  *reinterpret_cast<float2*>(m12_b + 2 * cn4) = make_float2(a1, a2);
+  *reinterpret_cast<unsigned*>(pk_b + cn4) = idx | (neg << (32 - D));
 }
 
-// ---- one variable node per lane: column class of D slots (real edges first, then dummies)
-template <int D>
-__device__ __forceinline__ void vn_col(const int32_t* __restrict__ ent, unsigned zz, unsigned z, int vn,
-                                       float* __restrict__ xt, const float* __restrict__ llr,
-                                       const float2* __restrict__ m12, const unsigned* __restrict__ pk) {
-  int e[D];
+// ---- partial sum over D edge slots of one variable node per lane (real edges, then dummies).
+// ent[2i] = (r*Z*4) | (shift*4 << 18), ent[2i+1] = position of the edge inside its row
+template <int D, bool POW2>
+__device__ __forceinline__ float vn_part(const int32_t* __restrict__ ent, unsigned zz4, unsigned zw,
+                                         const char* __restrict__ m12_b, const char* __restrict__ pk_b, float x) {
+  int e0[D], e1[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) e[i] = ent[i];
+  for (int i = 0; i < D; ++i) { e0[i] = ent[2 * i]; e1[i] = ent[2 * i + 1]; }
   float2 m[D];
   unsigned q[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    unsigned zi = zz - (unsigned)((e[i] >> 16) & 0x1FF);
-    zi = min(zi, zi + z);                                   // (zz - s) mod Z
-    const unsigned cn = (unsigned)(e[i] & 0x7FFF) + zi;
-    m[i] = m12[cn];
-    q[i] = pk[cn];
+    const unsigned a4 = (unsigned)(e0[i] & 0x3FFFF) + wrap_sub<POW2>(zz4, (unsigned)e0[i] >> 18, zw);
+    m[i] = *reinterpret_cast<const float2*>(m12_b + 2 * a4);
+    q[i] = *reinterpret_cast<const unsigned*>(pk_b + a4);
   }
-  float x = 0.f;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    const unsigned pos = (unsigned)e[i] >> 25;
+    const unsigned pos = (unsigned)e1[i];
     const float mag = ((q[i] & 31u) == pos) ? m[i].y : m[i].x;
-    x += u2f(bfi(0x80000000u, q[i] << (26u - pos), f2u(mag)));    // ascending CN = edge order
+    x += u2f(((q[i] << pos) & 0x80000000u) | f2u(mag));     // ascending CN = edge order
   }
-  xt[vn] = x + llr[vn];                                     // unclipped x_tot (decoding.py:716)
+  return x;
 }
 
-template <bool OFFSET>
+template <bool OFFSET, bool POW2>
 __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, RateMatch p, int n_cn, int ncu, int nbu, int batch,
     int num_iter, float llr_max, float offset, int hard_out, int return_infobits,
@@ -115,12 +134,16 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NT = kDecWaves * 64;
   const unsigned z = (unsigned)p.z;
+  const unsigned zw = POW2 ? 4u * z - 1u : 4u * z;
   const int n_vn = p.n_vn;
   const int nx = nbu * (int)z, ns = (ncu + 1) * (int)z;
   float* xt = smem;
   float* llr = xt + nx;
   float2* m12 = reinterpret_cast<float2*>(llr + nx);
   unsigned* pk = reinterpret_cast<unsigned*>(m12 + ns);
+  const char* xt_b = reinterpret_cast<const char*>(xt);
+  char* m12_b = reinterpret_cast<char*>(m12);
+  char* pk_b = reinterpret_cast<char*>(pk);
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int c0 = cn_sched_ptr[w], c1 = cn_sched_ptr[w + 1];
@@ -129,8 +152,9 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
   for (int b = blockIdx.x; b < batch; b += gridDim.x) {
     const float* row = llr_in + (size_t)b * p.n;
     for (int v = tid; v < nx; v += NT) {
-      // decoding.py:552-565: clip, then logits -> LLR
-      const float l = (v < n_vn) ? -1.f * clampf(recover_llr(p, row, v, llr_max), -llr_max, llr_max) : 0.f;
+      // decoding.py:552-565: clip, then logits -> LLR; "+ 0.f" turns -0 into +0 (numerically the
+      // same LLR) so that the sign bit of every later v2c equals (v2c < 0)
+      const float l = (v < n_vn) ? (-1.f * clampf(recover_llr(p, row, v, llr_max), -llr_max, llr_max)) + 0.f : 0.f;
       llr[v] = l;
       xt[v] = l;
     }
@@ -141,12 +165,12 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
       for (int t = c0; t < c1; ++t) {
         const int desc = __builtin_amdgcn_readfirstlane(cn_sched[t]);
         const int r = desc & 0xFF;
-        const unsigned zz = (unsigned)((desc >> 8) * 64 + lane);
-        const int cn = r * (int)z + (int)zz;
+        const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
+        const unsigned cn = (unsigned)r * z + zz;
         const int32_t* ent = row_pad + r * kRowStride;
-        if (zz < z && cn < n_cn) {
-#define SAMD_CN(D) case D: cn_row<D, OFFSET>(ent, zz, z, cn, xt, m12, pk, llr_max, offset); break
-          switch (__builtin_amdgcn_readfirstlane(row_deg[r])) {
+        if (zz < z && cn < (unsigned)n_cn) {
+#define SAMD_CN(D) case D: cn_row<D, OFFSET, POW2>(ent, 4u * zz, zw, 4u * cn, xt_b, m12_b, pk_b, llr_max, offset); break
+          switch (desc >> 16) {
             SAMD_CN(3); SAMD_CN(4); SAMD_CN(5); SAMD_CN(6); SAMD_CN(7); SAMD_CN(8); SAMD_CN(9); SAMD_CN(10); SAMD_CN(19);
             default: break;
           }
@@ -157,17 +181,24 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
       for (int t = v0; t < v1; ++t) {
         const int desc = __builtin_amdgcn_readfirstlane(vn_sched[t]);
         const int c = desc & 0xFF;
-        const unsigned zz = (unsigned)((desc >> 8) * 64 + lane);
+        const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
         const int vn = c * (int)z + (int)zz;
-        const int32_t* ent = col_pad + c * kColStride;
+        const int32_t* ent = col_pad + c * (2 * kColStride);
+        const int nfull = (desc >> 16) & 0xF, rem = desc >> 20;
         if (zz < z && vn < n_vn) {
-#define SAMD_VN(D) case D: vn_col<D>(ent, zz, z, vn, xt, llr, m12, pk); break
-          switch (__builtin_amdgcn_readfirstlane(col_cls[c])) {
-            SAMD_VN(1); SAMD_VN(4); SAMD_VN(5); SAMD_VN(6); SAMD_VN(7); SAMD_VN(8); SAMD_VN(9); SAMD_VN(10);
-            SAMD_VN(12); SAMD_VN(14); SAMD_VN(16); SAMD_VN(24); SAMD_VN(30);
+          float x = 0.f;
+          for (int f = 0; f < nfull; ++f) {
+            x = vn_part<16, POW2>(ent, 4u * zz, zw, m12_b, pk_b, x);
+            ent += 32;
+          }
+#define SAMD_VN(D) case D: x = vn_part<D, POW2>(ent, 4u * zz, zw, m12_b, pk_b, x); break
+          switch (rem) {
+            SAMD_VN(1); SAMD_VN(2); SAMD_VN(3); SAMD_VN(4); SAMD_VN(5); SAMD_VN(6); SAMD_VN(7); SAMD_VN(8);
+            SAMD_VN(10); SAMD_VN(12); SAMD_VN(14);
             default: break;
           }
 #undef SAMD_VN
+          xt[vn] = x + llr[vn];                               // unclipped x_tot (decoding.py:716)
         }
       }
       __syncthreads();
@@ -191,7 +222,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
 }
 
 static const int kCnDegrees[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
-static const int kVnClasses[] = {1, 4, 5, 6, 7, 8, 9, 10, 12, 14, 16, 24, 30};
+static const int kVnRemClasses[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14};   // remainder after full chunks of 16
 
 // longest-processing-time-first assignment of items to the waves of the workgroup
 static void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, std::vector<int32_t>* ptr,
@@ -218,9 +249,10 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
   const int z = h->z;
   h->ncu = (h->n_cn + z - 1) / z;
   h->nbu = (h->n_vn + z - 1) / z;
-  bool ok = h->mb <= 255 && h->nb <= 255 && h->ncu * z + z <= 0x7FFF && h->nbu * z <= 0xFFFF;
+  // packed fields: byte offsets < 2^18, byte shifts < 2^11, row/col index < 256
+  bool ok = h->mb <= 255 && h->nb <= 255 && (h->ncu + 1) * z * 4 < (1 << 18) && h->nbu * z * 4 < (1 << 18);
   std::vector<int32_t> row_pad((size_t)h->mb * kRowStride, 0), row_deg(h->mb, 0);
-  std::vector<std::vector<int32_t>> cols(h->nb);
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> cols(h->nb);
   for (int r = 0; r < h->mb && ok; ++r) {
     const int d = (int)by_row[r].size();
     row_deg[r] = d;
@@ -228,30 +260,40 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
     if (d > kRowStride) { ok = false; break; }
     for (int i = 0; i < d; ++i) {
       const int c = by_row[r][i].first, s = by_row[r][i].second;
-      row_pad[(size_t)r * kRowStride + i] = (c * z) | (s << 16);
-      if (r < h->ncu) cols[c].push_back((r * z) | (s << 16) | (i << 25));   // rows ascending
+      row_pad[(size_t)r * kRowStride + i] = (c * z * 4) | ((s * 4) << 18);
+      if (r < h->ncu) cols[c].push_back({(r * z * 4) | ((s * 4) << 18), i});   // rows ascending
     }
   }
-  std::vector<int32_t> col_pad((size_t)h->nb * kColStride, 0), col_cls(h->nb, 1);
+  // column tables: 2 dwords per slot, full chunks of 16 slots then a remainder class
+  std::vector<int32_t> col_pad((size_t)h->nb * 2 * kColStride, 0), col_cls(h->nb, 0);
+  const int32_t dummy = h->ncu * z * 4;                       // zero "dummy check node" block, shift 0
   for (int c = 0; c < h->nb && ok; ++c) {
     const int d = (int)cols[c].size();
-    int cls = -1;
-    for (int k : kVnClasses) if (k >= d) { cls = k; break; }
-    if (cls < 0 || cls > kColStride) { ok = false; break; }
-    col_cls[c] = cls;
-    for (int i = 0; i < kColStride; ++i)
-      col_pad[(size_t)c * kColStride + i] = i < d ? cols[c][i] : (h->ncu * z);   // dummy CN block, s = pos = 0
+    const int nfull = d / 16, r0 = d % 16;
+    int rem = -1;
+    for (int k : kVnRemClasses) if (k >= r0) { rem = k; break; }
+    if (rem < 0 || nfull * 16 + rem > kColStride) { ok = false; break; }
+    col_cls[c] = nfull | (rem << 4);
+    for (int i = 0; i < kColStride; ++i) {
+      col_pad[((size_t)c * kColStride + i) * 2] = i < d ? cols[c][i].first : dummy;
+      col_pad[((size_t)c * kColStride + i) * 2 + 1] = i < d ? cols[c][i].second : 0;
+    }
   }
   h->v2_ok = ok ? 1 : 0;
   if (!ok) return SAMD_OK;
   const int chunks = (z + 63) / 64;
+  if (chunks > 255) { h->v2_ok = 0; return SAMD_OK; }
+  // item descriptors: CN  r | chunk<<8 | degree<<16 ;  VN  c | chunk<<8 | nfull<<16 | rem<<20
   std::vector<std::pair<int, int32_t>> ci, vi;
   for (int r = 0; r < h->ncu; ++r)
     for (int q = 0; q < chunks; ++q)
-      if (r * z + q * 64 < h->n_cn) ci.push_back({row_deg[r], r | (q << 8)});
+      if (r * z + q * 64 < h->n_cn) ci.push_back({row_deg[r], r | (q << 8) | (row_deg[r] << 16)});
   for (int c = 0; c < h->nbu; ++c)
     for (int q = 0; q < chunks; ++q)
-      if (c * z + q * 64 < h->n_vn) vi.push_back({col_cls[c], c | (q << 8)});
+      if (c * z + q * 64 < h->n_vn) {
+        const int nfull = col_cls[c] & 0xF, rem = col_cls[c] >> 4;
+        vi.push_back({nfull * 16 + rem, c | (q << 8) | (nfull << 16) | (rem << 20)});
+      }
   std::vector<int32_t> cp, cl, vp, vl;
   lpt_schedule(ci, &cp, &cl);
   lpt_schedule(vi, &vp, &vl);
@@ -279,11 +321,17 @@ int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int bat
     return SAMD_ERR_UNSUPPORTED;
   }
   const bool off = (cn_mode == SAMD_CN_OFFSET_MINSUM);
-  const void* fn = off ? (const void*)ldpc5g_decode_v2_kernel<true> : (const void*)ldpc5g_decode_v2_kernel<false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[off]) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[off] = true;
+  const bool pow2 = (h->z & (h->z - 1)) == 0;
+  typedef void (*kern_t)(const float*, float*, RateMatch, int, int, int, int, int, float, float, int, int,
+                         const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                         const int32_t*, const int32_t*, const int32_t*);
+  static const kern_t kerns[4] = {ldpc5g_decode_v2_kernel<false, false>, ldpc5g_decode_v2_kernel<false, true>,
+                                  ldpc5g_decode_v2_kernel<true, false>, ldpc5g_decode_v2_kernel<true, true>};
+  const int ki = (off ? 2 : 0) | (pow2 ? 1 : 0);
+  static bool attr_set[4] = {false, false, false, false};
+  if (!attr_set[ki]) {
+    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[ki] = true;
   }
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
@@ -291,12 +339,9 @@ int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const size_t per_cu = std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
   const int grid = (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
-#define SAMD_V2_ARGS llr, out, rm, h->n_cn, h->ncu, h->nbu, batch, num_iter, llr_max, (off ? offset : 0.f), hard_out, \
-                     return_infobits, h->row_pad, h->row_deg, h->col_pad, h->col_cls, h->cn_sched_ptr, h->cn_sched,  \
-                     h->vn_sched_ptr, h->vn_sched
-  if (off) hipLaunchKernelGGL(ldpc5g_decode_v2_kernel<true>, dim3(grid), dim3(kDecWaves * 64), lds, st, SAMD_V2_ARGS);
-  else hipLaunchKernelGGL(ldpc5g_decode_v2_kernel<false>, dim3(grid), dim3(kDecWaves * 64), lds, st, SAMD_V2_ARGS);
-#undef SAMD_V2_ARGS
+  hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(kDecWaves * 64), lds, st, llr, out, rm, h->n_cn, h->ncu, h->nbu, batch,
+                     num_iter, llr_max, (off ? offset : 0.f), hard_out, return_infobits, h->row_pad, h->row_deg,
+                     h->col_pad, h->col_cls, h->cn_sched_ptr, h->cn_sched, h->vn_sched_ptr, h->vn_sched);
   return launch_status();
 }
 

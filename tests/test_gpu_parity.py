@@ -278,8 +278,8 @@ def test_5g_boxplus_vs_oracle(phy, k, n, bg, m, cn):
 
 
 def test_5g_large_z_falls_back_to_generic(phy):
-    # Z=384: does not fit in LDS -> generic engine, still bit-exact
-    k, n = 8448, 12354
+    # Z=384, rate 1/3: does not fit in LDS -> generic engine, still bit-exact
+    k, n = 8448, 25344
     code = LDPC5GCode(k, n)
     enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
     u, c, llr = _noisy_llr(code, 3, 1, sigma=0.5)
