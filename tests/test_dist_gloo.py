@@ -1,0 +1,80 @@
+"""World-size-2 tests of the data-parallel sim_ber path on CPU (gloo backend).
+
+On the GPU node the same code runs with backend nccl (= RCCL over xGMI); the only collective of
+the path is the SUM all-reduce of four int64 error counters."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sionna_amd.phy.utils import sim_ber
+    from sionna_amd.phy.config import PhiloxGenerator
+    from oracle import utils as outil
+
+    gen = PhiloxGenerator(1234)            # rank comes from the environment
+    calls = []
+
+    def mc_fun(batch_size, ebno_db):
+        # error injector on the rank's own random stream (host tensors): bit error probability
+        # 1/16 below 3 dB, 0 above
+        calls.append(float(ebno_db))
+        n = batch_size * 100
+        u = outil.random_bits(gen.seed, gen.next_call(), n).reshape(batch_size, 100)
+        flip = outil.random_bits(gen.seed, gen.next_call(), 4 * n).reshape(4, batch_size, 100)
+        err = (flip.sum(0) == 4).astype(np.float32) if ebno_db < 3 else np.zeros_like(u)
+        return torch.from_numpy(u), torch.from_numpy(np.abs(u - err).astype(np.float32))
+
+    ber, bler = sim_ber(mc_fun, np.array([0.0, 6.0, 20.0]), batch_size=50, max_mc_iter=8, distribute="all",
+                        verbose=False, early_stop=False)
+    single_calls = len(calls)
+    # a rule that needs per-iteration counters: stop after >= 300 bit errors (global)
+    calls.clear()
+    ber2, _ = sim_ber(mc_fun, np.array([0.0]), batch_size=50, max_mc_iter=100, num_target_bit_errors=300,
+                      distribute="all", verbose=False)
+    q.put((rank, ber.numpy().tolist(), bler.numpy().tolist(), single_calls, len(calls), gen.seed,
+           ber2.numpy().tolist()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sim_ber_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, ber0, bler0, n0, m0, seed0, b20), (r1, ber1, bler1, n1, m1, seed1, b21) = res
+    # identical, globally reduced results on both ranks
+    assert ber0 == ber1 and bler0 == bler1 and b20 == b21
+    # max_mc_iter is divided by the number of replicas (misc.py:651-655): 3 SNR points x 4 iterations
+    assert n0 == n1 == 12
+    # distinct random streams per rank (test_utils.py:112-127 requirement)
+    assert seed0 != seed1 and seed0 == 1234
+    # BER ~ 1/16 at 0 dB, exact zero at 6 and 20 dB
+    assert abs(ber0[0] - 1 / 16) < 0.01 and ber0[1] == 0.0 and ber0[2] == 0.0
+    # early stop on the GLOBAL counter: 300 errors need ~300/(1/16*5000*2) -> 1 iteration per rank
+    assert m0 == m1 and m0 <= 2
