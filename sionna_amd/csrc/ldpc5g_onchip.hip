@@ -55,17 +55,27 @@ __device__ __forceinline__ unsigned wrap_sub(unsigned zz4, unsigned s4, unsigned
 }
 
 // ---- one check node per lane: row of exact degree D.  ent[i] = (c*Z*4) | (shift*4 << 18)
-template <int D, bool OFFSET, bool POW2>
+// FUSE1: the row's last edge goes to a degree-1 variable node of the same lane (the identity
+// block of the base graph's extension part, shift 0).  Its total x_tot = c2v + llr is formed here
+// from the row's own state instead of by a VN-phase item - same arithmetic ((0 + c2v) + llr), no
+// LDS round trip: 42 of BG1's 68 columns (13 % of the edges, 62 % of the VN work items) vanish
+// from the VN phase.
+template <int D, bool OFFSET, bool POW2, bool FUSE1>
 __device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned zz4, unsigned zw, unsigned cn4,
-                                       const char* __restrict__ xt_b, char* __restrict__ m12_b,
-                                       char* __restrict__ pk_b, float llr_max, float offset) {
+                                       const char* __restrict__ xt_b, const char* __restrict__ llr_b,
+                                       char* __restrict__ m12_b, char* __restrict__ pk_b, float llr_max,
+                                       float offset) {
   int e[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) e[i] = ent[i];
   float x[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i)
-    x[i] = *reinterpret_cast<const float*>(xt_b + (unsigned)(e[i] & 0x3FFFF) + wrap_add<POW2>(zz4, (unsigned)e[i] >> 18, zw));
+  for (int i = 0; i < D; ++i) {
+    if (FUSE1 && i == D - 1)
+      x[i] = *reinterpret_cast<const float*>(llr_b + (unsigned)(e[i] & 0x3FFFF) + zz4);   // channel LLR of the VN
+    else
+      x[i] = *reinterpret_cast<const float*>(xt_b + (unsigned)(e[i] & 0x3FFFF) + wrap_add<POW2>(zz4, (unsigned)e[i] >> 18, zw));
+  }
   const float2 om = *reinterpret_cast<const float2*>(m12_b + 2 * cn4);
   unsigned w = *reinterpret_cast<const unsigned*>(pk_b + cn4);
   const unsigned oidx = w & 31u;
@@ -77,7 +87,8 @@ __device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned
     const float mag = (oidx == (unsigned)i) ? om.y : om.x;
     const float c2v = u2f((w & 0x80000000u) | f2u(mag));          // mag >= 0: one v_and_or
     asm("v_add_u32 %0, %1, %1" : "=v"(w) : "v"(w));         // w += w at the full VALU rate (not a shift)
-    const float v2c = med3(x[i] - c2v, -llr_max, llr_max);
+    const float xi = (FUSE1 && i == D - 1) ? c2v + x[i] : x[i];   // x_tot of the fused degree-1 VN
+    const float v2c = med3(xi - c2v, -llr_max, llr_max);
     neg = __builtin_amdgcn_alignbit(neg, f2u(v2c), 31);     // (neg << 1) | sign(v2c); v2c is never -0
     const bool lt = fabsf(v2c) < fabsf(m1s);
     idx = lt ? (unsigned)i : idx;
@@ -142,6 +153,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
   float2* m12 = reinterpret_cast<float2*>(llr + nx);
   unsigned* pk = reinterpret_cast<unsigned*>(m12 + ns);
   const char* xt_b = reinterpret_cast<const char*>(xt);
+  const char* llr_b = reinterpret_cast<const char*>(llr);
   char* m12_b = reinterpret_cast<char*>(m12);
   char* pk_b = reinterpret_cast<char*>(pk);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -169,16 +181,25 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
         const unsigned cn = (unsigned)r * z + zz;
         const int32_t* ent = row_pad + r * kRowStride;
         if (zz < z && cn < (unsigned)n_cn) {
-#define SAMD_CN(D) case D: cn_row<D, OFFSET, POW2>(ent, 4u * zz, zw, 4u * cn, xt_b, m12_b, pk_b, llr_max, offset); break
-          switch (desc >> 16) {
-            SAMD_CN(3); SAMD_CN(4); SAMD_CN(5); SAMD_CN(6); SAMD_CN(7); SAMD_CN(8); SAMD_CN(9); SAMD_CN(10); SAMD_CN(19);
-            default: break;
+#define SAMD_CN(D, F) case D: cn_row<D, OFFSET, POW2, F>(ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset); break
+          if ((desc >> 24) & 1) {                            // last edge fused with its degree-1 VN
+            switch ((desc >> 16) & 0xFF) {
+              SAMD_CN(3, true); SAMD_CN(4, true); SAMD_CN(5, true); SAMD_CN(6, true); SAMD_CN(7, true);
+              SAMD_CN(8, true); SAMD_CN(9, true); SAMD_CN(10, true);
+              default: break;
+            }
+          } else {
+            switch ((desc >> 16) & 0xFF) {
+              SAMD_CN(3, false); SAMD_CN(4, false); SAMD_CN(5, false); SAMD_CN(6, false); SAMD_CN(7, false);
+              SAMD_CN(8, false); SAMD_CN(9, false); SAMD_CN(10, false); SAMD_CN(19, false);
+              default: break;
+            }
           }
 #undef SAMD_CN
         }
       }
       __syncthreads();
-      for (int t = v0; t < v1; ++t) {
+      for (int t = v0; t < v1; ++t) {                        // columns of degree >= 2 (and unfused ones)
         const int desc = __builtin_amdgcn_readfirstlane(vn_sched[t]);
         const int c = desc & 0xFF;
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
@@ -200,6 +221,18 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
 #undef SAMD_VN
           xt[vn] = x + llr[vn];                               // unclipped x_tot (decoding.py:716)
         }
+      }
+      __syncthreads();
+    }
+    if (!return_infobits) {
+      // totals of the fused degree-1 VNs are only needed for the codeword output: one class-1 pass
+      for (int t = vn_sched_ptr[kDecWaves + 1 + w]; t < vn_sched_ptr[kDecWaves + 2 + w]; ++t) {
+        const int desc = __builtin_amdgcn_readfirstlane(vn_sched[t]);
+        const int c = desc & 0xFF;
+        const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
+        const int vn = c * (int)z + (int)zz;
+        if (zz < z && vn < n_vn)
+          xt[vn] = vn_part<1, POW2>(col_pad + c * (2 * kColStride), 4u * zz, zw, m12_b, pk_b, 0.f) + llr[vn];
       }
       __syncthreads();
     }
@@ -283,20 +316,34 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
   if (!ok) return SAMD_OK;
   const int chunks = (z + 63) / 64;
   if (chunks > 255) { h->v2_ok = 0; return SAMD_OK; }
-  // item descriptors: CN  r | chunk<<8 | degree<<16 ;  VN  c | chunk<<8 | nfull<<16 | rem<<20
-  std::vector<std::pair<int, int32_t>> ci, vi;
+  // rows whose last edge is the only edge of its column, with shift 0 and degree 3..10: that
+  // degree-1 VN is handled inside the CN phase (cn_row<..., FUSE1>)
+  std::vector<char> row_fused(h->mb, 0), col_fused(h->nb, 0);
+  for (int r = 0; r < h->ncu; ++r) {
+    const int d = row_deg[r];
+    const int c = by_row[r][d - 1].first, s = by_row[r][d - 1].second;
+    if (cols[c].size() == 1 && s == 0 && d >= 3 && d <= 10) { row_fused[r] = 1; col_fused[c] = 1; }
+  }
+  // item descriptors: CN  r | chunk<<8 | degree<<16 | fused<<24 ;  VN  c | chunk<<8 | nfull<<16 | rem<<20
+  std::vector<std::pair<int, int32_t>> ci, vi, v1i;
   for (int r = 0; r < h->ncu; ++r)
     for (int q = 0; q < chunks; ++q)
-      if (r * z + q * 64 < h->n_cn) ci.push_back({row_deg[r], r | (q << 8) | (row_deg[r] << 16)});
+      if (r * z + q * 64 < h->n_cn) ci.push_back({row_deg[r], r | (q << 8) | (row_deg[r] << 16) | (row_fused[r] << 24)});
   for (int c = 0; c < h->nbu; ++c)
     for (int q = 0; q < chunks; ++q)
       if (c * z + q * 64 < h->n_vn) {
         const int nfull = col_cls[c] & 0xF, rem = col_cls[c] >> 4;
-        vi.push_back({nfull * 16 + rem, c | (q << 8) | (nfull << 16) | (rem << 20)});
+        if (col_fused[c]) v1i.push_back({1, c | (q << 8)});
+        else vi.push_back({nfull * 16 + rem, c | (q << 8) | (nfull << 16) | (rem << 20)});
       }
-  std::vector<int32_t> cp, cl, vp, vl;
+  // vn_sched_ptr = [16+1 offsets of the per-iteration lists | 16+1 offsets of the final degree-1 pass]
+  std::vector<int32_t> cp, cl, vp, vl, v1p, v1l;
   lpt_schedule(ci, &cp, &cl);
   lpt_schedule(vi, &vp, &vl);
+  lpt_schedule(v1i, &v1p, &v1l);
+  for (int32_t o : v1p) vp.push_back(o + (int32_t)vl.size());
+  vl.insert(vl.end(), v1l.begin(), v1l.end());
+  if (vl.empty()) vl.push_back(0);
   int rc = upload(&h->row_pad, row_pad.data(), row_pad.size());
   if (rc == SAMD_OK) rc = upload(&h->row_deg, row_deg.data(), row_deg.size());
   if (rc == SAMD_OK) rc = upload(&h->col_pad, col_pad.data(), col_pad.size());
