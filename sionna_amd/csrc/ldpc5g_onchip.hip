@@ -60,7 +60,10 @@ __device__ __forceinline__ unsigned wrap_sub(unsigned zz4, unsigned s4, unsigned
 // from the row's own state instead of by a VN-phase item - same arithmetic ((0 + c2v) + llr), no
 // LDS round trip: 42 of BG1's 68 columns (13 % of the edges, 62 % of the VN work items) vanish
 // from the VN phase.
-template <int D, bool OFFSET, bool POW2, bool FUSE1>
+// NCH: number of consecutive 64-lane chunks of lifted copies handled by the wave in one pass
+// (lane z and lane z+64 share every scalar): two independent dependency chains per wave hide
+// LDS latency at 4 waves / SIMD and halve the per-item scalar work.
+template <int D, int NCH, bool OFFSET, bool POW2, bool FUSE1>
 __device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned zz4, unsigned zw, unsigned cn4,
                                        const char* __restrict__ xt_b, const char* __restrict__ llr_b,
                                        char* __restrict__ m12_b, char* __restrict__ pk_b, float llr_max,
@@ -68,70 +71,135 @@ __device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned
   int e[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) e[i] = ent[i];
-  float x[D];
+  float x[NCH][D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    if (FUSE1 && i == D - 1)
-      x[i] = *reinterpret_cast<const float*>(llr_b + (unsigned)(e[i] & 0x3FFFF) + zz4);   // channel LLR of the VN
-    else
-      x[i] = *reinterpret_cast<const float*>(xt_b + (unsigned)(e[i] & 0x3FFFF) + wrap_add<POW2>(zz4, (unsigned)e[i] >> 18, zw));
-  }
-  const float2 om = *reinterpret_cast<const float2*>(m12_b + 2 * cn4);
-  unsigned w = *reinterpret_cast<const unsigned*>(pk_b + cn4);
-  const unsigned oidx = w & 31u;
-  float m1s = INFINITY, min2 = INFINITY;                    // m1s: the minimum WITH its sign (|.| is free)
-  unsigned idx = 0, neg = 0;
+  for (int i = 0; i < D; ++i)
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    // previous c2v of this edge from the compressed state, then v2c = clip(x_tot - c2v)
-    const float mag = (oidx == (unsigned)i) ? om.y : om.x;
-    const float c2v = u2f((w & 0x80000000u) | f2u(mag));          // mag >= 0: one v_and_or
-    asm("v_add_u32 %0, %1, %1" : "=v"(w) : "v"(w));         // w += w at the full VALU rate (not a shift)
-    const float xi = (FUSE1 && i == D - 1) ? c2v + x[i] : x[i];   // x_tot of the fused degree-1 VN
-    const float v2c = med3(xi - c2v, -llr_max, llr_max);
-    neg = __builtin_amdgcn_alignbit(neg, f2u(v2c), 31);     // (neg << 1) | sign(v2c); v2c is never -0
-    const bool lt = fabsf(v2c) < fabsf(m1s);
-    idx = lt ? (unsigned)i : idx;
-    min2 = med3(fabsf(m1s), min2, fabsf(v2c));              // second smallest, with multiplicity
-    m1s = lt ? v2c : m1s;
+    for (int h = 0; h < NCH; ++h) {
+      if (FUSE1 && i == D - 1)                              // channel LLR of the fused degree-1 VN
+        x[h][i] = *reinterpret_cast<const float*>(llr_b + (unsigned)(e[i] & 0x3FFFF) + zz4 + 256u * h);
+      else
+        x[h][i] = *reinterpret_cast<const float*>(xt_b + (unsigned)(e[i] & 0x3FFFF) +
+                                                  wrap_add<POW2>(zz4 + 256u * h, (unsigned)e[i] >> 18, zw));
+    }
+  float2 om[NCH];
+  unsigned w[NCH], oidx[NCH], idx[NCH], neg[NCH];
+  float m1s[NCH], min2[NCH];                                // m1s: the minimum WITH its sign (|.| is free)
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    om[h] = *reinterpret_cast<const float2*>(m12_b + 2 * (cn4 + 256u * h));
+    w[h] = *reinterpret_cast<const unsigned*>(pk_b + cn4 + 256u * h);
+    oidx[h] = w[h] & 31u;
+    m1s[h] = INFINITY; min2[h] = INFINITY; idx[h] = 0; neg[h] = 0;
   }
-  const float min1 = fabsf(m1s);
-  // unique minimum <=> min2 > min1; (min2 - min1) + min1 is the reference's arithmetic (:863)
-  const float min_e = (min2 > min1) ? ((min2 - min1) + min1) : min1;
-  float a1 = min1, a2 = min_e;
-  if constexpr (OFFSET) { a1 -= offset; a2 -= offset; }
-  a1 = med3(a1, 0.f, llr_max);
-  a2 = med3(a2, 0.f, llr_max);
-  // neg holds sign(v2c_i) at bit D-1-i; own sign x node sign, then MSB-first
-  const unsigned all = (1u << D) - 1u;
-  neg = (__popc(neg) & 1) ? (neg ^ all) : neg;
-  *reinterpret_cast<float2*>(m12_b + 2 * cn4) = make_float2(a1, a2);
-  *reinterpret_cast<unsigned*>(pk_b + cn4) = idx | (neg << (32 - D));
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      // previous c2v of this edge from the compressed state, then v2c = clip(x_tot - c2v)
+      const float mag = (oidx[h] == (unsigned)i) ? om[h].y : om[h].x;
+      const float c2v = u2f((w[h] & 0x80000000u) | f2u(mag));     // mag >= 0: one v_and_or
+      asm("v_add_u32 %0, %1, %1" : "=v"(w[h]) : "v"(w[h]));       // w += w at the full VALU rate (not a shift)
+      const float xi = (FUSE1 && i == D - 1) ? c2v + x[h][i] : x[h][i];   // x_tot of the fused degree-1 VN
+      const float v2c = med3(xi - c2v, -llr_max, llr_max);
+      neg[h] = __builtin_amdgcn_alignbit(neg[h], f2u(v2c), 31);   // (neg << 1) | sign(v2c); v2c is never -0
+      const bool lt = fabsf(v2c) < fabsf(m1s[h]);
+      idx[h] = lt ? (unsigned)i : idx[h];
+      min2[h] = med3(fabsf(m1s[h]), min2[h], fabsf(v2c));         // second smallest, with multiplicity
+      m1s[h] = lt ? v2c : m1s[h];
+    }
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    const float min1 = fabsf(m1s[h]);
+    // unique minimum <=> min2 > min1; (min2 - min1) + min1 is the reference's arithmetic (:863)
+    const float min_e = (min2[h] > min1) ? ((min2[h] - min1) + min1) : min1;
+    float a1 = min1, a2 = min_e;
+    if constexpr (OFFSET) { a1 -= offset; a2 -= offset; }
+    a1 = med3(a1, 0.f, llr_max);
+    a2 = med3(a2, 0.f, llr_max);
+    // neg holds sign(v2c_i) at bit D-1-i; own sign x node sign, then MSB-first
+    const unsigned all = (1u << D) - 1u;
+    const unsigned sg = (__popc(neg[h]) & 1) ? (neg[h] ^ all) : neg[h];
+    *reinterpret_cast<float2*>(m12_b + 2 * (cn4 + 256u * h)) = make_float2(a1, a2);
+    *reinterpret_cast<unsigned*>(pk_b + cn4 + 256u * h) = idx[h] | (sg << (32 - D));
+  }
 }
 
-// ---- partial sum over D edge slots of one variable node per lane (real edges, then dummies).
+// ---- partial sums over D edge slots of NCH variable nodes per lane (real edges, then dummies).
 // ent[2i] = (r*Z*4) | (shift*4 << 18), ent[2i+1] = position of the edge inside its row
-template <int D, bool POW2>
-__device__ __forceinline__ float vn_part(const int32_t* __restrict__ ent, unsigned zz4, unsigned zw,
-                                         const char* __restrict__ m12_b, const char* __restrict__ pk_b, float x) {
+template <int D, int NCH, bool POW2>
+__device__ __forceinline__ void vn_part(const int32_t* __restrict__ ent, unsigned zz4, unsigned zw,
+                                        const char* __restrict__ m12_b, const char* __restrict__ pk_b,
+                                        float (&x)[NCH]) {
   int e0[D], e1[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) { e0[i] = ent[2 * i]; e1[i] = ent[2 * i + 1]; }
-  float2 m[D];
-  unsigned q[D];
+  float2 m[NCH][D];
+  unsigned q[NCH][D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const unsigned a4 = (unsigned)(e0[i] & 0x3FFFF) + wrap_sub<POW2>(zz4, (unsigned)e0[i] >> 18, zw);
-    m[i] = *reinterpret_cast<const float2*>(m12_b + 2 * a4);
-    q[i] = *reinterpret_cast<const unsigned*>(pk_b + a4);
-  }
+  for (int i = 0; i < D; ++i)
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const unsigned pos = (unsigned)e1[i];
-    const float mag = ((q[i] & 31u) == pos) ? m[i].y : m[i].x;
-    x += u2f(((q[i] << pos) & 0x80000000u) | f2u(mag));     // ascending CN = edge order
+    for (int h = 0; h < NCH; ++h) {
+      const unsigned a4 = (unsigned)(e0[i] & 0x3FFFF) + wrap_sub<POW2>(zz4 + 256u * h, (unsigned)e0[i] >> 18, zw);
+      m[h][i] = *reinterpret_cast<const float2*>(m12_b + 2 * a4);
+      q[h][i] = *reinterpret_cast<const unsigned*>(pk_b + a4);
+    }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const unsigned pos = (unsigned)e1[i];
+      const float mag = ((q[h][i] & 31u) == pos) ? m[h][i].y : m[h][i].x;
+      x[h] += u2f(((q[h][i] << pos) & 0x80000000u) | f2u(mag));    // ascending CN = edge order
+    }
+}
+
+// one VN work item: column c, NCH chunks starting at lane offset zz
+template <int NCH, bool POW2>
+__device__ __forceinline__ void vn_item(const int32_t* __restrict__ ent, int nfull, int rem, unsigned zz4,
+                                        unsigned zw, unsigned vn4, float* __restrict__ xt,
+                                        const float* __restrict__ llr, const char* __restrict__ m12_b,
+                                        const char* __restrict__ pk_b) {
+  float x[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) x[h] = 0.f;
+  for (int f = 0; f < nfull; ++f) {
+    vn_part<16, NCH, POW2>(ent, zz4, zw, m12_b, pk_b, x);
+    ent += 32;
   }
-  return x;
+#define SAMD_VN(D) case D: vn_part<D, NCH, POW2>(ent, zz4, zw, m12_b, pk_b, x); break
+  switch (rem) {
+    SAMD_VN(1); SAMD_VN(2); SAMD_VN(3); SAMD_VN(4); SAMD_VN(5); SAMD_VN(6); SAMD_VN(7); SAMD_VN(8);
+    SAMD_VN(10); SAMD_VN(12); SAMD_VN(14);
+    default: break;
+  }
+#undef SAMD_VN
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    const unsigned v = (vn4 >> 2) + 64u * h;
+    xt[v] = x[h] + llr[v];                                  // unclipped x_tot (decoding.py:716)
+  }
+}
+
+template <int NCH, bool OFFSET, bool POW2>
+__device__ __forceinline__ void cn_item(int desc, const int32_t* __restrict__ ent, unsigned zz4, unsigned zw,
+                                        unsigned cn4, const char* xt_b, const char* llr_b, char* m12_b, char* pk_b,
+                                        float llr_max, float offset) {
+#define SAMD_CN(D, F) case D: cn_row<D, NCH, OFFSET, POW2, F>(ent, zz4, zw, cn4, xt_b, llr_b, m12_b, pk_b, llr_max, offset); break
+  if ((desc >> 24) & 1) {                                   // last edge fused with its degree-1 VN
+    switch ((desc >> 16) & 0xFF) {
+      SAMD_CN(3, true); SAMD_CN(4, true); SAMD_CN(5, true); SAMD_CN(6, true); SAMD_CN(7, true);
+      SAMD_CN(8, true); SAMD_CN(9, true); SAMD_CN(10, true);
+      default: break;
+    }
+  } else {
+    switch ((desc >> 16) & 0xFF) {
+      SAMD_CN(3, false); SAMD_CN(4, false); SAMD_CN(5, false); SAMD_CN(6, false); SAMD_CN(7, false);
+      SAMD_CN(8, false); SAMD_CN(9, false); SAMD_CN(10, false); SAMD_CN(19, false);
+      default: break;
+    }
+  }
+#undef SAMD_CN
 }
 
 template <bool OFFSET, bool POW2>
@@ -175,51 +243,31 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
 
     for (int it = 0; it < num_iter; ++it) {
       for (int t = c0; t < c1; ++t) {
+        // desc: r | chunk<<8 | degree<<16 | fused<<24 | pair<<25  (pair: chunks q and q+1, all lanes valid)
         const int desc = __builtin_amdgcn_readfirstlane(cn_sched[t]);
         const int r = desc & 0xFF;
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
         const unsigned cn = (unsigned)r * z + zz;
         const int32_t* ent = row_pad + r * kRowStride;
-        if (zz < z && cn < (unsigned)n_cn) {
-#define SAMD_CN(D, F) case D: cn_row<D, OFFSET, POW2, F>(ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset); break
-          if ((desc >> 24) & 1) {                            // last edge fused with its degree-1 VN
-            switch ((desc >> 16) & 0xFF) {
-              SAMD_CN(3, true); SAMD_CN(4, true); SAMD_CN(5, true); SAMD_CN(6, true); SAMD_CN(7, true);
-              SAMD_CN(8, true); SAMD_CN(9, true); SAMD_CN(10, true);
-              default: break;
-            }
-          } else {
-            switch ((desc >> 16) & 0xFF) {
-              SAMD_CN(3, false); SAMD_CN(4, false); SAMD_CN(5, false); SAMD_CN(6, false); SAMD_CN(7, false);
-              SAMD_CN(8, false); SAMD_CN(9, false); SAMD_CN(10, false); SAMD_CN(19, false);
-              default: break;
-            }
-          }
-#undef SAMD_CN
+        if ((desc >> 25) & 1) {
+          cn_item<2, OFFSET, POW2>(desc, ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset);
+        } else if (zz < z && cn < (unsigned)n_cn) {
+          cn_item<1, OFFSET, POW2>(desc, ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset);
         }
       }
       __syncthreads();
       for (int t = v0; t < v1; ++t) {                        // columns of degree >= 2 (and unfused ones)
+        // desc: c | chunk<<8 | nfull<<16 | rem<<20 | pair<<25
         const int desc = __builtin_amdgcn_readfirstlane(vn_sched[t]);
         const int c = desc & 0xFF;
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
-        const int vn = c * (int)z + (int)zz;
+        const unsigned vn = (unsigned)c * z + zz;
         const int32_t* ent = col_pad + c * (2 * kColStride);
-        const int nfull = (desc >> 16) & 0xF, rem = desc >> 20;
-        if (zz < z && vn < n_vn) {
-          float x = 0.f;
-          for (int f = 0; f < nfull; ++f) {
-            x = vn_part<16, POW2>(ent, 4u * zz, zw, m12_b, pk_b, x);
-            ent += 32;
-          }
-#define SAMD_VN(D) case D: x = vn_part<D, POW2>(ent, 4u * zz, zw, m12_b, pk_b, x); break
-          switch (rem) {
-            SAMD_VN(1); SAMD_VN(2); SAMD_VN(3); SAMD_VN(4); SAMD_VN(5); SAMD_VN(6); SAMD_VN(7); SAMD_VN(8);
-            SAMD_VN(10); SAMD_VN(12); SAMD_VN(14);
-            default: break;
-          }
-#undef SAMD_VN
-          xt[vn] = x + llr[vn];                               // unclipped x_tot (decoding.py:716)
+        const int nfull = (desc >> 16) & 0xF, rem = (desc >> 20) & 0x1F;
+        if ((desc >> 25) & 1) {
+          vn_item<2, POW2>(ent, nfull, rem, 4u * zz, zw, 4u * vn, xt, llr, m12_b, pk_b);
+        } else if (zz < z && vn < (unsigned)n_vn) {
+          vn_item<1, POW2>(ent, nfull, rem, 4u * zz, zw, 4u * vn, xt, llr, m12_b, pk_b);
         }
       }
       __syncthreads();
@@ -231,8 +279,11 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
         const int c = desc & 0xFF;
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
         const int vn = c * (int)z + (int)zz;
-        if (zz < z && vn < n_vn)
-          xt[vn] = vn_part<1, POW2>(col_pad + c * (2 * kColStride), 4u * zz, zw, m12_b, pk_b, 0.f) + llr[vn];
+        if (zz < z && vn < n_vn) {
+          float x1[1] = {0.f};
+          vn_part<1, 1, POW2>(col_pad + c * (2 * kColStride), 4u * zz, zw, m12_b, pk_b, x1);
+          xt[vn] = x1[0] + llr[vn];
+        }
       }
       __syncthreads();
     }
@@ -325,17 +376,27 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
     if (cols[c].size() == 1 && s == 0 && d >= 3 && d <= 10) { row_fused[r] = 1; col_fused[c] = 1; }
   }
   // item descriptors: CN  r | chunk<<8 | degree<<16 | fused<<24 ;  VN  c | chunk<<8 | nfull<<16 | rem<<20
+  // two consecutive fully valid 64-lane chunks of a row / column form one "pair" item (bit 25);
+  // columns with >= 20 slots stay single-chunk items so that no item dwarfs a wave's fair share
   std::vector<std::pair<int, int32_t>> ci, vi, v1i;
   for (int r = 0; r < h->ncu; ++r)
-    for (int q = 0; q < chunks; ++q)
-      if (r * z + q * 64 < h->n_cn) ci.push_back({row_deg[r], r | (q << 8) | (row_deg[r] << 16) | (row_fused[r] << 24)});
+    for (int q = 0; q < chunks; ++q) {
+      if (r * z + q * 64 >= h->n_cn) continue;
+      const int32_t d0 = r | (q << 8) | (row_deg[r] << 16) | (row_fused[r] << 24);
+      const bool pair = (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn;
+      if (pair) { ci.push_back({2 * row_deg[r], d0 | (1 << 25)}); ++q; }
+      else ci.push_back({row_deg[r], d0});
+    }
   for (int c = 0; c < h->nbu; ++c)
-    for (int q = 0; q < chunks; ++q)
-      if (c * z + q * 64 < h->n_vn) {
-        const int nfull = col_cls[c] & 0xF, rem = col_cls[c] >> 4;
-        if (col_fused[c]) v1i.push_back({1, c | (q << 8)});
-        else vi.push_back({nfull * 16 + rem, c | (q << 8) | (nfull << 16) | (rem << 20)});
-      }
+    for (int q = 0; q < chunks; ++q) {
+      if (c * z + q * 64 >= h->n_vn) continue;
+      const int nfull = col_cls[c] & 0xF, rem = col_cls[c] >> 4, slots = nfull * 16 + rem;
+      if (col_fused[c]) { v1i.push_back({1, c | (q << 8)}); continue; }
+      const int32_t d0 = c | (q << 8) | (nfull << 16) | (rem << 20);
+      const bool pair = slots < 20 && (q + 2) * 64 <= z && c * z + (q + 2) * 64 <= h->n_vn;
+      if (pair) { vi.push_back({2 * slots, d0 | (1 << 25)}); ++q; }
+      else vi.push_back({slots, d0});
+    }
   // vn_sched_ptr = [16+1 offsets of the per-iteration lists | 16+1 offsets of the final degree-1 pass]
   std::vector<int32_t> cp, cl, vp, vl, v1p, v1l;
   lpt_schedule(ci, &cp, &cl);
