@@ -157,6 +157,75 @@ int samd_awgn_c64(const float* x, const float* no, int64_t no_len, uint64_t seed
                   uint64_t call, int64_t n, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * OFDM resource grid, frequency-domain channel, LS estimation, LMMSE equalisation
+ * (config C4 of the north star).  S below = num_tx * num_streams_per_tx, RE index = t*F + f.
+ * ---------------------------------------------------------------------------------- */
+/* ResourceGridMapper.call  ofdm/resource_grid.py:394-412.
+ * x [batch,S,num_data]; pilots DEVICE [S,num_pilots]; data_pos / pilot_pos DEVICE int32
+ * [S,num_re]: index of the data / pilot symbol carried by that RE of the FULL grid
+ * (num_re = num_ofdm_symbols*fft_size) or -1; out [batch,S,num_re]. */
+int samd_rg_map_c64(const float* x, const float* pilots, const int32_t* data_pos,
+                    const int32_t* pilot_pos, int batch, int num_streams, int num_re,
+                    int num_data, int num_pilots, float* out, void* stream);
+
+/* Generic index gather out[b,g,j] = in[b, src_group[g], idx[g,j]] on float32 (floats_per_elem
+ * = 1) or complex64 (= 2) elements.  Implements RemoveNulledSubcarriers.call
+ * (ofdm/resource_grid.py:551-552) and ResourceGridDemapper.call (:466-520). */
+int samd_gather3(const float* in, const int32_t* src_group, const int32_t* idx, int batch,
+                 int groups_in, int n_in, int groups_out, int n_out, int floats_per_elem,
+                 float* out, void* stream);
+
+/* TDL.__call__  channel/tr38901/tdl.py:372-470 (no spatial correlation): sum-of-sinusoids
+ * taps a [batch,1,num_rx_ant,1,num_tx_ant,num_paths,num_time_steps] complex64 on the Philox
+ * stream (seed, call .. call+3) - layout: oracle/ofdm.py::tdl_cir.  mean_powers DEVICE
+ * float[num_paths] (linear, normalised); los=1 adds the specular term to path 0. */
+int samd_tdl_cir_c64(uint64_t seed, uint64_t call, int batch, int num_rx_ant, int num_tx_ant,
+                     int num_paths, int num_time_steps, int num_sinusoids,
+                     float sampling_frequency, const float* mean_powers, float min_doppler,
+                     float max_doppler, int los, float los_power, float los_aoa, float* a,
+                     void* stream);
+
+/* cir_to_ofdm_channel  channel/utils.py:180-253.  a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P],
+ * frequencies DEVICE float[F] -> h_freq [B,rx,ra,tx,ta,T,F]; normalize: unit mean energy over
+ * (ra,ta,T,F) per (b,rx,tx). */
+int samd_cir_to_ofdm_c64(const float* a, const float* tau, const float* frequencies, int batch,
+                         int num_rx, int num_rx_ant, int num_tx, int num_tx_ant, int num_paths,
+                         int num_time_steps, int num_freqs, int normalize, float* h_freq,
+                         void* stream);
+
+/* ApplyOFDMChannel.call (noise-free part)  channel/apply_ofdm_channel.py:70-80.
+ * x [B, num_tx*num_tx_ant, num_re], h_freq [B, num_rx*num_rx_ant, num_tx*num_tx_ant, num_re]
+ * -> y [B, num_rx*num_rx_ant, num_re]. */
+int samd_apply_ofdm_channel_c64(const float* x, const float* h_freq, int batch, int num_rx_x_ant,
+                                int num_tx_x_ant, int num_re, float* y, void* stream);
+
+/* LSChannelEstimator (+ NearestNeighborInterpolator)  ofdm/channel_estimation.py:138-173,
+ * 257-285, 364-435: out[r,s,j] = y[r, src[s,j]] * coef[s,j]; rows r = batch*num_rx*num_rx_ant,
+ * y [rows,n_in] (full grid), src DEVICE int32 [S,n_out] = grid index of the (nearest) pilot RE,
+ * coef DEVICE complex64 [S,n_out] = 1/pilot (0 for zero pilots: divide_no_nan). */
+int samd_ls_gather_scale_c64(const float* y, const int32_t* src, const float* coef, int rows,
+                             int num_streams, int n_out, int n_in, float* out, void* stream);
+
+/* lmmse_equalizer  mimo/equalization.py:101-233 on n independent problems:
+ * y [n,m], h [n,m,k], s [n,m,m] complex64 -> x_hat [n,k] complex64, no_eff [n,k] float32.
+ * Supported (m,k): (1,1) (2,1) (2,2) (4,1) (4,2) (4,4) (8,1) (8,2) (8,4); else UNSUPPORTED. */
+int samd_lmmse_equalizer_c64(const float* y, const float* h, const float* s, int64_t n, int m,
+                             int k, int whiten, float* x_hat, float* no_eff, void* stream);
+
+/* LMMSEEqualizer / OFDMEqualizer.call  ofdm/equalization.py:109-275 fused with the per-RE solve.
+ * y [B,RX,M,T,FFT]; h_hat [B,RX,M,S,T,F]; err_var: ev_mode 0 none | 1 table [S,T*F] | 2 full
+ * [B,RX,M,S,T*F]; no [B,RX,M]; sc_ind [F] effective subcarrier -> fft bin; desired [RX,K] /
+ * undesired [RX,U] global stream ids; data_pos [S,T*F] (effective grid) -> data symbol index
+ * or -1.  Outputs x_hat, no_eff [B,S,num_data].  All index tables DEVICE int32. */
+int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const float* err_var, int ev_mode,
+                        const float* no, const int32_t* sc_ind, const int32_t* desired,
+                        const int32_t* undesired, const int32_t* data_pos, int batch, int num_rx,
+                        int num_rx_ant, int num_streams_total, int streams_per_rx,
+                        int num_undesired, int num_ofdm_symbols, int num_eff_subcarriers,
+                        int fft_size, int num_data, int whiten, float* x_hat, float* no_eff,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Error counting  utils/metrics.py:94-144 (count_errors, count_block_errors).
  * b, b_hat [num_blocks, block_len] float32; counters: DEVICE int64[2], ADDED to:
  * counters[0] += #(b != b_hat), counters[1] += #blocks with any mismatch.

@@ -1,0 +1,351 @@
+"""Oracle (NumPy, CPU): OFDM resource grid, pilots, stream management, frequency-domain channel
+(TDL / Rayleigh), LS channel estimation with nearest-neighbour interpolation and the per-RE
+LMMSE equaliser.
+
+TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  Restates (paths relative to
+/root/reference/src/sionna/phy):
+
+* StreamManagement                  mimo/stream_management.py:9-246
+* ResourceGrid / build_type_grid    ofdm/resource_grid.py:15-311
+* ResourceGridMapper / Demapper     ofdm/resource_grid.py:350-520, RemoveNulledSubcarriers :522-552
+* PilotPattern / Kronecker pattern  ofdm/pilot_pattern.py:17-378
+* subcarrier_frequencies            channel/utils.py:15-66
+* cir_to_ofdm_channel               channel/utils.py:180-253
+* TDL (sum of sinusoids)            channel/tr38901/tdl.py:372-498 (no spatial correlation)
+* ApplyOFDMChannel                  channel/apply_ofdm_channel.py:70-80
+* LSChannelEstimator + NN interp.   ofdm/channel_estimation.py:138-173, 257-285, 323-435
+* OFDMEqualizer / LMMSEEqualizer    ofdm/equalization.py:109-275
+* lmmse_equalizer / whiten_channel / lmmse_matrix / inv_cholesky
+                                    mimo/equalization.py:11-233, mimo/utils.py:292-356, utils/linalg.py:8-32
+
+Parity status: the reference pins LMMSE / TDL only statistically ("parity unpinned" by value,
+SURVEY section 8c); this restatement is checked by invariants (whitening gives identity
+covariance, perfect-CSI noiseless recovery, PDP / unit energy of the TDL) in tests/.
+Random draws use the build's Philox stream (oracle/utils.py) with the element layout documented
+in ``tdl_cir``; pilots of the Kronecker pattern are QPSK symbols drawn from that stream with the
+pattern's seed (the reference draws them from tf.random.Generator.from_seed(0)).
+"""
+import numpy as np
+
+from . import utils as outil
+from .mapping import qam
+
+PI = np.pi
+SPEED_OF_LIGHT = 299792458.0
+
+
+# ------------------------------------------------------------------ stream management
+class StreamManagement:
+    """mimo/stream_management.py:155-246 (literal)."""
+
+    def __init__(self, rx_tx_association, num_streams_per_tx):
+        self.num_streams_per_tx = int(num_streams_per_tx)
+        a = np.array(rx_tx_association, np.int32)
+        assert np.all((a == 0) | (a == 1))
+        self.num_rx, self.num_tx = a.shape
+        self.rx_tx_association = a
+        self.num_tx_per_rx = int(np.sum(a, 1)[0])
+        self.num_rx_per_tx = int(np.sum(a, 0)[0])
+        self.num_streams_per_rx = int(self.num_tx * self.num_streams_per_tx / self.num_rx)
+        sa = np.zeros([self.num_rx, self.num_tx, self.num_streams_per_tx], np.int32)
+        n_streams = min(self.num_streams_per_rx, self.num_streams_per_tx)
+        for j in range(self.num_tx):
+            c = 0
+            for i in range(self.num_rx):
+                if a[i, j]:
+                    sa[i, j, c:c + self.num_streams_per_rx] = np.ones([n_streams])
+                    c += self.num_streams_per_rx
+        self.stream_association = sa
+        self.detection_desired_ind = np.where(sa.reshape(-1) == 1)[0]
+        self.detection_undesired_ind = np.where(sa.reshape(-1) == 0)[0]
+        rx_ids = np.zeros([self.num_rx, self.num_streams_per_rx], np.int32)
+        for i in range(self.num_rx):
+            c = []
+            for j in range(self.num_tx):
+                if a[i, j]:
+                    c += list(np.where(sa[i, j])[0] + j * self.num_streams_per_tx)
+            rx_ids[i, :] = c
+        self.rx_stream_ids = rx_ids
+        self.stream_ind = np.argsort(rx_ids.reshape(-1))
+
+
+# ------------------------------------------------------------------ pilots / resource grid
+class PilotPattern:
+    def __init__(self, mask, pilots, normalize=False):
+        self.mask = np.asarray(mask, bool)
+        self._pilots = np.asarray(pilots, np.complex64)
+        self.normalize = normalize
+
+    @property
+    def num_pilot_symbols(self):
+        return self._pilots.shape[-1]
+
+    @property
+    def num_data_symbols(self):
+        return self.mask.shape[-1] * self.mask.shape[-2] - self.num_pilot_symbols
+
+    @property
+    def pilots(self):
+        if self.normalize and self._pilots.shape[-1] > 0:
+            scale = 1 / np.sqrt(np.mean(np.abs(self._pilots) ** 2, axis=-1, keepdims=True))
+            return (scale * self._pilots).astype(np.complex64)
+        return self._pilots
+
+
+def qpsk_pilots(seed, call, n):
+    """n random QPSK symbols from the build's bit stream (2 bits per symbol)."""
+    bits = outil.random_bits(seed, call, 2 * n)
+    pts = qam(2)
+    return pts[(bits[0::2] * 2 + bits[1::2]).astype(np.int64)]
+
+
+def kronecker_pilot_pattern(rg, pilot_ofdm_symbol_indices, normalize=True, seed=0):
+    """ofdm/pilot_pattern.py:330-378"""
+    num_tx, ns = rg.num_tx, rg.num_streams_per_tx
+    n_sym, n_sc = rg.num_ofdm_symbols, rg.num_effective_subcarriers
+    num_pilot_symbols = len(pilot_ofdm_symbol_indices)
+    num_seq = num_tx * ns
+    num_pilots = num_pilot_symbols * n_sc / num_seq
+    assert (num_pilots / num_pilot_symbols) % 1 == 0
+    per_sym = int(num_pilots / num_pilot_symbols)
+    mask = np.zeros([num_tx, ns, n_sym, n_sc], bool)
+    pilots = np.zeros([num_tx, ns, num_pilot_symbols, n_sc], np.complex64)
+    mask[..., pilot_ofdm_symbol_indices, :] = True
+    call = 0
+    for i in range(num_tx):
+        for j in range(ns):
+            p = qpsk_pilots(seed, call, num_pilot_symbols * per_sym).reshape(num_pilot_symbols, per_sym)
+            call += 1
+            pilots[i, j, :, i * ns + j::num_seq] = p
+    return PilotPattern(mask, pilots.reshape(num_tx, ns, -1), normalize)
+
+
+class ResourceGrid:
+    """ofdm/resource_grid.py:61-311"""
+
+    def __init__(self, num_ofdm_symbols, fft_size, subcarrier_spacing, num_tx=1, num_streams_per_tx=1,
+                 cyclic_prefix_length=0, num_guard_carriers=(0, 0), dc_null=False, pilot_pattern=None,
+                 pilot_ofdm_symbol_indices=None):
+        self.num_ofdm_symbols, self.fft_size = num_ofdm_symbols, fft_size
+        self.subcarrier_spacing = subcarrier_spacing
+        self.num_tx, self.num_streams_per_tx = num_tx, num_streams_per_tx
+        self.cyclic_prefix_length = int(cyclic_prefix_length)
+        self.num_guard_carriers = np.array(num_guard_carriers)
+        self.dc_null = dc_null
+        if pilot_pattern is None or pilot_pattern == "empty":
+            n_eff = self.num_effective_subcarriers
+            self.pilot_pattern = PilotPattern(np.zeros([num_tx, num_streams_per_tx, num_ofdm_symbols, n_eff], bool),
+                                              np.zeros([num_tx, num_streams_per_tx, 0], np.complex64))
+        elif pilot_pattern == "kronecker":
+            self.pilot_pattern = kronecker_pilot_pattern(self, pilot_ofdm_symbol_indices)
+        else:
+            self.pilot_pattern = pilot_pattern
+
+    @property
+    def num_effective_subcarriers(self):
+        return int(self.fft_size - self.dc_null - np.sum(self.num_guard_carriers))
+
+    @property
+    def dc_ind(self):
+        return int(self.fft_size / 2 - (self.fft_size % 2 == 1) / 2)
+
+    @property
+    def effective_subcarrier_ind(self):
+        g = self.num_guard_carriers
+        sc = np.arange(g[0], self.fft_size - g[1])
+        if self.dc_null:
+            sc = np.delete(sc, self.dc_ind - g[0])
+        return sc
+
+    @property
+    def num_pilot_symbols(self):
+        return self.pilot_pattern.num_pilot_symbols
+
+    @property
+    def num_data_symbols(self):
+        return self.num_effective_subcarriers * self.num_ofdm_symbols - self.num_pilot_symbols
+
+    @property
+    def ofdm_symbol_duration(self):
+        return (1. + self.cyclic_prefix_length / self.fft_size) / self.subcarrier_spacing
+
+    def build_type_grid(self):
+        """0 data, 1 pilot, 2 guard, 3 DC  (resource_grid.py:283-311)"""
+        shape = [self.num_tx, self.num_streams_per_tx, self.num_ofdm_symbols]
+        g = self.num_guard_carriers
+        mask = self.pilot_pattern.mask.astype(np.int32)
+        split = self.dc_ind - g[0]
+        return np.concatenate([2 * np.ones(shape + [g[0]], np.int32), mask[..., :split],
+                               3 * np.ones(shape + [int(self.dc_null)], np.int32), mask[..., split:],
+                               2 * np.ones(shape + [g[1]], np.int32)], -1)
+
+
+def rg_map(rg, x):
+    """ResourceGridMapper.call (resource_grid.py:394-412): x [B,tx,s,num_data] -> [B,tx,s,T,fft]."""
+    t = rg.build_type_grid()
+    out = np.zeros((x.shape[0],) + t.shape, np.complex64)
+    out[:, t == 1] = rg.pilot_pattern.pilots.reshape(-1)          # same (row-major) order as tf.where
+    out[:, t == 0] = x.reshape(x.shape[0], -1)
+    return out
+
+
+def remove_nulled(rg, x):
+    return x[..., rg.effective_subcarrier_ind]
+
+
+def data_ind(pp):
+    """argsort(mask) ascending, first num_data entries (resource_grid.py:455-459; stable)."""
+    m = pp.mask.reshape(pp.mask.shape[:2] + (-1,))
+    return np.argsort(m, axis=-1, kind="stable")[..., :pp.num_data_symbols]
+
+
+# ------------------------------------------------------------------ channel
+def subcarrier_frequencies(num_subcarriers, subcarrier_spacing):
+    """channel/utils.py:15-66"""
+    start = -(num_subcarriers // 2)
+    limit = num_subcarriers // 2 if num_subcarriers % 2 == 0 else num_subcarriers // 2 + 1
+    return (np.arange(start, limit, dtype=np.float32) * np.float32(subcarrier_spacing)).astype(np.float32)
+
+
+def cir_to_ofdm_channel(frequencies, a, tau, normalize=False):
+    """channel/utils.py:180-253.  a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P] -> [B,rx,ra,tx,ta,T,F]."""
+    tau = tau[:, :, None, :, None, :, None, None]                      # [B,rx,1,tx,1,P,1,1]
+    e = np.exp(-2j * PI * frequencies.astype(np.float64) * tau.astype(np.float64))
+    h_f = np.sum(a[..., None].astype(np.complex128) * e, axis=-3)      # sum over paths
+    if normalize:
+        c = np.mean(np.abs(h_f) ** 2, axis=(2, 4, 5, 6), keepdims=True)
+        h_f = np.where(c > 0, h_f / np.sqrt(np.where(c > 0, c, 1)), 0)
+    return h_f.astype(np.complex64)
+
+
+def _u(seed, call, n, lo, hi):
+    """n uniforms in (lo,hi): element i = word i%4 of Philox block i//4 of stream (seed, call)."""
+    nb = (n + 3) // 4
+    w = np.stack(outil.philox_block(seed, call, nb), axis=1).reshape(-1)[:n]
+    return (np.float32(lo) + (np.float32(hi) - np.float32(lo)) * outil._u01(w)).astype(np.float32)
+
+
+def tdl_cir(seed, call, batch, num_time_steps, sampling_frequency, delays_s, mean_powers, min_doppler,
+            max_doppler, num_rx_ant=1, num_tx_ant=1, num_sinusoids=20, los_power=None, los_aoa=PI / 4):
+    """tdl.py:372-470.  RNG layout (4 consecutive calls of the stream):
+    call+0 doppler[b]; call+1 theta[b,p,n]; call+2 phi[b,ra,ta,p,n]; call+3 phi_0[b] (LoS only).
+    Returns a [B,1,ra,1,ta,P,T] complex64, tau [B,1,1,P] float32."""
+    P, N, T = len(mean_powers), num_sinusoids, num_time_steps
+    f = np.float32
+    t = (np.arange(T, dtype=np.float32) / f(sampling_frequency)).astype(np.float32)
+    doppler = _u(seed, call, batch, min_doppler, max_doppler).reshape(batch, 1, 1, 1, 1, 1)
+    theta = _u(seed, call + 1, batch * P * N, -PI / N, PI / N).reshape(batch, 1, 1, P, 1, N)
+    phi = _u(seed, call + 2, batch * num_rx_ant * num_tx_ant * P * N, -PI, PI).reshape(batch, num_rx_ant, num_tx_ant, P, 1, N)
+    alpha = (f(2 * PI / N) * np.arange(1, N + 1, dtype=np.float32)).reshape(1, 1, 1, 1, 1, N) + theta
+    arg = (doppler * t.reshape(1, 1, 1, 1, T, 1) * np.cos(alpha) + phi).astype(np.float32)
+    h = (np.cos(arg) + 1j * np.sin(arg)).sum(-1) * f(1 / np.sqrt(N))      # [B,ra,ta,P,T]
+    h = np.sqrt(np.asarray(mean_powers, np.float32)).reshape(1, 1, 1, P, 1) * h
+    if los_power is not None:
+        phi0 = _u(seed, call + 3, batch, -PI, PI).reshape(batch, 1, 1, 1)
+        arg0 = doppler.reshape(batch, 1, 1, 1) * t.reshape(1, 1, 1, T) * f(np.cos(los_aoa)) + phi0
+        h[:, :, :, 0, :] += (np.cos(arg0) + 1j * np.sin(arg0)) * np.sqrt(f(los_power))
+    a = h.astype(np.complex64)[:, None, :, None, :, :, :]                   # [B,1,ra,1,ta,P,T]
+    tau = np.tile(np.asarray(delays_s, np.float32).reshape(1, 1, 1, P), [batch, 1, 1, 1])
+    return a, tau
+
+
+def apply_ofdm_channel(x, h_freq):
+    """apply_ofdm_channel.py:70-80 without noise: x [B,tx,ta,T,F], h [B,rx,ra,tx,ta,T,F]."""
+    return np.sum(h_freq * x[:, None, None], axis=(3, 4)).astype(np.complex64)
+
+
+# ------------------------------------------------------------------ LS estimation + NN interpolation
+def nn_gather_ind(pp):
+    """channel_estimation.py:364-411"""
+    mask = pp.mask
+    shp = mask.shape
+    m = mask.reshape([-1] + list(shp[-2:]))
+    pil = pp.pilots.reshape(-1, pp.pilots.shape[-1])
+    g = np.zeros_like(m, dtype=np.int32)
+    for a in range(m.shape[0]):
+        i_p, j_p = np.where(m[a])
+        for i in range(shp[-2]):
+            for j in range(shp[-1]):
+                d = np.abs(i - i_p) + np.abs(j - j_p)
+                d[np.abs(pil[a]) == 0] = np.sum(shp[-2:])
+                g[a, i, j] = np.argmin(d)
+    return g.reshape(shp)
+
+
+def ls_estimate(rg, y, no, interpolation="nn"):
+    """BaseChannelEstimator.call + LSChannelEstimator (channel_estimation.py:138-173, 257-285).
+    y [B,rx,ra,T,fft]; no scalar.  Returns h_hat [B,rx,ra,tx,s,T,Feff], err_var broadcastable."""
+    pp = rg.pilot_pattern
+    y_eff = remove_nulled(rg, y)
+    y_flat = y_eff.reshape(y_eff.shape[:-2] + (-1,))
+    m = pp.mask.reshape(pp.mask.shape[:2] + (-1,))
+    pilot_ind = np.argsort(~m, axis=-1, kind="stable")[..., :pp.num_pilot_symbols]   # DESCENDING on mask
+    y_p = y_flat[..., pilot_ind]                                        # [B,rx,ra,tx,s,Np]
+    pil = pp.pilots
+    with np.errstate(divide="ignore", invalid="ignore"):
+        h_ls = np.where(pil != 0, y_p / np.where(pil != 0, pil, 1), 0).astype(np.complex64)
+        ev = np.where(pil != 0, np.float32(no) / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(np.float32)
+    ev = ev[None, None, None]
+    if interpolation is None:
+        return h_ls, ev
+    g = nn_gather_ind(pp)                                               # [tx,s,T,F]
+    tx, s = np.indices(g.shape)[:2]
+    h_hat = h_ls[:, :, :, tx, s, g]
+    err = np.maximum(ev[:, :, :, tx, s, g], 0)
+    return h_hat, err
+
+
+# ------------------------------------------------------------------ LMMSE
+def lmmse_equalizer(y, h, s, whiten_interference=True):
+    """mimo/equalization.py:101-233 in complex128 (y [...,M], h [...,M,K], s [...,M,M])."""
+    y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
+    hh = np.conj(np.swapaxes(h, -1, -2))
+    if whiten_interference:
+        l_inv = np.linalg.inv(np.linalg.cholesky(s))
+        y = (l_inv @ y[..., None])[..., 0]
+        h = l_inv @ h
+        hh = np.conj(np.swapaxes(h, -1, -2))
+        g = np.linalg.solve(hh @ h + np.eye(h.shape[-1]), hh)
+    else:
+        g = hh @ np.linalg.inv(h @ hh + s)
+    gy = (g @ y[..., None])[..., 0]
+    d = np.diagonal(g @ h, axis1=-2, axis2=-1)
+    return gy / d, np.real(1 / d - 1)
+
+
+def ofdm_lmmse_equalize(rg, sm, y, h_hat, err_var, no, whiten_interference=True):
+    """OFDMEqualizer.call with the LMMSE equaliser (ofdm/equalization.py:109-275).
+    y [B,rx,ra,T,fft], h_hat [B,rx,ra,tx,s,T,Feff], err_var broadcastable, no scalar/[B]/[B,rx]/[B,rx,ra].
+    Returns x_hat, no_eff [B,tx,s,num_data]."""
+    y_eff = remove_nulled(rg, y)
+    B = y.shape[0]
+    y_dt = np.transpose(y_eff, [0, 1, 3, 4, 2])
+    ev = np.broadcast_to(err_var, h_hat.shape)
+    ev = np.transpose(ev, [0, 1, 5, 6, 2, 3, 4])
+    ev = ev.reshape(ev.shape[:5] + (-1,))
+    h_dt = np.transpose(h_hat, [1, 3, 4, 0, 2, 5, 6])
+    h_dt = h_dt.reshape((-1,) + h_dt.shape[3:])
+    hd = h_dt[sm.detection_desired_ind].reshape((sm.num_rx, sm.num_streams_per_rx) + h_dt.shape[1:])
+    hu = h_dt[sm.detection_undesired_ind].reshape((sm.num_rx, -1) + h_dt.shape[1:])
+    perm = [2, 0, 4, 5, 3, 1]
+    hd, hu = np.transpose(hd, perm), np.transpose(hu, perm)
+    no = np.asarray(no, np.float32)
+    no_dt = no.reshape(no.shape + (1,) * (3 - no.ndim))
+    no_dt = np.broadcast_to(no_dt, y.shape[:3])[..., None, None]
+    no_dt = np.broadcast_to(no_dt, y_eff.shape)
+    no_dt = np.transpose(no_dt, [0, 1, 3, 4, 2])
+    M = y_dt.shape[-1]
+    s = hu.astype(np.complex128) @ np.conj(np.swapaxes(hu, -1, -2)).astype(np.complex128)
+    eye = np.eye(M)
+    s = s + no_dt[..., None] * eye + np.sum(ev, -1)[..., None] * eye
+    x_hat, no_eff = lmmse_equalizer(y_dt, hd, s, whiten_interference)
+    # extract data symbols of all detected TX (equalization.py:233-273)
+    def extract(z):
+        z = np.transpose(z, [1, 4, 2, 3, 0])
+        z = z.reshape((-1,) + z.shape[2:])[sm.stream_ind]
+        z = z.reshape((sm.num_tx, sm.num_streams_per_tx) + z.shape[1:])
+        z = z.reshape(z.shape[:2] + (-1, B))
+        di = data_ind(rg.pilot_pattern)
+        tx, st = np.indices(di.shape)[:2]
+        return np.transpose(z[tx, st, di], [3, 0, 1, 2])
+    return extract(x_hat).astype(np.complex64), extract(no_eff).astype(np.float32)

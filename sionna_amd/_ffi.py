@@ -42,6 +42,16 @@ _SIGNATURES = {
     "samd_square_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "samd_binary_source_f32": (_i32, [_u64, _u64, _i64, _vp, _vp]),
     "samd_awgn_c64": (_i32, [_vp, _vp, _i64, _u64, _u64, _i64, _vp, _vp]),
+    "samd_rg_map_c64": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_gather3": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_tdl_cir_c64": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _f32, _f32, _i32, _f32,
+                                _f32, _vp, _vp]),
+    "samd_cir_to_ofdm_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_apply_ofdm_channel_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_ls_gather_scale_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_lmmse_equalizer_c64": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "samd_ofdm_lmmse_c64": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                   _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "samd_count_errors_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
 }
 

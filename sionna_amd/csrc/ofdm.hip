@@ -1,0 +1,275 @@
+// OFDM resource-grid plumbing, frequency-domain channel generation and application.
+//
+// Replaces (reference src/sionna/phy/):
+//   ResourceGridMapper.call          ofdm/resource_grid.py:394-412     (tf.scatter_nd x2 + transposes)
+//   ResourceGridDemapper.call        ofdm/resource_grid.py:466-520     (gathers + transposes)
+//   RemoveNulledSubcarriers.call     ofdm/resource_grid.py:551-552
+//   TDL.__call__                     channel/tr38901/tdl.py:372-470    (sum-of-sinusoids taps)
+//   cir_to_ofdm_channel              channel/utils.py:180-253          (taps -> frequency response)
+//   ApplyOFDMChannel.call            channel/apply_ofdm_channel.py:70-80
+//
+// All of these are HBM-streaming or trig-bound element-wise kernels; what the reference
+// materialises as rank-8 broadcast temporaries (3.4 GB for the TDL sinusoids, 12.8 GB for
+// the per-path frequency responses at config C4) stays in registers / LDS here.
+#include "common.h"
+
+namespace samd {
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// out[b, s, re] = x[b, s, data_pos[s,re]] | pilots[s, pilot_pos[s,re]] | 0
+__global__ __launch_bounds__(256) void rg_map_kernel(const float2* __restrict__ x, const float2* __restrict__ pilots,
+                                                     const int32_t* __restrict__ data_pos,
+                                                     const int32_t* __restrict__ pilot_pos, int64_t total, int S,
+                                                     int TF, int ND, int NP, float2* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int re = (int)(i % TF);
+    const int64_t bs = i / TF;
+    const int s = (int)(bs % S);
+    const int d = data_pos[s * TF + re];
+    float2 v = make_float2(0.f, 0.f);
+    if (d >= 0) v = x[bs * ND + d];
+    else {
+      const int p = pilot_pos[s * TF + re];
+      if (p >= 0) v = pilots[s * NP + p];
+    }
+    out[i] = v;
+  }
+}
+
+// out[b, g, j] = in[b, src_group[g], idx[g, j]]   (element = EL floats: 2 for complex64, 1 for float32)
+template <int EL>
+__global__ __launch_bounds__(256) void gather3_kernel(const float* __restrict__ in, const int32_t* __restrict__ src_group,
+                                                      const int32_t* __restrict__ idx, int64_t total, int G_in,
+                                                      int N_in, int G_out, int N_out, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % N_out);
+    const int64_t bg = i / N_out;
+    const int g = (int)(bg % G_out);
+    const int64_t b = bg / G_out;
+    const int64_t src = ((b * G_in + src_group[g]) * N_in + idx[(int64_t)g * N_out + j]) * EL;
+#pragma unroll
+    for (int e = 0; e < EL; ++e) out[i * EL + e] = in[src + e];
+  }
+}
+
+// ---- TDL taps.  One thread per (b, ra, ta, p); loops over time steps and sinusoids.
+// RNG layout = oracle/ofdm.py::tdl_cir: call+0 doppler[b], call+1 theta[b,p,n], call+2
+// phi[b,ra,ta,p,n], call+3 phi_0[b]; element i of a call = word i%4 of Philox block i/4.
+__device__ __forceinline__ float uni(uint64_t seed, uint64_t call, uint64_t i, float lo, float hi) {
+  const uint4 r = philox_block(seed, call, i >> 2);
+  const uint32_t w = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+  return lo + (hi - lo) * u01(w);
+}
+
+__global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t call, int B, int RA, int TA, int P,
+                                                      int T, int N, float sampling_frequency,
+                                                      const float* __restrict__ mean_powers, float min_doppler,
+                                                      float max_doppler, int los, float los_power, float los_aoa,
+                                                      float2* __restrict__ a) {
+  const int64_t total = (int64_t)B * RA * TA * P;
+  const float pi = 3.14159265358979323846f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    const int64_t r1 = i / P;            // (b*RA + ra)*TA + ta
+    const int64_t b = r1 / ((int64_t)RA * TA);
+    const float doppler = uni(seed, call, (uint64_t)b, min_doppler, max_doppler);
+    const float amp = sqrtf(mean_powers[p]);
+    const float norm = 1.f / sqrtf((float)N);
+    float2* o = a + i * T;
+    for (int t = 0; t < T; ++t) o[t] = make_float2(0.f, 0.f);
+    for (int n = 0; n < N; ++n) {
+      const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
+      const float phi = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
+      const float alpha = (2.f * pi / (float)N) * (float)(n + 1) + theta;
+      const float ca = cosf(alpha);
+      for (int t = 0; t < T; ++t) {
+        const float arg = doppler * ((float)t / sampling_frequency) * ca + phi;
+        float s, c;
+        sincosf(arg, &s, &c);
+        o[t].x += c; o[t].y += s;
+      }
+    }
+    for (int t = 0; t < T; ++t) {
+      float2 h = make_float2(amp * (o[t].x * norm), amp * (o[t].y * norm));
+      if (los && p == 0) {
+        const float phi0 = uni(seed, call + 3, (uint64_t)b, -pi, pi);
+        const float arg = doppler * ((float)t / sampling_frequency) * cosf(los_aoa) + phi0;
+        float s, c;
+        sincosf(arg, &s, &c);
+        const float k = sqrtf(los_power);
+        h.x += c * k; h.y += s * k;
+      }
+      o[t] = h;
+    }
+  }
+}
+
+// ---- taps -> frequency response.  One workgroup per (b, rx, tx): the P x F phase table
+// e^{-j 2 pi f tau_p} is built once in LDS and reused by all RA*TA*T outputs; the optional
+// normalisation (unit mean energy over ra, ta, t, f) is a deterministic in-block reduction.
+__global__ __launch_bounds__(256) void cir_to_ofdm_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
+                                                          const float* __restrict__ freqs, int RX, int RA, int TX,
+                                                          int TA, int P, int T, int F, int normalize,
+                                                          float2* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float2 tab[];   // [P][F] phases, then red[256]
+  float* red = reinterpret_cast<float*>(tab + (size_t)P * F);
+  const int tx = blockIdx.x % TX;
+  const int rx = (blockIdx.x / TX) % RX;
+  const int b = blockIdx.x / (TX * RX);
+  const float* tb = tau + ((size_t)(b * RX + rx) * TX + tx) * P;
+  for (int i = threadIdx.x; i < P * F; i += 256) {
+    const int p = i / F, f = i % F;
+    float s, c;
+    sincosf(-2.f * 3.14159265358979323846f * freqs[f] * tb[p], &s, &c);
+    tab[i] = make_float2(c, s);
+  }
+  __syncthreads();
+  const int per = RA * TA * T * F;
+  float energy = 0.f;
+  for (int i = threadIdx.x; i < per; i += 256) {
+    const int f = i % F;
+    const int t = (i / F) % T;
+    const int ta = (i / (F * T)) % TA;
+    const int ra = i / (F * T * TA);
+    const float2* ap = a + ((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * (size_t)P * T;
+    float2 h = make_float2(0.f, 0.f);
+    for (int p = 0; p < P; ++p) {
+      const float2 v = cmul(ap[(size_t)p * T + t], tab[p * F + f]);
+      h.x += v.x; h.y += v.y;
+    }
+    out[(((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * T + t) * F + f] = h;
+    energy += h.x * h.x + h.y * h.y;
+  }
+  if (!normalize) return;
+  red[threadIdx.x] = energy;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float c = sqrtf(red[0] / (float)per);
+  const float inv = c > 0.f ? 1.f / c : 0.f;                  // divide_no_nan
+  for (int i = threadIdx.x; i < per; i += 256) {
+    const int f = i % F;
+    const int t = (i / F) % T;
+    const int ta = (i / (F * T)) % TA;
+    const int ra = i / (F * T * TA);
+    float2* o = out + (((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * T + t) * F + f;
+    *o = make_float2(o->x * inv, o->y * inv);
+  }
+}
+
+// y[b,rx,ra,t,f] = sum_{tx,ta} h[b,rx,ra,tx,ta,t,f] * x[b,tx,ta,t,f]
+__global__ __launch_bounds__(256) void apply_ofdm_channel_kernel(const float2* __restrict__ x,
+                                                                 const float2* __restrict__ h, int64_t total,
+                                                                 int RXA, int TXA, int TF,
+                                                                 float2* __restrict__ y) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int re = (int)(i % TF);
+    const int64_t br = i / TF;             // b*RXA + rxa
+    const int64_t b = br / RXA;
+    float2 acc = make_float2(0.f, 0.f);
+    for (int k = 0; k < TXA; ++k) {
+      const float2 v = cmul(h[(br * TXA + k) * TF + re], x[(b * TXA + k) * TF + re]);
+      acc.x += v.x; acc.y += v.y;
+    }
+    y[i] = acc;
+  }
+}
+
+// LS estimate + (nearest-neighbour) spreading: out[b, rxa, s, j] = y[b, rxa, src[s,j]] * coef[s,j]
+__global__ __launch_bounds__(256) void ls_gather_scale_kernel(const float2* __restrict__ y,
+                                                              const int32_t* __restrict__ src,
+                                                              const float2* __restrict__ coef, int64_t total, int S,
+                                                              int N_out, int N_in, float2* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % N_out);
+    const int64_t r = i / N_out;
+    const int s = (int)(r % S);
+    const int64_t bra = r / S;
+    out[i] = cmul(y[bra * N_in + src[(int64_t)s * N_out + j]], coef[(int64_t)s * N_out + j]);
+  }
+}
+
+}  // namespace samd
+
+using namespace samd;
+
+static inline int grid_for(int64_t n, int block) {
+  const int64_t g = (n + block - 1) / block;
+  return (int)std::min<int64_t>(std::max<int64_t>(g, 1), 256 * 32);
+}
+
+extern "C" int samd_rg_map_c64(const float* x, const float* pilots, const int32_t* data_pos, const int32_t* pilot_pos,
+                               int batch, int num_streams, int num_re, int num_data, int num_pilots, float* out,
+                               void* stream) {
+  SAMD_REQUIRE(x && data_pos && pilot_pos && out && (pilots || num_pilots == 0), "null argument");
+  const int64_t total = (int64_t)batch * num_streams * num_re;
+  if (total == 0) return SAMD_OK;
+  hipLaunchKernelGGL(rg_map_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)x,
+                     (const float2*)pilots, data_pos, pilot_pos, total, num_streams, num_re, num_data, num_pilots,
+                     (float2*)out);
+  return launch_status();
+}
+
+extern "C" int samd_gather3(const float* in, const int32_t* src_group, const int32_t* idx, int batch, int groups_in,
+                            int n_in, int groups_out, int n_out, int floats_per_elem, float* out, void* stream) {
+  SAMD_REQUIRE(in && src_group && idx && out, "null argument");
+  SAMD_REQUIRE(floats_per_elem == 1 || floats_per_elem == 2, "element must be float32 or complex64");
+  const int64_t total = (int64_t)batch * groups_out * n_out;
+  if (total == 0) return SAMD_OK;
+  if (floats_per_elem == 2)
+    hipLaunchKernelGGL(gather3_kernel<2>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, src_group,
+                       idx, total, groups_in, n_in, groups_out, n_out, out);
+  else
+    hipLaunchKernelGGL(gather3_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, src_group,
+                       idx, total, groups_in, n_in, groups_out, n_out, out);
+  return launch_status();
+}
+
+extern "C" int samd_tdl_cir_c64(uint64_t seed, uint64_t call, int batch, int num_rx_ant, int num_tx_ant, int num_paths,
+                                int num_time_steps, int num_sinusoids, float sampling_frequency,
+                                const float* mean_powers, float min_doppler, float max_doppler, int los,
+                                float los_power, float los_aoa, float* a, void* stream) {
+  SAMD_REQUIRE(mean_powers && a && batch > 0 && num_paths > 0 && num_time_steps > 0 && num_sinusoids > 0, "bad argument");
+  const int64_t total = (int64_t)batch * num_rx_ant * num_tx_ant * num_paths;
+  hipLaunchKernelGGL(tdl_cir_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, seed, call, batch,
+                     num_rx_ant, num_tx_ant, num_paths, num_time_steps, num_sinusoids, sampling_frequency, mean_powers,
+                     min_doppler, max_doppler, los, los_power, los_aoa, (float2*)a);
+  return launch_status();
+}
+
+extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const float* frequencies, int batch, int num_rx,
+                                    int num_rx_ant, int num_tx, int num_tx_ant, int num_paths, int num_time_steps,
+                                    int num_freqs, int normalize, float* h_freq, void* stream) {
+  SAMD_REQUIRE(a && tau && frequencies && h_freq && batch > 0, "bad argument");
+  const size_t lds = (size_t)num_paths * num_freqs * sizeof(float2) + 256 * sizeof(float);
+  SAMD_REQUIRE(lds <= 64 * 1024, "num_paths * fft_size too large for the LDS phase table");
+  hipLaunchKernelGGL(cir_to_ofdm_kernel, dim3(batch * num_rx * num_tx), dim3(256), lds, (hipStream_t)stream,
+                     (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx, num_tx_ant, num_paths,
+                     num_time_steps, num_freqs, normalize, (float2*)h_freq);
+  return launch_status();
+}
+
+extern "C" int samd_apply_ofdm_channel_c64(const float* x, const float* h_freq, int batch, int num_rx_x_ant,
+                                           int num_tx_x_ant, int num_re, float* y, void* stream) {
+  SAMD_REQUIRE(x && h_freq && y, "null argument");
+  const int64_t total = (int64_t)batch * num_rx_x_ant * num_re;
+  if (total == 0) return SAMD_OK;
+  hipLaunchKernelGGL(apply_ofdm_channel_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)x, (const float2*)h_freq, total, num_rx_x_ant, num_tx_x_ant, num_re, (float2*)y);
+  return launch_status();
+}
+
+extern "C" int samd_ls_gather_scale_c64(const float* y, const int32_t* src, const float* coef, int rows, int num_streams,
+                                        int n_out, int n_in, float* out, void* stream) {
+  SAMD_REQUIRE(y && src && coef && out, "null argument");
+  const int64_t total = (int64_t)rows * num_streams * n_out;
+  if (total == 0) return SAMD_OK;
+  hipLaunchKernelGGL(ls_gather_scale_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float2*)y, src, (const float2*)coef, total, num_streams, n_out, n_in, (float2*)out);
+  return launch_status();
+}

@@ -1,6 +1,6 @@
 """``sionna_amd.phy`` - host-side mirror of the ``sionna.phy`` API for the MI355X hot path."""
 from .config import config, dtypes
 from .block import Block, Object, Tensor
-from . import mapping, utils, channel
+from . import mapping, utils, channel, mimo, ofdm
 from . import fec
 from .fec import ldpc

@@ -1,0 +1,7 @@
+"""OFDM resource grid, pilots, channel estimation and equalisation (mirror of
+``sionna.phy.ofdm`` for the hot path)."""
+from .pilot_pattern import PilotPattern, EmptyPilotPattern, KroneckerPilotPattern
+from .resource_grid import ResourceGrid, ResourceGridMapper, ResourceGridDemapper, RemoveNulledSubcarriers
+from .channel_estimation import LSChannelEstimator, NearestNeighborInterpolator
+from .equalization import OFDMEqualizer, LMMSEEqualizer
+from .detection import LinearDetector

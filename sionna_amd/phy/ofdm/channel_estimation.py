@@ -1,0 +1,108 @@
+"""LS channel estimation with nearest-neighbour interpolation - mirror of reference
+src/sionna/phy/ofdm/channel_estimation.py (``BaseChannelEstimator.call`` :138-173,
+``LSChannelEstimator`` :175-285, ``NearestNeighborInterpolator`` :323-435).
+
+The reference gathers the pilot REs, divides by the pilots and then gathers again to spread
+the estimates over the grid (plus ~6 transposes).  Estimation and spreading commute with the
+per-pilot division, so ONE kernel does both: h_hat[.., t, f] = y[.., nearest pilot RE] * (1 /
+pilot).  Linear / LMMSE interpolators are outside the hot path."""
+import numpy as np
+import torch
+
+from ... import _ffi
+from ..block import Block, Object, wrap
+
+
+class NearestNeighborInterpolator(Object):
+    """For every RE the index of the closest (Manhattan distance over (symbol, subcarrier),
+    first index on ties) pilot with non-zero energy (channel_estimation.py:364-411)."""
+
+    def __init__(self, pilot_pattern):
+        super().__init__()
+        assert pilot_pattern.num_pilot_symbols > 0, "The pilot pattern cannot be empty"
+        mask = np.asarray(pilot_pattern.mask)
+        pilots = np.asarray(pilot_pattern.pilots)
+        s = mask.shape[0] * mask.shape[1]
+        m = mask.reshape(s, mask.shape[2], mask.shape[3])
+        pil = pilots.reshape(s, -1)
+        assert np.max(np.sum(np.abs(pil) == 0, -1)) < pil.shape[-1], \
+            "Each pilot sequence must have at least one nonzero entry"
+        ii, jj = np.meshgrid(np.arange(mask.shape[2]), np.arange(mask.shape[3]), indexing="ij")
+        g = np.zeros(m.shape, np.int32)
+        for a in range(s):
+            ip, jp = np.nonzero(m[a])                                          # row-major pilot order
+            d = np.abs(ii[..., None] - ip) + np.abs(jj[..., None] - jp)        # [T, F, num_pilots]
+            d[..., np.abs(pil[a]) == 0] = mask.shape[2] + mask.shape[3]        # never pick empty pilots
+            g[a] = np.argmin(d, axis=-1)
+        self._gather_ind = g.reshape(mask.shape)
+
+    gather_ind = property(lambda self: self._gather_ind)
+
+    def __call__(self, h_hat, err_var):
+        """Spread estimates at the pilot positions [..., tx, s, num_pilots] over the grid
+        [..., tx, s, T, F] (generic torch indexing; the fused estimator does not go through here)."""
+        g = torch.from_numpy(self._gather_ind.reshape(self._gather_ind.shape[:2] + (-1,))).to(h_hat.device).long()
+        def spread(x):
+            x = torch.broadcast_to(x, tuple(x.shape[:-3]) + tuple(g.shape[:2]) + (x.shape[-1],))
+            idx = g.expand(tuple(x.shape[:-1]) + (g.shape[-1],))
+            return torch.gather(x, -1, idx).reshape(tuple(x.shape[:-1]) + tuple(self._gather_ind.shape[2:]))
+        return wrap(spread(h_hat)), wrap(spread(err_var))
+
+
+class LSChannelEstimator(Block):
+    """``LSChannelEstimator(resource_grid, interpolation_type="nn")(y, no) -> (h_hat, err_var)``;
+    y [batch, num_rx, num_rx_ant, num_ofdm_symbols, fft_size]; h_hat [batch, num_rx, num_rx_ant, num_tx,
+    num_streams_per_tx, num_ofdm_symbols, num_effective_subcarriers]; err_var broadcastable to it."""
+
+    def __init__(self, resource_grid, interpolation_type="nn", interpolator=None, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        assert interpolation_type in ["nn", "lin", "lin_time_avg", None], "Unsupported `interpolation_type`"
+        if interpolator is not None or interpolation_type in ("lin", "lin_time_avg"):
+            raise NotImplementedError("LSChannelEstimator: only nearest-neighbour interpolation (or none) is on the hot path")
+        self._rg = resource_grid
+        self._interpolation_type = interpolation_type
+        pp = resource_grid.pilot_pattern
+        s = pp.mask.shape[0] * pp.mask.shape[1]
+        m = pp.mask.reshape(s, -1)
+        # pilot REs in row-major order = argsort(mask, DESCENDING)[:num_pilots] (channel_estimation.py:108-112)
+        pilot_re = np.stack([np.flatnonzero(m[a]) for a in range(s)])         # [S, num_pilots] effective grid
+        pil = np.asarray(pp.pilots).reshape(s, -1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = np.where(pil != 0, 1 / np.where(pil != 0, pil, 1), 0).astype(np.complex64)      # divide_no_nan
+            ev = np.where(pil != 0, 1 / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(np.float32)
+        if interpolation_type == "nn":
+            g = NearestNeighborInterpolator(pp).gather_ind.reshape(s, -1)     # [S, T*F] pilot number
+            pilot_re = np.take_along_axis(pilot_re, g, axis=1)
+            inv = np.take_along_axis(inv, g, axis=1)
+            ev = np.take_along_axis(ev, g, axis=1)
+            self._out_shape = tuple(pp.mask.shape)
+        else:
+            self._out_shape = tuple(pp.mask.shape[:2]) + (pp.num_pilot_symbols,)
+        sc = np.asarray(resource_grid.effective_subcarrier_ind)
+        t, f = np.divmod(pilot_re, resource_grid.num_effective_subcarriers)
+        self._src = (t * resource_grid.fft_size + sc[f]).astype(np.int32)      # index into the full grid
+        self._inv, self._ev = inv, ev
+        self._dev = None
+
+    def call(self, y, no):
+        self._require_single()
+        rg = self._rg
+        y = _ffi.to_device(y, torch.complex64)
+        assert y.dim() == 5 and y.shape[-2:] == (rg.num_ofdm_symbols, rg.fft_size), \
+            "y must have shape [batch, num_rx, num_rx_ant, num_ofdm_symbols, fft_size]"
+        if self._dev is None:
+            self._dev = (_ffi.to_device(self._src, torch.int32), _ffi.to_device(self._inv, torch.complex64),
+                         _ffi.to_device(self._ev, torch.float32))
+        src, inv, ev = self._dev
+        s, n_out = src.shape
+        rows = y.shape[0] * y.shape[1] * y.shape[2]
+        h_hat = torch.empty(tuple(y.shape[:3]) + self._out_shape, dtype=torch.complex64, device=y.device)
+        _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(y), _ffi.ptr(src), _ffi.ptr(inv), rows, s, n_out,
+                                                       rg.num_ofdm_symbols * rg.fft_size, _ffi.ptr(h_hat),
+                                                       _ffi.stream()), "LSChannelEstimator")
+        # err_var = no / |pilot|^2, broadcastable to h_hat (channel_estimation.py:276-283); `no` has the
+        # first n <= 3 dims of [batch, num_rx, num_rx_ant] - a handful of elements, plain broadcasting
+        no = _ffi.to_device(no, torch.float32)
+        no = no.reshape(tuple(no.shape) + (1,) * (3 - no.dim()) + (1,) * len(self._out_shape))
+        err_var = torch.clamp_min(no * ev.reshape(self._out_shape), 0.)
+        return h_hat, err_var

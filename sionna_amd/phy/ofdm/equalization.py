@@ -1,0 +1,79 @@
+"""OFDM MIMO equalisation - mirror of reference src/sionna/phy/ofdm/equalization.py
+(``OFDMEqualizer`` :17-275, ``LMMSEEqualizer`` :277-344).  The whole ``call`` (layout changes,
+interference-plus-noise covariance, per-RE LMMSE solve, stream re-ordering, data-symbol gather)
+is ONE HIP kernel, ``samd_ofdm_lmmse_c64`` (csrc/mimo.hip)."""
+import numpy as np
+import torch
+
+from ... import _ffi
+from ..block import Block
+
+
+class OFDMEqualizer(Block):
+    """Base class kept for API parity.  Only the LMMSE equaliser has a HIP path; a user-supplied
+    ``equalizer`` callable would have to run per resource element on the host, which this build
+    deliberately does not offer."""
+
+    def __init__(self, equalizer, resource_grid, stream_management, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        if equalizer != "lmmse":
+            raise NotImplementedError("OFDMEqualizer: only the fused LMMSE equaliser is on the MI355X hot path")
+        self._rg, self._sm = resource_grid, stream_management
+        self._whiten = True
+        self._dev = None
+
+    def _tables(self):
+        if self._dev is None:
+            rg, sm = self._rg, self._sm
+            s = rg.num_tx * rg.num_streams_per_tx
+            nre = rg.num_ofdm_symbols * rg.num_effective_subcarriers
+            di = rg._data_ind_eff()                                              # [S, num_data]
+            data_pos = np.full((s, nre), -1, np.int32)
+            np.put_along_axis(data_pos, di, np.arange(di.shape[1], dtype=np.int32)[None, :], axis=1)
+            desired = np.asarray(sm.rx_stream_ids, np.int32)                     # [RX, K]
+            all_ids = np.arange(s)
+            undesired = np.stack([np.setdiff1d(all_ids, desired[i]) for i in range(sm.num_rx)]).astype(np.int32)
+            i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
+            self._dev = (i32(rg.effective_subcarrier_ind), i32(desired), i32(undesired) if undesired.size else None,
+                         i32(data_pos), undesired.shape[1])
+        return self._dev
+
+    def call(self, y, h_hat, err_var, no):
+        self._require_single()
+        rg, sm = self._rg, self._sm
+        y = _ffi.to_device(y, torch.complex64)
+        h_hat = _ffi.to_device(h_hat, torch.complex64)
+        b, rx, m = y.shape[:3]
+        s = rg.num_tx * rg.num_streams_per_tx
+        t, f = rg.num_ofdm_symbols, rg.num_effective_subcarriers
+        assert tuple(h_hat.shape) == (b, rx, m, rg.num_tx, rg.num_streams_per_tx, t, f), "unexpected h_hat shape"
+        # err_var: broadcastable to h_hat.  Recognise the two compact forms, expand anything else.
+        ev = _ffi.to_device(err_var, torch.float32)
+        ev = ev.reshape((1,) * (7 - ev.dim()) + tuple(ev.shape)) if ev.dim() < 7 else ev
+        if ev.numel() == 1 and float(ev.reshape(-1)[0]) == 0.0:
+            ev_mode, ev_arg = 0, None
+        elif ev.shape[:3] == (1, 1, 1):
+            ev_mode = 1
+            ev_arg = torch.broadcast_to(ev, (1, 1, 1, rg.num_tx, rg.num_streams_per_tx, t, f)).contiguous()
+        else:
+            ev_mode, ev_arg = 2, torch.broadcast_to(ev, tuple(h_hat.shape)).contiguous()
+        no = _ffi.to_device(no, torch.float32)
+        no = torch.broadcast_to(no.reshape(tuple(no.shape) + (1,) * (3 - no.dim())), (b, rx, m)).contiguous()
+        sc_ind, desired, undesired, data_pos, n_und = self._tables()
+        nd = rg.num_data_symbols
+        x_hat = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.complex64, device=y.device)
+        no_eff = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.float32, device=y.device)
+        _ffi.check(_ffi.lib().samd_ofdm_lmmse_c64(
+            _ffi.ptr(y), _ffi.ptr(h_hat), _ffi.ptr(ev_arg), ev_mode, _ffi.ptr(no), _ffi.ptr(sc_ind), _ffi.ptr(desired),
+            _ffi.ptr(undesired), _ffi.ptr(data_pos), b, rx, m, s, sm.num_streams_per_rx, n_und, t, f, rg.fft_size, nd,
+            int(self._whiten), _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.stream()), "LMMSEEqualizer")
+        return x_hat, no_eff
+
+
+class LMMSEEqualizer(OFDMEqualizer):
+    """``LMMSEEqualizer(resource_grid, stream_management, whiten_interference=True)``
+    ``(y, h_hat, err_var, no) -> (x_hat, no_eff)`` [batch, num_tx, num_streams, num_data_symbols]."""
+
+    def __init__(self, resource_grid, stream_management, whiten_interference=True, precision=None, **kwargs):
+        super().__init__("lmmse", resource_grid, stream_management, precision=precision, **kwargs)
+        self._whiten = bool(whiten_interference)

@@ -1,0 +1,235 @@
+"""GPU parity tests of the OFDM / MIMO part of the hot path (north-star config C4) against
+oracle/ofdm.py on the same inputs and the same Philox streams.
+
+The reference pins these blocks only statistically or through invariants (SURVEY.md section 4:
+LMMSE error statistics, whitening -> identity covariance, TDL power-delay profile, "ber == 0" at
+high SNR); the same invariants are asserted here next to the value-level comparison with the
+oracle (complex64 arithmetic: rtol 1e-4 / atol 1e-5 unless stated)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ofdm as o, mapping as omap, utils as outil
+
+
+@pytest.fixture(scope="module")
+def phy():
+    import sionna_amd.phy as p
+    from sionna_amd import _ffi
+    _ffi.device()
+    return p
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _grids(phy, num_tx=1, ns=2, fft=76, guards=(5, 6), dc=True, pilots=(2, 11)):
+    kw = dict(num_tx=num_tx, num_streams_per_tx=ns, cyclic_prefix_length=6, num_guard_carriers=list(guards),
+              dc_null=dc, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=list(pilots))
+    return phy.ofdm.ResourceGrid(14, fft, 15e3, **kw), o.ResourceGrid(14, fft, 15e3, **kw)
+
+
+def _tdl_params(phy, model="A", ds=300e-9):
+    t = phy.channel.tr38901.TDL(model, ds, 2.6e9, min_speed=10., num_rx_ant=4, num_tx_ant=2)
+    return t
+
+
+def test_resource_grid_tables_match_oracle(phy):
+    for kw in (dict(), dict(num_tx=2, ns=1), dict(fft=64, guards=(0, 0), dc=False, pilots=(0,)), dict(num_tx=2, ns=2, fft=72, guards=(3, 4))):
+        rg, org = _grids(phy, **kw)
+        assert np.array_equal(rg.build_type_grid(), org.build_type_grid())
+        assert np.array_equal(rg.effective_subcarrier_ind, org.effective_subcarrier_ind)
+        assert np.allclose(rg.pilot_pattern.pilots, org.pilot_pattern.pilots)
+        assert (rg.num_data_symbols, rg.num_pilot_symbols, rg.dc_ind) == (org.num_data_symbols, org.num_pilot_symbols, org.dc_ind)
+        assert np.array_equal(phy.ofdm.NearestNeighborInterpolator(rg.pilot_pattern).gather_ind, o.nn_gather_ind(org.pilot_pattern))
+
+
+def test_rg_mapper_demapper_roundtrip(phy):
+    rg, org = _grids(phy, num_tx=2, ns=2, fft=72, guards=(3, 4))
+    sm = phy.mimo.StreamManagement([[1, 0], [0, 1]], 2)
+    rng = np.random.default_rng(0)
+    x = (rng.normal(size=(5, 2, 2, rg.num_data_symbols)) + 1j * rng.normal(size=(5, 2, 2, rg.num_data_symbols))).astype(np.complex64)
+    grid = _np(phy.ofdm.ResourceGridMapper(rg)(x))
+    assert np.array_equal(grid, o.rg_map(org, x))
+    assert np.array_equal(_np(phy.ofdm.RemoveNulledSubcarriers(rg)(grid)), o.remove_nulled(org, grid))
+    # [b, rx, streams_per_rx, T, fft] with identity association -> back to the data symbols
+    back = _np(phy.ofdm.ResourceGridDemapper(rg, sm)(grid))
+    assert np.array_equal(back, x)
+
+
+@pytest.mark.parametrize("model", ["A", "C", "D"])
+def test_tdl_matches_oracle_and_statistics(phy, model):
+    phy.config.seed = 11
+    tdl = phy.channel.tr38901.TDL(model, 300e-9, 2.6e9, min_speed=3., max_speed=30., num_rx_ant=4, num_tx_ant=2)
+    fs = 1 / 71.4e-6
+    a, tau = tdl(64, 14, fs)
+    ref_a, ref_tau = o.tdl_cir(11, 0, 64, 14, fs, tdl.delays, tdl._mean_powers, tdl._min_doppler, tdl._max_doppler, 4, 2, 20,
+                               los_power=tdl._los_power if tdl.los else None)
+    assert a.shape == (64, 1, 4, 1, 2, tdl.num_clusters, 14) and tau.shape == (64, 1, 1, tdl.num_clusters)
+    assert np.allclose(_np(a), ref_a, rtol=1e-3, atol=2e-4)          # f32 sincos of arguments up to ~1e2
+    assert np.allclose(_np(tau), ref_tau)
+    # power delay profile (test_3gpp_channel_tdl.py:156-263): mean tap powers, unit total power
+    a2, _ = tdl(4096, 1, fs)
+    p = np.mean(np.abs(_np(a2)) ** 2, axis=(0, 1, 2, 3, 4, 6))
+    assert np.allclose(p, tdl.mean_powers, rtol=0.12, atol=2e-3)
+    assert abs(p.sum() - 1) < 0.03
+
+
+def test_cir_to_ofdm_and_apply_channel(phy):
+    rg, org = _grids(phy)
+    phy.config.seed = 5
+    tdl = _tdl_params(phy)
+    a, tau = tdl(8, 14, 1 / rg.ofdm_symbol_duration)
+    fr = phy.channel.subcarrier_frequencies(76, 15e3)
+    assert np.array_equal(fr, o.subcarrier_frequencies(76, 15e3))
+    for norm in (False, True):
+        h = _np(phy.channel.cir_to_ofdm_channel(fr, a, tau, normalize=norm))
+        ref = o.cir_to_ofdm_channel(fr, _np(a), _np(tau), normalize=norm)
+        assert np.allclose(h, ref, rtol=1e-4, atol=2e-5)
+    assert abs(np.mean(np.abs(h) ** 2) - 1) < 1e-4                   # unit energy after normalisation
+    rng = np.random.default_rng(1)
+    x = (rng.normal(size=(8, 1, 2, 14, 76)) + 1j * rng.normal(size=(8, 1, 2, 14, 76))).astype(np.complex64)
+    y = _np(phy.channel.ApplyOFDMChannel()(x, h))
+    assert np.allclose(y, o.apply_ofdm_channel(x, h), rtol=1e-4, atol=1e-5)   # test_apply_channel.py:62-104 uses 1e-5
+
+
+def test_ofdm_channel_block_and_rayleigh(phy):
+    rg, _ = _grids(phy)
+    phy.config.seed = 6
+    ch = phy.channel.OFDMChannel(_tdl_params(phy), rg, normalize_channel=True, return_channel=True, add_awgn=True)
+    x = torch.zeros((16, 1, 2, 14, 76), dtype=torch.complex64).cuda() + 1
+    y, h = ch(x, 0.0)
+    assert y.shape == (16, 1, 4, 14, 76) and h.shape == (16, 1, 4, 1, 2, 14, 76)
+    assert np.allclose(_np(y), _np(h).sum(axis=(3, 4)), rtol=1e-4, atol=1e-5)
+    ray = phy.channel.RayleighBlockFading(1, 4, 1, 2)
+    a, tau = ray(20000, 3)
+    assert a.shape == (20000, 1, 4, 1, 2, 1, 3) and float(tau.abs().max()) == 0
+    an = _np(a)
+    assert abs(np.mean(np.abs(an) ** 2) - 1) < 0.02 and np.array_equal(an[..., 0], an[..., 2])
+
+
+def test_ls_estimator_matches_oracle(phy):
+    rg, org = _grids(phy, num_tx=2, ns=1)
+    rng = np.random.default_rng(2)
+    y = (rng.normal(size=(6, 1, 4, 14, 76)) + 1j * rng.normal(size=(6, 1, 4, 14, 76))).astype(np.complex64)
+    for interp in ("nn", None):
+        h_hat, ev = phy.ofdm.LSChannelEstimator(rg, interpolation_type=interp)(y, 0.07)
+        rh, rev = o.ls_estimate(org, y, 0.07, interp)
+        assert h_hat.shape == rh.shape
+        assert np.allclose(_np(h_hat), rh, rtol=1e-5, atol=1e-6)
+        assert np.allclose(_np(ev), rev, rtol=1e-6) and np.broadcast_shapes(tuple(ev.shape), rh.shape) == rh.shape
+    # per-batch noise variance
+    no_b = rng.uniform(0.01, 1, size=(6,)).astype(np.float32)
+    _, ev = phy.ofdm.LSChannelEstimator(rg)(y, no_b)
+    assert ev.shape[0] == 6 and np.allclose(_np(ev)[3], o.ls_estimate(org, y, no_b[3])[1][0], rtol=1e-6)
+
+
+@pytest.mark.parametrize("m,k", [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 2), (8, 4)])
+@pytest.mark.parametrize("whiten", [True, False])
+def test_lmmse_equalizer_vs_oracle(phy, m, k, whiten):
+    rng = np.random.default_rng(m * 10 + k)
+    n = 500
+    h = (rng.normal(size=(n, m, k)) + 1j * rng.normal(size=(n, m, k))).astype(np.complex64) / np.sqrt(2)
+    q = (rng.normal(size=(n, m, m)) + 1j * rng.normal(size=(n, m, m))).astype(np.complex64)
+    s = (0.1 * q @ np.conj(np.swapaxes(q, -1, -2)) + 0.05 * np.eye(m)).astype(np.complex64)   # coloured noise
+    x = omap.qam(4)[rng.integers(0, 16, (n, k))]
+    y = ((h @ x[..., None])[..., 0] + 0.1 * (rng.normal(size=(n, m)) + 1j * rng.normal(size=(n, m)))).astype(np.complex64)
+    xh, ne = phy.mimo.lmmse_equalizer(y, h, s, whiten)
+    rx, rn = o.lmmse_equalizer(y, h, s, whiten)
+    assert np.allclose(_np(xh), rx, rtol=2e-3, atol=2e-4)
+    assert np.allclose(_np(ne), rn, rtol=2e-3, atol=2e-5)
+    assert np.all(_np(ne) > 0)
+
+
+def test_lmmse_error_statistics(phy):
+    # test_mimo_equalizers.py:55-102: unbiased estimate, error variance == no_eff
+    rng = np.random.default_rng(3)
+    n, m, k = 200000, 8, 4
+    h = ((rng.normal(size=(n, m, k)) + 1j * rng.normal(size=(n, m, k))) / np.sqrt(2)).astype(np.complex64)
+    x = omap.qam(2)[rng.integers(0, 4, (n, k))]
+    no = 0.3
+    w = np.sqrt(no / 2) * (rng.normal(size=(n, m)) + 1j * rng.normal(size=(n, m)))
+    y = ((h @ x[..., None])[..., 0] + w).astype(np.complex64)
+    s = (no * np.eye(m)).astype(np.complex64)
+    xh, ne = phy.mimo.lmmse_equalizer(y, h, np.broadcast_to(s, (n, m, m)).copy())
+    err = _np(xh) - x
+    assert abs(np.mean(err)) < 5e-3
+    assert abs(np.mean(np.abs(err) ** 2) - np.mean(_np(ne))) / np.mean(_np(ne)) < 1e-2
+
+
+@pytest.mark.parametrize("cfg", ["c4", "two_tx_interference", "two_rx"])
+def test_fused_ofdm_lmmse_vs_oracle(phy, cfg):
+    if cfg == "c4":
+        (rg, org), assoc, ns, nra, nta = _grids(phy), [[1]], 2, 4, 2
+    elif cfg == "two_tx_interference":      # one receiver detects tx 0, tx 1 is an interferer... both detected here
+        (rg, org), assoc, ns, nra, nta = _grids(phy, num_tx=2, ns=1), [[1, 1]], 1, 4, 1
+    else:                                   # two receivers, each detects its own transmitter, the other interferes
+        (rg, org), assoc, ns, nra, nta = _grids(phy, num_tx=2, ns=2, fft=72, guards=(3, 4)), [[1, 0], [0, 1]], 2, 4, 2
+    sm, osm = phy.mimo.StreamManagement(assoc, ns), o.StreamManagement(assoc, ns)
+    nrx, ntx = len(assoc), len(assoc[0])
+    rng = np.random.default_rng(4)
+    B = 5
+    x = omap.qam(2)[rng.integers(0, 4, (B, ntx, ns, rg.num_data_symbols))]
+    grid = o.rg_map(org, x)
+    h = ((rng.normal(size=(B, nrx, nra, ntx, nta, 14, rg.fft_size)) + 1j * rng.normal(size=(B, nrx, nra, ntx, nta, 14, rg.fft_size))) / np.sqrt(2)).astype(np.complex64)
+    no = 0.05
+    y = o.apply_ofdm_channel(grid, h)
+    y = (y + np.sqrt(no / 2) * (rng.normal(size=y.shape) + 1j * rng.normal(size=y.shape))).astype(np.complex64)
+    assert nta == ns
+    h_perf = o.remove_nulled(org, h)                       # streams = tx antennas (no precoding)
+    # perfect CSI, err_var = 0
+    xh, ne = phy.ofdm.LMMSEEqualizer(rg, sm)(y, h_perf, 0., no)
+    rxh, rne = o.ofdm_lmmse_equalize(org, osm, y, h_perf, np.zeros((1,) * 7, np.float32), no)
+    assert np.allclose(_np(xh), rxh, rtol=2e-3, atol=3e-4) and np.allclose(_np(ne), rne, rtol=2e-3, atol=1e-5)
+    # LS + nearest neighbour with its error variance table; per-batch noise
+    no_b = rng.uniform(0.02, 0.1, size=(B,)).astype(np.float32)
+    h_hat, ev = phy.ofdm.LSChannelEstimator(rg)(y, no_b)
+    xh2, ne2 = phy.ofdm.LMMSEEqualizer(rg, sm, whiten_interference=False)(y, h_hat, ev, no_b)
+    rh, rev = o.ls_estimate(org, y, 1.0)
+    rev = rev * no_b.reshape(B, 1, 1, 1, 1, 1, 1)
+    rxh2, rne2 = o.ofdm_lmmse_equalize(org, osm, y, rh, rev, no_b, whiten_interference=False)
+    assert np.allclose(_np(xh2), rxh2, rtol=2e-3, atol=3e-4) and np.allclose(_np(ne2), rne2, rtol=2e-3, atol=1e-5)
+    # detector = equaliser + demapper
+    det = phy.ofdm.LinearDetector("lmmse", "bit", "maxlog", rg, sm, "qam", 2)
+    llr = det(y, h_perf, 0., no)
+    ref_llr = omap.demapper(rxh, rne, omap.qam(2), "maxlog")
+    assert llr.shape == (B, ntx, ns, rg.num_data_symbols * 2)
+    assert np.allclose(_np(llr), ref_llr, rtol=5e-3, atol=5e-3)
+
+
+def test_c4_chain_high_snr_is_error_free(phy):
+    """Config C4 end to end (TDL-A 300 ns, 4x2, LS-NN + LMMSE + LDPC) at 25 dB: BER == 0
+    (the reference's own bar for this chain, test_mimo_ofdm_estimation_detection.py:183-195)."""
+    rg, _ = _grids(phy)
+    sm = phy.mimo.StreamManagement([[1]], 2)
+    k, n, m = 768, 1536, 2
+    assert rg.num_data_symbols * m == n
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=20)
+    src, mapper, rgm = phy.mapping.BinarySource(), phy.mapping.Mapper("qam", m), phy.ofdm.ResourceGridMapper(rg)
+    ch = phy.channel.OFDMChannel(_tdl_params(phy), rg, normalize_channel=True, return_channel=True)
+    est, eq, demap = phy.ofdm.LSChannelEstimator(rg), phy.ofdm.LMMSEEqualizer(rg, sm), phy.mapping.Demapper("app", "qam", m)
+    remove = phy.ofdm.RemoveNulledSubcarriers(rg)
+
+    def mc_fun(batch_size, ebno_db, perfect_csi=False):
+        no = phy.utils.ebnodb2no(ebno_db, m, k / n, rg)
+        b = src([batch_size, 1, 2, k])
+        x_rg = rgm(mapper(enc(b)))
+        y, h = ch(x_rg, no)
+        if perfect_csi:
+            h_hat, ev = remove(h), 0.
+        else:
+            h_hat, ev = est(y, no)
+        x_hat, no_eff = eq(y, h_hat, ev, no)
+        return b, dec(demap(x_hat, no_eff))
+
+    phy.config.seed = 8
+    for perfect in (True, False):
+        b, b_hat = mc_fun(64, 25.0, perfect)
+        assert b_hat.shape == b.shape == (64, 1, 2, k)
+        assert float((b != b_hat).float().mean()) == 0.0
+    ber, bler = phy.utils.sim_ber(mc_fun, [-5.0, 25.0], batch_size=32, max_mc_iter=2, verbose=False)
+    assert ber.numpy()[0] > 0.05 and ber.numpy()[1] == 0

@@ -40,3 +40,20 @@ for bg, (nrow, ncol) in (("bg1", (46, 68)), ("bg2", (42, 52))):
 dst = os.path.join(os.path.dirname(__file__), "..", "sionna_amd/phy/fec/ldpc/codes/bg_tables.npz")
 np.savez_compressed(dst, **out)
 print("wrote", os.path.normpath(dst))
+
+# ---- TDL power-delay profiles (3GPP TR 38.901 Tables 7.7.2-1..5 and the A30/B100/C300 variants
+# of TS 38.101/38.104), shipped by the reference as channel/tr38901/models/TDL-*.json
+# (parsed at channel/tr38901/tdl.py:539-600).  Re-packed into one JSON.
+import json
+tdl = {}
+mdir = os.path.join(ref, "src/sionna/phy/channel/tr38901/models")
+for name in ("A", "B", "C", "D", "E", "A30", "B100", "C300"):
+    with open(os.path.join(mdir, f"TDL-{name}.json")) as f:
+        p = json.load(f)
+    tdl[name] = {"los": int(p["los"]), "scale_delays": int(p["scale_delays"]),
+                 "num_clusters": int(p["num_clusters"]), "delays": [float(v) for v in p["delays"]],
+                 "powers": [float(v) for v in p["powers"]]}
+dst = os.path.join(os.path.dirname(__file__), "..", "sionna_amd/phy/channel/tr38901/tdl_models.json")
+with open(dst, "w") as f:
+    json.dump(tdl, f)
+print("wrote", os.path.normpath(dst))
