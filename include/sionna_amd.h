@@ -226,6 +226,33 @@ int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const float* err_var
                         void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * CRC and Polar codes (config C5 of the north star).
+ * ---------------------------------------------------------------------------------- */
+/* CRCEncoder.call / CRCDecoder.call  fec/crc.py:175-215, 289-321.  poly = coefficients of
+ * x^(crc_len-1)..x^0 of the generator (bit crc_len-1 = x^(crc_len-1)).  check=0: bits
+ * [n_words,k] -> out [n_words,k+crc_len] (bits followed by the parity); check=1: bits
+ * [n_words,k] INCLUDING the received parity -> out [n_words] = 1.0 where the CRC holds. */
+int samd_crc_f32(const float* bits, int64_t n_words, int k, uint32_t poly, int crc_len, int check,
+                 float* out, void* stream);
+
+/* PolarEncoder.call (+ rate-matching gather)  fec/polar/encoding.py:140-209, 732:
+ * u [batch,k] placed at info_pos (DEVICE int32[k]) of a length-n word (n a power of two), polar
+ * transform, out[b,i] = x[out_idx[i]] (DEVICE int32[n_out]). */
+int samd_polar_encode_f32(const float* u, const int32_t* info_pos, const int32_t* out_idx, int batch,
+                          int k, int n, int n_out, float* out, void* stream);
+
+/* PolarSCDecoder / PolarSCLDecoder (default TF path, fast SCL)  fec/polar/decoding.py:122-263,
+ * 525-723, 919-1045, 1345-1437.  llr [batch,n] logits; ops DEVICE int32[num_ops][4] decoding
+ * schedule built by the host (sionna_amd/phy/fec/polar/decoding.py::build_schedule); info_pos
+ * DEVICE int32[k]; iil_inv nullable DEVICE int32[k] (inverse input interleaver applied before the
+ * CRC check); sc_mode=1 -> hard SC decisions (list_size must be 1); crc_len=0 disables the
+ * CRC-aided selection.  u_hat [batch,k]; crc_status nullable [batch]. */
+int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, const int32_t* info_pos,
+                              const int32_t* iil_inv, int batch, int n, int k, int list_size,
+                              int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat,
+                              float* crc_status, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Error counting  utils/metrics.py:94-144 (count_errors, count_block_errors).
  * b, b_hat [num_blocks, block_len] float32; counters: DEVICE int64[2], ADDED to:
  * counters[0] += #(b != b_hat), counters[1] += #blocks with any mismatch.

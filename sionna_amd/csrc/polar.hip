@@ -1,0 +1,338 @@
+// CRC, Polar encoder and successive-cancellation (list) Polar decoder (north-star config C5).
+//
+// Replaces (reference src/sionna/phy/fec/):
+//   CRCEncoder.call / CRCDecoder.call     crc.py:175-215, 289-321  (dense GF(2) generator matmul)
+//   PolarEncoder.call                     polar/encoding.py:140-209 (scatter + log2(n) gather/XOR stages)
+//   PolarSCDecoder                        polar/decoding.py:122-263
+//   PolarSCLDecoder (default TF path, use_fast_scl) polar/decoding.py:525-723, 919-1045, 1345-1437
+//
+// MI355X design of the decoder: the reference unrolls the whole decoding tree into a TF graph
+// whose every leaf step re-concatenates a [batch, 2L, log2(n)+1, n] float state (1.44 MB per
+// codeword at n=1024, L=8) and itself recommends a NumPy fallback for n > 128.  Here ONE
+// workgroup owns one codeword and its complete list state lives in LDS (53 KB at n=1024, L=8):
+//   * LLR memory per path is the compact n-1 floats (stage s = 2^s values), the channel LLRs are
+//     shared by all paths; partial sums are two byte banks (left / right child results) per path;
+//   * only the L live paths are stored: at an information bit each path forks into (u=0, u=1), the
+//     2L candidates are ranked by a stable parallel rank (position order breaks ties - the
+//     behaviour of the reference's sort + duplicate), survivors whose parent also survives are
+//     cloned into the slots of dead parents;
+//   * the decoding schedule (f / g / leaf / rate-0 / repetition / combine operations, exactly the
+//     recursion of polar/decoding.py:919-1005 including the fast-SCL shortcuts) is a flat op list
+//     built once on the host and interpreted by the kernel - no recursion, no divergence;
+//   * CRC-aided selection (penalty llr_max*k on CRC failures, first minimum) runs in the same
+//     kernel; the f-operation is the exact boxplus softplus(x+y) - logsumexp(x,y) with the +-30
+//     clip of the reference.
+// The kernel is latency/synchronisation bound (about 4 n dependent steps per codeword), not
+// bandwidth bound: 4n bytes in, 4k bytes out per codeword.
+#include "common.h"
+
+namespace samd {
+
+// ------------------------------------------------------------------ CRC
+// parity of the systematic CRC with generator polynomial g(x) of degree len, zero initial state
+// (3GPP 38.212 Sec. 5.1): remainder of u(x) x^len / g(x).  poly = coefficients of x^(len-1)..x^0.
+__device__ __forceinline__ uint32_t crc_step(uint32_t reg, uint32_t bit, uint32_t poly, int len) {
+  const uint32_t fb = ((reg >> (len - 1)) & 1u) ^ bit;
+  reg = (reg << 1) & ((len == 32) ? 0xFFFFFFFFu : ((1u << len) - 1u));
+  return fb ? (reg ^ poly) : reg;
+}
+
+// out [N, k+len] = [bits, parity]  (or only the validity flag when check != 0: bits [N, k] incl. parity)
+__global__ __launch_bounds__(256) void crc_kernel(const float* __restrict__ bits, int64_t n_words, int k, uint32_t poly,
+                                                  int len, int check, float* __restrict__ out) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const float* b = bits + w * k;
+  uint32_t reg = 0;
+  for (int i = 0; i < k; ++i) reg = crc_step(reg, (uint32_t)((int)b[i] & 1), poly, len);
+  if (check) { out[w] = reg == 0 ? 1.f : 0.f; return; }
+  float* o = out + w * (k + len);
+  for (int i = 0; i < k; ++i) o[i] = b[i];
+  for (int i = 0; i < len; ++i) o[k + i] = (float)((reg >> (len - 1 - i)) & 1u);
+}
+
+// ------------------------------------------------------------------ Polar encoder
+__global__ __launch_bounds__(256) void polar_encode_kernel(const float* __restrict__ u, const int32_t* __restrict__ info_pos,
+                                                           const int32_t* __restrict__ out_idx, int k, int n,
+                                                           int n_out, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char x[];
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += 256) x[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += 256) x[info_pos[i]] = (unsigned char)((int)u[(size_t)b * k + i] & 1);
+  __syncthreads();
+  for (int s = 1; s < n; s <<= 1) {            // x[d] ^= x[d + s] for every d whose bit s is clear
+    for (int r = threadIdx.x; r < n / 2; r += 256) {
+      const int d = 2 * r - (r & (s - 1));
+      x[d] ^= x[d + s];
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < n_out; i += 256) out[(size_t)b * n_out + i] = (float)x[out_idx[i]];
+}
+
+// ------------------------------------------------------------------ SC / SCL decoder
+enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6 };
+constexpr float kPolarLlrMax = 30.f;
+
+__device__ __forceinline__ float softplus(float x) {       // log(1 + e^x)
+  return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));
+}
+__device__ __forceinline__ float cn_op(float x, float y) {  // polar/decoding.py:684-705
+  x = clampf(x, -kPolarLlrMax, kPolarLlrMax);
+  y = clampf(y, -kPolarLlrMax, kPolarLlrMax);
+  const float lse = fmaxf(x, y) + log1pf(expf(-fabsf(x - y)));
+  return softplus(x + y) - lse;
+}
+
+struct SclArgs {
+  const float* llr_in;     // [B, n] logits
+  float* u_hat;            // [B, k] bits at the information positions of the selected path
+  float* crc_status;       // nullable [B]
+  const int32_t* ops;      // [num_ops][4]
+  const int32_t* info_pos; // [k]
+  const int32_t* iil_inv;  // nullable [k] inverse input interleaver applied before the CRC check
+  int batch, n, m, k, L, sc_mode, crc_len;
+  uint32_t crc_poly;
+};
+
+__global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = p.n, L = p.L, tid = threadIdx.x;
+  const int words = (n + 31) / 32;
+  float* llr_ch = smem;                                   // [n]
+  float* llr = llr_ch + n;                                // [L][n]   stage s at [2^s, 2^(s+1))
+  unsigned char* betaL = reinterpret_cast<unsigned char*>(llr + (size_t)L * n);   // [L][n]
+  unsigned char* betaR = betaL + (size_t)L * n;                                   // [L][n]
+  uint32_t* bits = reinterpret_cast<uint32_t*>(betaR + (size_t)L * n);            // [L][words] decided u bits
+  float* pm = reinterpret_cast<float*>(bits + (size_t)L * words);                 // [L]   by position
+  float* cand = pm + L;                                   // [2L] candidate metrics
+  float* blk = cand + 2 * L;                              // [2L] block metrics (rate-0 / rep)
+  int* order = reinterpret_cast<int*>(blk + 2 * L);       // [L]   position -> slot
+  int* new_order = order + L;                             // [L]
+  int* clone_src = new_order + L;                         // [L]   for new position: slot to copy from (-1: none)
+  int* new_bit = clone_src + L;                           // [L]
+  float* new_pm = reinterpret_cast<float*>(new_bit + L);  // [L]
+  float* red = new_pm + L;                                // [256] reduction scratch
+
+  for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
+    for (int i = tid; i < n; i += 256) llr_ch[i] = -1.f * p.llr_in[(size_t)b * n + i];   // logits -> LLR
+    for (int i = tid; i < L * n; i += 256) { betaL[i] = 0; betaR[i] = 0; }
+    for (int i = tid; i < L * words; i += 256) bits[i] = 0u;
+    if (tid < L) { pm[tid] = tid == 0 ? 0.f : kPolarLlrMax; order[tid] = tid; }         // decoding.py:1029-1033
+    __syncthreads();
+
+    for (int ip = 0;; ++ip) {
+      const int op = p.ops[4 * ip], a0 = p.ops[4 * ip + 1], a1 = p.ops[4 * ip + 2], a2 = p.ops[4 * ip + 3];
+      if (op == OP_END) break;
+      if (op == OP_F || op == OP_G) {
+        // a0 = stage s of the inputs (block of 2^s), outputs go to stage s-1; OP_G uses betaL[s-1]
+        const int s = a0, half = 1 << (s - 1);
+        for (int w = tid; w < L * half; w += 256) {
+          const int pos = w / half, j = w - pos * half;
+          const int slot = order[pos];
+          const float* in = (s == p.m) ? llr_ch : (llr + (size_t)slot * n + (1 << s));
+          const float x = in[j], y = in[j + half];
+          float r;
+          if (op == OP_F) r = cn_op(x, y);
+          else r = (1.f - 2.f * (float)betaL[(size_t)slot * n + half + j]) * x + y;      // vn_op :707-714
+          llr[(size_t)slot * n + half + j] = r;
+        }
+        __syncthreads();
+      } else if (op == OP_COMBINE) {
+        // children results at stage s (a0) -> this node's result at stage s+1 on side a1
+        const int s = a0, sz = 1 << s;
+        for (int w = tid; w < L * sz; w += 256) {
+          const int pos = w / sz, j = w - pos * sz;
+          const size_t base = (size_t)order[pos] * n;
+          const unsigned char l = betaL[base + sz + j], r = betaR[base + sz + j];
+          unsigned char* dst = (a1 ? betaR : betaL) + base + 2 * sz;
+          dst[j] = l ^ r;
+          dst[sz + j] = r;
+        }
+        __syncthreads();
+      } else {
+        // ---- leaf / rate-0 / repetition node: a0 = stage s of the node, a1 = side, a2 = (last) bit index
+        // (frozen leaf: a2 = -1-index)
+        const int s = a0, sz = 1 << s;
+        const bool info = (op == OP_REP) || (op == OP_LEAF && a2 >= 0);
+        // block metrics of every live path: m0 = sum softplus(-l), m1 = sum softplus(+l)
+        for (int pos = 0; pos < L; ++pos) {
+          const int slot = order[pos];
+          const float* in = (s == p.m) ? llr_ch : (llr + (size_t)slot * n + sz);
+          float m0 = 0.f, m1 = 0.f;
+          for (int j = tid; j < sz; j += 256) {
+            const float l = clampf(in[j], -kPolarLlrMax, kPolarLlrMax);
+            m0 += softplus(-l);
+            m1 += softplus(l);
+          }
+          if (sz > 1) {                                       // deterministic tree reduction
+            red[tid] = m0; __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+            m0 = red[0]; __syncthreads();
+            red[tid] = m1; __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+            m1 = red[0]; __syncthreads();
+          }
+          if (tid == 0) { blk[pos] = m0; blk[L + pos] = m1; }
+        }
+        __syncthreads();
+        if (!info) {
+          // frozen leaf / rate-0: metric of the all-zero block, result zeros
+          if (tid < L) pm[tid] += blk[tid];
+          for (int w = tid; w < L * sz; w += 256) {
+            const int pos = w / sz, j = w - pos * sz;
+            ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = 0;
+          }
+          __syncthreads();
+          continue;
+        }
+        // ---- fork: candidates c = u*L + pos
+        if (p.sc_mode) {
+          // PolarSCDecoder leaf: u = 0.5 (1 - sign(l)), exact zero -> 1 (decoding.py:208-212)
+          if (tid == 0) {
+            const float l = ((s == p.m) ? llr_ch : (llr + (size_t)order[0] * n + sz))[0];
+            new_order[0] = order[0]; clone_src[0] = -1; new_bit[0] = (l <= 0.f) ? 1 : 0; new_pm[0] = 0.f;
+          }
+        } else {
+          int* rnk = reinterpret_cast<int*>(red);                                  // [2L] candidate ranks
+          if (tid < 2 * L) cand[tid] = pm[tid % L] + blk[tid];
+          __syncthreads();
+          if (tid < 2 * L) {
+            // stable rank of the 2L candidates (ties: lower candidate index first)
+            int rank = 0;
+            const float me = cand[tid];
+            for (int d = 0; d < 2 * L; ++d) rank += (cand[d] < me || (cand[d] == me && d < tid)) ? 1 : 0;
+            rnk[tid] = rank;
+          }
+          __syncthreads();
+          if (tid == 0) {
+            // survivors (rank < L) take position = rank; a parent's first survivor keeps its slot,
+            // a second survivor is cloned into the slot of a parent without survivors
+            int free_slots[32], nfree = 0;
+            for (int q = 0; q < L; ++q) if (rnk[q] >= L && rnk[L + q] >= L) free_slots[nfree++] = order[q];
+            for (int q = 0; q < L; ++q) {
+              const int slot = order[q], r0 = rnk[q], r1 = rnk[L + q];
+              if (r0 < L) { new_order[r0] = slot; clone_src[r0] = -1; new_bit[r0] = 0; new_pm[r0] = cand[q]; }
+              if (r1 < L) {
+                new_bit[r1] = 1; new_pm[r1] = cand[L + q];
+                if (r0 < L) { new_order[r1] = free_slots[--nfree]; clone_src[r1] = slot; }
+                else { new_order[r1] = slot; clone_src[r1] = -1; }
+              }
+            }
+          }
+        }
+        __syncthreads();
+        // clones: copy the parent's LLRs, partial sums and decided bits
+        for (int r = 0; r < L; ++r) {
+          const int src = clone_src[r];
+          if (src < 0) continue;
+          const int dst = new_order[r];
+          for (int i = tid; i < n; i += 256) {
+            llr[(size_t)dst * n + i] = llr[(size_t)src * n + i];
+            betaL[(size_t)dst * n + i] = betaL[(size_t)src * n + i];
+            betaR[(size_t)dst * n + i] = betaR[(size_t)src * n + i];
+          }
+          for (int i = tid; i < words; i += 256) bits[(size_t)dst * words + i] = bits[(size_t)src * words + i];
+        }
+        __syncthreads();
+        // commit: order, metrics, decided bit (the node's only information bit is its last one), result
+        const int bit_index = a2;
+        if (tid < L) {
+          order[tid] = new_order[tid];
+          pm[tid] = new_pm[tid];
+          if (new_bit[tid]) bits[(size_t)new_order[tid] * words + (bit_index >> 5)] |= 1u << (bit_index & 31);
+        }
+        __syncthreads();
+        for (int w = tid; w < L * sz; w += 256) {
+          const int pos = w / sz, j = w - pos * sz;
+          ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = (unsigned char)new_bit[pos];   // all-u codeword
+        }
+        __syncthreads();
+      }
+    }
+    // ---- final selection (decoding.py:1396-1419): CRC over the info bits of every path, penalty, first min
+    if (tid < L) {
+      const uint32_t* bw = bits + (size_t)order[tid] * words;
+      float pen = 0.f;
+      if (p.crc_len > 0) {
+        uint32_t reg = 0;
+        for (int i = 0; i < p.k; ++i) {
+          const int src = p.iil_inv ? p.iil_inv[i] : i;
+          const int pos = p.info_pos[src];
+          reg = crc_step(reg, (bw[pos >> 5] >> (pos & 31)) & 1u, p.crc_poly, p.crc_len);
+        }
+        blk[tid] = reg == 0 ? 1.f : 0.f;
+        pen = reg == 0 ? 0.f : kPolarLlrMax * (float)p.k;
+      }
+      cand[tid] = pm[tid] + pen;
+    }
+    __syncthreads();
+    int best = 0;
+    for (int q = 1; q < L; ++q) if (cand[q] < cand[best]) best = q;
+    const uint32_t* bw = bits + (size_t)order[best] * words;
+    for (int i = tid; i < p.k; i += 256) {
+      const int pos = p.info_pos[i];
+      p.u_hat[(size_t)b * p.k + i] = (float)((bw[pos >> 5] >> (pos & 31)) & 1u);
+    }
+    if (tid == 0 && p.crc_status) p.crc_status[b] = p.crc_len > 0 ? blk[best] : 1.f;
+    __syncthreads();
+  }
+}
+
+static size_t scl_lds_bytes(int n, int L) {
+  const size_t words = (n + 31) / 32;
+  return (size_t)n * 4 + (size_t)L * n * 4 + 2 * (size_t)L * n + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
+         (size_t)L * 4 * 5 + 256 * 4 + 64;
+}
+
+}  // namespace samd
+
+using namespace samd;
+
+extern "C" int samd_crc_f32(const float* bits, int64_t n_words, int k, uint32_t poly, int crc_len, int check,
+                            float* out, void* stream) {
+  SAMD_REQUIRE(bits && out && n_words >= 0 && k > 0 && crc_len > 0 && crc_len <= 32, "bad argument");
+  if (n_words == 0) return SAMD_OK;
+  hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bits,
+                     n_words, k, poly, crc_len, check, out);
+  return launch_status();
+}
+
+extern "C" int samd_polar_encode_f32(const float* u, const int32_t* info_pos, const int32_t* out_idx, int batch, int k,
+                                     int n, int n_out, float* out, void* stream) {
+  SAMD_REQUIRE(u && info_pos && out_idx && out && batch > 0 && k > 0 && n >= 2 && (n & (n - 1)) == 0 && n <= 65536,
+               "bad argument");
+  hipLaunchKernelGGL(polar_encode_kernel, dim3(batch), dim3(256), n, (hipStream_t)stream, u, info_pos, out_idx, k, n,
+                     n_out, out);
+  return launch_status();
+}
+
+extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, const int32_t* info_pos,
+                                         const int32_t* iil_inv, int batch, int n, int k, int list_size, int sc_mode,
+                                         uint32_t crc_poly, int crc_len, float* u_hat, float* crc_status,
+                                         void* stream) {
+  SAMD_REQUIRE(llr && ops && info_pos && u_hat && batch > 0, "bad argument");
+  SAMD_REQUIRE(n >= 8 && (n & (n - 1)) == 0 && k >= 0 && k <= n, "n must be a power of two >= 8, 0 <= k <= n");
+  SAMD_REQUIRE(list_size >= 1 && list_size <= 32 && (list_size & (list_size - 1)) == 0, "list_size must be a power of two <= 32");
+  const size_t lds = scl_lds_bytes(n, list_size);
+  if (lds > 160 * 1024) {
+    set_error("list state does not fit in LDS (reduce list_size or n)");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  int m = 0;
+  while ((1 << m) < n) ++m;
+  SclArgs p{llr, u_hat, crc_status, ops, info_pos, iil_inv, batch, n, m, k, list_size, sc_mode, crc_len, crc_poly};
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t per_cu = std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds));
+  const int grid = (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+  hipLaunchKernelGGL(polar_scl_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  return launch_status();
+}

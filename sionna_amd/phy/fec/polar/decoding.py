@@ -1,0 +1,277 @@
+"""Polar decoders - mirror of ``sionna.phy.fec.polar.PolarSCDecoder`` / ``PolarSCLDecoder`` /
+``Polar5GDecoder`` (reference src/sionna/phy/fec/polar/decoding.py:15-263, 266-1437, 1774-2086).
+
+The decoding tree of the reference's recursion (decoding.py:919-1005, with the fast-SCL
+rate-0 / repetition shortcuts of :525-599) is flattened ONCE on the host into a list of operations
+that the HIP kernel ``samd_polar_scl_decode_f32`` interprets with one workgroup per codeword and the
+whole list state in LDS (csrc/polar.hip).  BP decoding and the hybrid SC/NumPy-SCL mode are outside
+the hot path."""
+import numbers
+
+import numpy as np
+import torch
+
+from .... import _ffi
+from ...block import Block
+from ..crc import CRCEncoder, CRCDecoder, crc_poly_mask
+from .encoding import Polar5GEncoder, _channel_pattern, _subblock_pattern, _input_pattern
+
+OP_F, OP_G, OP_LEAF, OP_RATE0, OP_REP, OP_COMBINE, OP_END = range(7)
+
+
+def build_schedule(frozen_ind, use_fast=True, use_rep=True):
+    """Flatten the SC(L) decoding recursion into [num_ops, 4] int32 records (op, a0, a1, a2).
+
+    F/G:      a0 = stage s of the inputs (outputs go to stage s-1)
+    LEAF:     a0 = 0, a1 = side (0 left / 1 right result bank), a2 = bit index (info) or -1-index (frozen)
+    RATE0:    a0 = stage, a1 = side
+    REP:      a0 = stage, a1 = side, a2 = index of the node's only information bit (its last)
+    COMBINE:  a0 = stage of the two children, a1 = side of the parent
+    """
+    frozen_ind = np.asarray(frozen_ind).astype(int)
+    ops = []
+
+    def node(start, s, side, root):
+        size = 1 << s
+        if s == 0:
+            ops.append((OP_LEAF, 0, side, -1 - start if frozen_ind[start] else start))
+            return
+        blk = frozen_ind[start:start + size]
+        if use_fast:
+            if blk.sum() == size:
+                ops.append((OP_RATE0, s, side, 0))
+                return
+            if use_rep and blk[-1] == 0 and blk[:-1].sum() == size - 1:
+                ops.append((OP_REP, s, side, start + size - 1))
+                return
+        ops.append((OP_F, s, 0, 0))
+        node(start, s - 1, 0, False)
+        ops.append((OP_G, s, 0, 0))
+        node(start + size // 2, s - 1, 1, False)
+        if not root:
+            ops.append((OP_COMBINE, s - 1, side, 0))
+
+    node(0, int(np.log2(len(frozen_ind))), 0, True)
+    ops.append((OP_END, 0, 0, 0))
+    return np.asarray(ops, np.int32)
+
+
+class _PolarListDecoderBase(Block):
+    """Shared engine of the SC and SCL decoders."""
+
+    def _setup(self, frozen_pos, n, list_size, sc_mode, crc_degree, use_fast, ind_iil_inv):
+        if not isinstance(n, numbers.Number):
+            raise TypeError("n must be a number.")
+        n = int(n)
+        frozen_pos = np.asarray(frozen_pos)
+        if not np.issubdtype(frozen_pos.dtype, np.integer):
+            raise TypeError("frozen_pos contains non int.")
+        if len(frozen_pos) > n:
+            raise ValueError("Num. of elements in frozen_pos cannot be greater than n.")
+        if np.log2(n) != int(np.log2(n)):
+            raise ValueError("n must be a power of 2.")
+        self._n = n
+        self._frozen_pos = frozen_pos
+        self._k = n - len(frozen_pos)
+        self._info_pos = np.setdiff1d(np.arange(n), frozen_pos)
+        if self._k != len(self._info_pos):
+            raise ArithmeticError("Internal error: invalid info_pos generated.")
+        self._frozen_ind = np.zeros(n, int)
+        self._frozen_ind[frozen_pos] = 1
+        self._list_size, self._sc_mode = int(list_size), int(sc_mode)
+        self._llr_max = 30.
+        # the SC decoder of the reference prunes rate-0 sub-trees only (decoding.py:186-190)
+        self._ops = build_schedule(self._frozen_ind, use_fast, use_rep=not sc_mode)
+        self._crc_len, self._crc_mask = (crc_poly_mask(crc_degree) if crc_degree is not None else (0, 0))
+        self._ind_iil_inv = None if ind_iil_inv is None else np.asarray(ind_iil_inv, np.int32)
+        self._dev = None
+
+    n = property(lambda self: self._n)
+    k = property(lambda self: self._k)
+    frozen_pos = property(lambda self: self._frozen_pos)
+    info_pos = property(lambda self: self._info_pos)
+    llr_max = property(lambda self: self._llr_max)
+
+    def _decode_2d(self, llr, want_status=False):
+        if self._dev is None:
+            i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
+            self._dev = (i32(self._ops), i32(self._info_pos),
+                         i32(self._ind_iil_inv) if self._ind_iil_inv is not None else None)
+        ops, info, iil = self._dev
+        b = llr.shape[0]
+        u_hat = torch.empty((b, self._k), dtype=torch.float32, device=llr.device)
+        status = torch.empty((b,), dtype=torch.float32, device=llr.device) if want_status else None
+        if b > 0:
+            _ffi.check(_ffi.lib().samd_polar_scl_decode_f32(
+                _ffi.ptr(llr), _ffi.ptr(ops), _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size,
+                self._sc_mode, self._crc_mask, self._crc_len, _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.stream()),
+                type(self).__name__)
+        return u_hat, status
+
+    def build(self, input_shape):
+        if input_shape[-1] != self._n:
+            raise ValueError("Invalid input shape.")
+
+
+class PolarSCDecoder(_PolarListDecoderBase):
+    """``PolarSCDecoder(frozen_pos, n)(llr_ch[..., n]) -> u_hat[..., k]`` (decoding.py:15-263)."""
+
+    def __init__(self, frozen_pos, n, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._setup(frozen_pos, n, 1, 1, None, True, None)     # rate-0 shortcut = use_fast_sc (:186-190)
+
+    def call(self, llr_ch, /):
+        self._require_single()
+        llr = _ffi.to_device(llr_ch, torch.float32)
+        if llr.shape[-1] != self._n:
+            raise ValueError("Invalid input shape.")
+        u_hat, _ = self._decode_2d(llr.reshape(-1, self._n))
+        return u_hat.reshape(tuple(llr.shape[:-1]) + (self._k,))
+
+
+class PolarSCLDecoder(_PolarListDecoderBase):
+    """``PolarSCLDecoder(frozen_pos, n, list_size=8, crc_degree=None, use_hybrid_sc=False,
+    use_fast_scl=True, cpu_only=False, use_scatter=False, ind_iil_inv=None, return_crc_status=False)``
+    (decoding.py:266-1437).  ``cpu_only`` / ``use_scatter`` only select between equivalent TF
+    implementations in the reference and are accepted and ignored."""
+
+    def __init__(self, frozen_pos, n, list_size=8, crc_degree=None, use_hybrid_sc=False, use_fast_scl=True,
+                 cpu_only=False, use_scatter=False, ind_iil_inv=None, return_crc_status=False, precision=None,
+                 **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        for name, v in (("cpu_only", cpu_only), ("use_scatter", use_scatter), ("use_fast_scl", use_fast_scl),
+                        ("use_hybrid_sc", use_hybrid_sc), ("return_crc_status", return_crc_status)):
+            if not isinstance(v, bool):
+                raise TypeError(f"{name} must be bool.")
+        if not isinstance(list_size, int):
+            raise TypeError("list_size must be integer.")
+        if np.log2(list_size) != int(np.log2(list_size)):
+            raise ValueError("list_size must be a power of 2.")
+        if use_hybrid_sc:
+            raise NotImplementedError("PolarSCLDecoder: the hybrid SC / NumPy-SCL mode is a CPU work-around of the "
+                                      "reference and has no place on the MI355X path - use plain SCL")
+        self._setup(frozen_pos, n, list_size, 0, crc_degree, use_fast_scl, ind_iil_inv)
+        if crc_degree is not None:
+            self._crc_encoder = CRCEncoder(crc_degree, precision=precision)
+            self._crc_decoder = CRCDecoder(self._crc_encoder, precision=precision)
+            self._k_crc = self._crc_encoder.crc_length
+        else:
+            self._k_crc = 0
+        if self._k < self._k_crc:
+            raise ValueError("Value of k is too small for given CRC_degree.")
+        if crc_degree is None and return_crc_status:
+            raise ValueError("Returning CRC status requires given crc_degree.")
+        if ind_iil_inv is not None and len(ind_iil_inv) != self._k:
+            raise ValueError("ind_int must be of length k+k_crc.")
+        self._return_crc_status = return_crc_status
+
+    list_size = property(lambda self: self._list_size)
+    k_crc = property(lambda self: self._k_crc)
+
+    def call(self, llr_ch):
+        self._require_single()
+        llr = _ffi.to_device(llr_ch, torch.float32)
+        if llr.shape[-1] != self._n:
+            raise ValueError("Invalid input shape.")
+        u_hat, status = self._decode_2d(llr.reshape(-1, self._n), self._return_crc_status)
+        u_hat = u_hat.reshape(tuple(llr.shape[:-1]) + (self._k,))
+        if self._return_crc_status:
+            return u_hat, (status > 0.5).reshape(tuple(llr.shape[:-1]))
+        return u_hat
+
+
+class Polar5GDecoder(Block):
+    """``Polar5GDecoder(enc_polar, dec_type="SC", list_size=8, num_iter=20, return_crc_status=False)``:
+    rate recovery (channel de-interleaving, repetition combining / puncturing zeros / shortening
+    LLRs, sub-block de-interleaving), SC or CRC-aided SCL decoding, CRC removal
+    (decoding.py:1774-2086)."""
+
+    def __init__(self, enc_polar, dec_type="SC", list_size=8, num_iter=20, return_crc_status=False,
+                 precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        if not isinstance(enc_polar, Polar5GEncoder):
+            raise TypeError("enc_polar must be Polar5GEncoder.")
+        if not isinstance(dec_type, str):
+            raise TypeError("dec_type must be str.")
+        if not isinstance(return_crc_status, bool):
+            raise TypeError("return_crc_status must be bool.")
+        self._enc_polar = enc_polar
+        self._k_target, self._n_target = enc_polar.k_target, enc_polar.n_target
+        self._k_polar, self._n_polar = enc_polar.k_polar, enc_polar.n_polar
+        self._k_crc = enc_polar.enc_crc.crc_length
+        self._bil = enc_polar._channel_type == "uplink"
+        self._iil = enc_polar._channel_type == "downlink"
+        self._llr_max = 100.
+        self._dec_type = dec_type
+        self._return_crc_status = return_crc_status
+        self._ind_iil_inv = np.argsort(_input_pattern(self._k_polar)) if self._iil else None
+        if dec_type == "SC":
+            self._polar_dec = PolarSCDecoder(enc_polar.frozen_pos, self._n_polar, precision=precision)
+        elif dec_type == "SCL":
+            self._polar_dec = PolarSCLDecoder(enc_polar.frozen_pos, self._n_polar, crc_degree=enc_polar.enc_crc.crc_degree,
+                                              list_size=list_size, ind_iil_inv=self._ind_iil_inv, precision=precision)
+        elif dec_type in ("hybSCL", "BP"):
+            raise NotImplementedError(f"Polar5GDecoder: dec_type '{dec_type}' is outside the MI355X hot path (SC / SCL)")
+        else:
+            raise ValueError("Unknown value for dec_type.")
+        self._dec_crc = CRCDecoder(enc_polar.enc_crc, precision=precision) if return_crc_status else None
+        # rate-recovery gather: dematched[j] = sum of llr[src] over the received positions mapped to j
+        n, npol = self._n_target, self._n_polar
+        ch_inv = np.argsort(_channel_pattern(n)) if self._bil else np.arange(n)
+        sub_inv = np.argsort(_subblock_pattern(npol))
+        self._fill = 0.0
+        if n >= npol:                       # repetition: positions 0..n_rep-1 are received twice
+            n_rep = n - npol
+            a = np.concatenate([np.arange(n_rep), np.arange(n_rep, npol)])
+            b = np.concatenate([np.arange(npol, n), np.full(npol - n_rep, -1)])
+        elif self._k_polar / n <= 7 / 16:   # puncturing: first n_polar-n positions unknown (LLR 0)
+            a = np.concatenate([np.full(npol - n, -1), np.arange(n)])
+            b = np.full(npol, -1)
+        else:                               # shortening: last positions are known zeros (logit -llr_max)
+            a = np.concatenate([np.arange(n), np.full(npol - n, -2)])
+            b = np.full(npol, -1)
+        a, b = a[sub_inv], b[sub_inv]
+        self._src_a = np.where(a >= 0, ch_inv[np.clip(a, 0, n - 1)], a)
+        self._src_b = np.where(b >= 0, ch_inv[np.clip(b, 0, n - 1)], b)
+        self._dev = None
+
+    k_target = property(lambda self: self._k_target)
+    n_target = property(lambda self: self._n_target)
+    k_polar = property(lambda self: self._k_polar)
+    n_polar = property(lambda self: self._n_polar)
+    frozen_pos = property(lambda self: self._enc_polar.frozen_pos)
+    info_pos = property(lambda self: self._enc_polar.info_pos)
+    llr_max = property(lambda self: self._llr_max)
+    dec_type = property(lambda self: self._dec_type)
+    polar_dec = property(lambda self: self._polar_dec)
+
+    def build(self, input_shape):
+        if input_shape[-1] != self._n_target:
+            raise ValueError("Invalid input shape.")
+
+    def call(self, llr_ch):
+        self._require_single()
+        llr = _ffi.to_device(llr_ch, torch.float32)
+        if llr.shape[-1] != self._n_target:
+            raise ValueError("Invalid input shape.")
+        lead = tuple(llr.shape[:-1])
+        x = llr.reshape(-1, self._n_target)
+        if self._dev is None:
+            dev = x.device
+            t = lambda a: torch.from_numpy(np.asarray(a, np.int64)).to(dev)
+            self._dev = (t(np.clip(self._src_a, 0, None)), torch.from_numpy(self._src_a >= 0).to(dev),
+                         torch.from_numpy(self._src_a == -2).to(dev), t(np.clip(self._src_b, 0, None)),
+                         torch.from_numpy(self._src_b >= 0).to(dev), bool((self._src_b >= 0).any()))
+        ia, ma, sa, ib, mb, has_b = self._dev
+        # index plumbing of the rate recovery (gathers only; decoding.py:2018-2052)
+        dec_in = torch.where(ma, x.index_select(1, ia), torch.zeros((), device=x.device))
+        dec_in = torch.where(sa, torch.full((), -self._llr_max, device=x.device), dec_in)
+        if has_b:
+            dec_in = dec_in + torch.where(mb, x.index_select(1, ib), torch.zeros((), device=x.device))
+        u_crc = self._polar_dec(dec_in.contiguous()).as_subclass(torch.Tensor)
+        if self._iil:
+            u_crc = u_crc.index_select(1, torch.from_numpy(self._ind_iil_inv.astype(np.int64)).to(u_crc.device))
+        if self._return_crc_status:
+            u_hat, status = self._dec_crc(u_crc.contiguous())
+            return u_hat.reshape(lead + (self._k_target,)), status.reshape(lead)
+        return u_crc[:, :-self._k_crc].reshape(lead + (self._k_target,))

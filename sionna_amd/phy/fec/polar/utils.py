@@ -1,0 +1,35 @@
+"""Polar code construction helpers - mirror of reference src/sionna/phy/fec/polar/utils.py:13-112."""
+import os
+
+import numpy as np
+
+_SEQ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "codes", "polar_5g_sequence.npy")
+
+
+def generate_5g_ranking(k, n, sort=True):
+    """Frozen and information positions of the 5G Polar code (38.212 Tab. 5.3.1.2-1): the n-k
+    least reliable of the channels 0..n-1 are frozen.  Returns [frozen_pos, info_pos]."""
+    if not isinstance(k, int):
+        raise TypeError("k must be integer.")
+    if not isinstance(n, int):
+        raise TypeError("n must be integer.")
+    if not isinstance(sort, bool):
+        raise TypeError("sort must be bool.")
+    if k < 0:
+        raise ValueError("k cannot be negative.")
+    if k > 1024:
+        raise ValueError("k cannot be larger than 1024.")
+    if n > 1024:
+        raise ValueError("n cannot be larger than 1024.")
+    if n < 32:
+        raise ValueError("n must be >=32.")
+    if n < k:
+        raise ValueError("Invalid coderate (>1).")
+    if np.log2(n) != int(np.log2(n)):
+        raise ValueError("n must be a power of 2.")
+    seq = np.load(_SEQ).astype(int)            # channel indices in ascending reliability
+    seq = seq[seq < n]
+    frozen, info = seq[:n - k], seq[n - k:]
+    if sort:
+        frozen, info = np.sort(frozen), np.sort(info)
+    return [frozen.astype(int), info.astype(int)]

@@ -1,0 +1,143 @@
+"""GPU parity tests of the CRC / Polar part of the hot path (north-star config C5) against the
+reference's golden vectors (tests/golden/{crc,polar}_golden.npz) and oracle/polar.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import polar as op
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CRC = np.load(os.path.join(GOLD, "crc_golden.npz"))
+POL = np.load(os.path.join(GOLD, "polar_golden.npz"))
+
+
+@pytest.fixture(scope="module")
+def phy():
+    import sionna_amd.phy as p
+    from sionna_amd import _ffi
+    _ffi.device()
+    return p
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("pol", ["CRC24A", "CRC24B", "CRC24C", "CRC16", "CRC11", "CRC6"])
+def test_crc_golden_and_oracle(phy, pol):
+    enc = phy.fec.crc.CRCEncoder(pol)
+    dec = phy.fec.crc.CRCDecoder(enc)
+    u, ref = CRC[f"crc_u_{pol}"], CRC[f"crc_x_ref_np_{pol}"]
+    x = _np(enc(u))
+    assert np.array_equal(x.reshape(-1)[-len(ref):], ref) and (enc.k, enc.n) == (u.shape[-1], x.shape[-1])
+    rng = np.random.default_rng(1)
+    bits = rng.integers(0, 2, (7, 3, 333)).astype(np.float32)
+    xc = enc(bits)
+    assert np.array_equal(_np(xc), op.crc_encode(bits, pol))
+    info, valid = dec(xc)
+    assert np.array_equal(_np(info), bits) and bool(valid.all()) and valid.shape == (7, 3, 1)
+    bad = _np(xc).copy()
+    bad[..., 5] = 1 - bad[..., 5]
+    assert not bool(dec(bad)[1].any())
+
+
+@pytest.mark.parametrize("name", ["E45_k30_K41", "E70_k32_K43", "E127_k29_K40", "E1023_k400_K411", "E70_k28_K39"])
+def test_polar5g_encoder_golden(phy, name):
+    u, c_ref = POL[f"{name}_u"], POL[f"{name}_c"]
+    enc = phy.fec.polar.Polar5GEncoder(u.shape[1], c_ref.shape[1])
+    assert np.array_equal(_np(enc(u)), c_ref)
+
+
+@pytest.mark.parametrize("k,n,ch", [(512, 1024, "uplink"), (40, 200, "downlink"), (100, 150, "uplink"), (500, 1088, "uplink"),
+                                    (20, 576, "downlink"), (300, 400, "uplink")])
+def test_polar5g_encoder_vs_oracle(phy, k, n, ch):
+    enc = phy.fec.polar.Polar5GEncoder(k, n, channel_type=ch)
+    u = np.random.default_rng(k).integers(0, 2, (2, 9, k)).astype(np.float32)
+    assert np.array_equal(_np(enc(u)), op.Polar5GCode(k, n, ch).encode(u))
+    # plain PolarEncoder
+    fr, info = phy.fec.polar.generate_5g_ranking(64, 256)
+    pe = phy.fec.polar.PolarEncoder(fr, 256)
+    v = np.random.default_rng(0).integers(0, 2, (5, 64)).astype(np.float32)
+    assert np.array_equal(_np(pe(v)), op.polar_encode(v, info, 256))
+
+
+@pytest.mark.parametrize("name", ["P_128_37", "P_128_110", "P_256_128"])
+def test_sc_and_scl1_golden(phy, name):
+    a, lch, uhat = POL[f"{name}_Avec"], POL[f"{name}_Lch"], POL[f"{name}_uhat"]
+    frozen = np.where(a == 0)[0]
+    n = len(a)
+    logits = (-1. * lch).astype(np.float32)
+    assert np.array_equal(_np(phy.fec.polar.PolarSCDecoder(frozen, n)(logits)), uhat)
+    for fast in (False, True):
+        dec = phy.fec.polar.PolarSCLDecoder(frozen, n, list_size=1, use_fast_scl=fast)
+        assert np.array_equal(_np(dec(logits)), uhat)
+
+
+@pytest.mark.parametrize("n,k,L,crc,fast", [(128, 64, 8, None, True), (128, 64, 4, "CRC11", True), (256, 100, 8, "CRC11", False),
+                                            (64, 40, 2, "CRC6", True), (1024, 523, 8, "CRC11", True), (512, 300, 16, "CRC24C", True)])
+def test_scl_vs_oracle(phy, n, k, L, crc, fast):
+    """List decoding against the float32 restatement of the reference's TF path.  The survivor
+    selection compares float sums whose order differs (tree vs NumPy pairwise), so a codeword may
+    differ in a near-tie: the bar is >= 99 % identical codewords and identical block error rate."""
+    frozen, info = phy.fec.polar.generate_5g_ranking(k, n)
+    rng = np.random.default_rng(n + k + L)
+    B = 48 if n >= 512 else 200
+    kc = op.CRC_POLYS[crc][0] if crc else 0
+    u = rng.integers(0, 2, (B, k - kc)).astype(np.float32)
+    uc = op.crc_encode(u, crc) if crc else u
+    c = op.polar_encode(uc, info, n)
+    sigma = 0.75
+    y = (2 * c - 1) + sigma * rng.normal(size=c.shape)
+    logits = (2 * y / sigma ** 2).astype(np.float32)
+    dec = phy.fec.polar.PolarSCLDecoder(frozen, n, list_size=L, crc_degree=crc, use_fast_scl=fast,
+                                        return_crc_status=crc is not None)
+    out = dec(logits)
+    got, status = (out if crc else (out, None))
+    ref, ref_status = op.SCLDecoder(frozen, n, L, crc, fast).decode(logits)
+    same = np.all(_np(got) == ref, axis=1)
+    assert same.mean() >= 0.99, f"{(~same).sum()} of {B} codewords differ"
+    if crc:
+        assert np.mean(_np(status) == ref_status) >= 0.99
+    bler_gpu, bler_ref = np.mean(np.any(_np(got) != uc, 1)), np.mean(np.any(ref != uc, 1))
+    assert abs(bler_gpu - bler_ref) <= 0.02
+
+
+@pytest.mark.parametrize("k,n,ch,dec_type", [(64, 128, "uplink", "SCL"), (30, 70, "uplink", "SC"), (40, 200, "downlink", "SCL"),
+                                             (100, 150, "uplink", "SCL"), (300, 1088, "uplink", "SCL"), (512, 1024, "uplink", "SCL")])
+def test_polar5g_decoder_chain(phy, k, n, ch, dec_type):
+    enc = phy.fec.polar.Polar5GEncoder(k, n, channel_type=ch)
+    dec = phy.fec.polar.Polar5GDecoder(enc, dec_type=dec_type, list_size=8, return_crc_status=True)
+    code = op.Polar5GCode(k, n, ch)
+    rng = np.random.default_rng(k + n)
+    B = 32
+    u = rng.integers(0, 2, (B, k)).astype(np.float32)
+    c = _np(enc(u))
+    sigma = 0.6
+    logits = (2 * ((2 * c - 1) + sigma * rng.normal(size=c.shape)) / sigma ** 2).astype(np.float32)
+    u_hat, status = dec(logits)
+    ref = op.polar5g_decode(code, logits, dec_type, 8)
+    assert np.mean(np.all(_np(u_hat) == ref, axis=1)) >= 0.96
+    ok = np.all(_np(u_hat) == u, axis=1)
+    assert np.array_equal(_np(status)[ok], np.ones(ok.sum(), bool))        # decoded words pass their CRC
+    assert ok.mean() > 0.5
+
+
+def test_c5_full_batch_properties(phy):
+    """Config C5 (Polar5G uplink k=512 n=1024, SCL-8) on a large batch: noiseless round trip and
+    monotone error rate."""
+    enc = phy.fec.polar.Polar5GEncoder(512, 1024)
+    dec = phy.fec.polar.Polar5GDecoder(enc, "SCL", list_size=8)
+    phy.config.seed = 3
+    u = phy.mapping.BinarySource()([4096, 512])
+    c = enc(u)
+    assert torch.equal(dec(8.0 * (2 * c - 1)).as_subclass(torch.Tensor), u.as_subclass(torch.Tensor))
+    blers = []
+    for sigma in (1.0, 0.7):
+        y = (2 * c - 1) + sigma * torch.randn_like(c)
+        u_hat = dec(2 * y / sigma ** 2)
+        blers.append(float((u_hat != u).any(dim=1).float().mean()))
+    assert blers[0] > blers[1] and blers[1] < 0.05

@@ -1,0 +1,64 @@
+"""Pin oracle/polar.py against the reference's golden vectors (tests/golden/{crc,polar}_golden.npz,
+re-packed from /root/reference/test/codes by tools/gen_golden.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import polar as op
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+CRC = np.load(os.path.join(GOLD, "crc_golden.npz"))
+POL = np.load(os.path.join(GOLD, "polar_golden.npz"))
+
+
+@pytest.mark.parametrize("pol", ["CRC24A", "CRC24B", "CRC24C", "CRC16", "CRC11", "CRC6"])
+def test_crc_golden(pol):
+    # test/unit/fec/test_crc.py:153-198
+    u, ref = CRC[f"crc_u_{pol}"], CRC[f"crc_x_ref_np_{pol}"]
+    x = op.crc_encode(u, pol)
+    assert np.array_equal(x.reshape(-1)[-len(ref):], ref)
+    assert op.crc_check(x, pol)[1].all()
+    x[0, 3] = 1 - x[0, 3]
+    assert not op.crc_check(x, pol)[1].any()
+    one = op.crc_encode(np.ones((1, 1), np.float32), pol)[0, 1:]
+    length, coeffs = op.CRC_POLYS[pol]
+    assert np.array_equal(np.nonzero(one)[0], sorted(length - 1 - c for c in coeffs if c < length))   # crc of "1" = polynomial
+
+
+@pytest.mark.parametrize("name", ["E45_k30_K41", "E70_k32_K43", "E127_k29_K40", "E1023_k400_K411", "E70_k28_K39"])
+def test_polar5g_encoder_golden(name):
+    # test/unit/fec/test_polar_encoding.py:314-343 (puncturing, shortening, repetition)
+    u, c_ref = POL[f"{name}_u"], POL[f"{name}_c"]
+    code = op.Polar5GCode(u.shape[1], c_ref.shape[1])
+    assert np.array_equal(code.encode(u), c_ref)
+
+
+@pytest.mark.parametrize("name", ["P_128_37", "P_128_110", "P_256_128"])
+def test_sc_and_scl1_golden(name):
+    # test/unit/fec/test_polar_decoding.py:214-236, 549-583
+    a, lch, uhat = POL[f"{name}_Avec"], POL[f"{name}_Lch"], POL[f"{name}_uhat"]
+    frozen = np.where(a == 0)[0]
+    n = len(a)
+    logits = (-1. * lch).astype(np.float32)
+    assert np.array_equal(op.sc_decode(logits, frozen, n), uhat)
+    for fast in (False, True):
+        u, _ = op.SCLDecoder(frozen, n, list_size=1, use_fast_scl=fast).decode(logits)
+        assert np.array_equal(u, uhat)
+
+
+def test_ranking_and_e2e():
+    fr, inf = op.generate_5g_ranking(32, 64)
+    assert len(fr) == 32 and len(inf) == 32 and len(np.intersect1d(fr, inf)) == 0
+    # C5 parameters: k=512 -> k_polar=523, n_polar=1024, no puncturing
+    code = op.Polar5GCode(512, 1024)
+    assert (code.k_polar, code.n_polar, code.crc_degree) == (523, 1024, "CRC11")
+    rng = np.random.default_rng(0)
+    for k, n, ch in ((64, 128, "uplink"), (30, 70, "uplink"), (40, 200, "downlink"), (100, 150, "uplink")):
+        code = op.Polar5GCode(k, n, ch)
+        u = rng.integers(0, 2, (6, k)).astype(np.float32)
+        c = code.encode(u)
+        y = (2 * c - 1) + 0.5 * rng.normal(size=c.shape)
+        llr = (2 * y / 0.25).astype(np.float32)
+        assert np.array_equal(op.polar5g_decode(code, llr, "SCL", 4), u)
+        assert np.mean(op.polar5g_decode(code, llr, "SC") != u) < 0.05

@@ -57,3 +57,15 @@ dst = os.path.join(os.path.dirname(__file__), "..", "sionna_amd/phy/channel/tr38
 with open(dst, "w") as f:
     json.dump(tdl, f)
 print("wrote", os.path.normpath(dst))
+
+# ---- 5G Polar sequence (38.212 Table 5.3.1.2-1): reliability order of the 1024 bit channels,
+# shipped by the reference as fec/polar/codes/polar_5G.csv (rows "W;Q": reliability rank W and
+# channel index Q; parsed at fec/polar/utils.py:72-95).  Stored as int16 array q[w] = channel index.
+rows = np.genfromtxt(os.path.join(ref, "src/sionna/phy/fec/polar/codes/polar_5G.csv"), delimiter=";").astype(int)
+q = np.zeros(1024, np.int16)
+q[rows[:, 0]] = rows[:, 1]
+assert sorted(q.tolist()) == list(range(1024))
+dst = os.path.join(os.path.dirname(__file__), "..", "sionna_amd/phy/fec/polar/codes/polar_5g_sequence.npy")
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+np.save(dst, q)
+print("wrote", os.path.normpath(dst))
