@@ -120,6 +120,57 @@ def bench_c4(args):
     print(json.dumps(out))
 
 
+def bench_c5(args):
+    """Secondary workload (BASELINE config C5): Polar5G uplink k=512 n=1024 (CRC11, k_polar=523),
+    CRC-aided SCL list 8, batch 32768.  One step = Polar5GDecoder.call on resident LLRs; metric
+    codeword-decodes/s.  The kernel is synchronisation / latency bound ("report
+    decodes/s and occupancy only"); the roofline entry states the compulsory HBM bytes."""
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    _ffi.device()
+    phy.config.seed = 5
+    B, k, n, m = (args.batch if args.batch != 65536 else 32768), 512, 1024, 2
+    enc = phy.fec.polar.Polar5GEncoder(k, n)
+    dec = phy.fec.polar.Polar5GDecoder(enc, "SCL", list_size=8)
+    no = phy.utils.ebnodb2no(args.ebno_db, m, k / n)
+    u = phy.mapping.BinarySource()([B, k])
+    y = phy.channel.AWGN()(phy.mapping.Mapper("qam", m)(enc(u)), no)
+    llr = phy.mapping.Demapper("app", "qam", m)(y, no)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        dec(llr)
+    ev_t = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e0, e1 in ev_t:
+        e0.record(); u_hat = dec(llr); e1.record()
+    torch.cuda.synchronize()
+    t_wall = time.perf_counter() - t0
+    ms = float(np.mean([a.elapsed_time(c) for a, c in ev_t]))
+    io = (4 * n + 4 * k) * B / (ms * 1e-3) / 1e9
+    out = {"metric": "codeword-decodes/sec (Polar5G n=1024 k=512, SCL-8)", "value": round(B * args.steps / t_wall, 1),
+           "unit": "codewords/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(t_wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"C5: Polar5G uplink k=512 n=1024 (CRC11), SCL list 8, QPSK AWGN, batch {B}",
+                      "batch": B, "ebno_db": args.ebno_db},
+           "bler": float((u_hat != u).any(dim=1).float().mean()),
+           "roofline": {"bound": "hbm", "achieved": round(io, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(io / HBM_PEAK_GBPS, 5), "traffic": None, "kernel": "polar_scl_kernel",
+                        "note": "compulsory 4n+4k bytes per codeword; the kernel is latency/synchronisation bound",
+                        "ms_per_launch": round(ms, 3)}}
+    if not args.no_cpu_baseline:
+        from oracle import polar as op
+        code = op.Polar5GCode(k, n)
+        ns = 64
+        t0 = time.perf_counter()
+        op.polar5g_decode(code, llr[:ns].cpu().numpy(), "SCL", 8)
+        t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(ns / t_cpu, 2), "unit": "codewords/s", "cores": 1, "kind": "port",
+                               "sample": f"{ns} codewords, oracle/polar.py (NumPy float32 restatement of the reference's SCL), {t_cpu:.1f} s"}
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,13 +185,17 @@ def main():
     ap.add_argument("--also", default="boxplus-phi", help="second CN rule timed with fewer steps ('none' disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="codewords for the CPU baseline (0 = auto)")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
-                    help="c2 = headline LDPC decode (default); c4 = OFDM 4x2 LMMSE pass (single GPU)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2 = headline LDPC decode (default); c4 = OFDM 4x2 LMMSE pass; c5 = Polar SCL-8 (single GPU)")
     args = ap.parse_args()
     if args.workload == "c4":
         if args.ebno_db == 4.5:
             args.ebno_db = 10.0
         return bench_c4(args)
+    if args.workload == "c5":
+        if args.ebno_db == 4.5:
+            args.ebno_db = 2.5
+        return bench_c5(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -242,12 +242,13 @@ int samd_polar_encode_f32(const float* u, const int32_t* info_pos, const int32_t
                           int k, int n, int n_out, float* out, void* stream);
 
 /* PolarSCDecoder / PolarSCLDecoder (default TF path, fast SCL)  fec/polar/decoding.py:122-263,
- * 525-723, 919-1045, 1345-1437.  llr [batch,n] logits; ops DEVICE int32[num_ops][4] decoding
- * schedule built by the host (sionna_amd/phy/fec/polar/decoding.py::build_schedule); info_pos
+ * 525-723, 919-1045, 1345-1437.  llr [batch,n] logits (n <= 1024); ops DEVICE int32[num_ops]
+ * packed decoding schedule built by the host (sionna_amd/phy/fec/polar/decoding.py::
+ * build_schedule: op | stage<<3 | side<<7 | (bit_index+2048)<<8); info_pos
  * DEVICE int32[k]; iil_inv nullable DEVICE int32[k] (inverse input interleaver applied before the
  * CRC check); sc_mode=1 -> hard SC decisions (list_size must be 1); crc_len=0 disables the
  * CRC-aided selection.  u_hat [batch,k]; crc_status nullable [batch]. */
-int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, const int32_t* info_pos,
+int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
                               const int32_t* iil_inv, int batch, int n, int k, int list_size,
                               int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat,
                               float* crc_status, void* stream);

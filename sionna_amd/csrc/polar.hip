@@ -22,9 +22,15 @@
 //   * CRC-aided selection (penalty llr_max*k on CRC failures, first minimum) runs in the same
 //     kernel; the f-operation is the exact boxplus softplus(x+y) - logsumexp(x,y) with the +-30
 //     clip of the reference.
-// The kernel is latency/synchronisation bound (about 4 n dependent steps per codeword), not
-// bandwidth bound: 4n bytes in, 4k bytes out per codeword.
+// The kernel is instruction-issue / latency bound, not bandwidth bound (4n bytes in, 4k bytes out
+// per codeword): ~2200 dependent operations per codeword at n=1024 with at most 64 independent
+// work items each, i.e. ~1e6 wave-instructions on ONE wave per codeword (measured: 64- and
+// 256-thread workgroups run at the same rate; skipping the clone copies or the CRC changes
+// nothing, a free f-operation gains 19 %).  Throughput therefore scales with the number of
+// codewords resident per CU, which the 53 KB list state limits to 2-3: sharing the upper LLR
+// stages between paths (lazy copy) is the next step.
 #include "common.h"
+#include <cstdlib>
 
 namespace samd {
 
@@ -89,14 +95,18 @@ struct SclArgs {
   const float* llr_in;     // [B, n] logits
   float* u_hat;            // [B, k] bits at the information positions of the selected path
   float* crc_status;       // nullable [B]
-  const int32_t* ops;      // [num_ops][4]
+  const int32_t* ops;      // [num_ops] packed: op | stage<<3 | side<<7 | (a2+2048)<<8
+  int num_ops;
   const int32_t* info_pos; // [k]
   const int32_t* iil_inv;  // nullable [k] inverse input interleaver applied before the CRC check
   int batch, n, m, k, L, sc_mode, crc_len;
   uint32_t crc_poly;
 };
 
-__global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
+// NT = threads per workgroup: 64 (one wave per codeword: the hardware barrier of a single-wave
+// workgroup is free, which is what the ~14k dependent steps per codeword want) or 256.
+template <int NT>
+__global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = p.n, L = p.L, tid = threadIdx.x;
   const int words = (n + 31) / 32;
@@ -114,21 +124,25 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
   int* new_bit = clone_src + L;                           // [L]
   float* new_pm = reinterpret_cast<float*>(new_bit + L);  // [L]
   float* red = new_pm + L;                                // [256] reduction scratch
+  int* lops = reinterpret_cast<int*>(red + 256);          // [num_ops] decoding schedule (LDS copy: the
+                                                          // op fetch is on the critical path of every step)
+  for (int i = tid; i < p.num_ops; i += NT) lops[i] = p.ops[i];
 
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
-    for (int i = tid; i < n; i += 256) llr_ch[i] = -1.f * p.llr_in[(size_t)b * n + i];   // logits -> LLR
-    for (int i = tid; i < L * n; i += 256) { betaL[i] = 0; betaR[i] = 0; }
-    for (int i = tid; i < L * words; i += 256) bits[i] = 0u;
+    for (int i = tid; i < n; i += NT) llr_ch[i] = -1.f * p.llr_in[(size_t)b * n + i];   // logits -> LLR
+    for (int i = tid; i < L * n; i += NT) { betaL[i] = 0; betaR[i] = 0; }
+    for (int i = tid; i < L * words; i += NT) bits[i] = 0u;
     if (tid < L) { pm[tid] = tid == 0 ? 0.f : kPolarLlrMax; order[tid] = tid; }         // decoding.py:1029-1033
     __syncthreads();
 
     for (int ip = 0;; ++ip) {
-      const int op = p.ops[4 * ip], a0 = p.ops[4 * ip + 1], a1 = p.ops[4 * ip + 2], a2 = p.ops[4 * ip + 3];
+      const int rec = lops[ip];
+      const int op = rec & 7, a0 = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = (rec >> 8) - 2048;
       if (op == OP_END) break;
       if (op == OP_F || op == OP_G) {
         // a0 = stage s of the inputs (block of 2^s), outputs go to stage s-1; OP_G uses betaL[s-1]
         const int s = a0, half = 1 << (s - 1);
-        for (int w = tid; w < L * half; w += 256) {
+        for (int w = tid; w < L * half; w += NT) {
           const int pos = w / half, j = w - pos * half;
           const int slot = order[pos];
           const float* in = (s == p.m) ? llr_ch : (llr + (size_t)slot * n + (1 << s));
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
       } else if (op == OP_COMBINE) {
         // children results at stage s (a0) -> this node's result at stage s+1 on side a1
         const int s = a0, sz = 1 << s;
-        for (int w = tid; w < L * sz; w += 256) {
+        for (int w = tid; w < L * sz; w += NT) {
           const int pos = w / sz, j = w - pos * sz;
           const size_t base = (size_t)order[pos] * n;
           const unsigned char l = betaL[base + sz + j], r = betaR[base + sz + j];
@@ -157,30 +171,39 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
         const int s = a0, sz = 1 << s;
         const bool info = (op == OP_REP) || (op == OP_LEAF && a2 >= 0);
         // block metrics of every live path: m0 = sum softplus(-l), m1 = sum softplus(+l)
-        for (int pos = 0; pos < L; ++pos) {
-          const int slot = order[pos];
-          const float* in = (s == p.m) ? llr_ch : (llr + (size_t)slot * n + sz);
-          float m0 = 0.f, m1 = 0.f;
-          for (int j = tid; j < sz; j += 256) {
-            const float l = clampf(in[j], -kPolarLlrMax, kPolarLlrMax);
-            m0 += softplus(-l);
-            m1 += softplus(l);
+        if (sz == 1) {
+          if (tid < L) {                                      // one lane per path
+            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)order[tid] * n + sz);
+            const float l = clampf(in[0], -kPolarLlrMax, kPolarLlrMax);
+            blk[tid] = softplus(-l);
+            blk[L + tid] = softplus(l);
           }
-          if (sz > 1) {                                       // deterministic tree reduction
-            red[tid] = m0; __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-            m0 = red[0]; __syncthreads();
-            red[tid] = m1; __syncthreads();
-            for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
-            m1 = red[0]; __syncthreads();
+        } else {
+          for (int pos = 0; pos < L; ++pos) {
+            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)order[pos] * n + sz);
+            float m0 = 0.f, m1 = 0.f;
+            for (int j = tid; j < sz; j += NT) {
+              const float l = clampf(in[j], -kPolarLlrMax, kPolarLlrMax);
+              m0 += softplus(-l);
+              m1 += softplus(l);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { m0 += __shfl_xor(m0, o, 64); m1 += __shfl_xor(m1, o, 64); }
+            if constexpr (NT > 64) {                          // fixed-order combination of the waves
+              if ((tid & 63) == 0) { red[tid >> 6] = m0; red[8 + (tid >> 6)] = m1; }
+              __syncthreads();
+              m0 = 0.f; m1 = 0.f;
+              for (int w = 0; w < NT / 64; ++w) { m0 += red[w]; m1 += red[8 + w]; }
+              __syncthreads();
+            }
+            if (tid == 0) { blk[pos] = m0; blk[L + pos] = m1; }
           }
-          if (tid == 0) { blk[pos] = m0; blk[L + pos] = m1; }
         }
         __syncthreads();
         if (!info) {
           // frozen leaf / rate-0: metric of the all-zero block, result zeros
           if (tid < L) pm[tid] += blk[tid];
-          for (int w = tid; w < L * sz; w += 256) {
+          for (int w = tid; w < L * sz; w += NT) {
             const int pos = w / sz, j = w - pos * sz;
             ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = 0;
           }
@@ -206,19 +229,29 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
             rnk[tid] = rank;
           }
           __syncthreads();
-          if (tid == 0) {
-            // survivors (rank < L) take position = rank; a parent's first survivor keeps its slot,
-            // a second survivor is cloned into the slot of a parent without survivors
-            int free_slots[32], nfree = 0;
-            for (int q = 0; q < L; ++q) if (rnk[q] >= L && rnk[L + q] >= L) free_slots[nfree++] = order[q];
-            for (int q = 0; q < L; ++q) {
-              const int slot = order[q], r0 = rnk[q], r1 = rnk[L + q];
-              if (r0 < L) { new_order[r0] = slot; clone_src[r0] = -1; new_bit[r0] = 0; new_pm[r0] = cand[q]; }
-              if (r1 < L) {
-                new_bit[r1] = 1; new_pm[r1] = cand[L + q];
-                if (r0 < L) { new_order[r1] = free_slots[--nfree]; clone_src[r1] = slot; }
-                else { new_order[r1] = slot; clone_src[r1] = -1; }
-              }
+          // survivors (rank < L) take position = rank; a parent's first survivor keeps its slot, the
+          // j-th parent with two survivors clones its second child into the slot of the j-th parent
+          // without survivors (prefix counts over LDS flags - no private arrays, no scratch)
+          int* dead_slot = rnk + 2 * L;                                            // [L]
+          if (tid < L) {
+            const bool dead = rnk[tid] >= L && rnk[L + tid] >= L;
+            if (dead) {
+              int j = 0;
+              for (int d = 0; d < tid; ++d) j += (rnk[d] >= L && rnk[L + d] >= L) ? 1 : 0;
+              dead_slot[j] = order[tid];
+            }
+          }
+          __syncthreads();
+          if (tid < L) {
+            const int q = tid, slot = order[q], r0 = rnk[q], r1 = rnk[L + q];
+            if (r0 < L) { new_order[r0] = slot; clone_src[r0] = -1; new_bit[r0] = 0; new_pm[r0] = cand[q]; }
+            if (r1 < L) {
+              new_bit[r1] = 1; new_pm[r1] = cand[L + q];
+              if (r0 < L) {
+                int j = 0;
+                for (int d = 0; d < q; ++d) j += (rnk[d] < L && rnk[L + d] < L) ? 1 : 0;
+                new_order[r1] = dead_slot[j]; clone_src[r1] = slot;
+              } else { new_order[r1] = slot; clone_src[r1] = -1; }
             }
           }
         }
@@ -228,12 +261,12 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
           const int src = clone_src[r];
           if (src < 0) continue;
           const int dst = new_order[r];
-          for (int i = tid; i < n; i += 256) {
+          for (int i = tid; i < n; i += NT) {
             llr[(size_t)dst * n + i] = llr[(size_t)src * n + i];
             betaL[(size_t)dst * n + i] = betaL[(size_t)src * n + i];
             betaR[(size_t)dst * n + i] = betaR[(size_t)src * n + i];
           }
-          for (int i = tid; i < words; i += 256) bits[(size_t)dst * words + i] = bits[(size_t)src * words + i];
+          for (int i = tid; i < words; i += NT) bits[(size_t)dst * words + i] = bits[(size_t)src * words + i];
         }
         __syncthreads();
         // commit: order, metrics, decided bit (the node's only information bit is its last one), result
@@ -244,7 +277,7 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
           if (new_bit[tid]) bits[(size_t)new_order[tid] * words + (bit_index >> 5)] |= 1u << (bit_index & 31);
         }
         __syncthreads();
-        for (int w = tid; w < L * sz; w += 256) {
+        for (int w = tid; w < L * sz; w += NT) {
           const int pos = w / sz, j = w - pos * sz;
           ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = (unsigned char)new_bit[pos];   // all-u codeword
         }
@@ -271,7 +304,7 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
     int best = 0;
     for (int q = 1; q < L; ++q) if (cand[q] < cand[best]) best = q;
     const uint32_t* bw = bits + (size_t)order[best] * words;
-    for (int i = tid; i < p.k; i += 256) {
+    for (int i = tid; i < p.k; i += NT) {
       const int pos = p.info_pos[i];
       p.u_hat[(size_t)b * p.k + i] = (float)((bw[pos >> 5] >> (pos & 31)) & 1u);
     }
@@ -280,10 +313,10 @@ __global__ __launch_bounds__(256) void polar_scl_kernel(SclArgs p) {
   }
 }
 
-static size_t scl_lds_bytes(int n, int L) {
+static size_t scl_lds_bytes(int n, int L, int num_ops) {
   const size_t words = (n + 31) / 32;
   return (size_t)n * 4 + (size_t)L * n * 4 + 2 * (size_t)L * n + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
-         (size_t)L * 4 * 5 + 256 * 4 + 64;
+         (size_t)L * 4 * 5 + 256 * 4 + (size_t)num_ops * 4 + 64;
 }
 
 }  // namespace samd
@@ -308,31 +341,35 @@ extern "C" int samd_polar_encode_f32(const float* u, const int32_t* info_pos, co
   return launch_status();
 }
 
-extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, const int32_t* info_pos,
+extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
                                          const int32_t* iil_inv, int batch, int n, int k, int list_size, int sc_mode,
                                          uint32_t crc_poly, int crc_len, float* u_hat, float* crc_status,
                                          void* stream) {
   SAMD_REQUIRE(llr && ops && info_pos && u_hat && batch > 0, "bad argument");
   SAMD_REQUIRE(n >= 8 && (n & (n - 1)) == 0 && k >= 0 && k <= n, "n must be a power of two >= 8, 0 <= k <= n");
   SAMD_REQUIRE(list_size >= 1 && list_size <= 32 && (list_size & (list_size - 1)) == 0, "list_size must be a power of two <= 32");
-  const size_t lds = scl_lds_bytes(n, list_size);
+  SAMD_REQUIRE(num_ops > 0 && n <= 1024, "schedule missing or n > 1024");
+  const size_t lds = scl_lds_bytes(n, list_size, num_ops);
   if (lds > 160 * 1024) {
     set_error("list state does not fit in LDS (reduce list_size or n)");
     return SAMD_ERR_UNSUPPORTED;
   }
   static bool attr_set = false;
   if (!attr_set) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   int m = 0;
   while ((1 << m) < n) ++m;
-  SclArgs p{llr, u_hat, crc_status, ops, info_pos, iil_inv, batch, n, m, k, list_size, sc_mode, crc_len, crc_poly};
+  SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, batch, n, m, k, list_size, sc_mode, crc_len, crc_poly};
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const size_t per_cu = std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds));
   const int grid = (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
-  hipLaunchKernelGGL(polar_scl_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  const char* nt_env = getenv("SAMD_SCL_THREADS");
+  if (nt_env && atoi(nt_env) == 256) hipLaunchKernelGGL(polar_scl_kernel<256>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
   return launch_status();
 }

@@ -56,6 +56,13 @@ def build_schedule(frozen_ind, use_fast=True, use_rep=True):
     return np.asarray(ops, np.int32)
 
 
+def pack_schedule(ops):
+    """One int32 per operation: op | stage<<3 | side<<7 | (a2+2048)<<8 (the kernel keeps it in LDS)."""
+    ops = np.asarray(ops, np.int64)
+    a0 = np.where(ops[:, 0] == OP_LEAF, 0, ops[:, 1])
+    return (ops[:, 0] | (a0 << 3) | (ops[:, 2] << 7) | ((ops[:, 3] + 2048) << 8)).astype(np.int32)
+
+
 class _PolarListDecoderBase(Block):
     """Shared engine of the SC and SCL decoders."""
 
@@ -95,7 +102,7 @@ class _PolarListDecoderBase(Block):
     def _decode_2d(self, llr, want_status=False):
         if self._dev is None:
             i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
-            self._dev = (i32(self._ops), i32(self._info_pos),
+            self._dev = (i32(pack_schedule(self._ops)), i32(self._info_pos),
                          i32(self._ind_iil_inv) if self._ind_iil_inv is not None else None)
         ops, info, iil = self._dev
         b = llr.shape[0]
@@ -103,7 +110,7 @@ class _PolarListDecoderBase(Block):
         status = torch.empty((b,), dtype=torch.float32, device=llr.device) if want_status else None
         if b > 0:
             _ffi.check(_ffi.lib().samd_polar_scl_decode_f32(
-                _ffi.ptr(llr), _ffi.ptr(ops), _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size,
+                _ffi.ptr(llr), _ffi.ptr(ops), ops.numel(), _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size,
                 self._sc_mode, self._crc_mask, self._crc_len, _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.stream()),
                 type(self).__name__)
         return u_hat, status
