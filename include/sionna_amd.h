@@ -199,6 +199,40 @@ int samd_cir_to_ofdm_c64(const float* a, const float* tau, const float* frequenc
 int samd_apply_ofdm_channel_c64(const float* x, const float* h_freq, int batch, int num_rx_x_ant,
                                 int num_tx_x_ant, int num_re, float* y, void* stream);
 
+/* ---- time-domain variant of the OFDM chain -------------------------------------------- */
+
+/* OFDMModulator.call  ofdm/modulator.py:97-124 (ifftshift -> ifft (signal/utils.py:205-262,
+ * sqrt(N)-normalised) -> cyclic prefix).  x [rows, num_ofdm_symbols, fft_size] complex64 ->
+ * out [rows, out_len], out_len = sum_s (fft_size + cp_len[s]).  cp_len / sym_off DEVICE
+ * int32[num_ofdm_symbols] (prefix length and output offset of every symbol; max_cp = max
+ * cp_len <= fft_size); work = rows*num_ofdm_symbols*fft_size complex64 scratch.  The batched
+ * 1-D transform is rocFFT's (bound at first use; UNSUPPORTED if librocfft cannot be loaded). */
+int samd_ofdm_modulate_c64(const float* x, int rows, int num_ofdm_symbols, int fft_size,
+                           const int32_t* cp_len, const int32_t* sym_off, int max_cp, int out_len,
+                           float* work, float* out, void* stream);
+
+/* OFDMDemodulator.call  ofdm/demodulator.py:143-203 (cp removal -> fft -> exp(-j 2 pi l_min
+ * k / N) phase compensation -> fftshift).  y [rows, in_len] -> out [rows, num_ofdm_symbols,
+ * fft_size]; trailing samples beyond the last symbol are ignored. */
+int samd_ofdm_demodulate_c64(const float* y, int rows, int in_len, int num_ofdm_symbols,
+                             int fft_size, const int32_t* cp_len, const int32_t* sym_off,
+                             int l_min, float* work, float* out, void* stream);
+
+/* cir_to_time_channel  channel/utils.py:256-349.  a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P] ->
+ * h_time [B,rx,ra,tx,ta,T,l_max-l_min+1] = sum_p a_p(t) sinc(l - W tau_p); normalize: unit
+ * mean (over ra,ta,T) total tap energy per (b,rx,tx). */
+int samd_cir_to_time_c64(float bandwidth, const float* a, const float* tau, int l_min, int l_max,
+                         int batch, int num_rx, int num_rx_ant, int num_tx, int num_tx_ant,
+                         int num_paths, int num_time_steps, int normalize, float* h_time,
+                         void* stream);
+
+/* ApplyTimeChannel.call (noise-free part)  channel/apply_time_channel.py:95-175.
+ * x [B,tx,ta,num_time_samples], h_time [B,rx,ra,tx,ta,num_time_samples+l_tot-1,l_tot] ->
+ * y [B,rx,ra,num_time_samples+l_tot-1]. */
+int samd_apply_time_channel_c64(const float* x, const float* h_time, int batch, int num_rx,
+                                int num_rx_ant, int num_tx, int num_tx_ant, int num_time_samples,
+                                int l_tot, float* y, void* stream);
+
 /* LSChannelEstimator (+ NearestNeighborInterpolator)  ofdm/channel_estimation.py:138-173,
  * 257-285, 364-435: out[r,s,j] = y[r, src[s,j]] * coef[s,j]; rows r = batch*num_rx*num_rx_ant,
  * y [rows,n_in] (full grid), src DEVICE int32 [S,n_out] = grid index of the (nearest) pilot RE,

@@ -349,3 +349,68 @@ def ofdm_lmmse_equalize(rg, sm, y, h_hat, err_var, no, whiten_interference=True)
         tx, st = np.indices(di.shape)[:2]
         return np.transpose(z[tx, st, di], [3, 0, 1, 2])
     return extract(x_hat).astype(np.complex64), extract(no_eff).astype(np.float32)
+
+
+# ------------------------------------------------------------------ time-domain variant
+def _cp_vector(cyclic_prefix_length, num_ofdm_symbols):
+    cp = np.asarray(cyclic_prefix_length, np.int64)
+    return np.full(num_ofdm_symbols, int(cp), np.int64) if cp.ndim == 0 else cp
+
+
+def ofdm_modulate(x, cyclic_prefix_length):
+    """ofdm/modulator.py:97-124 with ifft = sqrt(N) * numpy ifft (signal/utils.py:205-262).
+    x [..., num_ofdm_symbols, fft_size] -> [..., sum_s (fft_size + cp_s)]."""
+    n = x.shape[-1]
+    xt = np.fft.ifft(np.fft.ifftshift(x.astype(np.complex128), axes=-1), axis=-1) * np.sqrt(n)
+    cp = _cp_vector(cyclic_prefix_length, x.shape[-2])
+    parts = [np.concatenate([xt[..., s, n - int(cp[s]):], xt[..., s, :]], axis=-1) for s in range(x.shape[-2])]
+    return np.concatenate(parts, axis=-1).astype(np.complex64)
+
+
+def ofdm_demodulate(y, fft_size, l_min, cyclic_prefix_length, num_ofdm_symbols=None):
+    """ofdm/demodulator.py:143-203.  y [..., num_time_samples] -> [..., num_ofdm_symbols, fft_size]."""
+    n = fft_size
+    cp0 = np.asarray(cyclic_prefix_length, np.int64)
+    if cp0.ndim == 0:
+        num_ofdm_symbols = y.shape[-1] // (n + int(cp0))
+    cp = _cp_vector(cyclic_prefix_length, num_ofdm_symbols)
+    off = np.concatenate([[0], np.cumsum(cp + n)[:-1]])
+    rows = np.stack([y[..., int(off[s] + cp[s]):int(off[s] + cp[s]) + n] for s in range(len(cp))], axis=-2)
+    xf = np.fft.fft(rows.astype(np.complex128), axis=-1) / np.sqrt(n)
+    tmp = (np.float32(-2 * PI * l_min) / np.float32(n) * np.arange(n, dtype=np.float32)).astype(np.float64)
+    xf = xf * np.exp(1j * tmp)
+    return np.fft.fftshift(xf, axes=-1).astype(np.complex64)
+
+
+def time_lag_discrete_time_channel(bandwidth, maximum_delay_spread=3e-6):
+    """channel/utils.py:121-178"""
+    return -6, int(np.ceil(maximum_delay_spread * bandwidth)) + 6
+
+
+def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False):
+    """channel/utils.py:256-349.  a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P] -> [B,rx,ra,tx,ta,T,L]."""
+    tau = tau[:, :, None, :, None, :, None, None].astype(np.float64)   # [B,rx,1,tx,1,P,1,1]
+    l = np.arange(l_min, l_max + 1, dtype=np.float64)
+    g = np.sinc(l - tau * bandwidth)                                   # [B,rx,1,tx,1,P,1,L]
+    hm = np.sum(a[..., None].astype(np.complex128) * g, axis=-3)       # [B,rx,ra,tx,ta,T,L]
+    if normalize:
+        c = np.mean(np.sum(np.abs(hm) ** 2, axis=6, keepdims=True), axis=(2, 4, 5), keepdims=True)
+        hm = np.where(c > 0, hm / np.sqrt(np.where(c > 0, c, 1)), 0)
+    return hm.astype(np.complex64)
+
+
+def apply_time_channel(x, h_time):
+    """channel/apply_time_channel.py:95-175 without noise: x [B,tx,ta,Tn],
+    h_time [B,rx,ra,tx,ta,Tn+L-1,L] -> y [B,rx,ra,Tn+L-1]."""
+    B, rx, ra, tx, ta, Tout, L = h_time.shape
+    Tn = x.shape[-1]
+    assert Tout == Tn + L - 1
+    xp = np.concatenate([x.astype(np.complex128), np.zeros(x.shape[:-1] + (L,), np.complex128)], axis=-1)
+    y = np.zeros((B, rx, ra, Tout), np.complex128)
+    t = np.arange(Tout)
+    for l in range(L):
+        idx = t - l
+        valid = (idx >= 0) & (idx < Tn)
+        xs = np.where(valid, xp[..., np.clip(idx, 0, Tn - 1)], 0)      # [B,tx,ta,Tout]
+        y += np.sum(h_time[..., l].astype(np.complex128) * xs[:, None, None], axis=(3, 4))
+    return y.astype(np.complex64)

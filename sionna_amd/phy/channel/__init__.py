@@ -2,4 +2,6 @@
 from .awgn import AWGN
 from .utils import subcarrier_frequencies, cir_to_ofdm_channel
 from .ofdm_channel import GenerateOFDMChannel, ApplyOFDMChannel, OFDMChannel, RayleighBlockFading
+from .time_channel import (time_lag_discrete_time_channel, cir_to_time_channel, GenerateTimeChannel,
+                           ApplyTimeChannel, TimeChannel)
 from . import tr38901

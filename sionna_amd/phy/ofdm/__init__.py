@@ -5,3 +5,4 @@ from .resource_grid import ResourceGrid, ResourceGridMapper, ResourceGridDemappe
 from .channel_estimation import LSChannelEstimator, NearestNeighborInterpolator
 from .equalization import OFDMEqualizer, LMMSEEqualizer
 from .detection import LinearDetector
+from .modulator import OFDMModulator, OFDMDemodulator

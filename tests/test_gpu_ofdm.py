@@ -233,3 +233,97 @@ def test_c4_chain_high_snr_is_error_free(phy):
         assert float((b != b_hat).float().mean()) == 0.0
     ber, bler = phy.utils.sim_ber(mc_fun, [-5.0, 25.0], batch_size=32, max_mc_iter=2, verbose=False)
     assert ber.numpy()[0] > 0.05 and ber.numpy()[1] == 0
+
+
+# ------------------------------------------------------------------ time-domain variant (rocFFT)
+def _cplx(rng, shape):
+    return (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(np.complex64)
+
+
+@pytest.mark.parametrize("cp", [0, 1, 6, 12, 72])
+def test_ofdm_modulator_demodulator_vs_oracle(phy, cp):
+    rng = np.random.default_rng(cp)
+    x = _cplx(rng, (16, 2, 14, 72))
+    xt = _np(phy.ofdm.OFDMModulator(cp)(x))
+    ref = o.ofdm_modulate(x, cp)
+    assert xt.shape == ref.shape
+    assert np.allclose(xt, ref, rtol=1e-4, atol=2e-5)
+    sym = xt.reshape(16, 2, 14, -1)
+    if cp:   # reference test_cyclic_prefixes: prefix is a bit copy of the tail
+        assert np.array_equal(sym[..., :cp], sym[..., -cp:])
+    for l_min in (0, -3):
+        xh = _np(phy.ofdm.OFDMDemodulator(72, l_min, cp)(ref))
+        assert np.allclose(xh, o.ofdm_demodulate(ref, 72, l_min, cp), rtol=1e-4, atol=2e-5)
+    # round trip + trailing samples ignored (reference test_overlapping_input)
+    x_time = np.concatenate([xt, xt[..., :10]], axis=-1)
+    assert np.max(np.abs(_np(phy.ofdm.OFDMDemodulator(72, 0, cp)(x_time)) - x)) < 1e-5 * 4
+
+
+def test_ofdm_modulator_variable_cp_and_errors(phy):
+    rng = np.random.default_rng(5)
+    cps = np.arange(72)
+    x = _cplx(rng, (3, 72, 72))
+    xt = _np(phy.ofdm.OFDMModulator(cps)(x))
+    assert np.allclose(xt, o.ofdm_modulate(x, cps), rtol=1e-4, atol=2e-5)
+    xh = _np(phy.ofdm.OFDMDemodulator(72, 0, cps)(xt))
+    assert np.max(np.abs(xh - x)) < 4e-5
+    with pytest.raises(ValueError):
+        phy.ofdm.OFDMModulator(73)(x)
+    with pytest.raises(ValueError):
+        phy.ofdm.OFDMModulator(-1)
+    # other transform sizes (power of two, odd, large)
+    for n in (64, 75, 1024, 4096):
+        x = _cplx(rng, (2, 3, n))
+        xt = _np(phy.ofdm.OFDMModulator(7)(x))
+        assert np.allclose(xt, o.ofdm_modulate(x, 7), rtol=1e-4, atol=1e-4)
+        assert np.max(np.abs(_np(phy.ofdm.OFDMDemodulator(n, 0, 7)(xt)) - x)) < 1e-4
+
+
+@pytest.mark.parametrize("tn,l_tot", [(1, 1), (5, 3), (32, 8), (128, 16), (300, 27)])
+def test_apply_time_channel_vs_oracle(phy, tn, l_tot):
+    rng = np.random.default_rng(tn)
+    B, rx, ra, tx, ta = 5, 2, 4, 2, 2
+    x = _cplx(rng, (B, tx, ta, tn))
+    h = _cplx(rng, (B, rx, ra, tx, ta, tn + l_tot - 1, l_tot))
+    y = _np(phy.channel.ApplyTimeChannel(tn, l_tot)(x, h))
+    assert y.shape == (B, rx, ra, tn + l_tot - 1)
+    assert np.allclose(y, o.apply_time_channel(x, h), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_cir_to_time_channel_vs_oracle(phy, normalize):
+    tdl = phy.channel.tr38901.TDL("C", 300e-9, 3.5e9, min_speed=3., max_speed=30., num_rx_ant=2, num_tx_ant=2)
+    bw = 76 * 30e3
+    l_min, l_max = phy.channel.time_lag_discrete_time_channel(bw)
+    assert (l_min, l_max) == o.time_lag_discrete_time_channel(bw)
+    a, tau = tdl(6, 200, bw)
+    h = _np(phy.channel.cir_to_time_channel(bw, a, tau, l_min, l_max, normalize))
+    ref = o.cir_to_time_channel(bw, _np(a), _np(tau), l_min, l_max, normalize)
+    assert h.shape == ref.shape == (6, 1, 2, 1, 2, 200, l_max - l_min + 1)
+    assert np.allclose(h, ref, rtol=1e-4, atol=2e-5)
+    if normalize:
+        e = np.mean(np.sum(np.abs(h) ** 2, axis=6), axis=(2, 4, 5))
+        assert np.allclose(e, 1.0, atol=1e-4)
+
+
+def test_time_domain_chain_matches_frequency_response(phy):
+    """Reference test_channel_utils.py:83-135 restated: mod -> TimeChannel (static TDL-A) -> demod
+    equals H[k] x[k] with H the DFT of the taps, for taps inside the cyclic prefix."""
+    cp, n, nsym, B = 10, 128, 5, 8
+    rg = phy.ofdm.ResourceGrid(nsym, n, 15e3, cyclic_prefix_length=cp)
+    l_min, l_max = -4, 6
+    tdl = phy.channel.tr38901.TDL("A", 100e-9, 3.5e9, min_speed=0., max_speed=0.)
+    ch = phy.channel.TimeChannel(tdl, rg.bandwidth, rg.num_time_samples, l_min=l_min, l_max=l_max,
+                                 normalize_channel=True, return_channel=True)
+    rng = np.random.default_rng(2)
+    x = _cplx(rng, (B, 1, 1, nsym, n))
+    xt = phy.ofdm.OFDMModulator(cp)(x)
+    y, h_time = ch(xt)
+    yf = _np(phy.ofdm.OFDMDemodulator(n, l_min, cp)(y))
+    taps = _np(h_time)[:, 0, 0, 0, 0, 0, :].astype(np.complex128)
+    k = np.arange(n) - n // 2
+    H = (taps[:, None, :] * np.exp(-2j * np.pi * k[None, :, None] * np.arange(l_min, l_max + 1)[None, None, :] / n)).sum(-1)
+    assert np.allclose(yf[:, 0, 0], H[:, None, :] * x[:, 0, 0], atol=1e-4)
+    # and the whole chain against the oracle on the same taps
+    ref = o.ofdm_demodulate(o.apply_time_channel(o.ofdm_modulate(x, cp), _np(h_time)), n, l_min, cp)
+    assert np.allclose(yf, ref, rtol=1e-4, atol=1e-4)
