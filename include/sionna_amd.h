@@ -75,6 +75,24 @@ int samd_ldpc_bp_decode_f32(const samd_ldpc_graph_t* g, const float* llr_in, flo
                             float offset, int hard_out, void* workspace,
                             size_t workspace_bytes, void* stream);
 
+/* Array CN schedule (`cn_schedule` argument of LDPCBPDecoder, decoding.py:252-270; "layered"
+ * of LDPC5GDecoder, :1383-1389): sub-iteration j updates the check nodes cn_schedule[j][:]
+ * (HOST int32 [num_sub][width], a node at most once per row) and then the variable nodes
+ * adjacent to them, num_iter times over all rows (_bp_iter, :463-520). */
+typedef struct samd_ldpc_schedule samd_ldpc_schedule_t;
+int samd_ldpc_schedule_create(const samd_ldpc_graph_t* g, const int32_t* cn_schedule, int num_sub,
+                              int width, samd_ldpc_schedule_t** out);
+void samd_ldpc_schedule_destroy(samd_ldpc_schedule_t* s);
+
+/* samd_ldpc_bp_decode_f32 under a schedule; same arguments, workspace and state semantics
+ * (state_in: the given msg_v2c is what the first sub-iteration's check nodes read, all c2v
+ * start at 0 - exactly the reference's behaviour). */
+int samd_ldpc_bp_decode_scheduled_f32(const samd_ldpc_graph_t* g, const samd_ldpc_schedule_t* sched,
+                                      const float* llr_in, float* out, int out_cols, float* state,
+                                      int state_in, int state_out, int batch, int num_iter,
+                                      int cn_mode, float llr_max, float offset, int hard_out,
+                                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * 5G-NR LDPC (quasi-cyclic) code handle: encoder, rate matching / recovery, decoder.
  * Replaces LDPC5GEncoder.__init__/call   fec/ldpc/encoding.py:61-137, 599-668

@@ -177,10 +177,10 @@ _VN = {"sum": vn_update_sum, "identity": vn_update_identity}
 
 # --------------------------------------------------------------------------- decoder
 class LDPCBPDecoder:
-    """decoding.py:13-637 (flooding schedule, built-in node updates, no callbacks)."""
+    """decoding.py:13-637 (flooding or array CN schedule, built-in node updates, no callbacks)."""
 
     def __init__(self, pcm, cn_update="boxplus-phi", vn_update="sum", hard_out=True,
-                 num_iter=20, llr_max=20., return_state=False, precision="single"):
+                 num_iter=20, llr_max=20., return_state=False, precision="single", cn_schedule="flooding"):
         if isinstance(pcm, np.ndarray):
             if not np.array_equal(pcm, pcm.astype(bool)):
                 raise ValueError("PC matrix must be binary.")
@@ -205,6 +205,28 @@ class LDPCBPDecoder:
         self._vn_update = _VN[vn_update]
         self.hard_out, self.num_iter, self.return_state = hard_out, num_iter, return_state
         self.llr_max = self.dtype(llr_max)
+        # decoding.py:252-270
+        if isinstance(cn_schedule, str) and cn_schedule == "flooding":
+            self.cn_schedule = None
+        elif isinstance(cn_schedule, np.ndarray):
+            cn_schedule = cn_schedule.astype(np.int32)
+            if cn_schedule.ndim != 2:
+                raise ValueError("cn_schedule must be of rank 2.")
+            if cn_schedule.max() >= self.num_cns:
+                raise ValueError("cn_schedule can only contain values smaller number_cns.")
+            if cn_schedule.min() < 0:
+                raise ValueError("cn_schedule cannot contain negative values.")
+            self.cn_schedule = cn_schedule
+            cn_sorted = self.cn_idx[self.v2c_perm]
+            starts = np.searchsorted(cn_sorted, np.arange(self.num_cns), "left")
+            ends = np.searchsorted(cn_sorted, np.arange(self.num_cns), "right")
+            self._sched = []
+            for row in cn_schedule:
+                pos = np.concatenate([np.arange(starts[c], ends[c]) for c in row])   # CN-view positions
+                rid = np.concatenate([np.full(ends[c] - starts[c], i) for i, c in enumerate(row)])
+                self._sched.append((pos, _Ragged(rid, len(row))))
+        else:
+            raise ValueError("cn_schedule can be 'flooding' or an array of ints.")
 
     def decode(self, llr_ch, num_iter=None, msg_v2c=None):
         """decoding.py:544-637.  llr_ch: [...,N_vn] logits; returns like the reference."""
@@ -223,10 +245,19 @@ class LDPCBPDecoder:
         msg_c2v = np.zeros_like(msg_v2c)
         x_hat = llr_ch
         for _ in range(int(num_iter)):
-            msg_cn = msg_v2c[self.v2c_perm]                                   # :479
-            msg_c2v = self._cn_update(self._cn_rag, msg_cn, self.llr_max)      # :482,500
-            msg_vn = msg_c2v[self.v2c_perm_inv]                               # :506
-            msg_v2c, x_hat = self._vn_update(self._vn_rag, msg_vn, llr_ch, self.llr_max)
+            if self.cn_schedule is None:
+                msg_cn = msg_v2c[self.v2c_perm]                                   # :479
+                msg_c2v = self._cn_update(self._cn_rag, msg_cn, self.llr_max)      # :482,500
+                msg_vn = msg_c2v[self.v2c_perm_inv]                               # :506
+                msg_v2c, x_hat = self._vn_update(self._vn_rag, msg_vn, llr_ch, self.llr_max)
+                continue
+            # array schedule (:463-520): msg_c2v lives in CN-view order between sub-iterations
+            for pos, rag in self._sched:
+                msg_cn = msg_v2c[self.v2c_perm[pos]]                              # :474-479
+                msg_c2v = msg_c2v.copy()
+                msg_c2v[pos] = self._cn_update(rag, msg_cn, self.llr_max)          # :488-497
+                msg_vn = msg_c2v[self.v2c_perm_inv]
+                msg_v2c, x_hat = self._vn_update(self._vn_rag, msg_vn, llr_ch, self.llr_max)
         x_hat = x_hat.T
         if self.hard_out:
             x_hat = (0 >= x_hat).astype(self.dtype)                           # :623
@@ -243,7 +274,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
 
     def __init__(self, code, cn_update="boxplus-phi", vn_update="sum", hard_out=True,
                  return_infobits=True, num_iter=20, llr_max=20., prune_pcm=True,
-                 return_state=False, precision="single"):
+                 return_state=False, precision="single", cn_schedule="flooding"):
         self.code = code
         pcm = code.pcm
         self.return_infobits = return_infobits
@@ -257,14 +288,19 @@ class LDPC5GDecoder(LDPCBPDecoder):
                     last_pos = idx
                 else:
                     break
+            if isinstance(cn_schedule, str) and cn_schedule == "layered":      # :1359-1364
+                nb_punc = int(np.floor(nb_punc / code.z) * code.z)
             self.n_pruned = int(max(last_pos, code.n_ldpc - nb_punc))
             self.nb_pruned = code.n_ldpc - self.n_pruned
             if self.nb_pruned > 0:
                 pcm = pcm[:-self.nb_pruned, :-self.nb_pruned]
         else:
             self.nb_pruned, self.n_pruned = 0, code.n_ldpc
+        if isinstance(cn_schedule, str) and cn_schedule == "layered":          # :1383-1389
+            z = code.z
+            cn_schedule = np.stack([np.arange(z) + i * z for i in range(pcm.shape[0] // z)], axis=0)
         super().__init__(pcm, cn_update, vn_update, hard_out, num_iter, llr_max,
-                         return_state, precision)
+                         return_state, precision, cn_schedule)
 
     def rate_recover(self, llr_ch):
         """decoding.py:1431-1475: [B,n] -> [B,N_vn] logits."""

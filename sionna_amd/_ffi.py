@@ -30,6 +30,10 @@ _SIGNATURES = {
     "samd_ldpc_bp_workspace_bytes": (_sz, [_vp, _i32]),
     "samd_ldpc_bp_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
                                        _i32, _vp, _sz, _vp]),
+    "samd_ldpc_schedule_create": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_vp)]),
+    "samd_ldpc_schedule_destroy": (None, [_vp]),
+    "samd_ldpc_bp_decode_scheduled_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32,
+                                                 _f32, _i32, _vp, _sz, _vp]),
     "samd_ldpc5g_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "samd_ldpc5g_destroy": (None, [_vp]),
     "samd_ldpc5g_encode_f32": (_i32, [_vp, _vp, _vp, _i32, _vp]),

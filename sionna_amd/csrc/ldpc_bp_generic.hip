@@ -23,6 +23,7 @@
 #include "common.h"
 #include "accurate_math.h"
 
+#include <algorithm>
 #include <vector>
 
 struct samd_ldpc_graph {
@@ -32,6 +33,18 @@ struct samd_ldpc_graph {
   int32_t* cn_edge = nullptr;  // [E] VN-major edge id of the i-th edge of each CN
   int32_t* cn_vn = nullptr;    // [E] VN index of that edge
   int32_t* vn_ptr = nullptr;   // [num_vn+1] (edges of a VN are contiguous)
+  std::vector<int32_t> h_cn_ptr, h_cn_vn;  // host copies for schedule construction
+};
+
+// CN schedule (decoding.py:252-270, 463-500): sub-iteration j updates the check nodes
+// cn_list[j] and then the variable nodes adjacent to them (all other VN outputs are
+// unchanged by construction, so recomputing them as the reference does is a no-op).
+struct samd_ldpc_schedule {
+  int num_sub = 0, width = 0, num_cn = 0;
+  int32_t* cn_list = nullptr;            // device [num_sub][width]
+  int32_t* vn_list = nullptr;            // device, concatenated per sub-iteration
+  std::vector<int32_t> vn_off;           // host [num_sub+1]
+  int32_t* first_mask = nullptr;         // device [num_cn]: 1 if CN is active in sub-iteration 0
 };
 
 namespace samd {
@@ -134,15 +147,23 @@ __device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr
   }
 }
 
-// ---- CN pass.  FIRST: v2c of iteration 0 = channel LLR of the edge's VN (decoding.py:571).
-template <int MODE, int MAXD, bool FIRST>
+// ---- CN pass.  Where the incoming v2c messages come from:
+//  SRC_V2C      the shared message buffer holds v2c (flooding, after a VN pass)
+//  SRC_LLR      v2c of iteration 0 = channel LLR of the edge's VN (decoding.py:571); aux = llr_t
+//  SRC_DERIVED  the buffer holds c2v and aux = x_tot [N_vn][Bs]: v2c_e = clip(x_tot[v] - c2v_e)
+//               (vn_update_sum, decoding.py:724-731) - scheduled decoding keeps c2v resident.
+// node_list (nullable): the check nodes to update, num_cn = its length.
+enum { SRC_V2C = 0, SRC_LLR = 1, SRC_DERIVED = 2 };
+
+template <int MODE, int MAXD, int SRC>
 __global__ __launch_bounds__(256) void cn_pass_kernel(
-    float* __restrict__ msg, const float* __restrict__ llr_t, const int32_t* __restrict__ cn_ptr,
-    const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ cn_vn, int num_cn, int bs4,
-    size_t stride, float llr_max, float offset) {
-  const int cn = blockIdx.y * 4 + threadIdx.y;
+    float* __restrict__ msg, const float* __restrict__ aux, const int32_t* __restrict__ cn_ptr,
+    const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ cn_vn,
+    const int32_t* __restrict__ node_list, int num_cn, int bs4, size_t stride, float llr_max, float offset) {
+  const int slot = blockIdx.y * 4 + threadIdx.y;
   const int b4 = blockIdx.x * kWave + threadIdx.x;
-  if (cn >= num_cn || b4 >= bs4) return;
+  if (slot >= num_cn || b4 >= bs4) return;
+  const int cn = node_list ? __builtin_amdgcn_readfirstlane(node_list[slot]) : slot;
   const int e0 = __builtin_amdgcn_readfirstlane(cn_ptr[cn]);
   const int d = __builtin_amdgcn_readfirstlane(cn_ptr[cn + 1]) - e0;
   float v0[MAXD], v1[MAXD], v2[MAXD], v3[MAXD];
@@ -150,8 +171,13 @@ __global__ __launch_bounds__(256) void cn_pass_kernel(
   for (int i = 0; i < MAXD; ++i)
     if (i < d) {
       float4 x;
-      if constexpr (FIRST) x = ld4(llr_t + (size_t)cn_vn[e0 + i] * stride + 4 * (size_t)b4);
+      if constexpr (SRC == SRC_LLR) x = ld4(aux + (size_t)cn_vn[e0 + i] * stride + 4 * (size_t)b4);
       else x = ld4(msg + (size_t)cn_edge[e0 + i] * stride + 4 * (size_t)b4);
+      if constexpr (SRC == SRC_DERIVED) {
+        const float4 t = ld4(aux + (size_t)cn_vn[e0 + i] * stride + 4 * (size_t)b4);
+        x.x = clampf(-1.f * x.x + t.x, -llr_max, llr_max); x.y = clampf(-1.f * x.y + t.y, -llr_max, llr_max);
+        x.z = clampf(-1.f * x.z + t.z, -llr_max, llr_max); x.w = clampf(-1.f * x.w + t.w, -llr_max, llr_max);
+      }
       v0[i] = x.x; v1[i] = x.y; v2[i] = x.z; v3[i] = x.w;
     }
   cn_update_col<MODE, MAXD>(v0, d, llr_max, offset);
@@ -166,17 +192,21 @@ __global__ __launch_bounds__(256) void cn_pass_kernel(
 }
 
 // High-degree fallback: one column per lane-slot, values re-read from memory (two passes).
-template <int MODE, bool FIRST>
+template <int MODE, int SRC>
 __global__ __launch_bounds__(256) void cn_pass_bigdeg_kernel(
-    float* __restrict__ msg, const float* __restrict__ llr_t, const int32_t* __restrict__ cn_ptr,
-    const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ cn_vn, int num_cn, int bs,
-    size_t stride, float llr_max, float offset) {
-  const int cn = blockIdx.y * 4 + threadIdx.y;
+    float* __restrict__ msg, const float* __restrict__ aux, const int32_t* __restrict__ cn_ptr,
+    const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ cn_vn,
+    const int32_t* __restrict__ node_list, int num_cn, int bs, size_t stride, float llr_max, float offset) {
+  const int slot = blockIdx.y * 4 + threadIdx.y;
   const int b = blockIdx.x * kWave + threadIdx.x;
-  if (cn >= num_cn || b >= bs) return;
+  if (slot >= num_cn || b >= bs) return;
+  const int cn = node_list ? node_list[slot] : slot;
   const int e0 = cn_ptr[cn], d = cn_ptr[cn + 1] - e0;
   auto load = [&](int i) -> float {
-    if constexpr (FIRST) return llr_t[(size_t)cn_vn[e0 + i] * stride + b];
+    if constexpr (SRC == SRC_LLR) return aux[(size_t)cn_vn[e0 + i] * stride + b];
+    else if constexpr (SRC == SRC_DERIVED)
+      return clampf(-1.f * msg[(size_t)cn_edge[e0 + i] * stride + b] + aux[(size_t)cn_vn[e0 + i] * stride + b],
+                    -llr_max, llr_max);
     else return msg[(size_t)cn_edge[e0 + i] * stride + b];
   };
   // chunks of 32 values through the register kernel are not possible for a reduction over
@@ -313,8 +343,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* __restrict__ in,
 }
 
 // ---- x_hat [rows, Bs] -> out [B, rows]: hard decision (0 >= x) or logits (-x).
+// clip: the scheduled path keeps the unclipped x_tot and clips here (INFINITY = identity).
 __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ xhat_t, float* __restrict__ out,
-                                                     int batch, int rows, size_t stride, int hard) {
+                                                     int batch, int rows, size_t stride, int hard, float clip) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -326,7 +357,7 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ x
   for (int r = ty; r < 64; r += 4) {
     const int b = b0 + r, row = r0 + tx;
     if (b < batch && row < rows) {
-      const float x = tile[tx][r];
+      const float x = clampf(tile[tx][r], -clip, clip);
       out[(size_t)b * rows + row] = hard ? ((0.f >= x) ? 1.f : 0.f) : -1.f * x;
     }
   }
@@ -350,35 +381,104 @@ __global__ void init_v2c_kernel(float* __restrict__ msg, const float* __restrict
   for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e) msg[(size_t)e * stride + b] = l;
 }
 
-template <int MODE, bool FIRST>
-static void launch_cn(const samd_ldpc_graph* g, float* msg, const float* llr_t, int bs, float llr_max,
-                      float offset, hipStream_t st) {
+// ---- scheduled decoding: x_tot[v] = (sum_e c2v_e) + llr[v] for the listed VNs (vn_update_sum
+// with the c2v-resident buffer; v2c is derived on the fly by the CN pass).
+template <int MAXD>
+__global__ __launch_bounds__(256) void vn_total_kernel(
+    const float* __restrict__ msg, const float* __restrict__ llr_t, float* __restrict__ xtot,
+    const int32_t* __restrict__ vn_ptr, const int32_t* __restrict__ node_list, int n_nodes, int bs4, size_t stride) {
+  const int slot = blockIdx.y * 4 + threadIdx.y;
+  const int b4 = blockIdx.x * kWave + threadIdx.x;
+  if (slot >= n_nodes || b4 >= bs4) return;
+  const int vn = __builtin_amdgcn_readfirstlane(node_list[slot]);
+  const int e0 = __builtin_amdgcn_readfirstlane(vn_ptr[vn]);
+  const int d = __builtin_amdgcn_readfirstlane(vn_ptr[vn + 1]) - e0;
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (MAXD > 0) {
+#pragma unroll
+    for (int i = 0; i < MAXD; ++i)
+      if (i < d) {
+        const float4 c = ld4(msg + (size_t)(e0 + i) * stride + 4 * (size_t)b4);
+        x.x += c.x; x.y += c.y; x.z += c.z; x.w += c.w;
+      }
+  } else {
+    for (int i = 0; i < d; ++i) {
+      const float4 c = ld4(msg + (size_t)(e0 + i) * stride + 4 * (size_t)b4);
+      x.x += c.x; x.y += c.y; x.z += c.z; x.w += c.w;
+    }
+  }
+  const float4 l = ld4(llr_t + (size_t)vn * stride + 4 * (size_t)b4);
+  x.x += l.x; x.y += l.y; x.z += l.z; x.w += l.w;
+  st4(xtot + (size_t)vn * stride + 4 * (size_t)b4, x);
+}
+
+// c2v = 0 for every check node that is not active in sub-iteration 0 (state_in start).
+__global__ void zero_inactive_kernel(float* __restrict__ msg, const int32_t* __restrict__ cn_ptr,
+                                     const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ active,
+                                     int bs, size_t stride) {
+  const int cn = blockIdx.y;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= bs || active[cn]) return;
+  for (int i = cn_ptr[cn]; i < cn_ptr[cn + 1]; ++i) msg[(size_t)cn_edge[i] * stride + b] = 0.f;
+}
+
+// state_out of the scheduled path: msg_v2c[e] = clip(x_tot[v] - c2v_e), logit sign, [E,B].
+__global__ void v2c_state_kernel(const float* __restrict__ msg, const float* __restrict__ xtot,
+                                 const int32_t* __restrict__ vn_ptr, float* __restrict__ state, int batch,
+                                 size_t stride, float llr_max) {
+  const int vn = blockIdx.y;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  const float x = xtot[(size_t)vn * stride + b];
+  for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e)
+    state[(size_t)e * batch + b] = -1.f * clampf(-1.f * msg[(size_t)e * stride + b] + x, -llr_max, llr_max);
+}
+
+static void launch_vn_total(const samd_ldpc_graph* g, const float* msg, const float* llr_t, float* xtot,
+                            const int32_t* node_list, int n_nodes, int bs, hipStream_t st) {
   const dim3 blk(kWave, 4);
   const int bs4 = bs / 4;
-  const dim3 grid((bs4 + kWave - 1) / kWave, (g->num_cn + 3) / 4);
-#define SAMD_CN_LAUNCH(MAXD)                                                                      \
-  hipLaunchKernelGGL((cn_pass_kernel<MODE, MAXD, FIRST>), grid, blk, 0, st, msg, llr_t, g->cn_ptr, \
-                     g->cn_edge, g->cn_vn, g->num_cn, bs4, (size_t)bs, llr_max, offset)
+  const dim3 grid((bs4 + kWave - 1) / kWave, (n_nodes + 3) / 4);
+#define SAMD_VT_LAUNCH(MAXD)                                                                          \
+  hipLaunchKernelGGL((vn_total_kernel<MAXD>), grid, blk, 0, st, msg, llr_t, xtot, g->vn_ptr, node_list, \
+                     n_nodes, bs4, (size_t)bs)
+  if (g->max_dv <= 8) SAMD_VT_LAUNCH(8);
+  else if (g->max_dv <= 32) SAMD_VT_LAUNCH(32);
+  else SAMD_VT_LAUNCH(0);
+#undef SAMD_VT_LAUNCH
+}
+
+template <int MODE, int SRC>
+static void launch_cn(const samd_ldpc_graph* g, float* msg, const float* aux, const int32_t* node_list, int n_nodes,
+                      int bs, float llr_max, float offset, hipStream_t st) {
+  const dim3 blk(kWave, 4);
+  const int bs4 = bs / 4;
+  const dim3 grid((bs4 + kWave - 1) / kWave, (n_nodes + 3) / 4);
+#define SAMD_CN_LAUNCH(MAXD)                                                                    \
+  hipLaunchKernelGGL((cn_pass_kernel<MODE, MAXD, SRC>), grid, blk, 0, st, msg, aux, g->cn_ptr,   \
+                     g->cn_edge, g->cn_vn, node_list, n_nodes, bs4, (size_t)bs, llr_max, offset)
   if (g->max_dc <= 8) SAMD_CN_LAUNCH(8);
   else if (g->max_dc <= 12) SAMD_CN_LAUNCH(12);
   else if (g->max_dc <= 20) SAMD_CN_LAUNCH(20);
   else if (g->max_dc <= 32) SAMD_CN_LAUNCH(32);
   else {
-    const dim3 grid1((bs + kWave - 1) / kWave, (g->num_cn + 3) / 4);
-    hipLaunchKernelGGL((cn_pass_bigdeg_kernel<MODE, FIRST>), grid1, blk, 0, st, msg, llr_t, g->cn_ptr,
-                       g->cn_edge, g->cn_vn, g->num_cn, bs, (size_t)bs, llr_max, offset);
+    const dim3 grid1((bs + kWave - 1) / kWave, (n_nodes + 3) / 4);
+    hipLaunchKernelGGL((cn_pass_bigdeg_kernel<MODE, SRC>), grid1, blk, 0, st, msg, aux, g->cn_ptr, g->cn_edge,
+                       g->cn_vn, node_list, n_nodes, bs, (size_t)bs, llr_max, offset);
   }
 #undef SAMD_CN_LAUNCH
 }
 
-template <bool FIRST>
-static int launch_cn_mode(const samd_ldpc_graph* g, int mode, float* msg, const float* llr_t, int bs,
-                          float llr_max, float offset, hipStream_t st) {
+// node_list == nullptr: all check nodes.
+template <int SRC>
+static int launch_cn_mode(const samd_ldpc_graph* g, int mode, float* msg, const float* aux, int bs, float llr_max,
+                          float offset, hipStream_t st, const int32_t* node_list = nullptr, int n_nodes = -1) {
+  if (n_nodes < 0) n_nodes = g->num_cn;
   switch (mode) {
-    case SAMD_CN_BOXPLUS: launch_cn<SAMD_CN_BOXPLUS, FIRST>(g, msg, llr_t, bs, llr_max, offset, st); break;
-    case SAMD_CN_BOXPLUS_PHI: launch_cn<SAMD_CN_BOXPLUS_PHI, FIRST>(g, msg, llr_t, bs, llr_max, offset, st); break;
-    case SAMD_CN_MINSUM: launch_cn<SAMD_CN_MINSUM, FIRST>(g, msg, llr_t, bs, llr_max, 0.f, st); break;
-    case SAMD_CN_OFFSET_MINSUM: launch_cn<SAMD_CN_OFFSET_MINSUM, FIRST>(g, msg, llr_t, bs, llr_max, offset, st); break;
+    case SAMD_CN_BOXPLUS: launch_cn<SAMD_CN_BOXPLUS, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, offset, st); break;
+    case SAMD_CN_BOXPLUS_PHI: launch_cn<SAMD_CN_BOXPLUS_PHI, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, offset, st); break;
+    case SAMD_CN_MINSUM: launch_cn<SAMD_CN_MINSUM, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, 0.f, st); break;
+    case SAMD_CN_OFFSET_MINSUM: launch_cn<SAMD_CN_OFFSET_MINSUM, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, offset, st); break;
     default: set_error("unknown cn_mode"); return SAMD_ERR_INVALID;
   }
   return SAMD_OK;
@@ -435,6 +535,7 @@ extern "C" int samd_ldpc_graph_create(const int32_t* cn_idx, const int32_t* vn_i
   auto* g = new samd_ldpc_graph();
   g->num_edges = num_edges; g->num_cn = num_cn; g->num_vn = num_vn;
   g->max_dc = max_dc; g->max_dv = max_dv;
+  g->h_cn_ptr = cn_ptr; g->h_cn_vn = cn_vn;
   int rc = upload(&g->cn_ptr, cn_ptr.data(), cn_ptr.size());
   if (rc == SAMD_OK) rc = upload(&g->cn_edge, cn_edge.data(), cn_edge.size());
   if (rc == SAMD_OK) rc = upload(&g->cn_vn, cn_vn.data(), cn_vn.size());
@@ -497,19 +598,123 @@ extern "C" int samd_ldpc_bp_decode_f32(const samd_ldpc_graph_t* g, const float* 
   }
   for (int it = 0; it < num_iter; ++it) {
     int rc;
-    if (it == 0 && !state_in) rc = launch_cn_mode<true>(g, cn_mode, msg, llr_t, (int)bs, llr_max, offset, st);
-    else rc = launch_cn_mode<false>(g, cn_mode, msg, llr_t, (int)bs, llr_max, offset, st);
+    if (it == 0 && !state_in) rc = launch_cn_mode<SRC_LLR>(g, cn_mode, msg, llr_t, (int)bs, llr_max, offset, st);
+    else rc = launch_cn_mode<SRC_V2C>(g, cn_mode, msg, llr_t, (int)bs, llr_max, offset, st);
     if (rc != SAMD_OK) return rc;
     if (it == num_iter - 1) launch_vn<true>(g, msg, llr_t, xhat_t, out_cols, (int)bs, llr_max, st);
     else launch_vn<false>(g, msg, llr_t, xhat_t, out_cols, (int)bs, llr_max, st);
   }
   {
     const dim3 grid((out_cols + 63) / 64, bs / 64);
-    hipLaunchKernelGGL(finish_kernel, grid, dim3(256), 0, st, xsrc, out, batch, out_cols, bs, hard_out);
+    hipLaunchKernelGGL(finish_kernel, grid, dim3(256), 0, st, xsrc, out, batch, out_cols, bs, hard_out, INFINITY);
   }
   if (state_out) {
     const dim3 grid((batch + 255) / 256, g->num_edges);
     hipLaunchKernelGGL(state_copy_kernel, grid, dim3(256), 0, st, msg, state, batch, bs, (size_t)batch, g->num_edges);
+  }
+  return launch_status();
+}
+
+
+// ---------------------------------------------------------------- scheduled (layered) decoding
+extern "C" int samd_ldpc_schedule_create(const samd_ldpc_graph_t* g, const int32_t* cn_schedule, int num_sub,
+                                         int width, samd_ldpc_schedule_t** out) {
+  SAMD_REQUIRE(g && cn_schedule && out, "null argument");
+  SAMD_REQUIRE(num_sub > 0 && width > 0, "empty schedule");
+  std::vector<int32_t> vn_list, vn_off(1, 0), mask(g->num_cn, 0);
+  std::vector<char> seen(g->num_vn);
+  for (int j = 0; j < num_sub; ++j) {
+    std::fill(seen.begin(), seen.end(), 0);
+    std::vector<char> cn_seen(g->num_cn, 0);
+    for (int i = 0; i < width; ++i) {
+      const int cn = cn_schedule[(size_t)j * width + i];
+      SAMD_REQUIRE(cn >= 0 && cn < g->num_cn, "cn_schedule entry out of range");
+      SAMD_REQUIRE(!cn_seen[cn], "cn_schedule row holds a check node twice");
+      cn_seen[cn] = 1;
+      if (j == 0) mask[cn] = 1;
+      for (int e = g->h_cn_ptr[cn]; e < g->h_cn_ptr[cn + 1]; ++e) seen[g->h_cn_vn[e]] = 1;
+    }
+    for (int v = 0; v < g->num_vn; ++v)
+      if (seen[v]) vn_list.push_back(v);
+    vn_off.push_back((int32_t)vn_list.size());
+  }
+  auto* s = new samd_ldpc_schedule();
+  s->num_sub = num_sub; s->width = width; s->num_cn = g->num_cn; s->vn_off = vn_off;
+  int rc = upload(&s->cn_list, cn_schedule, (size_t)num_sub * width);
+  if (rc == SAMD_OK) rc = upload(&s->vn_list, vn_list.data(), vn_list.size());
+  if (rc == SAMD_OK) rc = upload(&s->first_mask, mask.data(), mask.size());
+  if (rc != SAMD_OK) { samd_ldpc_schedule_destroy(s); return rc; }
+  *out = s;
+  return SAMD_OK;
+}
+
+extern "C" void samd_ldpc_schedule_destroy(samd_ldpc_schedule_t* s) {
+  if (!s) return;
+  (void)hipFree(s->cn_list); (void)hipFree(s->vn_list); (void)hipFree(s->first_mask);
+  delete s;
+}
+
+extern "C" int samd_ldpc_bp_decode_scheduled_f32(const samd_ldpc_graph_t* g, const samd_ldpc_schedule_t* sched,
+                                                 const float* llr_in, float* out, int out_cols, float* state,
+                                                 int state_in, int state_out, int batch, int num_iter, int cn_mode,
+                                                 float llr_max, float offset, int hard_out, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  SAMD_REQUIRE(g && sched && llr_in && out, "null argument");
+  SAMD_REQUIRE(sched->num_cn == g->num_cn, "schedule was built for another graph");
+  SAMD_REQUIRE(batch > 0 && num_iter >= 0, "bad batch / num_iter");
+  SAMD_REQUIRE(out_cols > 0 && out_cols <= g->num_vn, "bad out_cols");
+  SAMD_REQUIRE(!(state_in || state_out) || state, "state pointer missing");
+  SAMD_REQUIRE(cn_mode >= 0 && cn_mode <= 3, "unknown cn_mode");
+  if (workspace_bytes < samd_ldpc_bp_workspace_bytes(g, batch) || !workspace) {
+    set_error("workspace too small");
+    return SAMD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t bs = padded_batch(batch);
+  float* base = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
+  float* msg = base;                                  // c2v, resident for all edges
+  float* llr_t = msg + (size_t)g->num_edges * bs;
+  float* xtot = llr_t + (size_t)g->num_vn * bs;       // unclipped llr + sum c2v
+  {
+    const dim3 grid((g->num_vn + 63) / 64, bs / 64);
+    hipLaunchKernelGGL(prep_kernel, grid, dim3(256), 0, st, llr_in, llr_t, batch, g->num_vn, bs, llr_max);
+  }
+  SAMD_HIP_CHECK(hipMemcpyAsync(xtot, llr_t, (size_t)g->num_vn * bs * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (state_in) {
+    const dim3 grid((batch + 255) / 256, g->num_edges);
+    hipLaunchKernelGGL(state_copy_kernel, grid, dim3(256), 0, st, state, msg, batch, (size_t)batch, bs, g->num_edges);
+  } else {
+    SAMD_HIP_CHECK(hipMemsetAsync(msg, 0, (size_t)g->num_edges * bs * sizeof(float), st));  // msg_c2v = 0 (:581)
+  }
+  bool v2c_from_state = state_in != 0;  // only the very first sub-iteration sees the given v2c
+  for (int it = 0; it < num_iter; ++it)
+    for (int j = 0; j < sched->num_sub; ++j) {
+      const int32_t* cns = sched->cn_list + (size_t)j * sched->width;
+      int rc;
+      if (v2c_from_state) {
+        rc = launch_cn_mode<SRC_V2C>(g, cn_mode, msg, xtot, (int)bs, llr_max, offset, st, cns, sched->width);
+        const dim3 grid(((int)bs + 255) / 256, g->num_cn);
+        hipLaunchKernelGGL(zero_inactive_kernel, grid, dim3(256), 0, st, msg, g->cn_ptr, g->cn_edge, sched->first_mask,
+                           (int)bs, bs);
+        v2c_from_state = false;
+      } else {
+        rc = launch_cn_mode<SRC_DERIVED>(g, cn_mode, msg, xtot, (int)bs, llr_max, offset, st, cns, sched->width);
+      }
+      if (rc != SAMD_OK) return rc;
+      launch_vn_total(g, msg, llr_t, xtot, sched->vn_list + sched->vn_off[j], sched->vn_off[j + 1] - sched->vn_off[j],
+                      (int)bs, st);
+    }
+  {
+    const dim3 grid((out_cols + 63) / 64, bs / 64);
+    hipLaunchKernelGGL(finish_kernel, grid, dim3(256), 0, st, xtot, out, batch, out_cols, bs, hard_out, llr_max);
+  }
+  if (state_out) {
+    if (num_iter == 0 && state_in) {
+      // nothing ran: the state is returned as given
+    } else {
+      const dim3 grid((batch + 255) / 256, g->num_vn);
+      hipLaunchKernelGGL(v2c_state_kernel, grid, dim3(256), 0, st, msg, xtot, g->vn_ptr, state, batch, bs, llr_max);
+    }
   }
   return launch_status();
 }

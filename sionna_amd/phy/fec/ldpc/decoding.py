@@ -11,7 +11,7 @@ Two HIP engines sit behind the same Block API:
   rate recovery + all iterations + output mapping in one kernel (csrc/ldpc5g.hip).
 
 Both use the arithmetic and summation order of oracle/ldpc_bp.py.  Python callables for
-node updates, message callbacks and non-flooding schedules have no HIP path and raise
+node updates and message callbacks have no HIP path and raise
 ``NotImplementedError`` (there is deliberately no CPU fallback).
 """
 import ctypes as C
@@ -89,7 +89,11 @@ class LDPCBPDecoder(Block):
                 raise ValueError("cn_schedule can only contain values smaller number_cns.")
             if sched.min() < 0:
                 raise ValueError("cn_schedule cannot contain negative values.")
-            raise NotImplementedError("custom / layered cn_schedule has no HIP path yet (flooding only)")
+            for row in sched:
+                if len(np.unique(row)) != len(row):
+                    raise ValueError("cn_schedule rows must not hold a check node twice.")
+            self._scheduling = "custom"
+            self._cn_schedule = np.ascontiguousarray(sched, dtype=np.int32)
         else:
             raise ValueError("cn_schedule can be 'flooding' or an array of ints.")
 
@@ -117,6 +121,7 @@ class LDPCBPDecoder(Block):
         self._vn_idx = np.ascontiguousarray(vn_idx[order], dtype=np.int32)
         self._num_edges = len(self._vn_idx)
         self._graph = None
+        self._sched = None
         self._ws = _ffi.Workspace()
 
     # ------------------------------------------------------------ properties (decoding.py:351-410)
@@ -164,8 +169,20 @@ class LDPCBPDecoder(Block):
             self._graph = h
         return self._graph
 
+    def _schedule_handle(self):
+        if self._sched is None:
+            h = C.c_void_p()
+            sc = self._cn_schedule
+            _ffi.check(_ffi.lib().samd_ldpc_schedule_create(self._graph_handle(), sc.ctypes.data_as(C.c_void_p),
+                                                            sc.shape[0], sc.shape[1], C.byref(h)),
+                       "samd_ldpc_schedule_create")
+            self._sched = h
+        return self._sched
+
     def __del__(self):
         try:
+            if self._sched is not None:
+                _ffi.lib().samd_ldpc_schedule_destroy(self._sched)
             if self._graph is not None:
                 _ffi.lib().samd_ldpc_graph_destroy(self._graph)
         except Exception:  # pylint: disable=broad-except
@@ -196,11 +213,14 @@ class LDPCBPDecoder(Block):
             nb = min(step, batch - b0)
             need = lib.samd_ldpc_bp_workspace_bytes(g, nb)
             ws, ws_bytes = self._ws.get(need)
-            _ffi.check(lib.samd_ldpc_bp_decode_f32(
-                g, _ffi.ptr(llr[b0:b0 + nb]), _ffi.ptr(out[b0:b0 + nb]), out_cols, _ffi.ptr(state),
-                int(msg_v2c is not None), int(want_state), nb, int(num_iter), self._cn_mode,
-                self._llr_max, self._offset, int(bool(hard)), _ffi.ptr(ws), ws_bytes, _ffi.stream()),
-                "LDPCBPDecoder")
+            args = (_ffi.ptr(llr[b0:b0 + nb]), _ffi.ptr(out[b0:b0 + nb]), out_cols, _ffi.ptr(state),
+                    int(msg_v2c is not None), int(want_state), nb, int(num_iter), self._cn_mode,
+                    self._llr_max, self._offset, int(bool(hard)), _ffi.ptr(ws), ws_bytes, _ffi.stream())
+            if self._scheduling == "flooding":
+                _ffi.check(lib.samd_ldpc_bp_decode_f32(g, *args), "LDPCBPDecoder")
+            else:
+                _ffi.check(lib.samd_ldpc_bp_decode_scheduled_f32(g, self._schedule_handle(), *args),
+                           "LDPCBPDecoder(scheduled)")
         return out, (state if want_state else None)
 
     # ------------------------------------------------------------ Block interface
@@ -251,7 +271,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
             tail = np.nonzero(dv[::-1] != 1)[0]
             last_pos = encoder.n_ldpc - (int(tail[0]) if len(tail) else encoder.n_ldpc - 1)
             last_pos = max(last_pos, 1)
-            if cn_schedule == "layered":
+            if isinstance(cn_schedule, str) and cn_schedule == "layered":
                 nb_punc_bits = int(np.floor(nb_punc_bits / encoder.z) * encoder.z)
             self._n_pruned = int(max(last_pos, encoder.n_ldpc - nb_punc_bits))
             self._nb_pruned_nodes = encoder.n_ldpc - self._n_pruned
@@ -262,8 +282,9 @@ class LDPC5GDecoder(LDPCBPDecoder):
         else:
             self._nb_pruned_nodes = 0
             self._n_pruned = encoder.n_ldpc
-        if cn_schedule == "layered":
-            raise NotImplementedError("layered scheduling has no HIP path yet (flooding only)")
+        if isinstance(cn_schedule, str) and cn_schedule == "layered":       # decoding.py:1383-1389
+            z = encoder.z
+            cn_schedule = np.stack([np.arange(z) + i * z for i in range(pcm.shape[0] // z)], axis=0)
         super().__init__(sp.csr_matrix(pcm), cn_update=cn_update, vn_update=vn_update,
                          cn_schedule=cn_schedule, hard_out=hard_out, num_iter=num_iter, llr_max=llr_max,
                          v2c_callbacks=v2c_callbacks, c2v_callbacks=c2v_callbacks,
@@ -305,7 +326,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
         out_shape = shape[:-1] + ((enc.k,) if self._return_infobits else (enc.n,))
 
         use_onchip = (self._onchip_ok and self._cn_mode in (2, 3) and not self._return_state
-                      and msg_v2c is None and batch > 0)
+                      and msg_v2c is None and batch > 0 and self._scheduling == "flooding")
         if use_onchip:
             out = self._try_onchip(llr2d, num_iter)
             if out is not None:

@@ -12,6 +12,7 @@ import pytest
 
 from oracle.ldpc5g import LDPC5GCode, generate_out_int
 from oracle import ldpc_bp as bp
+from oracle import utils as outil
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ldpc_enc_golden.npz"))
 
@@ -195,3 +196,56 @@ def test_pruning_equivalence():
     a = bp.LDPC5GDecoder(code, hard_out=False, prune_pcm=True, num_iter=10).decode5g(llr)
     b = bp.LDPC5GDecoder(code, hard_out=False, prune_pcm=False, num_iter=10).decode5g(llr)
     assert np.mean(np.abs(a - b)) < 5e-2
+
+
+# ------------------------------------------------------------------ CN schedules (layered decoding)
+def test_scheduling_independent_checks():
+    """Reference test_ldpc_decoding.py:121-160: two disjoint checks -> layered == flooding
+    bit for bit; updating only CN 0 differs."""
+    pcm = np.array([[1, 1, 1, 0, 0, 0], [0, 0, 0, 1, 1, 1]])
+    x = np.arange(6, dtype=np.float32)
+    outs = []
+    for cns in ("flooding", np.stack([[0], [1]]), np.stack([[0], [0]])):
+        dec = bp.LDPCBPDecoder(pcm, num_iter=10, hard_out=False, cn_update="minsum", cn_schedule=cns, llr_max=100000)
+        outs.append(dec.decode(x))
+    assert np.array_equal(outs[0], outs[1])
+    assert not np.array_equal(outs[0], outs[2])
+    for bad in (np.zeros(3, np.int32), np.array([[0, 2]]), np.array([[-1, 0]])):
+        with pytest.raises(ValueError):
+            bp.LDPCBPDecoder(pcm, cn_schedule=bad)
+    with pytest.raises(ValueError):
+        bp.LDPCBPDecoder(pcm, cn_schedule="layered")
+
+
+@pytest.mark.parametrize("k,n", [(12, 25), (20, 65), (45, 63), (12, 59), (500, 1000)])
+def test_scheduling_pruning_5g(k, n):
+    """Reference test_ldpc_decoding.py:735-757: pruning must not disturb the layered schedule."""
+    code = LDPC5GCode(k, n)
+    x = np.arange(n, dtype=np.float32)[None]
+    out = []
+    for p in (False, True):
+        dec = bp.LDPC5GDecoder(code, cn_schedule="layered", num_iter=5, return_infobits=False, hard_out=False,
+                                llr_max=10000, cn_update="minsum", prune_pcm=p)
+        out.append(-dec.decode5g(-x))
+    assert np.allclose(out[0], out[1])
+
+
+def test_layered_needs_about_half_the_iterations():
+    """Rule of thumb asserted by reference test_ldpc_decoding.py:689-733 (8 layered ~ 16 flooding)."""
+    k, n, B = 200, 400, 600
+    code = LDPC5GCode(k, n)
+    rng = np.random.default_rng(3)
+    b = rng.integers(0, 2, (B, k)).astype(np.float32)
+    c = code.encode(b)
+    no = outil.ebnodb2no(1.5, 2, k / n)
+    y = (2 * c - 1) + np.sqrt(no) * rng.normal(size=c.shape).astype(np.float32)
+    llr = (2 * y / no).astype(np.float32)
+    bler = []
+    for cns, it in (("layered", 8), ("flooding", 16)):
+        dec = bp.LDPC5GDecoder(code, num_iter=it, cn_update="boxplus", cn_schedule=cns)
+        bler.append(np.mean(np.any(dec.decode5g(llr) != b, axis=1)))
+    assert 0 < bler[1] < 0.5
+    assert np.isclose(bler[0], bler[1], rtol=0.7)
+    # and layered beats flooding at the same iteration count
+    dec = bp.LDPC5GDecoder(code, num_iter=8, cn_update="boxplus", cn_schedule="flooding")
+    assert np.mean(np.any(dec.decode5g(llr) != b, axis=1)) > bler[0]
