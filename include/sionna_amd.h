@@ -217,6 +217,18 @@ int samd_cir_to_ofdm_c64(const float* a, const float* tau, const float* frequenc
 int samd_apply_ofdm_channel_c64(const float* x, const float* h_freq, int batch, int num_rx_x_ant,
                                 int num_tx_x_ant, int num_re, float* y, void* stream);
 
+/* ---- scrambling --------------------------------------------------- */
+
+/* Scrambler.call fec/scrambling.py:186-261 / TB5GScrambler.call :442-468:
+ * out[i] = |x[i] - seq[i % period]| (binary) or x[i] * (1 - 2 seq[i % period]) (soft values).
+ * seq DEVICE float32 0/1 [period]; period = numel of the trailing dims the sequence spans. */
+int samd_scramble_f32(const float* x, const float* seq, int64_t total, int64_t period, int binary,
+                      float* out, void* stream);
+
+/* generate_prng_seq nr/utils.py:14-78 (TS 38.211 5.2.1 length-31 Gold sequence, N_c = 1600):
+ * out DEVICE float32 0/1 [length].  Init-time helper (host recurrence + one upload). */
+int samd_nr_prng_seq_f32(uint32_t c_init, int64_t length, float* out, void* stream);
+
 /* ---- time-domain variant of the OFDM chain -------------------------------------------- */
 
 /* OFDMModulator.call  ofdm/modulator.py:97-124 (ifftshift -> ifft (signal/utils.py:205-262,

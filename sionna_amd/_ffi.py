@@ -53,6 +53,8 @@ _SIGNATURES = {
     "samd_cir_to_ofdm_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_apply_ofdm_channel_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_ls_gather_scale_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_scramble_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "samd_nr_prng_seq_f32": (_i32, [C.c_uint32, _i64, _vp, _vp]),
     "samd_ofdm_modulate_c64": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "samd_ofdm_demodulate_c64": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "samd_cir_to_time_c64": (_i32, [C.c_float, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
@@ -142,7 +144,8 @@ def to_device(x, dtype):
     if isinstance(x, torch.Tensor):
         t = x
     else:
-        t = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+        a = np.ascontiguousarray(np.asarray(x))
+        t = torch.from_numpy(a if a.flags.writeable else a.copy())
     if t.dtype != dtype or t.device != device():
         t = t.to(device=device(), dtype=dtype)
     return t.contiguous()
