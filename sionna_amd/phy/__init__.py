@@ -3,4 +3,5 @@ from .config import config, dtypes
 from .block import Block, Object, Tensor
 from . import mapping, utils, channel, mimo, ofdm
 from . import fec
+from . import nr
 from .fec import ldpc

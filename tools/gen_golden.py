@@ -68,3 +68,16 @@ for i in range(len(ex)):
     pk[f"rc_{i}"] = np.stack([r, c]).astype(np.int32)
 np.savez_compressed(os.path.join(out_dir, "example_pcms.npz"), **pk)
 print("example pcms:", [tuple(pk[f"shape_{i}"]) for i in range(len(ex))])
+
+# ---- 5G NR transport-block vectors (test/unit/nr/tb_refs/*.npz): bit-packed re-pack
+d = os.path.join(ref, "test/unit/nr/tb_refs")
+pk, meta = {}, []
+for i, f in enumerate(sorted(os.listdir(d))):
+    t = np.load(os.path.join(d, f))
+    for key in ("u_ref", "c_ref", "c_ref_no_scr"):
+        pk[f"{key}_{i}"] = np.packbits(t[key].astype(np.uint8), axis=1)
+    meta.append([t["u_ref"].shape[1], t["c_ref"].shape[1], int(t["n_id"]), int(t["n_rnti"]),
+                 int(round(float(t["coderate"]) * 1000)), int(t["num_bits_per_symbol"]), int(t["num_layers"])])
+pk["meta"] = np.array(meta, np.int64)     # tb_size, num_coded_bits, n_id, n_rnti, coderate*1000, m, layers
+np.savez_compressed(os.path.join(out_dir, "tb_golden.npz"), **pk)
+print("tb refs:", meta)
