@@ -79,30 +79,43 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
     const float amp = sqrtf(mean_powers[p]);
     const float norm = 1.f / sqrtf((float)N);
     float2* o = a + i * T;
-    for (int t = 0; t < T; ++t) o[t] = make_float2(0.f, 0.f);
-    for (int n = 0; n < N; ++n) {
-      const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
-      const float phi = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
-      const float alpha = (2.f * pi / (float)N) * (float)(n + 1) + theta;
-      const float ca = cosf(alpha);
-      for (int t = 0; t < T; ++t) {
-        const float arg = doppler * ((float)t / sampling_frequency) * ca + phi;
-        float s, c;
-        sincosf(arg, &s, &c);
-        o[t].x += c; o[t].y += s;
+    // time steps in register-resident chunks: every tap is accumulated over the sinusoids in
+    // registers (in sinusoid order, as the oracle sums) and written exactly once
+    constexpr int kChunk = 16;
+    for (int t0 = 0; t0 < T; t0 += kChunk) {
+      float accx[kChunk], accy[kChunk];
+#pragma unroll
+      for (int k = 0; k < kChunk; ++k) accx[k] = accy[k] = 0.f;
+      for (int n = 0; n < N; ++n) {
+        const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
+        const float phi = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
+        const float alpha = (2.f * pi / (float)N) * (float)(n + 1) + theta;
+        const float ca = cosf(alpha);
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+          const float arg = doppler * ((float)(t0 + k) / sampling_frequency) * ca + phi;
+          float sn, cs;
+          sincosf(arg, &sn, &cs);
+          accx[k] += cs; accy[k] += sn;
+        }
       }
-    }
-    for (int t = 0; t < T; ++t) {
-      float2 h = make_float2(amp * (o[t].x * norm), amp * (o[t].y * norm));
-      if (los && p == 0) {
-        const float phi0 = uni(seed, call + 3, (uint64_t)b, -pi, pi);
-        const float arg = doppler * ((float)t / sampling_frequency) * cosf(los_aoa) + phi0;
-        float s, c;
-        sincosf(arg, &s, &c);
-        const float k = sqrtf(los_power);
-        h.x += c * k; h.y += s * k;
+      float phi0 = 0.f;
+      if (los && p == 0) phi0 = uni(seed, call + 3, (uint64_t)b, -pi, pi);
+#pragma unroll
+      for (int k = 0; k < kChunk; ++k) {
+        const int t = t0 + k;
+        if (t < T) {
+          float2 h = make_float2(amp * (accx[k] * norm), amp * (accy[k] * norm));
+          if (los && p == 0) {
+            const float arg = doppler * ((float)t / sampling_frequency) * cosf(los_aoa) + phi0;
+            float sn, cs;
+            sincosf(arg, &sn, &cs);
+            const float kf = sqrtf(los_power);
+            h.x += cs * kf; h.y += sn * kf;
+          }
+          o[t] = h;
+        }
       }
-      o[t] = h;
     }
   }
 }

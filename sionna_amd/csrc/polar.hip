@@ -124,14 +124,23 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   int* new_bit = clone_src + L;                           // [L]
   float* new_pm = reinterpret_cast<float*>(new_bit + L);  // [L]
   float* red = new_pm + L;                                // [256] reduction scratch
-  int* lops = reinterpret_cast<int*>(red + 256);          // [num_ops] decoding schedule (LDS copy: the
-                                                          // op fetch is on the critical path of every step)
+  // Lazy path copies.  All live paths execute the same op in lockstep and every op rewrites one whole
+  // (array, stage) region of every path, so a path always writes into its OWN slot and records that in
+  // its pointer table; a clone only inherits the tables (3 x 16 small ints) instead of the parent's n
+  // LLRs and 2n partial sums.  No op reads the (array, stage) region it writes, so re-using a dead
+  // slot that other tables still point to is safe: those tables are rewritten by the very op that
+  // overwrites the region.
+  unsigned char* lp = reinterpret_cast<unsigned char*>(red + 256);   // [L][16] slot of the stage-s LLRs
+  unsigned char* bl = lp + (size_t)L * 16;                           // [L][16] slot of the stage-s left sums
+  unsigned char* br = bl + (size_t)L * 16;                           // [L][16] slot of the stage-s right sums
+  int* lops = reinterpret_cast<int*>(br + (size_t)L * 16);           // [num_ops] decoding schedule (LDS copy:
+                                                                     // the op fetch is on the critical path)
   for (int i = tid; i < p.num_ops; i += NT) lops[i] = p.ops[i];
 
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
     for (int i = tid; i < n; i += NT) llr_ch[i] = -1.f * p.llr_in[(size_t)b * n + i];   // logits -> LLR
-    for (int i = tid; i < L * n; i += NT) { betaL[i] = 0; betaR[i] = 0; }
     for (int i = tid; i < L * words; i += NT) bits[i] = 0u;
+    for (int i = tid; i < L * 16; i += NT) { lp[i] = (unsigned char)(i >> 4); bl[i] = lp[i]; br[i] = lp[i]; }
     if (tid < L) { pm[tid] = tid == 0 ? 0.f : kPolarLlrMax; order[tid] = tid; }         // decoding.py:1029-1033
     __syncthreads();
 
@@ -145,25 +154,28 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         for (int w = tid; w < L * half; w += NT) {
           const int pos = w / half, j = w - pos * half;
           const int slot = order[pos];
-          const float* in = (s == p.m) ? llr_ch : (llr + (size_t)slot * n + (1 << s));
+          const float* in = (s == p.m) ? llr_ch : (llr + (size_t)lp[slot * 16 + s] * n + (1 << s));
           const float x = in[j], y = in[j + half];
           float r;
           if (op == OP_F) r = cn_op(x, y);
-          else r = (1.f - 2.f * (float)betaL[(size_t)slot * n + half + j]) * x + y;      // vn_op :707-714
+          else r = (1.f - 2.f * (float)betaL[(size_t)bl[slot * 16 + s - 1] * n + half + j]) * x + y;  // vn_op :707-714
           llr[(size_t)slot * n + half + j] = r;
         }
+        if (tid < L) lp[order[tid] * 16 + s - 1] = (unsigned char)order[tid];
         __syncthreads();
       } else if (op == OP_COMBINE) {
         // children results at stage s (a0) -> this node's result at stage s+1 on side a1
         const int s = a0, sz = 1 << s;
         for (int w = tid; w < L * sz; w += NT) {
           const int pos = w / sz, j = w - pos * sz;
-          const size_t base = (size_t)order[pos] * n;
-          const unsigned char l = betaL[base + sz + j], r = betaR[base + sz + j];
-          unsigned char* dst = (a1 ? betaR : betaL) + base + 2 * sz;
+          const int slot = order[pos];
+          const unsigned char l = betaL[(size_t)bl[slot * 16 + s] * n + sz + j];
+          const unsigned char r = betaR[(size_t)br[slot * 16 + s] * n + sz + j];
+          unsigned char* dst = (a1 ? betaR : betaL) + (size_t)slot * n + 2 * sz;
           dst[j] = l ^ r;
           dst[sz + j] = r;
         }
+        if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s + 1] = (unsigned char)order[tid];
         __syncthreads();
       } else {
         // ---- leaf / rate-0 / repetition node: a0 = stage s of the node, a1 = side, a2 = (last) bit index
@@ -173,14 +185,14 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         // block metrics of every live path: m0 = sum softplus(-l), m1 = sum softplus(+l)
         if (sz == 1) {
           if (tid < L) {                                      // one lane per path
-            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)order[tid] * n + sz);
+            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)lp[order[tid] * 16 + s] * n + sz);
             const float l = clampf(in[0], -kPolarLlrMax, kPolarLlrMax);
             blk[tid] = softplus(-l);
             blk[L + tid] = softplus(l);
           }
         } else {
           for (int pos = 0; pos < L; ++pos) {
-            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)order[pos] * n + sz);
+            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)lp[order[pos] * 16 + s] * n + sz);
             float m0 = 0.f, m1 = 0.f;
             for (int j = tid; j < sz; j += NT) {
               const float l = clampf(in[j], -kPolarLlrMax, kPolarLlrMax);
@@ -207,6 +219,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
             const int pos = w / sz, j = w - pos * sz;
             ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = 0;
           }
+          if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s] = (unsigned char)order[tid];
           __syncthreads();
           continue;
         }
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         if (p.sc_mode) {
           // PolarSCDecoder leaf: u = 0.5 (1 - sign(l)), exact zero -> 1 (decoding.py:208-212)
           if (tid == 0) {
-            const float l = ((s == p.m) ? llr_ch : (llr + (size_t)order[0] * n + sz))[0];
+            const float l = ((s == p.m) ? llr_ch : (llr + (size_t)lp[order[0] * 16 + s] * n + sz))[0];
             new_order[0] = order[0]; clone_src[0] = -1; new_bit[0] = (l <= 0.f) ? 1 : 0; new_pm[0] = 0.f;
           }
         } else {
@@ -256,15 +269,15 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           }
         }
         __syncthreads();
-        // clones: copy the parent's LLRs, partial sums and decided bits
+        // clones: inherit the parent's pointer tables and decided bits (lazy copy, see above)
         for (int r = 0; r < L; ++r) {
           const int src = clone_src[r];
           if (src < 0) continue;
           const int dst = new_order[r];
-          for (int i = tid; i < n; i += NT) {
-            llr[(size_t)dst * n + i] = llr[(size_t)src * n + i];
-            betaL[(size_t)dst * n + i] = betaL[(size_t)src * n + i];
-            betaR[(size_t)dst * n + i] = betaR[(size_t)src * n + i];
+          if (tid < 16) {
+            lp[dst * 16 + tid] = lp[src * 16 + tid];
+            bl[dst * 16 + tid] = bl[src * 16 + tid];
+            br[dst * 16 + tid] = br[src * 16 + tid];
           }
           for (int i = tid; i < words; i += NT) bits[(size_t)dst * words + i] = bits[(size_t)src * words + i];
         }
@@ -281,6 +294,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           const int pos = w / sz, j = w - pos * sz;
           ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = (unsigned char)new_bit[pos];   // all-u codeword
         }
+        if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s] = (unsigned char)order[tid];
         __syncthreads();
       }
     }
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
 static size_t scl_lds_bytes(int n, int L, int num_ops) {
   const size_t words = (n + 31) / 32;
   return (size_t)n * 4 + (size_t)L * n * 4 + 2 * (size_t)L * n + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
-         (size_t)L * 4 * 5 + 256 * 4 + (size_t)num_ops * 4 + 64;
+         (size_t)L * 4 * 5 + 256 * 4 + 3 * (size_t)L * 16 + (size_t)num_ops * 4 + 64;
 }
 
 }  // namespace samd
