@@ -154,10 +154,13 @@ class PolarSCLDecoder(_PolarListDecoderBase):
             raise TypeError("list_size must be integer.")
         if np.log2(list_size) != int(np.log2(list_size)):
             raise ValueError("list_size must be a power of 2.")
-        if use_hybrid_sc:
-            raise NotImplementedError("PolarSCLDecoder: the hybrid SC / NumPy-SCL mode is a CPU work-around of the "
-                                      "reference and has no place on the MI355X path - use plain SCL")
+        self._use_hybrid_sc = use_hybrid_sc
         self._setup(frozen_pos, n, list_size, 0, crc_degree, use_fast_scl, ind_iil_inv)
+        if use_hybrid_sc:
+            # SC first, SCL only for the words whose CRC fails after SC (decoding.py:474-480, 1292-1334)
+            if crc_degree is None:
+                raise ValueError("Hybrid SC requires outer CRC.")
+            self._decoder_sc = PolarSCDecoder(frozen_pos, n, precision=precision)
         if crc_degree is not None:
             self._crc_encoder = CRCEncoder(crc_degree, precision=precision)
             self._crc_decoder = CRCDecoder(self._crc_encoder, precision=precision)
@@ -180,7 +183,24 @@ class PolarSCLDecoder(_PolarListDecoderBase):
         llr = _ffi.to_device(llr_ch, torch.float32)
         if llr.shape[-1] != self._n:
             raise ValueError("Invalid input shape.")
-        u_hat, status = self._decode_2d(llr.reshape(-1, self._n), self._return_crc_status)
+        llr2d = llr.reshape(-1, self._n)
+        if self._use_hybrid_sc and llr2d.shape[0] > 0:
+            u_hat, _ = self._decoder_sc._decode_2d(llr2d)
+            _, valid = self._crc_decoder(u_hat)                       # as the reference: no de-interleaving here
+            valid = valid.reshape(-1)
+            redo = torch.nonzero(~valid).reshape(-1)                   # indices of the words that need the list decoder
+            status = None
+            if self._return_crc_status:
+                chk = u_hat if self._ind_iil_inv is None else \
+                    u_hat[:, _ffi.to_device(np.asarray(self._ind_iil_inv, np.int64), torch.int64)]
+                status = self._crc_decoder(chk.contiguous())[1].reshape(-1).to(torch.float32)
+            if redo.numel() > 0:
+                u_scl, st = self._decode_2d(llr2d.index_select(0, redo).contiguous(), self._return_crc_status)
+                u_hat.index_copy_(0, redo, u_scl)
+                if self._return_crc_status:
+                    status.index_copy_(0, redo, st)
+        else:
+            u_hat, status = self._decode_2d(llr2d, self._return_crc_status)
         u_hat = u_hat.reshape(tuple(llr.shape[:-1]) + (self._k,))
         if self._return_crc_status:
             return u_hat, (status > 0.5).reshape(tuple(llr.shape[:-1]))
@@ -217,8 +237,12 @@ class Polar5GDecoder(Block):
         elif dec_type == "SCL":
             self._polar_dec = PolarSCLDecoder(enc_polar.frozen_pos, self._n_polar, crc_degree=enc_polar.enc_crc.crc_degree,
                                               list_size=list_size, ind_iil_inv=self._ind_iil_inv, precision=precision)
-        elif dec_type in ("hybSCL", "BP"):
-            raise NotImplementedError(f"Polar5GDecoder: dec_type '{dec_type}' is outside the MI355X hot path (SC / SCL)")
+        elif dec_type == "hybSCL":
+            self._polar_dec = PolarSCLDecoder(enc_polar.frozen_pos, self._n_polar, crc_degree=enc_polar.enc_crc.crc_degree,
+                                              list_size=list_size, use_hybrid_sc=True, ind_iil_inv=self._ind_iil_inv,
+                                              precision=precision)
+        elif dec_type == "BP":
+            raise NotImplementedError("Polar5GDecoder: dec_type 'BP' is outside the MI355X hot path (SC / SCL / hybSCL)")
         else:
             raise ValueError("Unknown value for dec_type.")
         self._dec_crc = CRCDecoder(enc_polar.enc_crc, precision=precision) if return_crc_status else None

@@ -126,6 +126,39 @@ def test_polar5g_decoder_chain(phy, k, n, ch, dec_type):
     assert ok.mean() > 0.5
 
 
+@pytest.mark.parametrize("k,n,ch,sigma", [(64, 128, "uplink", 0.75), (300, 1088, "uplink", 1.15), (512, 1024, "uplink", 0.85),
+                                           (40, 200, "downlink", 1.0)])
+def test_hybrid_scl(phy, k, n, ch, sigma):
+    """dec_type="hybSCL" (decoding.py:1292-1334): words whose CRC holds after SC keep the SC result, the
+    others get exactly the SCL result."""
+    enc = phy.fec.polar.Polar5GEncoder(k, n, channel_type=ch)
+    mk = lambda t: phy.fec.polar.Polar5GDecoder(enc, dec_type=t, list_size=8, return_crc_status=True)
+    rng = np.random.default_rng(k)
+    B = 256
+    u = rng.integers(0, 2, (B, k)).astype(np.float32)
+    c = _np(enc(u))
+    logits = (2 * ((2 * c - 1) + sigma * rng.normal(size=c.shape)) / sigma ** 2).astype(np.float32)
+    u_h, st_h = mk("hybSCL")(logits)
+    u_l, st_l = mk("SCL")(logits)
+    u_s, st_s = mk("SC")(logits)
+    u_h, u_l, u_s, st_h, st_l, st_s = (_np(t) for t in (u_h, u_l, u_s, st_h, st_l, st_s))
+    if ch == "uplink":
+        keep = st_s                                   # SC CRC status == the hybrid's switch
+        assert 0 < keep.sum() < B, keep.sum()
+        assert np.array_equal(u_h[keep], u_s[keep]) and np.array_equal(u_h[~keep], u_l[~keep])
+        assert np.array_equal(st_h[keep], np.ones(keep.sum(), bool)) and np.array_equal(st_h[~keep], st_l[~keep])
+    else:
+        # downlink: the reference checks the SC CRC without undoing the input interleaver, so (almost)
+        # every word takes the list decoder
+        assert np.mean(np.all(u_h == u_l, axis=1)) > 0.99
+    bler = lambda x: np.mean(np.any(x != u, axis=1))
+    assert bler(u_l) <= bler(u_h) + 0.02 and bler(u_h) <= bler(u_s)
+    with pytest.raises(ValueError):
+        phy.fec.polar.PolarSCLDecoder(enc.frozen_pos, enc.n_polar, use_hybrid_sc=True)
+    with pytest.raises(NotImplementedError):
+        phy.fec.polar.Polar5GDecoder(enc, dec_type="BP")
+
+
 def test_c5_full_batch_properties(phy):
     """Config C5 (Polar5G uplink k=512 n=1024, SCL-8) on a large batch: noiseless round trip and
     monotone error rate."""
