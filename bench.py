@@ -205,10 +205,18 @@ def main():
             print(f"bench.py: --gpus {args.gpus} needs a torch.distributed.run launch", file=sys.stderr)
             sys.exit(2)
     import torch.distributed as dist
+    # SAMD_BENCH_BACKEND=gloo: code-path check of the N>1 logic on a box with fewer GPUs than ranks
+    # (ranks then share devices); the driver's runs use the default, RCCL.
+    backend = os.environ.get("SAMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import sionna_amd.phy as phy
     from sionna_amd import _ffi
