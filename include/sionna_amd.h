@@ -270,6 +270,17 @@ int samd_apply_time_channel_c64(const float* x, const float* h_time, int batch, 
 int samd_ls_gather_scale_c64(const float* y, const int32_t* src, const float* coef, int rows,
                              int num_streams, int n_out, int n_in, float* out, void* stream);
 
+/* LinearInterpolator.__call__  ofdm/channel_estimation.py:437-733: linear interpolation of the
+ * estimates at the pilots, first across subcarriers, then across OFDM symbols (time_avg: mean over
+ * the pilot-carrying symbols instead).  hp [rows, num_streams, num_pilots] complex64; DEVICE index
+ * tables built once per pilot pattern: fi0/fi1 int32 [S,T,F] = 1 + pilot number of the left/right
+ * support (0 = zero pad), fx0/fx1 float [S,T,F] their subcarrier positions, t0/t1 int32 [S,T] the
+ * supporting symbols, npil float [S] number of pilot-carrying symbols -> out [rows,S,T,F]. */
+int samd_lin_interp_c64(const float* hp, const int32_t* fi0, const int32_t* fi1, const float* fx0,
+                        const float* fx1, const int32_t* t0, const int32_t* t1, const float* npil,
+                        int rows, int num_streams, int num_pilots, int num_ofdm_symbols,
+                        int num_subcarriers, int time_avg, float* out, void* stream);
+
 /* lmmse_equalizer  mimo/equalization.py:101-233 on n independent problems:
  * y [n,m], h [n,m,k], s [n,m,m] complex64 -> x_hat [n,k] complex64, no_eff [n,k] float32.
  * Supported (m,k): (1,1) (2,1) (2,2) (4,1) (4,2) (4,4) (8,1) (8,2) (8,4); else UNSUPPORTED. */

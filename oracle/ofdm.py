@@ -414,3 +414,94 @@ def apply_time_channel(x, h_time):
         xs = np.where(valid, xp[..., np.clip(idx, 0, Tn - 1)], 0)      # [B,tx,ta,Tout]
         y += np.sum(h_time[..., l].astype(np.complex128) * xs[:, None, None], axis=(3, 4))
     return y.astype(np.complex64)
+
+
+# ------------------------------------------------------------------ linear interpolation of LS estimates
+class LinearInterpolator:
+    """ofdm/channel_estimation.py:437-733: index tables (:529-640) and the two 1-D interpolations
+    (:642-733).  pp: oracle PilotPattern (mask [tx, streams, T, F], pilots [tx, streams, P])."""
+
+    def __init__(self, pp, time_avg=False):
+        assert pp.num_pilot_symbols > 0, "The pilot pattern cannot be empty"
+        self.time_avg = time_avg
+        mask = np.asarray(pp.mask)
+        self.mask_shape = mask.shape
+        mask = mask.reshape((-1,) + mask.shape[-2:])
+        pilots = np.asarray(pp.pilots).reshape(-1, pp.pilots.shape[-1])
+        assert np.max(np.sum(np.abs(pilots) == 0, -1)) < pilots.shape[-1], \
+            "Each pilot sequence must have at least one nonzero entry"
+        S, T, F = mask.shape
+        z = np.zeros(mask.shape, pilots.dtype)
+        for a in range(S):
+            z[a][np.where(mask[a])] = pilots[a]
+        x0 = np.zeros(mask.shape, np.int32)
+        x1 = np.zeros(mask.shape, np.int32)
+        empty = np.sum(np.abs(z), axis=-1) == 0
+        x0[empty] = -1
+        x1[empty] = -1
+        y0, y1 = x0.copy(), x1.copy()
+        for a in range(S):
+            count = 0
+            pilot_ind = np.where(np.abs(pilots[a]))[0]
+            for i in range(T):
+                po = np.where(np.abs(z[a][i]))[0]
+                if len(po) == 1:
+                    x0[a, i] = x1[a, i] = po[0]
+                    y0[a, i] = y1[a, i] = pilot_ind[count]
+                elif len(po) >= 2:
+                    k0, k1 = 0, 1
+                    for j in range(F):
+                        x0[a, i, j], x1[a, i, j] = po[k0], po[k1]
+                        y0[a, i, j], y1[a, i, j] = pilot_ind[count + k0], pilot_ind[count + k1]
+                        if j == po[k1] and k1 < len(po) - 1:
+                            k0, k1 = k1, k1 + 1
+                count += len(po)
+        self.x0f, self.x1f, self.y0f, self.y1f = x0, x1, y0 + 1, y1 + 1       # +1: index 0 = zero pad
+        t0 = np.zeros((S, T), np.int32)
+        t1 = np.zeros((S, T), np.int32)
+        for a in range(S):
+            sym = np.where(np.sum(np.abs(z[a]), axis=-1))[0]
+            if len(sym) == 1:
+                t0[a] = t1[a] = sym[0]
+            elif len(sym) >= 2:
+                k0, k1 = 0, 1
+                for i in range(T):
+                    t0[a, i], t1[a, i] = sym[k0], sym[k1]
+                    if i == sym[k1] and k1 < len(sym) - 1:
+                        k0, k1 = k1, k1 + 1
+        self.t0, self.t1 = t0, t1
+        self.npil = np.sum(np.sum(np.abs(z), axis=-1) > 0, axis=-1)             # [S]
+
+    def _interp(self, x):
+        """x [..., tx, streams, P] -> [..., tx, streams, T, F] (complex128 arithmetic)."""
+        S, T, F = self.x0f.shape
+        lead = x.shape[:-3]
+        xp = np.concatenate([np.zeros(x.shape[:-1] + (1,), np.complex128), x.astype(np.complex128)], axis=-1)
+        xp = xp.reshape(lead + (S, -1))
+        sidx = np.arange(S)[:, None, None]
+        y0 = xp[..., sidx, self.y0f]
+        y1 = xp[..., sidx, self.y1f]
+        dx = (self.x1f - self.x0f).astype(np.float64)
+        slope = np.where(dx != 0, (y1 - y0) / np.where(dx != 0, dx, 1), 0)
+        hf = (np.arange(F) - self.x0f) * slope + y0                                # [..., S, T, F]
+        if self.time_avg:
+            hf = np.sum(hf, axis=-2, keepdims=True) / self.npil[:, None, None]
+            hf = np.repeat(hf, T, axis=-2)
+        a = hf[..., sidx[:, :, 0], self.t0, :]
+        b = hf[..., sidx[:, :, 0], self.t1, :]
+        dt = (self.t1 - self.t0).astype(np.float64)[..., None]
+        slope = np.where(dt != 0, (b - a) / np.where(dt != 0, dt, 1), 0)
+        out = (np.arange(T)[None, :, None] - self.t0[..., None]) * slope + a
+        return out.reshape(lead + self.mask_shape)
+
+    def __call__(self, h_hat, err_var):
+        h = self._interp(h_hat).astype(np.complex64)
+        ev = np.real(self._interp(np.asarray(err_var, np.float64).astype(np.complex128))).astype(np.float32)
+        return h, ev
+
+
+def ls_estimate_lin(rg, y, no, time_avg=False):
+    """LSChannelEstimator(interpolation_type="lin" / "lin_time_avg") (channel_estimation.py:138-173, 257-285)."""
+    h_p, ev_p = ls_estimate(rg, y, no, interpolation=None)
+    h, ev = LinearInterpolator(rg.pilot_pattern, time_avg)(h_p, np.broadcast_to(ev_p, h_p.shape))
+    return h, np.maximum(ev, 0)

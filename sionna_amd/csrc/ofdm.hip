@@ -277,6 +277,70 @@ extern "C" int samd_apply_ofdm_channel_c64(const float* x, const float* h_freq, 
   return launch_status();
 }
 
+// ---- LinearInterpolator (channel_estimation.py:437-733): frequency then time interpolation of the
+// estimates at the pilots.  hp [rows, S, P]; fi0/fi1 [S,T,F] = 1 + pilot number of the left/right
+// support (0: the zero pad of symbols without pilots), fx0/fx1 their subcarrier positions;
+// t0/t1 [S,T] the supporting OFDM symbols.  divide_no_nan: a zero span gives slope 0.
+__device__ __forceinline__ float2 lin_freq(const float2* __restrict__ hp_rs, const int32_t* __restrict__ fi0,
+                                           const int32_t* __restrict__ fi1, const float* __restrict__ fx0,
+                                           const float* __restrict__ fx1, int idx, int f) {
+  const int i0 = fi0[idx], i1 = fi1[idx];
+  const float2 y0 = i0 > 0 ? hp_rs[i0 - 1] : make_float2(0.f, 0.f);
+  const float2 y1 = i1 > 0 ? hp_rs[i1 - 1] : make_float2(0.f, 0.f);
+  const float x0 = fx0[idx], dx = fx1[idx] - x0;
+  float2 slope = make_float2(0.f, 0.f);
+  if (dx != 0.f) slope = make_float2((y1.x - y0.x) / dx, (y1.y - y0.y) / dx);
+  const float w = (float)f - x0;
+  return make_float2(w * slope.x + y0.x, w * slope.y + y0.y);
+}
+
+__global__ void lin_interp_kernel(const float2* __restrict__ hp, const int32_t* __restrict__ fi0,
+                                  const int32_t* __restrict__ fi1, const float* __restrict__ fx0,
+                                  const float* __restrict__ fx1, const int32_t* __restrict__ t0,
+                                  const int32_t* __restrict__ t1, const float* __restrict__ npil, long long total, int S,
+                                  int P, int T, int F, int time_avg, float2* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+  const int f = (int)(i % F);
+  const int t = (int)((i / F) % T);
+  const int s = (int)((i / ((long long)F * T)) % S);
+  const long long r = i / ((long long)F * T * S);
+  const float2* hp_rs = hp + (r * S + s) * P;
+  const int base = s * T * F;
+  float2 res;
+  if (time_avg) {
+    float2 acc = make_float2(0.f, 0.f);
+    for (int tt = 0; tt < T; ++tt) {
+      const float2 v = lin_freq(hp_rs, fi0, fi1, fx0, fx1, base + tt * F + f, f);
+      acc.x += v.x; acc.y += v.y;
+    }
+    res = make_float2(acc.x / npil[s], acc.y / npil[s]);
+  } else {
+    const int a = t0[s * T + t], b = t1[s * T + t];
+    const float2 y0 = lin_freq(hp_rs, fi0, fi1, fx0, fx1, base + a * F + f, f);
+    const float2 y1 = lin_freq(hp_rs, fi0, fi1, fx0, fx1, base + b * F + f, f);
+    const float dx = (float)(b - a);
+    float2 slope = make_float2(0.f, 0.f);
+    if (dx != 0.f) slope = make_float2((y1.x - y0.x) / dx, (y1.y - y0.y) / dx);
+    const float w = (float)(t - a);
+    res = make_float2(w * slope.x + y0.x, w * slope.y + y0.y);
+  }
+  out[i] = res;
+  }
+}
+
+extern "C" int samd_lin_interp_c64(const float* hp, const int32_t* fi0, const int32_t* fi1, const float* fx0,
+                                   const float* fx1, const int32_t* t0, const int32_t* t1, const float* npil, int rows,
+                                   int num_streams, int num_pilots, int num_ofdm_symbols, int num_subcarriers,
+                                   int time_avg, float* out, void* stream) {
+  SAMD_REQUIRE(hp && fi0 && fi1 && fx0 && fx1 && t0 && t1 && npil && out, "null argument");
+  const long long total = (long long)rows * num_streams * num_ofdm_symbols * num_subcarriers;
+  if (total == 0) return SAMD_OK;
+  hipLaunchKernelGGL(lin_interp_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)hp,
+                     fi0, fi1, fx0, fx1, t0, t1, npil, total, num_streams, num_pilots, num_ofdm_symbols, num_subcarriers,
+                     time_avg, (float2*)out);
+  return launch_status();
+}
+
 extern "C" int samd_ls_gather_scale_c64(const float* y, const int32_t* src, const float* coef, int rows, int num_streams,
                                         int n_out, int n_in, float* out, void* stream) {
   SAMD_REQUIRE(y && src && coef && out, "null argument");

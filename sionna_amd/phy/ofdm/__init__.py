@@ -2,7 +2,7 @@
 ``sionna.phy.ofdm`` for the hot path)."""
 from .pilot_pattern import PilotPattern, EmptyPilotPattern, KroneckerPilotPattern
 from .resource_grid import ResourceGrid, ResourceGridMapper, ResourceGridDemapper, RemoveNulledSubcarriers
-from .channel_estimation import LSChannelEstimator, NearestNeighborInterpolator
+from .channel_estimation import LSChannelEstimator, NearestNeighborInterpolator, LinearInterpolator
 from .equalization import OFDMEqualizer, LMMSEEqualizer
 from .detection import LinearDetector
 from .modulator import OFDMModulator, OFDMDemodulator

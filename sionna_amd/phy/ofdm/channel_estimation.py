@@ -1,11 +1,13 @@
-"""LS channel estimation with nearest-neighbour interpolation - mirror of reference
+"""LS channel estimation with nearest-neighbour or linear interpolation - mirror of reference
 src/sionna/phy/ofdm/channel_estimation.py (``BaseChannelEstimator.call`` :138-173,
-``LSChannelEstimator`` :175-285, ``NearestNeighborInterpolator`` :323-435).
+``LSChannelEstimator`` :175-285, ``NearestNeighborInterpolator`` :323-435, ``LinearInterpolator``
+:437-733).
 
 The reference gathers the pilot REs, divides by the pilots and then gathers again to spread
 the estimates over the grid (plus ~6 transposes).  Estimation and spreading commute with the
 per-pilot division, so ONE kernel does both: h_hat[.., t, f] = y[.., nearest pilot RE] * (1 /
-pilot).  Linear / LMMSE interpolators are outside the hot path."""
+pilot).  Linear interpolation gathers its two supports per axis through ``samd_lin_interp_c64``;
+the LMMSE interpolator is outside the hot path."""
 import numpy as np
 import torch
 
@@ -49,6 +51,83 @@ class NearestNeighborInterpolator(Object):
         return wrap(spread(h_hat)), wrap(spread(err_var))
 
 
+class LinearInterpolator(Object):
+    """``LinearInterpolator(pilot_pattern, time_avg=False)(h_hat, err_var)``: estimates at the pilots
+    [..., num_tx, num_streams, num_pilots] -> [..., num_tx, num_streams, num_ofdm_symbols,
+    num_effective_subcarriers], first across subcarriers then across OFDM symbols
+    (channel_estimation.py:437-733)."""
+
+    def __init__(self, pilot_pattern, time_avg=False):
+        super().__init__()
+        assert pilot_pattern.num_pilot_symbols > 0, "The pilot pattern cannot be empty"
+        self._time_avg = bool(time_avg)
+        mask = np.asarray(pilot_pattern.mask)
+        self._mask_shape = tuple(mask.shape)
+        s = mask.shape[0] * mask.shape[1]
+        t_, f_ = mask.shape[2:]
+        m = mask.reshape(s, t_, f_)
+        pil = np.asarray(pilot_pattern.pilots).reshape(s, -1)
+        assert np.max(np.sum(np.abs(pil) == 0, -1)) < pil.shape[-1], \
+            "Each pilot sequence must have at least one nonzero entry"
+        fi0 = np.zeros((s, t_, f_), np.int32); fi1 = np.zeros_like(fi0)        # 0 = zero pad
+        fx0 = np.full((s, t_, f_), -1, np.float32); fx1 = fx0.copy()
+        t0 = np.zeros((s, t_), np.int32); t1 = np.zeros_like(t0)
+        npil = np.ones(s, np.float32)
+        sub = np.arange(f_)
+        for a in range(s):
+            ti, fj = np.nonzero(m[a])                            # row-major = pilot order
+            nz = np.abs(pil[a]) > 0
+            syms = []
+            for t in range(t_):
+                sel = np.flatnonzero((ti == t) & nz)             # pilot numbers with energy in this symbol
+                if len(sel) == 0:
+                    continue
+                syms.append(t)
+                cols = fj[sel]
+                if len(sel) == 1:
+                    k0 = k1 = np.zeros(f_, np.int64)
+                else:                                            # right support: first pilot >= f, at least the 2nd
+                    k1 = np.clip(np.searchsorted(cols, sub, side="left"), 1, len(sel) - 1)
+                    k0 = k1 - 1
+                fi0[a, t], fi1[a, t] = sel[k0] + 1, sel[k1] + 1
+                fx0[a, t], fx1[a, t] = cols[k0], cols[k1]
+            syms = np.asarray(syms)
+            npil[a] = len(syms)
+            if len(syms) == 1:
+                t0[a] = t1[a] = syms[0]
+            elif len(syms) >= 2:
+                k1 = np.clip(np.searchsorted(syms, np.arange(t_), side="left"), 1, len(syms) - 1)
+                t0[a], t1[a] = syms[k1 - 1], syms[k1]
+        self._tables = (fi0, fi1, fx0, fx1, t0, t1, npil)
+        self._dev = None
+        self._num_pilots = pil.shape[-1]
+
+    def _interpolate(self, x):
+        x = _ffi.to_device(x, torch.complex64)
+        s, t_, f_ = self._tables[0].shape
+        assert x.shape[-1] == self._num_pilots and x.shape[-3] * x.shape[-2] == s, \
+            "inputs must have shape [..., num_tx, num_streams_per_tx, num_pilots]"
+        if self._dev is None:
+            fi0, fi1, fx0, fx1, t0, t1, npil = self._tables
+            self._dev = tuple(_ffi.to_device(a, torch.int32 if a.dtype == np.int32 else torch.float32)
+                              for a in (fi0, fi1, fx0, fx1, t0, t1, npil))
+        lead = tuple(x.shape[:-3])
+        rows = int(np.prod(lead)) if lead else 1
+        out = torch.empty(lead + self._mask_shape, dtype=torch.complex64, device=x.device)
+        d = self._dev
+        _ffi.check(_ffi.lib().samd_lin_interp_c64(_ffi.ptr(x), _ffi.ptr(d[0]), _ffi.ptr(d[1]), _ffi.ptr(d[2]), _ffi.ptr(d[3]),
+                                                  _ffi.ptr(d[4]), _ffi.ptr(d[5]), _ffi.ptr(d[6]), rows, s, self._num_pilots,
+                                                  t_, f_, int(self._time_avg), _ffi.ptr(out), _ffi.stream()),
+                   "LinearInterpolator")
+        return out
+
+    def __call__(self, h_hat, err_var):
+        h = self._interpolate(h_hat)
+        ev = _ffi.to_device(err_var, torch.float32)
+        ev = self._interpolate(torch.complex(ev, torch.zeros_like(ev))).real      # :726-730
+        return wrap(h), wrap(ev.contiguous())
+
+
 class LSChannelEstimator(Block):
     """``LSChannelEstimator(resource_grid, interpolation_type="nn")(y, no) -> (h_hat, err_var)``;
     y [batch, num_rx, num_rx_ant, num_ofdm_symbols, fft_size]; h_hat [batch, num_rx, num_rx_ant, num_tx,
@@ -57,9 +136,17 @@ class LSChannelEstimator(Block):
     def __init__(self, resource_grid, interpolation_type="nn", interpolator=None, precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
         assert interpolation_type in ["nn", "lin", "lin_time_avg", None], "Unsupported `interpolation_type`"
-        if interpolator is not None or interpolation_type in ("lin", "lin_time_avg"):
-            raise NotImplementedError("LSChannelEstimator: only nearest-neighbour interpolation (or none) is on the hot path")
+        if interpolator is not None and not isinstance(interpolator, (NearestNeighborInterpolator, LinearInterpolator)):
+            raise NotImplementedError("LSChannelEstimator: custom interpolators have no HIP path")
         self._rg = resource_grid
+        self._lin = None
+        if isinstance(interpolator, LinearInterpolator):
+            self._lin, interpolation_type = interpolator, None
+        elif isinstance(interpolator, NearestNeighborInterpolator):
+            interpolation_type = "nn"
+        elif interpolation_type in ("lin", "lin_time_avg"):
+            self._lin = LinearInterpolator(resource_grid.pilot_pattern, time_avg=interpolation_type == "lin_time_avg")
+            interpolation_type = None
         self._interpolation_type = interpolation_type
         pp = resource_grid.pilot_pattern
         s = pp.mask.shape[0] * pp.mask.shape[1]
@@ -104,5 +191,8 @@ class LSChannelEstimator(Block):
         # first n <= 3 dims of [batch, num_rx, num_rx_ant] - a handful of elements, plain broadcasting
         no = _ffi.to_device(no, torch.float32)
         no = no.reshape(tuple(no.shape) + (1,) * (3 - no.dim()) + (1,) * len(self._out_shape))
-        err_var = torch.clamp_min(no * ev.reshape(self._out_shape), 0.)
-        return h_hat, err_var
+        err_var = no * ev.reshape(self._out_shape)
+        if self._lin is not None:
+            err_var = torch.broadcast_to(err_var, tuple(err_var.shape[:3]) + self._out_shape)
+            h_hat, err_var = self._lin(h_hat, err_var.contiguous())
+        return h_hat, torch.clamp_min(err_var, 0.)

@@ -327,3 +327,59 @@ def test_time_domain_chain_matches_frequency_response(phy):
     # and the whole chain against the oracle on the same taps
     ref = o.ofdm_demodulate(o.apply_time_channel(o.ofdm_modulate(x, cp), _np(h_time)), n, l_min, cp)
     assert np.allclose(yf, ref, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ linear interpolation ("lin", "lin_time_avg")
+from test_oracle_ofdm_time import LIN_PATTERNS
+
+
+@pytest.mark.parametrize("name", sorted(LIN_PATTERNS))
+@pytest.mark.parametrize("time_avg", [False, True])
+def test_linear_interpolator_vs_oracle(phy, name, time_avg):
+    opp = LIN_PATTERNS[name]()
+    pp = phy.ofdm.PilotPattern(opp.mask, opp.pilots)
+    rng = np.random.default_rng(len(name))
+    ntx, ns, T, F = opp.mask.shape
+    h_p = _cplx(rng, (3, 2, ntx, ns, opp.pilots.shape[-1])) * (np.abs(opp.pilots) > 0)
+    ev_p = rng.uniform(0.1, 1.0, h_p.shape).astype(np.float32) * (np.abs(opp.pilots) > 0)
+    h, ev = phy.ofdm.LinearInterpolator(pp, time_avg)(h_p, ev_p)
+    h_ref, ev_ref = o.LinearInterpolator(opp, time_avg)(h_p, ev_p)
+    assert tuple(h.shape) == h_ref.shape == (3, 2, ntx, ns, T, F)
+    assert np.allclose(_np(h), h_ref, rtol=1e-4, atol=1e-5) and np.allclose(_np(ev), ev_ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("itype", ["lin", "lin_time_avg"])
+def test_ls_estimator_linear_vs_oracle(phy, itype):
+    rg, org = _grids(phy, num_tx=2, ns=2, fft=72, guards=(3, 4))
+    rng = np.random.default_rng(7)
+    y = _cplx(rng, (6, 1, 4, 14, 72))
+    h, ev = phy.ofdm.LSChannelEstimator(rg, interpolation_type=itype)(y, 0.05)
+    h_ref, ev_ref = o.ls_estimate_lin(org, y, 0.05, time_avg=itype == "lin_time_avg")
+    assert np.allclose(_np(h), h_ref, rtol=1e-4, atol=1e-5)
+    assert np.allclose(np.broadcast_to(_np(ev), h_ref.shape), np.broadcast_to(ev_ref, h_ref.shape), rtol=1e-4, atol=1e-6)
+    # an explicit interpolator object is accepted like in the reference
+    h2, _ = phy.ofdm.LSChannelEstimator(rg, interpolator=phy.ofdm.LinearInterpolator(rg.pilot_pattern, itype == "lin_time_avg"))(y, 0.05)
+    assert np.array_equal(_np(h2), _np(h))
+
+
+def test_time_domain_chain_ls_lin_recovers_frequency_response(phy):
+    """Reference test_channel_utils.py:83-135: static TDL channel through modulator -> ApplyTimeChannel ->
+    demodulator; the noise-free LS estimate with linear interpolation equals the DFT of the taps."""
+    cp, n, nsym, B = 10, 128, 5, 8
+    l_min, l_max = -3, 5
+    rg = phy.ofdm.ResourceGrid(nsym, n, 15e3, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[0, 2, 4],
+                               cyclic_prefix_length=cp)
+    l_tot = l_max - l_min + 1
+    tdl = phy.channel.tr38901.TDL("A", 100e-9, 3.5e9, min_speed=0., max_speed=0.)
+    a, tau = tdl(B, rg.num_time_samples + l_tot - 1, rg.bandwidth)
+    h_time = phy.channel.cir_to_time_channel(rg.bandwidth, a, tau, l_min, l_max, normalize=True)
+    rng = np.random.default_rng(4)
+    x = (np.sign(rng.normal(size=(B, 1, 1, rg.num_data_symbols))) + 1j * np.sign(rng.normal(size=(B, 1, 1, rg.num_data_symbols)))).astype(np.complex64) / np.sqrt(2)
+    x_time = phy.ofdm.OFDMModulator(cp)(phy.ofdm.ResourceGridMapper(rg)(x))
+    y_time = phy.channel.ApplyTimeChannel(rg.num_time_samples, l_tot)(x_time, h_time)
+    y_freq = phy.ofdm.OFDMDemodulator(n, l_min, cp)(y_time)
+    h_hat, _ = phy.ofdm.LSChannelEstimator(rg, interpolation_type="lin")(y_freq, 1e-4)
+    taps = _np(h_time)[:, 0, 0, 0, 0, 0, :].astype(np.complex128)
+    k = np.arange(n) - n // 2
+    H = (taps[:, None, :] * np.exp(-2j * np.pi * k[None, :, None] * np.arange(l_min, l_max + 1)[None, None, :] / n)).sum(-1)
+    assert np.allclose(_np(h_hat)[:, 0, 0, 0, 0], np.broadcast_to(H[:, None, :], (B, nsym, n)), atol=1e-4)

@@ -86,3 +86,78 @@ def test_time_domain_chain_reproduces_frequency_response(l_min, l_max):
     k = np.arange(n) - n // 2
     H = (taps[:, None, :] * np.exp(-2j * np.pi * k[None, :, None] * np.arange(l_min, l_max + 1)[None, None, :] / n)).sum(-1)
     assert np.allclose(yf[:, 0, 0], H[:, None, :] * x[:, 0, 0], atol=2e-5)
+
+
+# ------------------------------------------------------------------ linear interpolation (LS, "lin")
+def _ref_linear_int(h, i, j, time_avg=False):
+    """Independent restatement of the reference test's NumPy model (test_ofdm_channel_estimation.py:17-88):
+    per OFDM symbol piecewise-linear through its pilots (extrapolating with the outer segments), then the
+    same across the pilot-carrying symbols."""
+    T, F = h.shape
+    hf = np.zeros_like(h)
+    for t in range(T):
+        cols = np.sort(j[i == t])
+        if len(cols) == 1:
+            hf[t] = h[t, cols[0]]
+        elif len(cols) > 1:
+            for f in range(F):
+                k = np.searchsorted(cols, f, side="left")          # first pilot >= f
+                k1 = min(max(k, 1), len(cols) - 1)
+                a, b = cols[k1 - 1], cols[k1]
+                hf[t, f] = (f - a) * (h[t, b] - h[t, a]) / (b - a) + h[t, a]
+    syms = np.where(np.sum(np.abs(hf), axis=-1))[0]
+    if time_avg:
+        hf[syms] = np.sum(hf, axis=0) / len(syms)
+    if len(syms) == 1:
+        return np.repeat(hf[syms], T, axis=0)
+    out = np.zeros_like(h)
+    for t in range(T):
+        k = np.searchsorted(syms, t, side="left")
+        k1 = min(max(k, 1), len(syms) - 1)
+        a, b = syms[k1 - 1], syms[k1]
+        out[t] = (t - a) * (hf[b] - hf[a]) / (b - a) + hf[a]
+    return out
+
+
+def _sparse_pattern():
+    mask = np.zeros([4, 1, 14, 64], bool)
+    mask[..., [2, 3, 10, 11], :] = True
+    pilots = np.zeros([4, 1, int(mask[0, 0].sum())], np.complex64)
+    pilots[0, 0, 10] = 1; pilots[0, 0, 234] = 1; pilots[1, 0, 20] = 1; pilots[2, 0, 70] = 1; pilots[3, 0, 120] = 1
+    return o.PilotPattern(mask, pilots)
+
+
+def _kron(num_tx, ns, T, F, idx):
+    return o.ResourceGrid(T, F, 30e3, num_tx=num_tx, num_streams_per_tx=ns, pilot_pattern="kronecker",
+                          pilot_ofdm_symbol_indices=list(idx)).pilot_pattern
+
+
+LIN_PATTERNS = {"sparse": _sparse_pattern, "k01": lambda: _kron(4, 1, 14, 64, [2, 11]), "k02": lambda: _kron(4, 1, 14, 64, [2]),
+                "k03": lambda: _kron(16, 1, 14, 16, [2]), "k04": lambda: _kron(4, 2, 14, 64, [2, 5, 8]),
+                "k05": lambda: _kron(1, 1, 5, 64, range(5)), "k06": lambda: _kron(4, 1, 14, 64, [2, 3, 8, 11])}
+
+
+@pytest.mark.parametrize("name", sorted(LIN_PATTERNS))
+@pytest.mark.parametrize("time_avg", [False, True])
+def test_linear_interpolator_matches_reference_model(name, time_avg):
+    """Reference test_ofdm_channel_estimation.py:91-330: noise-free LS estimates interpolated linearly equal
+    the NumPy model applied to the true channel, for the reference's own pilot patterns."""
+    pp = LIN_PATTERNS[name]()
+    rng = np.random.default_rng(len(name))
+    ntx, ns, T, F = pp.mask.shape
+    h_true = (rng.normal(size=(2, ntx, ns, T, F)) + 1j * rng.normal(size=(2, ntx, ns, T, F))).astype(np.complex64)
+    # perfect estimates at the pilot positions, zeros where the pilot is zero
+    h_p = np.zeros((2, ntx, ns, pp.pilots.shape[-1]), np.complex64)
+    for a in range(ntx):
+        for b in range(ns):
+            ii, jj = np.where(pp.mask[a, b])
+            h_p[:, a, b] = h_true[:, a, b, ii, jj] * (np.abs(pp.pilots[a, b]) > 0)
+    h_hat, ev = o.LinearInterpolator(pp, time_avg)(h_p, np.ones(h_p.shape, np.float32))
+    for a in range(ntx):
+        for b in range(ns):
+            ii, jj = np.where(pp.mask[a, b])
+            nz = np.abs(pp.pilots[a, b]) > 0
+            for r in range(2):
+                ref = _ref_linear_int(h_true[r, a, b].astype(np.complex128), ii[nz], jj[nz], time_avg)
+                assert np.allclose(h_hat[r, a, b], ref, atol=1e-5)
+    assert np.allclose(ev[0, 0, 0][np.abs(ev[0, 0, 0]) > 0], 1.0, atol=1e-5) or name == "sparse"
