@@ -217,6 +217,27 @@ int samd_cir_to_ofdm_c64(const float* a, const float* tau, const float* frequenc
 int samd_apply_ofdm_channel_c64(const float* x, const float* h_freq, int batch, int num_rx_x_ant,
                                 int num_tx_x_ant, int num_re, float* y, void* stream);
 
+/* MMSEPICDetector.call  mimo/detection.py:1496-1643, output="bit" ([CST2011] MMSE with parallel
+ * interference cancellation and num_iter self-iterations) on n independent problems:
+ * y [n,m], h [n,m,k], s [n,m,m] complex64, prior [n,k,num_bits_per_symbol] a-priori LLRs, points
+ * DEVICE complex64[2^num_bits_per_symbol] -> out [n,k,num_bits_per_symbol] extrinsic LLRs (hard_out:
+ * their hard decisions).  maxlog 0 = "app".  Same (m,k) support as samd_lmmse_equalizer_c64. */
+int samd_mmse_pic_f32(const float* y, const float* h, const float* s, const float* prior,
+                      const float* points, int64_t n, int m, int k, int num_bits_per_symbol,
+                      int maxlog, int num_iter, int hard_out, float* out, void* stream);
+
+/* ofdm.MMSEPICDetector.call  ofdm/detection.py:1062-1230 (OFDMDetectorWithPrior :320-560): the
+ * pre-processing of samd_ofdm_lmmse_c64 + the detector above in one launch.  prior / out
+ * [batch, num_streams_total, num_data * num_bits_per_symbol]. */
+int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode,
+                           const float* no, const float* prior, const float* points,
+                           const int32_t* sc_ind, const int32_t* desired, const int32_t* undesired,
+                           const int32_t* data_pos, int batch, int num_rx, int num_rx_ant,
+                           int num_streams_total, int streams_per_rx, int num_undesired,
+                           int num_ofdm_symbols, int num_eff_subcarriers, int fft_size, int num_data,
+                           int num_bits_per_symbol, int maxlog, int num_iter, int hard_out, float* out,
+                           void* stream);
+
 /* ---- scrambling --------------------------------------------------- */
 
 /* Scrambler.call fec/scrambling.py:186-261 / TB5GScrambler.call :442-468:

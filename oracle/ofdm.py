@@ -313,12 +313,11 @@ def lmmse_equalizer(y, h, s, whiten_interference=True):
     return gy / d, np.real(1 / d - 1)
 
 
-def ofdm_lmmse_equalize(rg, sm, y, h_hat, err_var, no, whiten_interference=True):
-    """OFDMEqualizer.call with the LMMSE equaliser (ofdm/equalization.py:109-275).
-    y [B,rx,ra,T,fft], h_hat [B,rx,ra,tx,s,T,Feff], err_var broadcastable, no scalar/[B]/[B,rx]/[B,rx,ra].
-    Returns x_hat, no_eff [B,tx,s,num_data]."""
+def _ofdm_preprocess(rg, sm, y, h_hat, err_var, no):
+    """OFDMEqualizer.call / OFDMDetector._preprocess_inputs (ofdm/equalization.py:109-230,
+    ofdm/detection.py:229-287): per-RE y [B,rx,T,F,M], desired channels [B,rx,T,F,M,K] and the
+    covariance of noise + estimation error + undesired streams [B,rx,T,F,M,M]."""
     y_eff = remove_nulled(rg, y)
-    B = y.shape[0]
     y_dt = np.transpose(y_eff, [0, 1, 3, 4, 2])
     ev = np.broadcast_to(err_var, h_hat.shape)
     ev = np.transpose(ev, [0, 1, 5, 6, 2, 3, 4])
@@ -338,17 +337,112 @@ def ofdm_lmmse_equalize(rg, sm, y, h_hat, err_var, no, whiten_interference=True)
     s = hu.astype(np.complex128) @ np.conj(np.swapaxes(hu, -1, -2)).astype(np.complex128)
     eye = np.eye(M)
     s = s + no_dt[..., None] * eye + np.sum(ev, -1)[..., None] * eye
+    return y_dt, hd, s
+
+
+def _extract_data(rg, sm, z, B):
+    """[B,rx,T,F,K,...] -> [B,tx,streams,num_data,...] (equalization.py:233-273)."""
+    extra = z.shape[5:]
+    z = z.reshape(z.shape[:5] + (-1,))
+    z = np.transpose(z, [1, 4, 2, 3, 5, 0])                      # [rx,K,T,F,X,B]
+    z = z.reshape((-1,) + z.shape[2:])[sm.stream_ind]
+    z = z.reshape((sm.num_tx, sm.num_streams_per_tx, -1) + z.shape[3:])     # [tx,s,T*F,X,B]
+    di = data_ind(rg.pilot_pattern)
+    tx, st = np.indices(di.shape)[:2]
+    z = z[tx, st, di]                                             # [tx,s,ND,X,B]
+    z = np.transpose(z, [4, 0, 1, 2, 3])
+    return z.reshape(z.shape[:4] + extra)
+
+
+def ofdm_lmmse_equalize(rg, sm, y, h_hat, err_var, no, whiten_interference=True):
+    """OFDMEqualizer.call with the LMMSE equaliser (ofdm/equalization.py:109-275).
+    y [B,rx,ra,T,fft], h_hat [B,rx,ra,tx,s,T,Feff], err_var broadcastable, no scalar/[B]/[B,rx]/[B,rx,ra].
+    Returns x_hat, no_eff [B,tx,s,num_data]."""
+    y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
     x_hat, no_eff = lmmse_equalizer(y_dt, hd, s, whiten_interference)
-    # extract data symbols of all detected TX (equalization.py:233-273)
-    def extract(z):
-        z = np.transpose(z, [1, 4, 2, 3, 0])
-        z = z.reshape((-1,) + z.shape[2:])[sm.stream_ind]
-        z = z.reshape((sm.num_tx, sm.num_streams_per_tx) + z.shape[1:])
-        z = z.reshape(z.shape[:2] + (-1, B))
-        di = data_ind(rg.pilot_pattern)
-        tx, st = np.indices(di.shape)[:2]
-        return np.transpose(z[tx, st, di], [3, 0, 1, 2])
-    return extract(x_hat).astype(np.complex64), extract(no_eff).astype(np.float32)
+    B = y.shape[0]
+    return _extract_data(rg, sm, x_hat, B).astype(np.complex64), _extract_data(rg, sm, no_eff, B).astype(np.float32)
+
+
+# ------------------------------------------------------------------ MMSE-PIC detector
+def _log_sigmoid(x):
+    return -np.logaddexp(0.0, -x)
+
+
+def _bit_labels(nb):
+    p = np.arange(2 ** nb)
+    return ((p[:, None] >> (nb - 1 - np.arange(nb))[None, :]) & 1).astype(np.float64)       # [P, nb], MSB first
+
+
+def mmse_pic(y, h, s, prior, points, method="maxlog", num_iter=1, hard_out=False):
+    """MMSEPICDetector.call, output="bit" (mimo/detection.py:1496-1643) in float64.
+    y [...,M], h [...,M,K], s [...,M,M], prior [...,K,nb] -> extrinsic LLRs [...,K,nb]."""
+    y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
+    points = np.asarray(points, np.complex128)
+    nb = prior.shape[-1]
+    K = h.shape[-1]
+    lab = _bit_labels(nb)
+    a = 2 * lab - 1
+    l_inv = np.linalg.inv(np.linalg.cholesky(s))
+    y = (l_inv @ y[..., None])[..., 0]
+    h = l_inv @ h
+    hh = np.conj(np.swapaxes(h, -1, -2))
+    y_mf = (hh @ y[..., None])                                   # [...,K,1]
+    g = hh @ h
+    gr = np.concatenate([np.concatenate([g.real, -g.imag], -1), np.concatenate([g.imag, g.real], -1)], -2)
+    red = (lambda v, axis: np.log(np.sum(np.exp(v - v.max(axis=axis, keepdims=True)), axis=axis)) + v.max(axis=axis)) \
+        if method == "app" else (lambda v, axis: v.max(axis=axis))
+    llr_d = prior.astype(np.float64)
+    llr_a = np.zeros_like(llr_d)
+    for _ in range(num_iter):
+        llr_a = llr_d
+        x_logits = np.sum(_log_sigmoid(a * llr_a[..., None, :]), axis=-1)              # [...,K,P]
+        pr = np.exp(x_logits - x_logits.max(-1, keepdims=True))
+        pr /= pr.sum(-1, keepdims=True)
+        x_hat = np.sum(pr * points, -1)
+        var_x = np.sum(pr * np.abs(points - x_hat[..., None]) ** 2, -1)                # [...,K]
+        y_mf_pic = y_mf + g * x_hat[..., None, :] - g @ x_hat[..., None]
+        var2 = np.concatenate([var_x, var_x], -1)
+        am = gr * var2[..., None, :] + np.eye(2 * K)
+        a_inv = np.linalg.inv(am)
+        mu = np.sum(a_inv * np.swapaxes(gr, -1, -2), -1)
+        ypt = np.swapaxes(y_mf_pic, -1, -2)
+        ypt = np.concatenate([ypt.real, ypt.imag], -1)
+        ypt = np.concatenate([ypt, ypt], -2)
+        xr = np.sum(a_inv * ypt, -1) / mu
+        x_hat = xr[..., :K] + 1j * xr[..., K:]
+        vx = (mu / np.maximum(1 - var2 * mu, 1e-4))[..., :K]
+        no_eff = np.maximum(1.0 / vx, np.finfo(np.float32).tiny)
+        expo = -np.abs(x_hat[..., None] - points) ** 2 / no_eff[..., None]             # [...,K,P]
+        t = expo + x_logits
+        one = lab.T.astype(bool)                                                       # [nb,P]
+        t1 = np.stack([red(t[..., one[b]], -1) for b in range(nb)], -1)
+        t0 = np.stack([red(t[..., ~one[b]], -1) for b in range(nb)], -1)
+        llr_d = t1 - t0
+    llr_e = llr_d - llr_a
+    return (llr_e > 0).astype(np.float32) if hard_out else llr_e.astype(np.float32)
+
+
+def ofdm_mmse_pic(rg, sm, y, h_hat, prior, err_var, no, points, method="maxlog", num_iter=1, hard_out=False):
+    """ofdm.MMSEPICDetector.call, output="bit" (ofdm/detection.py:448-560, 1062-1230).
+    prior [B,tx,streams,num_data*nb] -> LLRs of the same shape."""
+    nb = int(np.log2(len(points)))
+    B = y.shape[0]
+    y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
+    T, F = rg.num_ofdm_symbols, rg.num_effective_subcarriers
+    pr = prior.reshape(B, sm.num_tx, rg.num_streams_per_tx, -1, nb)
+    grid = np.zeros((B, sm.num_tx, rg.num_streams_per_tx, T * F, nb), np.float32)         # zero prior off the data REs
+    di = data_ind(rg.pilot_pattern)
+    tx, st = np.indices(di.shape)[:2]
+    grid[:, tx, st, di] = pr
+    grid = grid.reshape(B, -1, T, F, nb)                                                  # [B,S,T,F,nb]
+    # detection_desired_ind indexes the [rx, tx*streams] flattening of h; the stream id is its remainder
+    desired = np.asarray(sm.detection_desired_ind).reshape(sm.num_rx, sm.num_streams_per_rx) % grid.shape[1]
+    pri = np.stack([grid[:, desired[r]] for r in range(sm.num_rx)], axis=1)               # [B,rx,K,T,F,nb]
+    pri = np.transpose(pri, [0, 1, 3, 4, 2, 5])
+    llr = mmse_pic(y_dt, hd, s, pri, points, method, num_iter, hard_out)                  # [B,rx,T,F,K,nb]
+    out = _extract_data(rg, sm, llr, B)                                                   # [B,tx,s,ND,nb]
+    return out.reshape(out.shape[:3] + (-1,))
 
 
 # ------------------------------------------------------------------ time-domain variant

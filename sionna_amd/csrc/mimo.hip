@@ -192,24 +192,22 @@ struct OfdmEqArgs {
   int B, RX, S, T, F, FFT, U, ND, ev_mode, whiten;
 };
 
+// Loads one resource element of receiver rx: y, the desired columns of h_hat and the covariance
+// S = diag(no + sum err_var) + H_u H_u^H of noise, estimation error and undesired streams
+// (ofdm/equalization.py:204-230, ofdm/detection.py:229-287).  Returns false for pilot-only REs.
 template <int M, int K>
-__global__ __launch_bounds__(128) void ofdm_lmmse_kernel(OfdmEqArgs p) {
-  const int64_t total = (int64_t)p.B * p.RX * p.T * p.F;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
+__device__ __forceinline__ bool load_re(const OfdmEqArgs& p, int64_t i, c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M],
+                                        int (&dpos)[K], int64_t& b, int& rx) {
   const int TF = p.T * p.F;
   const int re = (int)(i % TF);
   const int f = re % p.F, t = re / p.F;
-  const int rx = (int)((i / TF) % p.RX);
-  const int64_t b = i / ((int64_t)TF * p.RX);
-  int dpos[K];
+  rx = (int)((i / TF) % p.RX);
+  b = i / ((int64_t)TF * p.RX);
   bool any = false;
 #pragma unroll
   for (int k = 0; k < K; ++k) { dpos[k] = p.data_pos[(int64_t)p.desired[rx * K + k] * TF + re]; any |= dpos[k] >= 0; }
-  if (!any) return;                                           // pilot-only resource element
+  if (!any) return false;                                     // pilot-only resource element
   const int64_t brx = b * p.RX + rx;
-  c32 y[M], h[M][K], s[M][M], xh[K];
-  float ne[K];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const float2 v = p.y[((brx * M + m) * p.T + t) * p.FFT + p.sc_ind[f]];
@@ -237,6 +235,19 @@ __global__ __launch_bounds__(128) void ofdm_lmmse_kernel(OfdmEqArgs p) {
 #pragma unroll
       for (int c = 0; c <= a; ++c) s[a][c] = s[a][c] + mulc(hu[a], hu[c]);
   }
+  return true;
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(128) void ofdm_lmmse_kernel(OfdmEqArgs p) {
+  const int64_t total = (int64_t)p.B * p.RX * p.T * p.F;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int dpos[K], rx;
+  int64_t b;
+  c32 y[M], h[M][K], s[M][M], xh[K];
+  float ne[K];
+  if (!load_re<M, K>(p, i, y, h, s, dpos, b, rx)) return;
   lmmse_solve<M, K>(y, h, s, p.whiten != 0, xh, ne);
 #pragma unroll
   for (int k = 0; k < K; ++k)
@@ -244,6 +255,234 @@ __global__ __launch_bounds__(128) void ofdm_lmmse_kernel(OfdmEqArgs p) {
       const int64_t o = (b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k];
       p.x_hat[o] = make_float2(xh[k].re, xh[k].im);
       p.no_eff[o] = ne[k];
+    }
+}
+
+// ------------------------------------------------------------------ MMSE-PIC detector
+// MMSEPICDetector.call  mimo/detection.py:1496-1643 ([CST2011] with self-iterations), output="bit":
+// whitening, matched filter y_mf = H^H y and Gramian G, then per self-iteration: soft symbols and
+// variances from the a-priori LLRs (LLRs2SymbolLogits :1045-1059, SymbolLogits2Moments :1129-1139),
+// parallel interference cancellation, A = G_r diag(v) + I inverted once for all streams (real 2K x
+// 2K), bias mu, post-filter variance, and demapping with priors (Demapper.call :664-691 +
+// SymbolLogits2LLRs.call :927-967).  Returns the extrinsic LLRs llr_d - llr_a.
+constexpr int kMaxBits = 8;
+
+__device__ __forceinline__ float log_sigmoid(float x) {
+  return x < 0.f ? x - log1pf(expf(x)) : -log1pf(expf(-x));
+}
+
+struct PicParams {
+  const float2* points;   // [2^nb]
+  int nb, maxlog, num_iter, hard_out;
+};
+
+template <int M, int K>
+__device__ void mmse_pic_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&llr)[K][kMaxBits],
+                               const PicParams& q) {
+  constexpr int N2 = 2 * K;
+  const int nb = q.nb, P = 1 << nb;
+  // whiten_channel(y, h, s, return_s=False): L = chol(S), y <- L^-1 y, H <- L^-1 H
+  cholesky<M>(s);
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    c32 v = y[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v = v - s[i][k] * y[k];
+    y[i] = scale(v, 1.f / s[i][i].re);
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      c32 w = h[i][c];
+#pragma unroll
+      for (int k = 0; k < i; ++k) w = w - s[i][k] * h[k][c];
+      h[i][c] = scale(w, 1.f / s[i][i].re);
+    }
+  }
+  c32 ymf[K], g[K][K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    c32 v = C(0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) v = v + mulc(y[m], h[m][k]);            // conj(h[m][k]) * y[m]
+    ymf[k] = v;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      c32 w = C(0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < M; ++m) w = w + mulc(h[m][j], h[m][k]);       // conj(h[m][k]) * h[m][j]
+      g[k][j] = w;
+    }
+  }
+  float gr[N2][N2];                                                     // real form of G (complex2real_matrix)
+#pragma unroll
+  for (int r = 0; r < K; ++r)
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      gr[r][c] = g[r][c].re; gr[r][K + c] = -g[r][c].im;
+      gr[K + r][c] = g[r][c].im; gr[K + r][K + c] = g[r][c].re;
+    }
+  float llr_a[K][kMaxBits];
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < kMaxBits; ++b) llr_a[k][b] = 0.f;
+
+  for (int it = 0; it < q.num_iter; ++it) {
+    for (int k = 0; k < K; ++k)
+      for (int b = 0; b < nb; ++b) llr_a[k][b] = llr[k][b];
+    // soft symbols and their variances from the a-priori LLRs
+    c32 xh[K];
+    float var[K];
+    for (int k = 0; k < K; ++k) {
+      float ls0[kMaxBits], ls1[kMaxBits];
+      for (int b = 0; b < nb; ++b) { ls1[b] = log_sigmoid(llr_a[k][b]); ls0[b] = log_sigmoid(-llr_a[k][b]); }
+      float mx = -INFINITY;
+      for (int pt = 0; pt < P; ++pt) {
+        float lg = 0.f;
+        for (int b = 0; b < nb; ++b) lg += ((pt >> (nb - 1 - b)) & 1) ? ls1[b] : ls0[b];
+        mx = fmaxf(mx, lg);
+      }
+      float den = 0.f, mr = 0.f, mi = 0.f;
+      for (int pt = 0; pt < P; ++pt) {
+        float lg = 0.f;
+        for (int b = 0; b < nb; ++b) lg += ((pt >> (nb - 1 - b)) & 1) ? ls1[b] : ls0[b];
+        const float e = expf(lg - mx);
+        den += e; mr += e * q.points[pt].x; mi += e * q.points[pt].y;
+      }
+      mr /= den; mi /= den;
+      float vv = 0.f;
+      for (int pt = 0; pt < P; ++pt) {
+        float lg = 0.f;
+        for (int b = 0; b < nb; ++b) lg += ((pt >> (nb - 1 - b)) & 1) ? ls1[b] : ls0[b];
+        const float dr = q.points[pt].x - mr, di = q.points[pt].y - mi;
+        vv += (expf(lg - mx) / den) * (dr * dr + di * di);
+      }
+      xh[k] = C(mr, mi);
+      var[k] = vv;
+    }
+    // parallel interference cancellation: ypic[k][j] = y_mf[k] + g[k][j] xh[j] - sum_i g[k][i] xh[i]
+    c32 ypic[K][K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      c32 gx = C(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < K; ++i) gx = gx + g[k][i] * xh[i];
+#pragma unroll
+      for (int j = 0; j < K; ++j) ypic[k][j] = ymf[k] + g[k][j] * xh[j] - gx;
+    }
+    // A = G_r * diag(v, v) + I, inverted by Gauss-Jordan elimination with partial pivoting
+    float a[N2][N2], ai[N2][N2];
+#pragma unroll
+    for (int r = 0; r < N2; ++r)
+#pragma unroll
+      for (int c = 0; c < N2; ++c) {
+        a[r][c] = gr[r][c] * var[c % K] + (r == c ? 1.f : 0.f);
+        ai[r][c] = r == c ? 1.f : 0.f;
+      }
+    for (int c = 0; c < N2; ++c) {
+      int piv = c;
+      float best = fabsf(a[c][c]);
+      for (int r = c + 1; r < N2; ++r)
+        if (fabsf(a[r][c]) > best) { best = fabsf(a[r][c]); piv = r; }
+      if (piv != c)
+        for (int j = 0; j < N2; ++j) {
+          float t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t;
+          t = ai[c][j]; ai[c][j] = ai[piv][j]; ai[piv][j] = t;
+        }
+      const float inv = 1.f / a[c][c];
+      for (int j = 0; j < N2; ++j) { a[c][j] *= inv; ai[c][j] *= inv; }
+      for (int r = 0; r < N2; ++r)
+        if (r != c) {
+          const float fct = a[r][c];
+          for (int j = 0; j < N2; ++j) { a[r][j] -= fct * a[c][j]; ai[r][j] -= fct * ai[c][j]; }
+        }
+    }
+    // bias mu, unbiased estimates and post-filter variance (detection.py:1580-1606)
+    for (int k = 0; k < K; ++k) {
+      float mu0 = 0.f, mu1 = 0.f, x0 = 0.f, x1 = 0.f;
+      for (int c = 0; c < N2; ++c) {
+        const float v = c < K ? ypic[c][k].re : ypic[c - K][k].im;      // real vector of column k of ypic
+        mu0 += ai[k][c] * gr[c][k];
+        mu1 += ai[K + k][c] * gr[c][K + k];
+        x0 += ai[k][c] * v;
+        x1 += ai[K + k][c] * v;
+      }
+      const float xr = x0 / mu0, xi = x1 / mu1;
+      const float vx = mu0 / fmaxf(1.f - var[k] * mu0, 1e-4f);
+      const float no_eff = fmaxf(1.f / vx, 1.17549435e-38f);
+      // demapping with priors llr_a (app: logsumexp, maxlog: max) over the points with bit b = 1 / 0
+      float ls0[kMaxBits], ls1[kMaxBits], m1[kMaxBits], m0[kMaxBits], s1[kMaxBits], s0[kMaxBits];
+      for (int b = 0; b < nb; ++b) {
+        ls1[b] = log_sigmoid(llr_a[k][b]); ls0[b] = log_sigmoid(-llr_a[k][b]);
+        m1[b] = m0[b] = -INFINITY; s1[b] = s0[b] = 0.f;
+      }
+      for (int pass = 0; pass < (q.maxlog ? 1 : 2); ++pass)
+        for (int pt = 0; pt < P; ++pt) {
+          const float dr = xr - q.points[pt].x, di = xi - q.points[pt].y;
+          float tl = -(dr * dr + di * di) / no_eff;
+          float ps = 0.f;
+          for (int b = 0; b < nb; ++b) ps += ((pt >> (nb - 1 - b)) & 1) ? ls1[b] : ls0[b];
+          tl += ps;
+          for (int b = 0; b < nb; ++b) {
+            const bool one = (pt >> (nb - 1 - b)) & 1;
+            if (pass == 0) { if (one) m1[b] = fmaxf(m1[b], tl); else m0[b] = fmaxf(m0[b], tl); }
+            else { if (one) s1[b] += expf(tl - m1[b]); else s0[b] += expf(tl - m0[b]); }
+          }
+        }
+      for (int b = 0; b < nb; ++b)
+        llr[k][b] = q.maxlog ? (m1[b] - m0[b]) : ((m1[b] + logf(s1[b])) - (m0[b] + logf(s0[b])));
+    }
+  }
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < nb; ++b) {
+      const float e = llr[k][b] - llr_a[k][b];
+      llr[k][b] = q.hard_out ? (e > 0.f ? 1.f : 0.f) : e;
+    }
+}
+
+// ---- standalone detector on n problems: y [n,M], h [n,M,K], s [n,M,M], prior [n,K,nb] -> out [n,K,nb]
+template <int M, int K>
+__global__ __launch_bounds__(64) void mmse_pic_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                            const float2* __restrict__ s, const float* __restrict__ prior,
+                                                            int64_t n, PicParams q, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  c32 yy[M], hh[M][K], ss[M][M];
+  float llr[K][kMaxBits];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    yy[m] = C(y[i * M + m].x, y[i * M + m].y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float2 v = h[(i * M + m) * K + k]; hh[m][k] = C(v.x, v.y); }
+#pragma unroll
+    for (int j = 0; j < M; ++j) { const float2 v = s[(i * M + m) * M + j]; ss[m][j] = C(v.x, v.y); }
+  }
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < q.nb; ++b) llr[k][b] = prior[(i * K + k) * q.nb + b];
+  mmse_pic_solve<M, K>(yy, hh, ss, llr, q);
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < q.nb; ++b) out[(i * K + k) * q.nb + b] = llr[k][b];
+}
+
+// ---- fused OFDM MMSE-PIC detector (ofdm/detection.py:1062-1230 + OFDMDetectorWithPrior :320-560):
+// prior / out [B, S, ND * nb]; REs without data for a stream enter with a zero prior.
+template <int M, int K>
+__global__ __launch_bounds__(64) void ofdm_mmse_pic_kernel(OfdmEqArgs p, const float* __restrict__ prior, PicParams q,
+                                                           float* __restrict__ out) {
+  const int64_t total = (int64_t)p.B * p.RX * p.T * p.F;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int dpos[K], rx;
+  int64_t b;
+  c32 y[M], h[M][K], s[M][M];
+  if (!load_re<M, K>(p, i, y, h, s, dpos, b, rx)) return;
+  float llr[K][kMaxBits];
+  for (int k = 0; k < K; ++k) {
+    const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + (dpos[k] >= 0 ? dpos[k] : 0)) * q.nb;
+    for (int bb = 0; bb < q.nb; ++bb) llr[k][bb] = dpos[k] >= 0 ? prior[o + bb] : 0.f;
+  }
+  mmse_pic_solve<M, K>(y, h, s, llr, q);
+  for (int k = 0; k < K; ++k)
+    if (dpos[k] >= 0) {
+      const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * q.nb;
+      for (int bb = 0; bb < q.nb; ++bb) out[o + bb] = llr[k][bb];
     }
 }
 
@@ -293,5 +532,54 @@ extern "C" int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const flo
   SAMD_MK_LIST(X)
 #undef X
   set_error("ofdm_lmmse: unsupported (num_rx_ant, streams_per_rx) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_mmse_pic_f32(const float* y, const float* h, const float* s, const float* prior,
+                                 const float* points, int64_t n, int m, int k, int num_bits_per_symbol, int maxlog,
+                                 int num_iter, int hard_out, float* out, void* stream) {
+  SAMD_REQUIRE(y && h && s && prior && points && out && n >= 0, "bad argument");
+  SAMD_REQUIRE(num_bits_per_symbol >= 1 && num_bits_per_symbol <= kMaxBits && num_iter >= 0, "bad detector parameters");
+  if (n == 0) return SAMD_OK;
+  const PicParams q{(const float2*)points, num_bits_per_symbol, maxlog, num_iter, hard_out};
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define X(M, K)                                                                                                   \
+  if (m == M && k == K) {                                                                                         \
+    hipLaunchKernelGGL((mmse_pic_items_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, (const float2*)y,  \
+                       (const float2*)h, (const float2*)s, prior, n, q, out);                                     \
+    return launch_status();                                                                                       \
+  }
+  SAMD_MK_LIST(X)
+#undef X
+  set_error("mmse_pic: unsupported (num_rx_ant, num_streams) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode,
+                                      const float* no, const float* prior, const float* points, const int32_t* sc_ind,
+                                      const int32_t* desired, const int32_t* undesired, const int32_t* data_pos,
+                                      int batch, int num_rx, int num_rx_ant, int num_streams_total, int streams_per_rx,
+                                      int num_undesired, int num_ofdm_symbols, int num_eff_subcarriers, int fft_size,
+                                      int num_data, int num_bits_per_symbol, int maxlog, int num_iter, int hard_out,
+                                      float* out, void* stream) {
+  SAMD_REQUIRE(y && h_hat && no && prior && points && sc_ind && desired && data_pos && out, "null argument");
+  SAMD_REQUIRE(ev_mode >= 0 && ev_mode <= 2 && (ev_mode == 0 || err_var), "bad err_var mode");
+  SAMD_REQUIRE(num_undesired == 0 || undesired, "undesired stream table missing");
+  SAMD_REQUIRE(num_bits_per_symbol >= 1 && num_bits_per_symbol <= kMaxBits && num_iter >= 0, "bad detector parameters");
+  OfdmEqArgs p{(const float2*)y, (const float2*)h_hat, err_var, no, sc_ind, desired, undesired, data_pos, nullptr,
+               nullptr, batch, num_rx, num_streams_total, num_ofdm_symbols, num_eff_subcarriers, fft_size,
+               num_undesired, num_data, ev_mode, 1};
+  const PicParams q{(const float2*)points, num_bits_per_symbol, maxlog, num_iter, hard_out};
+  const int64_t total = (int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers;
+  if (total == 0) return SAMD_OK;
+  const dim3 grid((unsigned)((total + 63) / 64));
+#define X(M, K)                                                                                              \
+  if (num_rx_ant == M && streams_per_rx == K) {                                                              \
+    hipLaunchKernelGGL((ofdm_mmse_pic_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, p, prior, q, out); \
+    return launch_status();                                                                                  \
+  }
+  SAMD_MK_LIST(X)
+#undef X
+  set_error("ofdm_mmse_pic: unsupported (num_rx_ant, streams_per_rx) combination");
   return SAMD_ERR_UNSUPPORTED;
 }

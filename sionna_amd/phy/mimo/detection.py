@@ -1,9 +1,11 @@
 """``mimo.LinearDetector`` - equaliser followed by a demapper (reference
-src/sionna/phy/mimo/detection.py:24-143).  Only the LMMSE equaliser with bit output is on the
-hot path."""
+src/sionna/phy/mimo/detection.py:24-143; only the LMMSE equaliser with bit output) - and
+``mimo.MMSEPICDetector`` (:1314-1643, bit output) on ``samd_mmse_pic_f32``."""
+import numpy as np
 import torch
 
-from ..block import Block
+from ... import _ffi
+from ..block import Block, wrap
 from ..mapping import Demapper, Constellation
 from .equalization import lmmse_equalizer
 
@@ -31,3 +33,49 @@ class LinearDetector(Block):
         z = self._demapper(x_hat, no_eff)                     # [..., K*m]
         m = self._constellation.num_bits_per_symbol
         return z.reshape(tuple(x_hat.shape) + (m,))           # [..., K, m] (detection.py:139-143)
+
+
+class MMSEPICDetector(Block):
+    """``MMSEPICDetector(output, demapping_method="maxlog", num_iter=1, constellation_type=None,
+    num_bits_per_symbol=None, constellation=None, hard_out=False)(y, h, s, prior)``:
+    y [...,M], h [...,M,K], s [...,M,M], prior [...,K,num_bits_per_symbol] (LLRs) ->
+    extrinsic LLRs [...,K,num_bits_per_symbol]."""
+
+    def __init__(self, output, demapping_method="maxlog", num_iter=1, constellation_type=None,
+                 num_bits_per_symbol=None, constellation=None, hard_out=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        assert isinstance(num_iter, int), "num_iter must be an integer"
+        assert output in ("bit", "symbol"), "Unknown output"
+        assert demapping_method in ("app", "maxlog"), "Unknown demapping method"
+        if output != "bit":
+            raise NotImplementedError("MMSEPICDetector: only output='bit' has a HIP path")
+        self._num_iter, self._output, self._demapping_method, self._hard_out = num_iter, output, demapping_method, hard_out
+        self._constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+
+    constellation = property(lambda self: self._constellation)
+
+    def _kernel_params(self):
+        pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex64), torch.complex64)
+        return pts, self._constellation.num_bits_per_symbol, int(self._demapping_method == "maxlog"), self._num_iter, \
+            int(bool(self._hard_out))
+
+    def call(self, y, h, s, prior):
+        self._require_single()
+        y = _ffi.to_device(y, torch.complex64)
+        h = _ffi.to_device(h, torch.complex64)
+        s = _ffi.to_device(s, torch.complex64)
+        prior = _ffi.to_device(prior, torch.float32)
+        m, k = h.shape[-2], h.shape[-1]
+        lead = tuple(h.shape[:-2])
+        pts, nb, maxlog, num_iter, hard = self._kernel_params()
+        assert tuple(prior.shape[-2:]) == (k, nb), "prior must have shape [..., num_streams, num_bits_per_symbol]"
+        y = torch.broadcast_to(y, lead + (m,)).contiguous()
+        s = torch.broadcast_to(s, lead + (m, m)).contiguous()
+        prior = torch.broadcast_to(prior, lead + (k, nb)).contiguous()
+        out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
+        _ffi.check(_ffi.lib().samd_mmse_pic_f32(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), _ffi.ptr(prior),
+                                                _ffi.ptr(pts), y.numel() // m, m, k, nb, maxlog, num_iter, hard,
+                                                _ffi.ptr(out), _ffi.stream()), "MMSEPICDetector")
+        return wrap(out)

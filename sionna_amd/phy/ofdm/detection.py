@@ -1,9 +1,14 @@
 """``ofdm.LinearDetector`` - mirror of reference src/sionna/phy/ofdm/detection.py:740-847
 (-> ``OFDMDetector.call`` :289-317 -> ``mimo.LinearDetector``): fused LMMSE equaliser followed by
-the LLR demapper with the per-symbol effective noise variance."""
-from ..block import Block
+the LLR demapper with the per-symbol effective noise variance - and ``ofdm.MMSEPICDetector``
+(:1062-1230 on ``OFDMDetectorWithPrior`` :320-560, bit output) in one fused launch."""
+import numpy as np
+import torch
+
+from ... import _ffi
+from ..block import Block, wrap
 from ..mapping import Demapper, Constellation
-from .equalization import LMMSEEqualizer
+from .equalization import LMMSEEqualizer, OFDMEqualizer
 
 
 class LinearDetector(Block):
@@ -25,3 +30,35 @@ class LinearDetector(Block):
     def call(self, y, h_hat, err_var, no):
         x_hat, no_eff = self._eq(y, h_hat, err_var, no)
         return self._demapper(x_hat, no_eff)          # [batch, num_tx, num_streams, num_data_symbols*m]
+
+
+class MMSEPICDetector(Block):
+    """``MMSEPICDetector(output, demapping_method, resource_grid, stream_management, num_iter=1,
+    constellation_type=None, num_bits_per_symbol=None, constellation=None, hard_out=False)``
+    ``(y, h_hat, prior, err_var, no)``; prior / output [batch, num_tx, num_streams,
+    num_data_symbols * num_bits_per_symbol] (LLRs; output = extrinsic LLRs)."""
+
+    def __init__(self, output, demapping_method, resource_grid, stream_management, num_iter=1,
+                 constellation_type=None, num_bits_per_symbol=None, constellation=None, hard_out=False,
+                 precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        from ..mimo.detection import MMSEPICDetector as _MimoPIC
+        self._det = _MimoPIC(output, demapping_method, num_iter, constellation_type, num_bits_per_symbol, constellation,
+                             hard_out, precision=precision)
+        self._pre = OFDMEqualizer("lmmse", resource_grid, stream_management, precision=precision)
+        self._rg = resource_grid
+
+    def call(self, y, h_hat, prior, err_var, no):
+        self._require_single()
+        rg = self._rg
+        pts, nb, maxlog, num_iter, hard = self._det._kernel_params()
+        prior = _ffi.to_device(prior, torch.float32)
+        keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
+        b, nd = dims[0], rg.num_data_symbols
+        shape = (b, rg.num_tx, rg.num_streams_per_tx, nd * nb)
+        assert tuple(prior.shape) == shape, "prior must have shape [batch, num_tx, num_streams, num_data_symbols*num_bits_per_symbol]"
+        prior = prior.contiguous()
+        out = torch.zeros(shape, dtype=torch.float32, device=prior.device)
+        _ffi.check(_ffi.lib().samd_ofdm_mmse_pic_f32(*head, _ffi.ptr(prior), _ffi.ptr(pts), *tabs, *dims, nb, maxlog, num_iter,
+                                                     hard, _ffi.ptr(out), _ffi.stream()), "ofdm.MMSEPICDetector")
+        return wrap(out)

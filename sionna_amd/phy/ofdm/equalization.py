@@ -38,8 +38,8 @@ class OFDMEqualizer(Block):
                          i32(data_pos), undesired.shape[1])
         return self._dev
 
-    def call(self, y, h_hat, err_var, no):
-        self._require_single()
+    def _prepare(self, y, h_hat, err_var, no):
+        """Device tensors + scalar arguments shared by the fused per-RE kernels."""
         rg, sm = self._rg, self._sm
         y = _ffi.to_device(y, torch.complex64)
         h_hat = _ffi.to_device(h_hat, torch.complex64)
@@ -60,13 +60,21 @@ class OFDMEqualizer(Block):
         no = _ffi.to_device(no, torch.float32)
         no = torch.broadcast_to(no.reshape(tuple(no.shape) + (1,) * (3 - no.dim())), (b, rx, m)).contiguous()
         sc_ind, desired, undesired, data_pos, n_und = self._tables()
-        nd = rg.num_data_symbols
-        x_hat = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.complex64, device=y.device)
-        no_eff = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.float32, device=y.device)
-        _ffi.check(_ffi.lib().samd_ofdm_lmmse_c64(
-            _ffi.ptr(y), _ffi.ptr(h_hat), _ffi.ptr(ev_arg), ev_mode, _ffi.ptr(no), _ffi.ptr(sc_ind), _ffi.ptr(desired),
-            _ffi.ptr(undesired), _ffi.ptr(data_pos), b, rx, m, s, sm.num_streams_per_rx, n_und, t, f, rg.fft_size, nd,
-            int(self._whiten), _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.stream()), "LMMSEEqualizer")
+        keep = (y, h_hat, ev_arg, no)                       # keeps the temporaries alive until the launch
+        head = (_ffi.ptr(y), _ffi.ptr(h_hat), _ffi.ptr(ev_arg), ev_mode, _ffi.ptr(no))
+        tabs = (_ffi.ptr(sc_ind), _ffi.ptr(desired), _ffi.ptr(undesired), _ffi.ptr(data_pos))
+        dims = (b, rx, m, s, sm.num_streams_per_rx, n_und, t, f, rg.fft_size, rg.num_data_symbols)
+        return keep, head, tabs, dims
+
+    def call(self, y, h_hat, err_var, no):
+        self._require_single()
+        rg = self._rg
+        keep, head, tabs, dims = self._prepare(y, h_hat, err_var, no)
+        b, nd, dev = dims[0], rg.num_data_symbols, keep[0].device
+        x_hat = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.complex64, device=dev)
+        no_eff = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.float32, device=dev)
+        _ffi.check(_ffi.lib().samd_ofdm_lmmse_c64(*head, *tabs, *dims, int(self._whiten), _ffi.ptr(x_hat),
+                                                  _ffi.ptr(no_eff), _ffi.stream()), "LMMSEEqualizer")
         return x_hat, no_eff
 
 

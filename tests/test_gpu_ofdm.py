@@ -383,3 +383,61 @@ def test_time_domain_chain_ls_lin_recovers_frequency_response(phy):
     k = np.arange(n) - n // 2
     H = (taps[:, None, :] * np.exp(-2j * np.pi * k[None, :, None] * np.arange(l_min, l_max + 1)[None, None, :] / n)).sum(-1)
     assert np.allclose(_np(h_hat)[:, 0, 0, 0, 0], np.broadcast_to(H[:, None, :], (B, nsym, n)), atol=1e-4)
+
+
+# ------------------------------------------------------------------ MMSE-PIC detector
+@pytest.mark.parametrize("m,k,nb", [(4, 2, 2), (4, 2, 4), (2, 2, 2), (8, 4, 4), (4, 1, 6), (1, 1, 2)])
+@pytest.mark.parametrize("method", ["app", "maxlog"])
+def test_mimo_mmse_pic_vs_oracle(phy, m, k, nb, method):
+    rng = np.random.default_rng(m * 10 + k + nb)
+    n = 300
+    pts = omap.qam(nb)
+    bits = rng.integers(0, 2, (n, k, nb))
+    x = pts[(bits * (2 ** np.arange(nb - 1, -1, -1))).sum(-1)]
+    h = _cplx(rng, (n, m, k)) / np.sqrt(2)
+    no = 0.15
+    y = ((h @ x[..., None])[..., 0] + np.sqrt(no / 2) * _cplx(rng, (n, m))).astype(np.complex64)
+    a = _cplx(rng, (n, m, m)) * 0.2
+    s = (a @ np.conj(np.swapaxes(a, -1, -2)) + no * np.eye(m)).astype(np.complex64)          # coloured noise covariance
+    prior = (rng.normal(size=(n, k, nb)) * 2).astype(np.float32)
+    for num_iter in (1, 3):
+        det = phy.mimo.MMSEPICDetector("bit", method, num_iter=num_iter, constellation_type="qam", num_bits_per_symbol=nb)
+        got = _np(det(y, h, s, prior))
+        ref = o.mmse_pic(y, h, s, prior, pts, method, num_iter)
+        assert got.shape == ref.shape == (n, k, nb)
+        assert np.mean(np.isclose(got, ref, rtol=2e-3, atol=2e-3)) > 0.995, np.max(np.abs(got - ref))
+    # zero prior, one iteration == LMMSE equaliser + demapper (x_hat = 0, unit variance: [CST2011] reduces to LMMSE)
+    det = phy.mimo.MMSEPICDetector("bit", method, num_iter=1, constellation_type="qam", num_bits_per_symbol=nb)
+    got = _np(det(y, h, s, np.zeros_like(prior)))
+    lin = _np(phy.mimo.LinearDetector("lmmse", "bit", method, constellation_type="qam", num_bits_per_symbol=nb)(y, h, s))
+    assert np.mean(np.isclose(got, lin, rtol=2e-3, atol=2e-3)) > 0.995
+    hard = _np(phy.mimo.MMSEPICDetector("bit", method, num_iter=2, constellation_type="qam", num_bits_per_symbol=nb,
+                                        hard_out=True)(y, h, s, prior))
+    assert set(np.unique(hard)) <= {0.0, 1.0}
+    with pytest.raises(NotImplementedError):
+        phy.mimo.MMSEPICDetector("symbol", method, constellation_type="qam", num_bits_per_symbol=nb)
+
+
+@pytest.mark.parametrize("num_tx,ns,assoc", [(1, 2, [[1]]), (2, 1, [[1, 1]]), (2, 2, [[1, 0], [0, 1]])])
+def test_ofdm_mmse_pic_vs_oracle(phy, num_tx, ns, assoc):
+    rg, org = _grids(phy, num_tx=num_tx, ns=ns, fft=72, guards=(3, 4))
+    sm, osm = phy.mimo.StreamManagement(np.array(assoc), ns), o.StreamManagement(np.array(assoc), ns)
+    rng = np.random.default_rng(num_tx + ns)
+    B, nb = 3, 2
+    pts = omap.qam(nb)
+    nrx = len(assoc)
+    y = _cplx(rng, (B, nrx, 4, 14, 72))
+    h_hat = _cplx(rng, (B, nrx, 4, num_tx, ns, 14, rg.num_effective_subcarriers))
+    err_var = rng.uniform(0.0, 0.05, (1, 1, 1, num_tx, ns, 14, rg.num_effective_subcarriers)).astype(np.float32)
+    prior = (rng.normal(size=(B, num_tx, ns, rg.num_data_symbols * nb)) * 1.5).astype(np.float32)
+    for method, it in (("maxlog", 1), ("app", 2)):
+        det = phy.ofdm.MMSEPICDetector("bit", method, rg, sm, num_iter=it, constellation_type="qam", num_bits_per_symbol=nb)
+        got = _np(det(y, h_hat, prior, err_var, 0.3))
+        ref = o.ofdm_mmse_pic(org, osm, y, h_hat, prior, err_var, 0.3, pts, method, it)
+        assert got.shape == ref.shape
+        assert np.mean(np.isclose(got, ref, rtol=2e-3, atol=2e-3)) > 0.995, np.max(np.abs(got - ref))
+    # zero prior + one iteration == the linear LMMSE detector of the same grid
+    det = phy.ofdm.MMSEPICDetector("bit", "app", rg, sm, num_iter=1, constellation_type="qam", num_bits_per_symbol=nb)
+    lin = phy.ofdm.LinearDetector("lmmse", "bit", "app", rg, sm, constellation_type="qam", num_bits_per_symbol=nb)
+    a, b = _np(det(y, h_hat, np.zeros_like(prior), err_var, 0.3)), _np(lin(y, h_hat, err_var, 0.3))
+    assert np.mean(np.isclose(a, b, rtol=2e-3, atol=2e-3)) > 0.995
