@@ -324,6 +324,22 @@ def main():
         "roofline": roofline,
     }
 
+    # whole chain source -> encoder -> mapper -> AWGN -> demapper -> decoder -> counters (SURVEY 8d "e2e")
+    def chain_step():
+        ub = src([B, k])
+        ll = demap(awgn(mapper(enc(ub)), no), no)
+        phy.utils.metrics.count_errors_into(ub, dec(ll), counters[:2])
+    chain_step()
+    barrier()
+    t0 = time.perf_counter()
+    n_e2e = 3
+    for _ in range(n_e2e):
+        chain_step()
+    barrier()
+    t_e2e = (time.perf_counter() - t0) / n_e2e
+    out["end_to_end"] = {"codewords_per_s_per_gpu": round(B / t_e2e, 1), "ms_per_batch": round(t_e2e * 1e3, 2),
+                         "stages": "BinarySource, LDPC5GEncoder, Mapper, AWGN, Demapper(app), LDPC5GDecoder, count_errors"}
+
     if args.also and args.also != "none" and args.also != args.cn_update:
         dec2 = make_dec(args.also)
         steps2 = max(2, args.steps // 3)
