@@ -112,9 +112,10 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   const int words = (n + 31) / 32;
   float* llr_ch = smem;                                   // [n]
   float* llr = llr_ch + n;                                // [L][n]   stage s at [2^s, 2^(s+1))
-  unsigned char* betaL = reinterpret_cast<unsigned char*>(llr + (size_t)L * n);   // [L][n]
-  unsigned char* betaR = betaL + (size_t)L * n;                                   // [L][n]
-  uint32_t* bits = reinterpret_cast<uint32_t*>(betaR + (size_t)L * n);            // [L][words] decided u bits
+  // partial sums: ONE byte per (slot, stage position), bit 0 = left child's result, bit 1 = right
+  // child's (halves the LDS of two byte banks: 3 instead of 2 codewords per CU at n = 1024, L = 8)
+  unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * n);    // [L][n]
+  uint32_t* bits = reinterpret_cast<uint32_t*>(beta + (size_t)L * n);             // [L][words] decided u bits
   float* pm = reinterpret_cast<float*>(bits + (size_t)L * words);                 // [L]   by position
   float* cand = pm + L;                                   // [2L] candidate metrics
   float* blk = cand + 2 * L;                              // [2L] block metrics (rate-0 / rep)
@@ -133,9 +134,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   unsigned char* lp = reinterpret_cast<unsigned char*>(red + 256);   // [L][16] slot of the stage-s LLRs
   unsigned char* bl = lp + (size_t)L * 16;                           // [L][16] slot of the stage-s left sums
   unsigned char* br = bl + (size_t)L * 16;                           // [L][16] slot of the stage-s right sums
-  int* lops = reinterpret_cast<int*>(br + (size_t)L * 16);           // [num_ops] decoding schedule (LDS copy:
-                                                                     // the op fetch is on the critical path)
-  for (int i = tid; i < p.num_ops; i += NT) lops[i] = p.ops[i];
+  // the schedule is read with scalar loads one op ahead (wave-uniform index): no LDS copy
 
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
     for (int i = tid; i < n; i += NT) llr_ch[i] = -1.f * p.llr_in[(size_t)b * n + i];   // logits -> LLR
@@ -144,8 +143,10 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
     if (tid < L) { pm[tid] = tid == 0 ? 0.f : kPolarLlrMax; order[tid] = tid; }         // decoding.py:1029-1033
     __syncthreads();
 
+    int next_rec = p.ops[0];
     for (int ip = 0;; ++ip) {
-      const int rec = lops[ip];
+      const int rec = next_rec;
+      next_rec = (ip + 1 < p.num_ops) ? p.ops[ip + 1] : (int)OP_END;
       const int op = rec & 7, a0 = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = (rec >> 8) - 2048;
       if (op == OP_END) break;
       if (op == OP_F || op == OP_G) {
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           const float x = in[j], y = in[j + half];
           float r;
           if (op == OP_F) r = cn_op(x, y);
-          else r = (1.f - 2.f * (float)betaL[(size_t)bl[slot * 16 + s - 1] * n + half + j]) * x + y;  // vn_op :707-714
+          else r = (1.f - 2.f * (float)(beta[(size_t)bl[slot * 16 + s - 1] * n + half + j] & 1)) * x + y;  // vn_op :707-714
           llr[(size_t)slot * n + half + j] = r;
         }
         if (tid < L) lp[order[tid] * 16 + s - 1] = (unsigned char)order[tid];
@@ -169,11 +170,12 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         for (int w = tid; w < L * sz; w += NT) {
           const int pos = w / sz, j = w - pos * sz;
           const int slot = order[pos];
-          const unsigned char l = betaL[(size_t)bl[slot * 16 + s] * n + sz + j];
-          const unsigned char r = betaR[(size_t)br[slot * 16 + s] * n + sz + j];
-          unsigned char* dst = (a1 ? betaR : betaL) + (size_t)slot * n + 2 * sz;
-          dst[j] = l ^ r;
-          dst[sz + j] = r;
+          const unsigned char l = beta[(size_t)bl[slot * 16 + s] * n + sz + j] & 1;
+          const unsigned char r = (beta[(size_t)br[slot * 16 + s] * n + sz + j] >> 1) & 1;
+          unsigned char* dst = beta + (size_t)slot * n + 2 * sz;
+          const unsigned char keep = a1 ? 1 : 2;                    // the other side's bit stays
+          dst[j] = (dst[j] & keep) | (unsigned char)((l ^ r) << a1);
+          dst[sz + j] = (dst[sz + j] & keep) | (unsigned char)(r << a1);
         }
         if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s + 1] = (unsigned char)order[tid];
         __syncthreads();
@@ -217,7 +219,8 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           if (tid < L) pm[tid] += blk[tid];
           for (int w = tid; w < L * sz; w += NT) {
             const int pos = w / sz, j = w - pos * sz;
-            ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = 0;
+            unsigned char* d = beta + (size_t)order[pos] * n + sz + j;
+            *d = *d & (a1 ? 1 : 2);
           }
           if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s] = (unsigned char)order[tid];
           __syncthreads();
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         __syncthreads();
         for (int w = tid; w < L * sz; w += NT) {
           const int pos = w / sz, j = w - pos * sz;
-          ((a1 ? betaR : betaL) + (size_t)order[pos] * n + sz)[j] = (unsigned char)new_bit[pos];   // all-u codeword
+          unsigned char* d = beta + (size_t)order[pos] * n + sz + j;
+          *d = (*d & (a1 ? 1 : 2)) | (unsigned char)(new_bit[pos] << a1);                          // all-u codeword
         }
         if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s] = (unsigned char)order[tid];
         __syncthreads();
@@ -329,8 +333,9 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
 
 static size_t scl_lds_bytes(int n, int L, int num_ops) {
   const size_t words = (n + 31) / 32;
-  return (size_t)n * 4 + (size_t)L * n * 4 + 2 * (size_t)L * n + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
-         (size_t)L * 4 * 5 + 256 * 4 + 3 * (size_t)L * 16 + (size_t)num_ops * 4 + 64;
+  (void)num_ops;
+  return (size_t)n * 4 + (size_t)L * n * 4 + (size_t)L * n + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
+         (size_t)L * 4 * 5 + 256 * 4 + 3 * (size_t)L * 16 + 64;
 }
 
 }  // namespace samd
