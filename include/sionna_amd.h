@@ -238,6 +238,12 @@ int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const float* err_
                            int num_bits_per_symbol, int maxlog, int num_iter, int hard_out, float* out,
                            void* stream);
 
+/* LinearEncoder.call  fec/linear/encoding.py:143-168: c = (u G) mod 2 for a binary generator
+ * matrix.  gm_cols DEVICE uint32 [n][ceil(k/32)]: bit (i & 31) of word (i >> 5) of row j = G[i][j]
+ * (the columns of G, packed).  u [batch,k] float 0/1 -> out [batch,n] float 0/1. */
+int samd_gf2_encode_f32(const float* u, const uint32_t* gm_cols, int64_t batch, int k, int n,
+                        float* out, void* stream);
+
 /* ---- scrambling --------------------------------------------------- */
 
 /* Scrambler.call fec/scrambling.py:186-261 / TB5GScrambler.call :442-468:

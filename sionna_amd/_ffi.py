@@ -53,6 +53,7 @@ _SIGNATURES = {
     "samd_cir_to_ofdm_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_apply_ofdm_channel_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_ls_gather_scale_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_gf2_encode_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "samd_scramble_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "samd_nr_prng_seq_f32": (_i32, [C.c_uint32, _i64, _vp, _vp]),
     "samd_ofdm_modulate_c64": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),

@@ -1,0 +1,119 @@
+"""CPU tests of the host-side code utilities (sionna_amd/phy/fec/utils.py), restating the
+reference's own unit tests test/unit/fec/test_fec_utils.py (explicit alist example :178-210, the
+WiMAX alist file :212-230, verify_gm_pcm / pcm2gm / gm2pcm / load_parity_check_examples :231-330,
+bin/int conversions, J-function pair)."""
+import os
+
+import numpy as np
+import pytest
+
+from sionna_amd.phy.fec import utils as u
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_alist_explicit_example():
+    alist = [[7, 3], [3, 4], [1, 1, 1, 2, 2, 2, 3], [4, 4, 4], [1, 0, 0], [2, 0, 0], [3, 0, 0], [1, 2, 0], [1, 3, 0],
+             [2, 3, 0], [1, 2, 3], [1, 4, 5, 7], [2, 4, 6, 7], [3, 5, 6, 7]]
+    pcm, k, n, r = u.alist2mat(alist, verbose=False)
+    assert (k, n, r) == (4, 7, 4 / 7)
+    assert np.array_equal(pcm, [[1, 0, 0, 1, 1, 0, 1], [0, 1, 0, 1, 0, 1, 1], [0, 0, 1, 0, 1, 1, 1]])
+    pcm2, *_ = u.alist2mat(alist[:4 + 7], verbose=False)            # VN perspective only
+    assert np.array_equal(pcm2, pcm)
+    bad = [row[:] for row in alist]
+    bad[11] = [1, 4, 6, 7]
+    with pytest.raises(AssertionError):
+        u.alist2mat(bad, verbose=False)
+
+
+def test_alist_wimax_file():
+    alist = u.load_alist(os.path.join(GOLD, "wimax_576_0.5.alist"))
+    pcm, k, n, r = u.alist2mat(alist, verbose=False)
+    assert (k, n, r) == (288, 576, 0.5) and pcm.shape == (288, 576)
+    gm = u.pcm2gm(pcm)
+    assert u.verify_gm_pcm(gm, pcm)
+
+
+def test_load_parity_check_examples():
+    shapes = {0: (3, 7), 1: (18, 63), 2: (21, 127), 3: (50, 100), 4: (324, 648)}
+    for i, shp in shapes.items():
+        pcm, k, n, r = u.load_parity_check_examples(i)
+        assert pcm.shape == shp and (k, n) == (shp[1] - shp[0], shp[1]) and r == k / n
+        assert ((pcm == 0) | (pcm == 1)).all()
+    with pytest.raises(IndexError):
+        u.load_parity_check_examples(5)
+
+
+def test_verify_gm_pcm_pcm2gm_gm2pcm():
+    with pytest.raises(AssertionError):
+        u.verify_gm_pcm(np.zeros((20, 12)), np.zeros((20, 12)))
+    for i in range(5):
+        pcm, *_ = u.load_parity_check_examples(i)
+        gm = u.pcm2gm(pcm)
+        assert u.verify_gm_pcm(gm, pcm)
+        # the built-in pcm interpreted as a generator matrix
+        assert u.verify_gm_pcm(pcm, u.gm2pcm(pcm))
+    pcm, *_ = u.load_parity_check_examples(3)                          # needs column swaps
+    gm = u.pcm2gm(pcm)
+    gm_sys, _ = u.make_systematic(gm)
+    assert not u.verify_gm_pcm(gm_sys, pcm)
+    pcm0, *_ = u.load_parity_check_examples(0)
+    gm0 = u.pcm2gm(pcm0)
+    for g, h in ((np.where(np.arange(gm0.size).reshape(gm0.shape) == 0, 2, gm0), pcm0),
+                 (gm0, np.where(np.arange(pcm0.size).reshape(pcm0.shape) == 0, 2, pcm0))):
+        with pytest.raises(AssertionError):
+            u.verify_gm_pcm(g, h)
+    # manual case of the reference (PR #236)
+    pcm = np.array([[1, 0, 0, 0, 0, 1, 1], [0, 1, 0, 0, 1, 0, 1], [0, 0, 1, 0, 1, 0, 0], [0, 0, 0, 1, 0, 1, 0]])
+    assert u.verify_gm_pcm(u.pcm2gm(pcm, verify_results=False), pcm)
+
+
+def test_make_systematic():
+    rng = np.random.default_rng(0)
+    for m, n in ((4, 10), (20, 50), (50, 100)):
+        while True:
+            mat = rng.integers(0, 2, (m, n))
+            try:
+                sys_g, swaps = u.make_systematic(mat)
+                break
+            except ValueError:
+                continue
+        assert np.array_equal(sys_g[:, :m], np.eye(m))
+        sys_h, swaps_h = u.make_systematic(mat, is_pcm=True)
+        assert np.array_equal(sys_h[:, -m:], np.eye(m)) and len(swaps_h) >= m
+    with pytest.raises(ValueError):
+        u.make_systematic(np.zeros((3, 6)))
+    with pytest.raises(AssertionError):
+        u.make_systematic(np.zeros((6, 3)))
+    with pytest.warns(UserWarning):
+        u.make_systematic(np.array([[1, 0, 1, 0], [0, 1, 1, 0]]), is_pcm=True)
+
+
+def test_bin_int_helpers():
+    for num, length, ref in ((5, 4, [0, 1, 0, 1]), (0, 3, [0, 0, 0]), (12, 4, [1, 1, 0, 0]), (1, 0, []), (13, 2, [0, 1])):
+        assert u.int2bin(num, length) == ref
+    assert u.bin2int([1, 0, 1]) == 5 and u.bin2int([]) is None and u.bin2int([0, 1, 1, 0]) == 6
+    assert np.array_equal(u.bin2int_tf(np.array([[1, 0, 1], [0, 1, 1]])), [5, 3])
+    assert np.array_equal(u.int2bin_tf(np.array([5, 12]), 4), [[0, 1, 0, 1], [1, 1, 0, 0]])
+    assert np.array_equal(u.int_mod_2(np.array([0, 1, 2, 3, -1])), [0, 1, 0, 1, 1])
+    assert np.array_equal(u.int_mod_2(np.array([0.2, 1.1, 2.0, 2.9, -1.0])), [0, 1, 0, 1, 1])
+
+
+def test_j_function_pair_and_llr2mi():
+    mi = np.linspace(0.01, 0.99, 50)
+    assert np.allclose(u.j_fun(u.j_fun_inv(mi)), mi, atol=1e-6)
+    assert u.j_fun(1e-12) < 1e-6 and abs(u.j_fun(1000.) - 1) < 1e-9 and u.j_fun_inv(1.0) == 20
+    rng = np.random.default_rng(1)
+    for mu in (0.5, 2.0, 6.0):                       # consistent Gaussian LLRs of the all-zero codeword
+        llr = rng.normal(-mu, np.sqrt(2 * mu), 400000).astype(np.float32)
+        assert abs(u.llr2mi(llr) - u.j_fun(mu)) < 0.01
+    with pytest.raises(TypeError):
+        u.llr2mi(np.arange(4))
+
+
+def test_generate_reg_ldpc():
+    pcm, k, n, r = u.generate_reg_ldpc(3, 6, 100, verbose=False)
+    assert pcm.shape == (50, 100) and (k, n, r) == (50, 100, 0.5)
+    assert (pcm.sum(0) == 3).all() and (pcm.sum(1) == 6).all()
+    pcm, k, n, r = u.generate_reg_ldpc(3, 6, 101, verbose=False)     # n is adapted to the next feasible length
+    assert n == 102 and pcm.shape == (51, 102)

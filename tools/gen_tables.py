@@ -69,3 +69,16 @@ dst = os.path.join(os.path.dirname(__file__), "..", "sionna_amd/phy/fec/polar/co
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 np.save(dst, q)
 print("wrote", os.path.normpath(dst))
+
+
+# ---- example parity-check matrices of fec/utils.load_parity_check_examples (coordinate form)
+ex = np.load(os.path.join(ref, "src/sionna/phy/fec/ldpc/codes/example_codes.npy"), allow_pickle=True)
+pk = {}
+for i in range(len(ex)):
+    pcm = np.array(ex[i])
+    r, c = np.nonzero(pcm)
+    pk[f"shape_{i}"] = np.array(pcm.shape, np.int32)
+    pk[f"rc_{i}"] = np.stack([r, c]).astype(np.int32)
+np.savez_compressed(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                 "sionna_amd/phy/fec/ldpc/codes/example_pcms.npz"), **pk)
+print("example pcms:", [tuple(pk[f"shape_{i}"]) for i in range(len(ex))])
