@@ -299,3 +299,60 @@ class BinarySource(Block):
         _ffi.check(_ffi.lib().samd_binary_source_f32(rng.seed, rng.next_call(), out.numel(), _ffi.ptr(out),
                                                      _ffi.stream()), "BinarySource")
         return out
+
+
+class SymbolSource(Block):
+    """``SymbolSource(constellation_type=None, num_bits_per_symbol=None, constellation=None,
+    return_indices=False, return_bits=False, seed=None)(shape)``: random constellation symbols of
+    the given shape (BinarySource -> Mapper, reference mapping.py:1354-1450); optionally also the
+    symbol indices and/or the bits [..., num_bits_per_symbol]."""
+
+    def __init__(self, constellation_type=None, num_bits_per_symbol=None, constellation=None, return_indices=False,
+                 return_bits=False, seed=None, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+        self._num_bits_per_symbol = constellation.num_bits_per_symbol
+        self._return_indices, self._return_bits = return_indices, return_bits
+        self._binary_source = BinarySource(seed=seed, precision=precision)
+        self._mapper = Mapper(constellation=constellation, return_indices=return_indices, precision=precision)
+
+    def __call__(self, inputs):          # the argument is a shape, not a tensor
+        return super().__call__(tuple(int(s) for s in np.asarray(inputs).reshape(-1)))
+
+    def _convert_to_tensor(self, v):
+        return v
+
+    def call(self, inputs):
+        b = self._binary_source(tuple(inputs) + (self._num_bits_per_symbol,))
+        if self._return_indices:
+            x, ind = self._mapper(b)
+        else:
+            x = self._mapper(b)
+        result = x.squeeze(-1)
+        if self._return_indices or self._return_bits:
+            result = [result]
+        if self._return_indices:
+            result.append(ind.squeeze(-1))
+        if self._return_bits:
+            result.append(b)
+        return tuple(result) if isinstance(result, list) else result
+
+
+class QAMSource(SymbolSource):
+    """``QAMSource(num_bits_per_symbol, return_indices=False, return_bits=False, seed=None)`` (:1452-1514)."""
+
+    def __init__(self, num_bits_per_symbol=None, return_indices=False, return_bits=False, seed=None, precision=None,
+                 **kwargs):
+        super().__init__(constellation_type="qam", num_bits_per_symbol=num_bits_per_symbol, return_indices=return_indices,
+                         return_bits=return_bits, seed=seed, precision=precision, **kwargs)
+
+
+class PAMSource(SymbolSource):
+    """``PAMSource(num_bits_per_symbol, return_indices=False, return_bits=False, seed=None)`` (:1516-1576)."""
+
+    def __init__(self, num_bits_per_symbol=None, return_indices=False, return_bits=False, seed=None, precision=None,
+                 **kwargs):
+        super().__init__(constellation_type="pam", num_bits_per_symbol=num_bits_per_symbol, return_indices=return_indices,
+                         return_bits=return_bits, seed=seed, precision=precision, **kwargs)

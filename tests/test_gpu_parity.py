@@ -199,6 +199,22 @@ def test_big_degree_fallback(phy):
             _close(x, xr, "bigdeg phi")
 
 
+def test_symbol_sources(phy):
+    phy.config.seed = 5
+    x, ind, b = phy.mapping.QAMSource(4, return_indices=True, return_bits=True)([3, 50])
+    pts = omap.qam(4)
+    assert tuple(x.shape) == (3, 50) and tuple(b.shape) == (3, 50, 4)
+    assert np.array_equal(_np(ind), (_np(b) * [8, 4, 2, 1]).sum(-1).astype(np.int32))
+    assert np.allclose(_np(x), pts[_np(ind)])
+    assert np.array_equal(_np(b), outil.random_bits(5, 0, 600).reshape(3, 50, 4))
+    y = _np(phy.mapping.QAMSource(2, seed=7)([1000]))
+    assert y.shape == (1000,) and np.allclose(np.abs(y), 1.0, atol=1e-6) and abs(y.mean()) < 0.1
+    z = _np(phy.mapping.PAMSource(2)([4, 8]))
+    assert np.allclose(z.imag, 0) and set(np.round(np.unique(z.real) * np.sqrt(5), 3)) <= {-3.0, -1.0, 1.0, 3.0}
+    custom = phy.mapping.Constellation("custom", 1, points=np.array([1j, -1j]))
+    assert set(np.unique(_np(phy.mapping.SymbolSource(constellation=custom)([64])))) <= {1j, -1j}
+
+
 # ------------------------------------------------------------------ CN schedules (layered decoding)
 def test_scheduling_independent_checks(phy):
     """Reference test_ldpc_decoding.py:121-160."""
