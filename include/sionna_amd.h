@@ -349,11 +349,15 @@ int samd_polar_encode_f32(const float* u, const int32_t* info_pos, const int32_t
  * build_schedule: op | stage<<3 | side<<7 | (bit_index+2048)<<8); info_pos
  * DEVICE int32[k]; iil_inv nullable DEVICE int32[k] (inverse input interleaver applied before the
  * CRC check); sc_mode=1 -> hard SC decisions (list_size must be 1); crc_len=0 disables the
- * CRC-aided selection.  u_hat [batch,k]; crc_status nullable [batch]. */
+ * CRC-aided selection.  u_hat [batch,k]; crc_status nullable [batch].  workspace: caller-owned
+ * device scratch of samd_polar_scl_workspace_bytes() bytes (top LLR stage of the resident
+ * codewords; it lives in L2 so that more codewords fit in LDS). */
+size_t samd_polar_scl_workspace_bytes(int batch, int n, int list_size);
 int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
                               const int32_t* iil_inv, int batch, int n, int k, int list_size,
                               int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat,
-                              float* crc_status, void* stream);
+                              float* crc_status, void* workspace, size_t workspace_bytes,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Error counting  utils/metrics.py:94-144 (count_errors, count_block_errors).

@@ -99,23 +99,41 @@ struct SclArgs {
   int num_ops;
   const int32_t* info_pos; // [k]
   const int32_t* iil_inv;  // nullable [k] inverse input interleaver applied before the CRC check
+  float* gscratch;         // [grid][L][n - n/2^G] the G top LLR stages of every slot: touched by a handful
+                           // of ops per decode, kept in L2 instead of LDS so that more codewords fit on a CU
+  unsigned char* gbeta;    // [grid][L][n - n/2^G] partial sums of the same top stages
+  int gstages;             // G
   int batch, n, m, k, L, sc_mode, crc_len;
   uint32_t crc_poly;
 };
 
 // NT = threads per workgroup: 64 (one wave per codeword: the hardware barrier of a single-wave
 // workgroup is free, which is what the ~14k dependent steps per codeword want) or 256.
+// The decoder is a latency-bound dependent chain (measured ~10 cycles per wave instruction with one
+// resident wave per SIMD), so throughput scales with the number of codewords resident on a CU.  Only
+// the state that is touched by (almost) every op stays in LDS - the low LLR / partial-sum stages,
+// the decided bits and the path bookkeeping (~4 KB at n = 1024, L = 8); the top G stages, touched by
+// 2^(G+1) ops per decode, and the channel LLRs live in L2: 32 instead of 2 codewords per CU
+// (measured on MI355X, n=1024 k=512 L=8: 137k -> 642k decodes/s).
 template <int NT>
 __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = p.n, L = p.L, tid = threadIdx.x;
   const int words = (n + 31) / 32;
-  float* llr_ch = smem;                                   // [n]
-  float* llr = llr_ch + n;                                // [L][n]   stage s at [2^s, 2^(s+1))
+  float* llr = smem;                                      // [L][n/2^G] stage s < m-G at [2^s, 2^(s+1))
+  const int hn = n >> p.gstages;
+  auto stage = [&](int slot, int s) -> float* {           // the 2^s LLRs of stage s held by `slot`
+    if (s >= p.m - p.gstages) return p.gscratch + ((size_t)blockIdx.x * L + slot) * (n - hn) + ((1 << s) - hn);
+    return llr + (size_t)slot * hn + (1 << s);
+  };
   // partial sums: ONE byte per (slot, stage position), bit 0 = left child's result, bit 1 = right
   // child's (halves the LDS of two byte banks: 3 instead of 2 codewords per CU at n = 1024, L = 8)
-  unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * n);    // [L][n]
-  uint32_t* bits = reinterpret_cast<uint32_t*>(beta + (size_t)L * n);             // [L][words] decided u bits
+  unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * hn);   // [L][n/2^G] (+ top stages in gbeta)
+  auto bstage = [&](int slot, int s) -> unsigned char* {  // the 2^s partial-sum bytes of stage s held by `slot`
+    if (s >= p.m - p.gstages) return p.gbeta + ((size_t)blockIdx.x * L + slot) * (n - hn) + ((1 << s) - hn);
+    return beta + (size_t)slot * hn + (1 << s);
+  };
+  uint32_t* bits = reinterpret_cast<uint32_t*>(beta + (size_t)L * hn);            // [L][words] decided u bits
   float* pm = reinterpret_cast<float*>(bits + (size_t)L * words);                 // [L]   by position
   float* cand = pm + L;                                   // [2L] candidate metrics
   float* blk = cand + 2 * L;                              // [2L] block metrics (rate-0 / rep)
@@ -137,7 +155,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   // the schedule is read with scalar loads one op ahead (wave-uniform index): no LDS copy
 
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
-    for (int i = tid; i < n; i += NT) llr_ch[i] = -1.f * p.llr_in[(size_t)b * n + i];   // logits -> LLR
+    const float* llr_ch = p.llr_in + (size_t)b * n;       // logits: negated where they are read (LLR = -logit)
     for (int i = tid; i < L * words; i += NT) bits[i] = 0u;
     for (int i = tid; i < L * 16; i += NT) { lp[i] = (unsigned char)(i >> 4); bl[i] = lp[i]; br[i] = lp[i]; }
     if (tid < L) { pm[tid] = tid == 0 ? 0.f : kPolarLlrMax; order[tid] = tid; }         // decoding.py:1029-1033
@@ -155,12 +173,13 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         for (int w = tid; w < L * half; w += NT) {
           const int pos = w / half, j = w - pos * half;
           const int slot = order[pos];
-          const float* in = (s == p.m) ? llr_ch : (llr + (size_t)lp[slot * 16 + s] * n + (1 << s));
-          const float x = in[j], y = in[j + half];
+          const float* in = (s == p.m) ? llr_ch : stage(lp[slot * 16 + s], s);
+          const float sg = (s == p.m) ? -1.f : 1.f;
+          const float x = sg * in[j], y = sg * in[j + half];
           float r;
           if (op == OP_F) r = cn_op(x, y);
-          else r = (1.f - 2.f * (float)(beta[(size_t)bl[slot * 16 + s - 1] * n + half + j] & 1)) * x + y;  // vn_op :707-714
-          llr[(size_t)slot * n + half + j] = r;
+          else r = (1.f - 2.f * (float)(bstage(bl[slot * 16 + s - 1], s - 1)[j] & 1)) * x + y;  // vn_op :707-714
+          stage(slot, s - 1)[j] = r;
         }
         if (tid < L) lp[order[tid] * 16 + s - 1] = (unsigned char)order[tid];
         __syncthreads();
@@ -170,9 +189,9 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         for (int w = tid; w < L * sz; w += NT) {
           const int pos = w / sz, j = w - pos * sz;
           const int slot = order[pos];
-          const unsigned char l = beta[(size_t)bl[slot * 16 + s] * n + sz + j] & 1;
-          const unsigned char r = (beta[(size_t)br[slot * 16 + s] * n + sz + j] >> 1) & 1;
-          unsigned char* dst = beta + (size_t)slot * n + 2 * sz;
+          const unsigned char l = bstage(bl[slot * 16 + s], s)[j] & 1;
+          const unsigned char r = (bstage(br[slot * 16 + s], s)[j] >> 1) & 1;
+          unsigned char* dst = bstage(slot, s + 1);
           const unsigned char keep = a1 ? 1 : 2;                    // the other side's bit stays
           dst[j] = (dst[j] & keep) | (unsigned char)((l ^ r) << a1);
           dst[sz + j] = (dst[sz + j] & keep) | (unsigned char)(r << a1);
@@ -187,17 +206,17 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         // block metrics of every live path: m0 = sum softplus(-l), m1 = sum softplus(+l)
         if (sz == 1) {
           if (tid < L) {                                      // one lane per path
-            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)lp[order[tid] * 16 + s] * n + sz);
-            const float l = clampf(in[0], -kPolarLlrMax, kPolarLlrMax);
+            const float* in = (s == p.m) ? llr_ch : stage(lp[order[tid] * 16 + s], s);
+            const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[0], -kPolarLlrMax, kPolarLlrMax);
             blk[tid] = softplus(-l);
             blk[L + tid] = softplus(l);
           }
         } else {
           for (int pos = 0; pos < L; ++pos) {
-            const float* in = (s == p.m) ? llr_ch : (llr + (size_t)lp[order[pos] * 16 + s] * n + sz);
+            const float* in = (s == p.m) ? llr_ch : stage(lp[order[pos] * 16 + s], s);
             float m0 = 0.f, m1 = 0.f;
             for (int j = tid; j < sz; j += NT) {
-              const float l = clampf(in[j], -kPolarLlrMax, kPolarLlrMax);
+              const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[j], -kPolarLlrMax, kPolarLlrMax);
               m0 += softplus(-l);
               m1 += softplus(l);
             }
@@ -219,7 +238,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           if (tid < L) pm[tid] += blk[tid];
           for (int w = tid; w < L * sz; w += NT) {
             const int pos = w / sz, j = w - pos * sz;
-            unsigned char* d = beta + (size_t)order[pos] * n + sz + j;
+            unsigned char* d = bstage(order[pos], s) + j;
             *d = *d & (a1 ? 1 : 2);
           }
           if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s] = (unsigned char)order[tid];
@@ -230,7 +249,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         if (p.sc_mode) {
           // PolarSCDecoder leaf: u = 0.5 (1 - sign(l)), exact zero -> 1 (decoding.py:208-212)
           if (tid == 0) {
-            const float l = ((s == p.m) ? llr_ch : (llr + (size_t)lp[order[0] * 16 + s] * n + sz))[0];
+            const float l = ((s == p.m) ? -1.f : 1.f) * ((s == p.m) ? llr_ch : stage(lp[order[0] * 16 + s], s))[0];
             new_order[0] = order[0]; clone_src[0] = -1; new_bit[0] = (l <= 0.f) ? 1 : 0; new_pm[0] = 0.f;
           }
         } else {
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         __syncthreads();
         for (int w = tid; w < L * sz; w += NT) {
           const int pos = w / sz, j = w - pos * sz;
-          unsigned char* d = beta + (size_t)order[pos] * n + sz + j;
+          unsigned char* d = bstage(order[pos], s) + j;
           *d = (*d & (a1 ? 1 : 2)) | (unsigned char)(new_bit[pos] << a1);                          // all-u codeword
         }
         if (tid < L) (a1 ? br : bl)[order[tid] * 16 + s] = (unsigned char)order[tid];
@@ -331,11 +350,31 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   }
 }
 
+static int scl_gstages(int n) {
+  // top LLR stages kept in L2 (SAMD_SCL_GSTAGES overrides: 0..3); never more than log2(n) - 2
+  int m = 0;
+  while ((1 << m) < n) ++m;
+  const char* e = getenv("SAMD_SCL_GSTAGES");
+  int g = e ? atoi(e) : 5;
+  return std::max(0, std::min(g, std::min(5, m - 2)));
+}
+
 static size_t scl_lds_bytes(int n, int L, int num_ops) {
   const size_t words = (n + 31) / 32;
   (void)num_ops;
-  return (size_t)n * 4 + (size_t)L * n * 4 + (size_t)L * n + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
+  return (size_t)L * (n >> scl_gstages(n)) * 5 + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
          (size_t)L * 4 * 5 + 256 * 4 + 3 * (size_t)L * 16 + 64;
+}
+
+static int scl_grid(int batch, int n, int L) {
+  const size_t lds = scl_lds_bytes(n, L, 0);
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const char* e = getenv("SAMD_SCL_PER_CU");
+  const size_t cap = e ? (size_t)std::max(1, atoi(e)) : 32;   // one wave per workgroup: 8 per SIMD
+  const size_t per_cu = std::min<size_t>(cap, std::max<size_t>(1, (160 * 1024) / lds));
+  return (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
 }
 
 }  // namespace samd
@@ -360,11 +399,21 @@ extern "C" int samd_polar_encode_f32(const float* u, const int32_t* info_pos, co
   return launch_status();
 }
 
+extern "C" size_t samd_polar_scl_workspace_bytes(int batch, int n, int list_size) {
+  if (batch <= 0 || n < 8 || list_size < 1) return 0;
+  // float + byte scratch of the top stages: n - n/2^G entries per slot, rounded up to n
+  return (size_t)scl_grid(batch, n, list_size) * list_size * (size_t)n * (sizeof(float) + 1) + 512;
+}
+
 extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
                                          const int32_t* iil_inv, int batch, int n, int k, int list_size, int sc_mode,
                                          uint32_t crc_poly, int crc_len, float* u_hat, float* crc_status,
-                                         void* stream) {
+                                         void* workspace, size_t workspace_bytes, void* stream) {
   SAMD_REQUIRE(llr && ops && info_pos && u_hat && batch > 0, "bad argument");
+  if (!workspace || workspace_bytes < samd_polar_scl_workspace_bytes(batch, n, list_size)) {
+    set_error("workspace too small");
+    return SAMD_ERR_WORKSPACE;
+  }
   SAMD_REQUIRE(n >= 8 && (n & (n - 1)) == 0 && k >= 0 && k <= n, "n must be a power of two >= 8, 0 <= k <= n");
   SAMD_REQUIRE(list_size >= 1 && list_size <= 32 && (list_size & (list_size - 1)) == 0, "list_size must be a power of two <= 32");
   SAMD_REQUIRE(num_ops > 0 && n <= 1024, "schedule missing or n > 1024");
@@ -381,12 +430,11 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   }
   int m = 0;
   while ((1 << m) < n) ++m;
-  SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, batch, n, m, k, list_size, sc_mode, crc_len, crc_poly};
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const size_t per_cu = std::min<size_t>(8, std::max<size_t>(1, (160 * 1024) / lds));
-  const int grid = (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+  const int grid = scl_grid(batch, n, list_size);
+  float* gs = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
+  unsigned char* gb = reinterpret_cast<unsigned char*>(gs + (size_t)grid * list_size * n);
+  SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n), batch, n, m, k, list_size,
+            sc_mode, crc_len, crc_poly};
   const char* nt_env = getenv("SAMD_SCL_THREADS");
   if (nt_env && atoi(nt_env) == 256) hipLaunchKernelGGL(polar_scl_kernel<256>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);

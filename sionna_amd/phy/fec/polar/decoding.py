@@ -109,10 +109,13 @@ class _PolarListDecoderBase(Block):
         u_hat = torch.empty((b, self._k), dtype=torch.float32, device=llr.device)
         status = torch.empty((b,), dtype=torch.float32, device=llr.device) if want_status else None
         if b > 0:
+            if getattr(self, "_ws", None) is None:
+                self._ws = _ffi.Workspace()
+            ws, ws_bytes = self._ws.get(_ffi.lib().samd_polar_scl_workspace_bytes(b, self._n, self._list_size))
             _ffi.check(_ffi.lib().samd_polar_scl_decode_f32(
                 _ffi.ptr(llr), _ffi.ptr(ops), ops.numel(), _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size,
-                self._sc_mode, self._crc_mask, self._crc_len, _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.stream()),
-                type(self).__name__)
+                self._sc_mode, self._crc_mask, self._crc_len, _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.ptr(ws), ws_bytes,
+                _ffi.stream()), type(self).__name__)
         return u_hat, status
 
     def build(self, input_shape):
