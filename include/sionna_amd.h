@@ -203,6 +203,28 @@ int samd_tdl_cir_c64(uint64_t seed, uint64_t call, int batch, int num_rx_ant, in
                      float max_doppler, int los, float los_power, float los_aoa, float* a,
                      void* stream);
 
+/* CDL.__call__  channel/tr38901/cdl.py:258-333 + ChannelCoefficientsGenerator (TR 38.901 Sec. 7.5
+ * steps 10-11, no sub-clustering)  channel/tr38901/channel_coefficients.py:173-194, 459-1031.
+ * Model / array / orientation dependent factors are tabulated by the host for the 20 x 20 (zenith
+ * ray, azimuth ray) pairs of every cluster (index ((n*20 + zenith)*20 + azimuth)); all DEVICE:
+ *   f_rx, f_tx  float [N][20][20][2 pol][2]   GCS field (F_theta, F_phi) per polarisation
+ *   a_rx / a_tx complex64 [N][20][20][ant]    array responses exp(j 2 pi r.d / lambda)
+ *   r_rx        float [N][20][20][3]          arrival unit vectors (Doppler)
+ *   pol_rx/tx   int32 [ant] polarisation index; order int32 [N] cluster of output tap n (ascending
+ *   delay); amp float [N] sqrt(P_n/20) (x sqrt(1/(K+1)) with a LoS path)
+ *   los         nullable float [8 + 2U + 2S + 4]: f_rx[2][2], f_tx[2][2], a_rx[U] c64, a_tx[S] c64,
+ *               r_rx[3], sqrt(K/(K+1)) of the specular path added to tap 0
+ * Random part on the Philox stream (seed, call .. call+7), layout: oracle/cdl.py.
+ * -> a [batch, num_rx_ant, num_tx_ant, N, num_time_steps] complex64. */
+size_t samd_cdl_workspace_bytes(int batch, int num_clusters);
+int samd_cdl_cir_c64(uint64_t seed, uint64_t call, int batch, int num_clusters, int num_rx_ant,
+                     int num_tx_ant, int num_time_steps, float sampling_frequency, const float* f_rx,
+                     const float* f_tx, const float* a_rx, const float* a_tx, const float* r_rx,
+                     const int32_t* pol_rx, const int32_t* pol_tx, const int32_t* order,
+                     const float* amp, const float* los, float xpr_scale, float two_pi_over_lambda,
+                     float min_speed, float max_speed, void* workspace, size_t workspace_bytes,
+                     float* a, void* stream);
+
 /* cir_to_ofdm_channel  channel/utils.py:180-253.  a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P],
  * frequencies DEVICE float[F] -> h_freq [B,rx,ra,tx,ta,T,F]; normalize: unit mean energy over
  * (ra,ta,T,F) per (b,rx,tx). */

@@ -82,3 +82,16 @@ for i in range(len(ex)):
 np.savez_compressed(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                  "sionna_amd/phy/fec/ldpc/codes/example_pcms.npz"), **pk)
 print("example pcms:", [tuple(pk[f"shape_{i}"]) for i in range(len(ex))])
+
+# ---- CDL cluster tables (3GPP TR 38.901 Tables 7.7.1-1..5), shipped by the reference as
+# channel/tr38901/models/CDL-*.json (parsed at channel/tr38901/cdl.py:385-555).  Re-packed into one JSON.
+cdl = {}
+for name in "ABCDE":
+    with open(os.path.join(mdir, f"CDL-{name}.json")) as f:
+        p = json.load(f)
+    cdl[name] = {k: (int(p[k]) if k in ("los", "num_clusters") else
+                     ([float(v) for v in p[k]] if isinstance(p[k], list) else float(p[k]))) for k in p}
+dst = os.path.join(os.path.dirname(__file__), "..", "sionna_amd/phy/channel/tr38901/cdl_models.json")
+with open(dst, "w") as f:
+    json.dump(cdl, f, indent=0)
+print("wrote", os.path.normpath(dst))
