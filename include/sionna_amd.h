@@ -266,6 +266,24 @@ int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const float* err_
 int samd_gf2_encode_f32(const float* u, const uint32_t* gm_cols, int64_t batch, int k, int n,
                         float* out, void* stream);
 
+/* EPDetector.call  mimo/detection.py:1229-1312, output="bit" (expectation propagation, l iterations,
+ * damping beta): y [n,m], h [n,m,k], s [n,m,m] -> out [n,k,num_bits_per_symbol] max-log LLRs.
+ * pam_points DEVICE float[2^(num_bits_per_symbol/2)]: unit-energy Gray PAM points / sqrt(2) in label
+ * order; es = their variance; prec = numerical floor (1e-6 in single precision). */
+int samd_ep_f32(const float* y, const float* h, const float* s, const float* pam_points, int64_t n,
+                int m, int k, int num_bits_per_symbol, int l, float beta, float es, float prec,
+                int hard_out, float* out, void* stream);
+
+/* ofdm.EPDetector.call  ofdm/detection.py (OFDMDetector pre-processing + the detector above).
+ * out [batch, num_streams_total, num_data * num_bits_per_symbol]. */
+int samd_ofdm_ep_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode,
+                     const float* no, const float* pam_points, const int32_t* sc_ind,
+                     const int32_t* desired, const int32_t* undesired, const int32_t* data_pos, int batch,
+                     int num_rx, int num_rx_ant, int num_streams_total, int streams_per_rx,
+                     int num_undesired, int num_ofdm_symbols, int num_eff_subcarriers, int fft_size,
+                     int num_data, int num_bits_per_symbol, int l, float beta, float es, float prec,
+                     int hard_out, float* out, void* stream);
+
 /* ---- scrambling --------------------------------------------------- */
 
 /* Scrambler.call fec/scrambling.py:186-261 / TB5GScrambler.call :442-468:

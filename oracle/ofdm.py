@@ -599,3 +599,64 @@ def ls_estimate_lin(rg, y, no, time_avg=False):
     h_p, ev_p = ls_estimate(rg, y, no, interpolation=None)
     h, ev = LinearInterpolator(rg.pilot_pattern, time_avg)(h_p, np.broadcast_to(ev_p, h_p.shape))
     return h, np.maximum(ev, 0)
+
+
+# ------------------------------------------------------------------ EP detector
+def _pam_points_over_sqrt2(nbh):
+    """Unit-energy Gray PAM points in label order / sqrt(2) (mimo/detection.py:1157-1163, mapping.py:15-42, 120-192)."""
+    pts = np.zeros(2 ** nbh)
+    for i in range(2 ** nbh):
+        b = [(i >> (nbh - 1 - j)) & 1 for j in range(nbh)]
+        def gray(b):                                    # mapping.py:15-42
+            return 1 - 2 * b[0] if len(b) == 1 else (1 - 2 * b[0]) * (2 ** (len(b) - 1) - gray(b[1:]))
+        pts[i] = gray(b)
+    pts = pts / np.sqrt(np.mean(pts ** 2))
+    return pts / np.sqrt(2.0)
+
+
+def ep_detector(y, h, s, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, prec=1e-6):
+    """EPDetector.call, output="bit" (mimo/detection.py:1166-1312) in float64.
+    y [...,M], h [...,M,K], s [...,M,M] -> max-log LLRs [...,K,num_bits_per_symbol]."""
+    nbh = num_bits_per_symbol // 2
+    pts = _pam_points_over_sqrt2(nbh)
+    es = np.var(pts)
+    y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
+    l_inv = np.linalg.inv(np.linalg.cholesky(s))
+    y = (l_inv @ y[..., None])[..., 0]
+    h = l_inv @ h
+    K = h.shape[-1]
+    yr = np.concatenate([y.real, y.imag], -1)
+    hr = np.concatenate([np.concatenate([h.real, -h.imag], -1), np.concatenate([h.imag, h.real], -1)], -2)
+    no = 0.5
+    hth = np.swapaxes(hr, -1, -2) @ hr
+    hty = (np.swapaxes(hr, -1, -2) @ yr[..., None])[..., 0]
+    lam = np.ones(hty.shape) / es
+    gam = np.zeros(hty.shape)
+    eye = np.eye(2 * K)
+    for _ in range(l):
+        sig_full = np.linalg.inv(hth + no * lam[..., None] * eye)
+        mu = (sig_full @ (hty + no * gam)[..., None])[..., 0]
+        sigma = no * np.diagonal(sig_full, axis1=-2, axis2=-1)
+        v_obs = np.maximum(1 / (1 / sigma - lam), prec)
+        x_obs = v_obs * (mu / sigma - gam)
+        logits = -(x_obs[..., None] - pts) ** 2 / (2 * v_obs[..., None])
+        pmf = np.exp(logits - logits.max(-1, keepdims=True))
+        pmf /= pmf.sum(-1, keepdims=True)
+        x = np.sum(pts * pmf, -1)
+        v = np.maximum(np.sum((pts - x[..., None]) ** 2 * pmf, -1), prec)
+        lam_n, gam_n = 1 / v - 1 / v_obs, x / v - x_obs / v_obs
+        keep = lam_n < 0
+        lam_n, gam_n = np.where(keep, lam, lam_n), np.where(keep, gam, gam_n)
+        lam, gam = (1 - beta) * lam_n + beta * lam, (1 - beta) * gam_n + beta * gam
+    lab = _bit_labels(nbh).T.astype(bool)                                          # [nbh, P]
+    llr = np.stack([logits[..., lab[b]].max(-1) - logits[..., ~lab[b]].max(-1) for b in range(nbh)], -1)   # [..., 2K, nbh]
+    llr = np.stack([llr[..., :K, :], llr[..., K:, :]], -1).reshape(llr.shape[:-2] + (K, 2 * nbh))
+    return (llr > 0).astype(np.float32) if hard_out else llr.astype(np.float32)
+
+
+def ofdm_ep_detector(rg, sm, y, h_hat, err_var, no, num_bits_per_symbol, l=10, beta=0.9, hard_out=False):
+    """ofdm.EPDetector.call, output="bit" -> [B,tx,streams,num_data*num_bits_per_symbol]."""
+    y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
+    llr = ep_detector(y_dt, hd, s, num_bits_per_symbol, l, beta, hard_out)
+    out = _extract_data(rg, sm, llr, y.shape[0])
+    return out.reshape(out.shape[:3] + (-1,))

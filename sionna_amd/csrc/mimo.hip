@@ -437,6 +437,171 @@ __device__ void mmse_pic_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], floa
     }
 }
 
+// ------------------------------------------------------------------ EP detector
+// EPDetector.call  mimo/detection.py:1229-1312 (expectation propagation of [EP2014], bit output):
+// whitening, real-valued decomposition (2M x 2K, noise variance 1/2 per real dimension), l iterations
+// of (28)-(38) with damping beta on PAM symbols, then max-log LLRs of the I and Q bit halves.
+struct EpParams {
+  const float* pam;       // [2^nbh] PAM points / sqrt(2) in label order
+  int nbh, l, hard_out;   // bits per real dimension, iterations
+  float beta, es, prec;   // damping, variance of the PAM points, numerical floor
+};
+
+template <int M, int K>
+__device__ void ep_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&llr)[K][kMaxBits], const EpParams& q) {
+  constexpr int N2 = 2 * K;
+  const int P = 1 << q.nbh;
+  cholesky<M>(s);                                             // whiten_channel
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    c32 v = y[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v = v - s[i][k] * y[k];
+    y[i] = scale(v, 1.f / s[i][i].re);
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      c32 w = h[i][c];
+#pragma unroll
+      for (int k = 0; k < i; ++k) w = w - s[i][k] * h[k][c];
+      h[i][c] = scale(w, 1.f / s[i][i].re);
+    }
+  }
+  // H_r^T H_r and H_r^T y_r from the complex Gramian / matched filter
+  float hth[N2][N2], hty[N2];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    c32 mf = C(0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) mf = mf + mulc(y[m], h[m][k]);
+    hty[k] = mf.re; hty[K + k] = mf.im;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      c32 g = C(0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < M; ++m) g = g + mulc(h[m][j], h[m][k]);          // conj(h[m][k]) h[m][j]
+      hth[k][j] = g.re; hth[k][K + j] = -g.im; hth[K + k][j] = g.im; hth[K + k][K + j] = g.re;
+    }
+  }
+  const float no = 0.5f;
+  float lam[N2], gam[N2], xo[N2], vo[N2];
+#pragma unroll
+  for (int r = 0; r < N2; ++r) { lam[r] = 1.f / q.es; gam[r] = 0.f; xo[r] = 0.f; vo[r] = 1.f; }
+  for (int it = 0; it < q.l; ++it) {
+    float a[N2][N2], ai[N2][N2];
+#pragma unroll
+    for (int r = 0; r < N2; ++r)
+#pragma unroll
+      for (int c = 0; c < N2; ++c) { a[r][c] = hth[r][c] + (r == c ? no * lam[r] : 0.f); ai[r][c] = r == c ? 1.f : 0.f; }
+    for (int c = 0; c < N2; ++c) {                             // Gauss-Jordan with partial pivoting
+      int piv = c;
+      float best = fabsf(a[c][c]);
+      for (int r = c + 1; r < N2; ++r)
+        if (fabsf(a[r][c]) > best) { best = fabsf(a[r][c]); piv = r; }
+      if (piv != c)
+        for (int j = 0; j < N2; ++j) {
+          float t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t;
+          t = ai[c][j]; ai[c][j] = ai[piv][j]; ai[piv][j] = t;
+        }
+      const float inv = 1.f / a[c][c];
+      for (int j = 0; j < N2; ++j) { a[c][j] *= inv; ai[c][j] *= inv; }
+      for (int r = 0; r < N2; ++r)
+        if (r != c) {
+          const float fct = a[r][c];
+          for (int j = 0; j < N2; ++j) { a[r][j] -= fct * a[c][j]; ai[r][j] -= fct * ai[c][j]; }
+        }
+    }
+    float mu_all[N2];
+    for (int r = 0; r < N2; ++r) {                             // (29) with the multipliers of the previous iteration
+      float mu = 0.f;
+      for (int c = 0; c < N2; ++c) mu += ai[r][c] * (hty[c] + no * gam[c]);
+      mu_all[r] = mu;
+    }
+    for (int r = 0; r < N2; ++r) {
+      const float mu = mu_all[r];
+      const float sigma = no * ai[r][r];                                               // (28)
+      const float v_obs = fmaxf(1.f / (1.f / sigma - lam[r]), q.prec);                 // (31)
+      const float x_obs = v_obs * (mu / sigma - gam[r]);                               // (32)
+      float mx = -INFINITY;
+      for (int p = 0; p < P; ++p) { const float d = x_obs - q.pam[p]; mx = fmaxf(mx, -(d * d) / (2.f * v_obs)); }
+      float den = 0.f, x = 0.f;
+      for (int p = 0; p < P; ++p) {
+        const float d = x_obs - q.pam[p];
+        const float e = expf(-(d * d) / (2.f * v_obs) - mx);
+        den += e; x += e * q.pam[p];
+      }
+      x /= den;
+      float v = 0.f;
+      for (int p = 0; p < P; ++p) {
+        const float d = x_obs - q.pam[p];
+        const float dd = q.pam[p] - x;
+        v += dd * dd * (expf(-(d * d) / (2.f * v_obs) - mx) / den);
+      }
+      v = fmaxf(v, q.prec);                                                            // (33)
+      const float ln = 1.f / v - 1.f / v_obs, gn = x / v - x_obs / v_obs;              // (35), (36)
+      const float l_new = ln < 0.f ? lam[r] : ln, g_new = ln < 0.f ? gam[r] : gn;
+      lam[r] = (1.f - q.beta) * l_new + q.beta * lam[r];                               // (37), (38)
+      gam[r] = (1.f - q.beta) * g_new + q.beta * gam[r];
+      xo[r] = x_obs; vo[r] = v_obs;
+    }
+  }
+  // max-log LLRs of the PAM logits of the last iteration; bit order: I and Q bits interleaved
+  for (int k = 0; k < K; ++k)
+    for (int half = 0; half < 2; ++half) {
+      const int r = half * K + k;
+      for (int b = 0; b < q.nbh; ++b) {
+        float m1 = -INFINITY, m0 = -INFINITY;
+        for (int p = 0; p < P; ++p) {
+          const float d = xo[r] - q.pam[p];
+          const float lg = -(d * d) / (2.f * vo[r]);
+          if ((p >> (q.nbh - 1 - b)) & 1) m1 = fmaxf(m1, lg); else m0 = fmaxf(m0, lg);
+        }
+        const float e = m1 - m0;
+        llr[k][2 * b + half] = q.hard_out ? (e > 0.f ? 1.f : 0.f) : e;
+      }
+    }
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(64) void ep_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                      const float2* __restrict__ s, int64_t n, EpParams q,
+                                                      float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  c32 yy[M], hh[M][K], ss[M][M];
+  float llr[K][kMaxBits];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    yy[m] = C(y[i * M + m].x, y[i * M + m].y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float2 v = h[(i * M + m) * K + k]; hh[m][k] = C(v.x, v.y); }
+#pragma unroll
+    for (int j = 0; j < M; ++j) { const float2 v = s[(i * M + m) * M + j]; ss[m][j] = C(v.x, v.y); }
+  }
+  ep_solve<M, K>(yy, hh, ss, llr, q);
+  const int nb = 2 * q.nbh;
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < nb; ++b) out[(i * K + k) * nb + b] = llr[k][b];
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(64) void ofdm_ep_kernel(OfdmEqArgs p, EpParams q, float* __restrict__ out) {
+  const int64_t total = (int64_t)p.B * p.RX * p.T * p.F;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int dpos[K], rx;
+  int64_t b;
+  c32 y[M], h[M][K], s[M][M];
+  if (!load_re<M, K>(p, i, y, h, s, dpos, b, rx)) return;
+  float llr[K][kMaxBits];
+  ep_solve<M, K>(y, h, s, llr, q);
+  const int nb = 2 * q.nbh;
+  for (int k = 0; k < K; ++k)
+    if (dpos[k] >= 0) {
+      const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * nb;
+      for (int bb = 0; bb < nb; ++bb) out[o + bb] = llr[k][bb];
+    }
+}
+
 // ---- standalone detector on n problems: y [n,M], h [n,M,K], s [n,M,M], prior [n,K,nb] -> out [n,K,nb]
 template <int M, int K>
 __global__ __launch_bounds__(64) void mmse_pic_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
@@ -581,5 +746,56 @@ extern "C" int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const 
   SAMD_MK_LIST(X)
 #undef X
   set_error("ofdm_mmse_pic: unsupported (num_rx_ant, streams_per_rx) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_ep_f32(const float* y, const float* h, const float* s, const float* pam_points, int64_t n, int m,
+                           int k, int num_bits_per_symbol, int l, float beta, float es, float prec, int hard_out,
+                           float* out, void* stream) {
+  SAMD_REQUIRE(y && h && s && pam_points && out && n >= 0, "bad argument");
+  SAMD_REQUIRE(num_bits_per_symbol >= 2 && num_bits_per_symbol <= kMaxBits && num_bits_per_symbol % 2 == 0 && l >= 1,
+               "bad detector parameters");
+  if (n == 0) return SAMD_OK;
+  const EpParams q{pam_points, num_bits_per_symbol / 2, l, hard_out, beta, es, prec};
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define X(M, K)                                                                                              \
+  if (m == M && k == K) {                                                                                    \
+    hipLaunchKernelGGL((ep_items_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, (const float2*)y,   \
+                       (const float2*)h, (const float2*)s, n, q, out);                                       \
+    return launch_status();                                                                                  \
+  }
+  SAMD_MK_LIST(X)
+#undef X
+  set_error("ep: unsupported (num_rx_ant, num_streams) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_ofdm_ep_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode, const float* no,
+                                const float* pam_points, const int32_t* sc_ind, const int32_t* desired,
+                                const int32_t* undesired, const int32_t* data_pos, int batch, int num_rx,
+                                int num_rx_ant, int num_streams_total, int streams_per_rx, int num_undesired,
+                                int num_ofdm_symbols, int num_eff_subcarriers, int fft_size, int num_data,
+                                int num_bits_per_symbol, int l, float beta, float es, float prec, int hard_out,
+                                float* out, void* stream) {
+  SAMD_REQUIRE(y && h_hat && no && pam_points && sc_ind && desired && data_pos && out, "null argument");
+  SAMD_REQUIRE(ev_mode >= 0 && ev_mode <= 2 && (ev_mode == 0 || err_var), "bad err_var mode");
+  SAMD_REQUIRE(num_undesired == 0 || undesired, "undesired stream table missing");
+  SAMD_REQUIRE(num_bits_per_symbol >= 2 && num_bits_per_symbol <= kMaxBits && num_bits_per_symbol % 2 == 0 && l >= 1,
+               "bad detector parameters");
+  OfdmEqArgs p{(const float2*)y, (const float2*)h_hat, err_var, no, sc_ind, desired, undesired, data_pos, nullptr,
+               nullptr, batch, num_rx, num_streams_total, num_ofdm_symbols, num_eff_subcarriers, fft_size,
+               num_undesired, num_data, ev_mode, 1};
+  const EpParams q{pam_points, num_bits_per_symbol / 2, l, hard_out, beta, es, prec};
+  const int64_t total = (int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers;
+  if (total == 0) return SAMD_OK;
+  const dim3 grid((unsigned)((total + 63) / 64));
+#define X(M, K)                                                                                       \
+  if (num_rx_ant == M && streams_per_rx == K) {                                                       \
+    hipLaunchKernelGGL((ofdm_ep_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, p, q, out);   \
+    return launch_status();                                                                           \
+  }
+  SAMD_MK_LIST(X)
+#undef X
+  set_error("ofdm_ep: unsupported (num_rx_ant, streams_per_rx) combination");
   return SAMD_ERR_UNSUPPORTED;
 }

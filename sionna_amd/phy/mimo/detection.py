@@ -79,3 +79,48 @@ class MMSEPICDetector(Block):
                                                 _ffi.ptr(pts), y.numel() // m, m, k, nb, maxlog, num_iter, hard,
                                                 _ffi.ptr(out), _ffi.stream()), "MMSEPICDetector")
         return wrap(out)
+
+
+def _pam_points_over_sqrt2(nbh):
+    """Constellation("pam", nbh)() / sqrt(2): the real dimensions of the unit-energy QAM constellation."""
+    from ..mapping import pam
+    return np.asarray(pam(nbh), np.complex128).real / np.sqrt(2.0)
+
+
+class EPDetector(Block):
+    """``EPDetector(output, num_bits_per_symbol, hard_out=False, l=10, beta=0.9)(y, h, s)``: expectation
+    propagation MIMO detector of [EP2014] for QAM (mimo/detection.py:1039-1312), bit output:
+    y [...,M], h [...,M,K], s [...,M,M] -> LLRs [...,K,num_bits_per_symbol]."""
+
+    def __init__(self, output, num_bits_per_symbol, hard_out=False, l=10, beta=0.9, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        assert output in ("bit", "symbol"), "Unknown output"
+        if output != "bit":
+            raise NotImplementedError("EPDetector: only output='bit' has a HIP path")
+        assert l >= 1, "l must be a positive integer"
+        assert 0.0 <= beta <= 1.0, "beta must be in [0,1]"
+        assert num_bits_per_symbol % 2 == 0, "EPDetector works on QAM constellations"
+        self._output, self._hard_out, self._l, self._beta = output, hard_out, int(l), float(beta)
+        self._num_bits_per_symbol = int(num_bits_per_symbol)
+        self._points = _pam_points_over_sqrt2(self._num_bits_per_symbol // 2)
+        self._es = float(np.var(self._points))
+        self._prec = 1e-6
+
+    def _kernel_params(self):
+        pam = _ffi.to_device(self._points.astype(np.float32), torch.float32)
+        return pam, self._num_bits_per_symbol, self._l, self._beta, self._es, self._prec, int(bool(self._hard_out))
+
+    def call(self, y, h, s):
+        self._require_single()
+        y = _ffi.to_device(y, torch.complex64)
+        h = _ffi.to_device(h, torch.complex64)
+        s = _ffi.to_device(s, torch.complex64)
+        m, k = h.shape[-2], h.shape[-1]
+        lead = tuple(h.shape[:-2])
+        pam, nb, l, beta, es, prec, hard = self._kernel_params()
+        y = torch.broadcast_to(y, lead + (m,)).contiguous()
+        s = torch.broadcast_to(s, lead + (m, m)).contiguous()
+        out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
+        _ffi.check(_ffi.lib().samd_ep_f32(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), _ffi.ptr(pam), y.numel() // m, m, k,
+                                          nb, l, beta, es, prec, hard, _ffi.ptr(out), _ffi.stream()), "EPDetector")
+        return wrap(out)

@@ -62,3 +62,28 @@ class MMSEPICDetector(Block):
         _ffi.check(_ffi.lib().samd_ofdm_mmse_pic_f32(*head, _ffi.ptr(prior), _ffi.ptr(pts), *tabs, *dims, nb, maxlog, num_iter,
                                                      hard, _ffi.ptr(out), _ffi.stream()), "ofdm.MMSEPICDetector")
         return wrap(out)
+
+
+class EPDetector(Block):
+    """``EPDetector(output, resource_grid, stream_management, num_bits_per_symbol, hard_out=False, l=10,
+    beta=0.9)(y, h_hat, err_var, no)`` -> LLRs [batch, num_tx, num_streams, num_data_symbols *
+    num_bits_per_symbol] (ofdm/detection.py EPDetector on OFDMDetector :198-317), one fused launch."""
+
+    def __init__(self, output, resource_grid, stream_management, num_bits_per_symbol, hard_out=False, l=10, beta=0.9,
+                 precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        from ..mimo.detection import EPDetector as _MimoEP
+        self._det = _MimoEP(output, num_bits_per_symbol, hard_out, l, beta, precision=precision)
+        self._pre = OFDMEqualizer("lmmse", resource_grid, stream_management, precision=precision)
+        self._rg = resource_grid
+
+    def call(self, y, h_hat, err_var, no):
+        self._require_single()
+        rg = self._rg
+        pam, nb, l, beta, es, prec, hard = self._det._kernel_params()
+        keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
+        out = torch.zeros((dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols * nb), dtype=torch.float32,
+                          device=keep[0].device)
+        _ffi.check(_ffi.lib().samd_ofdm_ep_f32(*head, _ffi.ptr(pam), *tabs, *dims, nb, l, beta, es, prec, hard, _ffi.ptr(out),
+                                               _ffi.stream()), "ofdm.EPDetector")
+        return wrap(out)

@@ -441,3 +441,49 @@ def test_ofdm_mmse_pic_vs_oracle(phy, num_tx, ns, assoc):
     lin = phy.ofdm.LinearDetector("lmmse", "bit", "app", rg, sm, constellation_type="qam", num_bits_per_symbol=nb)
     a, b = _np(det(y, h_hat, np.zeros_like(prior), err_var, 0.3)), _np(lin(y, h_hat, err_var, 0.3))
     assert np.mean(np.isclose(a, b, rtol=2e-3, atol=2e-3)) > 0.995
+
+
+# ------------------------------------------------------------------ EP detector
+@pytest.mark.parametrize("m,k,nb", [(4, 4, 4), (4, 2, 2), (8, 4, 6), (2, 2, 4), (1, 1, 2)])
+def test_mimo_ep_detector_vs_oracle(phy, m, k, nb):
+    rng = np.random.default_rng(m + k + nb)
+    n = 400
+    pts = omap.qam(nb)
+    bits = rng.integers(0, 2, (n, k, nb))
+    x = pts[(bits * (2 ** np.arange(nb - 1, -1, -1))).sum(-1)]
+    h = _cplx(rng, (n, m, k)) / np.sqrt(2)
+    no = 0.05
+    y = ((h @ x[..., None])[..., 0] + np.sqrt(no / 2) * _cplx(rng, (n, m))).astype(np.complex64)
+    a = _cplx(rng, (n, m, m)) * 0.1
+    s = (a @ np.conj(np.swapaxes(a, -1, -2)) + no * np.eye(m)).astype(np.complex64)
+    for l, beta in ((1, 0.9), (10, 0.9), (5, 0.5)):
+        got = _np(phy.mimo.EPDetector("bit", nb, l=l, beta=beta)(y, h, s))
+        ref = o.ep_detector(y, h, s, nb, l=l, beta=beta)
+        assert got.shape == ref.shape == (n, k, nb)
+        # EP iterates a fixed-point map with 1e-6 floors: compare on the scale of the LLRs
+        tol = 2e-2 * (1 + np.abs(ref))
+        assert np.mean(np.abs(got - ref) <= tol) > 0.99, np.max(np.abs(got - ref))
+        assert np.mean((got > 0) == (ref > 0)) > 0.998
+    hard = _np(phy.mimo.EPDetector("bit", nb, hard_out=True)(y, h, s))
+    assert set(np.unique(hard)) <= {0.0, 1.0}
+    if m == k == 4:            # EP beats the linear detector on a square 16-QAM system
+        lin = _np(phy.mimo.LinearDetector("lmmse", "bit", "maxlog", constellation_type="qam", num_bits_per_symbol=nb)(y, h, s))
+        got = _np(phy.mimo.EPDetector("bit", nb)(y, h, s))
+        assert np.mean((got > 0) != bits) < 0.7 * np.mean((lin > 0) != bits)
+    with pytest.raises(NotImplementedError):
+        phy.mimo.EPDetector("symbol", nb)
+
+
+def test_ofdm_ep_detector_vs_oracle(phy):
+    rg, org = _grids(phy, num_tx=2, ns=2, fft=72, guards=(3, 4))
+    assoc = [[1, 0], [0, 1]]
+    sm, osm = phy.mimo.StreamManagement(np.array(assoc), 2), o.StreamManagement(np.array(assoc), 2)
+    rng = np.random.default_rng(3)
+    B, nb = 3, 4
+    y = _cplx(rng, (B, 2, 4, 14, 72))
+    h_hat = _cplx(rng, (B, 2, 4, 2, 2, 14, rg.num_effective_subcarriers))
+    err_var = rng.uniform(0.0, 0.05, (1, 1, 1, 2, 2, 14, rg.num_effective_subcarriers)).astype(np.float32)
+    got = _np(phy.ofdm.EPDetector("bit", rg, sm, nb, l=6)(y, h_hat, err_var, 0.3))
+    ref = o.ofdm_ep_detector(org, osm, y, h_hat, err_var, 0.3, nb, l=6)
+    assert got.shape == ref.shape
+    assert np.mean(np.abs(got - ref) <= 2e-2 * (1 + np.abs(ref))) > 0.99, np.max(np.abs(got - ref))
