@@ -284,6 +284,23 @@ int samd_ofdm_ep_f32(const float* y, const float* h_hat, const float* err_var, i
                      int num_data, int num_bits_per_symbol, int l, float beta, float es, float prec,
                      int hard_out, float* out, void* stream);
 
+/* KBestDetector.call  mimo/detection.py:815-1037 (complex representation) with List2LLRSimple
+ * mimo/utils.py:539-578: y [n,m], h [n,m,k], s [n,m,m] -> out [n,k,num_bits_per_symbol] LLRs clipped to
+ * +-llr_clip (hard_out: bits of the best path).  num_paths = the detector's "k" (<= 64). */
+int samd_kbest_f32(const float* y, const float* h, const float* s, const float* points, int64_t n, int m,
+                   int k, int num_bits_per_symbol, int num_paths, float llr_clip, int hard_out,
+                   float* out, void* stream);
+
+/* ofdm.KBestDetector.call (OFDMDetector pre-processing + the detector above).
+ * out [batch, num_streams_total, num_data * num_bits_per_symbol]. */
+int samd_ofdm_kbest_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode,
+                        const float* no, const float* points, const int32_t* sc_ind,
+                        const int32_t* desired, const int32_t* undesired, const int32_t* data_pos,
+                        int batch, int num_rx, int num_rx_ant, int num_streams_total, int streams_per_rx,
+                        int num_undesired, int num_ofdm_symbols, int num_eff_subcarriers, int fft_size,
+                        int num_data, int num_bits_per_symbol, int num_paths, float llr_clip,
+                        int hard_out, float* out, void* stream);
+
 /* ---- scrambling --------------------------------------------------- */
 
 /* Scrambler.call fec/scrambling.py:186-261 / TB5GScrambler.call :442-468:

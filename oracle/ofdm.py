@@ -660,3 +660,55 @@ def ofdm_ep_detector(rg, sm, y, h_hat, err_var, no, num_bits_per_symbol, l=10, b
     llr = ep_detector(y_dt, hd, s, num_bits_per_symbol, l, beta, hard_out)
     out = _extract_data(rg, sm, llr, y.shape[0])
     return out.reshape(out.shape[:3] + (-1,))
+
+
+# ------------------------------------------------------------------ K-Best detector
+def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0):
+    """KBestDetector.call (complex representation, mimo/detection.py:815-1037) + List2LLRSimple
+    (mimo/utils.py:539-578) in float64: y [n,M], h [n,M,K], s [n,M,M] -> LLRs [n,K,nb]."""
+    y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
+    points = np.asarray(points, np.complex128)
+    P, nb = len(points), int(np.log2(len(points)))
+    n, M, K = h.shape
+    l_inv = np.linalg.inv(np.linalg.cholesky(s))
+    y = (l_inv @ y[..., None])[..., 0]
+    h = l_inv @ h
+    order = np.argsort(-np.sum(np.abs(h) ** 2, axis=1), axis=-1, kind="stable")              # :820-824
+    h = np.take_along_axis(h, order[:, None, :], axis=2)
+    q, r = np.linalg.qr(h)
+    y = (np.conj(np.swapaxes(q, -1, -2)) @ y[..., None])[..., 0]
+    k = min(k, P ** K)
+    dists = np.zeros((n, 1))
+    inds = np.zeros((n, 1, 0), np.int64)
+    for stream in range(K):
+        col = K - 1 - stream
+        npth = dists.shape[1]
+        d = np.repeat(dists, P, axis=1)                                                        # path-major candidates
+        pi = np.concatenate([np.repeat(inds, P, axis=1), np.tile(np.arange(P), npth)[None, :, None].repeat(n, 0)], axis=-1)
+        syms = points[pi]                                                                      # [n, cand, stream+1]
+        rr = r[:, col, col:][:, ::-1]                                                          # reversed like :915
+        d = d + np.abs(y[:, col, None] - np.sum(rr[:, None, :] * syms, axis=-1)) ** 2
+        sel = np.argsort(d, axis=1, kind="stable")[:, :min(k, d.shape[1])]                     # top_k: ties -> lower index
+        dists = np.take_along_axis(d, sel, axis=1)
+        inds = np.take_along_axis(pi, sel[:, :, None], axis=1)
+    inds = inds[:, :, ::-1]                                                                    # sorted-column order
+    unsort = np.argsort(order, axis=-1, kind="stable")
+    inds = np.take_along_axis(inds, unsort[:, None, :], axis=2)                                # original stream order
+    bits = (inds[..., None] >> (nb - 1 - np.arange(nb))) & 1                                   # [n, paths, K, nb]
+    if hard_out:
+        return bits[:, 0].astype(np.float32)
+    dd = dists[:, :, None, None]
+    l0 = np.min(np.where(bits == 0, dd, np.inf), axis=1)
+    l1 = np.min(np.where(bits == 1, dd, np.inf), axis=1)
+    with np.errstate(invalid="ignore"):
+        return np.clip(l0 - l1, -llr_clip, llr_clip).astype(np.float32)
+
+
+def ofdm_kbest_detector(rg, sm, y, h_hat, err_var, no, points, k, hard_out=False):
+    """ofdm.KBestDetector.call, output="bit" -> [B,tx,streams,num_data*nb]."""
+    y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
+    shp = hd.shape[:-2]
+    llr = kbest_detector(y_dt.reshape((-1,) + y_dt.shape[-1:]), hd.reshape((-1,) + hd.shape[-2:]),
+                         s.reshape((-1,) + s.shape[-2:]), points, k, hard_out)
+    out = _extract_data(rg, sm, llr.reshape(shp + llr.shape[-2:]), y.shape[0])
+    return out.reshape(out.shape[:3] + (-1,))

@@ -602,6 +602,174 @@ __global__ __launch_bounds__(64) void ofdm_ep_kernel(OfdmEqArgs p, EpParams q, f
     }
 }
 
+// ------------------------------------------------------------------ K-Best detector
+// KBestDetector.call  mimo/detection.py:815-1037 (complex representation) + List2LLRSimple
+// mimo/utils.py:539-578: whitening, columns sorted by decreasing norm, QR, breadth-first tree search
+// from the last stream keeping the k best partial paths per layer (ascending distance, ties: lower
+// candidate index first), LLRs = clip(min dist over paths with bit 0 - min dist with bit 1, +-20).
+constexpr int kMaxPaths = 64;
+
+struct KBestParams {
+  const float2* points;   // [2^nb]
+  int nb, k, hard_out;
+  float clip;
+};
+
+template <int M, int K>
+__device__ void kbest_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&llr)[K][kMaxBits], const KBestParams& q) {
+  const int P = 1 << q.nb;
+  cholesky<M>(s);                                             // whiten_channel
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    c32 v = y[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v = v - s[i][k] * y[k];
+    y[i] = scale(v, 1.f / s[i][i].re);
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      c32 w = h[i][c];
+#pragma unroll
+      for (int k = 0; k < i; ++k) w = w - s[i][k] * h[k][c];
+      h[i][c] = scale(w, 1.f / s[i][i].re);
+    }
+  }
+  // column order: decreasing norm (stable)
+  float nrm[K];
+  int ord[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float v = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) v += h[m][k].re * h[m][k].re + h[m][k].im * h[m][k].im;
+    nrm[k] = v;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) rank += (nrm[j] > nrm[k] || (nrm[j] == nrm[k] && j < k)) ? 1 : 0;
+    ord[rank] = k;
+  }
+  // QR by modified Gram-Schmidt on the sorted columns: R upper triangular (real positive diagonal), yq = Q^H y
+  c32 qm[M][K], r[K][K], yq[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) qm[m][j] = h[m][ord[j]];
+#pragma unroll
+    for (int i = 0; i < K; ++i) r[i][j] = C(0.f, 0.f);
+    for (int i = 0; i < j; ++i) {
+      c32 d = C(0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < M; ++m) d = d + mulc(qm[m][j], qm[m][i]);        // q_i^H v
+      r[i][j] = d;
+#pragma unroll
+      for (int m = 0; m < M; ++m) qm[m][j] = qm[m][j] - d * qm[m][i];
+    }
+    float nn = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) nn += qm[m][j].re * qm[m][j].re + qm[m][j].im * qm[m][j].im;
+    nn = sqrtf(nn);
+    r[j][j] = C(nn, 0.f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) qm[m][j] = scale(qm[m][j], 1.f / nn);
+    c32 d = C(0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) d = d + mulc(y[m], qm[m][j]);
+    yq[j] = d;
+  }
+  // tree search; path symbol of layer `stream` belongs to sorted column K-1-stream
+  float dist[2][kMaxPaths];
+  unsigned char sym[2][kMaxPaths][K];
+  int np_old = 1, cur = 0;
+  dist[0][0] = 0.f;
+  for (int stream = 0; stream < K; ++stream) {
+    const int col = K - 1 - stream, nxt = cur ^ 1;
+    int np_new = 0;
+    for (int pth = 0; pth < np_old; ++pth) {
+      c32 base = yq[col];                                      // y' - sum over the already decided streams
+      for (int t = 0; t < stream; ++t) {
+        const float2 x = q.points[sym[cur][pth][t]];
+        base = base - r[col][K - 1 - t] * C(x.x, x.y);
+      }
+      for (int c = 0; c < P; ++c) {
+        const float2 x = q.points[c];
+        const c32 e = base - r[col][col] * C(x.x, x.y);
+        const float d = dist[cur][pth] + (e.re * e.re + e.im * e.im);
+        // insertion into the ascending list of the k best (later candidates go behind equal distances)
+        if (np_new < q.k || d < dist[nxt][np_new - 1]) {
+          int pos = np_new < q.k ? np_new : q.k - 1;
+          while (pos > 0 && dist[nxt][pos - 1] > d) {
+            dist[nxt][pos] = dist[nxt][pos - 1];
+            for (int t = 0; t <= stream; ++t) sym[nxt][pos][t] = sym[nxt][pos - 1][t];
+            --pos;
+          }
+          dist[nxt][pos] = d;
+          for (int t = 0; t < stream; ++t) sym[nxt][pos][t] = sym[cur][pth][t];
+          sym[nxt][pos][stream] = (unsigned char)c;
+          if (np_new < q.k) ++np_new;
+        }
+      }
+    }
+    np_old = np_new;
+    cur = nxt;
+  }
+  // outputs in the original stream order: layer t decided sorted column K-1-t = stream ord[K-1-t]
+  for (int t = 0; t < K; ++t) {
+    const int k = ord[K - 1 - t];
+    for (int b = 0; b < q.nb; ++b) {
+      if (q.hard_out) {
+        llr[k][b] = (float)((sym[cur][0][t] >> (q.nb - 1 - b)) & 1);
+        continue;
+      }
+      float l0 = INFINITY, l1 = INFINITY;
+      for (int pth = 0; pth < np_old; ++pth) {
+        if ((sym[cur][pth][t] >> (q.nb - 1 - b)) & 1) l1 = fminf(l1, dist[cur][pth]); else l0 = fminf(l0, dist[cur][pth]);
+      }
+      llr[k][b] = clampf(l0 - l1, -q.clip, q.clip);
+    }
+  }
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(64) void kbest_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                         const float2* __restrict__ s, int64_t n, KBestParams q,
+                                                         float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  c32 yy[M], hh[M][K], ss[M][M];
+  float llr[K][kMaxBits];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    yy[m] = C(y[i * M + m].x, y[i * M + m].y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float2 v = h[(i * M + m) * K + k]; hh[m][k] = C(v.x, v.y); }
+#pragma unroll
+    for (int j = 0; j < M; ++j) { const float2 v = s[(i * M + m) * M + j]; ss[m][j] = C(v.x, v.y); }
+  }
+  kbest_solve<M, K>(yy, hh, ss, llr, q);
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < q.nb; ++b) out[(i * K + k) * q.nb + b] = llr[k][b];
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(64) void ofdm_kbest_kernel(OfdmEqArgs p, KBestParams q, float* __restrict__ out) {
+  const int64_t total = (int64_t)p.B * p.RX * p.T * p.F;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int dpos[K], rx;
+  int64_t b;
+  c32 y[M], h[M][K], s[M][M];
+  if (!load_re<M, K>(p, i, y, h, s, dpos, b, rx)) return;
+  float llr[K][kMaxBits];
+  kbest_solve<M, K>(y, h, s, llr, q);
+  for (int k = 0; k < K; ++k)
+    if (dpos[k] >= 0) {
+      const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * q.nb;
+      for (int bb = 0; bb < q.nb; ++bb) out[o + bb] = llr[k][bb];
+    }
+}
+
 // ---- standalone detector on n problems: y [n,M], h [n,M,K], s [n,M,M], prior [n,K,nb] -> out [n,K,nb]
 template <int M, int K>
 __global__ __launch_bounds__(64) void mmse_pic_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
@@ -797,5 +965,59 @@ extern "C" int samd_ofdm_ep_f32(const float* y, const float* h_hat, const float*
   SAMD_MK_LIST(X)
 #undef X
   set_error("ofdm_ep: unsupported (num_rx_ant, streams_per_rx) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+// (m, k) pairs with at least as many receive antennas as streams (KBestDetector.build, :945-948)
+#define SAMD_MK_SQUARE_LIST(X) X(1, 1) X(2, 1) X(2, 2) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 4)
+
+extern "C" int samd_kbest_f32(const float* y, const float* h, const float* s, const float* points, int64_t n, int m,
+                              int k, int num_bits_per_symbol, int num_paths, float llr_clip, int hard_out, float* out,
+                              void* stream) {
+  SAMD_REQUIRE(y && h && s && points && out && n >= 0, "bad argument");
+  SAMD_REQUIRE(num_bits_per_symbol >= 1 && num_bits_per_symbol <= kMaxBits && num_paths >= 1 && num_paths <= kMaxPaths,
+               "bad detector parameters (num_paths <= 64)");
+  if (n == 0) return SAMD_OK;
+  const KBestParams q{(const float2*)points, num_bits_per_symbol, num_paths, hard_out, llr_clip};
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define X(M, K)                                                                                                 \
+  if (m == M && k == K) {                                                                                       \
+    hipLaunchKernelGGL((kbest_items_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, (const float2*)y,   \
+                       (const float2*)h, (const float2*)s, n, q, out);                                          \
+    return launch_status();                                                                                     \
+  }
+  SAMD_MK_SQUARE_LIST(X)
+#undef X
+  set_error("kbest: unsupported (num_rx_ant, num_streams) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_ofdm_kbest_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode,
+                                   const float* no, const float* points, const int32_t* sc_ind, const int32_t* desired,
+                                   const int32_t* undesired, const int32_t* data_pos, int batch, int num_rx,
+                                   int num_rx_ant, int num_streams_total, int streams_per_rx, int num_undesired,
+                                   int num_ofdm_symbols, int num_eff_subcarriers, int fft_size, int num_data,
+                                   int num_bits_per_symbol, int num_paths, float llr_clip, int hard_out, float* out,
+                                   void* stream) {
+  SAMD_REQUIRE(y && h_hat && no && points && sc_ind && desired && data_pos && out, "null argument");
+  SAMD_REQUIRE(ev_mode >= 0 && ev_mode <= 2 && (ev_mode == 0 || err_var), "bad err_var mode");
+  SAMD_REQUIRE(num_undesired == 0 || undesired, "undesired stream table missing");
+  SAMD_REQUIRE(num_bits_per_symbol >= 1 && num_bits_per_symbol <= kMaxBits && num_paths >= 1 && num_paths <= kMaxPaths,
+               "bad detector parameters (num_paths <= 64)");
+  OfdmEqArgs p{(const float2*)y, (const float2*)h_hat, err_var, no, sc_ind, desired, undesired, data_pos, nullptr,
+               nullptr, batch, num_rx, num_streams_total, num_ofdm_symbols, num_eff_subcarriers, fft_size,
+               num_undesired, num_data, ev_mode, 1};
+  const KBestParams q{(const float2*)points, num_bits_per_symbol, num_paths, hard_out, llr_clip};
+  const int64_t total = (int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers;
+  if (total == 0) return SAMD_OK;
+  const dim3 grid((unsigned)((total + 63) / 64));
+#define X(M, K)                                                                                          \
+  if (num_rx_ant == M && streams_per_rx == K) {                                                          \
+    hipLaunchKernelGGL((ofdm_kbest_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, p, q, out);   \
+    return launch_status();                                                                              \
+  }
+  SAMD_MK_SQUARE_LIST(X)
+#undef X
+  set_error("ofdm_kbest: unsupported (num_rx_ant, streams_per_rx) combination");
   return SAMD_ERR_UNSUPPORTED;
 }

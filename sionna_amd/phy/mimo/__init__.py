@@ -2,4 +2,4 @@
 for the hot path: StreamManagement, lmmse_equalizer, LinearDetector("lmmse"))."""
 from .stream_management import StreamManagement
 from .equalization import lmmse_equalizer
-from .detection import LinearDetector, MMSEPICDetector, EPDetector
+from .detection import LinearDetector, MMSEPICDetector, EPDetector, KBestDetector

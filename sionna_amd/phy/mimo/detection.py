@@ -124,3 +124,56 @@ class EPDetector(Block):
         _ffi.check(_ffi.lib().samd_ep_f32(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), _ffi.ptr(pam), y.numel() // m, m, k,
                                           nb, l, beta, es, prec, hard, _ffi.ptr(out), _ffi.stream()), "EPDetector")
         return wrap(out)
+
+
+class KBestDetector(Block):
+    """``KBestDetector(output, num_streams, k, constellation_type=None, num_bits_per_symbol=None,
+    constellation=None, hard_out=False, use_real_rep=False, list2llr=None)(y, h, s)``: breadth-first
+    tree search keeping the k best partial paths (mimo/detection.py:539-1037) with the default
+    ``List2LLRSimple`` (mimo/utils.py:420-578); complex representation, bit output:
+    y [...,M], h [...,M,K], s [...,M,M] -> [...,K,num_bits_per_symbol] (LLRs clipped to +-20, or bits)."""
+
+    def __init__(self, output, num_streams, k, constellation_type=None, num_bits_per_symbol=None, constellation=None,
+                 hard_out=False, use_real_rep=False, list2llr=None, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        assert output in ("bit", "symbol"), "Unknown output"
+        if output != "bit":
+            raise NotImplementedError("KBestDetector: only output='bit' has a HIP path")
+        if use_real_rep:
+            raise NotImplementedError("KBestDetector: the real-valued representation has no HIP path (use_real_rep=False)")
+        if list2llr is not None:
+            raise NotImplementedError("KBestDetector: custom list2llr callables have no HIP path (List2LLRSimple only)")
+        self._constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+        self._num_streams, self._hard_out = int(num_streams), bool(hard_out)
+        num_symbols = 2 ** self._constellation.num_bits_per_symbol
+        self._k = int(min(k, num_symbols ** self._num_streams))
+        if self._k < k:
+            import warnings
+            warnings.warn(f"KBestDetector: The provided value of k={k} is larger than the possible maximum number of "
+                          f"paths. It has been set to k={self._k}.")
+        if self._k > 64:
+            raise NotImplementedError("KBestDetector: k <= 64 on the HIP path")
+        self._llr_clip_val = 20.0
+
+    def _kernel_params(self):
+        pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex64), torch.complex64)
+        return pts, self._constellation.num_bits_per_symbol, self._k, self._llr_clip_val, int(self._hard_out)
+
+    def call(self, y, h, s):
+        self._require_single()
+        y = _ffi.to_device(y, torch.complex64)
+        h = _ffi.to_device(h, torch.complex64)
+        s = _ffi.to_device(s, torch.complex64)
+        m, k = h.shape[-2], h.shape[-1]
+        assert m >= k, "The number of receive antennas cannot be smaller than the number of streams"
+        assert k == self._num_streams, "h must have num_streams columns"
+        lead = tuple(h.shape[:-2])
+        pts, nb, kk, clip, hard = self._kernel_params()
+        y = torch.broadcast_to(y, lead + (m,)).contiguous()
+        s = torch.broadcast_to(s, lead + (m, m)).contiguous()
+        out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
+        _ffi.check(_ffi.lib().samd_kbest_f32(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), _ffi.ptr(pts), y.numel() // m, m,
+                                             k, nb, kk, clip, hard, _ffi.ptr(out), _ffi.stream()), "KBestDetector")
+        return wrap(out)

@@ -4,5 +4,5 @@ from .pilot_pattern import PilotPattern, EmptyPilotPattern, KroneckerPilotPatter
 from .resource_grid import ResourceGrid, ResourceGridMapper, ResourceGridDemapper, RemoveNulledSubcarriers
 from .channel_estimation import LSChannelEstimator, NearestNeighborInterpolator, LinearInterpolator
 from .equalization import OFDMEqualizer, LMMSEEqualizer
-from .detection import LinearDetector, MMSEPICDetector, EPDetector
+from .detection import LinearDetector, MMSEPICDetector, EPDetector, KBestDetector
 from .modulator import OFDMModulator, OFDMDemodulator

@@ -87,3 +87,30 @@ class EPDetector(Block):
         _ffi.check(_ffi.lib().samd_ofdm_ep_f32(*head, _ffi.ptr(pam), *tabs, *dims, nb, l, beta, es, prec, hard, _ffi.ptr(out),
                                                _ffi.stream()), "ofdm.EPDetector")
         return wrap(out)
+
+
+class KBestDetector(Block):
+    """``KBestDetector(output, num_streams, k, resource_grid, stream_management, constellation_type=None,
+    num_bits_per_symbol=None, constellation=None, hard_out=False, use_real_rep=False, list2llr="default")``
+    ``(y, h_hat, err_var, no)`` -> [batch, num_tx, num_streams, num_data_symbols * num_bits_per_symbol]."""
+
+    def __init__(self, output, num_streams, k, resource_grid, stream_management, constellation_type=None,
+                 num_bits_per_symbol=None, constellation=None, hard_out=False, use_real_rep=False, list2llr="default",
+                 precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        from ..mimo.detection import KBestDetector as _MimoKBest
+        self._det = _MimoKBest(output, num_streams, k, constellation_type, num_bits_per_symbol, constellation, hard_out,
+                               use_real_rep, None if list2llr in (None, "default") else list2llr, precision=precision)
+        self._pre = OFDMEqualizer("lmmse", resource_grid, stream_management, precision=precision)
+        self._rg = resource_grid
+
+    def call(self, y, h_hat, err_var, no):
+        self._require_single()
+        rg = self._rg
+        pts, nb, kk, clip, hard = self._det._kernel_params()
+        keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
+        out = torch.zeros((dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols * nb), dtype=torch.float32,
+                          device=keep[0].device)
+        _ffi.check(_ffi.lib().samd_ofdm_kbest_f32(*head, _ffi.ptr(pts), *tabs, *dims, nb, kk, clip, hard, _ffi.ptr(out),
+                                                  _ffi.stream()), "ofdm.KBestDetector")
+        return wrap(out)

@@ -487,3 +487,47 @@ def test_ofdm_ep_detector_vs_oracle(phy):
     ref = o.ofdm_ep_detector(org, osm, y, h_hat, err_var, 0.3, nb, l=6)
     assert got.shape == ref.shape
     assert np.mean(np.abs(got - ref) <= 2e-2 * (1 + np.abs(ref))) > 0.99, np.max(np.abs(got - ref))
+
+
+# ------------------------------------------------------------------ K-Best detector
+@pytest.mark.parametrize("m,k,nb,paths", [(2, 2, 2, 16), (4, 4, 2, 8), (4, 2, 4, 16), (8, 4, 4, 32), (4, 4, 4, 64), (1, 1, 6, 5)])
+def test_mimo_kbest_vs_oracle(phy, m, k, nb, paths):
+    rng = np.random.default_rng(m + k + nb + paths)
+    n = 300
+    pts = omap.qam(nb)
+    bits = rng.integers(0, 2, (n, k, nb))
+    x = pts[(bits * (2 ** np.arange(nb - 1, -1, -1))).sum(-1)]
+    h = _cplx(rng, (n, m, k)) / np.sqrt(2)
+    no = 0.1
+    y = ((h @ x[..., None])[..., 0] + np.sqrt(no / 2) * _cplx(rng, (n, m))).astype(np.complex64)
+    a = _cplx(rng, (n, m, m)) * 0.1
+    s = (a @ np.conj(np.swapaxes(a, -1, -2)) + no * np.eye(m)).astype(np.complex64)
+    det = phy.mimo.KBestDetector("bit", k, paths, constellation_type="qam", num_bits_per_symbol=nb)
+    got = _np(det(y, h, s))
+    ref = o.kbest_detector(y, h, s, pts, paths)
+    assert got.shape == ref.shape == (n, k, nb)
+    # identical surviving lists except for float32 near-ties in the partial distances
+    ok = np.all(np.isclose(got, ref, rtol=1e-3, atol=2e-3), axis=(1, 2))
+    assert ok.mean() > 0.97, (1 - ok.mean(), np.max(np.abs(got - ref)))
+    hard = _np(phy.mimo.KBestDetector("bit", k, paths, constellation_type="qam", num_bits_per_symbol=nb, hard_out=True)(y, h, s))
+    ref_h = o.kbest_detector(y, h, s, pts, paths, hard_out=True)
+    assert np.mean(np.all(hard == ref_h, axis=(1, 2))) > 0.99
+    if (m, k, nb, paths) == (2, 2, 2, 16):       # full enumeration == max-log ML: more bits right than the linear detector
+        lin = _np(phy.mimo.LinearDetector("lmmse", "bit", "maxlog", constellation_type="qam", num_bits_per_symbol=nb)(y, h, s))
+        assert np.mean((got > 0) != bits) <= np.mean((lin > 0) != bits)
+    with pytest.raises(NotImplementedError):
+        phy.mimo.KBestDetector("bit", k, paths, constellation_type="qam", num_bits_per_symbol=nb, use_real_rep=True)
+
+
+def test_ofdm_kbest_vs_oracle(phy):
+    rg, org = _grids(phy, num_tx=1, ns=2, fft=72, guards=(3, 4))
+    sm, osm = phy.mimo.StreamManagement(np.array([[1]]), 2), o.StreamManagement(np.array([[1]]), 2)
+    rng = np.random.default_rng(8)
+    B, nb = 3, 2
+    pts = omap.qam(nb)
+    y = _cplx(rng, (B, 1, 4, 14, 72))
+    h_hat = _cplx(rng, (B, 1, 4, 1, 2, 14, rg.num_effective_subcarriers))
+    got = _np(phy.ofdm.KBestDetector("bit", 2, 8, rg, sm, constellation_type="qam", num_bits_per_symbol=nb)(y, h_hat, 0.0, 0.4))
+    ref = o.ofdm_kbest_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.4, pts, 8)
+    assert got.shape == ref.shape
+    assert np.mean(np.isclose(got, ref, rtol=1e-3, atol=2e-3)) > 0.99
