@@ -91,6 +91,28 @@ def bench_c4(args):
         chain()
     torch.cuda.synchronize()
     t_e2e = (time.perf_counter() - t0) / 3
+    # time-domain variant of the same chain: OFDMModulator (rocFFT) -> TimeChannel (TDL taps, time-varying
+    # FIR) -> OFDMDemodulator (rocFFT) in place of the frequency-domain channel
+    bw = rg.bandwidth
+    l_min, l_max = phy.channel.time_lag_discrete_time_channel(bw)
+    tch = phy.channel.TimeChannel(tdl, bw, rg.num_time_samples, l_min=l_min, l_max=l_max, normalize_channel=True)
+    omod, odem = phy.ofdm.OFDMModulator(rg.cyclic_prefix_length), phy.ofdm.OFDMDemodulator(rg.fft_size, l_min, rg.cyclic_prefix_length)
+    est_lin = phy.ofdm.LSChannelEstimator(rg, interpolation_type="lin")
+    Bt = min(B, 2048)
+
+    def chain_td():
+        bb = src([Bt, 1, 2, k])
+        yt = odem(tch(omod(rgm(mapper(enc(bb)))), no))
+        hh, evv = est_lin(yt, no)
+        xh, ne = eq(yt, hh, evv, no)
+        return bb, dec(demap(xh, ne))
+    bt, bt_hat = chain_td()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        chain_td()
+    torch.cuda.synchronize()
+    t_td = (time.perf_counter() - t0) / 3
     out = {"metric": "LMMSE-equalised resource elements/sec (4x2, config C4)", "value": round(n_data_re * args.steps / t_wall, 1),
            "unit": "resource-elements/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(t_wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
@@ -102,7 +124,11 @@ def bench_c4(args):
            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "ofdm_lmmse_kernel<4,2>",
                         "algorithmic_bytes_per_re": 120, "ms_per_launch": round(ms, 3)},
-           "end_to_end": {"codewords_per_s": round(2 * B / t_e2e, 1), "ms_per_batch": round(t_e2e * 1e3, 2)}}
+           "end_to_end": {"codewords_per_s": round(2 * B / t_e2e, 1), "ms_per_batch": round(t_e2e * 1e3, 2)},
+           "end_to_end_time_domain": {"codewords_per_s": round(2 * Bt / t_td, 1), "ms_per_batch": round(t_td * 1e3, 2),
+                                      "batch": Bt, "ber": float((bt != bt_hat).float().mean()),
+                                      "stages": "rocFFT OFDM mod/demod, cir_to_time_channel + ApplyTimeChannel "
+                                                f"(l_min={l_min}, l_max={l_max}), LS with linear interpolation"}}
     if not args.no_cpu_baseline:
         from oracle import ofdm as o
         org = o.ResourceGrid(14, 76, 15e3, num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6,
