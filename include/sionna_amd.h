@@ -367,7 +367,9 @@ int samd_lin_interp_c64(const float* hp, const int32_t* fi0, const int32_t* fi1,
 
 /* lmmse_equalizer  mimo/equalization.py:101-233 on n independent problems:
  * y [n,m], h [n,m,k], s [n,m,m] complex64 -> x_hat [n,k] complex64, no_eff [n,k] float32.
- * Supported (m,k): (1,1) (2,1) (2,2) (4,1) (4,2) (4,4) (8,1) (8,2) (8,4); else UNSUPPORTED. */
+ * Supported (m,k): (1,1) (2,1) (2,2) (4,1) (4,2) (4,4) (8,1) (8,2) (8,4); else UNSUPPORTED.
+ * whiten: 1 / 0 = lmmse_equalizer with / without whitening; 2 = zf_equalizer (:235-298); 3 = mf_equalizer
+ * (:300-470) - same inputs and outputs. */
 int samd_lmmse_equalizer_c64(const float* y, const float* h, const float* s, int64_t n, int m,
                              int k, int whiten, float* x_hat, float* no_eff, void* stream);
 

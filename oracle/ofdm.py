@@ -712,3 +712,34 @@ def ofdm_kbest_detector(rg, sm, y, h_hat, err_var, no, points, k, hard_out=False
                          s.reshape((-1,) + s.shape[-2:]), points, k, hard_out)
     out = _extract_data(rg, sm, llr.reshape(shp + llr.shape[-2:]), y.shape[0])
     return out.reshape(out.shape[:3] + (-1,))
+
+
+# ------------------------------------------------------------------ ZF / MF equalisers
+def zf_equalizer(y, h, s):
+    """mimo/equalization.py:235-298 (complex128)."""
+    y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
+    hh = np.conj(np.swapaxes(h, -1, -2))
+    g = np.linalg.solve(hh @ h, hh)
+    x = (g @ y[..., None])[..., 0]
+    return x, np.real(np.diagonal(g @ s @ np.conj(np.swapaxes(g, -1, -2)), axis1=-2, axis2=-1))
+
+
+def mf_equalizer(y, h, s):
+    """mimo/equalization.py:300-470 (complex128)."""
+    y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
+    hh = np.conj(np.swapaxes(h, -1, -2))
+    d = 1 / np.diagonal(hh @ h, axis1=-2, axis2=-1)
+    g = d[..., None] * hh
+    x = (g @ y[..., None])[..., 0]
+    gh = g @ h
+    e = np.eye(h.shape[-1]) - gh
+    cov = e @ np.conj(np.swapaxes(e, -1, -2)) + g @ s @ np.conj(np.swapaxes(g, -1, -2))
+    return x, np.abs(np.diagonal(cov, axis1=-2, axis2=-1))
+
+
+def ofdm_linear_equalize(rg, sm, y, h_hat, err_var, no, kind):
+    """OFDMEqualizer.call with the ZF / MF equaliser."""
+    y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
+    x_hat, no_eff = {"zf": zf_equalizer, "mf": mf_equalizer}[kind](y_dt, hd, s)
+    B = y.shape[0]
+    return _extract_data(rg, sm, x_hat, B).astype(np.complex64), _extract_data(rg, sm, no_eff, B).astype(np.float32)

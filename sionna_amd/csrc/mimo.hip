@@ -154,6 +154,86 @@ __device__ __forceinline__ void lmmse_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s
   }
 }
 
+// zf_equalizer (mimo/equalization.py:235-298; G = (H^H H)^-1 H^H via Cholesky, utils/linalg.py:35-58) and
+// mf_equalizer (:300-470; G = diag(H^H H)^-1 H^H).  Only the lower triangle of s is read.
+// no_eff: ZF real(diag(G S G^H)); MF |diag((I - G H)(I - G H)^H + G S G^H)|.
+template <int M, int K>
+__device__ __forceinline__ void zf_mf_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], bool mf, c32 (&xh)[K],
+                                            float (&ne)[K]) {
+  c32 a[K][K], g[K][M];
+#pragma unroll
+  for (int i = 0; i < K; ++i)
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      c32 v = C(0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < M; ++m) v = v + mulc(h[m][j], h[m][i]);       // conj(h[m][i]) h[m][j]
+      a[i][j] = v;
+    }
+  if (mf) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int m = 0; m < M; ++m) g[k][m] = cdiv(cj(h[m][k]), C(a[k][k].re, a[k][k].im));
+  } else {
+    c32 l[K][K];
+#pragma unroll
+    for (int i = 0; i < K; ++i)
+#pragma unroll
+      for (int j = 0; j < K; ++j) l[i][j] = a[i][j];
+    cholesky<K>(l);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {                              // solve (L L^H) g[:, m] = H^H e_m
+      c32 z[K];
+#pragma unroll
+      for (int i = 0; i < K; ++i) {
+        c32 v = cj(h[m][i]);
+#pragma unroll
+        for (int k = 0; k < i; ++k) v = v - l[i][k] * z[k];
+        z[i] = scale(v, 1.f / l[i][i].re);
+      }
+#pragma unroll
+      for (int i = K - 1; i >= 0; --i) {
+        c32 v = z[i];
+#pragma unroll
+        for (int k = i + 1; k < K; ++k) v = v - cj(l[k][i]) * g[k][m];
+        g[i][m] = scale(v, 1.f / l[i][i].re);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    c32 gy = C(0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) gy = gy + g[k][m] * y[m];
+    xh[k] = gy;
+    // (G S G^H)_kk = sum_{a,b} g[k][a] S[a][b] conj(g[k][b]), S Hermitian from its lower triangle
+    c32 q = C(0.f, 0.f);
+#pragma unroll
+    for (int a2 = 0; a2 < M; ++a2)
+#pragma unroll
+      for (int b2 = 0; b2 < M; ++b2) {
+        const c32 sv = b2 <= a2 ? s[a2][b2] : cj(s[b2][a2]);
+        q = q + mulc(g[k][a2] * sv, g[k][b2]);
+      }
+    if (mf) {
+      float r = 0.f;                                           // row k of (I - G H): sum_j |delta_kj - (GH)_kj|^2
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        c32 gh = C(0.f, 0.f);
+#pragma unroll
+        for (int m = 0; m < M; ++m) gh = gh + g[k][m] * h[m][j];
+        const c32 e = C((k == j ? 1.f : 0.f) - gh.re, -gh.im);
+        r += e.re * e.re + e.im * e.im;
+      }
+      const float re = r + q.re, im = q.im;
+      ne[k] = sqrtf(re * re + im * im);
+    } else {
+      ne[k] = q.re;
+    }
+  }
+}
+
 // ---- standalone lmmse_equalizer on [N,M], [N,M,K], [N,M,M]
 template <int M, int K>
 __global__ __launch_bounds__(128) void lmmse_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
@@ -172,7 +252,8 @@ __global__ __launch_bounds__(128) void lmmse_items_kernel(const float2* __restri
 #pragma unroll
     for (int j = 0; j < M; ++j) { const float2 w = s[(i * M + m) * M + j]; ss[m][j] = C(w.x, w.y); }
   }
-  lmmse_solve<M, K>(yy, hh, ss, whiten != 0, xh, ne);
+  if (whiten >= 2) zf_mf_solve<M, K>(yy, hh, ss, whiten == 3, xh, ne);
+  else lmmse_solve<M, K>(yy, hh, ss, whiten != 0, xh, ne);
 #pragma unroll
   for (int k = 0; k < K; ++k) { x_hat[i * K + k] = make_float2(xh[k].re, xh[k].im); no_eff[i * K + k] = ne[k]; }
 }
@@ -248,7 +329,8 @@ __global__ __launch_bounds__(128) void ofdm_lmmse_kernel(OfdmEqArgs p) {
   c32 y[M], h[M][K], s[M][M], xh[K];
   float ne[K];
   if (!load_re<M, K>(p, i, y, h, s, dpos, b, rx)) return;
-  lmmse_solve<M, K>(y, h, s, p.whiten != 0, xh, ne);
+  if (p.whiten >= 2) zf_mf_solve<M, K>(y, h, s, p.whiten == 3, xh, ne);
+  else lmmse_solve<M, K>(y, h, s, p.whiten != 0, xh, ne);
 #pragma unroll
   for (int k = 0; k < K; ++k)
     if (dpos[k] >= 0) {

@@ -7,7 +7,7 @@ import torch
 from ... import _ffi
 from ..block import Block, wrap
 from ..mapping import Demapper, Constellation
-from .equalization import lmmse_equalizer
+from .equalization import lmmse_equalizer, zf_equalizer, mf_equalizer
 
 
 class LinearDetector(Block):
@@ -16,8 +16,8 @@ class LinearDetector(Block):
         super().__init__(precision=precision, **kwargs)
         if output != "bit":
             raise NotImplementedError("LinearDetector: only output='bit' is on the MI355X hot path")
-        if equalizer == "lmmse":
-            self._equalizer = lmmse_equalizer
+        if equalizer in ("lmmse", "zf", "mf"):
+            self._equalizer = {"lmmse": lmmse_equalizer, "zf": zf_equalizer, "mf": mf_equalizer}[equalizer]
         elif callable(equalizer):
             self._equalizer = equalizer
         else:

@@ -1,15 +1,15 @@
-"""``lmmse_equalizer(y, h, s, whiten_interference=True)`` - mirror of reference
-src/sionna/phy/mimo/equalization.py:101-233 on the HIP kernel ``samd_lmmse_equalizer_c64``."""
+"""``lmmse_equalizer`` / ``zf_equalizer`` / ``mf_equalizer`` - mirrors of reference
+src/sionna/phy/mimo/equalization.py:101-233, 235-298, 300-470 on the HIP kernel
+``samd_lmmse_equalizer_c64`` (mode 1/0 LMMSE with / without whitening, 2 ZF, 3 MF)."""
 import torch
 
 from ... import _ffi
 from ..block import wrap
 
 
-def lmmse_equalizer(y, h, s, whiten_interference=True, precision=None):
-    """y [...,M], h [...,M,K], s [...,M,M] -> (x_hat [...,K] complex, no_eff [...,K] float)."""
+def _equalize(y, h, s, mode, precision, name):
     if precision not in (None, "single"):
-        raise NotImplementedError("lmmse_equalizer: the MI355X kernels implement precision='single' only")
+        raise NotImplementedError(f"{name}: the MI355X kernels implement precision='single' only")
     y = _ffi.to_device(y, torch.complex64)
     h = _ffi.to_device(h, torch.complex64)
     s = _ffi.to_device(s, torch.complex64)
@@ -20,7 +20,21 @@ def lmmse_equalizer(y, h, s, whiten_interference=True, precision=None):
     n = y.numel() // m
     x_hat = torch.empty(lead + (k,), dtype=torch.complex64, device=y.device)
     no_eff = torch.empty(lead + (k,), dtype=torch.float32, device=y.device)
-    _ffi.check(_ffi.lib().samd_lmmse_equalizer_c64(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), n, m, k,
-                                                  int(bool(whiten_interference)), _ffi.ptr(x_hat),
-                                                  _ffi.ptr(no_eff), _ffi.stream()), "lmmse_equalizer")
+    _ffi.check(_ffi.lib().samd_lmmse_equalizer_c64(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), n, m, k, int(mode),
+                                                  _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.stream()), name)
     return wrap(x_hat), wrap(no_eff)
+
+
+def lmmse_equalizer(y, h, s, whiten_interference=True, precision=None):
+    """y [...,M], h [...,M,K], s [...,M,M] -> (x_hat [...,K] complex, no_eff [...,K] float)."""
+    return _equalize(y, h, s, int(bool(whiten_interference)), precision, "lmmse_equalizer")
+
+
+def zf_equalizer(y, h, s, precision=None):
+    """Zero-forcing: G = (H^H H)^-1 H^H, x_hat = G y, no_eff = diag(G S G^H)."""
+    return _equalize(y, h, s, 2, precision, "zf_equalizer")
+
+
+def mf_equalizer(y, h, s, precision=None):
+    """Matched filter: G = diag(H^H H)^-1 H^H, no_eff = |diag((I - G H)(I - G H)^H + G S G^H)|."""
+    return _equalize(y, h, s, 3, precision, "mf_equalizer")

@@ -3,6 +3,6 @@
 from .pilot_pattern import PilotPattern, EmptyPilotPattern, KroneckerPilotPattern
 from .resource_grid import ResourceGrid, ResourceGridMapper, ResourceGridDemapper, RemoveNulledSubcarriers
 from .channel_estimation import LSChannelEstimator, NearestNeighborInterpolator, LinearInterpolator
-from .equalization import OFDMEqualizer, LMMSEEqualizer
+from .equalization import OFDMEqualizer, LMMSEEqualizer, ZFEqualizer, MFEqualizer
 from .detection import LinearDetector, MMSEPICDetector, EPDetector, KBestDetector
 from .modulator import OFDMModulator, OFDMDemodulator

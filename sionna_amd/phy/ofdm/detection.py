@@ -16,11 +16,11 @@ class LinearDetector(Block):
                  constellation_type=None, num_bits_per_symbol=None, constellation=None, hard_out=False,
                  precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
-        if equalizer != "lmmse":
-            raise NotImplementedError(f"LinearDetector: equalizer '{equalizer}' is outside the hot path (lmmse only)")
+        if equalizer not in ("lmmse", "zf", "mf"):
+            raise NotImplementedError(f"LinearDetector: equalizer '{equalizer}' has no HIP path (lmmse / zf / mf)")
         if output != "bit":
             raise NotImplementedError("LinearDetector: only output='bit' is on the MI355X hot path")
-        self._eq = LMMSEEqualizer(resource_grid, stream_management, precision=precision)
+        self._eq = OFDMEqualizer(equalizer, resource_grid, stream_management, precision=precision)
         self._constellation = Constellation.check_or_create(
             constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
             constellation=constellation, precision=precision)

@@ -16,10 +16,10 @@ class OFDMEqualizer(Block):
 
     def __init__(self, equalizer, resource_grid, stream_management, precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
-        if equalizer != "lmmse":
-            raise NotImplementedError("OFDMEqualizer: only the fused LMMSE equaliser is on the MI355X hot path")
+        if equalizer not in ("lmmse", "zf", "mf"):
+            raise NotImplementedError("OFDMEqualizer: the fused kernel implements the 'lmmse', 'zf' and 'mf' equalisers")
         self._rg, self._sm = resource_grid, stream_management
-        self._whiten = True
+        self._whiten = {"lmmse": 1, "zf": 2, "mf": 3}[equalizer]      # kernel mode
         self._dev = None
 
     def _tables(self):
@@ -84,4 +84,18 @@ class LMMSEEqualizer(OFDMEqualizer):
 
     def __init__(self, resource_grid, stream_management, whiten_interference=True, precision=None, **kwargs):
         super().__init__("lmmse", resource_grid, stream_management, precision=precision, **kwargs)
-        self._whiten = bool(whiten_interference)
+        self._whiten = int(bool(whiten_interference))
+
+
+class ZFEqualizer(OFDMEqualizer):
+    """``ZFEqualizer(resource_grid, stream_management)(y, h_hat, err_var, no)`` (ofdm/equalization.py:346-403)."""
+
+    def __init__(self, resource_grid, stream_management, precision=None, **kwargs):
+        super().__init__("zf", resource_grid, stream_management, precision=precision, **kwargs)
+
+
+class MFEqualizer(OFDMEqualizer):
+    """``MFEqualizer(resource_grid, stream_management)(y, h_hat, err_var, no)`` (ofdm/equalization.py:405-460)."""
+
+    def __init__(self, resource_grid, stream_management, precision=None, **kwargs):
+        super().__init__("mf", resource_grid, stream_management, precision=precision, **kwargs)

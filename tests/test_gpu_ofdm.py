@@ -531,3 +531,39 @@ def test_ofdm_kbest_vs_oracle(phy):
     ref = o.ofdm_kbest_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.4, pts, 8)
     assert got.shape == ref.shape
     assert np.mean(np.isclose(got, ref, rtol=1e-3, atol=2e-3)) > 0.99
+
+
+# ------------------------------------------------------------------ ZF / MF equalisers
+@pytest.mark.parametrize("m,k", [(4, 2), (4, 4), (8, 4), (2, 1), (1, 1)])
+def test_zf_mf_equalizers_vs_oracle(phy, m, k):
+    rng = np.random.default_rng(m * 3 + k)
+    n = 200
+    y, h = _cplx(rng, (n, m)), _cplx(rng, (n, m, k))
+    a = _cplx(rng, (n, m, m)) * 0.3
+    s = (a @ np.conj(np.swapaxes(a, -1, -2)) + 0.2 * np.eye(m)).astype(np.complex64)
+    for fn, ref_fn in ((phy.mimo.zf_equalizer, o.zf_equalizer), (phy.mimo.mf_equalizer, o.mf_equalizer)):
+        x, ne = fn(y, h, s)
+        xr, nr = ref_fn(y, h, s)
+        assert np.allclose(_np(x), xr, rtol=2e-3, atol=2e-3 * np.abs(xr).max()) and np.allclose(_np(ne), nr, rtol=2e-3, atol=1e-4 * nr.max())
+    # zero forcing removes the interference exactly in the noise-free case
+    x0 = _cplx(rng, (n, k))
+    xz, _ = phy.mimo.zf_equalizer((h @ x0[..., None])[..., 0], h, s)
+    assert np.allclose(_np(xz), x0, rtol=1e-2, atol=1e-2)
+    det = phy.mimo.LinearDetector("zf", "bit", "app", constellation_type="qam", num_bits_per_symbol=2)
+    assert tuple(det(y, h, s).shape) == (n, k, 2)
+
+
+@pytest.mark.parametrize("kind", ["zf", "mf"])
+def test_ofdm_zf_mf_vs_oracle(phy, kind):
+    rg, org = _grids(phy, num_tx=2, ns=1, fft=72, guards=(3, 4))
+    sm, osm = phy.mimo.StreamManagement(np.array([[1, 1]]), 1), o.StreamManagement(np.array([[1, 1]]), 1)
+    rng = np.random.default_rng(2)
+    y = _cplx(rng, (4, 1, 4, 14, 72))
+    h_hat = _cplx(rng, (4, 1, 4, 2, 1, 14, rg.num_effective_subcarriers))
+    err_var = rng.uniform(0.0, 0.05, (1, 1, 1, 2, 1, 14, rg.num_effective_subcarriers)).astype(np.float32)
+    cls = {"zf": phy.ofdm.ZFEqualizer, "mf": phy.ofdm.MFEqualizer}[kind]
+    x, ne = cls(rg, sm)(y, h_hat, err_var, 0.2)
+    xr, nr = o.ofdm_linear_equalize(org, osm, y, h_hat, err_var, 0.2, kind)
+    assert np.allclose(_np(x), xr, rtol=2e-3, atol=2e-3 * np.abs(xr).max()) and np.allclose(_np(ne), nr, rtol=2e-3, atol=1e-4 * nr.max())
+    llr = phy.ofdm.LinearDetector(kind, "bit", "maxlog", rg, sm, constellation_type="qam", num_bits_per_symbol=2)(y, h_hat, err_var, 0.2)
+    assert tuple(llr.shape) == (4, 2, 1, rg.num_data_symbols * 2)
