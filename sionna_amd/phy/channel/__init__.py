@@ -4,4 +4,5 @@ from .utils import subcarrier_frequencies, cir_to_ofdm_channel
 from .ofdm_channel import GenerateOFDMChannel, ApplyOFDMChannel, OFDMChannel, RayleighBlockFading
 from .time_channel import (time_lag_discrete_time_channel, cir_to_time_channel, GenerateTimeChannel,
                            ApplyTimeChannel, TimeChannel)
+from .flat_fading_channel import GenerateFlatFadingChannel, ApplyFlatFadingChannel, FlatFadingChannel
 from . import tr38901

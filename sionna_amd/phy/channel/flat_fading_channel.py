@@ -1,0 +1,69 @@
+"""Flat-fading MIMO channel - mirrors of ``GenerateFlatFadingChannel``, ``ApplyFlatFadingChannel`` and
+``FlatFadingChannel`` (reference src/sionna/phy/channel/flat_fading_channel.py:14-290): i.i.d. CN(0,1)
+channel matrices on the Philox stream and y = H x (+ AWGN) through ``samd_apply_ofdm_channel_c64``
+(one "resource element" per batch item).  Spatial correlation models have no HIP path."""
+import torch
+
+from ... import _ffi
+from ..block import Block, Object, wrap
+from .awgn import AWGN
+
+
+class GenerateFlatFadingChannel(Object):
+    """``GenerateFlatFadingChannel(num_tx_ant, num_rx_ant, spatial_corr=None)(batch_size)`` ->
+    h [batch_size, num_rx_ant, num_tx_ant]."""
+
+    def __init__(self, num_tx_ant, num_rx_ant, spatial_corr=None, precision=None):
+        super().__init__(precision=precision)
+        if spatial_corr is not None:
+            raise NotImplementedError("GenerateFlatFadingChannel: spatial correlation models have no HIP path")
+        self._num_tx_ant, self._num_rx_ant = int(num_tx_ant), int(num_rx_ant)
+
+    spatial_corr = property(lambda self: None)
+
+    def __call__(self, batch_size):
+        from ..utils.misc import complex_normal
+        return complex_normal([int(batch_size), self._num_rx_ant, self._num_tx_ant], 1.0, precision=self.precision)
+
+
+class ApplyFlatFadingChannel(Block):
+    """``ApplyFlatFadingChannel()(x [batch, num_tx_ant], h [batch, num_rx_ant, num_tx_ant], no=None)``
+    -> y [batch, num_rx_ant]."""
+
+    def __init__(self, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._awgn = AWGN(precision=self.precision)
+
+    def call(self, x, h, no=None):
+        self._require_single()
+        x = _ffi.to_device(x, torch.complex64)
+        h = _ffi.to_device(h, torch.complex64)
+        b, rx, tx = h.shape
+        x = torch.broadcast_to(x, (b, tx)).contiguous()
+        y = torch.empty((b, rx), dtype=torch.complex64, device=x.device)
+        if b:
+            _ffi.check(_ffi.lib().samd_apply_ofdm_channel_c64(_ffi.ptr(x), _ffi.ptr(h.contiguous()), b, rx, tx, 1, _ffi.ptr(y),
+                                                              _ffi.stream()), "ApplyFlatFadingChannel")
+        if no is not None:
+            y = self._awgn(y, no)
+        return wrap(y)
+
+
+class FlatFadingChannel(Block):
+    """``FlatFadingChannel(num_tx_ant, num_rx_ant, spatial_corr=None, return_channel=False)(x, no=None)``
+    -> y or (y, h)."""
+
+    def __init__(self, num_tx_ant, num_rx_ant, spatial_corr=None, return_channel=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._num_tx_ant, self._num_rx_ant, self._return_channel = int(num_tx_ant), int(num_rx_ant), return_channel
+        self._gen_chn = GenerateFlatFadingChannel(num_tx_ant, num_rx_ant, spatial_corr, precision=self.precision)
+        self._app_chn = ApplyFlatFadingChannel(precision=self.precision)
+
+    spatial_corr = property(lambda self: None)
+    generate = property(lambda self: self._gen_chn)
+    apply = property(lambda self: self._app_chn)
+
+    def call(self, x, no=None):
+        h = self._gen_chn(x.shape[0])
+        y = self._app_chn(x, h, no)
+        return (y, h) if self._return_channel else y

@@ -120,3 +120,21 @@ def test_rng_streams_differ_per_rank():
     b = outil.random_bits(g1.seed, 0, 4096)
     assert 0.4 < np.mean(a != b) < 0.6
     assert g0.next_call() == 0 and g0.next_call() == 1
+
+
+def test_tensor_shape_helpers():
+    """utils/tensors.py of the reference: pure reshapes (reference tests test/unit/utils/test_tensors.py)."""
+    import torch
+    from sionna_amd.phy import utils as u
+    x = torch.arange(24.).reshape(2, 3, 4)
+    assert tuple(u.expand_to_rank(x, 5, axis=-1).shape) == (2, 3, 4, 1, 1)
+    assert tuple(u.expand_to_rank(x, 5, axis=0).shape) == (1, 1, 2, 3, 4)
+    assert tuple(u.expand_to_rank(x, 2).shape) == (2, 3, 4)
+    assert tuple(u.insert_dims(x, 2, axis=1).shape) == (2, 1, 1, 3, 4) and tuple(u.insert_dims(x, 1, axis=-2).shape) == (2, 3, 1, 4)
+    assert tuple(u.flatten_dims(x, 2, 0).shape) == (6, 4) and tuple(u.flatten_dims(x, 2, 1).shape) == (2, 12)
+    assert tuple(u.flatten_last_dims(x).shape) == (2, 12) and tuple(u.flatten_last_dims(x, 3).shape) == (24,)
+    assert tuple(u.split_dim(x, [2, 2], 2).shape) == (2, 3, 2, 2)
+    assert torch.equal(u.split_dim(u.flatten_dims(x, 2, 1), [3, 4], 1), x)
+    assert float(u.db(100.)) == 20.0 and float(u.log2(8.)) == 3.0 and float(u.log10(1000.)) == 3.0
+    with pytest.raises(AssertionError):
+        u.flatten_dims(x, 1, 0)

@@ -567,3 +567,21 @@ def test_ofdm_zf_mf_vs_oracle(phy, kind):
     assert np.allclose(_np(x), xr, rtol=2e-3, atol=2e-3 * np.abs(xr).max()) and np.allclose(_np(ne), nr, rtol=2e-3, atol=1e-4 * nr.max())
     llr = phy.ofdm.LinearDetector(kind, "bit", "maxlog", rg, sm, constellation_type="qam", num_bits_per_symbol=2)(y, h_hat, err_var, 0.2)
     assert tuple(llr.shape) == (4, 2, 1, rg.num_data_symbols * 2)
+
+
+def test_flat_fading_channel(phy):
+    phy.config.seed = 9
+    ch = phy.channel.FlatFadingChannel(3, 4, return_channel=True)
+    rng = np.random.default_rng(1)
+    x = _cplx(rng, (5000, 3))
+    y, h = ch(x)
+    assert tuple(h.shape) == (5000, 4, 3) and tuple(y.shape) == (5000, 4)
+    assert np.allclose(_np(y), (_np(h) @ x[..., None])[..., 0], rtol=1e-4, atol=1e-5)
+    assert abs(np.mean(np.abs(_np(h)) ** 2) - 1.0) < 0.03 and abs(np.mean(_np(h))) < 0.02
+    y2, h2 = ch(x, 0.5)
+    nvar = np.mean(np.abs(_np(y2) - (_np(h2) @ x[..., None])[..., 0]) ** 2)
+    assert abs(nvar - 0.5) < 0.03
+    h3 = phy.channel.GenerateFlatFadingChannel(2, 2)(7)
+    assert tuple(phy.channel.ApplyFlatFadingChannel()(x[:7, :2], h3).shape) == (7, 2)
+    with pytest.raises(NotImplementedError):
+        phy.channel.FlatFadingChannel(2, 2, spatial_corr=object())
