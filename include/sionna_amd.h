@@ -154,6 +154,13 @@ int samd_qam_demap_f32(const float* y, const float* no, int64_t no_len, const fl
                        int m, int64_t num_symbols, int method, int hard_out, float* out,
                        void* stream);
 
+/* Demapper.call with prior knowledge on the bits (mapping.py:664-691, 927-967): as samd_qam_demap_f32 with
+ * the a-priori term sum_i log_sigmoid(+-prior_i) added to the exponent of every point.  prior DEVICE
+ * float LLRs, [m] (shared by all symbols) or [num_symbols, m]. */
+int samd_qam_demap_prior_f32(const float* y, const float* no, int64_t no_len, const float* points, int m,
+                             int64_t num_symbols, const float* prior, int64_t prior_len, int method,
+                             int hard_out, float* out, void* stream);
+
 /* Same contract for a SQUARE QAM constellation whose label interleaves the bits of two
  * identical PAM axes (qam() of mapping.py:44-118: even label bits -> real axis, odd ->
  * imaginary): the per-bit sums factorise per axis, so only the 2^(m/2) PAM levels are needed.

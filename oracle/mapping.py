@@ -68,8 +68,8 @@ def _logsumexp(x, axis):
     return (np.log(np.sum(np.exp(x - mx), axis=axis, keepdims=True)) + mx).squeeze(axis)
 
 
-def demapper(y, no, points, method="app", hard_out=False):
-    """mapping.py:664-691 + 927-967 (no prior).  y: [...,S] complex; no scalar or [...,S].
+def demapper(y, no, points, method="app", hard_out=False, prior=None):
+    """mapping.py:664-691 + 927-967.  y: [...,S] complex; no scalar or [...,S]; prior: LLRs [m] or [...,S,m].
 
     Returns logits log p(b=1)/p(b=0), shape [..., S*m], symbol-major then bit index.
     """
@@ -82,6 +82,11 @@ def demapper(y, no, points, method="app", hard_out=False):
         no = np.broadcast_to(no, y.shape)
     no = np.maximum(no[..., None], np.finfo(rdtype).tiny)
     expo = (-sq / no).astype(rdtype)
+    if prior is not None:                                            # :944-958
+        pr = np.broadcast_to(np.asarray(prior, rdtype), y.shape + (m,))
+        lab = ((np.arange(2 ** m)[:, None] >> (m - 1 - np.arange(m))) & 1) * 2 - 1        # [2^m, m] +-1
+        logsig = -np.logaddexp(0, -(lab * pr[..., None, :]).astype(np.float64))
+        expo = (np.sum(logsig, axis=-1) + expo).astype(rdtype)
     e0 = expo[..., c0]                                               # [...,S,2^m/2,m]
     e1 = expo[..., c1]
     if method == "app":

@@ -43,6 +43,7 @@ _SIGNATURES = {
     "samd_ldpc5g_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, _sz, _vp]),
     "samd_qam_map_c64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "samd_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
+    "samd_qam_demap_prior_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "samd_square_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "samd_binary_source_f32": (_i32, [_u64, _u64, _i64, _vp, _vp]),
     "samd_awgn_c64": (_i32, [_vp, _vp, _i64, _u64, _u64, _i64, _vp, _vp]),

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(256) void qam_map_kernel(const float* __restrict__ 
 template <int M, bool MAXLOG>
 __global__ __launch_bounds__(256) void demap_kernel(const float2* __restrict__ y, const float* __restrict__ no,
                                                     int64_t no_len, const float2* __restrict__ points,
-                                                    int64_t num_symbols, int hard_out, float* __restrict__ out) {
+                                                    int64_t num_symbols, int hard_out, float* __restrict__ out,
+                                                    const float* __restrict__ prior = nullptr, int64_t prior_len = 0) {
   constexpr int P = 1 << M;
   __shared__ float2 lut[P];
   for (int i = threadIdx.x; i < P; i += blockDim.x) lut[i] = points[i];
@@ -47,6 +48,14 @@ __global__ __launch_bounds__(256) void demap_kernel(const float2* __restrict__ y
        s += (int64_t)gridDim.x * blockDim.x) {
     const float2 ys = y[s];
     const float n0 = fmaxf(no_len == 1 ? no[0] : no[s], 1.17549435e-38f);   // finfo(float32).tiny
+    // a-priori term of a point: sum_i log_sigmoid(+-prior_i) (SymbolLogits2LLRs.call, mapping.py:944-958)
+    float ls[M][2];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const float p = prior ? prior[prior_len == M ? i : s * M + i] : 0.f;
+      ls[i][1] = prior ? (p < 0.f ? p - log1pf(expf(p)) : -log1pf(expf(-p))) : 0.f;
+      ls[i][0] = prior ? (-p < 0.f ? -p - log1pf(expf(-p)) : -log1pf(expf(p))) : 0.f;
+    }
     // pass 1: per (bit, value) maximum of the exponents
     float mx[M][2];
 #pragma unroll
@@ -55,7 +64,13 @@ __global__ __launch_bounds__(256) void demap_kernel(const float2* __restrict__ y
       const float dr = ys.x - lut[c].x, di = ys.y - lut[c].y;
       // |y-c|^2 (mapping.py:672 forms it as abs()**2; the direct sum of squares is the same
       // quantity without the sqrt round trip)
-      const float e = -(dr * dr + di * di) / n0;
+      float e = -(dr * dr + di * di) / n0;
+      if (prior) {
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) ps += ls[i][(c >> (M - 1 - i)) & 1];
+        e = ps + e;
+      }
 #pragma unroll
       for (int i = 0; i < M; ++i) {
         const int bit = (c >> (M - 1 - i)) & 1;            // label bit i, MSB first
@@ -72,7 +87,13 @@ __global__ __launch_bounds__(256) void demap_kernel(const float2* __restrict__ y
       for (int i = 0; i < M; ++i) { sm[i][0] = 0.f; sm[i][1] = 0.f; }
       for (int c = 0; c < P; ++c) {
         const float dr = ys.x - lut[c].x, di = ys.y - lut[c].y;
-        const float e = -(dr * dr + di * di) / n0;
+        float e = -(dr * dr + di * di) / n0;
+        if (prior) {
+          float ps = 0.f;
+#pragma unroll
+          for (int i = 0; i < M; ++i) ps += ls[i][(c >> (M - 1 - i)) & 1];
+          e = ps + e;
+        }
 #pragma unroll
         for (int i = 0; i < M; ++i) {
           const int bit = (c >> (M - 1 - i)) & 1;
@@ -153,8 +174,9 @@ __global__ __launch_bounds__(256) void demap_square_qam_kernel(const float2* __r
 
 template <bool MAXLOG>
 static int launch_demap(int m, dim3 grid, hipStream_t st, const float2* y, const float* no, int64_t no_len,
-                        const float2* pts, int64_t ns, int hard, float* out) {
-#define SAMD_DM(M) case M: hipLaunchKernelGGL((demap_kernel<M, MAXLOG>), grid, dim3(256), 0, st, y, no, no_len, pts, ns, hard, out); break
+                        const float2* pts, int64_t ns, int hard, float* out, const float* prior = nullptr,
+                        int64_t prior_len = 0) {
+#define SAMD_DM(M) case M: hipLaunchKernelGGL((demap_kernel<M, MAXLOG>), grid, dim3(256), 0, st, y, no, no_len, pts, ns, hard, out, prior, prior_len); break
   switch (m) {
     SAMD_DM(1); SAMD_DM(2); SAMD_DM(3); SAMD_DM(4); SAMD_DM(5); SAMD_DM(6); SAMD_DM(7); SAMD_DM(8); SAMD_DM(9); SAMD_DM(10);
     default: set_error("num_bits_per_symbol must be in 1..10"); return SAMD_ERR_UNSUPPORTED;
@@ -212,6 +234,23 @@ extern "C" int samd_qam_demap_f32(const float* y, const float* no, int64_t no_le
   int rc = method == 1
                ? launch_demap<true>(m, grid, (hipStream_t)stream, (const float2*)y, no, no_len, (const float2*)points, num_symbols, hard_out, out)
                : launch_demap<false>(m, grid, (hipStream_t)stream, (const float2*)y, no, no_len, (const float2*)points, num_symbols, hard_out, out);
+  if (rc != SAMD_OK) return rc;
+  return launch_status();
+}
+
+extern "C" int samd_qam_demap_prior_f32(const float* y, const float* no, int64_t no_len, const float* points, int m,
+                                        int64_t num_symbols, const float* prior, int64_t prior_len, int method,
+                                        int hard_out, float* out, void* stream) {
+  SAMD_REQUIRE(y && no && points && prior && out, "null argument");
+  SAMD_REQUIRE(num_symbols >= 0 && (no_len == 1 || no_len == num_symbols), "no must be scalar or per symbol");
+  SAMD_REQUIRE(prior_len == m || prior_len == num_symbols * m, "prior must be [m] or [num_symbols, m]");
+  SAMD_REQUIRE(method == 0 || method == 1, "method must be 0 (app) or 1 (maxlog)");
+  if (num_symbols == 0) return SAMD_OK;
+  const dim3 grid(grid_for(num_symbols, 256));
+  int rc = method == 1 ? launch_demap<true>(m, grid, (hipStream_t)stream, (const float2*)y, no, no_len, (const float2*)points,
+                                            num_symbols, hard_out, out, prior, prior_len)
+                       : launch_demap<false>(m, grid, (hipStream_t)stream, (const float2*)y, no, no_len, (const float2*)points,
+                                             num_symbols, hard_out, out, prior, prior_len);
   if (rc != SAMD_OK) return rc;
   return launch_status();
 }

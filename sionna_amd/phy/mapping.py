@@ -235,7 +235,7 @@ class Mapper(Block):
 
 class Demapper(Block):
     """LLRs (logits) for every bit of every received symbol (reference mapping.py:521-691,
-    794-967).  ``call(y, no, prior=None)``; priors are not supported on the HIP path."""
+    794-967).  ``call(y, no, prior=None)``; ``prior``: LLRs [num_bits_per_symbol] or [..., n, num_bits_per_symbol]."""
 
     def __init__(self, demapping_method, constellation_type=None, num_bits_per_symbol=None,
                  constellation=None, hard_out=False, precision=None, **kwargs):
@@ -254,8 +254,6 @@ class Demapper(Block):
 
     def call(self, y, no, prior=None):
         self._require_single()
-        if prior is not None:
-            raise NotImplementedError("Demapper: prior information is outside the MI355X hot path")
         m = self._constellation.num_bits_per_symbol
         y = _ffi.to_device(y, torch.complex64)
         no = _ffi.to_device(no, torch.float32)
@@ -264,6 +262,18 @@ class Demapper(Block):
         else:
             no = torch.broadcast_to(no, y.shape).contiguous()
         out = torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] * m,), dtype=torch.float32, device=y.device)
+        if prior is not None:                                     # generic 2^m-point kernel with the a-priori term
+            prior = _ffi.to_device(prior, torch.float32)
+            if prior.dim() == 1:
+                assert prior.numel() == m, "prior must have num_bits_per_symbol entries"
+                prior = prior.contiguous()
+            else:
+                prior = torch.broadcast_to(prior, tuple(y.shape) + (m,)).contiguous()
+            _ffi.check(_ffi.lib().samd_qam_demap_prior_f32(
+                _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points()), m, y.numel(),
+                _ffi.ptr(prior), prior.numel(), 0 if self._method == "app" else 1, int(bool(self._hard_out)), _ffi.ptr(out),
+                _ffi.stream()), "Demapper(prior)")
+            return out
         lev = self._constellation.pam_levels() if self._separable else None
         if lev is not None:
             _ffi.check(_ffi.lib().samd_square_qam_demap_f32(

@@ -88,6 +88,28 @@ def test_demapper_vs_oracle(phy, m, method, separable):
         assert np.array_equal(hard[sure], (ref64 > 0).astype(np.float32)[sure])
 
 
+@pytest.mark.parametrize("m", [1, 2, 4, 6])
+@pytest.mark.parametrize("method", ["app", "maxlog"])
+def test_demapper_with_prior(phy, m, method):
+    """Demapper.call(y, no, prior) (mapping.py:664-691, 944-967)."""
+    rng = np.random.default_rng(m)
+    pts = omap.qam(m) if m > 1 else omap.pam(1).astype(np.complex64) if hasattr(omap, "pam") else np.array([1, -1], np.complex64)
+    ctype = "qam" if m > 1 else "pam"
+    y = (rng.normal(size=(7, 50)) + 1j * rng.normal(size=(7, 50))).astype(np.complex64)
+    no = rng.uniform(0.05, 1.0, (7, 50)).astype(np.float32)
+    dm = phy.mapping.Demapper(method, ctype, m)
+    pts = np.asarray(dm.constellation.points)
+    for prior in (rng.normal(size=m).astype(np.float32) * 2, rng.normal(size=(7, 50, m)).astype(np.float32) * 3):
+        got = _np(dm(y, no, prior))
+        ref = omap.demapper(y, no, pts, method, prior=prior)
+        assert np.allclose(got, ref, rtol=1e-4, atol=2e-4), np.max(np.abs(got - ref))
+    # a zero prior changes nothing; a strong prior dominates the decision
+    assert np.allclose(_np(dm(y, no, np.zeros(m, np.float32))), _np(dm(y, no)), rtol=1e-4, atol=2e-4)
+    strong = np.where(rng.integers(0, 2, m) > 0, 5000.0, -5000.0).astype(np.float32)
+    hard = _np(phy.mapping.Demapper(method, ctype, m, hard_out=True)(y, no, strong))
+    assert np.array_equal(hard.reshape(7, 50, m), np.broadcast_to(strong > 0, (7, 50, m)).astype(np.float32))
+
+
 def test_demapper_custom_constellation(phy):
     # a rotated / non-square constellation has no per-axis structure -> generic kernel
     rng = np.random.default_rng(2)
