@@ -235,6 +235,35 @@ def test_c4_chain_high_snr_is_error_free(phy):
     assert ber.numpy()[0] > 0.05 and ber.numpy()[1] == 0
 
 
+def test_c4_full_batch_properties(phy):
+    """Config C4 at BASELINE.json's full batch (8192): size-independent properties - BER falls with the SNR,
+    perfect CSI is never worse than LS estimation, noiseless transmission is error free."""
+    rg, _ = _grids(phy)
+    sm = phy.mimo.StreamManagement([[1]], 2)
+    k, n, m, B = 768, 1536, 2, 8192
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=20)
+    src, mapper, rgm = phy.mapping.BinarySource(), phy.mapping.Mapper("qam", m), phy.ofdm.ResourceGridMapper(rg)
+    ch = phy.channel.OFDMChannel(_tdl_params(phy), rg, normalize_channel=True, return_channel=True)
+    est, eq, demap = phy.ofdm.LSChannelEstimator(rg), phy.ofdm.LMMSEEqualizer(rg, sm), phy.mapping.Demapper("app", "qam", m)
+    remove = phy.ofdm.RemoveNulledSubcarriers(rg)
+    phy.config.seed = 21
+
+    def ber(ebno_db, perfect):
+        no = phy.utils.ebnodb2no(ebno_db, m, k / n, rg)
+        b = src([B, 1, 2, k])
+        y, h = ch(rgm(mapper(enc(b))), no)
+        h_hat, ev = (remove(h), 0.) if perfect else est(y, no)
+        x_hat, no_eff = eq(y, h_hat, ev, no)
+        return float((b != dec(demap(x_hat, no_eff))).float().mean())
+
+    ls = [ber(e, False) for e in (-6.0, -3.0, 0.0)]
+    pc = [ber(e, True) for e in (-6.0, -3.0, 0.0)]
+    assert ls[0] > ls[1] > ls[2] and pc[0] > pc[1] > pc[2]
+    assert all(p <= l for p, l in zip(pc, ls))
+    assert ber(40.0, True) == 0.0 and ber(40.0, False) == 0.0
+
+
 # ------------------------------------------------------------------ time-domain variant (rocFFT)
 def _cplx(rng, shape):
     return (rng.normal(size=shape) + 1j * rng.normal(size=shape)).astype(np.complex64)
