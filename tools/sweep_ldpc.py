@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Decode throughput of LDPC5GDecoder (min-sum, 20 iterations) over a set of 5G code sizes: which
+engine runs, lifting size, lane utilisation of the on-chip engine (Z / (64 ceil(Z/64))) and the rate.
+    python tools/sweep_ldpc.py > gpurun_out/ldpc_sweep.json"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sionna_amd.phy as phy
+from sionna_amd import _ffi
+
+_ffi.device()
+phy.config.seed = 1
+rows = []
+for k, n, bg in [(512, 1024, None), (768, 1536, None), (1024, 2048, "bg1"), (1500, 3000, None), (2048, 6144, "bg1"),
+                 (2816, 8448, "bg1"), (3840, 7680, None), (4096, 6144, None), (6144, 9216, None), (8448, 16896, None),
+                 (8448, 25344, None)]:
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, bg=bg)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=20)
+    B = int(min(65536, max(4096, 2 ** int(np.log2(5e8 / n)))))
+    u = phy.mapping.BinarySource()([B, k])
+    c = enc(u).as_subclass(torch.Tensor)
+    llr = (4.0 * (2 * c - 1) + 2.0 * torch.randn_like(c)).contiguous()
+    out = dec(llr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        dec(llr)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    z = enc.z
+    rows.append({"k": k, "n": n, "bg": enc._bg, "z": z, "engine": "on-chip" if dec._onchip_ok else "generic-hbm",
+                 "lane_utilisation": round(z / (64 * -(-z // 64)), 3), "batch": B, "ms": round(dt * 1e3, 2),
+                 "decodes_per_s": round(B / dt), "coded_gbit_per_s": round(B * n / dt / 1e9, 2),
+                 "ber": float((out != u).float().mean())})
+    print(rows[-1], file=sys.stderr)
+print(json.dumps({"sweep": "LDPC5GDecoder minsum 20 iterations", "rows": rows}))
