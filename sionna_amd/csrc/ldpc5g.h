@@ -27,12 +27,13 @@ struct samd_ldpc5g {
   int32_t* col_cls = nullptr;  // [nb]     unrolled class size (>= column degree)
   int32_t* cn_sched_ptr = nullptr; int32_t* cn_sched = nullptr;   // per-wave item lists (LPT balanced)
   int32_t* vn_sched_ptr = nullptr; int32_t* vn_sched = nullptr;
+  int dec_waves = 16;          // waves per workgroup of the on-chip decoder (16 / 8 / 4: small codes share a CU)
 };
 
 namespace samd {
 constexpr int kRowStride = 20;   // max row degree of BG1 is 19
 constexpr int kColStride = 32;   // max column degree of BG1 is 30
-constexpr int kDecWaves = 16;    // 1024-thread workgroup
+constexpr int kDecWaves = 16;    // waves of one CU's decoder workgroups (1 x 16, 2 x 8 or 4 x 4)
 // build the v2 tables (host); defined in ldpc5g_onchip.hip
 int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
 void free_onchip_tables(samd_ldpc5g* h);

@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned wrap_sub(unsigned zz4, unsigned s4, unsigned
 // NCH: number of consecutive 64-lane chunks of lifted copies handled by the wave in one pass
 // (lane z and lane z+64 share every scalar): two independent dependency chains per wave hide
 // LDS latency at 4 waves / SIMD and halve the per-item scalar work.
-template <int D, int NCH, bool OFFSET, bool POW2, bool FUSE1>
+template <int D, int NCH, bool POW2, bool FUSE1>
 __device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned zz4, unsigned zw, unsigned cn4,
                                        const char* __restrict__ xt_b, const char* __restrict__ llr_b,
                                        char* __restrict__ m12_b, char* __restrict__ pk_b, float llr_max,
@@ -114,7 +114,7 @@ __device__ __forceinline__ void cn_row(const int32_t* __restrict__ ent, unsigned
     // unique minimum <=> min2 > min1; (min2 - min1) + min1 is the reference's arithmetic (:863)
     const float min_e = (min2[h] > min1) ? ((min2[h] - min1) + min1) : min1;
     float a1 = min1, a2 = min_e;
-    if constexpr (OFFSET) { a1 -= offset; a2 -= offset; }
+    a1 -= offset; a2 -= offset;                                   // plain min-sum: offset = 0 (exact)
     a1 = med3(a1, 0.f, llr_max);
     a2 = med3(a2, 0.f, llr_max);
     // neg holds sign(v2c_i) at bit D-1-i; own sign x node sign, then MSB-first
@@ -181,11 +181,11 @@ __device__ __forceinline__ void vn_item(const int32_t* __restrict__ ent, int nfu
   }
 }
 
-template <int NCH, bool OFFSET, bool POW2>
+template <int NCH, bool POW2>
 __device__ __forceinline__ void cn_item(int desc, const int32_t* __restrict__ ent, unsigned zz4, unsigned zw,
                                         unsigned cn4, const char* xt_b, const char* llr_b, char* m12_b, char* pk_b,
                                         float llr_max, float offset) {
-#define SAMD_CN(D, F) case D: cn_row<D, NCH, OFFSET, POW2, F>(ent, zz4, zw, cn4, xt_b, llr_b, m12_b, pk_b, llr_max, offset); break
+#define SAMD_CN(D, F) case D: cn_row<D, NCH, POW2, F>(ent, zz4, zw, cn4, xt_b, llr_b, m12_b, pk_b, llr_max, offset); break
   if ((desc >> 24) & 1) {                                   // last edge fused with its degree-1 VN
     switch ((desc >> 16) & 0xFF) {
       SAMD_CN(3, true); SAMD_CN(4, true); SAMD_CN(5, true); SAMD_CN(6, true); SAMD_CN(7, true);
@@ -202,8 +202,11 @@ __device__ __forceinline__ void cn_item(int desc, const int32_t* __restrict__ en
 #undef SAMD_CN
 }
 
-template <bool OFFSET, bool POW2>
-__global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
+// NW = waves per workgroup.  One workgroup owns one codeword; codes whose state needs <= 80 / <= 40 KB of
+// LDS run as 2 x 8 / 4 x 4 waves per CU: the per-wave item lists get longer (better balance) and the two
+// barriers per iteration only synchronise the waves of one codeword.
+template <bool POW2, int NW>
+__global__ __launch_bounds__(NW * 64) void ldpc5g_decode_v2_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, RateMatch p, int n_cn, int ncu, int nbu, int batch,
     int num_iter, float llr_max, float offset, int hard_out, int return_infobits,
     const int32_t* __restrict__ row_pad, const int32_t* __restrict__ row_deg, const int32_t* __restrict__ col_pad,
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
     const int32_t* __restrict__ cn_sched, const int32_t* __restrict__ vn_sched_ptr,
     const int32_t* __restrict__ vn_sched) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int NT = kDecWaves * 64;
+  constexpr int NT = NW * 64;
   const unsigned z = (unsigned)p.z;
   const unsigned zw = POW2 ? 4u * z - 1u : 4u * z;
   const int n_vn = p.n_vn;
@@ -250,9 +253,9 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
         const unsigned cn = (unsigned)r * z + zz;
         const int32_t* ent = row_pad + r * kRowStride;
         if ((desc >> 25) & 1) {
-          cn_item<2, OFFSET, POW2>(desc, ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset);
+          cn_item<2, POW2>(desc, ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset);
         } else if (zz < z && cn < (unsigned)n_cn) {
-          cn_item<1, OFFSET, POW2>(desc, ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset);
+          cn_item<1, POW2>(desc, ent, 4u * zz, zw, 4u * cn, xt_b, llr_b, m12_b, pk_b, llr_max, offset);
         }
       }
       __syncthreads();
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(kDecWaves * 64) void ldpc5g_decode_v2_kernel(
     }
     if (!return_infobits) {
       // totals of the fused degree-1 VNs are only needed for the codeword output: one class-1 pass
-      for (int t = vn_sched_ptr[kDecWaves + 1 + w]; t < vn_sched_ptr[kDecWaves + 2 + w]; ++t) {
+      for (int t = vn_sched_ptr[NW + 1 + w]; t < vn_sched_ptr[NW + 2 + w]; ++t) {
         const int desc = __builtin_amdgcn_readfirstlane(vn_sched[t]);
         const int c = desc & 0xFF;
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
@@ -309,13 +312,13 @@ static const int kCnDegrees[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
 static const int kVnRemClasses[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14};   // remainder after full chunks of 16
 
 // longest-processing-time-first assignment of items to the waves of the workgroup
-static void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, std::vector<int32_t>* ptr,
+static void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, int nw, std::vector<int32_t>* ptr,
                          std::vector<int32_t>* list) {
   std::vector<size_t> order(items.size());
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].first > items[b].first; });
-  std::vector<std::vector<int32_t>> per(kDecWaves);
-  std::vector<long> load(kDecWaves, 0);
+  std::vector<std::vector<int32_t>> per(nw);
+  std::vector<long> load(nw, 0);
   for (size_t i : order) {
     const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
     per[w].push_back(items[i].second);
@@ -323,7 +326,7 @@ static void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, std:
   }
   ptr->assign(1, 0);
   list->clear();
-  for (int w = 0; w < kDecWaves; ++w) {
+  for (int w = 0; w < nw; ++w) {
     list->insert(list->end(), per[w].begin(), per[w].end());
     ptr->push_back((int32_t)list->size());
   }
@@ -399,9 +402,19 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
     }
   // vn_sched_ptr = [16+1 offsets of the per-iteration lists | 16+1 offsets of the final degree-1 pass]
   std::vector<int32_t> cp, cl, vp, vl, v1p, v1l;
-  lpt_schedule(ci, &cp, &cl);
-  lpt_schedule(vi, &vp, &vl);
-  lpt_schedule(v1i, &v1p, &v1l);
+  // waves per workgroup from the LDS footprint: as many codewords per CU as fit, 16 waves in total
+  const size_t lds = ((size_t)2 * h->nbu + (size_t)3 * (h->ncu + 1)) * z * 4;
+  h->dec_waves = 16;
+  for (int nwc : {8, 4, 2, 1})
+    if (lds * (size_t)(kDecWaves / nwc) <= 160 * 1024) h->dec_waves = nwc;
+  if (const char* e = getenv("SAMD_ONCHIP_WAVES")) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_waves = v;      // experiments: force a workgroup size
+  }
+  const int nw = h->dec_waves;
+  lpt_schedule(ci, nw, &cp, &cl);
+  lpt_schedule(vi, nw, &vp, &vl);
+  lpt_schedule(v1i, nw, &v1p, &v1l);
   for (int32_t o : v1p) vp.push_back(o + (int32_t)vl.size());
   vl.insert(vl.end(), v1l.begin(), v1l.end());
   if (vl.empty()) vl.push_back(0);
@@ -433,10 +446,14 @@ int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int bat
   typedef void (*kern_t)(const float*, float*, RateMatch, int, int, int, int, int, float, float, int, int,
                          const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                          const int32_t*, const int32_t*, const int32_t*);
-  static const kern_t kerns[4] = {ldpc5g_decode_v2_kernel<false, false>, ldpc5g_decode_v2_kernel<false, true>,
-                                  ldpc5g_decode_v2_kernel<true, false>, ldpc5g_decode_v2_kernel<true, true>};
-  const int ki = (off ? 2 : 0) | (pow2 ? 1 : 0);
-  static bool attr_set[4] = {false, false, false, false};
+  static const kern_t kerns[10] = {
+      ldpc5g_decode_v2_kernel<false, 16>, ldpc5g_decode_v2_kernel<true, 16>, ldpc5g_decode_v2_kernel<false, 8>,
+      ldpc5g_decode_v2_kernel<true, 8>,   ldpc5g_decode_v2_kernel<false, 4>, ldpc5g_decode_v2_kernel<true, 4>,
+      ldpc5g_decode_v2_kernel<false, 2>,  ldpc5g_decode_v2_kernel<true, 2>,  ldpc5g_decode_v2_kernel<false, 1>,
+      ldpc5g_decode_v2_kernel<true, 1>};
+  const int nw = h->dec_waves;
+  const int ki = (nw == 16 ? 0 : nw == 8 ? 2 : nw == 4 ? 4 : nw == 2 ? 6 : 8) | (pow2 ? 1 : 0);
+  static bool attr_set[10] = {};
   if (!attr_set[ki]) {
     SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[ki] = true;
@@ -444,10 +461,10 @@ int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int bat
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const size_t per_cu = std::min<size_t>(2, std::max<size_t>(1, (160 * 1024) / lds));
+  const size_t per_cu = std::min<size_t>((size_t)(kDecWaves / nw), std::max<size_t>(1, (160 * 1024) / lds));
   const int grid = (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
-  hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(kDecWaves * 64), lds, st, llr, out, rm, h->n_cn, h->ncu, h->nbu, batch,
+  hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(nw * 64), lds, st, llr, out, rm, h->n_cn, h->ncu, h->nbu, batch,
                      num_iter, llr_max, (off ? offset : 0.f), hard_out, return_infobits, h->row_pad, h->row_deg,
                      h->col_pad, h->col_cls, h->cn_sched_ptr, h->cn_sched, h->vn_sched_ptr, h->vn_sched);
   return launch_status();
