@@ -130,8 +130,10 @@ size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int
 /* Whole LDPC5GDecoder.call on chip: rate recovery + num_iter flooding BP iterations +
  * output mapping in ONE kernel, one codeword per workgroup, messages resident in LDS
  * (min-sum family: compressed check-node state).  cn_mode must be SAMD_CN_MINSUM or
- * SAMD_CN_OFFSET_MINSUM; returns SAMD_ERR_UNSUPPORTED when the code does not fit in
- * LDS (caller then uses rate_recover + samd_ldpc_bp_decode_f32 + extract).
+ * SAMD_CN_OFFSET_MINSUM; returns SAMD_ERR_UNSUPPORTED when the code cannot be scheduled
+ * on chip (caller then uses rate_recover + samd_ldpc_bp_decode_f32 + extract).  Codes whose state
+ * exceeds 160 KB keep the channel LLRs, then the VN totals, then the sign words in `workspace`
+ * (samd_ldpc5g_decode_workspace_bytes() > 0; one L2-resident row per workgroup); results are identical.
  * llr [batch,n] logits -> out [batch,k] (return_infobits=1) or [batch,n] (=0). */
 int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
                            int batch, int num_iter, int cn_mode, float llr_max,

@@ -28,6 +28,7 @@ struct samd_ldpc5g {
   int32_t* cn_sched_ptr = nullptr; int32_t* cn_sched = nullptr;   // per-wave item lists (LPT balanced)
   int32_t* vn_sched_ptr = nullptr; int32_t* vn_sched = nullptr;
   int dec_waves = 16;          // waves per workgroup of the on-chip decoder (16 / 8 / 4: small codes share a CU)
+  int llr_global = 0;          // 1: channel LLRs in the caller's workspace (L2) instead of LDS (larger codes fit)
 };
 
 namespace samd {
@@ -37,8 +38,10 @@ constexpr int kDecWaves = 16;    // waves of one CU's decoder workgroups (1 x 16
 // build the v2 tables (host); defined in ldpc5g_onchip.hip
 int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
 void free_onchip_tables(samd_ldpc5g* h);
+size_t onchip_workspace_bytes(const samd_ldpc5g* h, int batch);
 int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
-                     float llr_max, float offset, int hard_out, int return_infobits, hipStream_t st);
+                     float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
+                     size_t workspace_bytes, hipStream_t st);
 }
 
 namespace samd {

@@ -361,14 +361,14 @@ extern "C" int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const fl
 }
 
 extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode) {
-  (void)h; (void)batch; (void)cn_mode;
-  return 0;  // the on-chip decoder keeps its whole state in LDS
+  (void)cn_mode;
+  // 0 when the whole state fits in LDS; larger codes keep their channel LLRs in this (L2-resident) scratch
+  return h ? onchip_workspace_bytes(h, batch) : 0;
 }
 
 extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out, int batch, int num_iter,
                                       int cn_mode, float llr_max, float offset, int hard_out, int return_infobits,
                                       void* workspace, size_t workspace_bytes, void* stream) {
-  (void)workspace; (void)workspace_bytes;
   SAMD_REQUIRE(h && llr && out && batch > 0 && num_iter >= 0, "bad argument");
   if (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM) {
     set_error("on-chip decoder implements the min-sum family only");
@@ -383,7 +383,7 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   }
   if (h->v2_ok && !getenv("SAMD_ONCHIP_V1")) {   // statically scheduled, unrolled engine
     const int rc = launch_onchip_v2(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out,
-                                    return_infobits, (hipStream_t)stream);
+                                    return_infobits, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
   if (lds > 160 * 1024) {

@@ -205,9 +205,15 @@ __device__ __forceinline__ void cn_item(int desc, const int32_t* __restrict__ en
 // NW = waves per workgroup.  One workgroup owns one codeword; codes whose state needs <= 80 / <= 40 KB of
 // LDS run as 2 x 8 / 4 x 4 waves per CU: the per-wave item lists get longer (better balance) and the two
 // barriers per iteration only synchronise the waves of one codeword.
-template <bool POW2, int NW>
+// LLRG: the clipped channel LLRs live in the caller's workspace (one nbu*Z row per workgroup, L2 resident:
+// read once per VN and iteration) instead of LDS - codes up to (nbu + 3 (ncu+1)) Z 4 <= 160 KB fit.
+// XTG (with LLRG): the variable-node totals x_tot live in the workspace too; LDS then only holds the
+// compressed check-node state, 12 (ncu+1) Z bytes - every 5G code with rate >= ~0.45 at Z = 384 fits.
+// PKG (with XTG): the packed sign / min-position words move out as well; LDS = (M1, M2) only, 8 (ncu+1) Z
+// bytes <= 144 KB for every 5G code.
+template <bool POW2, int NW, bool LLRG = false, bool XTG = false, bool PKG = false>
 __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_v2_kernel(
-    const float* __restrict__ llr_in, float* __restrict__ out, RateMatch p, int n_cn, int ncu, int nbu, int batch,
+    const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ llr_ws, RateMatch p, int n_cn, int ncu, int nbu, int batch,
     int num_iter, float llr_max, float offset, int hard_out, int return_infobits,
     const int32_t* __restrict__ row_pad, const int32_t* __restrict__ row_deg, const int32_t* __restrict__ col_pad,
     const int32_t* __restrict__ col_cls, const int32_t* __restrict__ cn_sched_ptr,
@@ -219,10 +225,12 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_v2_kernel(
   const unsigned zw = POW2 ? 4u * z - 1u : 4u * z;
   const int n_vn = p.n_vn;
   const int nx = nbu * (int)z, ns = (ncu + 1) * (int)z;
-  float* xt = smem;
-  float* llr = xt + nx;
-  float2* m12 = reinterpret_cast<float2*>(llr + nx);
-  unsigned* pk = reinterpret_cast<unsigned*>(m12 + ns);
+  // workspace row of a workgroup: [llr nx | xt nx | pk ns] (only the parts that are global)
+  float* wsrow = llr_ws + (size_t)blockIdx.x * ((size_t)(XTG ? 2 : 1) * nx + (PKG ? ns : 0));
+  float* xt = XTG ? wsrow + nx : smem;
+  float* llr = LLRG ? wsrow : xt + nx;
+  float2* m12 = reinterpret_cast<float2*>(XTG ? smem : (LLRG ? smem + nx : smem + 2 * nx));
+  unsigned* pk = PKG ? reinterpret_cast<unsigned*>(wsrow + 2 * nx) : reinterpret_cast<unsigned*>(m12 + ns);
   const char* xt_b = reinterpret_cast<const char*>(xt);
   const char* llr_b = reinterpret_cast<const char*>(llr);
   char* m12_b = reinterpret_cast<char*>(m12);
@@ -403,7 +411,18 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
   // vn_sched_ptr = [16+1 offsets of the per-iteration lists | 16+1 offsets of the final degree-1 pass]
   std::vector<int32_t> cp, cl, vp, vl, v1p, v1l;
   // waves per workgroup from the LDS footprint: as many codewords per CU as fit, 16 waves in total
-  const size_t lds = ((size_t)2 * h->nbu + (size_t)3 * (h->ncu + 1)) * z * 4;
+  size_t lds = ((size_t)2 * h->nbu + (size_t)3 * (h->ncu + 1)) * z * 4;
+  h->llr_global = 0;
+  if (lds > 160 * 1024 && ((size_t)h->nbu + (size_t)3 * (h->ncu + 1)) * z * 4 <= 160 * 1024) {
+    h->llr_global = 1;                                          // channel LLRs move to the workspace (L2)
+    lds = ((size_t)h->nbu + (size_t)3 * (h->ncu + 1)) * z * 4;
+  } else if (lds > 160 * 1024 && (size_t)3 * (h->ncu + 1) * z * 4 <= 160 * 1024 && !getenv("SAMD_NO_XTG")) {
+    h->llr_global = 2;                                          // x_tot as well: LDS = check-node state only
+    lds = (size_t)3 * (h->ncu + 1) * z * 4;
+  } else if (lds > 160 * 1024 && (size_t)2 * (h->ncu + 1) * z * 4 <= 160 * 1024 && !getenv("SAMD_NO_XTG")) {
+    h->llr_global = 3;                                          // ... and the sign words: LDS = (M1, M2)
+    lds = (size_t)2 * (h->ncu + 1) * z * 4;
+  }
   h->dec_waves = 16;
   for (int nwc : {8, 4, 2, 1})
     if (lds * (size_t)(kDecWaves / nwc) <= 160 * 1024) h->dec_waves = nwc;
@@ -434,37 +453,65 @@ void free_onchip_tables(samd_ldpc5g* h) {
   (void)hipFree(h->cn_sched_ptr); (void)hipFree(h->cn_sched); (void)hipFree(h->vn_sched_ptr); (void)hipFree(h->vn_sched);
 }
 
+// llr_global: 0 all in LDS; 1 LLRs in L2; 2 LLRs and x_tot in L2; 3 also the packed sign words (LDS = M1, M2)
+static size_t onchip_lds_bytes(const samd_ldpc5g* h) {
+  const int g = h->llr_global;
+  return ((size_t)(g >= 2 ? 0 : 2 - g) * h->nbu + (size_t)(g == 3 ? 2 : 3) * (h->ncu + 1)) * h->z * 4;
+}
+
+static int onchip_grid(const samd_ldpc5g* h, int batch) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t per_cu = std::min<size_t>((size_t)(kDecWaves / h->dec_waves), std::max<size_t>(1, (160 * 1024) / onchip_lds_bytes(h)));
+  return (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+}
+
+size_t onchip_workspace_bytes(const samd_ldpc5g* h, int batch) {
+  if (!h->v2_ok || !h->llr_global || batch <= 0) return 0;
+  const size_t row = (size_t)std::min(h->llr_global, 2) * h->nbu * h->z + (h->llr_global == 3 ? (size_t)(h->ncu + 1) * h->z : 0);
+  return (size_t)onchip_grid(h, batch) * row * sizeof(float) + 256;
+}
+
 int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
-                     float llr_max, float offset, int hard_out, int return_infobits, hipStream_t st) {
-  const size_t lds = ((size_t)2 * h->nbu + (size_t)3 * (h->ncu + 1)) * h->z * 4;
+                     float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
+                     size_t workspace_bytes, hipStream_t st) {
+  const size_t lds = onchip_lds_bytes(h);
   if (lds > 160 * 1024) {
     set_error("code does not fit in LDS");
     return SAMD_ERR_UNSUPPORTED;
   }
+  float* llr_ws = nullptr;
+  if (h->llr_global) {
+    if (!workspace || workspace_bytes < onchip_workspace_bytes(h, batch)) {
+      set_error("workspace too small (samd_ldpc5g_decode_workspace_bytes)");
+      return SAMD_ERR_WORKSPACE;
+    }
+    llr_ws = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
+  }
   const bool off = (cn_mode == SAMD_CN_OFFSET_MINSUM);
   const bool pow2 = (h->z & (h->z - 1)) == 0;
-  typedef void (*kern_t)(const float*, float*, RateMatch, int, int, int, int, int, float, float, int, int,
+  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, int, int, float, float, int, int,
                          const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
                          const int32_t*, const int32_t*, const int32_t*);
-  static const kern_t kerns[10] = {
+  static const kern_t kerns[16] = {
       ldpc5g_decode_v2_kernel<false, 16>, ldpc5g_decode_v2_kernel<true, 16>, ldpc5g_decode_v2_kernel<false, 8>,
       ldpc5g_decode_v2_kernel<true, 8>,   ldpc5g_decode_v2_kernel<false, 4>, ldpc5g_decode_v2_kernel<true, 4>,
       ldpc5g_decode_v2_kernel<false, 2>,  ldpc5g_decode_v2_kernel<true, 2>,  ldpc5g_decode_v2_kernel<false, 1>,
-      ldpc5g_decode_v2_kernel<true, 1>};
+      ldpc5g_decode_v2_kernel<true, 1>,   ldpc5g_decode_v2_kernel<false, 16, true>, ldpc5g_decode_v2_kernel<true, 16, true>,
+      ldpc5g_decode_v2_kernel<false, 16, true, true>, ldpc5g_decode_v2_kernel<true, 16, true, true>,
+      ldpc5g_decode_v2_kernel<false, 16, true, true, true>, ldpc5g_decode_v2_kernel<true, 16, true, true, true>};
   const int nw = h->dec_waves;
-  const int ki = (nw == 16 ? 0 : nw == 8 ? 2 : nw == 4 ? 4 : nw == 2 ? 6 : 8) | (pow2 ? 1 : 0);
-  static bool attr_set[10] = {};
+  const int ki = h->llr_global ? 8 + 2 * h->llr_global + (pow2 ? 1 : 0)
+                               : ((nw == 16 ? 0 : nw == 8 ? 2 : nw == 4 ? 4 : nw == 2 ? 6 : 8) | (pow2 ? 1 : 0));
+  static bool attr_set[16] = {};
   if (!attr_set[ki]) {
     SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set[ki] = true;
   }
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const size_t per_cu = std::min<size_t>((size_t)(kDecWaves / nw), std::max<size_t>(1, (160 * 1024) / lds));
-  const int grid = (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+  const int grid = onchip_grid(h, batch);
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
-  hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(nw * 64), lds, st, llr, out, rm, h->n_cn, h->ncu, h->nbu, batch,
+  hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(nw * 64), lds, st, llr, out, llr_ws, rm, h->n_cn, h->ncu, h->nbu, batch,
                      num_iter, llr_max, (off ? offset : 0.f), hard_out, return_infobits, h->row_pad, h->row_deg,
                      h->col_pad, h->col_cls, h->cn_sched_ptr, h->cn_sched, h->vn_sched_ptr, h->vn_sched);
   return launch_status();

@@ -305,10 +305,13 @@ class LDPC5GDecoder(LDPCBPDecoder):
         enc = self._encoder
         out_cols = enc.k if self._return_infobits else enc.n
         out = torch.empty((llr2d.shape[0], out_cols), dtype=torch.float32, device=llr2d.device)
-        rc = _ffi.lib().samd_ldpc5g_decode_f32(
-            enc._handle(self._nb_pruned_nodes), _ffi.ptr(llr2d), _ffi.ptr(out), llr2d.shape[0], int(num_iter),
+        lib, h = _ffi.lib(), enc._handle(self._nb_pruned_nodes)
+        need = lib.samd_ldpc5g_decode_workspace_bytes(h, llr2d.shape[0], self._cn_mode)   # 0 unless the LLRs live in L2
+        ws, ws_bytes = self._ws.get(need) if need else (None, 0)
+        rc = lib.samd_ldpc5g_decode_f32(
+            h, _ffi.ptr(llr2d), _ffi.ptr(out), llr2d.shape[0], int(num_iter),
             self._cn_mode, self._llr_max, self._offset, int(self._hard_out), int(self._return_infobits),
-            None, 0, _ffi.stream())
+            _ffi.ptr(ws), ws_bytes, _ffi.stream())
         if rc == _ffi.ERR_UNSUPPORTED:
             self._onchip_ok = False
             return None

@@ -338,7 +338,9 @@ def test_layered_5g_vs_oracle_and_convergence(phy):
 
 # ------------------------------------------------------------------ 5G decoder (both engines)
 CODES5G = [(64, 128, None, None), (200, 600, None, 2), (1024, 2048, "bg1", None), (500, 1000, None, 4),
-           (2816, 8448, "bg1", 6)]
+           (2816, 8448, "bg1", 6),
+           (4224, 12672, "bg1", None), (7040, 14080, None, 4),      # on-chip with the channel LLRs in L2 (workspace)
+           (8448, 16896, None, 2)]                                  # ... and the VN totals as well
 
 
 def _noisy_llr(code, batch, seed, sigma=0.8):
@@ -416,8 +418,8 @@ def test_5g_boxplus_vs_oracle(phy, k, n, bg, m, cn):
     assert np.array_equal(_np(phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, return_infobits=False)(llr)), c)
 
 
-def test_5g_large_z_falls_back_to_generic(phy):
-    # Z=384, rate 1/3: does not fit in LDS -> generic engine, still bit-exact
+def test_5g_large_z_rate_third_on_chip(phy):
+    # Z=384, rate 1/3: only (M1, M2) stay in LDS, LLRs / VN totals / sign words live in the L2 workspace
     k, n = 8448, 25344
     code = LDPC5GCode(k, n)
     enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
@@ -425,7 +427,7 @@ def test_5g_large_z_falls_back_to_generic(phy):
     dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=5)
     odec = obp.LDPC5GDecoder(code, cn_update="minsum", hard_out=False, num_iter=5)
     got = _np(dec(llr))
-    assert not dec._onchip_ok
+    assert dec._onchip_ok and dec._ws is not None
     assert np.array_equal(got, cbind.bp_decode(odec, odec.rate_recover(llr))[:, :k])
 
 
