@@ -1,6 +1,8 @@
 // Shared declarations of the 5G-NR QC-LDPC kernels (handle layout, rate-matching index maps).
 #pragma once
 #include "common.h"
+#include <algorithm>
+#include <numeric>
 #include <utility>
 #include <vector>
 
@@ -27,6 +29,13 @@ struct samd_ldpc5g {
   int32_t* col_cls = nullptr;  // [nb]     unrolled class size (>= column degree)
   int32_t* cn_sched_ptr = nullptr; int32_t* cn_sched = nullptr;   // per-wave item lists (LPT balanced)
   int32_t* vn_sched_ptr = nullptr; int32_t* vn_sched = nullptr;
+  // ---- on-chip boxplus / boxplus-phi engine (csrc/ldpc5g_onchip_bp.hip): one float per edge in LDS
+  int bp_ok = 0, bp_waves = 16, bp_llr_global = 0, bp_edges = 0;   // bp_edges: base-graph edges of the used rows
+  int32_t* bp_row_off = nullptr;   // [mb]     byte offset of the row's first edge block (blocks are Z floats) | degree << 18
+  int32_t* bp_col_ent = nullptr;   // [nb*32]  (edge block byte offset) | (4*shift) << 18, rows ascending
+  int32_t* bp_col_deg = nullptr;   // [nb]
+  int32_t* bp_cn_ptr = nullptr; int32_t* bp_cn_list = nullptr;     // per-wave item lists (LPT balanced)
+  int32_t* bp_vn_ptr = nullptr; int32_t* bp_vn_list = nullptr;
   int dec_waves = 16;          // waves per workgroup of the on-chip decoder (16 / 8 / 4: small codes share a CU)
   int llr_global = 0;          // 1: channel LLRs in the caller's workspace (L2) instead of LDS (larger codes fit)
 };
@@ -39,12 +48,39 @@ constexpr int kDecWaves = 16;    // waves of one CU's decoder workgroups (1 x 16
 int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
 void free_onchip_tables(samd_ldpc5g* h);
 size_t onchip_workspace_bytes(const samd_ldpc5g* h, int batch);
+int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
+void free_onchip_bp_tables(samd_ldpc5g* h);
+size_t onchip_bp_workspace_bytes(const samd_ldpc5g* h, int batch);
+int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                     float llr_max, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes,
+                     hipStream_t st);
 int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
                      size_t workspace_bytes, hipStream_t st);
 }
 
 namespace samd {
+
+// longest-processing-time-first assignment of items to the waves of the workgroup
+inline void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, int nw, std::vector<int32_t>* ptr,
+                         std::vector<int32_t>* list) {
+  std::vector<size_t> order(items.size());
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].first > items[b].first; });
+  std::vector<std::vector<int32_t>> per(nw);
+  std::vector<long> load(nw, 0);
+  for (size_t i : order) {
+    const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+    per[w].push_back(items[i].second);
+    load[w] += items[i].first + 3;                       // + fixed per-item overhead
+  }
+  ptr->assign(1, 0);
+  list->clear();
+  for (int w = 0; w < nw; ++w) {
+    list->insert(list->end(), per[w].begin(), per[w].end());
+    ptr->push_back((int32_t)list->size());
+  }
+}
 
 // ------------------------------------------------------------------ index maps (shared)
 struct RateMatch {

@@ -312,6 +312,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   if (rc == SAMD_OK) rc = upload(&h->cn_items, cn_items.data(), cn_items.size());
   if (rc == SAMD_OK) rc = upload(&h->vn_items, vn_items.data(), vn_items.size());
   if (rc == SAMD_OK) rc = build_onchip_tables(h, by_row);
+  if (rc == SAMD_OK) rc = build_onchip_bp_tables(h, by_row);
   if (rc != SAMD_OK) { samd_ldpc5g_destroy(h); return rc; }
   *out = h;
   return SAMD_OK;
@@ -322,6 +323,7 @@ extern "C" void samd_ldpc5g_destroy(samd_ldpc5g_t* h) {
   (void)hipFree(h->row_ptr); (void)hipFree(h->row_ent); (void)hipFree(h->col_ptr); (void)hipFree(h->col_ent);
   (void)hipFree(h->cn_items); (void)hipFree(h->vn_items);
   free_onchip_tables(h);
+  free_onchip_bp_tables(h);
   delete h;
 }
 
@@ -361,17 +363,23 @@ extern "C" int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const fl
 }
 
 extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode) {
-  (void)cn_mode;
-  // 0 when the whole state fits in LDS; larger codes keep their channel LLRs in this (L2-resident) scratch
-  return h ? onchip_workspace_bytes(h, batch) : 0;
+  // 0 when the whole state fits in LDS; larger codes keep part of it in this (L2-resident) scratch
+  if (!h) return 0;
+  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) return onchip_bp_workspace_bytes(h, batch);
+  return onchip_workspace_bytes(h, batch);
 }
 
 extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out, int batch, int num_iter,
                                       int cn_mode, float llr_max, float offset, int hard_out, int return_infobits,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   SAMD_REQUIRE(h && llr && out && batch > 0 && num_iter >= 0, "bad argument");
+  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) {   // one float per edge in LDS
+    SAMD_REQUIRE(llr_max >= 0.f, "bad argument");
+    return launch_onchip_bp(h, llr, out, batch, num_iter, cn_mode, llr_max, hard_out, return_infobits, workspace,
+                            workspace_bytes, (hipStream_t)stream);
+  }
   if (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM) {
-    set_error("on-chip decoder implements the min-sum family only");
+    set_error("unknown cn_mode");
     return SAMD_ERR_UNSUPPORTED;
   }
   const size_t lds = decode_lds_bytes(h);

@@ -319,27 +319,6 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_v2_kernel(
 static const int kCnDegrees[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
 static const int kVnRemClasses[] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 14};   // remainder after full chunks of 16
 
-// longest-processing-time-first assignment of items to the waves of the workgroup
-static void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, int nw, std::vector<int32_t>* ptr,
-                         std::vector<int32_t>* list) {
-  std::vector<size_t> order(items.size());
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].first > items[b].first; });
-  std::vector<std::vector<int32_t>> per(nw);
-  std::vector<long> load(nw, 0);
-  for (size_t i : order) {
-    const int w = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-    per[w].push_back(items[i].second);
-    load[w] += items[i].first + 3;                       // + fixed per-item overhead
-  }
-  ptr->assign(1, 0);
-  list->clear();
-  for (int w = 0; w < nw; ++w) {
-    list->insert(list->end(), per[w].begin(), per[w].end());
-    ptr->push_back((int32_t)list->size());
-  }
-}
-
 int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row) {
   const int z = h->z;
   h->ncu = (h->n_cn + z - 1) / z;

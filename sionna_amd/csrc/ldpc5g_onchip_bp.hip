@@ -1,0 +1,306 @@
+// On-chip flooding decoder for 5G-NR LDPC codes with the boxplus-phi (reference default) and
+// boxplus (tanh) check-node rules: one float per edge, resident in LDS for all iterations.
+//
+// Replaces LDPC5GDecoder.call = rate recovery + LDPCBPDecoder._bp_iter x num_iter + cn_update_phi /
+// cn_update_tanh + vn_update_sum + output mapping (reference src/sionna/phy/fec/ldpc/decoding.py:
+// 1427-1536, 416-524, 681-732, 955-1166) for codes whose E 4-byte messages fit in 160 KB - C2
+// (n=8448, rate 1/3, Z=128: 316 Z edges = 158 KB, channel LLRs in an L2 workspace row) and everything
+// smaller.  The HBM-resident engine (ldpc_bp_generic.hip) moves 16 E + 4 N bytes per codeword and
+// iteration through HBM and sits at ~41 % of the HBM roofline; here the messages never leave the CU.
+//
+// Layout: edge block e = (row r, position i in the row) holds msg[e][zr], zr = lifted copy of the
+// CHECK node - the CN phase reads/writes lane-contiguous rows, the VN phase of column c reads the block
+// rotated by the edge's shift.  A message slot holds v2c after the VN phase and c2v after the CN phase
+// (in place, like the HBM engine).  Arithmetic and summation order are those of ldpc_bp_generic.hip
+// (bp_math.h: ascending VN inside a CN, ascending CN inside a VN, channel LLR last), so the two engines
+// return the same bits.
+//
+// Work split: (row, 64-lane chunk) and (column, chunk) items are assigned to the waves on the host
+// (longest-processing-time first); every item is an instantiation for the row's exact degree / the
+// column's degree class, all table entries are wave-uniform scalars.
+#include "ldpc5g.h"
+#include "bp_math.h"
+
+namespace samd {
+
+template <bool POW2>
+__device__ __forceinline__ unsigned bp_wrap_sub(unsigned zz4, unsigned s4, unsigned zw) {
+  const unsigned t = zz4 - s4;
+  return POW2 ? (t & zw) : min(t, t + zw);
+}
+
+// one check node per lane: row of exact degree D; its messages are D lane-contiguous blocks
+template <int MODE, int D>
+__device__ __forceinline__ void bp_cn_row(char* __restrict__ msg_b, unsigned a0, unsigned z4, float llr_max) {
+  float v[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) v[i] = *reinterpret_cast<const float*>(msg_b + a0 + (unsigned)i * z4);
+  cn_update_col<MODE, D>(v, D, llr_max, 0.f);
+#pragma unroll
+  for (int i = 0; i < D; ++i) *reinterpret_cast<float*>(msg_b + a0 + (unsigned)i * z4) = v[i];
+}
+
+// one variable node per lane: column of degree d <= DMAX.  ent[i] = block byte offset | (4 shift) << 18.
+// INIT: v2c of iteration 0 = channel LLR (decoding.py:571).  LAST: the marginal replaces the channel LLR.
+template <int DMAX, bool POW2, bool INIT>
+__device__ __forceinline__ void bp_vn_col(const int32_t* __restrict__ ent, int d, unsigned zz4, unsigned zw,
+                                          char* __restrict__ msg_b, float* __restrict__ llr_v, float llr_max,
+                                          bool last) {
+  unsigned a[DMAX];
+  float c[DMAX];
+  const float l = *llr_v;
+  float x = 0.f;
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i)
+    if (i < d) {
+      const unsigned e = (unsigned)ent[i];
+      a[i] = (e & 0x3FFFFu) + bp_wrap_sub<POW2>(zz4, e >> 18, zw);
+      if (INIT) {
+        *reinterpret_cast<float*>(msg_b + a[i]) = l;
+      } else {
+        c[i] = *reinterpret_cast<const float*>(msg_b + a[i]);
+        x += c[i];
+      }
+    }
+  if (INIT) return;
+  x += l;
+#pragma unroll
+  for (int i = 0; i < DMAX; ++i)
+    if (i < d) *reinterpret_cast<float*>(msg_b + a[i]) = clampf(-1.f * c[i] + x, -llr_max, llr_max);
+  if (last) *llr_v = x;
+}
+
+template <bool POW2, bool INIT>
+__device__ __forceinline__ void bp_vn_item(const int32_t* __restrict__ ent, int d, unsigned zz4, unsigned zw,
+                                           char* __restrict__ msg_b, float* __restrict__ llr_v, float llr_max,
+                                           bool last) {
+  if (d <= 1) bp_vn_col<1, POW2, INIT>(ent, d, zz4, zw, msg_b, llr_v, llr_max, last);
+  else if (d <= 3) bp_vn_col<3, POW2, INIT>(ent, d, zz4, zw, msg_b, llr_v, llr_max, last);
+  else if (d <= 6) bp_vn_col<6, POW2, INIT>(ent, d, zz4, zw, msg_b, llr_v, llr_max, last);
+  else if (d <= 10) bp_vn_col<10, POW2, INIT>(ent, d, zz4, zw, msg_b, llr_v, llr_max, last);
+  else if (d <= 16) bp_vn_col<16, POW2, INIT>(ent, d, zz4, zw, msg_b, llr_v, llr_max, last);
+  else bp_vn_col<kColStride, POW2, INIT>(ent, d, zz4, zw, msg_b, llr_v, llr_max, last);
+}
+
+// NW waves per workgroup, one codeword per workgroup at a time.  LLRG: channel LLRs (and, after the last
+// iteration, the marginals) in a workspace row (L2) instead of LDS.
+template <int MODE, bool POW2, int NW, bool LLRG>
+__global__ __launch_bounds__(NW * 64) void ldpc5g_decode_bp_kernel(
+    const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ llr_ws, RateMatch p, int n_cn,
+    int nbu, int batch, int num_iter, float llr_max, int hard_out, int return_infobits, int msg_floats,
+    const int32_t* __restrict__ row_off, const int32_t* __restrict__ col_ent,
+    const int32_t* __restrict__ col_deg, const int32_t* __restrict__ cn_ptr, const int32_t* __restrict__ cn_list,
+    const int32_t* __restrict__ vn_ptr, const int32_t* __restrict__ vn_list) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NT = NW * 64;
+  const unsigned z = (unsigned)p.z, z4 = 4u * z;
+  const unsigned zw = POW2 ? z4 - 1u : z4;
+  const int n_vn = p.n_vn;
+  const int nx = nbu * (int)z;
+  float* llr = LLRG ? llr_ws + (size_t)blockIdx.x * nx : smem + msg_floats;
+  char* msg_b = reinterpret_cast<char*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = cn_ptr[w], c1 = cn_ptr[w + 1];
+  const int v0 = vn_ptr[w], v1 = vn_ptr[w + 1];
+
+  for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+    const float* row = llr_in + (size_t)b * p.n;
+    // decoding.py:552-565: clip, then logits -> LLR
+    for (int v = tid; v < nx; v += NT)
+      llr[v] = (v < n_vn) ? -1.f * clampf(recover_llr(p, row, v, llr_max), -llr_max, llr_max) : 0.f;
+    __syncthreads();
+    for (int t = v0; t < v1; ++t) {                                // v2c of iteration 0
+      const int desc = __builtin_amdgcn_readfirstlane(vn_list[t]);  // c | chunk<<8
+      const int c = desc & 0xFF;
+      const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
+      const int vn = c * (int)z + (int)zz;
+      if (zz < z && vn < n_vn)
+        bp_vn_item<POW2, true>(col_ent + c * kColStride, __builtin_amdgcn_readfirstlane(col_deg[c]), 4u * zz, zw,
+                               msg_b, llr + vn, llr_max, false);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < num_iter; ++it) {
+      for (int t = c0; t < c1; ++t) {
+        const int desc = __builtin_amdgcn_readfirstlane(cn_list[t]);  // r | chunk<<8
+        const int r = desc & 0xFF;
+        const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
+        if (zz < z && (unsigned)r * z + zz < (unsigned)n_cn) {
+          const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(row_off[r]);
+          const unsigned a0 = (ro & 0x3FFFFu) + 4u * zz;
+#define SAMD_BP_CN(D) case D: bp_cn_row<MODE, D>(msg_b, a0, z4, llr_max); break
+          switch (ro >> 18) {
+            SAMD_BP_CN(3); SAMD_BP_CN(4); SAMD_BP_CN(5); SAMD_BP_CN(6); SAMD_BP_CN(7); SAMD_BP_CN(8); SAMD_BP_CN(9);
+            SAMD_BP_CN(10); SAMD_BP_CN(19);
+            default: break;
+          }
+#undef SAMD_BP_CN
+        } else if (zz < z) {
+          // pruned check node of the last, partial base row (decoding.py:1330-1370 prunes by node count): its
+          // edges do not exist - keep their slots at 0 so that the VN sums of the neighbouring columns skip them
+          const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(row_off[r]);
+          for (unsigned i = 0; i < (ro >> 18); ++i)
+            *reinterpret_cast<float*>(msg_b + (ro & 0x3FFFFu) + 4u * zz + i * z4) = 0.f;
+        }
+      }
+      __syncthreads();
+      const bool last = (it == num_iter - 1);
+      for (int t = v0; t < v1; ++t) {
+        const int desc = __builtin_amdgcn_readfirstlane(vn_list[t]);
+        const int c = desc & 0xFF;
+        const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
+        const int vn = c * (int)z + (int)zz;
+        if (zz < z && vn < n_vn)
+          bp_vn_item<POW2, false>(col_ent + c * kColStride, __builtin_amdgcn_readfirstlane(col_deg[c]), 4u * zz, zw,
+                                  msg_b, llr + vn, llr_max, last);
+      }
+      __syncthreads();
+    }
+    // ---------------- output (decoding.py:620-626, 1486-1531); llr[] now holds the marginals
+    if (return_infobits) {
+      float* o = out + (size_t)b * p.k;
+      for (int v = tid; v < p.k; v += NT) {
+        const float x = clampf(llr[v], -llr_max, llr_max);
+        o[v] = hard_out ? ((0.f >= x) ? 1.f : 0.f) : -1.f * x;
+      }
+    } else {
+      float* o = out + (size_t)b * p.n;
+      for (int i = tid; i < p.n; i += NT) {
+        const float x = clampf(llr[short_to_full(p, out_to_short(p, i))], -llr_max, llr_max);
+        o[i] = hard_out ? ((0.f >= x) ? 1.f : 0.f) : -1.f * x;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static const int kBpCnDegrees[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
+
+int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row) {
+  const int z = h->z;
+  const int ncu = (h->n_cn + z - 1) / z, nbu = (h->n_vn + z - 1) / z;
+  h->bp_ok = 0;
+  if (h->mb > 255 || h->nb > 255 || (z + 63) / 64 > 255) return SAMD_OK;
+  std::vector<int32_t> row_off(h->mb, 0), col_ent((size_t)h->nb * kColStride, 0), col_deg(h->nb, 0);
+  int edges = 0;
+  for (int r = 0; r < ncu; ++r) {
+    const int d = (int)by_row[r].size();
+    if (std::find(std::begin(kBpCnDegrees), std::end(kBpCnDegrees), d) == std::end(kBpCnDegrees)) return SAMD_OK;
+    row_off[r] = (edges * z * 4) | (d << 18);               // byte offset of the first edge block | degree << 18
+    for (int i = 0; i < d; ++i) {
+      const int c = by_row[r][i].first, s = by_row[r][i].second;
+      if (c >= nbu || col_deg[c] >= kColStride) return SAMD_OK;
+      col_ent[(size_t)c * kColStride + col_deg[c]++] = ((edges + i) * z * 4) | ((s * 4) << 18);   // rows ascending
+    }
+    edges += d;
+  }
+  const size_t msg_bytes = (size_t)edges * z * 4;
+  if (msg_bytes > 160 * 1024 || msg_bytes >= (1u << 18)) return SAMD_OK;   // the HBM-resident engine takes it
+  h->bp_edges = edges;
+  size_t lds = msg_bytes + (size_t)nbu * z * 4;
+  h->bp_llr_global = 0;
+  if (lds > 160 * 1024) { h->bp_llr_global = 1; lds = msg_bytes; }
+  h->bp_waves = 16;
+  if (!h->bp_llr_global)
+    for (int nwc : {8, 4, 2, 1})
+      if (lds * (size_t)(kDecWaves / nwc) <= 160 * 1024) h->bp_waves = nwc;
+  if (const char* e = getenv("SAMD_ONCHIP_BP_WAVES")) {
+    const int v = atoi(e);
+    if (!h->bp_llr_global && (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && lds * (size_t)(kDecWaves / v) <= 160 * 1024)
+      h->bp_waves = v;
+  }
+  // items: CN cost ~ degree (two phi evaluations per edge), VN cost ~ degree
+  const int chunks = (z + 63) / 64;
+  std::vector<std::pair<int, int32_t>> ci, vi;
+  for (int r = 0; r < ncu; ++r)
+    for (int q = 0; q < chunks; ++q)
+      if (r * z + q * 64 < h->n_cn) ci.push_back({8 * (int)by_row[r].size(), r | (q << 8)});
+  for (int c = 0; c < nbu; ++c)
+    for (int q = 0; q < chunks; ++q)
+      if (c * z + q * 64 < h->n_vn) vi.push_back({col_deg[c] + 2, c | (q << 8)});
+  std::vector<int32_t> cp, cl, vp, vl;
+  lpt_schedule(ci, h->bp_waves, &cp, &cl);
+  lpt_schedule(vi, h->bp_waves, &vp, &vl);
+  int rc = upload(&h->bp_row_off, row_off.data(), row_off.size());
+  if (rc == SAMD_OK) rc = upload(&h->bp_col_ent, col_ent.data(), col_ent.size());
+  if (rc == SAMD_OK) rc = upload(&h->bp_col_deg, col_deg.data(), col_deg.size());
+  if (rc == SAMD_OK) rc = upload(&h->bp_cn_ptr, cp.data(), cp.size());
+  if (rc == SAMD_OK) rc = upload(&h->bp_cn_list, cl.data(), cl.size());
+  if (rc == SAMD_OK) rc = upload(&h->bp_vn_ptr, vp.data(), vp.size());
+  if (rc == SAMD_OK) rc = upload(&h->bp_vn_list, vl.data(), vl.size());
+  if (rc == SAMD_OK) h->bp_ok = 1;
+  return rc;
+}
+
+void free_onchip_bp_tables(samd_ldpc5g* h) {
+  (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg);
+  (void)hipFree(h->bp_cn_ptr); (void)hipFree(h->bp_cn_list); (void)hipFree(h->bp_vn_ptr); (void)hipFree(h->bp_vn_list);
+}
+
+static size_t bp_lds_bytes(const samd_ldpc5g* h) {
+  const int nbu = (h->n_vn + h->z - 1) / h->z;
+  return (size_t)h->bp_edges * h->z * 4 + (h->bp_llr_global ? 0 : (size_t)nbu * h->z * 4);
+}
+
+static int bp_grid(const samd_ldpc5g* h, int batch) {
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const size_t per_cu = std::min<size_t>((size_t)(kDecWaves / h->bp_waves), std::max<size_t>(1, (160 * 1024) / bp_lds_bytes(h)));
+  return (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+}
+
+size_t onchip_bp_workspace_bytes(const samd_ldpc5g* h, int batch) {
+  if (!h->bp_ok || !h->bp_llr_global || batch <= 0) return 0;
+  const int nbu = (h->n_vn + h->z - 1) / h->z;
+  return (size_t)bp_grid(h, batch) * nbu * h->z * sizeof(float) + 256;
+}
+
+int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                     float llr_max, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes,
+                     hipStream_t st) {
+  if (!h->bp_ok) {
+    set_error("messages of this code do not fit in LDS");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  float* llr_ws = nullptr;
+  if (h->bp_llr_global) {
+    if (!workspace || workspace_bytes < onchip_bp_workspace_bytes(h, batch)) {
+      set_error("workspace too small (samd_ldpc5g_decode_workspace_bytes)");
+      return SAMD_ERR_WORKSPACE;
+    }
+    llr_ws = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
+  }
+  const bool pow2 = (h->z & (h->z - 1)) == 0;
+  const bool phi = (cn_mode == SAMD_CN_BOXPLUS_PHI);
+  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, int, float, int, int, int,
+                         const int32_t*, const int32_t*, const int32_t*, const int32_t*, const int32_t*,
+                         const int32_t*, const int32_t*);
+#define SAMD_BP_K(M, NWV, G) ldpc5g_decode_bp_kernel<M, false, NWV, G>, ldpc5g_decode_bp_kernel<M, true, NWV, G>
+  static const kern_t kerns[24] = {
+      SAMD_BP_K(SAMD_CN_BOXPLUS_PHI, 16, false), SAMD_BP_K(SAMD_CN_BOXPLUS_PHI, 8, false),
+      SAMD_BP_K(SAMD_CN_BOXPLUS_PHI, 4, false),  SAMD_BP_K(SAMD_CN_BOXPLUS_PHI, 2, false),
+      SAMD_BP_K(SAMD_CN_BOXPLUS_PHI, 1, false),  SAMD_BP_K(SAMD_CN_BOXPLUS_PHI, 16, true),
+      SAMD_BP_K(SAMD_CN_BOXPLUS, 16, false),     SAMD_BP_K(SAMD_CN_BOXPLUS, 8, false),
+      SAMD_BP_K(SAMD_CN_BOXPLUS, 4, false),      SAMD_BP_K(SAMD_CN_BOXPLUS, 2, false),
+      SAMD_BP_K(SAMD_CN_BOXPLUS, 1, false),      SAMD_BP_K(SAMD_CN_BOXPLUS, 16, true)};
+#undef SAMD_BP_K
+  const int nw = h->bp_waves;
+  const int wi = h->bp_llr_global ? 5 : (nw == 16 ? 0 : nw == 8 ? 1 : nw == 4 ? 2 : nw == 2 ? 3 : 4);
+  const int ki = (phi ? 0 : 12) + 2 * wi + (pow2 ? 1 : 0);
+  static bool attr_set[24] = {};
+  if (!attr_set[ki]) {
+    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[ki] = true;
+  }
+  const int nbu = (h->n_vn + h->z - 1) / h->z;
+  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  hipLaunchKernelGGL(kerns[ki], dim3(bp_grid(h, batch)), dim3(nw * 64), bp_lds_bytes(h), st, llr, out, llr_ws, rm,
+                     h->n_cn, nbu, batch, num_iter, llr_max, hard_out, return_infobits, h->bp_edges * h->z,
+                     h->bp_row_off, h->bp_col_ent, h->bp_col_deg, h->bp_cn_ptr, h->bp_cn_list,
+                     h->bp_vn_ptr, h->bp_vn_list);
+  return launch_status();
+}
+
+}  // namespace samd

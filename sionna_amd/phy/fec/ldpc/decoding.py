@@ -301,7 +301,8 @@ class LDPC5GDecoder(LDPCBPDecoder):
             raise ValueError("Last dimension must be of length n.")
 
     def _try_onchip(self, llr2d, num_iter):
-        """Whole decode in one kernel when the code fits in LDS (min-sum family)."""
+        """Whole decode in one kernel: min-sum family for every 5G code (compressed check-node state), boxplus /
+        boxplus-phi when the per-edge messages fit in LDS (n=8448 rate 1/3 and everything smaller)."""
         enc = self._encoder
         out_cols = enc.k if self._return_infobits else enc.n
         out = torch.empty((llr2d.shape[0], out_cols), dtype=torch.float32, device=llr2d.device)
@@ -331,7 +332,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
         batch = llr2d.shape[0]
         out_shape = shape[:-1] + ((enc.k,) if self._return_infobits else (enc.n,))
 
-        use_onchip = (self._onchip_ok and self._cn_mode in (2, 3) and not self._return_state
+        use_onchip = (self._onchip_ok and self._cn_mode in (0, 1, 2, 3) and not self._return_state
                       and msg_v2c is None and batch > 0 and self._scheduling == "flooding")
         if use_onchip:
             out = self._try_onchip(llr2d, num_iter)

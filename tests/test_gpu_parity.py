@@ -383,6 +383,32 @@ def test_5g_minsum_bit_exact_both_engines(phy, k, n, bg, m, cn):
 
 @pytest.mark.parametrize("k,n,bg,m", CODES5G)
 @pytest.mark.parametrize("cn", ["boxplus-phi", "boxplus"])
+def test_5g_boxplus_onchip_equals_hbm_engine(phy, k, n, bg, m, cn):
+    """The on-chip boxplus engine (one float per edge in LDS) uses the arithmetic and the summation order of the
+    HBM-resident engine: the two return the same bits (which test_5g_boxplus_vs_oracle holds to the oracle)."""
+    code = LDPC5GCode(k, n, m, bg)
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    u, c, llr = _noisy_llr(code, 11, 2 * k + n, sigma=0.6)
+    llr[0, :9] = 0
+    llr[1] = np.round(llr[1])
+    llr[2] = 0                                                   # all-erasure word stays all-zero
+    ran_onchip = False
+    for it, infobits in ((0, False), (1, True), (3, False), (20, True)):
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=it)
+        a = _np(dec(llr))
+        if not dec._onchip_ok:                                   # messages do not fit in LDS: HBM engine only
+            continue
+        ran_onchip = True
+        dec._onchip_ok = False
+        b = _np(dec(llr))
+        assert np.array_equal(a, b), f"{cn} it={it} infobits={infobits}: max diff {np.max(np.abs(a - b))}"
+        assert np.all(a[2] == 0)
+    if k <= 4096:
+        assert ran_onchip
+
+
+@pytest.mark.parametrize("k,n,bg,m", CODES5G)
+@pytest.mark.parametrize("cn", ["boxplus-phi", "boxplus"])
 def test_5g_boxplus_vs_oracle(phy, k, n, bg, m, cn):
     """boxplus rules: float32 transcendental chains.
 
