@@ -20,11 +20,64 @@ __device__ __forceinline__ float sgn3(float x) { return x > 0.f ? 1.f : (x < 0.f
 // value; everywhere else the float32 device functions are used (accurate_math.h keeps the
 // float64 evaluation that was measured 1.75x slower on the whole decoder for no gain in
 // agreement with the oracle - DESIGN.md "phi conditioning").
+//
+// exp and log are the device libm's float32 algorithms (v_exp_f32 / v_log_f32 with a two-term
+// extended-precision scaling) WITHOUT their special-case handling: after the clip, x is in
+// [8.5e-8, 16.64], e^x +- 1 in [2^-23, 3.4e7] - no denormal scaling, overflow, underflow, inf or NaN
+// branch can trigger, so dropping them (19 of 43 VALU operations per phi) leaves every bit of the
+// result unchanged (tools/ubench/phi_check.hip compares all 1.1e9 floats in [0, 20]).
+__device__ __forceinline__ float exp_core_f32(float x) {            // e^x for moderate x
+  const float c = __uint_as_float(0x3fb8aa3bu);                      // log2(e), high part
+  const float t = x * c;
+  float lo = __builtin_fmaf(x, c, -t);
+  lo = __builtin_fmaf(x, __uint_as_float(0x32a5705fu), lo);          // low part of log2(e)
+  const float r = __builtin_rintf(t);
+  const float f = (t - r) + lo;
+  return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)r);
+}
+__device__ __forceinline__ float log_core_f32(float x) {            // ln x for normal positive x
+  const float y = __builtin_amdgcn_logf(x);                          // log2
+  const float c = __uint_as_float(0x3f317217u);                      // ln 2, high part
+  const float r = y * c;
+  float lo = __builtin_fmaf(y, c, -r);
+  lo = __builtin_fmaf(y, __uint_as_float(0x3377d1cfu), lo);          // low part of ln 2
+  return r + lo;
+}
 __device__ __forceinline__ float phi_fast_f32(float x) {
   x = clampf(x, 8.5e-8f, 16.635532f);
-  const float e = expf(x);
-  const float r = logf(e + 1.f) - logf(e - 1.f);
+  const float e = exp_core_f32(x);
+  const float r = log_core_f32(e + 1.f) - log_core_f32(e - 1.f);
   return (x == 16.635532f) ? 0.f : r;                    // select, not a branch
+}
+
+// Two phi evaluations at once: the same operations as phi_fast_f32 per component, with every
+// multiply / add / fma issued as a packed-fp32 instruction (v_pk_mul/add/fma_f32: two IEEE results
+// per issue slot) - 17 instead of 25 VALU operations per phi, identical bits.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 log_core2_f32(f32x2 x) {
+  const f32x2 y = {__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+  const float c = __uint_as_float(0x3f317217u), cl = __uint_as_float(0x3377d1cfu);
+  const f32x2 c2 = {c, c}, cl2 = {cl, cl};
+  const f32x2 r = y * c2;
+  f32x2 lo = __builtin_elementwise_fma(y, c2, -r);
+  lo = __builtin_elementwise_fma(y, cl2, lo);
+  return r + lo;
+}
+__device__ __forceinline__ f32x2 phi_fast2_f32(float x0, float x1) {
+  const f32x2 x = {clampf(x0, 8.5e-8f, 16.635532f), clampf(x1, 8.5e-8f, 16.635532f)};
+  const float c = __uint_as_float(0x3fb8aa3bu), cl = __uint_as_float(0x32a5705fu);
+  const f32x2 c2 = {c, c}, cl2 = {cl, cl}, one = {1.f, 1.f};
+  const f32x2 t = x * c2;
+  f32x2 lo = __builtin_elementwise_fma(x, c2, -t);
+  lo = __builtin_elementwise_fma(x, cl2, lo);
+  const f32x2 r = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  const f32x2 f = (t - r) + lo;
+  const f32x2 e = {__builtin_ldexpf(__builtin_amdgcn_exp2f(f.x), (int)r.x),
+                   __builtin_ldexpf(__builtin_amdgcn_exp2f(f.y), (int)r.y)};
+  f32x2 res = log_core2_f32(e + one) - log_core2_f32(e - one);
+  res.x = (x.x == 16.635532f) ? 0.f : res.x;
+  res.y = (x.y == 16.635532f) ? 0.f : res.y;
+  return res;
 }
 
 // ---- check-node update on one batch column; v[0..d) in CN edge order, in place.
@@ -63,22 +116,39 @@ __device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr
         v[i] = clampf((sgn[i] * node_sign) * m, -llr_max, llr_max);
       }
   } else if constexpr (MODE == SAMD_CN_BOXPLUS_PHI) {
-    float sgn[MAXD];
-    float node_sign = 1.f, sum = 0.f;
+    // signs as bits: sign_nz(v) = -1 <=> v < 0 (a -0 counts as +), (s_i * node_sign) * q = q with the
+    // sign bit s_i ^ node, clip(+-q, +-llr_max) = +-min(q, llr_max) for q >= 0; edges two at a time (phi_fast2)
+    unsigned sg[MAXD];
+    unsigned node = 0u;
+    float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXD; ++i)
-      if (i < d) {
-        sgn[i] = sign_nz(v[i]);
-        node_sign *= sgn[i];
+    for (int i = 0; i < MAXD; i += 2) {
+      if (i + 1 < MAXD && i + 1 < d) {
+        sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
+        sg[i + 1] = (v[i + 1] < 0.f) ? 0x80000000u : 0u;
+        node ^= sg[i] ^ sg[i + 1];
+        const f32x2 p = phi_fast2_f32(fabsf(v[i]), fabsf(v[i + 1]));
+        v[i] = p.x; v[i + 1] = p.y;
+        sum += p.x;
+        sum += p.y;
+      } else if (i < d) {
+        sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
+        node ^= sg[i];
         v[i] = phi_fast_f32(fabsf(v[i]));
         sum += v[i];
       }
+    }
 #pragma unroll
-    for (int i = 0; i < MAXD; ++i)
-      if (i < d) {
-        const float e = -1.f * v[i] + sum;
-        v[i] = clampf((sgn[i] * node_sign) * phi_fast_f32(e), -llr_max, llr_max);
+    for (int i = 0; i < MAXD; i += 2) {
+      if (i + 1 < MAXD && i + 1 < d) {
+        const f32x2 q = phi_fast2_f32(-1.f * v[i] + sum, -1.f * v[i + 1] + sum);
+        v[i] = __uint_as_float(__float_as_uint(fminf(q.x, llr_max)) ^ (sg[i] ^ node));
+        v[i + 1] = __uint_as_float(__float_as_uint(fminf(q.y, llr_max)) ^ (sg[i + 1] ^ node));
+      } else if (i < d) {
+        const float q = phi_fast_f32(-1.f * v[i] + sum);
+        v[i] = __uint_as_float(__float_as_uint(fminf(q, llr_max)) ^ (sg[i] ^ node));
       }
+    }
   } else {  // SAMD_CN_BOXPLUS (tanh), decoding.py:1000-1042
     float prod = 1.f;
 #pragma unroll
