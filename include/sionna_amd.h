@@ -128,12 +128,15 @@ int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const float* x_hat,
 size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode);
 
 /* Whole LDPC5GDecoder.call on chip: rate recovery + num_iter flooding BP iterations +
- * output mapping in ONE kernel, one codeword per workgroup, messages resident in LDS
- * (min-sum family: compressed check-node state).  cn_mode must be SAMD_CN_MINSUM or
- * SAMD_CN_OFFSET_MINSUM; returns SAMD_ERR_UNSUPPORTED when the code cannot be scheduled
- * on chip (caller then uses rate_recover + samd_ldpc_bp_decode_f32 + extract).  Codes whose state
- * exceeds 160 KB keep the channel LLRs, then the VN totals, then the sign words in `workspace`
- * (samd_ldpc5g_decode_workspace_bytes() > 0; one L2-resident row per workgroup); results are identical.
+ * output mapping in ONE kernel, one codeword per workgroup, messages resident in LDS.
+ *   SAMD_CN_MINSUM / SAMD_CN_OFFSET_MINSUM: compressed check-node state, every 5G code; codes whose
+ *     state exceeds 160 KB keep the channel LLRs, then the VN totals, then the sign words in `workspace`
+ *     (one L2-resident row per workgroup); results are identical.
+ *   SAMD_CN_BOXPLUS_PHI / SAMD_CN_BOXPLUS: one float per edge in LDS (codes whose E messages x 4 B fit in 160 KB, i.e.
+ *     n=8448 rate 1/3 and smaller; channel LLRs in `workspace` when they do not fit beside the messages);
+ *     same arithmetic and summation order as samd_ldpc_bp_decode_f32 - identical bits.
+ * Returns SAMD_ERR_UNSUPPORTED when the code cannot run on chip (caller then uses rate_recover +
+ * samd_ldpc_bp_decode_f32 + extract).  samd_ldpc5g_decode_workspace_bytes(h, batch, cn_mode) sizes `workspace`.
  * llr [batch,n] logits -> out [batch,k] (return_infobits=1) or [batch,n] (=0). */
 int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
                            int batch, int num_iter, int cn_mode, float llr_max,

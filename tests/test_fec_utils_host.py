@@ -112,6 +112,8 @@ def test_j_function_pair_and_llr2mi():
 
 
 def test_generate_reg_ldpc():
+    from sionna_amd.phy import config
+    config.seed = 11        # socket matching can dead-end for some draws (like the reference's); fix the stream
     pcm, k, n, r = u.generate_reg_ldpc(3, 6, 100, verbose=False)
     assert pcm.shape == (50, 100) and (k, n, r) == (50, 100, 0.5)
     assert (pcm.sum(0) == 3).all() and (pcm.sum(1) == 6).all()
