@@ -33,6 +33,11 @@ struct samd_ldpc5g {
   int bp_ok = 0, bp_waves = 16, bp_llr_global = 0, bp_edges = 0;   // bp_edges: base-graph edges of the used rows
   int32_t* bp_row_off = nullptr;   // [mb]     byte offset of the row's first edge block (blocks are Z floats) | degree << 18
   int32_t* bp_col_ent = nullptr;   // [nb*32]  (edge block byte offset) | (4*shift) << 18, rows ascending
+  // explicit-message min-sum engine (ldpc5g_onchip_ms.hip): compact edge tables + self-contained list entries
+  int32_t* ms_col_ent = nullptr;   // [2 E + pad] per column, rows ascending: edge block byte offset, 4*shift
+  int32_t* ms_cn_ptr = nullptr; int32_t* ms_vn_ptr = nullptr;   // per-wave list offsets (VN: per-iteration lists, then fused columns)
+  int32_t* ms_cn_list = nullptr;   // [2 items]  row block byte offset | (degree | fused<<5)<<18,  r | chunk<<8 | fused column<<16
+  int32_t* ms_vn_list = nullptr;   // [2 items]  c | chunk<<8 | degree<<16,  dword offset into ms_col_ent
   int32_t* bp_col_deg = nullptr;   // [nb]
   int32_t* bp_cn_ptr = nullptr; int32_t* bp_cn_list = nullptr;     // per-wave item lists (LPT balanced)
   int32_t* bp_vn_ptr = nullptr; int32_t* bp_vn_list = nullptr;
@@ -51,6 +56,12 @@ size_t onchip_workspace_bytes(const samd_ldpc5g* h, int batch);
 int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
 void free_onchip_bp_tables(samd_ldpc5g* h);
 size_t onchip_bp_workspace_bytes(const samd_ldpc5g* h, int batch);
+size_t onchip_bp_lds_bytes(const samd_ldpc5g* h);
+int onchip_bp_grid(const samd_ldpc5g* h, int batch);
+// explicit-message min-sum engine (ldpc5g_onchip_ms.hip), same tables as the boxplus engine
+int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                     float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
+                     size_t workspace_bytes, hipStream_t st);
 int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes,
                      hipStream_t st);

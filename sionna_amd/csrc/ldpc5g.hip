@@ -362,10 +362,15 @@ extern "C" int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const fl
   return launch_status();
 }
 
+// min-sum family: explicit messages (ldpc5g_onchip_ms.hip) when they fit in LDS, else the compressed
+// check-node state (ldpc5g_onchip.hip, every 5G code).  SAMD_ONCHIP_COMPRESSED=1 forces the latter.
+static bool use_explicit_minsum(const samd_ldpc5g* h) { return h->bp_ok && !getenv("SAMD_ONCHIP_COMPRESSED"); }
+
 extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode) {
   // 0 when the whole state fits in LDS; larger codes keep part of it in this (L2-resident) scratch
   if (!h) return 0;
-  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) return onchip_bp_workspace_bytes(h, batch);
+  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || use_explicit_minsum(h))
+    return onchip_bp_workspace_bytes(h, batch);
   return onchip_workspace_bytes(h, batch);
 }
 
@@ -388,6 +393,11 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   if (h->max_dc > 27 || !(llr_max >= 0.f) || (double)h->max_dc * 2.0 * (double)llr_max >= 99999.0) {
     set_error("code / llr_max outside the on-chip decoder's envelope");
     return SAMD_ERR_UNSUPPORTED;
+  }
+  if (use_explicit_minsum(h)) {
+    const int rc = launch_onchip_ms(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits,
+                                    workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
   if (h->v2_ok && !getenv("SAMD_ONCHIP_V1")) {   // statically scheduled, unrolled engine
     const int rc = launch_onchip_v2(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out,

@@ -183,6 +183,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   h->bp_ok = 0;
   if (h->mb > 255 || h->nb > 255 || (z + 63) / 64 > 255) return SAMD_OK;
   std::vector<int32_t> row_off(h->mb, 0), col_ent((size_t)h->nb * kColStride, 0), col_deg(h->nb, 0);
+
   int edges = 0;
   for (int r = 0; r < ncu; ++r) {
     const int d = (int)by_row[r].size();
@@ -222,8 +223,54 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::vector<int32_t> cp, cl, vp, vl;
   lpt_schedule(ci, h->bp_waves, &cp, &cl);
   lpt_schedule(vi, h->bp_waves, &vp, &vl);
+  // ldpc5g_onchip_ms.hip: compact per-column edge tables (block byte offset, 4 shift) - a few KB, they stay in the
+  // scalar cache - and self-contained two-dword list entries in the same order as the lists above
+  std::vector<int32_t> col_ent2, col_start(h->nb, 0), cl2, vl2;
+  for (int c = 0; c < h->nb; ++c) {
+    col_start[c] = (int32_t)col_ent2.size();
+    for (int i = 0; i < col_deg[c]; ++i) {
+      const int32_t e = col_ent[(size_t)c * kColStride + i];
+      col_ent2.push_back(e & 0x3FFFF);
+      col_ent2.push_back((int32_t)((uint32_t)e >> 18));
+    }
+  }
+  col_ent2.resize(col_ent2.size() + 64, 0);                    // wide scalar loads may run past the last edge
+  // rows whose last edge is the only edge of its column with shift 0 (extension part of the base graph): that
+  // degree-1 VN is updated inside the CN phase (ms_cn_row<D, true>) and leaves the per-iteration VN lists
+  std::vector<int> fused_col(h->mb, -1);
+  std::vector<char> col_fused(h->nb, 0);
+  for (int r = 0; r < ncu; ++r) {
+    const int d = (int)by_row[r].size();
+    const int c = by_row[r][d - 1].first, sft = by_row[r][d - 1].second;
+    if (col_deg[c] == 1 && sft == 0 && d >= 3 && d <= 10) { fused_col[r] = c; col_fused[c] = 1; }
+  }
+  std::vector<std::pair<int, int32_t>> ci2, vi2, vf2;
+  for (int r = 0; r < ncu; ++r)
+    for (int q = 0; q < chunks; ++q)
+      if (r * z + q * 64 < h->n_cn) ci2.push_back({(int)by_row[r].size() + 2, r | (q << 8)});
+  for (int c = 0; c < nbu; ++c)
+    for (int q = 0; q < chunks; ++q)
+      if (c * z + q * 64 < h->n_vn) (col_fused[c] ? vf2 : vi2).push_back({col_deg[c] + 3, c | (q << 8)});
+  std::vector<int32_t> mcp, mcl, mvp, mvl, mfp, mfl;
+  lpt_schedule(ci2, h->bp_waves, &mcp, &mcl);
+  lpt_schedule(vi2, h->bp_waves, &mvp, &mvl);
+  lpt_schedule(vf2, h->bp_waves, &mfp, &mfl);
+  for (int32_t o : mfp) mvp.push_back(o + (int32_t)mvl.size());
+  mvl.insert(mvl.end(), mfl.begin(), mfl.end());
+  for (int32_t d : mcl) {
+    const int r = d & 0xFF, f = fused_col[r] >= 0;
+    cl2.push_back((row_off[r] & 0x3FFFF) | (((int)by_row[r].size() | (f << 5)) << 18));
+    cl2.push_back(d | ((f ? fused_col[r] : 0) << 16));
+  }
+  for (int32_t d : mvl) { vl2.push_back(d | (col_deg[d & 0xFF] << 16)); vl2.push_back(col_start[d & 0xFF]); }
+  cl2.resize(cl2.size() + 2, 0); vl2.resize(vl2.size() + 2, 0);
   int rc = upload(&h->bp_row_off, row_off.data(), row_off.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_col_ent, col_ent.data(), col_ent.size());
+  if (rc == SAMD_OK) rc = upload(&h->ms_col_ent, col_ent2.data(), col_ent2.size());
+  if (rc == SAMD_OK) rc = upload(&h->ms_cn_ptr, mcp.data(), mcp.size());
+  if (rc == SAMD_OK) rc = upload(&h->ms_vn_ptr, mvp.data(), mvp.size());
+  if (rc == SAMD_OK) rc = upload(&h->ms_cn_list, cl2.data(), cl2.size());
+  if (rc == SAMD_OK) rc = upload(&h->ms_vn_list, vl2.data(), vl2.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_col_deg, col_deg.data(), col_deg.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_cn_ptr, cp.data(), cp.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_cn_list, cl.data(), cl.size());
@@ -234,27 +281,27 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
 }
 
 void free_onchip_bp_tables(samd_ldpc5g* h) {
-  (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg);
+  (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg); (void)hipFree(h->ms_col_ent); (void)hipFree(h->ms_cn_list); (void)hipFree(h->ms_cn_ptr); (void)hipFree(h->ms_vn_ptr); (void)hipFree(h->ms_vn_list);
   (void)hipFree(h->bp_cn_ptr); (void)hipFree(h->bp_cn_list); (void)hipFree(h->bp_vn_ptr); (void)hipFree(h->bp_vn_list);
 }
 
-static size_t bp_lds_bytes(const samd_ldpc5g* h) {
+size_t onchip_bp_lds_bytes(const samd_ldpc5g* h) {
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   return (size_t)h->bp_edges * h->z * 4 + (h->bp_llr_global ? 0 : (size_t)nbu * h->z * 4);
 }
 
-static int bp_grid(const samd_ldpc5g* h, int batch) {
+int onchip_bp_grid(const samd_ldpc5g* h, int batch) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const size_t per_cu = std::min<size_t>((size_t)(kDecWaves / h->bp_waves), std::max<size_t>(1, (160 * 1024) / bp_lds_bytes(h)));
+  const size_t per_cu = std::min<size_t>((size_t)(kDecWaves / h->bp_waves), std::max<size_t>(1, (160 * 1024) / onchip_bp_lds_bytes(h)));
   return (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
 }
 
 size_t onchip_bp_workspace_bytes(const samd_ldpc5g* h, int batch) {
   if (!h->bp_ok || !h->bp_llr_global || batch <= 0) return 0;
   const int nbu = (h->n_vn + h->z - 1) / h->z;
-  return (size_t)bp_grid(h, batch) * nbu * h->z * sizeof(float) + 256;
+  return (size_t)onchip_bp_grid(h, batch) * nbu * h->z * sizeof(float) + 256;
 }
 
 int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
@@ -296,7 +343,7 @@ int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int bat
   }
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
-  hipLaunchKernelGGL(kerns[ki], dim3(bp_grid(h, batch)), dim3(nw * 64), bp_lds_bytes(h), st, llr, out, llr_ws, rm,
+  hipLaunchKernelGGL(kerns[ki], dim3(onchip_bp_grid(h, batch)), dim3(nw * 64), onchip_bp_lds_bytes(h), st, llr, out, llr_ws, rm,
                      h->n_cn, nbu, batch, num_iter, llr_max, hard_out, return_infobits, h->bp_edges * h->z,
                      h->bp_row_off, h->bp_col_ent, h->bp_col_deg, h->bp_cn_ptr, h->bp_cn_list,
                      h->bp_vn_ptr, h->bp_vn_list);

@@ -1,0 +1,265 @@
+// On-chip flooding min-sum / offset-min-sum decoder with EXPLICIT messages: one float per edge in LDS.
+//
+// Replaces LDPC5GDecoder.call = rate recovery + LDPCBPDecoder._bp_iter x num_iter +
+// cn_update_(offset_)minsum + vn_update_sum + output mapping (reference
+// src/sionna/phy/fec/ldpc/decoding.py:1427-1536, 416-524, 681-953) for codes whose E 4-byte messages
+// fit in 160 KB (C2: 316 Z edges = 158 KB, channel LLRs in an L2 workspace row).
+//
+// Why a third min-sum engine: ldpc5g_onchip.hip keeps the check-node state COMPRESSED (M1, M2, index,
+// signs - 12 B per check node) because messages + LLRs + totals of C2 do not fit in LDS together; the price
+// is that every edge's c2v is rebuilt from the compressed state twice per iteration (27 VALU operations
+// per edge, the kernel is 85 % VALU busy).  With the channel LLRs moved to L2 the 158 KB of messages fit
+// by themselves, and the per-edge work drops to
+//   CN: read v2c, m2 = med3(m1, m2, |v|), m1 = min(m1, |v|), sign ^= v;  then  mag = (|v| == m1) ? a2 : a1,
+//       c2v = ((v ^ sign) & msb) | mag, write                                   (~9 VALU)
+//   VN: read c2v, x += c;  then  v2c = med3(x - c, -L, L), write                (~5 VALU)
+// Same arithmetic as the compressed engine and the oracle (bit-exact): the second minimum is tracked with
+// multiplicity, a unique minimum gives min_e = (m2 - m1) + m1 (decoding.py:863), ties give min_e = m1;
+// v2c is never -0 (the channel LLR is never -0), so the raw sign bit equals (v2c < 0).
+//
+// Layout, work split and tables are those of ldpc5g_onchip_bp.hip (edge blocks indexed by the check node's
+// lifted copy; (row, chunk) / (column, chunk) items balanced over the waves on the host); every row /
+// column runs an instantiation for its exact degree, table entries are wave-uniform scalars that feed
+// the VALU operations directly (no scalar unpacking per edge).
+#include "ldpc5g.h"
+
+namespace samd {
+
+// LDS is addressed by plain byte offsets (address space 3): the kernel has no static __shared__ data, so
+// the dynamic segment starts at offset 0 (checked once per workgroup) and no base has to be added per access.
+typedef __attribute__((address_space(3))) float lds_f32;
+__device__ __forceinline__ float lds_ld(unsigned a) { return *(lds_f32*)(uintptr_t)a; }
+__device__ __forceinline__ void lds_st(unsigned a, float v) { *(lds_f32*)(uintptr_t)a = v; }
+
+__device__ __forceinline__ float ms_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+
+// one check node per lane: row of exact degree D, its messages are D lane-contiguous blocks from byte a0.
+// FUSE1: the row's last edge goes to a degree-1 variable node of the same lane (identity block of the base
+// graph's extension part).  Its VN update - x = c2v + llr, v2c = clip(x - c2v) - is done right here, so
+// these columns (42 of C2's 68) never appear in the VN phase; llr_v points at that VN's channel LLR.
+template <int D, bool FUSE1>
+__device__ __forceinline__ void ms_cn_row(unsigned a0, unsigned z4, float llr_max, float offset,
+                                          float* __restrict__ llr_v, bool last) {
+  float v[D];
+  unsigned a[D];
+  float lf = 0.f;
+  if (FUSE1) lf = *llr_v;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    a[i] = i ? a[i - 1] + z4 : a0;
+    v[i] = lds_ld(a[i]);
+  }
+  float m1 = INFINITY, m2 = INFINITY;
+  unsigned sx = 0u;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    m2 = ms_med3(m1, m2, fabsf(v[i]));              // second smallest, with multiplicity
+    m1 = ms_med3(m1, fabsf(v[i]), -INFINITY);       // min(m1, |v|) without a canonicalising extra operation
+    sx ^= __float_as_uint(v[i]);                    // bit 31 = node sign
+  }
+  // unique minimum <=> m2 > m1; (m2 - m1) + m1 is the reference's arithmetic (decoding.py:863)
+  const float min_e = (m2 > m1) ? ((m2 - m1) + m1) : m1;
+  const float a1 = ms_med3(m1 - offset, 0.f, llr_max);      // plain min-sum: offset = 0 (exact)
+  const float a2 = ms_med3(min_e - offset, 0.f, llr_max);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const float mag = (fabsf(v[i]) == m1) ? a2 : a1;
+    const unsigned s = (__float_as_uint(v[i]) ^ sx) & 0x80000000u;   // own sign x node sign
+    float c2v = __uint_as_float(s | __float_as_uint(mag));
+    if (FUSE1 && i == D - 1) {
+      const float x = c2v + lf;                     // (0 + c2v) + llr; llr is never -0, so 0 + c2v needs no operation
+      if (last) *llr_v = x;
+      c2v = ms_med3(x - c2v, -llr_max, llr_max);    // the slot now holds the next v2c
+    }
+    lds_st(a[i], c2v);
+  }
+}
+
+// one variable node per lane, column of exact degree D.  ent[2i] = edge block byte offset, ent[2i+1] = 4 shift
+// zwv: 4Z-1 (POW2) or 4Z, in a VGPR so that (t & zw) | base is one v_and_or_b32
+template <int D, bool POW2, bool INIT>
+__device__ __forceinline__ void ms_vn_col(const int32_t* __restrict__ ent, unsigned zz4, unsigned zwv,
+                                          float* __restrict__ llr_v, float llr_max, bool last) {
+  unsigned a[D];
+  float c[D];
+  const float l = *llr_v;
+  float x = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    const unsigned t = zz4 - (unsigned)ent[2 * i + 1];
+    // edge blocks are aligned to 4Z when Z is a power of two: (t mod 4Z) | base
+    a[i] = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t + zwv) + (unsigned)ent[2 * i]);
+    if (INIT) {
+      lds_st(a[i], l);
+    } else {
+      c[i] = lds_ld(a[i]);
+      x += c[i];
+    }
+  }
+  if (INIT) return;
+  x += l;
+#pragma unroll
+  for (int i = 0; i < D; ++i) lds_st(a[i], ms_med3(x - c[i], -llr_max, llr_max));
+  if (last) *llr_v = x;
+}
+
+template <bool POW2, bool INIT>
+__device__ __forceinline__ void ms_vn_item(const int32_t* __restrict__ ent, int d, unsigned zz4, unsigned zwv,
+                                           float* __restrict__ llr_v, float llr_max, bool last) {
+#define SAMD_MS_VN(D) case D: ms_vn_col<D, POW2, INIT>(ent, zz4, zwv, llr_v, llr_max, last); break
+  switch (d) {
+    SAMD_MS_VN(1); SAMD_MS_VN(2); SAMD_MS_VN(3); SAMD_MS_VN(4); SAMD_MS_VN(5); SAMD_MS_VN(6); SAMD_MS_VN(7);
+    SAMD_MS_VN(8); SAMD_MS_VN(9); SAMD_MS_VN(10); SAMD_MS_VN(11); SAMD_MS_VN(12); SAMD_MS_VN(13); SAMD_MS_VN(14);
+    SAMD_MS_VN(15); SAMD_MS_VN(16); SAMD_MS_VN(17); SAMD_MS_VN(18); SAMD_MS_VN(19); SAMD_MS_VN(20); SAMD_MS_VN(21);
+    SAMD_MS_VN(22); SAMD_MS_VN(23); SAMD_MS_VN(24); SAMD_MS_VN(25); SAMD_MS_VN(26); SAMD_MS_VN(27); SAMD_MS_VN(28);
+    SAMD_MS_VN(29); SAMD_MS_VN(30);
+    default: break;
+  }
+#undef SAMD_MS_VN
+}
+
+// list entries are self-contained (no dependent table look-ups) and the next one is fetched while the current
+// item runs:  VN (c | chunk<<8 | degree<<16,  dword offset of the column's edge table),
+//             CN (row block byte offset | degree<<18 | fused<<23,  r | chunk<<8 | fused column<<16)
+// vn_ptr = [NW+1 offsets of the per-iteration lists | NW+1 offsets of the fused degree-1 columns (init only)]
+template <bool POW2, int NW, bool LLRG>
+__global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
+    const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ llr_ws, RateMatch p, int n_cn,
+    int nbu, int batch, int num_iter, float llr_max, float offset, int hard_out, int return_infobits,
+    int msg_floats, const int32_t* __restrict__ col_ent, const int32_t* __restrict__ cn_ptr,
+    const int2* __restrict__ cn_list, const int32_t* __restrict__ vn_ptr, const int2* __restrict__ vn_list) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  if ((unsigned)(size_t)(lds_f32*)smem != 0u) __builtin_trap();      // see lds_ld
+  constexpr int NT = NW * 64;
+  const unsigned z = (unsigned)p.z, z4 = 4u * z;
+  const unsigned zw = POW2 ? z4 - 1u : z4;
+  unsigned zwv;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(zwv) : "s"(zw));
+  const int n_vn = p.n_vn;
+  const int nx = nbu * (int)z;
+  float* llr = LLRG ? llr_ws + (size_t)blockIdx.x * nx : smem + msg_floats;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c0 = cn_ptr[w], c1 = cn_ptr[w + 1];
+  const int v0 = vn_ptr[w], v1 = vn_ptr[w + 1];
+  const int f0 = vn_ptr[NW + 1 + w], f1 = vn_ptr[NW + 2 + w];
+
+  for (int b = blockIdx.x; b < batch; b += gridDim.x) {
+    const float* row = llr_in + (size_t)b * p.n;
+    // decoding.py:552-565: clip, then logits -> LLR; "+ 0.f" turns -0 into +0 (numerically the same LLR)
+    // so that no total and no v2c is ever -0 and the sign bit of a v2c equals (v2c < 0)
+    for (int v = tid; v < nx; v += NT)
+      llr[v] = (v < n_vn) ? (-1.f * clampf(recover_llr(p, row, v, llr_max), -llr_max, llr_max)) + 0.f : 0.f;
+    __syncthreads();
+    for (int seg = 0; seg < 2; ++seg) {                              // v2c of iteration 0 = channel LLR, all columns
+      const int t0 = seg ? f0 : v0, t1 = seg ? f1 : v1;
+      for (int t = t0; t < t1; ++t) {
+        const int2 e = vn_list[t];
+        const int d0 = __builtin_amdgcn_readfirstlane(e.x), d1 = __builtin_amdgcn_readfirstlane(e.y);
+        const int c = d0 & 0xFF;
+        const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
+        const int vn = c * (int)z + (int)zz;
+        if (zz < z && vn < n_vn) ms_vn_item<POW2, true>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, false);
+      }
+    }
+    __syncthreads();
+
+    for (int it = 0; it < num_iter; ++it) {
+      const bool last = (it == num_iter - 1);
+      {
+        int2 nxt = c0 < c1 ? cn_list[c0] : make_int2(0, 0);
+        for (int t = c0; t < c1; ++t) {
+          const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(nxt.x);
+          const int d1 = __builtin_amdgcn_readfirstlane(nxt.y);
+          if (t + 1 < c1) nxt = cn_list[t + 1];
+          const int r = d1 & 0xFF;
+          const unsigned zz = (unsigned)(((d1 >> 8) & 0xFF) * 64 + lane);
+          const unsigned a0 = (ro & 0x3FFFFu) + 4u * zz;
+          if (zz < z && (unsigned)r * z + zz < (unsigned)n_cn) {
+            float* lv = llr + (d1 >> 16) * (int)z + (int)zz;          // channel LLR of the fused degree-1 VN
+#define SAMD_MS_CN(D) case D: ms_cn_row<D, false>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CNF(D) case 32 + D: ms_cn_row<D, true>(a0, z4, llr_max, offset, lv, last); break
+            switch (ro >> 18) {                                      // degree | fused << 5
+              SAMD_MS_CN(3); SAMD_MS_CN(4); SAMD_MS_CN(5); SAMD_MS_CN(6); SAMD_MS_CN(7); SAMD_MS_CN(8); SAMD_MS_CN(9);
+              SAMD_MS_CN(10); SAMD_MS_CN(19);
+              SAMD_MS_CNF(3); SAMD_MS_CNF(4); SAMD_MS_CNF(5); SAMD_MS_CNF(6); SAMD_MS_CNF(7); SAMD_MS_CNF(8);
+              SAMD_MS_CNF(9); SAMD_MS_CNF(10);
+              default: break;
+            }
+#undef SAMD_MS_CN
+#undef SAMD_MS_CNF
+          } else if (zz < z) {
+            // pruned check node of the last, partial base row: its edges do not exist - keep their slots at 0
+            for (unsigned i = 0; i < ((ro >> 18) & 31u); ++i) lds_st(a0 + i * z4, 0.f);
+          }
+        }
+      }
+      __syncthreads();
+      {
+        int2 nxt = v0 < v1 ? vn_list[v0] : make_int2(0, 0);
+        for (int t = v0; t < v1; ++t) {
+          const int d0 = __builtin_amdgcn_readfirstlane(nxt.x), d1 = __builtin_amdgcn_readfirstlane(nxt.y);
+          if (t + 1 < v1) nxt = vn_list[t + 1];
+          const int c = d0 & 0xFF;
+          const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
+          const int vn = c * (int)z + (int)zz;
+          if (zz < z && vn < n_vn) ms_vn_item<POW2, false>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, last);
+        }
+      }
+      __syncthreads();
+    }
+    // ---------------- output (decoding.py:620-626, 1486-1531); llr[] now holds the marginals
+    if (return_infobits) {
+      float* o = out + (size_t)b * p.k;
+      for (int v = tid; v < p.k; v += NT) {
+        const float x = clampf(llr[v], -llr_max, llr_max);
+        o[v] = hard_out ? ((0.f >= x) ? 1.f : 0.f) : -1.f * x;
+      }
+    } else {
+      float* o = out + (size_t)b * p.n;
+      for (int i = tid; i < p.n; i += NT) {
+        const float x = clampf(llr[short_to_full(p, out_to_short(p, i))], -llr_max, llr_max);
+        o[i] = hard_out ? ((0.f >= x) ? 1.f : 0.f) : -1.f * x;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                     float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
+                     size_t workspace_bytes, hipStream_t st) {
+  if (!h->bp_ok || !h->ms_col_ent || !h->ms_cn_list || !h->ms_vn_list || !h->ms_vn_ptr) {
+    set_error("messages of this code do not fit in LDS");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  float* llr_ws = nullptr;
+  if (h->bp_llr_global) {
+    if (!workspace || workspace_bytes < onchip_bp_workspace_bytes(h, batch)) {
+      set_error("workspace too small (samd_ldpc5g_decode_workspace_bytes)");
+      return SAMD_ERR_WORKSPACE;
+    }
+    llr_ws = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
+  }
+  const bool pow2 = (h->z & (h->z - 1)) == 0;
+  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, int, float, float, int, int, int,
+                         const int32_t*, const int32_t*, const int2*, const int32_t*, const int2*);
+#define SAMD_MS_K(NWV, G) ldpc5g_decode_ms_kernel<false, NWV, G>, ldpc5g_decode_ms_kernel<true, NWV, G>
+  static const kern_t kerns[12] = {SAMD_MS_K(16, false), SAMD_MS_K(8, false), SAMD_MS_K(4, false),
+                                   SAMD_MS_K(2, false),  SAMD_MS_K(1, false), SAMD_MS_K(16, true)};
+#undef SAMD_MS_K
+  const int nw = h->bp_waves;
+  const int wi = h->bp_llr_global ? 5 : (nw == 16 ? 0 : nw == 8 ? 1 : nw == 4 ? 2 : nw == 2 ? 3 : 4);
+  const int ki = 2 * wi + (pow2 ? 1 : 0);
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int nbu = (h->n_vn + h->z - 1) / h->z;
+  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;
+  hipLaunchKernelGGL(kerns[ki], dim3(onchip_bp_grid(h, batch)), dim3(nw * 64), onchip_bp_lds_bytes(h), st, llr, out,
+                     llr_ws, rm, h->n_cn, nbu, batch, num_iter, llr_max, off, hard_out, return_infobits,
+                     h->bp_edges * h->z, h->ms_col_ent, h->ms_cn_ptr, reinterpret_cast<const int2*>(h->ms_cn_list),
+                     h->ms_vn_ptr, reinterpret_cast<const int2*>(h->ms_vn_list));
+  return launch_status();
+}
+
+}  // namespace samd

@@ -373,6 +373,12 @@ def test_5g_minsum_bit_exact_both_engines(phy, k, n, bg, m, cn):
         got_onchip = _np(dec(llr))
         assert dec._onchip_ok, "on-chip engine should accept this code"
         assert np.array_equal(got_onchip, ref), f"on-chip {cn} it={it}"
+        os.environ["SAMD_ONCHIP_COMPRESSED"] = "1"              # compressed check-node state engine (every code size)
+        try:
+            got_compressed = _np(dec(llr))
+        finally:
+            del os.environ["SAMD_ONCHIP_COMPRESSED"]
+        assert dec._onchip_ok and np.array_equal(got_compressed, ref), f"on-chip (compressed state) {cn} it={it}"
         dec._onchip_ok = False                                  # force the HBM-resident engine
         got_generic = _np(dec(llr))
         assert np.array_equal(got_generic, ref), f"generic {cn} it={it}"
