@@ -244,13 +244,25 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     const int c = by_row[r][d - 1].first, sft = by_row[r][d - 1].second;
     if (col_deg[c] == 1 && sft == 0 && d >= 3 && d <= 10) { fused_col[r] = c; col_fused[c] = 1; }
   }
+  // two consecutive fully valid chunks of a row (degree <= 10) / column (degree <= 12) form one pair item (bit 24)
   std::vector<std::pair<int, int32_t>> ci2, vi2, vf2;
   for (int r = 0; r < ncu; ++r)
-    for (int q = 0; q < chunks; ++q)
-      if (r * z + q * 64 < h->n_cn) ci2.push_back({(int)by_row[r].size() + 2, r | (q << 8)});
+    for (int q = 0; q < chunks; ++q) {
+      if (r * z + q * 64 >= h->n_cn) continue;
+      const int d = (int)by_row[r].size();
+      const bool pair = d <= 10 && (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn &&
+                        (fused_col[r] < 0 || fused_col[r] * z + (q + 2) * 64 <= h->n_vn);
+      if (pair) { ci2.push_back({2 * d + 2, r | (q << 8) | (1 << 24)}); ++q; }
+      else ci2.push_back({d + 2, r | (q << 8)});
+    }
   for (int c = 0; c < nbu; ++c)
-    for (int q = 0; q < chunks; ++q)
-      if (c * z + q * 64 < h->n_vn) (col_fused[c] ? vf2 : vi2).push_back({col_deg[c] + 3, c | (q << 8)});
+    for (int q = 0; q < chunks; ++q) {
+      if (c * z + q * 64 >= h->n_vn) continue;
+      const bool pair = col_deg[c] <= 12 && (q + 2) * 64 <= z && c * z + (q + 2) * 64 <= h->n_vn;
+      auto& dst = col_fused[c] ? vf2 : vi2;
+      if (pair) { dst.push_back({2 * col_deg[c] + 3, c | (q << 8) | (1 << 24)}); ++q; }
+      else dst.push_back({col_deg[c] + 3, c | (q << 8)});
+    }
   std::vector<int32_t> mcp, mcl, mvp, mvl, mfp, mfl;
   lpt_schedule(ci2, h->bp_waves, &mcp, &mcl);
   lpt_schedule(vi2, h->bp_waves, &mvp, &mvl);
@@ -258,11 +270,15 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   for (int32_t o : mfp) mvp.push_back(o + (int32_t)mvl.size());
   mvl.insert(mvl.end(), mfl.begin(), mfl.end());
   for (int32_t d : mcl) {
-    const int r = d & 0xFF, f = fused_col[r] >= 0;
-    cl2.push_back((row_off[r] & 0x3FFFF) | (((int)by_row[r].size() | (f << 5)) << 18));
-    cl2.push_back(d | ((f ? fused_col[r] : 0) << 16));
+    const int r = d & 0xFF, f = fused_col[r] >= 0, pr = (d >> 24) & 1;
+    cl2.push_back((row_off[r] & 0x3FFFF) | (((int)by_row[r].size() | (f << 5) | (pr << 6)) << 18));
+    cl2.push_back((d & 0xFFFF) | ((f ? fused_col[r] : 0) << 16));
   }
-  for (int32_t d : mvl) { vl2.push_back(d | (col_deg[d & 0xFF] << 16)); vl2.push_back(col_start[d & 0xFF]); }
+  for (int32_t d : mvl) {
+    const int c = d & 0xFF, pr = (d >> 24) & 1;
+    vl2.push_back((d & 0xFFFF) | ((col_deg[c] | (pr << 5)) << 16));
+    vl2.push_back(col_start[c]);
+  }
   cl2.resize(cl2.size() + 2, 0); vl2.resize(vl2.size() + 2, 0);
   int rc = upload(&h->bp_row_off, row_off.data(), row_off.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_col_ent, col_ent.data(), col_ent.size());

@@ -33,94 +33,118 @@ __device__ __forceinline__ void lds_st(unsigned a, float v) { *(lds_f32*)(uintpt
 
 __device__ __forceinline__ float ms_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
-// one check node per lane: row of exact degree D, its messages are D lane-contiguous blocks from byte a0.
+// one check node per lane and chunk: row of exact degree D, its messages are D lane-contiguous blocks from byte a0.
+// NCH: consecutive 64-lane chunks of lifted copies handled in one pass (lane z and lane z+64 share every
+// scalar and every address register - the second chunk is the same address + 256 bytes): two independent
+// dependency chains per wave and half as many work items (their dispatch is scalar overhead).
 // FUSE1: the row's last edge goes to a degree-1 variable node of the same lane (identity block of the base
 // graph's extension part).  Its VN update - x = c2v + llr, v2c = clip(x - c2v) - is done right here, so
 // these columns (42 of C2's 68) never appear in the VN phase; llr_v points at that VN's channel LLR.
-template <int D, bool FUSE1>
+template <int D, int NCH, bool FUSE1>
 __device__ __forceinline__ void ms_cn_row(unsigned a0, unsigned z4, float llr_max, float offset,
                                           float* __restrict__ llr_v, bool last) {
-  float v[D];
+  float v[NCH][D];
   unsigned a[D];
-  float lf = 0.f;
-  if (FUSE1) lf = *llr_v;
+  float lf[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) lf[h] = FUSE1 ? llr_v[64 * h] : 0.f;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     a[i] = i ? a[i - 1] + z4 : a0;
-    v[i] = lds_ld(a[i]);
-  }
-  float m1 = INFINITY, m2 = INFINITY;
-  unsigned sx = 0u;
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    m2 = ms_med3(m1, m2, fabsf(v[i]));              // second smallest, with multiplicity
-    m1 = ms_med3(m1, fabsf(v[i]), -INFINITY);       // min(m1, |v|) without a canonicalising extra operation
-    sx ^= __float_as_uint(v[i]);                    // bit 31 = node sign
+    for (int h = 0; h < NCH; ++h) v[h][i] = lds_ld(a[i] + 256u * h);
   }
-  // unique minimum <=> m2 > m1; (m2 - m1) + m1 is the reference's arithmetic (decoding.py:863)
-  const float min_e = (m2 > m1) ? ((m2 - m1) + m1) : m1;
-  const float a1 = ms_med3(m1 - offset, 0.f, llr_max);      // plain min-sum: offset = 0 (exact)
-  const float a2 = ms_med3(min_e - offset, 0.f, llr_max);
+  float m1[NCH], m2[NCH];
+  unsigned sx[NCH];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const float mag = (fabsf(v[i]) == m1) ? a2 : a1;
-    const unsigned s = (__float_as_uint(v[i]) ^ sx) & 0x80000000u;   // own sign x node sign
-    float c2v = __uint_as_float(s | __float_as_uint(mag));
-    if (FUSE1 && i == D - 1) {
-      const float x = c2v + lf;                     // (0 + c2v) + llr; llr is never -0, so 0 + c2v needs no operation
-      if (last) *llr_v = x;
-      c2v = ms_med3(x - c2v, -llr_max, llr_max);    // the slot now holds the next v2c
+  for (int h = 0; h < NCH; ++h) { m1[h] = INFINITY; m2[h] = INFINITY; sx[h] = 0u; }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      m2[h] = ms_med3(m1[h], m2[h], fabsf(v[h][i]));      // second smallest, with multiplicity
+      m1[h] = ms_med3(m1[h], fabsf(v[h][i]), 0.f);        // = min(m1, |v|) for non-negative values, one operation
+      sx[h] ^= __float_as_uint(v[h][i]);                  // bit 31 = node sign
     }
-    lds_st(a[i], c2v);
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    // unique minimum <=> m2 > m1; (m2 - m1) + m1 is the reference's arithmetic (decoding.py:863)
+    const float min_e = (m2[h] > m1[h]) ? ((m2[h] - m1[h]) + m1[h]) : m1[h];
+    const float a1 = ms_med3(m1[h] - offset, 0.f, llr_max);      // plain min-sum: offset = 0 (exact)
+    const float a2 = ms_med3(min_e - offset, 0.f, llr_max);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const float mag = (fabsf(v[h][i]) == m1[h]) ? a2 : a1;
+      const unsigned sg = (__float_as_uint(v[h][i]) ^ sx[h]) & 0x80000000u;   // own sign x node sign
+      float c2v = __uint_as_float(sg | __float_as_uint(mag));
+      if (FUSE1 && i == D - 1) {
+        const float x = c2v + lf[h];                // (0 + c2v) + llr; llr is never -0, so 0 + c2v needs no operation
+        if (last) llr_v[64 * h] = x;
+        c2v = ms_med3(x - c2v, -llr_max, llr_max);  // the slot now holds the next v2c
+      }
+      lds_st(a[i] + 256u * h, c2v);
+    }
   }
 }
 
-// one variable node per lane, column of exact degree D.  ent[2i] = edge block byte offset, ent[2i+1] = 4 shift
-// zwv: 4Z-1 (POW2) or 4Z, in a VGPR so that (t & zw) | base is one v_and_or_b32
-template <int D, bool POW2, bool INIT>
+// one variable node per lane and chunk, column of exact degree D.  ent[2i] = edge block byte offset,
+// ent[2i+1] = 4 shift; zwv: 4Z-1 (POW2) or 4Z, in a VGPR so that (t & zw) | base is one v_and_or_b32
+template <int D, int NCH, bool POW2, bool INIT>
 __device__ __forceinline__ void ms_vn_col(const int32_t* __restrict__ ent, unsigned zz4, unsigned zwv,
                                           float* __restrict__ llr_v, float llr_max, bool last) {
-  unsigned a[D];
-  float c[D];
-  const float l = *llr_v;
-  float x = 0.f;
+  unsigned a[NCH][D];
+  float c[NCH][D];
+  float l[NCH], x[NCH];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    const unsigned t = zz4 - (unsigned)ent[2 * i + 1];
-    // edge blocks are aligned to 4Z when Z is a power of two: (t mod 4Z) | base
-    a[i] = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t + zwv) + (unsigned)ent[2 * i]);
-    if (INIT) {
-      lds_st(a[i], l);
-    } else {
-      c[i] = lds_ld(a[i]);
-      x += c[i];
+  for (int h = 0; h < NCH; ++h) { l[h] = llr_v[64 * h]; x[h] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const unsigned t = zz4 + 256u * h - (unsigned)ent[2 * i + 1];
+      // edge blocks are aligned to 4Z when Z is a power of two: (t mod 4Z) | base
+      a[h][i] = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t + zwv) + (unsigned)ent[2 * i]);
+      if (INIT) {
+        lds_st(a[h][i], l[h]);
+      } else {
+        c[h][i] = lds_ld(a[h][i]);
+        x[h] += c[h][i];
+      }
     }
-  }
   if (INIT) return;
-  x += l;
 #pragma unroll
-  for (int i = 0; i < D; ++i) lds_st(a[i], ms_med3(x - c[i], -llr_max, llr_max));
-  if (last) *llr_v = x;
+  for (int h = 0; h < NCH; ++h) {
+    x[h] += l[h];
+#pragma unroll
+    for (int i = 0; i < D; ++i) lds_st(a[h][i], ms_med3(x[h] - c[h][i], -llr_max, llr_max));
+    if (last) llr_v[64 * h] = x[h];
+  }
 }
+
 
 template <bool POW2, bool INIT>
 __device__ __forceinline__ void ms_vn_item(const int32_t* __restrict__ ent, int d, unsigned zz4, unsigned zwv,
                                            float* __restrict__ llr_v, float llr_max, bool last) {
-#define SAMD_MS_VN(D) case D: ms_vn_col<D, POW2, INIT>(ent, zz4, zwv, llr_v, llr_max, last); break
-  switch (d) {
+#define SAMD_MS_VN(D) case D: ms_vn_col<D, 1, POW2, INIT>(ent, zz4, zwv, llr_v, llr_max, last); break
+#define SAMD_MS_VN2(D) case 32 + D: ms_vn_col<D, 2, POW2, INIT>(ent, zz4, zwv, llr_v, llr_max, last); break
+  switch (d) {                                                       // degree | pair << 5
     SAMD_MS_VN(1); SAMD_MS_VN(2); SAMD_MS_VN(3); SAMD_MS_VN(4); SAMD_MS_VN(5); SAMD_MS_VN(6); SAMD_MS_VN(7);
     SAMD_MS_VN(8); SAMD_MS_VN(9); SAMD_MS_VN(10); SAMD_MS_VN(11); SAMD_MS_VN(12); SAMD_MS_VN(13); SAMD_MS_VN(14);
     SAMD_MS_VN(15); SAMD_MS_VN(16); SAMD_MS_VN(17); SAMD_MS_VN(18); SAMD_MS_VN(19); SAMD_MS_VN(20); SAMD_MS_VN(21);
     SAMD_MS_VN(22); SAMD_MS_VN(23); SAMD_MS_VN(24); SAMD_MS_VN(25); SAMD_MS_VN(26); SAMD_MS_VN(27); SAMD_MS_VN(28);
     SAMD_MS_VN(29); SAMD_MS_VN(30);
+    SAMD_MS_VN2(1); SAMD_MS_VN2(2); SAMD_MS_VN2(3); SAMD_MS_VN2(4); SAMD_MS_VN2(5); SAMD_MS_VN2(6); SAMD_MS_VN2(7);
+    SAMD_MS_VN2(8); SAMD_MS_VN2(9); SAMD_MS_VN2(10); SAMD_MS_VN2(11); SAMD_MS_VN2(12);
     default: break;
   }
 #undef SAMD_MS_VN
+#undef SAMD_MS_VN2
 }
 
 // list entries are self-contained (no dependent table look-ups) and the next one is fetched while the current
 // item runs:  VN (c | chunk<<8 | degree<<16,  dword offset of the column's edge table),
-//             CN (row block byte offset | degree<<18 | fused<<23,  r | chunk<<8 | fused column<<16)
+//             CN (row block byte offset | degree<<18 | fused<<23 | pair<<24,  r | chunk<<8 | fused column<<16)
+// a pair item covers chunks (chunk, chunk+1), all 128 lanes valid; VN degree field = degree | pair<<5
 // vn_ptr = [NW+1 offsets of the per-iteration lists | NW+1 offsets of the fused degree-1 columns (init only)]
 template <bool POW2, int NW, bool LLRG>
 __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
@@ -159,7 +183,8 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
         const int c = d0 & 0xFF;
         const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
         const int vn = c * (int)z + (int)zz;
-        if (zz < z && vn < n_vn) ms_vn_item<POW2, true>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, false);
+        if (((d0 >> 21) & 1) || (zz < z && vn < n_vn))
+          ms_vn_item<POW2, true>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, false);
       }
     }
     __syncthreads();
@@ -175,17 +200,25 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
           const int r = d1 & 0xFF;
           const unsigned zz = (unsigned)(((d1 >> 8) & 0xFF) * 64 + lane);
           const unsigned a0 = (ro & 0x3FFFFu) + 4u * zz;
-          if (zz < z && (unsigned)r * z + zz < (unsigned)n_cn) {
+          if (((ro >> 24) & 1u) || (zz < z && (unsigned)r * z + zz < (unsigned)n_cn)) {
             float* lv = llr + (d1 >> 16) * (int)z + (int)zz;          // channel LLR of the fused degree-1 VN
-#define SAMD_MS_CN(D) case D: ms_cn_row<D, false>(a0, z4, llr_max, offset, lv, last); break
-#define SAMD_MS_CNF(D) case 32 + D: ms_cn_row<D, true>(a0, z4, llr_max, offset, lv, last); break
-            switch (ro >> 18) {                                      // degree | fused << 5
+#define SAMD_MS_CN(D) case D: ms_cn_row<D, 1, false>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CNF(D) case 32 + D: ms_cn_row<D, 1, true>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CN2(D) case 64 + D: ms_cn_row<D, 2, false>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CNF2(D) case 96 + D: ms_cn_row<D, 2, true>(a0, z4, llr_max, offset, lv, last); break
+            switch (ro >> 18) {                                      // degree | fused << 5 | pair << 6
               SAMD_MS_CN(3); SAMD_MS_CN(4); SAMD_MS_CN(5); SAMD_MS_CN(6); SAMD_MS_CN(7); SAMD_MS_CN(8); SAMD_MS_CN(9);
               SAMD_MS_CN(10); SAMD_MS_CN(19);
               SAMD_MS_CNF(3); SAMD_MS_CNF(4); SAMD_MS_CNF(5); SAMD_MS_CNF(6); SAMD_MS_CNF(7); SAMD_MS_CNF(8);
               SAMD_MS_CNF(9); SAMD_MS_CNF(10);
+              SAMD_MS_CN2(3); SAMD_MS_CN2(4); SAMD_MS_CN2(5); SAMD_MS_CN2(6); SAMD_MS_CN2(7); SAMD_MS_CN2(8);
+              SAMD_MS_CN2(9); SAMD_MS_CN2(10);
+              SAMD_MS_CNF2(3); SAMD_MS_CNF2(4); SAMD_MS_CNF2(5); SAMD_MS_CNF2(6); SAMD_MS_CNF2(7); SAMD_MS_CNF2(8);
+              SAMD_MS_CNF2(9); SAMD_MS_CNF2(10);
               default: break;
             }
+#undef SAMD_MS_CN2
+#undef SAMD_MS_CNF2
 #undef SAMD_MS_CN
 #undef SAMD_MS_CNF
           } else if (zz < z) {
@@ -203,7 +236,8 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
           const int c = d0 & 0xFF;
           const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
           const int vn = c * (int)z + (int)zz;
-          if (zz < z && vn < n_vn) ms_vn_item<POW2, false>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, last);
+          if (((d0 >> 21) & 1) || (zz < z && vn < n_vn))
+            ms_vn_item<POW2, false>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, last);
         }
       }
       __syncthreads();
