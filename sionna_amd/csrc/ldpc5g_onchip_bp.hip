@@ -244,24 +244,25 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     const int c = by_row[r][d - 1].first, sft = by_row[r][d - 1].second;
     if (col_deg[c] == 1 && sft == 0 && d >= 3 && d <= 10) { fused_col[r] = c; col_fused[c] = 1; }
   }
-  // two consecutive fully valid chunks of a row (degree <= 10) / column (degree <= 12) form one pair item (bit 24)
+  // two consecutive fully valid chunks of a row / column (degree <= 12) form one pair item (bit 24);
+  // weights ~ instructions: 9 (CN) / 5 (VN) per edge and chunk + ~40 for the item's dispatch
   std::vector<std::pair<int, int32_t>> ci2, vi2, vf2;
   for (int r = 0; r < ncu; ++r)
     for (int q = 0; q < chunks; ++q) {
       if (r * z + q * 64 >= h->n_cn) continue;
       const int d = (int)by_row[r].size();
-      const bool pair = d <= 10 && (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn &&
+      const bool pair = (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn &&
                         (fused_col[r] < 0 || fused_col[r] * z + (q + 2) * 64 <= h->n_vn);
-      if (pair) { ci2.push_back({2 * d + 2, r | (q << 8) | (1 << 24)}); ++q; }
-      else ci2.push_back({d + 2, r | (q << 8)});
+      if (pair) { ci2.push_back({18 * d + 40, r | (q << 8) | (1 << 24)}); ++q; }
+      else ci2.push_back({9 * d + 40, r | (q << 8)});
     }
   for (int c = 0; c < nbu; ++c)
     for (int q = 0; q < chunks; ++q) {
       if (c * z + q * 64 >= h->n_vn) continue;
       const bool pair = col_deg[c] <= 12 && (q + 2) * 64 <= z && c * z + (q + 2) * 64 <= h->n_vn;
       auto& dst = col_fused[c] ? vf2 : vi2;
-      if (pair) { dst.push_back({2 * col_deg[c] + 3, c | (q << 8) | (1 << 24)}); ++q; }
-      else dst.push_back({col_deg[c] + 3, c | (q << 8)});
+      if (pair) { dst.push_back({10 * col_deg[c] + 40, c | (q << 8) | (1 << 24)}); ++q; }
+      else dst.push_back({5 * col_deg[c] + 40, c | (q << 8)});
     }
   std::vector<int32_t> mcp, mcl, mvp, mvl, mfp, mfl;
   lpt_schedule(ci2, h->bp_waves, &mcp, &mcl);

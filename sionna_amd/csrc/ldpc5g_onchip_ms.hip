@@ -89,14 +89,15 @@ __device__ __forceinline__ void ms_cn_row(unsigned a0, unsigned z4, float llr_ma
 
 // one variable node per lane and chunk, column of exact degree D.  ent[2i] = edge block byte offset,
 // ent[2i+1] = 4 shift; zwv: 4Z-1 (POW2) or 4Z, in a VGPR so that (t & zw) | base is one v_and_or_b32
+// l0 / l1: channel LLRs of the lane's VN in chunk 0 / 1 (fetched by the caller one item ahead)
 template <int D, int NCH, bool POW2, bool INIT>
 __device__ __forceinline__ void ms_vn_col(const int32_t* __restrict__ ent, unsigned zz4, unsigned zwv,
-                                          float* __restrict__ llr_v, float llr_max, bool last) {
+                                          float* __restrict__ llr_v, float l0, float l1, float llr_max, bool last) {
   unsigned a[NCH][D];
   float c[NCH][D];
   float l[NCH], x[NCH];
 #pragma unroll
-  for (int h = 0; h < NCH; ++h) { l[h] = llr_v[64 * h]; x[h] = 0.f; }
+  for (int h = 0; h < NCH; ++h) { l[h] = h ? l1 : l0; x[h] = 0.f; }
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -124,9 +125,9 @@ __device__ __forceinline__ void ms_vn_col(const int32_t* __restrict__ ent, unsig
 
 template <bool POW2, bool INIT>
 __device__ __forceinline__ void ms_vn_item(const int32_t* __restrict__ ent, int d, unsigned zz4, unsigned zwv,
-                                           float* __restrict__ llr_v, float llr_max, bool last) {
-#define SAMD_MS_VN(D) case D: ms_vn_col<D, 1, POW2, INIT>(ent, zz4, zwv, llr_v, llr_max, last); break
-#define SAMD_MS_VN2(D) case 32 + D: ms_vn_col<D, 2, POW2, INIT>(ent, zz4, zwv, llr_v, llr_max, last); break
+                                           float* __restrict__ llr_v, float l0, float l1, float llr_max, bool last) {
+#define SAMD_MS_VN(D) case D: ms_vn_col<D, 1, POW2, INIT>(ent, zz4, zwv, llr_v, l0, l1, llr_max, last); break
+#define SAMD_MS_VN2(D) case 32 + D: ms_vn_col<D, 2, POW2, INIT>(ent, zz4, zwv, llr_v, l0, l1, llr_max, last); break
   switch (d) {                                                       // degree | pair << 5
     SAMD_MS_VN(1); SAMD_MS_VN(2); SAMD_MS_VN(3); SAMD_MS_VN(4); SAMD_MS_VN(5); SAMD_MS_VN(6); SAMD_MS_VN(7);
     SAMD_MS_VN(8); SAMD_MS_VN(9); SAMD_MS_VN(10); SAMD_MS_VN(11); SAMD_MS_VN(12); SAMD_MS_VN(13); SAMD_MS_VN(14);
@@ -183,14 +184,26 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
         const int c = d0 & 0xFF;
         const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
         const int vn = c * (int)z + (int)zz;
-        if (((d0 >> 21) & 1) || (zz < z && vn < n_vn))
-          ms_vn_item<POW2, true>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, false);
+        const bool pr = (d0 >> 21) & 1;
+        if (pr || (zz < z && vn < n_vn))
+          ms_vn_item<POW2, true>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr[vn], pr ? llr[vn + 64] : 0.f, llr_max, false);
       }
     }
     __syncthreads();
 
     for (int it = 0; it < num_iter; ++it) {
       const bool last = (it == num_iter - 1);
+      // vn_fetch: descriptor and channel LLRs of this wave's first VN item, in flight during the CN phase
+      int2 vfirst = make_int2(0, 0);
+      float lf0 = 0.f, lf1 = 0.f;
+      if (v0 < v1) {
+        vfirst = vn_list[v0];
+        const int e0 = __builtin_amdgcn_readfirstlane(vfirst.x);
+        const int vn2 = (e0 & 0xFF) * (int)z + ((e0 >> 8) & 0xFF) * 64 + lane;
+        const bool pr2 = (e0 >> 21) & 1;
+        if (pr2 || vn2 < n_vn) lf0 = llr[vn2];
+        if (pr2) lf1 = llr[vn2 + 64];
+      }
       {
         int2 nxt = c0 < c1 ? cn_list[c0] : make_int2(0, 0);
         for (int t = c0; t < c1; ++t) {
@@ -212,7 +225,7 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
               SAMD_MS_CNF(3); SAMD_MS_CNF(4); SAMD_MS_CNF(5); SAMD_MS_CNF(6); SAMD_MS_CNF(7); SAMD_MS_CNF(8);
               SAMD_MS_CNF(9); SAMD_MS_CNF(10);
               SAMD_MS_CN2(3); SAMD_MS_CN2(4); SAMD_MS_CN2(5); SAMD_MS_CN2(6); SAMD_MS_CN2(7); SAMD_MS_CN2(8);
-              SAMD_MS_CN2(9); SAMD_MS_CN2(10);
+              SAMD_MS_CN2(9); SAMD_MS_CN2(10); SAMD_MS_CN2(19);
               SAMD_MS_CNF2(3); SAMD_MS_CNF2(4); SAMD_MS_CNF2(5); SAMD_MS_CNF2(6); SAMD_MS_CNF2(7); SAMD_MS_CNF2(8);
               SAMD_MS_CNF2(9); SAMD_MS_CNF2(10);
               default: break;
@@ -229,15 +242,28 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
       }
       __syncthreads();
       {
-        int2 nxt = v0 < v1 ? vn_list[v0] : make_int2(0, 0);
+        // the channel LLRs of an item are fetched one item ahead (the first item's before the CN phase, see
+        // vn_fetch above): an L2 round trip is longer than a whole VN item
+        int2 cur = vfirst;
+        float l0 = lf0, l1 = lf1;
         for (int t = v0; t < v1; ++t) {
-          const int d0 = __builtin_amdgcn_readfirstlane(nxt.x), d1 = __builtin_amdgcn_readfirstlane(nxt.y);
-          if (t + 1 < v1) nxt = vn_list[t + 1];
+          const int d0 = __builtin_amdgcn_readfirstlane(cur.x), d1 = __builtin_amdgcn_readfirstlane(cur.y);
+          int2 nxt = make_int2(0, 0);
+          float n0 = 0.f, n1 = 0.f;
+          if (t + 1 < v1) {
+            nxt = vn_list[t + 1];
+            const int e0 = __builtin_amdgcn_readfirstlane(nxt.x);
+            const int vn2 = (e0 & 0xFF) * (int)z + ((e0 >> 8) & 0xFF) * 64 + lane;
+            const bool pr2 = (e0 >> 21) & 1;
+            if (pr2 || vn2 < n_vn) n0 = llr[vn2];
+            if (pr2) n1 = llr[vn2 + 64];
+          }
           const int c = d0 & 0xFF;
           const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
           const int vn = c * (int)z + (int)zz;
           if (((d0 >> 21) & 1) || (zz < z && vn < n_vn))
-            ms_vn_item<POW2, false>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr_max, last);
+            ms_vn_item<POW2, false>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, l0, l1, llr_max, last);
+          cur = nxt; l0 = n0; l1 = n1;
         }
       }
       __syncthreads();
