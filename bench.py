@@ -316,7 +316,8 @@ def main():
     value = total_cw / t_wall
     bytes_alg = b_msg(args.num_iter, k) * B
     achieved = bytes_alg / (dec_ms * 1e-3) / 1e9
-    kernel = ("ldpc5g_decode_v2_kernel (on-chip, LDS-resident compressed min-sum state)" if dec._cn_mode in (2, 3)
+    kernel = ("ldpc5g_decode_ms_kernel (on-chip min-sum, one float per edge in LDS, channel LLRs in an L2 workspace row)"
+              if dec._cn_mode in (2, 3)
               else "ldpc5g_decode_bp_kernel (on-chip, one float per edge in LDS)") if onchip else \
              "cn_pass_kernel + vn_pass_kernel (HBM-resident, 2 launches per iteration)"
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -335,7 +336,8 @@ def main():
             pass
     if onchip:
         roofline["note"] = ("messages stay in LDS: frac is relative to the HBM-resident formulation's "
-                            "algorithmic bytes and may exceed 1; real HBM traffic = compulsory_io")
+                            "algorithmic bytes and may exceed 1; real HBM traffic = compulsory_io "
+                            "(+ write-backs of the L2 workspace rows, see traffic)")
 
     out = {
         "metric": "codeword-decodes/sec (n=8448, BP iters=20)", "value": round(value, 1),

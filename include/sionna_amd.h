@@ -126,15 +126,20 @@ int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const float* x_hat,
                                      float* out, int batch, void* stream);
 
 size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode);
+/* Which engine samd_ldpc5g_decode_f32 runs for this code and rule: 0 none (SAMD_ERR_UNSUPPORTED: use the
+ * HBM-resident samd_ldpc_bp_decode_f32), 1 on chip with compressed check-node state (min-sum family, every
+ * code), 2 on chip with one float per edge in LDS (all rules; codes whose messages fit in 160 KB). */
+int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode);
 
 /* Whole LDPC5GDecoder.call on chip: rate recovery + num_iter flooding BP iterations +
  * output mapping in ONE kernel, one codeword per workgroup, messages resident in LDS.
- *   SAMD_CN_MINSUM / SAMD_CN_OFFSET_MINSUM: compressed check-node state, every 5G code; codes whose
- *     state exceeds 160 KB keep the channel LLRs, then the VN totals, then the sign words in `workspace`
- *     (one L2-resident row per workgroup); results are identical.
- *   SAMD_CN_BOXPLUS_PHI / SAMD_CN_BOXPLUS: one float per edge in LDS (codes whose E messages x 4 B fit in 160 KB, i.e.
- *     n=8448 rate 1/3 and smaller; channel LLRs in `workspace` when they do not fit beside the messages);
- *     same arithmetic and summation order as samd_ldpc_bp_decode_f32 - identical bits.
+ *   One float per edge in LDS (engine 2) when the code's E messages x 4 B fit in 160 KB - n=8448 rate 1/3
+ *     and smaller; channel LLRs in `workspace` (one L2-resident row per workgroup) when they do not fit
+ *     beside the messages.  All four check-node rules; boxplus / boxplus-phi use the arithmetic and summation
+ *     order of samd_ldpc_bp_decode_f32 (identical bits), min-sum is bit-exact.
+ *   SAMD_CN_MINSUM / SAMD_CN_OFFSET_MINSUM on larger codes (engine 1): compressed check-node state, every 5G
+ *     code; codes whose state exceeds 160 KB keep the channel LLRs, then the VN totals, then the sign words
+ *     in `workspace`; same results.
  * Returns SAMD_ERR_UNSUPPORTED when the code cannot run on chip (caller then uses rate_recover +
  * samd_ldpc_bp_decode_f32 + extract).  samd_ldpc5g_decode_workspace_bytes(h, batch, cn_mode) sizes `workspace`.
  * llr [batch,n] logits -> out [batch,k] (return_infobits=1) or [batch,n] (=0). */

@@ -330,11 +330,8 @@ extern "C" void samd_ldpc5g_destroy(samd_ldpc5g_t* h) {
 extern "C" int samd_ldpc5g_encode_f32(const samd_ldpc5g_t* h, const float* bits, float* out, int batch, void* stream) {
   SAMD_REQUIRE(h && bits && out && batch > 0, "bad argument");
   const size_t lds = (size_t)h->n_ldpc + 4 * (size_t)h->z;
-  static bool attr_set = false;
-  if (!attr_set) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc5g_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-    attr_set = true;
-  }
+  // set on every launch: the attribute is per device and a process may drive several
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc5g_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   hipLaunchKernelGGL(ldpc5g_encode_kernel, dim3(batch), dim3(256), lds, (hipStream_t)stream, bits, out, make_rm(h),
                      h->mb, h->k_b, h->bg, h->s_a, h->s_b, h->row_ptr, h->row_ent);
   return launch_status();
@@ -374,6 +371,14 @@ extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int
   return onchip_workspace_bytes(h, batch);
 }
 
+extern "C" int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode) {
+  if (!h) return 0;
+  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) return h->bp_ok ? 2 : 0;
+  if (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM) return 0;
+  if (use_explicit_minsum(h)) return 2;
+  return (h->v2_ok || decode_lds_bytes(h) <= 160 * 1024) ? 1 : 0;
+}
+
 extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out, int batch, int num_iter,
                                       int cn_mode, float llr_max, float offset, int hard_out, int return_infobits,
                                       void* workspace, size_t workspace_bytes, void* stream) {
@@ -410,11 +415,8 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   }
   const bool off = (cn_mode == SAMD_CN_OFFSET_MINSUM);
   const void* fn = off ? (const void*)ldpc5g_decode_kernel<true> : (const void*)ldpc5g_decode_kernel<false>;
-  static bool attr_set[2] = {false, false};
-  if (!attr_set[off]) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[off] = true;
-  }
+  // set on every launch: the attribute is per device and a process may drive several
+  SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

@@ -483,11 +483,8 @@ int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const int nw = h->dec_waves;
   const int ki = h->llr_global ? 8 + 2 * h->llr_global + (pow2 ? 1 : 0)
                                : ((nw == 16 ? 0 : nw == 8 ? 2 : nw == 4 ? 4 : nw == 2 ? 6 : 8) | (pow2 ? 1 : 0));
-  static bool attr_set[16] = {};
-  if (!attr_set[ki]) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[ki] = true;
-  }
+  // set on every launch: the attribute is per device and a process may drive several
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int grid = onchip_grid(h, batch);
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
   hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(nw * 64), lds, st, llr, out, llr_ws, rm, h->n_cn, h->ncu, h->nbu, batch,

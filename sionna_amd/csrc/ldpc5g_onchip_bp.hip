@@ -353,11 +353,8 @@ int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const int nw = h->bp_waves;
   const int wi = h->bp_llr_global ? 5 : (nw == 16 ? 0 : nw == 8 ? 1 : nw == 4 ? 2 : nw == 2 ? 3 : 4);
   const int ki = (phi ? 0 : 12) + 2 * wi + (pow2 ? 1 : 0);
-  static bool attr_set[24] = {};
-  if (!attr_set[ki]) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[ki] = true;
-  }
+  // set on every launch: the attribute is per device and a process may drive several
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
   hipLaunchKernelGGL(kerns[ki], dim3(onchip_bp_grid(h, batch)), dim3(nw * 64), onchip_bp_lds_bytes(h), st, llr, out, llr_ws, rm,

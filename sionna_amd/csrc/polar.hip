@@ -422,12 +422,9 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
     set_error("list state does not fit in LDS (reduce list_size or n)");
     return SAMD_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  // set on every launch: the attribute is per device and a process may drive several
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int m = 0;
   while ((1 << m) < n) ++m;
   const int grid = scl_grid(batch, n, list_size);
