@@ -66,24 +66,30 @@ __device__ __forceinline__ void ms_cn_row(unsigned a0, unsigned z4, float llr_ma
       m1[h] = ms_med3(m1[h], fabsf(v[h][i]), 0.f);        // = min(m1, |v|) for non-negative values, one operation
       sx[h] ^= __float_as_uint(v[h][i]);                  // bit 31 = node sign
     }
+  float a1[NCH], a2[NCH];
 #pragma unroll
   for (int h = 0; h < NCH; ++h) {
     // unique minimum <=> m2 > m1; (m2 - m1) + m1 is the reference's arithmetic (decoding.py:863)
     const float min_e = (m2[h] > m1[h]) ? ((m2[h] - m1[h]) + m1[h]) : m1[h];
-    const float a1 = ms_med3(m1[h] - offset, 0.f, llr_max);      // plain min-sum: offset = 0 (exact)
-    const float a2 = ms_med3(min_e - offset, 0.f, llr_max);
+    a1[h] = ms_med3(m1[h] - offset, 0.f, llr_max);      // plain min-sum: offset = 0 (exact)
+    a2[h] = ms_med3(min_e - offset, 0.f, llr_max);
+  }
 #pragma unroll
-    for (int i = 0; i < D; ++i) {
-      const float mag = (fabsf(v[h][i]) == m1[h]) ? a2 : a1;
+  for (int i = 0; i < D; ++i) {
+    float c2v[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const float mag = (fabsf(v[h][i]) == m1[h]) ? a2[h] : a1[h];
       const unsigned sg = (__float_as_uint(v[h][i]) ^ sx[h]) & 0x80000000u;   // own sign x node sign
-      float c2v = __uint_as_float(sg | __float_as_uint(mag));
+      c2v[h] = __uint_as_float(sg | __float_as_uint(mag));
       if (FUSE1 && i == D - 1) {
-        const float x = c2v + lf[h];                // (0 + c2v) + llr; llr is never -0, so 0 + c2v needs no operation
+        const float x = c2v[h] + lf[h];             // (0 + c2v) + llr; llr is never -0, so 0 + c2v needs no operation
         if (last) llr_v[64 * h] = x;
-        c2v = ms_med3(x - c2v, -llr_max, llr_max);  // the slot now holds the next v2c
+        c2v[h] = ms_med3(x - c2v[h], -llr_max, llr_max);   // the slot now holds the next v2c
       }
-      lds_st(a[i] + 256u * h, c2v);
     }
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) lds_st(a[i] + 256u * h, c2v[h]);   // adjacent: one ds_write2st64_b32 per pair
   }
 }
 
