@@ -5,6 +5,8 @@ The reference pins these blocks only statistically or through invariants (SURVEY
 LMMSE error statistics, whitening -> identity covariance, TDL power-delay profile, "ber == 0" at
 high SNR); the same invariants are asserted here next to the value-level comparison with the
 oracle (complex64 arithmetic: rtol 1e-4 / atol 1e-5 unless stated)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -184,6 +186,14 @@ def test_fused_ofdm_lmmse_vs_oracle(phy, cfg):
     xh, ne = phy.ofdm.LMMSEEqualizer(rg, sm)(y, h_perf, 0., no)
     rxh, rne = o.ofdm_lmmse_equalize(org, osm, y, h_perf, np.zeros((1,) * 7, np.float32), no)
     assert np.allclose(_np(xh), rxh, rtol=2e-3, atol=3e-4) and np.allclose(_np(ne), rne, rtol=2e-3, atol=1e-5)
+    # without undesired streams the covariance is diagonal and a leaner kernel runs; it performs the general
+    # kernel's operations minus products with exact zeros
+    os.environ["SAMD_LMMSE_GENERAL"] = "1"
+    try:
+        xg, ng = phy.ofdm.LMMSEEqualizer(rg, sm)(y, h_perf, 0., no)
+    finally:
+        del os.environ["SAMD_LMMSE_GENERAL"]
+    assert np.array_equal(_np(xh), _np(xg)) and np.array_equal(_np(ne), _np(ng))
     # LS + nearest neighbour with its error variance table; per-batch noise
     no_b = rng.uniform(0.02, 0.1, size=(B,)).astype(np.float32)
     h_hat, ev = phy.ofdm.LSChannelEstimator(rg)(y, no_b)
