@@ -343,10 +343,12 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
   const int32_t dummy = h->ncu * z * 4;                       // zero "dummy check node" block, shift 0
   for (int c = 0; c < h->nb && ok; ++c) {
     const int d = (int)cols[c].size();
-    const int nfull = d / 16, r0 = d % 16;
+    int nfull = d / 16;
+    const int r0 = d % 16;
     int rem = -1;
     for (int k : kVnRemClasses) if (k >= r0) { rem = k; break; }
-    if (rem < 0 || nfull * 16 + rem > kColStride) { ok = false; break; }
+    if (rem < 0) { ++nfull; rem = 0; }                          // remainder 15: one more full chunk, one dummy slot
+    if (nfull * 16 + rem > kColStride) { ok = false; break; }
     col_cls[c] = nfull | (rem << 4);
     for (int i = 0; i < kColStride; ++i) {
       col_pad[((size_t)c * kColStride + i) * 2] = i < d ? cols[c][i].first : dummy;

@@ -216,7 +216,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::vector<std::pair<int, int32_t>> ci, vi;
   for (int r = 0; r < ncu; ++r)
     for (int q = 0; q < chunks; ++q)
-      if (r * z + q * 64 < h->n_cn) ci.push_back({8 * (int)by_row[r].size(), r | (q << 8)});
+      ci.push_back({8 * (int)by_row[r].size(), r | (q << 8)});   // also chunks of pruned check nodes only: the item keeps their slots at 0
   for (int c = 0; c < nbu; ++c)
     for (int q = 0; q < chunks; ++q)
       if (c * z + q * 64 < h->n_vn) vi.push_back({col_deg[c] + 2, c | (q << 8)});
@@ -249,8 +249,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::vector<std::pair<int, int32_t>> ci2, vi2, vf2;
   for (int r = 0; r < ncu; ++r)
     for (int q = 0; q < chunks; ++q) {
-      if (r * z + q * 64 >= h->n_cn) continue;
-      const int d = (int)by_row[r].size();
+      const int d = (int)by_row[r].size();                    // chunks of pruned check nodes only still get an item (it zeroes their slots)
       const bool pair = (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn &&
                         (fused_col[r] < 0 || fused_col[r] * z + (q + 2) * 64 <= h->n_vn);
       if (pair) { ci2.push_back({18 * d + 40, r | (q << 8) | (1 << 24)}); ++q; }

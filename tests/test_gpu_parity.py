@@ -387,6 +387,46 @@ def test_5g_minsum_bit_exact_both_engines(phy, k, n, bg, m, cn):
     assert np.array_equal(hard, cbind.bp_decode(odec, odec.rate_recover(llr))[:, :k])
 
 
+# random (k, n) pairs (seeded draw, fillers, odd lifting sizes, partial last base rows, rates 0.2 ... 0.9)
+RANDOM_CODES = [(7202, 11115), (1544, 2929), (711, 1585), (3155, 4187), (5962, 17392), (7650, 11644), (867, 988),
+                (2548, 3019), (2415, 3322), (5386, 9607), (5459, 10623), (6984, 15975), (1362, 3799), (2376, 4182),
+                (810, 1219), (3663, 17527), (3956, 8682), (3804, 11295), (4055, 8034), (5041, 12295),
+                (1840, 3054), (92, 207), (139, 286), (2003, 7522), (188, 241), (1582, 2468), (49, 105), (2940, 3216),
+                (1191, 3751), (3068, 9642), (156, 340), (204, 716), (66, 87), (36, 73), (24, 44), (38, 168),
+                (2125, 6061), (2115, 5342), (1994, 3815), (974, 1068), (75, 113), (37, 68), (58, 76), (43, 81)]
+
+
+@pytest.mark.parametrize("k,n", RANDOM_CODES)
+def test_5g_random_codes_all_engines(phy, k, n):
+    """Whatever engine the library picks for a code (explicit messages, compressed state with part of it in L2,
+    HBM-resident): min-sum equals the oracle bit for bit, boxplus-phi on chip equals the HBM engine."""
+    code = LDPC5GCode(k, n)
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    u, c, llr = _noisy_llr(code, 5, k ^ n, sigma=0.7)
+    assert np.array_equal(_np(enc(u)), c)
+    odec = obp.LDPC5GDecoder(code, cn_update="minsum", hard_out=False, num_iter=6)
+    ref = cbind.bp_decode(odec, odec.rate_recover(llr), num_iter=6, hard_out=0)[:, :k]
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=6)
+    assert np.array_equal(_np(dec(llr)), ref) and dec._onchip_ok
+    os.environ["SAMD_ONCHIP_COMPRESSED"] = "1"
+    try:
+        assert np.array_equal(_np(dec(llr)), ref)
+    finally:
+        del os.environ["SAMD_ONCHIP_COMPRESSED"]
+    dec._onchip_ok = False
+    assert np.array_equal(_np(dec(llr)), ref)
+    for cn, infobits in (("boxplus-phi", True), ("boxplus", False)):
+        decp = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=4)
+        a = _np(decp(llr))
+        if decp._onchip_ok:
+            decp._onchip_ok = False
+            assert np.array_equal(a, _np(decp(llr))), cn
+    # codeword output of the min-sum engines (marginals of the fused degree-1 columns)
+    odec = obp.LDPC5GDecoder(code, cn_update="offset-minsum", hard_out=True, return_infobits=False, num_iter=3)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="offset-minsum", hard_out=True, return_infobits=False, num_iter=3)
+    assert np.array_equal(_np(dec(llr)), odec.decode5g(llr))
+
+
 @pytest.mark.parametrize("k,n,bg,m", CODES5G)
 @pytest.mark.parametrize("cn", ["boxplus-phi", "boxplus"])
 def test_5g_boxplus_onchip_equals_hbm_engine(phy, k, n, bg, m, cn):
