@@ -80,23 +80,49 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
     const float norm = 1.f / sqrtf((float)N);
     float2* o = a + i * T;
     // time steps in register-resident chunks: every tap is accumulated over the sinusoids in
-    // registers (in sinusoid order, as the oracle sums) and written exactly once
+    // registers (in sinusoid order, as the oracle sums) and written exactly once.
+    // Per sinusoid the phase advances by a constant w = doppler cos(alpha) / fs per step: the chunk's first
+    // step is evaluated directly (the reference's float32 argument), the other 15 by rotating with
+    // (cos w, sin w) - |error| < 2e-6, below the float32 rounding of the reference's own arguments (~1e-5 at
+    // arguments of ~1e2) - 2 instead of 16 sincos per sinusoid and chunk.  The per-sinusoid random draws
+    // (Philox) are made once per thread, not once per chunk.
     constexpr int kChunk = 16;
+    constexpr int kMaxSin = 24;                                    // register-resident draws up to this many sinusoids
+    float ca_r[kMaxSin], ph_r[kMaxSin];
+    const bool cached = N <= kMaxSin;
+    if (cached) {
+#pragma unroll
+      for (int n = 0; n < kMaxSin; ++n)
+        if (n < N) {
+          const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
+          ph_r[n] = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
+          ca_r[n] = cosf((2.f * pi / (float)N) * (float)(n + 1) + theta);
+        }
+    }
     for (int t0 = 0; t0 < T; t0 += kChunk) {
       float accx[kChunk], accy[kChunk];
 #pragma unroll
       for (int k = 0; k < kChunk; ++k) accx[k] = accy[k] = 0.f;
-      for (int n = 0; n < N; ++n) {
-        const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
-        const float phi = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
-        const float alpha = (2.f * pi / (float)N) * (float)(n + 1) + theta;
-        const float ca = cosf(alpha);
+      auto one = [&](float ca, float phi) {
+        float sn, cs, sw, cw;
+        sincosf(doppler * ((float)t0 / sampling_frequency) * ca + phi, &sn, &cs);
+        sincosf(doppler * (1.f / sampling_frequency) * ca, &sw, &cw);
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
-          const float arg = doppler * ((float)(t0 + k) / sampling_frequency) * ca + phi;
-          float sn, cs;
-          sincosf(arg, &sn, &cs);
           accx[k] += cs; accy[k] += sn;
+          const float c2 = cs * cw - sn * sw, s2 = sn * cw + cs * sw;
+          cs = c2; sn = s2;
+        }
+      };
+      if (cached) {
+#pragma unroll
+        for (int n = 0; n < kMaxSin; ++n)
+          if (n < N) one(ca_r[n], ph_r[n]);
+      } else {
+        for (int n = 0; n < N; ++n) {
+          const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
+          const float phi = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
+          one(cosf((2.f * pi / (float)N) * (float)(n + 1) + theta), phi);
         }
       }
       float phi0 = 0.f;

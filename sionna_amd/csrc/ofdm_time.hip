@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) cir_to_time_kernel(const float2* __restri
                                                           float bandwidth, int l_min, int L, int num_rx, int RA,
                                                           int num_tx, int TA, int P, int T, int normalize,
                                                           float2* __restrict__ h) {
-  extern __shared__ float g[];  // [P][L]
+  extern __shared__ __attribute__((aligned(16))) float g[];  // [P][L], then the per-wave output stage
   __shared__ float red[256];
   const int grp = blockIdx.x;  // (b, rx, tx)
   const int tx = grp % num_tx;
@@ -219,43 +219,64 @@ __global__ void __launch_bounds__(256) cir_to_time_kernel(const float2* __restri
     g[i] = sincf((float)(l_min + l) - tau_g[p] * bandwidth);
   }
   __syncthreads();
-  const long long per = (long long)RA * TA * T * L;
+  // one lane per time step, kTapTile taps at a time in registers: every path coefficient a[p][t] is read once
+  // per tile (coalesced over t), the sinc weights are LDS broadcasts, no per-element index arithmetic;
+  // the sum over paths keeps its order (p ascending), so h is what the element-per-thread form produced.
+  // A wave's 64 x L results go through an LDS stage so that h[t][l] leaves as contiguous 512-byte stores
+  // (one lane per t would scatter every store instruction over 64 cache lines).
+  constexpr int kTapTile = 9;
+  float2* stage = reinterpret_cast<float2*>(g + ((P * L + 1) & ~1)) + (size_t)(threadIdx.x >> 6) * 64 * L;   // [64][L] per wave
+  const int lane = threadIdx.x & 63;
   float energy = 0.0f;
-  for (long long i = threadIdx.x; i < per; i += blockDim.x) {
-    const int l = (int)(i % L);
-    const int t = (int)((i / L) % T);
-    const int ta = (int)((i / ((long long)L * T)) % TA);
-    const int ra = (int)(i / ((long long)L * T * TA));
+  for (int lk = 0; lk < RA * TA; ++lk) {
+    const int ra = lk / TA, ta = lk - ra * TA;
     const long long link = ((((b * num_rx + rx) * RA + ra) * num_tx + tx) * TA + ta);
-    const float2* ap = a + link * P * T + t;
-    float re = 0.0f, im = 0.0f;
-    for (int p = 0; p < P; ++p) {
-      const float2 v = ap[(long long)p * T];
-      const float w = g[p * L + l];
-      re += v.x * w;
-      im += v.y * w;
+    const float2* ap = a + link * P * T;
+    float2* hp = h + link * T * L;
+    for (int t0 = (threadIdx.x >> 6) * 64; t0 < T; t0 += blockDim.x) {      // 64 time steps per wave and pass
+      const int t = t0 + lane;
+      for (int l0 = 0; l0 < L; l0 += kTapTile) {
+        float re[kTapTile], im[kTapTile];
+#pragma unroll
+        for (int j = 0; j < kTapTile; ++j) { re[j] = 0.0f; im[j] = 0.0f; }
+        if (t < T)
+          for (int p = 0; p < P; ++p) {
+            const float2 v = ap[(long long)p * T + t];
+            const float* gp = g + p * L + l0;
+#pragma unroll
+            for (int j = 0; j < kTapTile; ++j)
+              if (l0 + j < L) { const float w = gp[j]; re[j] += v.x * w; im[j] += v.y * w; }
+          }
+#pragma unroll
+        for (int j = 0; j < kTapTile; ++j)
+          if (l0 + j < L) {
+            stage[lane * L + l0 + j] = make_float2(re[j], im[j]);
+            energy += re[j] * re[j] + im[j] * im[j];                       // zero for t >= T
+          }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int cnt = min(64, T - t0) * L;
+      for (int i = lane; i < cnt; i += 64) hp[(long long)t0 * L + i] = stage[i];
+      __builtin_amdgcn_wave_barrier();
     }
-    h[(link * T + t) * L + l] = make_float2(re, im);
-    energy += re * re + im * im;
   }
   if (!normalize) return;
   red[threadIdx.x] = energy;
-  __syncthreads();
+  __syncthreads();                                                          // also orders the h writes above
   for (int s = blockDim.x / 2; s > 0; s >>= 1) {
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
   const float c = sqrtf(red[0] / (float)(RA * TA * T));
   const float inv = c > 0.0f ? 1.0f / c : 0.0f;  // divide_no_nan
-  for (long long i = threadIdx.x; i < per; i += blockDim.x) {
-    const int l = (int)(i % L);
-    const int t = (int)((i / L) % T);
-    const int ta = (int)((i / ((long long)L * T)) % TA);
-    const int ra = (int)(i / ((long long)L * T * TA));
-    const long long link = ((((b * num_rx + rx) * RA + ra) * num_tx + tx) * TA + ta);
-    float2* hp = h + (link * T + t) * L + l;
-    const float2 v = *hp;  // written by this very thread above
-    *hp = make_float2(v.x * inv, v.y * inv);
+  for (int ra = 0; ra < RA; ++ra) {               // the TA links of one receive antenna are contiguous in h
+    const long long link0 = ((((b * num_rx + rx) * RA + ra) * num_tx + tx) * TA);
+    float2* hp = h + link0 * T * L;
+    const long long cnt = (long long)TA * T * L;
+    for (long long i = threadIdx.x; i < cnt; i += blockDim.x) {
+      const float2 v = hp[i];
+      hp[i] = make_float2(v.x * inv, v.y * inv);
+    }
   }
 }
 
@@ -338,7 +359,7 @@ extern "C" int samd_cir_to_time_c64(float bandwidth, const float* a, const float
   SAMD_REQUIRE(a && tau && h_time && batch > 0 && l_max >= l_min && num_paths > 0 && num_time_steps > 0,
                "bad argument");
   const int L = l_max - l_min + 1;
-  const size_t lds = (size_t)num_paths * L * sizeof(float);
+  const size_t lds = (size_t)((num_paths * L + 1) & ~1) * sizeof(float) + (size_t)4 * 64 * L * sizeof(float2);   // sinc table + per-wave stage
   SAMD_REQUIRE(lds <= 64 * 1024, "num_paths * l_tot too large for the LDS sinc table");
   cir_to_time_kernel<<<batch * num_rx * num_tx, 256, lds, (hipStream_t)stream>>>(
       (const float2*)a, tau, bandwidth, l_min, L, num_rx, num_rx_ant, num_tx, num_tx_ant, num_paths, num_time_steps,
