@@ -282,30 +282,40 @@ __global__ void __launch_bounds__(256) cir_to_time_kernel(const float2* __restri
 
 // y[b, rxa, t] = sum_{txa} sum_l h[b, rxa, txa, t, l] x[b, txa, t - l], 0 <= t - l < Tn
 // (apply_time_channel.py:155-166); rxa = rx * RA + ra, txa = tx * TA + ta.
-__global__ void apply_time_kernel(const float2* __restrict__ x, const float2* __restrict__ h, int num_rx, int RA,
-                                  int num_tx, int TA, int Tn, int L, int ntb, float2* __restrict__ y) {
+__global__ void __launch_bounds__(256) apply_time_kernel(const float2* __restrict__ x, const float2* __restrict__ h,
+                                                         int num_rx, int RA, int num_tx, int TA, int Tn, int L, int ntb,
+                                                         float2* __restrict__ y) {
+  // the 256 x L taps of a block's time steps are one contiguous piece of h per link: staged through LDS with
+  // coalesced loads (a lane reading its own L taps directly would touch 64 cache lines per load instruction)
+  extern __shared__ __attribute__((aligned(16))) float2 hs[];   // [256][L]
   const int Tout = Tn + L - 1;
-  const int t = (blockIdx.x % ntb) * blockDim.x + threadIdx.x;
+  const int t0 = (blockIdx.x % ntb) * blockDim.x;
+  const int t = t0 + threadIdx.x;
   const int rxa = (blockIdx.x / ntb) % (num_rx * RA);
   const long long b = blockIdx.x / ntb / (num_rx * RA);
-  if (t >= Tout) return;
   const int rx = rxa / RA, ra = rxa % RA;
+  const int cnt = min((int)blockDim.x, Tout - t0) * L;
   float re = 0.0f, im = 0.0f;
   for (int tx = 0; tx < num_tx; ++tx)
     for (int ta = 0; ta < TA; ++ta) {
       const long long link = ((((b * num_rx + rx) * RA + ra) * num_tx + tx) * TA + ta);
-      const float2* hp = h + (link * Tout + t) * L;
-      const float2* xp = x + (b * num_tx * TA + tx * TA + ta) * Tn;
-      const int lo = t - (Tn - 1) > 0 ? t - (Tn - 1) : 0;
-      const int hi = t < L - 1 ? t : L - 1;
-      for (int l = lo; l <= hi; ++l) {
-        const float2 hv = hp[l];
-        const float2 xv = xp[t - l];
-        re += hv.x * xv.x - hv.y * xv.y;
-        im += hv.x * xv.y + hv.y * xv.x;
+      const float2* hp = h + (link * Tout + t0) * L;
+      __syncthreads();
+      for (int i = threadIdx.x; i < cnt; i += blockDim.x) hs[i] = hp[i];
+      __syncthreads();
+      if (t < Tout) {
+        const float2* xp = x + (b * num_tx * TA + tx * TA + ta) * Tn;
+        const int lo = t - (Tn - 1) > 0 ? t - (Tn - 1) : 0;
+        const int hi = t < L - 1 ? t : L - 1;
+        for (int l = lo; l <= hi; ++l) {
+          const float2 hv = hs[threadIdx.x * L + l];
+          const float2 xv = xp[t - l];
+          re += hv.x * xv.x - hv.y * xv.y;
+          im += hv.x * xv.y + hv.y * xv.x;
+        }
       }
     }
-  y[(b * num_rx * RA + rxa) * Tout + t] = make_float2(re, im);
+  if (t < Tout) y[(b * num_rx * RA + rxa) * Tout + t] = make_float2(re, im);
 }
 
 }  // namespace
@@ -374,7 +384,9 @@ extern "C" int samd_apply_time_channel_c64(const float* x, const float* h_time, 
   const int Tout = num_time_samples + l_tot - 1;
   const int ntb = (Tout + 255) / 256;
   SAMD_REQUIRE((long long)ntb * num_rx * num_rx_ant * batch < (1ll << 31), "grid too large");
-  apply_time_kernel<<<(unsigned)((long long)ntb * num_rx * num_rx_ant * batch), 256, 0, (hipStream_t)stream>>>(
+  SAMD_REQUIRE((size_t)256 * l_tot * sizeof(float2) <= 64 * 1024, "l_tot too large for the LDS tap stage");
+  apply_time_kernel<<<(unsigned)((long long)ntb * num_rx * num_rx_ant * batch), 256, (size_t)256 * l_tot * sizeof(float2),
+                      (hipStream_t)stream>>>(
       (const float2*)x, (const float2*)h_time, num_rx, num_rx_ant, num_tx, num_tx_ant, num_time_samples, l_tot, ntb,
       (float2*)y);
   return launch_status();

@@ -12,5 +12,5 @@ rows = list(cur.execute("select name, total_calls, total_duration, average, perc
 print(f"# rocprofv3 --kernel-trace --stats summary of {sys.argv[1]} (durations in microseconds)")
 print(f"{'calls':>6} {'total_us':>14} {'avg_us':>12} {'pct':>7}  kernel")
 for name, calls, total, avg, pct in rows:
-    short = name.split("(")[0].replace("void ", "")
+    short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
     print(f"{calls:>6} {total:>14.1f} {avg:>12.1f} {pct:>7.2f}  {short}")
