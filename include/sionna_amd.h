@@ -351,18 +351,21 @@ int samd_ofdm_demodulate_c64(const float* y, int rows, int in_len, int num_ofdm_
 
 /* cir_to_time_channel  channel/utils.py:256-349.  a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P] ->
  * h_time [B,rx,ra,tx,ta,T,l_max-l_min+1] = sum_p a_p(t) sinc(l - W tau_p); normalize: unit
- * mean (over ra,ta,T) total tap energy per (b,rx,tx). */
+ * mean (over ra,ta,T) total tap energy per (b,rx,tx).  norm_scale (nullable, only with normalize): instead of a second pass over
+ * h_time the normalisation factor of every (b, rx, tx) link goes to norm_scale [B,rx,tx] and h_time stays
+ * un-normalised - samd_apply_time_channel_c64(link_scale = norm_scale) applies it to the received signal
+ * (TimeChannel without return_channel). */
 int samd_cir_to_time_c64(float bandwidth, const float* a, const float* tau, int l_min, int l_max,
                          int batch, int num_rx, int num_rx_ant, int num_tx, int num_tx_ant,
                          int num_paths, int num_time_steps, int normalize, float* h_time,
-                         void* stream);
+                         float* norm_scale, void* stream);
 
 /* ApplyTimeChannel.call (noise-free part)  channel/apply_time_channel.py:95-175.
  * x [B,tx,ta,num_time_samples], h_time [B,rx,ra,tx,ta,num_time_samples+l_tot-1,l_tot] ->
- * y [B,rx,ra,num_time_samples+l_tot-1]. */
-int samd_apply_time_channel_c64(const float* x, const float* h_time, int batch, int num_rx,
-                                int num_rx_ant, int num_tx, int num_tx_ant, int num_time_samples,
-                                int l_tot, float* y, void* stream);
+ * y [B,rx,ra,num_time_samples+l_tot-1].  link_scale: nullable [B,rx,tx] factor per link. */
+int samd_apply_time_channel_c64(const float* x, const float* h_time, const float* link_scale, int batch,
+                                int num_rx, int num_rx_ant, int num_tx, int num_tx_ant,
+                                int num_time_samples, int l_tot, float* y, void* stream);
 
 /* LSChannelEstimator (+ NearestNeighborInterpolator)  ofdm/channel_estimation.py:138-173,
  * 257-285, 364-435: out[r,s,j] = y[r, src[s,j]] * coef[s,j]; rows r = batch*num_rx*num_rx_ant,

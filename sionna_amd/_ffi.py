@@ -64,8 +64,8 @@ _SIGNATURES = {
     "samd_ofdm_modulate_c64": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "samd_ofdm_demodulate_c64": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "samd_cir_to_time_c64": (_i32, [C.c_float, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
-                                    _vp, _vp]),
-    "samd_apply_time_channel_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+                                    _vp, _vp, _vp]),
+    "samd_apply_time_channel_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_lin_interp_c64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_lmmse_equalizer_c64": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "samd_ofdm_lmmse_c64": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,

@@ -206,7 +206,7 @@ __device__ __forceinline__ float sincf(float x) {
 __global__ void __launch_bounds__(256) cir_to_time_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
                                                           float bandwidth, int l_min, int L, int num_rx, int RA,
                                                           int num_tx, int TA, int P, int T, int normalize,
-                                                          float2* __restrict__ h) {
+                                                          float2* __restrict__ h, float* __restrict__ scale_out) {
   extern __shared__ __attribute__((aligned(16))) float g[];  // [P][L], then the per-wave output stage
   __shared__ float red[256];
   const int grp = blockIdx.x;  // (b, rx, tx)
@@ -269,6 +269,10 @@ __global__ void __launch_bounds__(256) cir_to_time_kernel(const float2* __restri
   }
   const float c = sqrtf(red[0] / (float)(RA * TA * T));
   const float inv = c > 0.0f ? 1.0f / c : 0.0f;  // divide_no_nan
+  if (scale_out) {                                // the caller applies the factor to the received signal
+    if (threadIdx.x == 0) scale_out[grp] = inv;
+    return;
+  }
   for (int ra = 0; ra < RA; ++ra) {               // the TA links of one receive antenna are contiguous in h
     const long long link0 = ((((b * num_rx + rx) * RA + ra) * num_tx + tx) * TA);
     float2* hp = h + link0 * T * L;
@@ -283,7 +287,8 @@ __global__ void __launch_bounds__(256) cir_to_time_kernel(const float2* __restri
 // y[b, rxa, t] = sum_{txa} sum_l h[b, rxa, txa, t, l] x[b, txa, t - l], 0 <= t - l < Tn
 // (apply_time_channel.py:155-166); rxa = rx * RA + ra, txa = tx * TA + ta.
 __global__ void __launch_bounds__(256) apply_time_kernel(const float2* __restrict__ x, const float2* __restrict__ h,
-                                                         int num_rx, int RA, int num_tx, int TA, int Tn, int L, int ntb,
+                                                         const float* __restrict__ link_scale, int num_rx, int RA,
+                                                         int num_tx, int TA, int Tn, int L, int ntb,
                                                          float2* __restrict__ y) {
   // the 256 x L taps of a block's time steps are one contiguous piece of h per link: staged through LDS with
   // coalesced loads (a lane reading its own L taps directly would touch 64 cache lines per load instruction)
@@ -296,7 +301,9 @@ __global__ void __launch_bounds__(256) apply_time_kernel(const float2* __restric
   const int rx = rxa / RA, ra = rxa % RA;
   const int cnt = min((int)blockDim.x, Tout - t0) * L;
   float re = 0.0f, im = 0.0f;
-  for (int tx = 0; tx < num_tx; ++tx)
+  for (int tx = 0; tx < num_tx; ++tx) {
+    // deferred channel normalisation (samd_cir_to_time_c64 norm_scale): one factor per (b, rx, tx)
+    const float sc = link_scale ? link_scale[(b * num_rx + rx) * num_tx + tx] : 1.0f;
     for (int ta = 0; ta < TA; ++ta) {
       const long long link = ((((b * num_rx + rx) * RA + ra) * num_tx + tx) * TA + ta);
       const float2* hp = h + (link * Tout + t0) * L;
@@ -308,13 +315,15 @@ __global__ void __launch_bounds__(256) apply_time_kernel(const float2* __restric
         const int lo = t - (Tn - 1) > 0 ? t - (Tn - 1) : 0;
         const int hi = t < L - 1 ? t : L - 1;
         for (int l = lo; l <= hi; ++l) {
-          const float2 hv = hs[threadIdx.x * L + l];
+          float2 hv = hs[threadIdx.x * L + l];
+          if (link_scale) { hv.x *= sc; hv.y *= sc; }      // the value the normalising second pass would have stored
           const float2 xv = xp[t - l];
           re += hv.x * xv.x - hv.y * xv.y;
           im += hv.x * xv.y + hv.y * xv.x;
         }
       }
     }
+  }
   if (t < Tout) y[(b * num_rx * RA + rxa) * Tout + t] = make_float2(re, im);
 }
 
@@ -365,7 +374,7 @@ extern "C" int samd_ofdm_demodulate_c64(const float* y, int rows, int in_len, in
 
 extern "C" int samd_cir_to_time_c64(float bandwidth, const float* a, const float* tau, int l_min, int l_max,
                                     int batch, int num_rx, int num_rx_ant, int num_tx, int num_tx_ant, int num_paths,
-                                    int num_time_steps, int normalize, float* h_time, void* stream) {
+                                    int num_time_steps, int normalize, float* h_time, float* norm_scale, void* stream) {
   SAMD_REQUIRE(a && tau && h_time && batch > 0 && l_max >= l_min && num_paths > 0 && num_time_steps > 0,
                "bad argument");
   const int L = l_max - l_min + 1;
@@ -373,11 +382,11 @@ extern "C" int samd_cir_to_time_c64(float bandwidth, const float* a, const float
   SAMD_REQUIRE(lds <= 64 * 1024, "num_paths * l_tot too large for the LDS sinc table");
   cir_to_time_kernel<<<batch * num_rx * num_tx, 256, lds, (hipStream_t)stream>>>(
       (const float2*)a, tau, bandwidth, l_min, L, num_rx, num_rx_ant, num_tx, num_tx_ant, num_paths, num_time_steps,
-      normalize, (float2*)h_time);
+      normalize, (float2*)h_time, normalize ? norm_scale : nullptr);
   return launch_status();
 }
 
-extern "C" int samd_apply_time_channel_c64(const float* x, const float* h_time, int batch, int num_rx, int num_rx_ant,
+extern "C" int samd_apply_time_channel_c64(const float* x, const float* h_time, const float* link_scale, int batch, int num_rx, int num_rx_ant,
                                            int num_tx, int num_tx_ant, int num_time_samples, int l_tot, float* y,
                                            void* stream) {
   SAMD_REQUIRE(x && h_time && y && batch > 0 && num_time_samples > 0 && l_tot > 0, "bad argument");
@@ -387,7 +396,7 @@ extern "C" int samd_apply_time_channel_c64(const float* x, const float* h_time, 
   SAMD_REQUIRE((size_t)256 * l_tot * sizeof(float2) <= 64 * 1024, "l_tot too large for the LDS tap stage");
   apply_time_kernel<<<(unsigned)((long long)ntb * num_rx * num_rx_ant * batch), 256, (size_t)256 * l_tot * sizeof(float2),
                       (hipStream_t)stream>>>(
-      (const float2*)x, (const float2*)h_time, num_rx, num_rx_ant, num_tx, num_tx_ant, num_time_samples, l_tot, ntb,
+      (const float2*)x, (const float2*)h_time, link_scale, num_rx, num_rx_ant, num_tx, num_tx_ant, num_time_samples, l_tot, ntb,
       (float2*)y);
   return launch_status();
 }

@@ -15,9 +15,11 @@ def time_lag_discrete_time_channel(bandwidth, maximum_delay_spread=3e-6):
     return -6, int(np.ceil(maximum_delay_spread * bandwidth)) + 6
 
 
-def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False):
+def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False, _defer_norm=False):
     """h[b,rx,ra,tx,ta,t,l] = sum_p a[b,rx,ra,tx,ta,p,t] sinc(l - W tau[b,rx,tx,p]),
-    l = l_min..l_max (utils.py:256-349)."""
+    l = l_min..l_max (utils.py:256-349).  ``_defer_norm`` (internal, TimeChannel): return (h un-normalised,
+    scale [b,rx,tx]) so that the normalisation is applied to the received signal instead of in a second
+    pass over h."""
     a = _ffi.to_device(a, torch.complex64)
     tau = _ffi.to_device(tau, torch.float32)
     if tau.dim() != 4:
@@ -26,10 +28,12 @@ def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False):
     assert tuple(tau.shape) == (b, rx, tx, p), "tau must have shape [batch, num_rx, num_tx, num_paths]"
     l_min, l_max = int(l_min), int(l_max)
     h = torch.empty((b, rx, ra, tx, ta, t, l_max - l_min + 1), dtype=torch.complex64, device=a.device)
+    scale = torch.empty((b, rx, tx), dtype=torch.float32, device=a.device) if (_defer_norm and normalize) else None
     _ffi.check(_ffi.lib().samd_cir_to_time_c64(float(bandwidth), _ffi.ptr(a), _ffi.ptr(tau), l_min, l_max, b, rx, ra,
-                                               tx, ta, p, t, int(bool(normalize)), _ffi.ptr(h), _ffi.stream()),
+                                               tx, ta, p, t, int(bool(normalize)), _ffi.ptr(h), _ffi.ptr(scale),
+                                               _ffi.stream()),
                "cir_to_time_channel")
-    return wrap(h)
+    return (wrap(h), scale) if _defer_norm else wrap(h)
 
 
 class GenerateTimeChannel(Object):
@@ -47,9 +51,10 @@ class GenerateTimeChannel(Object):
         self._num_time_steps = int(num_time_samples)
         self._normalize_channel = normalize_channel
 
-    def __call__(self, batch_size=None):
+    def __call__(self, batch_size=None, _defer_norm=False):
         h, tau = self._cir_sampler(batch_size, self._num_time_steps + self._l_tot - 1, self._bandwidth)
-        return cir_to_time_channel(self._bandwidth, h, tau, self._l_min, self._l_max, self._normalize_channel)
+        return cir_to_time_channel(self._bandwidth, h, tau, self._l_min, self._l_max, self._normalize_channel,
+                                   _defer_norm=_defer_norm)
 
 
 class ApplyTimeChannel(Block):
@@ -60,7 +65,7 @@ class ApplyTimeChannel(Block):
         self._num_time_samples, self._l_tot = int(num_time_samples), int(l_tot)
         self._awgn = AWGN(precision=self.precision)
 
-    def call(self, x, h_time, no=None):
+    def call(self, x, h_time, no=None, _link_scale=None):
         self._require_single()
         x = _ffi.to_device(x, torch.complex64)
         h = _ffi.to_device(h_time, torch.complex64)
@@ -69,8 +74,8 @@ class ApplyTimeChannel(Block):
         assert l == self._l_tot and tout == tn + l - 1, "h_time must have num_time_samples + l_tot - 1 time steps"
         assert tuple(x.shape) == (b, tx, ta, tn), "x must have shape [batch, num_tx, num_tx_ant, num_time_samples]"
         y = torch.empty((b, rx, ra, tout), dtype=torch.complex64, device=x.device)
-        _ffi.check(_ffi.lib().samd_apply_time_channel_c64(_ffi.ptr(x), _ffi.ptr(h), b, rx, ra, tx, ta, tn, l,
-                                                          _ffi.ptr(y), _ffi.stream()), "ApplyTimeChannel")
+        _ffi.check(_ffi.lib().samd_apply_time_channel_c64(_ffi.ptr(x), _ffi.ptr(h), _ffi.ptr(_link_scale), b, rx, ra, tx,
+                                                          ta, tn, l, _ffi.ptr(y), _ffi.stream()), "ApplyTimeChannel")
         if no is not None:
             y = self._awgn(y, no)
         return wrap(y)
@@ -93,6 +98,11 @@ class TimeChannel(Block):
         self._apply_channel = ApplyTimeChannel(num_time_samples, self._l_tot, precision=self.precision)
 
     def call(self, x, no=None):
+        if not self._return_channel:
+            # the channel itself is not handed out: its normalisation factor goes onto the received signal
+            # instead of a second pass over h_time (same result up to float32 rounding)
+            h_time, scale = self._generate_channel(x.shape[0], _defer_norm=True)
+            return self._apply_channel(x, h_time, no, _link_scale=scale)
         h_time = self._generate_channel(x.shape[0])
         y = self._apply_channel(x, h_time, no)
-        return (y, h_time) if self._return_channel else y
+        return y, h_time

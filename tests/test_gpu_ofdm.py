@@ -368,6 +368,23 @@ def test_time_domain_chain_matches_frequency_response(phy):
     assert np.allclose(yf, ref, rtol=1e-4, atol=1e-4)
 
 
+def test_time_channel_deferred_normalisation_is_identical(phy):
+    """Without return_channel the normalisation factor of h_time is applied while the channel is applied (no second
+    pass over h_time): the received signal equals the one of the two-pass path bit for bit."""
+    rg = phy.ofdm.ResourceGrid(3, 64, 30e3, cyclic_prefix_length=8)
+    mk = lambda ret: phy.channel.TimeChannel(
+        phy.channel.tr38901.TDL("C", 300e-9, 3.5e9, min_speed=3., max_speed=30., num_rx_ant=2, num_tx_ant=2),
+        rg.bandwidth, rg.num_time_samples, normalize_channel=True, return_channel=ret)
+    x = _cplx(np.random.default_rng(5), (7, 1, 2, rg.num_time_samples))
+    phy.config.seed = 21
+    y1 = _np(mk(False)(x))
+    phy.config.seed = 21
+    y2, h = mk(True)(x)
+    assert np.array_equal(y1, _np(y2))
+    e = np.mean(np.sum(np.abs(_np(h)) ** 2, axis=6), axis=(2, 4, 5))
+    assert np.allclose(e, 1.0, atol=1e-4)
+
+
 # ------------------------------------------------------------------ linear interpolation ("lin", "lin_time_avg")
 from test_oracle_ofdm_time import LIN_PATTERNS
 
