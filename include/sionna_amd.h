@@ -128,7 +128,8 @@ int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const float* x_hat,
 size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode);
 /* Which engine samd_ldpc5g_decode_f32 runs for this code and rule: 0 none (SAMD_ERR_UNSUPPORTED: use the
  * HBM-resident samd_ldpc_bp_decode_f32), 1 on chip with compressed check-node state (min-sum family, every
- * code), 2 on chip with one float per edge in LDS (all rules; codes whose messages fit in 160 KB). */
+ * code), 2 on chip with one float per edge in LDS (all rules; codes whose messages fit in 160 KB), 3 the
+ * same for min-sum with the messages of the last base rows in the L2 workspace row (larger codes). */
 int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode);
 
 /* Whole LDPC5GDecoder.call on chip: rate recovery + num_iter flooding BP iterations +

@@ -41,6 +41,10 @@ struct samd_ldpc5g {
   int32_t* bp_col_deg = nullptr;   // [nb]
   int32_t* bp_cn_ptr = nullptr; int32_t* bp_cn_list = nullptr;     // per-wave item lists (LPT balanced)
   int32_t* bp_vn_ptr = nullptr; int32_t* bp_vn_list = nullptr;
+  // explicit-message min-sum engine with the last rows' messages in the L2 workspace row (ldpc5g_onchip_mss.hip)
+  int sp_ok = 0, sp_lds_bytes = 0, sp_g_floats = 0;
+  int32_t* sp_col_ent = nullptr; int32_t* sp_cn_ptr = nullptr; int32_t* sp_vn_ptr = nullptr;
+  int32_t* sp_cn_list = nullptr; int32_t* sp_vn_list = nullptr;
   int dec_waves = 16;          // waves per workgroup of the on-chip decoder (16 / 8 / 4: small codes share a CU)
   int llr_global = 0;          // 1: channel LLRs in the caller's workspace (L2) instead of LDS (larger codes fit)
 };
@@ -65,6 +69,12 @@ int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int bat
 int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes,
                      hipStream_t st);
+int build_onchip_mss_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
+void free_onchip_mss_tables(samd_ldpc5g* h);
+size_t onchip_mss_workspace_bytes(const samd_ldpc5g* h, int batch);
+int launch_onchip_mss(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
+                      size_t workspace_bytes, hipStream_t st);
 int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
                      size_t workspace_bytes, hipStream_t st);

@@ -313,6 +313,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   if (rc == SAMD_OK) rc = upload(&h->vn_items, vn_items.data(), vn_items.size());
   if (rc == SAMD_OK) rc = build_onchip_tables(h, by_row);
   if (rc == SAMD_OK) rc = build_onchip_bp_tables(h, by_row);
+  if (rc == SAMD_OK) rc = build_onchip_mss_tables(h, by_row);
   if (rc != SAMD_OK) { samd_ldpc5g_destroy(h); return rc; }
   *out = h;
   return SAMD_OK;
@@ -324,6 +325,7 @@ extern "C" void samd_ldpc5g_destroy(samd_ldpc5g_t* h) {
   (void)hipFree(h->cn_items); (void)hipFree(h->vn_items);
   free_onchip_tables(h);
   free_onchip_bp_tables(h);
+  free_onchip_mss_tables(h);
   delete h;
 }
 
@@ -362,12 +364,17 @@ extern "C" int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const fl
 // min-sum family: explicit messages (ldpc5g_onchip_ms.hip) when they fit in LDS, else the compressed
 // check-node state (ldpc5g_onchip.hip, every 5G code).  SAMD_ONCHIP_COMPRESSED=1 forces the latter.
 static bool use_explicit_minsum(const samd_ldpc5g* h) { return h->bp_ok && !getenv("SAMD_ONCHIP_COMPRESSED"); }
+// ... or explicit messages with the last base rows' blocks in the L2 workspace row (ldpc5g_onchip_mss.hip)
+static bool use_spill_minsum(const samd_ldpc5g* h) {
+  return !h->bp_ok && h->sp_ok && !getenv("SAMD_ONCHIP_COMPRESSED") && !getenv("SAMD_NO_SPILL");
+}
 
 extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode) {
   // 0 when the whole state fits in LDS; larger codes keep part of it in this (L2-resident) scratch
   if (!h) return 0;
   if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || use_explicit_minsum(h))
     return onchip_bp_workspace_bytes(h, batch);
+  if (use_spill_minsum(h)) return onchip_mss_workspace_bytes(h, batch);
   return onchip_workspace_bytes(h, batch);
 }
 
@@ -376,6 +383,7 @@ extern "C" int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode) {
   if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) return h->bp_ok ? 2 : 0;
   if (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM) return 0;
   if (use_explicit_minsum(h)) return 2;
+  if (use_spill_minsum(h)) return 3;
   return (h->v2_ok || decode_lds_bytes(h) <= 160 * 1024) ? 1 : 0;
 }
 
@@ -402,6 +410,11 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   if (use_explicit_minsum(h)) {
     const int rc = launch_onchip_ms(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits,
                                     workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc != SAMD_ERR_UNSUPPORTED) return rc;
+  }
+  if (use_spill_minsum(h)) {
+    const int rc = launch_onchip_mss(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits,
+                                     workspace, workspace_bytes, (hipStream_t)stream);
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
   if (h->v2_ok && !getenv("SAMD_ONCHIP_V1")) {   // statically scheduled, unrolled engine

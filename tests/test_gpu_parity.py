@@ -413,6 +413,15 @@ def test_5g_random_codes_all_engines(phy, k, n):
         assert np.array_equal(_np(dec(llr)), ref)
     finally:
         del os.environ["SAMD_ONCHIP_COMPRESSED"]
+    # explicit messages with the last rows in L2, also beyond the size range where the library selects it
+    # (the handle caches its tables, so a fresh encoder / handle is built under the flag)
+    os.environ["SAMD_FORCE_SPILL"] = "1"
+    try:
+        enc2 = phy.fec.ldpc.LDPC5GEncoder(k, n)
+        dec2 = phy.fec.ldpc.LDPC5GDecoder(enc2, cn_update="minsum", hard_out=False, num_iter=6)
+        assert np.array_equal(_np(dec2(llr)), ref)
+    finally:
+        del os.environ["SAMD_FORCE_SPILL"]
     dec._onchip_ok = False
     assert np.array_equal(_np(dec(llr)), ref)
     for cn, infobits in (("boxplus-phi", True), ("boxplus", False)):

@@ -36,10 +36,11 @@ for k, n, bg in [(512, 1024, None), (768, 1536, None), (1024, 2048, "bg1"), (150
     dt = (time.perf_counter() - t0) / reps
     z = enc.z
     ws = _ffi.lib().samd_ldpc5g_decode_workspace_bytes(enc._handle(dec._nb_pruned_nodes), B, 2) if dec._onchip_ok else 0
-    explicit = bool(_ffi.lib().samd_ldpc5g_decode_engine(enc._handle(dec._nb_pruned_nodes), 2) == 2)
+    eng = int(_ffi.lib().samd_ldpc5g_decode_engine(enc._handle(dec._nb_pruned_nodes), 2))
     rows.append({"k": k, "n": n, "bg": enc._bg, "z": z,
-                 "engine": (("on-chip explicit messages" if explicit else "on-chip compressed state") +
-                            (" (part of the state in L2)" if ws else "")) if dec._onchip_ok else "generic-hbm",
+                 "engine": {0: "generic-hbm", 1: "on-chip compressed state" + (" (part of it in L2)" if ws else ""),
+                            2: "on-chip explicit messages" + (" (channel LLRs in L2)" if ws else ""),
+                            3: "on-chip explicit messages, last rows in L2"}[eng if dec._onchip_ok else 0],
                  "lane_utilisation": round(z / (64 * -(-z // 64)), 3), "batch": B, "ms": round(dt * 1e3, 2),
                  "decodes_per_s": round(B / dt), "coded_gbit_per_s": round(B * n / dt / 1e9, 2),
                  "ber": float((out != u).float().mean())})
