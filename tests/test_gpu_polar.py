@@ -106,6 +106,33 @@ def test_scl_vs_oracle(phy, n, k, L, crc, fast):
     assert abs(bler_gpu - bler_ref) <= 0.02
 
 
+# random (k, n, channel) draws over the 5G ranges: puncturing, shortening and repetition, with and without the
+# uplink interleaver / the downlink input interleaver, odd CRC and parity-check-bit configurations
+RANDOM_POLAR = [(595, 818, 'uplink'), (734, 931, 'uplink'), (84, 465, 'uplink'), (885, 981, 'uplink'),
+                (351, 443, 'uplink'), (417, 1018, 'uplink'), (13, 339, 'downlink'), (405, 705, 'uplink'),
+                (306, 450, 'uplink'), (409, 695, 'uplink'), (312, 918, 'uplink'), (63, 373, 'uplink'),
+                (301, 1075, 'uplink'), (336, 1072, 'uplink'), (102, 201, 'downlink'), (57, 389, 'downlink'),
+                (204, 865, 'uplink'), (560, 885, 'uplink'), (92, 731, 'uplink'), (423, 657, 'uplink'),
+                (81, 291, 'downlink'), (307, 405, 'uplink'), (978, 1007, 'uplink'), (929, 1040, 'uplink'),
+                (683, 710, 'uplink'), (861, 881, 'uplink'), (74, 757, 'uplink'), (100, 532, 'downlink')]
+
+
+@pytest.mark.parametrize("k,n,ch", RANDOM_POLAR)
+def test_polar5g_random_configs(phy, k, n, ch):
+    """Encoder bit-exact against the oracle; noise-free logits decode back to the information bits with a passing
+    CRC for SC, SCL-8 and hybrid SCL (rate matching / recovery and the interleavers are exercised end to end)."""
+    enc = phy.fec.polar.Polar5GEncoder(k, n, channel_type=ch)
+    u = np.random.default_rng(k * 2000 + n).integers(0, 2, (6, k)).astype(np.float32)
+    c = _np(enc(u))
+    assert np.array_equal(c, op.Polar5GCode(k, n, ch).encode(u))
+    logits = (8.0 * (2 * c - 1)).astype(np.float32)
+    for dec_type in ("SC", "SCL", "hybSCL"):
+        dec = phy.fec.polar.Polar5GDecoder(enc, dec_type=dec_type, list_size=8, return_crc_status=True)
+        u_hat, status = dec(logits)
+        assert np.array_equal(_np(u_hat), u), dec_type
+        assert np.all(_np(status)), dec_type
+
+
 @pytest.mark.parametrize("k,n,ch,dec_type", [(64, 128, "uplink", "SCL"), (30, 70, "uplink", "SC"), (40, 200, "downlink", "SCL"),
                                              (100, 150, "uplink", "SCL"), (300, 1088, "uplink", "SCL"), (512, 1024, "uplink", "SCL")])
 def test_polar5g_decoder_chain(phy, k, n, ch, dec_type):
