@@ -30,6 +30,7 @@
 // codewords resident per CU, which the 53 KB list state limits to 2-3: sharing the upper LLR
 // stages between paths (lazy copy) is the next step.
 #include "common.h"
+#include "bp_math.h"
 #include <cstdlib>
 
 namespace samd {
@@ -81,13 +82,19 @@ __global__ __launch_bounds__(256) void polar_encode_kernel(const float* __restri
 enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6 };
 constexpr float kPolarLlrMax = 30.f;
 
-__device__ __forceinline__ float softplus(float x) {       // log(1 + e^x)
-  return x > 0.f ? x + log1pf(expf(-x)) : log1pf(expf(x));
+// log(1 + e^x) = max(x, 0) + log(1 + e^-|x|).  The decoder evaluates this ~3000 times per codeword on a few
+// lanes, and the libm forms (log1pf in double-float arithmetic, expf with its special cases: ~135 VALU
+// operations) were 40 % of all instructions of the kernel.  Here -|x| is in [-60, 0] (LLRs are clipped to +-30)
+// and 1 + e^-|x| in [1, 2]: the range-specialised exp / log cores of bp_math.h apply (17 operations).  The
+// absolute error stays below 1e-7 (1 + e rounds e to the grid of 1.0) on metrics and LLRs of magnitude 1e-1 ...
+// 1e2 - the size of the float32 rounding differences between any two libms.
+__device__ __forceinline__ float softplus(float x) {
+  return fmaxf(x, 0.f) + log_core_f32(1.f + exp_core_f32(-fabsf(x)));
 }
 __device__ __forceinline__ float cn_op(float x, float y) {  // polar/decoding.py:684-705
   x = clampf(x, -kPolarLlrMax, kPolarLlrMax);
   y = clampf(y, -kPolarLlrMax, kPolarLlrMax);
-  const float lse = fmaxf(x, y) + log1pf(expf(-fabsf(x - y)));
+  const float lse = fmaxf(x, y) + log_core_f32(1.f + exp_core_f32(-fabsf(x - y)));
   return softplus(x + y) - lse;
 }
 
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         // a0 = stage s of the inputs (block of 2^s), outputs go to stage s-1; OP_G uses betaL[s-1]
         const int s = a0, half = 1 << (s - 1);
         for (int w = tid; w < L * half; w += NT) {
-          const int pos = w / half, j = w - pos * half;
+          const int pos = w >> (s - 1), j = w & (half - 1);     // half = 2^(s-1): no integer division
           const int slot = order[pos];
           const float* in = (s == p.m) ? llr_ch : stage(lp[slot * 16 + s], s);
           const float sg = (s == p.m) ? -1.f : 1.f;
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         // children results at stage s (a0) -> this node's result at stage s+1 on side a1
         const int s = a0, sz = 1 << s;
         for (int w = tid; w < L * sz; w += NT) {
-          const int pos = w / sz, j = w - pos * sz;
+          const int pos = w >> s, j = w & (sz - 1);
           const int slot = order[pos];
           const unsigned char l = bstage(bl[slot * 16 + s], s)[j] & 1;
           const unsigned char r = (bstage(br[slot * 16 + s], s)[j] >> 1) & 1;
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           // frozen leaf / rate-0: metric of the all-zero block, result zeros
           if (tid < L) pm[tid] += blk[tid];
           for (int w = tid; w < L * sz; w += NT) {
-            const int pos = w / sz, j = w - pos * sz;
+            const int pos = w >> s, j = w & (sz - 1);
             unsigned char* d = bstage(order[pos], s) + j;
             *d = *d & (a1 ? 1 : 2);
           }
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         }
         __syncthreads();
         for (int w = tid; w < L * sz; w += NT) {
-          const int pos = w / sz, j = w - pos * sz;
+          const int pos = w >> s, j = w & (sz - 1);
           unsigned char* d = bstage(order[pos], s) + j;
           *d = (*d & (a1 ? 1 : 2)) | (unsigned char)(new_bit[pos] << a1);                          // all-u codeword
         }

@@ -13,14 +13,14 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         rd = csv.DictReader(fh)
         per_dispatch = defaultdict(dict)
         for row in rd:
-            k = row.get("Kernel_Name", "").split("(")[0].replace("void ", "")
+            k = row.get("Kernel_Name", "").replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             per_dispatch[(row.get("Dispatch_Id"), k)][row["Counter_Name"]] = float(row["Counter_Value"])
         for (_, k), d in per_dispatch.items():
             for c, v in d.items():
                 acc[k][c].append(v)
 print(f"# mean PMC value per dispatch, from {root}")
 for k in sorted(acc, key=lambda k: -sum(len(v) for v in acc[k].values())):
-    if not any(s in k for s in ("ldpc", "cn_pass", "vn_pass", "demap")):
+    if not any(s in k for s in ("ldpc", "cn_pass", "vn_pass", "demap", "polar_scl", "lmmse")):
         continue
     print(k)
     for c in sorted(acc[k]):
