@@ -263,8 +263,16 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           int* rnk = reinterpret_cast<int*>(red);                                  // [2L] candidate ranks
           if (tid < 2 * L) cand[tid] = pm[tid % L] + blk[tid];
           __syncthreads();
-          if (tid < 2 * L) {
-            // stable rank of the 2L candidates (ties: lower candidate index first)
+          // stable rank of the 2L candidates (ties: lower candidate index first).  With one wave per codeword
+          // every candidate gets g = 64 / 2L lanes, each counting a slice of the comparisons (xor-shuffle sum)
+          if (NT == 64 && 2 * L <= 64 && (64 % (2 * L)) == 0) {
+            const int g = 64 / (2 * L), c = tid / g, q = tid - c * g, per = (2 * L + g - 1) / g;
+            const float me = cand[c];
+            int rank = 0;
+            for (int d = q * per; d < min((q + 1) * per, 2 * L); ++d) rank += (cand[d] < me || (cand[d] == me && d < c)) ? 1 : 0;
+            for (int o = 1; o < g; o <<= 1) rank += __shfl_xor(rank, o, 64);
+            if (q == 0) rnk[c] = rank;
+          } else if (tid < 2 * L) {
             int rank = 0;
             const float me = cand[tid];
             for (int d = 0; d < 2 * L; ++d) rank += (cand[d] < me || (cand[d] == me && d < tid)) ? 1 : 0;
@@ -275,6 +283,25 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           // j-th parent with two survivors clones its second child into the slot of the j-th parent
           // without survivors (prefix counts over LDS flags - no private arrays, no scratch)
           int* dead_slot = rnk + 2 * L;                                            // [L]
+          if (NT == 64 && L <= 32) {
+            // prefix counts by ballot: the j-th dead parent / the j-th parent with two survivors
+            const bool act = tid < L;
+            const int r0 = act ? rnk[tid] : 2 * L, r1 = act ? rnk[L + tid] : 2 * L;
+            const bool dead = act && r0 >= L && r1 >= L, both = act && r0 < L && r1 < L;
+            const unsigned long long md = __ballot(dead), mb = __ballot(both);
+            const unsigned long long below = (1ull << tid) - 1ull;
+            if (dead) dead_slot[__popcll(md & below)] = order[tid];
+            __syncthreads();
+            if (act) {
+              const int q = tid, slot = order[q];
+              if (r0 < L) { new_order[r0] = slot; clone_src[r0] = -1; new_bit[r0] = 0; new_pm[r0] = cand[q]; }
+              if (r1 < L) {
+                new_bit[r1] = 1; new_pm[r1] = cand[L + q];
+                if (r0 < L) { new_order[r1] = dead_slot[__popcll(mb & below)]; clone_src[r1] = slot; }
+                else { new_order[r1] = slot; clone_src[r1] = -1; }
+              }
+            }
+          } else {
           if (tid < L) {
             const bool dead = rnk[tid] >= L && rnk[L + tid] >= L;
             if (dead) {
@@ -296,19 +323,35 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
               } else { new_order[r1] = slot; clone_src[r1] = -1; }
             }
           }
+          }
         }
         __syncthreads();
         // clones: inherit the parent's pointer tables and decided bits (lazy copy, see above)
-        for (int r = 0; r < L; ++r) {
+        // (sources are live parents, destinations dead slots: disjoint, so all clones copy concurrently)
+        if (NT % L == 0) {
+          const int per = NT / L, r = tid / per, i = tid - r * per;
           const int src = clone_src[r];
-          if (src < 0) continue;
-          const int dst = new_order[r];
-          if (tid < 16) {
-            lp[dst * 16 + tid] = lp[src * 16 + tid];
-            bl[dst * 16 + tid] = bl[src * 16 + tid];
-            br[dst * 16 + tid] = br[src * 16 + tid];
+          if (src >= 0) {
+            const int dst = new_order[r];
+            for (int e = i; e < 16; e += per) {
+              lp[dst * 16 + e] = lp[src * 16 + e];
+              bl[dst * 16 + e] = bl[src * 16 + e];
+              br[dst * 16 + e] = br[src * 16 + e];
+            }
+            for (int w2 = i; w2 < words; w2 += per) bits[(size_t)dst * words + w2] = bits[(size_t)src * words + w2];
           }
-          for (int i = tid; i < words; i += NT) bits[(size_t)dst * words + i] = bits[(size_t)src * words + i];
+        } else {
+          for (int r = 0; r < L; ++r) {
+            const int src = clone_src[r];
+            if (src < 0) continue;
+            const int dst = new_order[r];
+            if (tid < 16) {
+              lp[dst * 16 + tid] = lp[src * 16 + tid];
+              bl[dst * 16 + tid] = bl[src * 16 + tid];
+              br[dst * 16 + tid] = br[src * 16 + tid];
+            }
+            for (int i = tid; i < words; i += NT) bits[(size_t)dst * words + i] = bits[(size_t)src * words + i];
+          }
         }
         __syncthreads();
         // commit: order, metrics, decided bit (the node's only information bit is its last one), result
