@@ -215,8 +215,9 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           if (tid < L) {                                      // one lane per path
             const float* in = (s == p.m) ? llr_ch : stage(lp[order[tid] * 16 + s], s);
             const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[0], -kPolarLlrMax, kPolarLlrMax);
-            blk[tid] = softplus(-l);
-            blk[L + tid] = softplus(l);
+            const float tl = log_core_f32(1.f + exp_core_f32(-fabsf(l)));     // shared by softplus(-l) and softplus(l)
+            blk[tid] = fmaxf(-l, 0.f) + tl;
+            if (info) blk[L + tid] = fmaxf(l, 0.f) + tl;
           }
         } else {
           for (int pos = 0; pos < L; ++pos) {
@@ -224,8 +225,9 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
             float m0 = 0.f, m1 = 0.f;
             for (int j = tid; j < sz; j += NT) {
               const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[j], -kPolarLlrMax, kPolarLlrMax);
-              m0 += softplus(-l);
-              m1 += softplus(l);
+              const float tl = log_core_f32(1.f + exp_core_f32(-fabsf(l)));
+              m0 += fmaxf(-l, 0.f) + tl;
+              m1 += fmaxf(l, 0.f) + tl;
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { m0 += __shfl_xor(m0, o, 64); m1 += __shfl_xor(m1, o, 64); }
