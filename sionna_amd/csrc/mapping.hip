@@ -13,6 +13,7 @@
 // Within a wave the m LLRs of a symbol are written as m consecutive floats per lane, i.e.
 // each store instruction covers a contiguous 64*m*4-byte span across the wave.
 #include "common.h"
+#include "bp_math.h"
 
 namespace samd {
 
@@ -97,11 +98,11 @@ __global__ __launch_bounds__(256) void demap_kernel(const float2* __restrict__ y
 #pragma unroll
         for (int i = 0; i < M; ++i) {
           const int bit = (c >> (M - 1 - i)) & 1;
-          if (bit) sm[i][1] += expf(e - mx[i][1]); else sm[i][0] += expf(e - mx[i][0]);
+          if (bit) sm[i][1] += exp_core_f32(e - mx[i][1]); else sm[i][0] += exp_core_f32(e - mx[i][0]);
         }
       }
 #pragma unroll
-      for (int i = 0; i < M; ++i) llr[i] = (logf(sm[i][1]) + mx[i][1]) - (logf(sm[i][0]) + mx[i][0]);
+      for (int i = 0; i < M; ++i) llr[i] = (log_core_f32(sm[i][1]) + mx[i][1]) - (log_core_f32(sm[i][0]) + mx[i][0]);
     }
     float* o = out + s * M;
 #pragma unroll
@@ -155,9 +156,11 @@ __global__ __launch_bounds__(256) void demap_square_qam_kernel(const float2* __r
           float s0 = 0.f, s1 = 0.f;
 #pragma unroll
           for (int j = 0; j < L; ++j) {
-            if ((j >> (NB - 1 - t)) & 1) s1 += expf(e[j] - mx1); else s0 += expf(e[j] - mx0);
+            if ((j >> (NB - 1 - t)) & 1) s1 += exp_core_f32(e[j] - mx1); else s0 += exp_core_f32(e[j] - mx0);
           }
-          r = (logf(s1) + mx1) - (logf(s0) + mx0);
+          // arguments <= 0 and sums in [1, 2^(NB-1)]: the special-case free exp / log of bp_math.h give the libm's
+          // bits (terms that underflow differ by < 1e-38)
+          r = (log_core_f32(s1) + mx1) - (log_core_f32(s0) + mx0);
         }
         llr[2 * t + ax] = r;
       }
