@@ -129,7 +129,8 @@ size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int
 /* Which engine samd_ldpc5g_decode_f32 runs for this code and rule: 0 none (SAMD_ERR_UNSUPPORTED: use the
  * HBM-resident samd_ldpc_bp_decode_f32), 1 on chip with compressed check-node state (min-sum family, every
  * code), 2 on chip with one float per edge in LDS (all rules; codes whose messages fit in 160 KB), 3 the
- * same for min-sum with the messages of the last base rows in the L2 workspace row (larger codes). */
+ * same with the messages of the last base rows in the L2 workspace row (larger codes: boxplus rules always,
+ * min-sum while at most ~27 % of the edges spill - beyond that engine 1 is faster). */
 int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode);
 
 /* Whole LDPC5GDecoder.call on chip: rate recovery + num_iter flooding BP iterations +

@@ -42,7 +42,7 @@ struct samd_ldpc5g {
   int32_t* bp_cn_ptr = nullptr; int32_t* bp_cn_list = nullptr;     // per-wave item lists (LPT balanced)
   int32_t* bp_vn_ptr = nullptr; int32_t* bp_vn_list = nullptr;
   // explicit-message min-sum engine with the last rows' messages in the L2 workspace row (ldpc5g_onchip_mss.hip)
-  int sp_ok = 0, sp_lds_bytes = 0, sp_g_floats = 0;
+  int sp_ok = 0, sp_lds_bytes = 0, sp_g_floats = 0, sp_spill_pct = 0;   // sp_spill_pct: share of the edges in L2
   int32_t* sp_col_ent = nullptr; int32_t* sp_cn_ptr = nullptr; int32_t* sp_vn_ptr = nullptr;
   int32_t* sp_cn_list = nullptr; int32_t* sp_vn_list = nullptr;
   int dec_waves = 16;          // waves per workgroup of the on-chip decoder (16 / 8 / 4: small codes share a CU)

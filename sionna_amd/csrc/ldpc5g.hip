@@ -365,22 +365,29 @@ extern "C" int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const fl
 // check-node state (ldpc5g_onchip.hip, every 5G code).  SAMD_ONCHIP_COMPRESSED=1 forces the latter.
 static bool use_explicit_minsum(const samd_ldpc5g* h) { return h->bp_ok && !getenv("SAMD_ONCHIP_COMPRESSED"); }
 // ... or explicit messages with the last base rows' blocks in the L2 workspace row (ldpc5g_onchip_mss.hip)
+// measured (tools/sweep_ldpc.py): up to about a quarter of the edges in L2 this beats the compressed state engine
+// (+16 % at 4 %, +9 % at 26 %, even at 28 %); beyond that the L2 round trips of the VN phase dominate
 static bool use_spill_minsum(const samd_ldpc5g* h) {
-  return !h->bp_ok && h->sp_ok && !getenv("SAMD_ONCHIP_COMPRESSED") && !getenv("SAMD_NO_SPILL");
+  return !h->bp_ok && h->sp_ok && (h->sp_spill_pct <= 27 || getenv("SAMD_FORCE_SPILL")) &&
+         !getenv("SAMD_ONCHIP_COMPRESSED") && !getenv("SAMD_NO_SPILL");
 }
+// boxplus rules on codes whose messages exceed LDS: the alternative is the HBM-resident engine, and the phi / tanh
+// arithmetic (VALU bound) hides the L2 round trips - any spill share
+static bool use_spill_boxplus(const samd_ldpc5g* h) { return !h->bp_ok && h->sp_ok && !getenv("SAMD_NO_SPILL"); }
 
 extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode) {
   // 0 when the whole state fits in LDS; larger codes keep part of it in this (L2-resident) scratch
   if (!h) return 0;
-  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || use_explicit_minsum(h))
-    return onchip_bp_workspace_bytes(h, batch);
+  const bool boxplus = cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI;
+  if (boxplus && use_spill_boxplus(h)) return onchip_mss_workspace_bytes(h, batch);
+  if (boxplus || use_explicit_minsum(h)) return onchip_bp_workspace_bytes(h, batch);
   if (use_spill_minsum(h)) return onchip_mss_workspace_bytes(h, batch);
   return onchip_workspace_bytes(h, batch);
 }
 
 extern "C" int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode) {
   if (!h) return 0;
-  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) return h->bp_ok ? 2 : 0;
+  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) return h->bp_ok ? 2 : (use_spill_boxplus(h) ? 3 : 0);
   if (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM) return 0;
   if (use_explicit_minsum(h)) return 2;
   if (use_spill_minsum(h)) return 3;
@@ -393,6 +400,9 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   SAMD_REQUIRE(h && llr && out && batch > 0 && num_iter >= 0, "bad argument");
   if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) {   // one float per edge in LDS
     SAMD_REQUIRE(llr_max >= 0.f, "bad argument");
+    if (use_spill_boxplus(h))                                             // ... the last rows' messages in L2
+      return launch_onchip_mss(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits,
+                               workspace, workspace_bytes, (hipStream_t)stream);
     return launch_onchip_bp(h, llr, out, batch, num_iter, cn_mode, llr_max, hard_out, return_infobits, workspace,
                             workspace_bytes, (hipStream_t)stream);
   }

@@ -14,6 +14,7 @@
 // Used while at most ~27 % of the edges are spilled (codes with 160 KB < 4 E Z <~ 215 KB, e.g. k=6144 rate 2/3,
 // k=5632 rate 1/2): +9 ... +16 % over the compressed engine; larger codes stay on the compressed engine.
 #include "ldpc5g.h"
+#include "bp_math.h"
 
 namespace samd {
 
@@ -23,7 +24,9 @@ __device__ __forceinline__ void mss_lds_st(unsigned a, float v) { *(mss_lds_f32*
 __device__ __forceinline__ float mss_med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 
 // GLB: the row's blocks are at gbase + a (global), else at LDS byte offset a.  See ms_cn_row for the rest.
-template <int D, int NCH, bool FUSE1, bool GLB>
+// MODE: SAMD_CN_MINSUM (also offset min-sum: offset is a runtime value) or a boxplus rule (bp_math.h arithmetic,
+// identical bits to the HBM engine).
+template <int D, int NCH, bool FUSE1, bool GLB, int MODE>
 __device__ __forceinline__ void mss_cn_row(unsigned a0, unsigned z4, char* __restrict__ gbase, float llr_max,
                                            float offset, float* __restrict__ llr_v, bool last) {
   float v[NCH][D];
@@ -37,6 +40,25 @@ __device__ __forceinline__ void mss_cn_row(unsigned a0, unsigned z4, char* __res
 #pragma unroll
     for (int h = 0; h < NCH; ++h)
       v[h][i] = GLB ? *reinterpret_cast<const float*>(gbase + a[i] + 256u * h) : mss_lds_ld(a[i] + 256u * h);
+  }
+  if constexpr (MODE != SAMD_CN_MINSUM) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) cn_update_col<MODE, D>(v[h], D, llr_max, 0.f);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        float c2v = v[h][i];
+        if (FUSE1 && i == D - 1) {
+          const float x = c2v + lf[h];              // (0 + c2v) + llr up to the sign of a zero
+          if (last) llr_v[64 * h] = x;
+          c2v = clampf(-1.f * c2v + x, -llr_max, llr_max);
+        }
+        if (GLB) *reinterpret_cast<float*>(gbase + a[i] + 256u * h) = c2v;
+        else mss_lds_st(a[i] + 256u * h, c2v);
+      }
+    }
+    return;
   }
   float m1[NCH], m2[NCH];
   unsigned sx[NCH];
@@ -166,7 +188,7 @@ __device__ __forceinline__ void mss_vn_item(const int32_t* __restrict__ ent, int
 //   VN  c | chunk<<8 | LDS degree<<16 | pair<<21 | L2 degree<<22,  dword offset of the column's edge table
 // vn_ptr = [17 offsets of the per-iteration lists | 17 offsets of the fused degree-1 columns (init only)]
 // workspace row of a workgroup: [channel LLRs nx | spilled messages g_floats]
-template <bool POW2>
+template <bool POW2, int MODE>
 __global__ __launch_bounds__(1024) void ldpc5g_decode_mss_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ ws, RateMatch p, int n_cn,
     int nbu, int batch, int num_iter, float llr_max, float offset, int hard_out, int return_infobits, int g_floats,
@@ -236,11 +258,11 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_mss_kernel(
           if (((d1 >> 25) & 1) || (zz < z && (unsigned)r * z + zz < (unsigned)n_cn)) {
             float* lv = llr + ((d1 >> 11) & 0xFF) * (int)z + (int)zz;
 #define SAMD_MSS_CN(D, G) \
-  case (G ? 128 : 0) + D: mss_cn_row<D, 1, false, G>(a0, z4, gbase, llr_max, offset, lv, last); break; \
-  case (G ? 128 : 0) + 64 + D: mss_cn_row<D, 2, false, G>(a0, z4, gbase, llr_max, offset, lv, last); break
+  case (G ? 128 : 0) + D: mss_cn_row<D, 1, false, G, MODE>(a0, z4, gbase, llr_max, offset, lv, last); break; \
+  case (G ? 128 : 0) + 64 + D: mss_cn_row<D, 2, false, G, MODE>(a0, z4, gbase, llr_max, offset, lv, last); break
 #define SAMD_MSS_CNF(D, G) \
-  case (G ? 128 : 0) + 32 + D: mss_cn_row<D, 1, true, G>(a0, z4, gbase, llr_max, offset, lv, last); break; \
-  case (G ? 128 : 0) + 96 + D: mss_cn_row<D, 2, true, G>(a0, z4, gbase, llr_max, offset, lv, last); break
+  case (G ? 128 : 0) + 32 + D: mss_cn_row<D, 1, true, G, MODE>(a0, z4, gbase, llr_max, offset, lv, last); break; \
+  case (G ? 128 : 0) + 96 + D: mss_cn_row<D, 2, true, G, MODE>(a0, z4, gbase, llr_max, offset, lv, last); break
             switch (deg | (((d1 >> 24) & 3) << 5) | ((int)glb << 7)) {   // degree | fused<<5 | pair<<6 | L2<<7
               SAMD_MSS_CN(3, false); SAMD_MSS_CN(4, false); SAMD_MSS_CN(5, false); SAMD_MSS_CN(6, false);
               SAMD_MSS_CN(7, false); SAMD_MSS_CN(8, false); SAMD_MSS_CN(9, false); SAMD_MSS_CN(10, false);
@@ -396,7 +418,7 @@ int build_onchip_mss_tables(samd_ldpc5g* h, const std::vector<std::vector<std::p
   cl2.resize(cl2.size() + 2, 0); vl2.resize(vl2.size() + 2, 0);
   // measured (tools/sweep_ldpc.py): with up to about a quarter of the edges in L2 this engine beats the compressed
   // state engine (+16 % at 4 %, +9 % at 26 %, even at 28 %); beyond that the L2 round trips of the VN phase dominate
-  if (eg * 100 > 27 * (el + eg) && !getenv("SAMD_FORCE_SPILL")) return SAMD_OK;
+  h->sp_spill_pct = (eg * 100 + el + eg - 1) / (el + eg);     // min-sum uses this engine up to 27 %, see ldpc5g.hip
   h->sp_lds_bytes = el * z * 4;
   h->sp_g_floats = eg * z;
   int rc = upload(&h->sp_col_ent, col_ent.data(), col_ent.size());
@@ -439,17 +461,21 @@ int launch_onchip_mss(const samd_ldpc5g* h, const float* llr, float* out, int ba
   }
   float* ws = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
   const bool pow2 = (h->z & (h->z - 1)) == 0;
-  const void* fn = pow2 ? (const void*)ldpc5g_decode_mss_kernel<true> : (const void*)ldpc5g_decode_mss_kernel<false>;
-  SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, int, float, float, int, int, int,
+                         const int32_t*, const int32_t*, const int2*, const int32_t*, const int2*);
+  static const kern_t kerns[6] = {ldpc5g_decode_mss_kernel<false, SAMD_CN_MINSUM>, ldpc5g_decode_mss_kernel<true, SAMD_CN_MINSUM>,
+                                  ldpc5g_decode_mss_kernel<false, SAMD_CN_BOXPLUS_PHI>, ldpc5g_decode_mss_kernel<true, SAMD_CN_BOXPLUS_PHI>,
+                                  ldpc5g_decode_mss_kernel<false, SAMD_CN_BOXPLUS>, ldpc5g_decode_mss_kernel<true, SAMD_CN_BOXPLUS>};
+  const int mi = cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : cn_mode == SAMD_CN_BOXPLUS ? 2 : 0;
+  const kern_t fn = kerns[2 * mi + (pow2 ? 1 : 0)];
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;
-#define SAMD_MSS_ARGS llr, out, ws, rm, h->n_cn, nbu, batch, num_iter, llr_max, off, hard_out, return_infobits,           \
-                      h->sp_g_floats, h->sp_col_ent, h->sp_cn_ptr, reinterpret_cast<const int2*>(h->sp_cn_list), h->sp_vn_ptr, \
-                      reinterpret_cast<const int2*>(h->sp_vn_list)
-  if (pow2) hipLaunchKernelGGL(ldpc5g_decode_mss_kernel<true>, dim3(mss_grid(h, batch)), dim3(1024), h->sp_lds_bytes, st, SAMD_MSS_ARGS);
-  else hipLaunchKernelGGL(ldpc5g_decode_mss_kernel<false>, dim3(mss_grid(h, batch)), dim3(1024), h->sp_lds_bytes, st, SAMD_MSS_ARGS);
-#undef SAMD_MSS_ARGS
+  hipLaunchKernelGGL(fn, dim3(mss_grid(h, batch)), dim3(1024), h->sp_lds_bytes, st, llr, out, ws, rm, h->n_cn, nbu, batch,
+                     num_iter, llr_max, off, hard_out, return_infobits, h->sp_g_floats, h->sp_col_ent, h->sp_cn_ptr,
+                     reinterpret_cast<const int2*>(h->sp_cn_list), h->sp_vn_ptr,
+                     reinterpret_cast<const int2*>(h->sp_vn_list));
   return launch_status();
 }
 
