@@ -31,6 +31,7 @@
 // stages between paths (lazy copy) is the next step.
 #include "common.h"
 #include "bp_math.h"
+#include "scl_math.h"
 #include <cstdlib>
 
 namespace samd {
@@ -82,19 +83,14 @@ __global__ __launch_bounds__(256) void polar_encode_kernel(const float* __restri
 enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6 };
 constexpr float kPolarLlrMax = 30.f;
 
-// log(1 + e^x) = max(x, 0) + log(1 + e^-|x|).  The decoder evaluates this ~3000 times per codeword on a few
-// lanes, and the libm forms (log1pf in double-float arithmetic, expf with its special cases: ~135 VALU
-// operations) were 40 % of all instructions of the kernel.  Here -|x| is in [-60, 0] (LLRs are clipped to +-30)
-// and 1 + e^-|x| in [1, 2]: the range-specialised exp / log cores of bp_math.h apply (17 operations).  The
-// absolute error stays below 1e-7 (1 + e rounds e to the grid of 1.0) on metrics and LLRs of magnitude 1e-1 ...
-// 1e2 - the size of the float32 rounding differences between any two libms.
-__device__ __forceinline__ float softplus(float x) {
-  return fmaxf(x, 0.f) + log_core_f32(1.f + exp_core_f32(-fabsf(x)));
-}
+// Metric arithmetic: scl_math.h (float32 operations in a defined order, restated by the CPU oracle
+// oracle/polar_scl.c - hard decisions and CRC status are compared bit for bit, tests/test_gpu_polar.py).
+// log(1 + e^x) = max(x, 0) + T(|x|) is evaluated ~3000 times per codeword on a few lanes (19 VALU operations).
+__device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + scl_T(fabsf(x)); }
 __device__ __forceinline__ float cn_op(float x, float y) {  // polar/decoding.py:684-705
   x = clampf(x, -kPolarLlrMax, kPolarLlrMax);
   y = clampf(y, -kPolarLlrMax, kPolarLlrMax);
-  const float lse = fmaxf(x, y) + log_core_f32(1.f + exp_core_f32(-fabsf(x - y)));
+  const float lse = fmaxf(x, y) + scl_T(fabsf(x - y));
   return softplus(x + y) - lse;
 }
 
@@ -215,17 +211,20 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           if (tid < L) {                                      // one lane per path
             const float* in = (s == p.m) ? llr_ch : stage(lp[order[tid] * 16 + s], s);
             const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[0], -kPolarLlrMax, kPolarLlrMax);
-            const float tl = log_core_f32(1.f + exp_core_f32(-fabsf(l)));     // shared by softplus(-l) and softplus(l)
+            const float tl = scl_T(fabsf(l));                 // shared by softplus(-l) and softplus(l)
             blk[tid] = fmaxf(-l, 0.f) + tl;
             if (info) blk[L + tid] = fmaxf(l, 0.f) + tl;
           }
         } else {
           for (int pos = 0; pos < L; ++pos) {
             const float* in = (s == p.m) ? llr_ch : stage(lp[order[pos] * 16 + s], s);
+            // defined summation order (oracle/polar_scl.c block_sum_f32): lane l accumulates terms l, l+64, l+128, ...
+            // in ascending order, then the halving tree over the 64 lanes (xor butterfly: both operands of every
+            // addition are the same two numbers on both lanes, so all lanes hold lane 0's tree)
             float m0 = 0.f, m1 = 0.f;
             for (int j = tid; j < sz; j += NT) {
               const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[j], -kPolarLlrMax, kPolarLlrMax);
-              const float tl = log_core_f32(1.f + exp_core_f32(-fabsf(l)));
+              const float tl = scl_T(fabsf(l));
               m0 += fmaxf(-l, 0.f) + tl;
               m1 += fmaxf(l, 0.f) + tl;
             }
@@ -390,8 +389,12 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
       cand[tid] = pm[tid] + pen;
     }
     __syncthreads();
+    // first minimum of the penalised metrics in the order of the final stable sort by path metric (:1391, 1415):
+    // among equal penalised metrics (30 k + pm rounds to a grid of ~1e-3) the smaller path metric, then the
+    // lower position
     int best = 0;
-    for (int q = 1; q < L; ++q) if (cand[q] < cand[best]) best = q;
+    for (int q = 1; q < L; ++q)
+      if (cand[q] < cand[best] || (cand[q] == cand[best] && pm[q] < pm[best])) best = q;
     const uint32_t* bw = bits + (size_t)order[best] * words;
     for (int i = tid; i < p.k; i += NT) {
       const int pos = p.info_pos[i];
@@ -476,7 +479,6 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   }
   // set on every launch: the attribute is per device and a process may drive several
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int m = 0;
   while ((1 << m) < n) ++m;
   const int grid = scl_grid(batch, n, list_size);
@@ -484,8 +486,7 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   unsigned char* gb = reinterpret_cast<unsigned char*>(gs + (size_t)grid * list_size * n);
   SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n), batch, n, m, k, list_size,
             sc_mode, crc_len, crc_poly};
-  const char* nt_env = getenv("SAMD_SCL_THREADS");
-  if (nt_env && atoi(nt_env) == 256) hipLaunchKernelGGL(polar_scl_kernel<256>, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
+  // one wave per codeword: the block sums of rate-0 / repetition nodes are defined on 64 lanes (scl_math.h)
+  hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
   return launch_status();
 }

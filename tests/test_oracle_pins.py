@@ -1,0 +1,91 @@
+"""CPU tests that close pinning holes of the oracle:
+
+(i)   oracle/ldpc_bp.c (the fast checker behind every "bit-exact on 5G codes" GPU assertion, and the CPU baseline) is
+      compared DIRECTLY with oracle/ldpc_bp.py (the literal restatement pinned in tests/test_oracle_ldpc.py);
+(ii)  oracle/mapping.demapper against the formula of the reference's own NumPy test, scipy ``logsumexp`` over the
+      point sets C_{i,1} / C_{i,0} (/root/reference/test/unit/mapping/test_mapping.py:175-199, atol 1e-5);
+(iii) ebnodb2no with a resource grid: host function == oracle == the formula of utils/misc.py:225-251 by hand."""
+import numpy as np
+import pytest
+from scipy.special import logsumexp
+
+from oracle.ldpc5g import LDPC5GCode
+from oracle import ldpc_bp as bp, cbind, mapping as omap, utils as outil, ofdm as o
+
+
+def _noisy_llr(code, m, batch, ebno_db, seed):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 2, (batch, code.k)).astype(np.float32)
+    c = code.encode(u)
+    no = float(outil.ebnodb2no(ebno_db, m, code.k / code.n))
+    pts = omap.qam(m)
+    x = omap.mapper(c, pts)
+    y = (x + np.sqrt(no / 2) * (rng.normal(size=x.shape) + 1j * rng.normal(size=x.shape))).astype(np.complex64)
+    return u, omap.demapper(y, np.float32(no), pts, "app")
+
+
+@pytest.mark.parametrize("k,n,m,bg,batch,iters,ebno", [
+    (1024, 2048, 2, "bg1", 32, 10, 1.5),           # BASELINE config C1
+    (2816, 8448, 6, "bg1", 4, 20, 4.5),            # BASELINE config C2 (n=8448, BP-20, 64-QAM)
+    (200, 400, 2, None, 16, 6, 2.0),               # BG2, partial last row of the pruned graph
+])
+def test_c_oracle_equals_numpy_oracle(k, n, m, bg, batch, iters, ebno):
+    code = LDPC5GCode(k, n, m, bg)
+    u, llr = _noisy_llr(code, m, batch, ebno, k)
+    for cn in ("minsum", "offset-minsum", "boxplus-phi", "boxplus"):
+        dec = bp.LDPC5GDecoder(code, cn_update=cn, num_iter=iters, hard_out=False)
+        llr_full = dec.rate_recover(llr)
+        ref = dec.decode(llr_full)                                        # NumPy, literal restatement, [B, N_vn]
+        got = cbind.bp_decode(dec, llr_full)                              # C, OpenMP
+        assert got.shape == ref.shape
+        if cn in ("minsum", "offset-minsum"):
+            assert np.array_equal(got, ref), cn                           # same defined order: bit for bit
+        else:
+            # transcendental rules: glibc vs NumPy SIMD libm differ in the last bits and phi amplifies that on
+            # saturating messages (DESIGN.md "phi conditioning"): after ONE iteration the two agree to 1e-4, after all
+            # iterations the decisions agree on every decoded word and the soft values on most positions
+            one_c, one_py = cbind.bp_decode(dec, llr_full, num_iter=1), dec.decode(llr_full, num_iter=1)
+            assert np.isclose(one_c, one_py, rtol=1e-4, atol=1e-3).mean() > 0.995, cn
+            conv = np.all((ref[:, :k] > 0) == u, axis=1)
+            assert conv.any() and np.array_equal((got[:, :k] > 0)[conv], (ref[:, :k] > 0)[conv]), cn
+            assert np.mean(np.abs(got - ref) <= 1e-2 * (1 + np.abs(ref))) > 0.9, cn
+        hard = cbind.bp_decode(dec, llr_full, hard_out=True)
+        assert np.array_equal(hard, (got > 0).astype(np.float32))
+    # zero iterations = hard decision on the channel LLRs, one iteration on a generic PCM as well
+    dec0 = bp.LDPC5GDecoder(code, cn_update="minsum", num_iter=0, hard_out=False)
+    assert np.array_equal(cbind.bp_decode(dec0, dec0.rate_recover(llr)), dec0.decode(dec0.rate_recover(llr)))
+
+
+@pytest.mark.parametrize("m", [2, 4, 6])
+def test_demapper_oracle_against_reference_test_formula(m):
+    """The loop of test_mapping.py:175-199 (per-symbol noise variance in [0.01, 100]) on the oracle's demapper."""
+    rng = np.random.default_rng(m)
+    pts = omap.qam(m)
+    c0, c1 = omap._bit_sets(m)
+    bits = rng.integers(0, 2, (20, 10 * m)).astype(np.float32)
+    x = omap.mapper(bits, pts)
+    x = (x + 0.2 * (rng.normal(size=x.shape) + 1j * rng.normal(size=x.shape))).astype(np.complex64)
+    no = rng.uniform(0.01, 100, x.shape).astype(np.float32)
+    app, maxlog = omap.demapper(x, no, pts, "app"), omap.demapper(x, no, pts, "maxlog")
+    for l in range(x.shape[0]):
+        for i, y in enumerate(x[l]):
+            e = -np.abs(y - pts) ** 2 / no[l, i]
+            want_app = logsumexp(np.take(e, c1), axis=0) - logsumexp(np.take(e, c0), axis=0)
+            want_max = np.max(np.take(e, c1), axis=0) - np.max(np.take(e, c0), axis=0)
+            assert np.allclose(want_app, app[l, i * m:(i + 1) * m], atol=1e-5)
+            assert np.allclose(want_max, maxlog[l, i * m:(i + 1) * m], atol=1e-5)
+
+
+def test_ebnodb2no_with_resource_grid():
+    import sionna_amd.phy as phy
+    # (the Kronecker pilots are drawn on the device, so the CPU test uses a pilot-free grid; the C4 GPU chain test
+    # asserts the same equality for the config-4 grid with pilots)
+    kw = dict(num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6], dc_null=True)
+    rg, org = phy.ofdm.ResourceGrid(14, 76, 15e3, **kw), o.ResourceGrid(14, 76, 15e3, **kw)
+    for db, m, r in ((-3.0, 2, 0.5), (0.0, 4, 1 / 3), (7.5, 6, 0.75)):
+        got, ref = float(phy.utils.ebnodb2no(db, m, r, rg)), float(outil.ebnodb2no(db, m, r, org))
+        # utils/misc.py:225-251 by hand: Es = 1/num_streams_per_tx, scaled by (all REs incl. CP) / (data REs)
+        es = (1 / 2) * (14 * (1 + 6 / 76) * 64) / rg.num_data_symbols
+        want = 1 / (10 ** (db / 10) * r * m / es)
+        assert got == ref and abs(got - want) < 2e-6 * want
+    assert rg.num_data_symbols == org.num_data_symbols == 14 * 64 and rg.num_effective_subcarriers == 64
