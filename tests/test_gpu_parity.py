@@ -499,6 +499,35 @@ def test_5g_boxplus_vs_oracle(phy, k, n, bg, m, cn):
     assert np.array_equal(_np(phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, return_infobits=False)(llr)), c)
 
 
+@pytest.mark.parametrize("ebno,min_soft", [(4.0, 0.93), (4.5, 0.998)])
+def test_c2_boxplus_phi_at_scale_vs_oracle(phy, ebno, min_soft):
+    """The reference's DEFAULT rule at BASELINE config C2 scale (n=8448, k=2816, 64-QAM, 20 iterations, 2048 codewords
+    in the waterfall) against the C oracle (glibc float32 exp / log) on the same LLRs.  phi is evaluated literally in
+    float32 (decoding.py:1110-1120), so last-bit differences between exp / log implementations are amplified on
+    saturating messages; what is asserted (measured on MI355X, tools/phi_scale_check.py ->
+    profiles/r02_phi_scale.json: 4.0 dB: 99.76 % of the codewords identical, 95.1 % of the soft outputs within 1e-5;
+    4.5 dB: 100 % / 99.93 %):
+      (i)  every word the oracle decodes is decoded identically, >= 99.5 % of all codewords have identical decisions,
+           BLER identical within 2 codewords;
+      (ii) the stated fraction of soft outputs lies within the north-star bar 1e-5 relative (+1e-4 absolute)."""
+    k, n, m, B = 2816, 8448, 6, 2048
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
+    code = LDPC5GCode(k, n, m, "bg1")
+    phy.config.seed = int(ebno * 100)
+    no = phy.utils.ebnodb2no(ebno, m, k / n)
+    u = phy.mapping.BinarySource()([B, k])
+    llr = phy.mapping.Demapper("app", "qam", m)(phy.channel.AWGN()(phy.mapping.Mapper("qam", m)(enc(u)), no), no)
+    got = _np(phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="boxplus-phi", num_iter=20, hard_out=False)(llr))
+    odec = obp.LDPC5GDecoder(code, cn_update="boxplus-phi", num_iter=20, hard_out=False)
+    ref = cbind.bp_decode(odec, odec.rate_recover(_np(llr)))[:, :k]
+    hg, hr, ub = got > 0, ref > 0, _np(u) > 0
+    decoded = np.all(hr == ub, axis=1)
+    assert decoded.any() and np.array_equal(hg[decoded], hr[decoded])
+    assert np.mean(np.all(hg == hr, axis=1)) >= 0.995
+    assert abs(int(np.any(hg != ub, axis=1).sum()) - int(np.any(hr != ub, axis=1).sum())) <= 2
+    assert np.mean(np.isclose(got, ref, rtol=1e-5, atol=1e-4)) >= min_soft
+
+
 def test_5g_large_z_rate_third_on_chip(phy):
     # Z=384, rate 1/3: only (M1, M2) stay in LDS, LLRs / VN totals / sign words live in the L2 workspace
     k, n = 8448, 25344
