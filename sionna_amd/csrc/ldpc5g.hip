@@ -341,7 +341,7 @@ extern "C" int samd_ldpc5g_encode_f32(const samd_ldpc5g_t* h, const float* bits,
 
 extern "C" int samd_ldpc5g_rate_recover_f32(const samd_ldpc5g_t* h, const float* llr, float* out, int batch,
                                             float llr_max, void* stream) {
-  SAMD_REQUIRE(h && llr && out && batch > 0 && batch <= 65535 * 16, "bad argument");
+  SAMD_REQUIRE(h && llr && out && batch > 0, "bad argument");   // any batch: the loop below walks 65535-row chunks
   for (int b0 = 0; b0 < batch; b0 += 65535) {
     const int nb = std::min(65535, batch - b0);
     hipLaunchKernelGGL(ldpc5g_rate_recover_kernel, dim3((h->n_vn + 255) / 256, nb), dim3(256), 0, (hipStream_t)stream,

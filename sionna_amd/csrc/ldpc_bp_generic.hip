@@ -269,22 +269,28 @@ __global__ __launch_bounds__(256) void finish_kernel(const float* __restrict__ x
   }
 }
 
+// grid.y of the row-indexed helper kernels below: the rows are walked with a gridDim.y stride, because large
+// 5G codes (n_ldpc = 26112: ~121 k edges) and user PCMs exceed the 65535 limit of grid.y
+static inline unsigned rows_grid(int rows) { return (unsigned)std::max(1, std::min(rows, 65535)); }
+
 // state [E,B] (logit sign) <-> msg [E,Bs] (internal sign)
 __global__ void state_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, int batch,
                                   size_t src_stride, size_t dst_stride, int rows) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int e = blockIdx.y;
-  if (b < batch && e < rows) dst[(size_t)e * dst_stride + b] = -1.f * src[(size_t)e * src_stride + b];
+  if (b >= batch) return;
+  for (int e = blockIdx.y; e < rows; e += gridDim.y)      // grid.y is capped at 65535 (rows_grid)
+    dst[(size_t)e * dst_stride + b] = -1.f * src[(size_t)e * src_stride + b];
 }
 
 // v2c init when no iteration runs but the state is requested: msg[e] = llr_t[vn(e)]
 __global__ void init_v2c_kernel(float* __restrict__ msg, const float* __restrict__ llr_t,
                                 const int32_t* __restrict__ vn_ptr, int num_vn, int bs, size_t stride) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int vn = blockIdx.y;
   if (b >= bs) return;
-  const float l = llr_t[(size_t)vn * stride + b];
-  for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e) msg[(size_t)e * stride + b] = l;
+  for (int vn = blockIdx.y; vn < num_vn; vn += gridDim.y) {
+    const float l = llr_t[(size_t)vn * stride + b];
+    for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e) msg[(size_t)e * stride + b] = l;
+  }
 }
 
 // ---- scheduled decoding: x_tot[v] = (sum_e c2v_e) + llr[v] for the listed VNs (vn_update_sum
@@ -321,23 +327,26 @@ __global__ __launch_bounds__(256) void vn_total_kernel(
 // c2v = 0 for every check node that is not active in sub-iteration 0 (state_in start).
 __global__ void zero_inactive_kernel(float* __restrict__ msg, const int32_t* __restrict__ cn_ptr,
                                      const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ active,
-                                     int bs, size_t stride) {
-  const int cn = blockIdx.y;
+                                     int num_cn, int bs, size_t stride) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= bs || active[cn]) return;
-  for (int i = cn_ptr[cn]; i < cn_ptr[cn + 1]; ++i) msg[(size_t)cn_edge[i] * stride + b] = 0.f;
+  if (b >= bs) return;
+  for (int cn = blockIdx.y; cn < num_cn; cn += gridDim.y) {
+    if (active[cn]) continue;
+    for (int i = cn_ptr[cn]; i < cn_ptr[cn + 1]; ++i) msg[(size_t)cn_edge[i] * stride + b] = 0.f;
+  }
 }
 
 // state_out of the scheduled path: msg_v2c[e] = clip(x_tot[v] - c2v_e), logit sign, [E,B].
 __global__ void v2c_state_kernel(const float* __restrict__ msg, const float* __restrict__ xtot,
-                                 const int32_t* __restrict__ vn_ptr, float* __restrict__ state, int batch,
+                                 const int32_t* __restrict__ vn_ptr, float* __restrict__ state, int num_vn, int batch,
                                  size_t stride, float llr_max) {
-  const int vn = blockIdx.y;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= batch) return;
-  const float x = xtot[(size_t)vn * stride + b];
-  for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e)
-    state[(size_t)e * batch + b] = -1.f * clampf(-1.f * msg[(size_t)e * stride + b] + x, -llr_max, llr_max);
+  for (int vn = blockIdx.y; vn < num_vn; vn += gridDim.y) {
+    const float x = xtot[(size_t)vn * stride + b];
+    for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e)
+      state[(size_t)e * batch + b] = -1.f * clampf(-1.f * msg[(size_t)e * stride + b] + x, -llr_max, llr_max);
+  }
 }
 
 static void launch_vn_total(const samd_ldpc_graph* g, const float* msg, const float* llr_t, float* xtot,
@@ -491,14 +500,14 @@ extern "C" int samd_ldpc_bp_decode_f32(const samd_ldpc_graph_t* g, const float* 
   }
   if (state_in) {
     // padded columns stay whatever they are: they never reach an output
-    const dim3 grid((batch + 255) / 256, g->num_edges);
+    const dim3 grid((batch + 255) / 256, rows_grid(g->num_edges));
     hipLaunchKernelGGL(state_copy_kernel, grid, dim3(256), 0, st, state, msg, batch, (size_t)batch, bs, g->num_edges);
   }
   const float* xsrc = xhat_t;
   if (num_iter == 0) {
     xsrc = llr_t;  // decoding.py:603-608: x_hat = clipped input
     if (state_out && !state_in) {
-      const dim3 grid((bs + 255) / 256, g->num_vn);
+      const dim3 grid((bs + 255) / 256, rows_grid(g->num_vn));
       hipLaunchKernelGGL(init_v2c_kernel, grid, dim3(256), 0, st, msg, llr_t, g->vn_ptr, g->num_vn, (int)bs, bs);
     }
   }
@@ -515,7 +524,7 @@ extern "C" int samd_ldpc_bp_decode_f32(const samd_ldpc_graph_t* g, const float* 
     hipLaunchKernelGGL(finish_kernel, grid, dim3(256), 0, st, xsrc, out, batch, out_cols, bs, hard_out, INFINITY);
   }
   if (state_out) {
-    const dim3 grid((batch + 255) / 256, g->num_edges);
+    const dim3 grid((batch + 255) / 256, rows_grid(g->num_edges));
     hipLaunchKernelGGL(state_copy_kernel, grid, dim3(256), 0, st, msg, state, batch, bs, (size_t)batch, g->num_edges);
   }
   return launch_status();
@@ -587,7 +596,7 @@ extern "C" int samd_ldpc_bp_decode_scheduled_f32(const samd_ldpc_graph_t* g, con
   }
   SAMD_HIP_CHECK(hipMemcpyAsync(xtot, llr_t, (size_t)g->num_vn * bs * sizeof(float), hipMemcpyDeviceToDevice, st));
   if (state_in) {
-    const dim3 grid((batch + 255) / 256, g->num_edges);
+    const dim3 grid((batch + 255) / 256, rows_grid(g->num_edges));
     hipLaunchKernelGGL(state_copy_kernel, grid, dim3(256), 0, st, state, msg, batch, (size_t)batch, bs, g->num_edges);
   } else {
     SAMD_HIP_CHECK(hipMemsetAsync(msg, 0, (size_t)g->num_edges * bs * sizeof(float), st));  // msg_c2v = 0 (:581)
@@ -599,9 +608,9 @@ extern "C" int samd_ldpc_bp_decode_scheduled_f32(const samd_ldpc_graph_t* g, con
       int rc;
       if (v2c_from_state) {
         rc = launch_cn_mode<SRC_V2C>(g, cn_mode, msg, xtot, (int)bs, llr_max, offset, st, cns, sched->width);
-        const dim3 grid(((int)bs + 255) / 256, g->num_cn);
+        const dim3 grid(((int)bs + 255) / 256, rows_grid(g->num_cn));
         hipLaunchKernelGGL(zero_inactive_kernel, grid, dim3(256), 0, st, msg, g->cn_ptr, g->cn_edge, sched->first_mask,
-                           (int)bs, bs);
+                           g->num_cn, (int)bs, bs);
         v2c_from_state = false;
       } else {
         rc = launch_cn_mode<SRC_DERIVED>(g, cn_mode, msg, xtot, (int)bs, llr_max, offset, st, cns, sched->width);
@@ -618,8 +627,8 @@ extern "C" int samd_ldpc_bp_decode_scheduled_f32(const samd_ldpc_graph_t* g, con
     if (num_iter == 0 && state_in) {
       // nothing ran: the state is returned as given
     } else {
-      const dim3 grid((batch + 255) / 256, g->num_vn);
-      hipLaunchKernelGGL(v2c_state_kernel, grid, dim3(256), 0, st, msg, xtot, g->vn_ptr, state, batch, bs, llr_max);
+      const dim3 grid((batch + 255) / 256, rows_grid(g->num_vn));
+      hipLaunchKernelGGL(v2c_state_kernel, grid, dim3(256), 0, st, msg, xtot, g->vn_ptr, state, g->num_vn, batch, bs, llr_max);
     }
   }
   return launch_status();

@@ -39,7 +39,8 @@ extern "C" int samd_nr_prng_seq_f32(uint32_t c_init, int64_t length, float* out,
   SAMD_REQUIRE(out && length > 0, "bad argument");
   // Length-31 Gold sequence, N_c = 1600: x1(n+31) = x1(n+3) + x1(n), x2(n+31) = x2(n+3) +
   // x2(n+2) + x2(n+1) + x2(n) mod 2, x1 = 1 0 0 ..., x2 = bits of c_init LSB first;
-  // c(n) = x1(n+N_c) + x2(n+N_c).  Init-time: generated on the host, uploaded once.
+  // c(n) = x1(n+N_c) + x2(n+N_c).  Init-time (the host class caches the sequence per (c_init, length)): generated
+  // on the host, uploaded asynchronously.
   const int64_t nc = 1600, total = length + nc + 31;
   std::vector<uint8_t> x1(total, 0), x2(total, 0);
   x1[0] = 1;
@@ -48,9 +49,18 @@ extern "C" int samd_nr_prng_seq_f32(uint32_t c_init, int64_t length, float* out,
     x1[i + 31] = x1[i + 3] ^ x1[i];
     x2[i + 31] = x2[i + 3] ^ x2[i + 2] ^ x2[i + 1] ^ x2[i];
   }
-  std::vector<float> c(length);
-  for (int64_t i = 0; i < length; ++i) c[i] = (float)(x1[i + nc] ^ x2[i + nc]);
-  SAMD_HIP_CHECK(hipMemcpyAsync(out, c.data(), length * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
-  SAMD_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));  // c is a host temporary
+  // stream-ordered upload without a host synchronisation: the staging vector is released by a host callback that
+  // the stream runs after the copy
+  auto* c = new std::vector<float>(length);
+  for (int64_t i = 0; i < length; ++i) (*c)[i] = (float)(x1[i + nc] ^ x2[i + nc]);
+  hipError_t e = hipMemcpyAsync(out, c->data(), length * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e == hipSuccess)
+    e = hipLaunchHostFunc((hipStream_t)stream, [](void* p) { delete static_cast<std::vector<float>*>(p); }, c);
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize((hipStream_t)stream);
+    delete c;
+    set_error(hipGetErrorString(e));
+    return SAMD_ERR_HIP;
+  }
   return SAMD_OK;
 }

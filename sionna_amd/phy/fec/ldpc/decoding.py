@@ -73,12 +73,17 @@ class LDPCBPDecoder(Block):
         self._num_cns, self._num_vns = pcm.shape
         self._llr_max = float(llr_max)
 
+        cb_lists = {}
         for name, cbs in (("v2c_callbacks", v2c_callbacks), ("c2v_callbacks", c2v_callbacks)):
-            if cbs is None or (isinstance(cbs, (list, tuple)) and len(cbs) == 0):
-                continue
-            if isinstance(cbs, (list, tuple, types.FunctionType)):
-                raise NotImplementedError(f"{name}: message callbacks have no HIP path")
-            raise TypeError(f"{name} must be a list of callables.")
+            if cbs is None:
+                cb_lists[name] = []
+            elif isinstance(cbs, (list, tuple)):
+                cb_lists[name] = list(cbs)
+            elif callable(cbs):
+                cb_lists[name] = [cbs]                 # a single callable is accepted (decoding.py:236-239)
+            else:
+                raise TypeError(f"{name} must be a list of callables.")
+        self._v2c_callbacks, self._c2v_callbacks = cb_lists["v2c_callbacks"], cb_lists["c2v_callbacks"]
 
         if isinstance(cn_schedule, str) and cn_schedule == "flooding":
             self._scheduling = "flooding"
@@ -98,19 +103,35 @@ class LDPCBPDecoder(Block):
         else:
             raise ValueError("cn_schedule can be 'flooding' or an array of ints.")
 
-        if cn_update in _ffi.CN_MODES:
+        # node updates (decoding.py:291-322): the string rules - and the exported functions that implement them -
+        # run on the HIP engines; any other callable, "identity" and message callbacks run on the torch engine of
+        # custom.py (same loop, device tensors, differentiable)
+        from . import custom
+        if isinstance(cn_update, types.FunctionType) and cn_update in custom.FUNCTION_TO_RULE:
+            cn_update = custom.FUNCTION_TO_RULE[cn_update]
+        if vn_update is custom.vn_update_sum:
+            vn_update = "sum"
+        self._cn_mode = None
+        if isinstance(cn_update, str) and cn_update in _ffi.CN_MODES:
             self._cn_mode = _ffi.CN_MODES[cn_update]
-        elif cn_update == "identity" or isinstance(cn_update, types.FunctionType):
-            raise NotImplementedError("custom / identity cn_update functions have no HIP path")
+            cn_fn = custom.BUILTIN_CN[cn_update]
+        elif cn_update == "identity":
+            cn_fn = custom.cn_node_update_identity
+        elif isinstance(cn_update, types.FunctionType):
+            cn_fn = cn_update
         else:
             raise TypeError("Provided cn_update not supported.")
         self._cn_update_name = cn_update
-        if vn_update == "sum":
-            pass
-        elif vn_update == "identity" or isinstance(vn_update, types.FunctionType):
-            raise NotImplementedError("custom / identity vn_update functions have no HIP path")
+        if isinstance(vn_update, str) and vn_update in custom.BUILTIN_VN:
+            vn_fn = custom.BUILTIN_VN[vn_update]
+        elif isinstance(vn_update, types.FunctionType):
+            vn_fn = vn_update
         else:
             raise TypeError("Provided vn_update not supported.")
+        self._custom = (self._cn_mode is None or vn_update != "sum" or bool(self._v2c_callbacks)
+                        or bool(self._c2v_callbacks))
+        self._custom_fns = (cn_fn, vn_fn)
+        self._custom_engine = None
         self._offset = 0.5                       # reference default of cn_update_offset_minsum
 
         # graph: VN-major edge list, ascending CN inside a VN (decoding.py:277-292, stable order)
@@ -191,9 +212,11 @@ class LDPCBPDecoder(Block):
 
     def _decode_2d(self, llr, out_cols, num_iter, msg_v2c, hard_out=None):
         """llr [B, N_vn] device float32 -> (x_hat [B, out_cols], state or None)."""
-        lib, g = _ffi.lib(), self._graph_handle()
         hard = self._hard_out if hard_out is None else hard_out
         batch = llr.shape[0]
+        if self._custom:
+            return self._decode_custom(llr, out_cols, num_iter, msg_v2c, hard)
+        lib, g = _ffi.lib(), self._graph_handle()
         out = torch.empty((batch, out_cols), dtype=torch.float32, device=llr.device)
         want_state = self._return_state
         state = None
@@ -208,6 +231,12 @@ class LDPCBPDecoder(Block):
             return out, state
         per_cw = lib.samd_ldpc_bp_workspace_bytes(g, 64) // 64
         step = batch
+        if state is not None and per_cw * batch > _MAX_WORKSPACE_BYTES:
+            # the [num_edges, batch] state is batch-last, so a batch slice is not a contiguous view: one launch,
+            # whose workspace ((E + 2 N) * 4 bytes per codeword) has to fit
+            raise ValueError(f"return_state / msg_v2c: the message workspace of {batch} codewords "
+                             f"({per_cw * batch / 2 ** 30:.1f} GiB) exceeds {_MAX_WORKSPACE_BYTES >> 30} GiB; "
+                             f"decode at most {_MAX_WORKSPACE_BYTES // per_cw} codewords per call")
         if state is None and per_cw * batch > _CACHE_SLICE_BYTES:
             # slices whose whole message state stays in the 256 MiB Infinity Cache: measured +20 %
             # (min-sum) / +4 % (phi) at config C2 over one 65536-codeword pass per launch
@@ -225,6 +254,24 @@ class LDPCBPDecoder(Block):
                 _ffi.check(lib.samd_ldpc_bp_decode_scheduled_f32(g, self._schedule_handle(), *args),
                            "LDPCBPDecoder(scheduled)")
         return out, (state if want_state else None)
+
+    def _decode_custom(self, llr, out_cols, num_iter, msg_v2c, hard):
+        """Custom node updates / message callbacks: the torch engine of custom.py on the device tensors."""
+        from . import custom
+        if self._custom_engine is None:
+            sched = self._cn_schedule if self._scheduling == "custom" else None
+            self._custom_engine = custom.CustomBPEngine(self._cn_idx, self._vn_idx, self._num_cns, self._num_vns,
+                                                        self._custom_fns[0], self._custom_fns[1], self._c2v_callbacks,
+                                                        self._v2c_callbacks, sched)
+        state_in = None
+        if msg_v2c is not None:
+            state_in = _ffi.to_device(msg_v2c, torch.float32)
+            if tuple(state_in.shape) != (self._num_edges, llr.shape[0]):
+                raise ValueError("msg_v2c must have shape [num_edges, batch_size]")
+        x_hat, v2c = self._custom_engine.decode(llr, num_iter, self._llr_max, state_in)
+        x_hat = x_hat[:, :out_cols]
+        out = (0 >= x_hat).to(torch.float32) if hard else -1.0 * x_hat          # decoding.py:620-626
+        return out.contiguous(), ((-1.0 * v2c).contiguous() if self._return_state else None)
 
     # ------------------------------------------------------------ Block interface
     def build(self, input_shape, **kwargs):
@@ -332,7 +379,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
         batch = llr2d.shape[0]
         out_shape = shape[:-1] + ((enc.k,) if self._return_infobits else (enc.n,))
 
-        use_onchip = (self._onchip_ok and self._cn_mode in (0, 1, 2, 3) and not self._return_state
+        use_onchip = (self._onchip_ok and not self._custom and self._cn_mode in (0, 1, 2, 3) and not self._return_state
                       and msg_v2c is None and batch > 0 and self._scheduling == "flooding")
         if use_onchip:
             out = self._try_onchip(llr2d, num_iter)

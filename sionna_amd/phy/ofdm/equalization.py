@@ -9,6 +9,25 @@ from ... import _ffi
 from ..block import Block
 
 
+# kernel modes of samd_ofdm_lmmse_c64 / samd_lmmse_equalizer_c64 (csrc/mimo.hip)
+MODE_LMMSE_NO_WHITENING, MODE_LMMSE, MODE_ZF, MODE_MF = 0, 1, 2, 3
+# err_var argument forms of the fused per-RE kernels
+EV_NONE, EV_TABLE, EV_FULL = 0, 1, 2
+
+
+def _is_host_zero(err_var):
+    """True if ``err_var`` is a HOST scalar equal to zero (Python / NumPy number, 0-d or 1-element NumPy array, CPU
+    tensor).  Device tensors are never inspected: that would be a device-to-host synchronisation on every call of
+    the config-4 hot path; a zero device tensor simply takes the table path and adds exact zeros."""
+    if isinstance(err_var, (int, float, np.number)):
+        return float(err_var) == 0.0
+    if isinstance(err_var, np.ndarray):
+        return err_var.size == 1 and float(err_var.reshape(-1)[0]) == 0.0
+    if isinstance(err_var, torch.Tensor) and err_var.device.type == "cpu":
+        return err_var.numel() == 1 and float(err_var.reshape(-1)[0]) == 0.0
+    return False
+
+
 class OFDMEqualizer(Block):
     """Base class kept for API parity.  Only the LMMSE equaliser has a HIP path; a user-supplied
     ``equalizer`` callable would have to run per resource element on the host, which this build
@@ -19,7 +38,7 @@ class OFDMEqualizer(Block):
         if equalizer not in ("lmmse", "zf", "mf"):
             raise NotImplementedError("OFDMEqualizer: the fused kernel implements the 'lmmse', 'zf' and 'mf' equalisers")
         self._rg, self._sm = resource_grid, stream_management
-        self._whiten = {"lmmse": 1, "zf": 2, "mf": 3}[equalizer]      # kernel mode
+        self._mode = {"lmmse": MODE_LMMSE, "zf": MODE_ZF, "mf": MODE_MF}[equalizer]
         self._dev = None
 
     def _tables(self):
@@ -48,15 +67,16 @@ class OFDMEqualizer(Block):
         t, f = rg.num_ofdm_symbols, rg.num_effective_subcarriers
         assert tuple(h_hat.shape) == (b, rx, m, rg.num_tx, rg.num_streams_per_tx, t, f), "unexpected h_hat shape"
         # err_var: broadcastable to h_hat.  Recognise the two compact forms, expand anything else.
-        ev = _ffi.to_device(err_var, torch.float32)
-        ev = ev.reshape((1,) * (7 - ev.dim()) + tuple(ev.shape)) if ev.dim() < 7 else ev
-        if ev.numel() == 1 and float(ev.reshape(-1)[0]) == 0.0:
-            ev_mode, ev_arg = 0, None
-        elif ev.shape[:3] == (1, 1, 1):
-            ev_mode = 1
-            ev_arg = torch.broadcast_to(ev, (1, 1, 1, rg.num_tx, rg.num_streams_per_tx, t, f)).contiguous()
+        if _is_host_zero(err_var):
+            ev_mode, ev_arg = EV_NONE, None
         else:
-            ev_mode, ev_arg = 2, torch.broadcast_to(ev, tuple(h_hat.shape)).contiguous()
+            ev = _ffi.to_device(err_var, torch.float32)
+            ev = ev.reshape((1,) * (7 - ev.dim()) + tuple(ev.shape)) if ev.dim() < 7 else ev
+            if ev.shape[:3] == (1, 1, 1):
+                ev_mode = EV_TABLE
+                ev_arg = torch.broadcast_to(ev, (1, 1, 1, rg.num_tx, rg.num_streams_per_tx, t, f)).contiguous()
+            else:
+                ev_mode, ev_arg = EV_FULL, torch.broadcast_to(ev, tuple(h_hat.shape)).contiguous()
         no = _ffi.to_device(no, torch.float32)
         no = torch.broadcast_to(no.reshape(tuple(no.shape) + (1,) * (3 - no.dim())), (b, rx, m)).contiguous()
         sc_ind, desired, undesired, data_pos, n_und = self._tables()
@@ -73,7 +93,7 @@ class OFDMEqualizer(Block):
         b, nd, dev = dims[0], rg.num_data_symbols, keep[0].device
         x_hat = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.complex64, device=dev)
         no_eff = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.float32, device=dev)
-        _ffi.check(_ffi.lib().samd_ofdm_lmmse_c64(*head, *tabs, *dims, int(self._whiten), _ffi.ptr(x_hat),
+        _ffi.check(_ffi.lib().samd_ofdm_lmmse_c64(*head, *tabs, *dims, int(self._mode), _ffi.ptr(x_hat),
                                                   _ffi.ptr(no_eff), _ffi.stream()), "LMMSEEqualizer")
         return x_hat, no_eff
 
@@ -84,7 +104,7 @@ class LMMSEEqualizer(OFDMEqualizer):
 
     def __init__(self, resource_grid, stream_management, whiten_interference=True, precision=None, **kwargs):
         super().__init__("lmmse", resource_grid, stream_management, precision=precision, **kwargs)
-        self._whiten = int(bool(whiten_interference))
+        self._mode = MODE_LMMSE if whiten_interference else MODE_LMMSE_NO_WHITENING
 
 
 class ZFEqualizer(OFDMEqualizer):

@@ -99,8 +99,12 @@ def test_constructor_errors_mirror_reference():
         LDPC5GDecoder(pcm)
     with pytest.raises(TypeError):
         LDPC5GDecoder(enc, return_infobits=1)
-    with pytest.raises(NotImplementedError):
-        LDPCBPDecoder(pcm, c2v_callbacks=[lambda m, it: m])     # no HIP path, no CPU fallback
+    with pytest.raises(TypeError):
+        LDPCBPDecoder(pcm, c2v_callbacks=3)
+    dcb = LDPCBPDecoder(pcm, c2v_callbacks=[lambda m, it: m])   # accepted: runs on the torch engine of custom.py ...
+    assert dcb._custom
+    with pytest.raises(RuntimeError):                           # ... on the device only - no CPU fallback
+        dcb(np.zeros((1, 3), np.float32))
     d = LDPCBPDecoder(sp.csr_matrix(pcm), cn_update="minsum", num_iter=3)
     assert (d.num_cns, d.num_vns, d.num_edges, d.num_iter) == (2, 3, 4, 3)
     d.num_iter = 5

@@ -58,3 +58,32 @@ def test_idd_beats_one_shot_detection():
     assert 1e-4 < ber_one_shot < 0.2, ber_one_shot               # operating point where errors remain
     assert bers[-1] < bers[0], bers                               # iterations help
     assert bers[-1] < 0.5 * ber_one_shot, (bers, ber_one_shot)    # and beat one-shot detection at equal decoder effort
+
+
+def test_return_state_on_a_large_5g_code():
+    """IDD state passing on a code with more than 65535 edges (BG1, Z=384: k=8448, n=25344 -> 121,344 edges, 26,112
+    variable nodes): the row-indexed helper kernels of the generic engine walk the rows with a grid stride (grid.y is
+    limited to 65535).  min-sum: outputs and the returned v2c state bit for bit against the oracle, and 2 x 3
+    iterations with state == 6 iterations."""
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    from oracle.ldpc5g import LDPC5GCode
+    from oracle import ldpc_bp as obp
+    _ffi.device()
+    k, n, B = 8448, 25344, 3
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    code = LDPC5GCode(k, n)
+    rng = np.random.default_rng(7)
+    u = rng.integers(0, 2, (B, k)).astype(np.float32)
+    c = code.encode(u)
+    llr = ((2 * c - 1) * 1.2 + rng.normal(size=c.shape)).astype(np.float32) * 2
+    mk = lambda it: phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=it, return_state=True)
+    x3, st3 = mk(3)(llr)
+    ref = obp.LDPC5GDecoder(code, cn_update="minsum", hard_out=False, num_iter=3, return_state=True)
+    assert ref.num_edges > 65535 and tuple(st3.shape) == (ref.num_edges, B)
+    xr, sr = ref.decode5g(llr)
+    assert np.array_equal(x3.cpu().numpy(), xr) and np.array_equal(st3.cpu().numpy(), sr)
+    x6a, st6a = mk(3)(llr, msg_v2c=st3)
+    x6, st6 = mk(6)(llr)
+    assert torch.equal(x6a.as_subclass(torch.Tensor), x6.as_subclass(torch.Tensor))
+    assert torch.equal(st6a.as_subclass(torch.Tensor), st6.as_subclass(torch.Tensor))

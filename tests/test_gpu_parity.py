@@ -626,3 +626,52 @@ def test_c2_full_batch_properties(phy):
     dec2._onchip_ok = False
     b = dec2(noisy)
     assert torch.equal(a.as_subclass(torch.Tensor), b.as_subclass(torch.Tensor))
+
+
+# ------------------------------------------------------------------ extension points (custom.py) on the device
+def test_decoder_callbacks_and_custom_updates_on_device(phy):
+    """Message callbacks / callable node updates run the torch engine on device tensors: with pass-through callbacks
+    the result equals the HIP engine's (min-sum: to float32 rounding - segment sums may associate differently),
+    exported rule functions select the HIP engine, statistics callbacks see every iteration."""
+    from sionna_amd.phy.fec.ldpc import (cn_update_minsum, cn_update_phi, DecoderStatisticsCallback, EXITCallback,
+                                         WeightedBPCallback)
+    k, n = 400, 800
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    code = LDPC5GCode(k, n)
+    u, c, llr = _noisy_llr(code, 64, 5, sigma=0.7)
+    plain = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=6)
+    ref = _np(plain(llr))
+    by_fn = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn_update_minsum, hard_out=False, num_iter=6)
+    assert not by_fn._custom and np.array_equal(_np(by_fn(llr)), ref)
+    stats = DecoderStatisticsCallback(6)
+    seen = []
+    cb = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=6, c2v_callbacks=[stats],
+                                    v2c_callbacks=[lambda m, it, x_hat: (seen.append((it, m.flat_values.is_cuda)), m)[1]])
+    assert cb._custom
+    got = _np(cb(llr))
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-4)
+    assert seen == [(i, True) for i in range(1, 7)] and np.all(stats.num_samples == 64)
+    assert np.all(np.diff(stats.success_rate) >= 0) and stats.success_rate[-1] > 0.9
+    # state out / in on the custom path, hard output, generic decoder with a scaled min-sum written by the user
+    cbs = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=True, num_iter=3, return_state=True,
+                                     c2v_callbacks=[lambda m, it: m])
+    hb, st = cbs(llr)
+    hb2, _ = cbs(llr, msg_v2c=st)
+    assert tuple(st.shape) == (cbs.num_edges, 64) and np.array_equal(_np(hb2), (ref > 0).astype(np.float32))
+    pcm = phy.fec.utils.load_parity_check_examples(1)[0]
+    scaled = lambda msg, llr_clipping=None: cn_update_minsum(msg, llr_clipping) * 0.75
+    dec = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=scaled, hard_out=False, num_iter=5)
+    y = torch.randn(32, pcm.shape[1], device="cuda") * 2 - 3
+    out = dec(y)
+    assert tuple(out.shape) == (32, pcm.shape[1]) and bool(torch.isfinite(out.as_subclass(torch.Tensor)).all())
+    # weighted BP: gradient reaches the trainable edge weights through the device engine
+    w = WeightedBPCallback(cb.num_edges)
+    wdec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn_update_phi, hard_out=False, num_iter=3, v2c_callbacks=[w])
+    assert wdec._custom
+    soft = wdec(torch.as_tensor(llr).cuda()).as_subclass(torch.Tensor)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(soft, torch.as_tensor(u).cuda())
+    loss.backward()
+    assert w.weights.grad is not None and float(w.weights.grad.abs().sum()) > 0
+    mi = EXITCallback(3)
+    phy.fec.ldpc.LDPC5GDecoder(enc, num_iter=3, v2c_callbacks=[mi])(-4.0 - 2 * torch.randn(16, n, device="cuda"))
+    assert np.all(np.isfinite(mi.mi[1:]))
