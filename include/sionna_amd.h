@@ -409,6 +409,30 @@ int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const float* err_var
                         void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * precision = "double" (reference block.py:25-52): float64 variants of the blocks whose
+ * results depend on the arithmetic precision - the BP decoders and the LLR demapper.
+ * ---------------------------------------------------------------------------------- */
+/* LDPCBPDecoder.call in float64 (decoding.py:544-637; phi clip :1115-1116).  sched = NULL: flooding;
+ * otherwise the array schedule of samd_ldpc_schedule_create.  Buffers like samd_ldpc_bp_decode_f32
+ * but double: llr_in [batch, num_vn], out [batch, out_cols], state [num_edges, batch]. */
+size_t samd_ldpc_bp_workspace_bytes_f64(const samd_ldpc_graph_t* g, int batch);
+int samd_ldpc_bp_decode_f64(const samd_ldpc_graph_t* g, const samd_ldpc_schedule_t* sched,
+                            const double* llr_in, double* out, int out_cols, double* state,
+                            int state_in, int state_out, int batch, int num_iter, int cn_mode,
+                            double llr_max, double offset, int hard_out, void* workspace,
+                            size_t workspace_bytes, void* stream);
+/* LDPC5GDecoder rate recovery / output mapping in float64 (decoding.py:1438-1475, 1508-1531). */
+int samd_ldpc5g_rate_recover_f64(const samd_ldpc5g_t* h, const double* llr, double* out, int batch,
+                                 double llr_max, void* stream);
+int samd_ldpc5g_extract_codeword_f64(const samd_ldpc5g_t* h, const double* x_hat, double* out,
+                                     int batch, void* stream);
+/* Demapper.call in float64 (mapping.py:664-691, 927-967): y [num_symbols] complex128, points
+ * [2^m] complex128, prior NULL | [m] | [num_symbols, m]; method 0 = app, 1 = maxlog. */
+int samd_qam_demap_f64(const double* y, const double* no, int64_t no_len, const double* points,
+                       int m, int64_t num_symbols, const double* prior, int64_t prior_len,
+                       int method, int hard_out, double* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * CRC and Polar codes (config C5 of the north star).
  * ---------------------------------------------------------------------------------- */
 /* CRCEncoder.call / CRCDecoder.call  fec/crc.py:175-215, 289-321.  poly = coefficients of

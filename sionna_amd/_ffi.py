@@ -34,6 +34,12 @@ _SIGNATURES = {
     "samd_ldpc_schedule_destroy": (None, [_vp]),
     "samd_ldpc_bp_decode_scheduled_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _f32,
                                                  _f32, _i32, _vp, _sz, _vp]),
+    "samd_ldpc_bp_workspace_bytes_f64": (_sz, [_vp, _i32]),
+    "samd_ldpc_bp_decode_f64": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, C.c_double,
+                                       C.c_double, _i32, _vp, _sz, _vp]),
+    "samd_ldpc5g_rate_recover_f64": (_i32, [_vp, _vp, _vp, _i32, C.c_double, _vp]),
+    "samd_ldpc5g_extract_codeword_f64": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "samd_qam_demap_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "samd_ldpc5g_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "samd_ldpc5g_destroy": (None, [_vp]),
     "samd_ldpc5g_encode_f32": (_i32, [_vp, _vp, _vp, _i32, _vp]),

@@ -1,0 +1,342 @@
+// precision = "double" (reference src/sionna/phy/block.py:25-52): float64 variants of the belief-propagation
+// decoders and the LLR demapper - the blocks whose results depend on the arithmetic precision.
+//
+//   LDPCBPDecoder.call / _bp_iter     fec/ldpc/decoding.py:544-637, 416-524 (flooding and array schedules)
+//   vn_update_sum                     :681-732
+//   cn_update_offset_minsum / minsum  :755-953
+//   cn_update_tanh                    :955-1043
+//   cn_update_phi                     :1045-1166 (float64 clip of phi: [1e-12, 28.324079], :1115-1116)
+//   LDPC5GDecoder rate recovery / codeword extraction  :1438-1475, 1508-1531
+//   Demapper.call + SymbolLogits2LLRs mapping.py:664-691, 927-967
+//
+// float32 is the hot path (north star); float64 is the reference's second numeric type and exists for analysis
+// runs, so this engine is the plain HBM-resident formulation: messages batch-last [E][B] (every access of a wave is
+// a contiguous row segment), one lane per (node, codeword), c2v resident + unclipped totals x_tot, v2c derived on
+// the fly as clip(x_tot - c2v) - one code path for flooding (a schedule with a single sub-iteration of all check
+// nodes) and array schedules.  Sums run sequentially in edge order like in the float32 engines and the oracle.
+#include "ldpc5g.h"
+#include "ldpc_graph.h"
+
+namespace samd {
+namespace {
+
+constexpr double kLarge64 = 100000.0;
+__device__ __forceinline__ double clampd(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+__device__ __forceinline__ double sign_nz64(double x) { return x < 0.0 ? -1.0 : 1.0; }
+__device__ __forceinline__ double sgn364(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : 0.0); }
+__device__ __forceinline__ double phi64(double x) {
+  x = clampd(x, 1e-12, 28.324079);
+  const double e = exp(x);
+  return log(e + 1.0) - log(e - 1.0);
+}
+
+// [B, cols] logits -> [cols][B] internal LLRs (-clip(logit))
+__global__ void prep64_kernel(const double* __restrict__ in, double* __restrict__ llr_t, int batch, int cols, double llr_max) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  for (int c = blockIdx.y; c < cols; c += gridDim.y) llr_t[(size_t)c * batch + b] = -1.0 * clampd(in[(size_t)b * cols + c], -llr_max, llr_max);
+}
+
+__global__ void negate64_kernel(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = -1.0 * src[i];
+}
+
+// CN update of the listed check nodes.  from_state: the buffer holds v2c (first sub-iteration with msg_v2c given);
+// otherwise it holds c2v and v2c_e = clip(x_tot[v] - c2v_e).
+template <int MODE>
+__global__ void cn64_kernel(double* __restrict__ msg, const double* __restrict__ xtot, const int32_t* __restrict__ cn_ptr,
+                            const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ cn_vn,
+                            const int32_t* __restrict__ node_list, int n_nodes, int batch, int from_state,
+                            double llr_max, double offset) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  for (int slot = blockIdx.y; slot < n_nodes; slot += gridDim.y) {
+    const int cn = node_list ? node_list[slot] : slot;
+    const int e0 = cn_ptr[cn], d = cn_ptr[cn + 1] - e0;
+    auto load = [&](int i) -> double {
+      const double m = msg[(size_t)cn_edge[e0 + i] * batch + b];
+      if (from_state) return m;
+      return clampd(-1.0 * m + xtot[(size_t)cn_vn[e0 + i] * batch + b], -llr_max, llr_max);
+    };
+    auto store = [&](int i, double v) { msg[(size_t)cn_edge[e0 + i] * batch + b] = v; };
+    if constexpr (MODE == SAMD_CN_MINSUM || MODE == SAMD_CN_OFFSET_MINSUM) {
+      double node_sign = 1.0, min1 = INFINITY;
+      for (int i = 0; i < d; ++i) {
+        const double x = clampd(load(i), -kLarge64, kLarge64);
+        node_sign *= sign_nz64(x);
+        min1 = fmin(min1, fabs(x));
+      }
+      double min2 = INFINITY, node_sum = 0.0;
+      for (int i = 0; i < d; ++i) {
+        const double t = fabs(clampd(load(i), -kLarge64, kLarge64)) - min1;
+        const double r = (t == 0.0) ? kLarge64 : t;
+        min2 = fmin(min2, r);
+        node_sum += r;
+      }
+      min2 = min2 + min1;
+      node_sum = node_sum - (2.0 * kLarge64 - 1.0);
+      const double dm = 0.5 * (1.0 - sgn364(node_sum));
+      const double min_e = (1.0 - dm) * min1 + dm * min2;
+      // the new c2v of edge i must not disturb the v2c derivation of the edges still to come: results first
+      // into registers is impossible for unbounded degrees, but store() only touches edge i and load(j != i)
+      // reads edge j and x_tot - independent
+      for (int i = 0; i < d; ++i) {
+        const double x = clampd(load(i), -kLarge64, kLarge64);
+        const double t = fabs(x) - min1;
+        double m = (t == 0.0) ? min_e : min1;
+        m = fmax(m - offset, 0.0);
+        store(i, clampd((sign_nz64(x) * node_sign) * m, -llr_max, llr_max));
+      }
+    } else if constexpr (MODE == SAMD_CN_BOXPLUS_PHI) {
+      double node_sign = 1.0, sum = 0.0;
+      for (int i = 0; i < d; ++i) {
+        const double x = load(i);
+        node_sign *= sign_nz64(x);
+        sum += phi64(fabs(x));
+      }
+      for (int i = 0; i < d; ++i) {
+        const double x = load(i);
+        const double e = -1.0 * phi64(fabs(x)) + sum;
+        store(i, clampd((sign_nz64(x) * node_sign) * phi64(e), -llr_max, llr_max));
+      }
+    } else {
+      double prod = 1.0;
+      for (int i = 0; i < d; ++i) {
+        const double t = tanh(load(i) / 2.0);
+        prod *= (t == 0.0) ? 1e-12 : t;
+      }
+      const double ac = 1.0 - 1e-7;
+      for (int i = 0; i < d; ++i) {
+        double t = tanh(load(i) / 2.0);
+        t = (t == 0.0) ? 1e-12 : t;
+        double e = (1.0 / t) * prod;
+        e = (fabs(e) < 1e-7) ? 0.0 : e;
+        e = clampd(e, -ac, ac);
+        store(i, clampd(2.0 * atanh(e), -llr_max, llr_max));
+      }
+    }
+  }
+}
+
+__global__ void zero_inactive64_kernel(double* __restrict__ msg, const int32_t* __restrict__ cn_ptr,
+                                       const int32_t* __restrict__ cn_edge, const int32_t* __restrict__ active, int num_cn,
+                                       int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  for (int cn = blockIdx.y; cn < num_cn; cn += gridDim.y) {
+    if (active[cn]) continue;
+    for (int i = cn_ptr[cn]; i < cn_ptr[cn + 1]; ++i) msg[(size_t)cn_edge[i] * batch + b] = 0.0;
+  }
+}
+
+// x_tot[v] = (sum_e c2v_e) + llr[v] for the listed VNs (all if node_list == nullptr)
+__global__ void vn_total64_kernel(const double* __restrict__ msg, const double* __restrict__ llr_t, double* __restrict__ xtot,
+                                  const int32_t* __restrict__ vn_ptr, const int32_t* __restrict__ node_list, int n_nodes,
+                                  int batch) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  for (int slot = blockIdx.y; slot < n_nodes; slot += gridDim.y) {
+    const int vn = node_list ? node_list[slot] : slot;
+    double x = 0.0;
+    for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e) x += msg[(size_t)e * batch + b];
+    xtot[(size_t)vn * batch + b] = x + llr_t[(size_t)vn * batch + b];
+  }
+}
+
+__global__ void finish64_kernel(const double* __restrict__ xtot, double* __restrict__ out, int batch, int rows, int hard,
+                                double llr_max) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const double x = clampd(xtot[(size_t)r * batch + b], -llr_max, llr_max);
+    out[(size_t)b * rows + r] = hard ? ((0.0 >= x) ? 1.0 : 0.0) : -1.0 * x;
+  }
+}
+
+__global__ void v2c_state64_kernel(const double* __restrict__ msg, const double* __restrict__ xtot,
+                                   const int32_t* __restrict__ vn_ptr, double* __restrict__ state, int num_vn, int batch,
+                                   double llr_max) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= batch) return;
+  for (int vn = blockIdx.y; vn < num_vn; vn += gridDim.y) {
+    const double x = xtot[(size_t)vn * batch + b];
+    for (int e = vn_ptr[vn]; e < vn_ptr[vn + 1]; ++e)
+      state[(size_t)e * batch + b] = -1.0 * clampd(-1.0 * msg[(size_t)e * batch + b] + x, -llr_max, llr_max);
+  }
+}
+
+inline unsigned ygrid(int rows) { return (unsigned)std::max(1, std::min(rows, 4096)); }
+
+void launch_cn64(int mode, dim3 grid, hipStream_t st, double* msg, const double* xtot, const samd_ldpc_graph* g,
+                 const int32_t* nodes, int n_nodes, int batch, int from_state, double llr_max, double offset) {
+#define SAMD_CN64(M) hipLaunchKernelGGL((cn64_kernel<M>), grid, dim3(64), 0, st, msg, xtot, g->cn_ptr, g->cn_edge, g->cn_vn, nodes, n_nodes, batch, from_state, llr_max, offset)
+  switch (mode) {
+    case SAMD_CN_BOXPLUS: SAMD_CN64(SAMD_CN_BOXPLUS); break;
+    case SAMD_CN_BOXPLUS_PHI: SAMD_CN64(SAMD_CN_BOXPLUS_PHI); break;
+    case SAMD_CN_MINSUM: offset = 0.0; SAMD_CN64(SAMD_CN_MINSUM); break;
+    default: SAMD_CN64(SAMD_CN_OFFSET_MINSUM); break;
+  }
+#undef SAMD_CN64
+}
+
+// ---- 5G rate recovery / codeword extraction in float64 (index maps of ldpc5g.h)
+__global__ void rate_recover64_kernel(const double* __restrict__ llr, double* __restrict__ out, RateMatch p, double llr_max,
+                                      int batch) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= p.n_vn) return;
+  for (int b = blockIdx.y; b < batch; b += gridDim.y) {
+    const double* row = llr + (size_t)b * p.n;
+    double r;
+    int u = -1;
+    if (v < p.k) u = v;
+    else if (v >= p.k_ldpc) u = v - (p.k_ldpc - p.k);
+    if (u < 0) r = -llr_max;                                       // filler bits
+    else {
+      const int t = u - 2 * p.z;
+      if (t < 0 || t >= p.n) r = 0.0;                              // punctured
+      else {
+        int o = t;
+        if (p.m_int > 0) { const int q = p.n / p.m_int; o = (t / q) + (t % q) * p.m_int; }
+        r = row[o];
+      }
+    }
+    out[(size_t)b * p.n_vn + v] = r;
+  }
+}
+
+__global__ void extract64_kernel(const double* __restrict__ x_hat, double* __restrict__ out, RateMatch p, int batch) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= p.n) return;
+  for (int b = blockIdx.y; b < batch; b += gridDim.y)
+    out[(size_t)b * p.n + o] = x_hat[(size_t)b * p.n_vn + short_to_full(p, out_to_short(p, o))];
+}
+
+// ---- demapper (any constellation, app / maxlog, optional prior LLRs)
+__device__ __forceinline__ double log_sigmoid64(double x) { return x < 0.0 ? x - log1p(exp(x)) : -log1p(exp(-x)); }
+
+__global__ __launch_bounds__(256) void demap64_kernel(const double2* __restrict__ y, const double* __restrict__ no,
+                                                      int64_t no_len, const double2* __restrict__ points, int m,
+                                                      int64_t num_symbols, const double* __restrict__ prior,
+                                                      int64_t prior_len, int maxlog, int hard_out,
+                                                      double* __restrict__ out) {
+  const int P = 1 << m;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < num_symbols; s += (int64_t)gridDim.x * blockDim.x) {
+    const double2 ys = y[s];
+    const double n0 = fmax(no_len == 1 ? no[0] : no[s], 2.2250738585072014e-308);   // finfo(float64).tiny
+    double ls0[10], ls1[10], m0[10], m1[10], s0[10], s1[10];
+    for (int i = 0; i < m; ++i) {
+      const double p = prior ? prior[prior_len == m ? i : s * m + i] : 0.0;
+      ls1[i] = prior ? log_sigmoid64(p) : 0.0;
+      ls0[i] = prior ? log_sigmoid64(-p) : 0.0;
+      m0[i] = m1[i] = -INFINITY;
+      s0[i] = s1[i] = 0.0;
+    }
+    for (int pass = 0; pass < (maxlog ? 1 : 2); ++pass)
+      for (int c = 0; c < P; ++c) {
+        const double dr = ys.x - points[c].x, di = ys.y - points[c].y;
+        double e = -(dr * dr + di * di) / n0;
+        if (prior) {
+          double ps = 0.0;
+          for (int i = 0; i < m; ++i) ps += ((c >> (m - 1 - i)) & 1) ? ls1[i] : ls0[i];
+          e = ps + e;
+        }
+        for (int i = 0; i < m; ++i) {
+          const bool one = (c >> (m - 1 - i)) & 1;
+          if (pass == 0) { if (one) m1[i] = fmax(m1[i], e); else m0[i] = fmax(m0[i], e); }
+          else { if (one) s1[i] += exp(e - m1[i]); else s0[i] += exp(e - m0[i]); }
+        }
+      }
+    for (int i = 0; i < m; ++i) {
+      const double r = maxlog ? (m1[i] - m0[i]) : ((log(s1[i]) + m1[i]) - (log(s0[i]) + m0[i]));
+      out[s * m + i] = hard_out ? (r > 0.0 ? 1.0 : 0.0) : r;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace samd
+
+using namespace samd;
+
+extern "C" size_t samd_ldpc_bp_workspace_bytes_f64(const samd_ldpc_graph_t* g, int batch) {
+  if (!g || batch <= 0) return 0;
+  return ((size_t)g->num_edges + 2 * (size_t)g->num_vn) * (size_t)batch * sizeof(double) + 256;
+}
+
+extern "C" int samd_ldpc_bp_decode_f64(const samd_ldpc_graph_t* g, const samd_ldpc_schedule_t* sched, const double* llr_in,
+                                       double* out, int out_cols, double* state, int state_in, int state_out, int batch,
+                                       int num_iter, int cn_mode, double llr_max, double offset, int hard_out,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  SAMD_REQUIRE(g && llr_in && out && batch > 0, "bad argument");
+  SAMD_REQUIRE(out_cols > 0 && out_cols <= g->num_vn && num_iter >= 0, "bad out_cols / num_iter");
+  SAMD_REQUIRE(cn_mode >= 0 && cn_mode <= 3, "unknown cn_mode");
+  SAMD_REQUIRE(!(state_in || state_out) || state, "state buffer missing");
+  SAMD_REQUIRE(!sched || sched->num_cn == g->num_cn, "schedule belongs to another graph");
+  if (!workspace || workspace_bytes < samd_ldpc_bp_workspace_bytes_f64(g, batch)) {
+    set_error("workspace too small (samd_ldpc_bp_workspace_bytes_f64)");
+    return SAMD_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  double* msg = reinterpret_cast<double*>(align_up((size_t)workspace, 256));
+  double* llr_t = msg + (size_t)g->num_edges * batch;
+  double* xtot = llr_t + (size_t)g->num_vn * batch;
+  const unsigned gx = (unsigned)((batch + 63) / 64);
+  hipLaunchKernelGGL(prep64_kernel, dim3(gx, ygrid(g->num_vn)), dim3(64), 0, st, llr_in, llr_t, batch, g->num_vn, llr_max);
+  SAMD_HIP_CHECK(hipMemcpyAsync(xtot, llr_t, (size_t)g->num_vn * batch * sizeof(double), hipMemcpyDeviceToDevice, st));
+  const size_t nmsg = (size_t)g->num_edges * batch;
+  if (state_in) hipLaunchKernelGGL(negate64_kernel, dim3((unsigned)((nmsg + 255) / 256)), dim3(256), 0, st, state, msg, nmsg);
+  else SAMD_HIP_CHECK(hipMemsetAsync(msg, 0, nmsg * sizeof(double), st));
+  bool from_state = state_in != 0;
+  const int num_sub = sched ? sched->num_sub : 1;
+  for (int it = 0; it < num_iter; ++it)
+    for (int j = 0; j < num_sub; ++j) {
+      const int32_t* cns = sched ? sched->cn_list + (size_t)j * sched->width : nullptr;
+      const int n_cns = sched ? sched->width : g->num_cn;
+      launch_cn64(cn_mode, dim3(gx, ygrid(n_cns)), st, msg, xtot, g, cns, n_cns, batch, from_state ? 1 : 0, llr_max, offset);
+      if (from_state && sched)
+        hipLaunchKernelGGL(zero_inactive64_kernel, dim3(gx, ygrid(g->num_cn)), dim3(64), 0, st, msg, g->cn_ptr, g->cn_edge,
+                           sched->first_mask, g->num_cn, batch);
+      from_state = false;
+      const int32_t* vns = sched ? sched->vn_list + sched->vn_off[j] : nullptr;
+      const int n_vns = sched ? sched->vn_off[j + 1] - sched->vn_off[j] : g->num_vn;
+      hipLaunchKernelGGL(vn_total64_kernel, dim3(gx, ygrid(n_vns)), dim3(64), 0, st, msg, llr_t, xtot, g->vn_ptr, vns, n_vns, batch);
+    }
+  hipLaunchKernelGGL(finish64_kernel, dim3(gx, ygrid(out_cols)), dim3(64), 0, st, xtot, out, batch, out_cols, hard_out, llr_max);
+  if (state_out && !(num_iter == 0 && state_in))
+    hipLaunchKernelGGL(v2c_state64_kernel, dim3(gx, ygrid(g->num_vn)), dim3(64), 0, st, msg, xtot, g->vn_ptr, state, g->num_vn,
+                       batch, llr_max);
+  return launch_status();
+}
+
+extern "C" int samd_ldpc5g_rate_recover_f64(const samd_ldpc5g_t* h, const double* llr, double* out, int batch, double llr_max,
+                                            void* stream) {
+  SAMD_REQUIRE(h && llr && out && batch > 0, "bad argument");
+  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  hipLaunchKernelGGL(rate_recover64_kernel, dim3((h->n_vn + 255) / 256, ygrid(batch)), dim3(256), 0, (hipStream_t)stream, llr, out,
+                     rm, llr_max, batch);
+  return launch_status();
+}
+
+extern "C" int samd_ldpc5g_extract_codeword_f64(const samd_ldpc5g_t* h, const double* x_hat, double* out, int batch, void* stream) {
+  SAMD_REQUIRE(h && x_hat && out && batch > 0, "bad argument");
+  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  hipLaunchKernelGGL(extract64_kernel, dim3((h->n + 255) / 256, ygrid(batch)), dim3(256), 0, (hipStream_t)stream, x_hat, out, rm,
+                     batch);
+  return launch_status();
+}
+
+extern "C" int samd_qam_demap_f64(const double* y, const double* no, int64_t no_len, const double* points, int m,
+                                  int64_t num_symbols, const double* prior, int64_t prior_len, int method, int hard_out,
+                                  double* out, void* stream) {
+  SAMD_REQUIRE(y && no && points && out, "null argument");
+  SAMD_REQUIRE(num_symbols >= 0 && (no_len == 1 || no_len == num_symbols), "no must be scalar or per symbol");
+  SAMD_REQUIRE(m >= 1 && m <= 10, "num_bits_per_symbol must be in 1..10");
+  SAMD_REQUIRE(method == 0 || method == 1, "method must be 0 (app) or 1 (maxlog)");
+  SAMD_REQUIRE(!prior || prior_len == m || prior_len == num_symbols * m, "prior must be [m] or [num_symbols, m]");
+  if (num_symbols == 0) return SAMD_OK;
+  const int64_t gsz = std::min<int64_t>((num_symbols + 255) / 256, 256 * 32);
+  hipLaunchKernelGGL(demap64_kernel, dim3((unsigned)gsz), dim3(256), 0, (hipStream_t)stream, (const double2*)y, no, no_len,
+                     (const double2*)points, m, num_symbols, prior, prior_len, method, hard_out, out);
+  return launch_status();
+}

@@ -13,7 +13,19 @@ class AWGN(Block):
         super().__init__(precision=precision, **kwargs)
 
     def call(self, x, no):
-        self._require_single()
+        if self.precision == "double":
+            # the unit-variance draws come from the same float32 Philox / Box-Muller stream (the build's own RNG
+            # specification, oracle/utils.py); scaling and addition in float64
+            x = _ffi.to_device(x, torch.complex128)
+            no = _ffi.to_device(no, torch.float64)
+            while 1 < no.numel() and no.dim() < x.dim():
+                no = no.unsqueeze(-1)
+            w = torch.empty(x.shape, dtype=torch.complex64, device=x.device)
+            one = torch.ones(1, dtype=torch.float32, device=x.device)
+            rng = config.rng
+            _ffi.check(_ffi.lib().samd_awgn_c64(_ffi.ptr(torch.zeros_like(w)), _ffi.ptr(one), 1, rng.seed, rng.next_call(),
+                                                w.numel(), _ffi.ptr(w), _ffi.stream()), "AWGN")
+            return x + w.to(torch.complex128) * torch.sqrt(no)
         x = _ffi.to_device(x, torch.complex64)
         no = _ffi.to_device(no, torch.float32)
         if no.numel() == 1:

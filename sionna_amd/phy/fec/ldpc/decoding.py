@@ -216,6 +216,8 @@ class LDPCBPDecoder(Block):
         batch = llr.shape[0]
         if self._custom:
             return self._decode_custom(llr, out_cols, num_iter, msg_v2c, hard)
+        if self.precision == "double":
+            return self._decode_2d_f64(llr, out_cols, num_iter, msg_v2c, hard)
         lib, g = _ffi.lib(), self._graph_handle()
         out = torch.empty((batch, out_cols), dtype=torch.float32, device=llr.device)
         want_state = self._return_state
@@ -255,6 +257,29 @@ class LDPCBPDecoder(Block):
                            "LDPCBPDecoder(scheduled)")
         return out, (state if want_state else None)
 
+    def _decode_2d_f64(self, llr, out_cols, num_iter, msg_v2c, hard):
+        """precision="double": the float64 engine samd_ldpc_bp_decode_f64 (csrc/f64.hip), flooding and schedules."""
+        lib, g = _ffi.lib(), self._graph_handle()
+        sched = self._schedule_handle() if self._scheduling != "flooding" else None
+        batch = llr.shape[0]
+        out = torch.empty((batch, out_cols), dtype=torch.float64, device=llr.device)
+        state = None
+        if msg_v2c is not None:
+            state = _ffi.to_device(msg_v2c, torch.float64)
+            if tuple(state.shape) != (self._num_edges, batch):
+                raise ValueError("msg_v2c must have shape [num_edges, batch_size]")
+            state = state.clone() if self._return_state else state
+        elif self._return_state:
+            state = torch.empty((self._num_edges, batch), dtype=torch.float64, device=llr.device)
+        if batch == 0:
+            return out, state
+        ws, ws_bytes = self._ws.get(lib.samd_ldpc_bp_workspace_bytes_f64(g, batch))
+        _ffi.check(lib.samd_ldpc_bp_decode_f64(g, sched, _ffi.ptr(llr), _ffi.ptr(out), out_cols, _ffi.ptr(state),
+                                               int(msg_v2c is not None), int(self._return_state), batch, int(num_iter),
+                                               self._cn_mode, self._llr_max, self._offset, int(bool(hard)), _ffi.ptr(ws),
+                                               ws_bytes, _ffi.stream()), "LDPCBPDecoder(double)")
+        return out, (state if self._return_state else None)
+
     def _decode_custom(self, llr, out_cols, num_iter, msg_v2c, hard):
         """Custom node updates / message callbacks: the torch engine of custom.py on the device tensors."""
         from . import custom
@@ -265,12 +290,12 @@ class LDPCBPDecoder(Block):
                                                         self._v2c_callbacks, sched)
         state_in = None
         if msg_v2c is not None:
-            state_in = _ffi.to_device(msg_v2c, torch.float32)
+            state_in = _ffi.to_device(msg_v2c, llr.dtype)
             if tuple(state_in.shape) != (self._num_edges, llr.shape[0]):
                 raise ValueError("msg_v2c must have shape [num_edges, batch_size]")
         x_hat, v2c = self._custom_engine.decode(llr, num_iter, self._llr_max, state_in)
         x_hat = x_hat[:, :out_cols]
-        out = (0 >= x_hat).to(torch.float32) if hard else -1.0 * x_hat          # decoding.py:620-626
+        out = (0 >= x_hat).to(llr.dtype) if hard else -1.0 * x_hat              # decoding.py:620-626
         return out.contiguous(), ((-1.0 * v2c).contiguous() if self._return_state else None)
 
     # ------------------------------------------------------------ Block interface
@@ -278,10 +303,9 @@ class LDPCBPDecoder(Block):
         assert input_shape[-1] == self._num_vns, "Last dimension must be of length n."
 
     def call(self, llr_ch, /, *, num_iter=None, msg_v2c=None):
-        self._require_single()
         if num_iter is None:
             num_iter = self._num_iter
-        llr_ch = _ffi.to_device(llr_ch, torch.float32)
+        llr_ch = _ffi.to_device(llr_ch, self.rdtype)            # float32, or float64 for precision="double"
         assert llr_ch.shape[-1] == self._num_vns, "Last dimension must be of length n."
         shape = tuple(llr_ch.shape)
         x, state = self._decode_2d(llr_ch.reshape(-1, self._num_vns), self._num_vns, num_iter, msg_v2c)
@@ -367,11 +391,11 @@ class LDPC5GDecoder(LDPCBPDecoder):
         return out
 
     def call(self, llr_ch, /, *, num_iter=None, msg_v2c=None):
-        self._require_single()
         enc = self._encoder
         if num_iter is None:
             num_iter = self._num_iter
-        llr_ch = _ffi.to_device(llr_ch, torch.float32)
+        double = self.precision == "double"
+        llr_ch = _ffi.to_device(llr_ch, self.rdtype)
         if llr_ch.shape[-1] != enc.n:
             raise ValueError("Last dimension must be of length n.")
         shape = tuple(llr_ch.shape)
@@ -379,7 +403,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
         batch = llr2d.shape[0]
         out_shape = shape[:-1] + ((enc.k,) if self._return_infobits else (enc.n,))
 
-        use_onchip = (self._onchip_ok and not self._custom and self._cn_mode in (0, 1, 2, 3) and not self._return_state
+        use_onchip = (self._onchip_ok and not double and not self._custom and self._cn_mode in (0, 1, 2, 3) and not self._return_state
                       and msg_v2c is None and batch > 0 and self._scheduling == "flooding")
         if use_onchip:
             out = self._try_onchip(llr2d, num_iter)
@@ -388,18 +412,19 @@ class LDPC5GDecoder(LDPCBPDecoder):
 
         # generic engine: rate recovery -> BP -> output mapping (decoding.py:1431-1536)
         h = enc._handle(self._nb_pruned_nodes)
-        llr_5g = torch.empty((batch, self._num_vns), dtype=torch.float32, device=llr2d.device)
+        lib = _ffi.lib()
+        recover = lib.samd_ldpc5g_rate_recover_f64 if double else lib.samd_ldpc5g_rate_recover_f32
+        extract = lib.samd_ldpc5g_extract_codeword_f64 if double else lib.samd_ldpc5g_extract_codeword_f32
+        llr_5g = torch.empty((batch, self._num_vns), dtype=llr2d.dtype, device=llr2d.device)
         if batch > 0:
-            _ffi.check(_ffi.lib().samd_ldpc5g_rate_recover_f32(h, _ffi.ptr(llr2d), _ffi.ptr(llr_5g), batch,
-                                                               self._llr_max, _ffi.stream()), "rate_recover")
+            _ffi.check(recover(h, _ffi.ptr(llr2d), _ffi.ptr(llr_5g), batch, self._llr_max, _ffi.stream()), "rate_recover")
         if self._return_infobits:
             x, state = self._decode_2d(llr_5g, enc.k, num_iter, msg_v2c)
             res = x.reshape(out_shape)
         else:
             x, state = self._decode_2d(llr_5g, self._num_vns, num_iter, msg_v2c)
-            res = torch.empty((batch, enc.n), dtype=torch.float32, device=llr2d.device)
+            res = torch.empty((batch, enc.n), dtype=llr2d.dtype, device=llr2d.device)
             if batch > 0:
-                _ffi.check(_ffi.lib().samd_ldpc5g_extract_codeword_f32(h, _ffi.ptr(x), _ffi.ptr(res), batch,
-                                                                       _ffi.stream()), "extract_codeword")
+                _ffi.check(extract(h, _ffi.ptr(x), _ffi.ptr(res), batch, _ffi.stream()), "extract_codeword")
             res = res.reshape(out_shape)
         return (res, state) if self._return_state else res

@@ -173,8 +173,7 @@ class LDPC5GEncoder(Block):
     def call(self, bits):
         """[..., k] float 0/1 -> [..., n] (encode, drop filler and first 2Z, keep n,
         interleave; encoding.py:599-668)."""
-        self._require_single()
-        bits = _ffi.to_device(bits, torch.float32)
+        bits = _ffi.to_device(bits, torch.float32)          # bits are exact in either precision
         if bits.shape[-1] != self._k:
             raise ValueError("Last dimension must be of length k.")
         lead = tuple(bits.shape[:-1])
@@ -183,4 +182,4 @@ class LDPC5GEncoder(Block):
         if u.shape[0] > 0:
             _ffi.check(_ffi.lib().samd_ldpc5g_encode_f32(self._handle(0), _ffi.ptr(u), _ffi.ptr(out), u.shape[0],
                                                          _ffi.stream()), "LDPC5GEncoder")
-        return out.reshape(lead + (self._n,))
+        return out.reshape(lead + (self._n,)).to(self.rdtype)

@@ -33,3 +33,29 @@ def generate_5g_ranking(k, n, sort=True):
     if sort:
         frozen, info = np.sort(frozen), np.sort(info)
     return [frozen.astype(int), info.astype(int)]
+
+
+def generate_rm_code(r, m):
+    """Reed-Muller code RM(r, m) as a Polar-like code (reference polar/utils.py:148-214): the rows of the Polar
+    transform whose index has Hamming weight < m - r are frozen.  Returns (frozen_pos, info_pos, n, k, d_min)."""
+    if not isinstance(r, int):
+        raise TypeError("r must be int.")
+    if not isinstance(m, int):
+        raise TypeError("m must be int.")
+    if r > m:
+        raise ValueError("order r cannot be larger than m.")
+    if r < 0:
+        raise ValueError("r must be positive.")
+    if m < 0:
+        raise ValueError("m must be positive.")
+    from math import comb
+    n = 1 << m
+    idx = np.arange(n)
+    weight = np.zeros(n, int)
+    for b in range(m):
+        weight += (idx >> b) & 1
+    frozen = weight < m - r
+    k = int(np.sum(~frozen))
+    if k != sum(comb(m, i) for i in range(r + 1)):
+        raise ValueError("Error: resulting k is inconsistent.")
+    return idx[frozen], idx[~frozen], n, k, 1 << (m - r)

@@ -179,11 +179,15 @@ class Constellation(Block):
             self._pam_dev = _ffi.to_device(lev, torch.float32)
         return self._pam_dev
 
-    def device_points(self):
-        """Device copy (complex64) used by the kernels; rebuilt after a setter call."""
+    def device_points(self, double=False):
+        """Device copy (complex64, or complex128 for precision="double") used by the kernels; rebuilt after a
+        setter call."""
+        if double:
+            if getattr(self, "_dev64", None) is None or self._dev is None:
+                self._dev64 = _ffi.to_device(np.asarray(self._host_points(), np.complex128), torch.complex128)
         if self._dev is None:
             self._dev = _ffi.to_device(self._host_points().astype(np.complex64), torch.complex64)
-        return self._dev
+        return self._dev64 if double else self._dev
 
     def __call__(self):
         return self.call()
@@ -216,12 +220,17 @@ class Mapper(Block):
     constellation = property(lambda self: self._constellation)
 
     def call(self, bits):
-        self._require_single()
         m = self._constellation.num_bits_per_symbol
         bits = _ffi.to_device(bits, torch.float32)
         if bits.shape[-1] % m != 0:
             raise ValueError("last dimension must be a multiple of num_bits_per_symbol")
         out_shape = tuple(bits.shape[:-1]) + (bits.shape[-1] // m,)
+        if self.precision == "double":
+            # a table look-up, no arithmetic: the complex128 points are gathered by the symbol index
+            w = (1 << torch.arange(m - 1, -1, -1, device=bits.device)).to(torch.int64)
+            ind = (bits.reshape(out_shape + (m,)).to(torch.int64) * w).sum(-1)
+            x = self._constellation.device_points(double=True)[ind]
+            return (x, ind.to(torch.int32)) if self._return_indices else x
         x = torch.empty(out_shape, dtype=torch.complex64, device=bits.device)
         ns = x.numel()
         _ffi.check(_ffi.lib().samd_qam_map_c64(_ffi.ptr(bits), _ffi.ptr(self._constellation.device_points()),
@@ -252,8 +261,28 @@ class Demapper(Block):
 
     constellation = property(lambda self: self._constellation)
 
+    def _call_double(self, y, no, prior):
+        """precision="double": float64 kernel samd_qam_demap_f64 (csrc/f64.hip)."""
+        m = self._constellation.num_bits_per_symbol
+        y = _ffi.to_device(y, torch.complex128)
+        no = _ffi.to_device(no, torch.float64)
+        no = no.reshape(1) if no.numel() == 1 else torch.broadcast_to(no, y.shape).contiguous()
+        out = torch.empty(tuple(y.shape[:-1]) + (y.shape[-1] * m,), dtype=torch.float64, device=y.device)
+        if prior is not None:
+            prior = _ffi.to_device(prior, torch.float64)
+            if prior.dim() == 1:
+                assert prior.numel() == m, "prior must have num_bits_per_symbol entries"
+            else:
+                prior = torch.broadcast_to(prior, tuple(y.shape) + (m,)).contiguous()
+        _ffi.check(_ffi.lib().samd_qam_demap_f64(
+            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points(double=True)), m, y.numel(),
+            _ffi.ptr(prior), 0 if prior is None else prior.numel(), 0 if self._method == "app" else 1,
+            int(bool(self._hard_out)), _ffi.ptr(out), _ffi.stream()), "Demapper(double)")
+        return out
+
     def call(self, y, no, prior=None):
-        self._require_single()
+        if self.precision == "double":
+            return self._call_double(y, no, prior)
         m = self._constellation.num_bits_per_symbol
         y = _ffi.to_device(y, torch.complex64)
         no = _ffi.to_device(no, torch.float32)
@@ -303,12 +332,11 @@ class BinarySource(Block):
         return v
 
     def call(self, inputs):
-        self._require_single()
         rng = self._rng if self._rng is not None else config.rng
         out = torch.empty(tuple(inputs), dtype=torch.float32, device=_ffi.device())
         _ffi.check(_ffi.lib().samd_binary_source_f32(rng.seed, rng.next_call(), out.numel(), _ffi.ptr(out),
                                                      _ffi.stream()), "BinarySource")
-        return out
+        return out.to(self.rdtype)                     # bits are exact in either precision
 
 
 class SymbolSource(Block):

@@ -1,0 +1,116 @@
+"""precision="double" (reference block.py:25-52): the float64 BP engine and demapper (csrc/f64.hip) against the
+oracle's float64 mode, and a C1-like chain run entirely in double precision."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.ldpc5g import LDPC5GCode
+from oracle import ldpc_bp as obp, mapping as omap
+
+
+@pytest.fixture(scope="module")
+def phy():
+    import sionna_amd.phy as p
+    from sionna_amd import _ffi
+    _ffi.device()
+    return p
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize("cn", ["boxplus-phi", "boxplus", "minsum", "offset-minsum"])
+@pytest.mark.parametrize("sched", ["flooding", "rows"])
+def test_generic_decoder_double_vs_oracle(phy, cn, sched):
+    pcm = phy.fec.utils.load_parity_check_examples(3)[0]                      # (3,6)-regular LDPC, n = 100
+    m, n = pcm.shape
+    schedule = "flooding" if sched == "flooding" else np.arange(m).reshape(-1, 5)
+    rng = np.random.default_rng(1)
+    llr = rng.normal(size=(9, n)) * 3 + 2.0
+    for it in (0, 1, 6):
+        dec = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=cn, hard_out=False, num_iter=it, return_state=True,
+                                         cn_schedule=schedule, precision="double")
+        ref = obp.LDPCBPDecoder(pcm, cn_update=cn, hard_out=False, num_iter=it, return_state=True, cn_schedule=schedule,
+                                precision="double")
+        x, st = dec(llr)
+        xr, sr = ref.decode(llr)
+        assert x.dtype == torch.float64 and st.dtype == torch.float64
+        assert np.allclose(_np(x), xr, rtol=1e-9, atol=1e-9), (cn, it, np.max(np.abs(_np(x) - xr)))
+        assert np.allclose(_np(st), sr, rtol=1e-9, atol=1e-9), (cn, it)
+        x2, st2 = dec(llr, msg_v2c=st)                                        # IDD: continue from the state
+        xr2, sr2 = ref.decode(llr, msg_v2c=sr)
+        assert np.allclose(_np(x2), xr2, rtol=1e-9, atol=1e-9) and np.allclose(_np(st2), sr2, rtol=1e-9, atol=1e-9)
+    hard = _np(phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=cn, num_iter=6, cn_schedule=schedule, precision="double")(llr))
+    sure = np.abs(xr) > 1e-6
+    assert hard.dtype == np.float64 and np.array_equal(hard[sure], (xr > 0).astype(np.float64)[sure])
+
+
+@pytest.mark.parametrize("k,n,m,cn", [(1024, 2048, 2, "boxplus-phi"), (400, 1200, 4, "minsum"), (2816, 8448, 6, "boxplus-phi")])
+def test_5g_decoder_double_vs_oracle(phy, k, n, m, cn):
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, precision="double")
+    code = LDPC5GCode(k, n, m)
+    rng = np.random.default_rng(k)
+    u = rng.integers(0, 2, (6, k)).astype(np.float64)
+    c = enc(u)
+    assert c.dtype == torch.float64 and np.array_equal(_np(c), code.encode(u.astype(np.float32)))
+    llr = (2 * _np(c) - 1) * 2.5 + rng.normal(size=(6, n)) * 1.6
+    for infobits in (True, False):
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, num_iter=8, return_infobits=infobits,
+                                         precision="double")
+        ref = obp.LDPC5GDecoder(code, cn_update=cn, hard_out=False, num_iter=8, return_infobits=infobits, precision="double")
+        got, want = _np(dec(llr)), ref.decode5g(llr)
+        assert got.dtype == np.float64 and got.shape == want.shape
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-8), np.max(np.abs(got - want))
+    # double and single agree to single precision on a well-conditioned input
+    single = _np(phy.fec.ldpc.LDPC5GDecoder(phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m), cn_update="minsum",
+                                            hard_out=False, num_iter=3)(llr.astype(np.float32)))
+    double = _np(phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=3, precision="double")(llr))
+    assert np.allclose(single, double, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("m", [2, 4, 6])
+@pytest.mark.parametrize("method", ["app", "maxlog"])
+def test_demapper_double_vs_oracle(phy, m, method):
+    rng = np.random.default_rng(m)
+    pts = omap.qam(m, dtype=np.complex128)
+    y = pts[rng.integers(0, 2 ** m, (5, 200))] + (rng.normal(size=(5, 200)) + 1j * rng.normal(size=(5, 200))) * 0.3
+    dm = phy.mapping.Demapper(method, "qam", m, precision="double")
+    assert np.allclose(np.asarray(dm.constellation.points), pts, rtol=1e-15)
+    for no in (0.2, rng.uniform(0.01, 100, size=(5, 200))):
+        got = _np(dm(y, no))
+        ref = omap.demapper(y, np.asarray(no, np.float64), pts, method)
+        assert got.dtype == np.float64 and np.allclose(got, ref, rtol=1e-11, atol=1e-10)
+    prior = rng.normal(size=(5, 200, m)) * 2
+    assert np.allclose(_np(dm(y, 0.3, prior)), omap.demapper(y, np.float64(0.3), pts, method, prior=prior), rtol=1e-10, atol=1e-9)
+    hard = _np(phy.mapping.Demapper(method, "qam", m, hard_out=True, precision="double")(y, 0.2))
+    assert set(np.unique(hard)) <= {0.0, 1.0}
+
+
+def test_chain_in_double_precision(phy):
+    """config.precision = "double": source -> encoder -> mapper -> AWGN -> demapper -> decoder all return float64 /
+    complex128 and decode error-free at high SNR."""
+    old = phy.config.precision
+    phy.config.precision = "double"
+    try:
+        phy.config.seed = 3
+        k, n, m = 512, 1024, 4
+        enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m)
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, num_iter=10)
+        u = phy.mapping.BinarySource()([64, k])
+        x = phy.mapping.Mapper("qam", m)(enc(u))
+        no = phy.utils.ebnodb2no(7.0, m, k / n)
+        y = phy.channel.AWGN()(x, no)
+        llr = phy.mapping.Demapper("app", "qam", m)(y, no)
+        u_hat = dec(llr)
+        assert (u.dtype, x.dtype, y.dtype, llr.dtype, u_hat.dtype) == (torch.float64, torch.complex128, torch.complex128,
+                                                                         torch.float64, torch.float64)
+        assert isinstance(no, np.float64)
+        nvar = float((y - x).abs().pow(2).mean())
+        assert abs(nvar - float(no)) < 0.05 * float(no)
+        assert float((u != u_hat).double().mean()) == 0.0
+        assert int(phy.utils.count_errors(u, u_hat)) == 0
+    finally:
+        phy.config.precision = old
