@@ -12,7 +12,7 @@ import re
 import torch  # imported first so that libamdhip64 is resolved once, process-wide
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsionna_amd.so")
+LIB_PATH = os.environ.get("SAMD_LIB") or os.path.join(_HERE, "lib", "libsionna_amd.so")   # SAMD_LIB: development builds
 HEADER_PATH = os.path.join(_HERE, "..", "include", "sionna_amd.h")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4

@@ -363,7 +363,7 @@ extern "C" int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const fl
 
 // min-sum family: explicit messages (ldpc5g_onchip_ms.hip) when they fit in LDS, else the compressed
 // check-node state (ldpc5g_onchip.hip, every 5G code).  SAMD_ONCHIP_COMPRESSED=1 forces the latter.
-static bool use_explicit_minsum(const samd_ldpc5g* h) { return h->bp_ok && !getenv("SAMD_ONCHIP_COMPRESSED"); }
+static bool use_explicit_minsum(const samd_ldpc5g* h) { return h->bp_ok && h->ms_cn_list && h->ms_vn_list && !getenv("SAMD_ONCHIP_COMPRESSED"); }
 // ... or explicit messages with the last base rows' blocks in the L2 workspace row (ldpc5g_onchip_mss.hip)
 // measured (tools/sweep_ldpc.py): up to about a quarter of the edges in L2 this beats the compressed state engine
 // (+16 % at 4 %, +9 % at 26 %, even at 28 %); beyond that the L2 round trips of the VN phase dominate

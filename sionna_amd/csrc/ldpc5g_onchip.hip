@@ -257,6 +257,7 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_v2_kernel(
         // desc: r | chunk<<8 | degree<<16 | fused<<24 | pair<<25  (pair: chunks q and q+1, all lanes valid)
         const int desc = __builtin_amdgcn_readfirstlane(cn_sched[t]);
         const int r = desc & 0xFF;
+        onchip_setprio(desc >> 28);                          // longest remaining work first (ldpc5g.h)
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
         const unsigned cn = (unsigned)r * z + zz;
         const int32_t* ent = row_pad + r * kRowStride;
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_v2_kernel(
         // desc: c | chunk<<8 | nfull<<16 | rem<<20 | pair<<25
         const int desc = __builtin_amdgcn_readfirstlane(vn_sched[t]);
         const int c = desc & 0xFF;
+        onchip_setprio(desc >> 28);
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
         const unsigned vn = (unsigned)c * z + zz;
         const int32_t* ent = col_pad + c * (2 * kColStride);
@@ -414,6 +416,11 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
   const int nw = h->dec_waves;
   lpt_schedule(ci, nw, &cp, &cl);
   lpt_schedule(vi, nw, &vp, &vl);
+  {
+    const std::vector<int> pc = item_priorities(ci, cp, cl), pv = item_priorities(vi, vp, vl);   // bits 28-29, see ldpc5g.h
+    for (size_t j = 0; j < cl.size(); ++j) cl[j] |= pc[j] << 28;
+    for (size_t j = 0; j < vl.size(); ++j) vl[j] |= pv[j] << 28;
+  }
   lpt_schedule(v1i, nw, &v1p, &v1l);
   for (int32_t o : v1p) vp.push_back(o + (int32_t)vl.size());
   vl.insert(vl.end(), v1l.begin(), v1l.end());

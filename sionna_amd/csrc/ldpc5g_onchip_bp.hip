@@ -19,6 +19,8 @@
 // (longest-processing-time first); every item is an instantiation for the row's exact degree / the
 // column's degree class, all table entries are wave-uniform scalars.
 #include "ldpc5g.h"
+
+#include <cmath>
 #include "bp_math.h"
 
 namespace samd {
@@ -123,8 +125,9 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_bp_kernel(
 
     for (int it = 0; it < num_iter; ++it) {
       for (int t = c0; t < c1; ++t) {
-        const int desc = __builtin_amdgcn_readfirstlane(cn_list[t]);  // r | chunk<<8
+        const int desc = __builtin_amdgcn_readfirstlane(cn_list[t]);  // r | chunk<<8 | priority<<24
         const int r = desc & 0xFF;
+        onchip_setprio(desc >> 24);                                   // longest remaining work first (ldpc5g.h)
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
         if (zz < z && (unsigned)r * z + zz < (unsigned)n_cn) {
           const unsigned ro = (unsigned)__builtin_amdgcn_readfirstlane(row_off[r]);
@@ -149,6 +152,7 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_bp_kernel(
       for (int t = v0; t < v1; ++t) {
         const int desc = __builtin_amdgcn_readfirstlane(vn_list[t]);
         const int c = desc & 0xFF;
+        onchip_setprio(desc >> 24);
         const unsigned zz = (unsigned)(((desc >> 8) & 0xFF) * 64 + lane);
         const int vn = c * (int)z + (int)zz;
         if (zz < z && vn < n_vn)
@@ -223,6 +227,11 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::vector<int32_t> cp, cl, vp, vl;
   lpt_schedule(ci, h->bp_waves, &cp, &cl);
   lpt_schedule(vi, h->bp_waves, &vp, &vl);
+  {
+    const std::vector<int> pc = item_priorities(ci, cp, cl), pv = item_priorities(vi, vp, vl);   // see ldpc5g.h
+    for (size_t j = 0; j < cl.size(); ++j) cl[j] |= pc[j] << 24;
+    for (size_t j = 0; j < vl.size(); ++j) vl[j] |= pv[j] << 24;
+  }
   // ldpc5g_onchip_ms.hip: compact per-column edge tables (block byte offset, 4 shift) - a few KB, they stay in the
   // scalar cache - and self-contained two-dword list entries in the same order as the lists above
   std::vector<int32_t> col_ent2, col_start(h->nb, 0), cl2, vl2;
@@ -247,36 +256,51 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // two consecutive fully valid chunks of a row / column (degree <= 12) form one pair item (bit 24);
   // weights ~ instructions: 9 (CN) / 5 (VN) per edge and chunk + ~40 for the item's dispatch
   std::vector<std::pair<int, int32_t>> ci2, vi2, vf2;
+  // development knobs: per-item overhead of the cost model, capacities by wave launch order
+  // (measured at C2 with tools/ms_sweep.py: a fixed cost of ~20 edges per item balances best)
+  const int cn_ovh = getenv("SAMD_MS_CN_OVH") ? atoi(getenv("SAMD_MS_CN_OVH")) : 400;
+  const int vn_ovh = getenv("SAMD_MS_VN_OVH") ? atoi(getenv("SAMD_MS_VN_OVH")) : 200;
   for (int r = 0; r < ncu; ++r)
     for (int q = 0; q < chunks; ++q) {
       const int d = (int)by_row[r].size();                    // chunks of pruned check nodes only still get an item (it zeroes their slots)
       const bool pair = (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn &&
                         (fused_col[r] < 0 || fused_col[r] * z + (q + 2) * 64 <= h->n_vn);
-      if (pair) { ci2.push_back({18 * d + 40, r | (q << 8) | (1 << 24)}); ++q; }
-      else ci2.push_back({9 * d + 40, r | (q << 8)});
+      if (pair) { ci2.push_back({18 * d + cn_ovh, r | (q << 8) | (1 << 24)}); ++q; }
+      else ci2.push_back({9 * d + cn_ovh, r | (q << 8)});
     }
   for (int c = 0; c < nbu; ++c)
     for (int q = 0; q < chunks; ++q) {
       if (c * z + q * 64 >= h->n_vn) continue;
       const bool pair = col_deg[c] <= 12 && (q + 2) * 64 <= z && c * z + (q + 2) * 64 <= h->n_vn;
       auto& dst = col_fused[c] ? vf2 : vi2;
-      if (pair) { dst.push_back({10 * col_deg[c] + 40, c | (q << 8) | (1 << 24)}); ++q; }
-      else dst.push_back({5 * col_deg[c] + 40, c | (q << 8)});
+      if (pair) { dst.push_back({10 * col_deg[c] + vn_ovh, c | (q << 8) | (1 << 24)}); ++q; }
+      else dst.push_back({5 * col_deg[c] + vn_ovh, c | (q << 8)});
     }
   std::vector<int32_t> mcp, mcl, mvp, mvl, mfp, mfl;
-  lpt_schedule(ci2, h->bp_waves, &mcp, &mcl);
-  lpt_schedule(vi2, h->bp_waves, &mvp, &mvl);
+  // wave w runs on SIMD w % 4 as its (w / 4)-th oldest wave: optional capacities by age class (SAMD_MS_CAP="a,b,c,d")
+  std::vector<double> cap(h->bp_waves, 1.0);
+  {
+    double cls[4] = {1.0, 1.0, 1.0, 1.0};
+    if (const char* e = getenv("SAMD_MS_CAP")) sscanf(e, "%lf,%lf,%lf,%lf", &cls[0], &cls[1], &cls[2], &cls[3]);
+    const int per_simd = std::max(1, h->bp_waves / 4);
+    for (int wv = 0; wv < h->bp_waves; ++wv) cap[wv] = cls[std::min(3, (wv / 4) * 4 / per_simd)];
+  }
+  lpt_schedule(ci2, h->bp_waves, &mcp, &mcl, &cap);
+  lpt_schedule(vi2, h->bp_waves, &mvp, &mvl, &cap);
+  const std::vector<int> cprio = item_priorities(ci2, mcp, mcl), vprio = item_priorities(vi2, mvp, mvl);
   lpt_schedule(vf2, h->bp_waves, &mfp, &mfl);
   for (int32_t o : mfp) mvp.push_back(o + (int32_t)mvl.size());
   mvl.insert(mvl.end(), mfl.begin(), mfl.end());
-  for (int32_t d : mcl) {
+  for (size_t j = 0; j < mcl.size(); ++j) {
+    const int32_t d = mcl[j];
     const int r = d & 0xFF, f = fused_col[r] >= 0, pr = (d >> 24) & 1;
     cl2.push_back((row_off[r] & 0x3FFFF) | (((int)by_row[r].size() | (f << 5) | (pr << 6)) << 18));
-    cl2.push_back((d & 0xFFFF) | ((f ? fused_col[r] : 0) << 16));
+    cl2.push_back((d & 0xFFFF) | ((f ? fused_col[r] : 0) << 16) | (cprio[j] << 24));
   }
-  for (int32_t d : mvl) {
+  for (size_t j = 0; j < mvl.size(); ++j) {
+    const int32_t d = mvl[j];
     const int c = d & 0xFF, pr = (d >> 24) & 1;
-    vl2.push_back((d & 0xFFFF) | ((col_deg[c] | (pr << 5)) << 16));
+    vl2.push_back((d & 0xFFFF) | ((col_deg[c] | (pr << 5)) << 16) | ((j < vprio.size() ? vprio[j] : 0) << 24));
     vl2.push_back(col_start[c]);
   }
   cl2.resize(cl2.size() + 2, 0); vl2.resize(vl2.size() + 2, 0);

@@ -96,6 +96,8 @@ __device__ __forceinline__ void ms_cn_row(unsigned a0, unsigned z4, float llr_ma
 // one variable node per lane and chunk, column of exact degree D.  ent[2i] = edge block byte offset,
 // ent[2i+1] = 4 shift; zwv: 4Z-1 (POW2) or 4Z, in a VGPR so that (t & zw) | base is one v_and_or_b32
 // l0 / l1: channel LLRs of the lane's VN in chunk 0 / 1 (fetched by the caller one item ahead)
+typedef float ms_f32x2 __attribute__((ext_vector_type(2)));
+
 template <int D, int NCH, bool POW2, bool INIT>
 __device__ __forceinline__ void ms_vn_col(const int32_t* __restrict__ ent, unsigned zz4, unsigned zwv,
                                           float* __restrict__ llr_v, float l0, float l1, float llr_max, bool last) {
@@ -111,20 +113,34 @@ __device__ __forceinline__ void ms_vn_col(const int32_t* __restrict__ ent, unsig
       const unsigned t = zz4 + 256u * h - (unsigned)ent[2 * i + 1];
       // edge blocks are aligned to 4Z when Z is a power of two: (t mod 4Z) | base
       a[h][i] = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t + zwv) + (unsigned)ent[2 * i]);
-      if (INIT) {
-        lds_st(a[h][i], l[h]);
-      } else {
-        c[h][i] = lds_ld(a[h][i]);
-        x[h] += c[h][i];
-      }
+      if (INIT) lds_st(a[h][i], l[h]);
+      else c[h][i] = lds_ld(a[h][i]);
     }
   if (INIT) return;
+  if constexpr (NCH == 2) {
+    // both chunks of an edge in one packed-fp32 operation (v_pk_add_f32: two IEEE additions per issue slot, the
+    // same results as two v_add_f32): x += c and x - c cost one VALU operation per edge instead of two
+    ms_f32x2 xv = {0.f, 0.f};
 #pragma unroll
-  for (int h = 0; h < NCH; ++h) {
-    x[h] += l[h];
+    for (int i = 0; i < D; ++i) xv += ms_f32x2{c[0][i], c[1][i]};
+    xv += ms_f32x2{l[0], l[1]};
 #pragma unroll
-    for (int i = 0; i < D; ++i) lds_st(a[h][i], ms_med3(x[h] - c[h][i], -llr_max, llr_max));
-    if (last) llr_v[64 * h] = x[h];
+    for (int i = 0; i < D; ++i) {
+      const ms_f32x2 e = xv - ms_f32x2{c[0][i], c[1][i]};
+      lds_st(a[0][i], ms_med3(e.x, -llr_max, llr_max));
+      lds_st(a[1][i], ms_med3(e.y, -llr_max, llr_max));
+    }
+    if (last) { llr_v[0] = xv.x; llr_v[64] = xv.y; }
+  } else {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) x[h] += c[h][i];
+      x[h] += l[h];
+#pragma unroll
+      for (int i = 0; i < D; ++i) lds_st(a[h][i], ms_med3(x[h] - c[h][i], -llr_max, llr_max));
+      if (last) llr_v[64 * h] = x[h];
+    }
   }
 }
 
@@ -153,6 +169,17 @@ __device__ __forceinline__ void ms_vn_item(const int32_t* __restrict__ ent, int 
 //             CN (row block byte offset | degree<<18 | fused<<23 | pair<<24,  r | chunk<<8 | fused column<<16)
 // a pair item covers chunks (chunk, chunk+1), all 128 lanes valid; VN degree field = degree | pair<<5
 // vn_ptr = [NW+1 offsets of the per-iteration lists | NW+1 offsets of the fused degree-1 columns (init only)]
+#ifdef SAMD_MS_TRACE
+// Development aid (tools/ms_trace.py; not part of the product build): per-wave timestamps of workgroup 0 at the phase
+// boundaries of iterations 2..5 -> where the time of an iteration goes (CN items, barrier wait, VN items, barrier wait).
+__device__ unsigned long long* g_ms_trace = nullptr;
+#define SAMD_TRACE_MARK(slot)                                                                               \
+  if (g_ms_trace && blockIdx.x == 0 && it >= 2 && it < 6 && lane == 0)                                        \
+    g_ms_trace[((it - 2) * 5 + (slot)) * NW + w] = __builtin_readcyclecounter();
+#else
+#define SAMD_TRACE_MARK(slot)
+#endif
+
 template <bool POW2, int NW, bool LLRG>
 __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ llr_ws, RateMatch p, int n_cn,
@@ -192,13 +219,14 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
         const int vn = c * (int)z + (int)zz;
         const bool pr = (d0 >> 21) & 1;
         if (pr || (zz < z && vn < n_vn))
-          ms_vn_item<POW2, true>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, llr[vn], pr ? llr[vn + 64] : 0.f, llr_max, false);
+          ms_vn_item<POW2, true>(col_ent + d1, (d0 >> 16) & 63, 4u * zz, zwv, llr + vn, llr[vn], pr ? llr[vn + 64] : 0.f, llr_max, false);
       }
     }
     __syncthreads();
 
     for (int it = 0; it < num_iter; ++it) {
       const bool last = (it == num_iter - 1);
+      SAMD_TRACE_MARK(0)
       // vn_fetch: descriptor and channel LLRs of this wave's first VN item, in flight during the CN phase
       int2 vfirst = make_int2(0, 0);
       float lf0 = 0.f, lf1 = 0.f;
@@ -217,10 +245,11 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
           const int d1 = __builtin_amdgcn_readfirstlane(nxt.y);
           if (t + 1 < c1) nxt = cn_list[t + 1];
           const int r = d1 & 0xFF;
+          onchip_setprio(d1 >> 24);
           const unsigned zz = (unsigned)(((d1 >> 8) & 0xFF) * 64 + lane);
           const unsigned a0 = (ro & 0x3FFFFu) + 4u * zz;
           if (((ro >> 24) & 1u) || (zz < z && (unsigned)r * z + zz < (unsigned)n_cn)) {
-            float* lv = llr + (d1 >> 16) * (int)z + (int)zz;          // channel LLR of the fused degree-1 VN
+            float* lv = llr + ((d1 >> 16) & 0xFF) * (int)z + (int)zz;   // channel LLR of the fused degree-1 VN
 #define SAMD_MS_CN(D) case D: ms_cn_row<D, 1, false>(a0, z4, llr_max, offset, lv, last); break
 #define SAMD_MS_CNF(D) case 32 + D: ms_cn_row<D, 1, true>(a0, z4, llr_max, offset, lv, last); break
 #define SAMD_MS_CN2(D) case 64 + D: ms_cn_row<D, 2, false>(a0, z4, llr_max, offset, lv, last); break
@@ -246,7 +275,9 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
           }
         }
       }
+      SAMD_TRACE_MARK(1)
       __syncthreads();
+      SAMD_TRACE_MARK(2)
       {
         // the channel LLRs of an item are fetched one item ahead (the first item's before the CN phase, see
         // vn_fetch above): an L2 round trip is longer than a whole VN item
@@ -267,12 +298,15 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
           const int c = d0 & 0xFF;
           const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
           const int vn = c * (int)z + (int)zz;
+          onchip_setprio(d0 >> 24);
           if (((d0 >> 21) & 1) || (zz < z && vn < n_vn))
-            ms_vn_item<POW2, false>(col_ent + d1, d0 >> 16, 4u * zz, zwv, llr + vn, l0, l1, llr_max, last);
+            ms_vn_item<POW2, false>(col_ent + d1, (d0 >> 16) & 63, 4u * zz, zwv, llr + vn, l0, l1, llr_max, last);
           cur = nxt; l0 = n0; l1 = n1;
         }
       }
+      SAMD_TRACE_MARK(3)
       __syncthreads();
+      SAMD_TRACE_MARK(4)
     }
     // ---------------- output (decoding.py:620-626, 1486-1531); llr[] now holds the marginals
     if (return_infobits) {
@@ -291,6 +325,14 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
     __syncthreads();
   }
 }
+
+#ifdef SAMD_MS_TRACE
+}  // namespace samd
+extern "C" int samd_debug_set_ms_trace(unsigned long long* p) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(samd::g_ms_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+namespace samd {
+#endif
 
 int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace,

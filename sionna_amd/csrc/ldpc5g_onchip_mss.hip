@@ -251,6 +251,7 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_mss_kernel(
           const int d1 = __builtin_amdgcn_readfirstlane(nxt.y);
           if (t + 1 < c1) nxt = cn_list[t + 1];
           const int r = d1 & 0xFF;
+          onchip_setprio(d1 >> 27);
           const unsigned zz = (unsigned)(((d1 >> 8) & 7) * 64 + lane);
           const unsigned a0 = ro + 4u * zz;
           const int deg = (d1 >> 19) & 31;
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_mss_kernel(
           const int c = d0 & 0xFF;
           const unsigned zz = (unsigned)(((d0 >> 8) & 0xFF) * 64 + lane);
           const int vn = c * (int)z + (int)zz;
+          onchip_setprio(d0 >> 27);
           if (((d0 >> 21) & 1) || (zz < z && vn < n_vn))
             mss_vn_item<POW2, false>(col_ent + d1, (d0 >> 16) & 63, (d0 >> 22) & 31, 4u * zz, zwv, gbase, llr + vn, l0, l1,
                                      llr_max, last);
@@ -402,17 +404,21 @@ int build_onchip_mss_tables(samd_ldpc5g* h, const std::vector<std::vector<std::p
   lpt_schedule(ci, 16, &cp, &cls);
   lpt_schedule(vi, 16, &vp, &vls);
   lpt_schedule(vf, 16, &fp, &fls);
+  const std::vector<int> cprio = item_priorities(ci, cp, cls), vprio = item_priorities(vi, vp, vls);   // see ldpc5g.h
   for (int32_t o : fp) vp.push_back(o + (int32_t)vls.size());
   vls.insert(vls.end(), fls.begin(), fls.end());
-  for (int32_t d : cls) {
+  for (size_t j = 0; j < cls.size(); ++j) {
+    const int32_t d = cls[j];
     const int r = d & 0xFF, q = (d >> 8) & 7, f = fused_col[r] >= 0, pr = (d >> 24) & 1, g = r >= lds_rows;
     cl2.push_back(row_off[r]);
     cl2.push_back(r | (q << 8) | ((f ? fused_col[r] : 0) << 11) | ((int)by_row[r].size() << 19) | (f << 24) | (pr << 25) |
-                  (g << 26));
+                  (g << 26) | (cprio[j] << 27));
   }
-  for (int32_t d : vls) {
+  for (size_t j = 0; j < vls.size(); ++j) {
+    const int32_t d = vls[j];
     const int c = d & 0xFF, pr = (d >> 24) & 1;
-    vl2.push_back((d & 0xFFFF) | ((int)cl[c].size() << 16) | (pr << 21) | ((int)cg[c].size() << 22));
+    vl2.push_back((d & 0xFFFF) | ((int)cl[c].size() << 16) | (pr << 21) | ((int)cg[c].size() << 22) |
+                  ((j < vprio.size() ? vprio[j] : 0) << 27));
     vl2.push_back(col_start[c]);
   }
   cl2.resize(cl2.size() + 2, 0); vl2.resize(vl2.size() + 2, 0);

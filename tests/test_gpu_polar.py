@@ -106,11 +106,13 @@ def test_scl_vs_oracle(phy, n, k, L, crc, fast):
     assert np.mean(np.all(_np(got) == ref2, axis=1)) >= 0.9
 
 
-def test_c5_scl8_bit_exact_at_scale(phy):
+@pytest.mark.parametrize("ebno,B", [(2.5, 4096), (1.0, 2048)])
+def test_c5_scl8_bit_exact_at_scale(phy, ebno, B):
     """BASELINE config 5 (Polar5G uplink k=512 -> n_polar=1024 with CRC11: 523 information positions, SCL-8, QPSK
-    over AWGN at 2.5 dB): 4096 codewords through the GPU chain; decoded bits and CRC status equal the C oracle's on
+    over AWGN): 4096 codewords at the bench's 2.5 dB (practically error free) and 2048 at 1.0 dB (in the waterfall,
+    where list decisions are contested) through the GPU chain; decoded bits and CRC status equal the C oracle's on
     the same LLRs, bit for bit."""
-    k, n, m, B, ebno = 512, 1024, 2, 4096, 2.5
+    k, n, m = 512, 1024, 2
     enc = phy.fec.polar.Polar5GEncoder(k, n)
     dec = phy.fec.polar.Polar5GDecoder(enc, "SCL", list_size=8, return_crc_status=True)
     phy.config.seed = 55
@@ -122,7 +124,10 @@ def test_c5_scl8_bit_exact_at_scale(phy):
     assert np.array_equal(_np(u_hat), ref), f"{(~np.all(_np(u_hat) == ref, axis=1)).sum()} of {B} codewords differ"
     assert np.array_equal(_np(status).astype(bool), ref_status)
     bler = np.mean(np.any(_np(u_hat) != _np(u), axis=1))
-    assert 0.0 < bler < 0.5, bler                  # the waterfall region: both outcomes occur in the batch
+    if ebno < 2.0:
+        assert 0.0 < bler < 0.9, bler              # both outcomes occur in the batch
+    else:
+        assert bler < 0.01, bler
 
 
 # random (k, n, channel) draws over the 5G ranges: puncturing, shortening and repetition, with and without the
