@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""rocprofv3 --pmc output (tools/gpu_pmc.sh) -> profiles/counters.json: per-UNIT counters of the dominant kernels, which
+bench.py combines with the launch duration it measures live (roofline.achieved = instructions per unit x units / time).
+
+    python tools/pmc_counters.py gpurun_out/pmc_<tag> --tag <tag> ldpc5g_ms=65536 ldpc5g_bp=65536 polar_scl=32768 ofdm_lmmse=6291456
+
+An argument key=N says how many units (decodes, resource elements) one launch of that kernel processed in the profiled
+command.  HBM bytes follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE is in KB and counts wide coalesced reads at half
+their size on gfx950 -> 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024.  `source_sha16` lets bench.py flag counters that are
+older than the kernel source."""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = {   # key -> (substring of the kernel name, unit, source file)
+    "ldpc5g_ms": ("ldpc5g_decode_ms_kernel", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
+    "ldpc5g_bp": ("ldpc5g_decode_bp_kernel", "decode", "sionna_amd/csrc/ldpc5g_onchip_bp.hip"),
+    "polar_scl": ("polar_scl_kernel", "decode", "sionna_amd/csrc/polar.hip"),
+    "ofdm_lmmse": ("ofdm_lmmse_diag_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
+}
+
+
+def per_kernel_means(root):
+    acc = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            per_dispatch = defaultdict(dict)
+            for row in csv.DictReader(fh):
+                per_dispatch[(row.get("Dispatch_Id"), row.get("Kernel_Name", ""))][row["Counter_Name"]] = float(row["Counter_Value"])
+            for (_, k), d in per_dispatch.items():
+                for c, v in d.items():
+                    acc[k][c].append(v)
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+
+
+def main():
+    root = sys.argv[1]
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else os.path.basename(root.rstrip("/"))
+    units = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[2:] if "=" in a}
+    means = per_kernel_means(root)
+    out = {"_comment": "per-unit PMC counters of the dominant kernels (tools/pmc_counters.py); bench.py multiplies them by the "
+                       "units of a launch and divides by the launch time it measures", "tag": tag, "kernels": {}}
+    for key, (sub, unit, src) in KERNELS.items():
+        if key not in units:
+            continue
+        match = [k for k in means if sub in k]
+        if not match:
+            print(f"no kernel matching {sub}", file=sys.stderr)
+            continue
+        m = defaultdict(float)
+        for k in match:                      # template variants of one kernel: the one that ran
+            for c, v in means[k].items():
+                m[c] = max(m[c], v)
+        n = units[key]
+        with open(os.path.join(ROOT, src), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        rec = {"kernel": match[0].split("(")[0], "unit": unit, "units_per_launch": n, "from": f"profiles/{tag}_pmc/summary.txt",
+               "source": src, "source_sha16": sha,
+               "valu_insts_per_unit": round(m["SQ_INSTS_VALU"] / n, 2), "salu_insts_per_unit": round(m["SQ_INSTS_SALU"] / n, 2),
+               "lds_insts_per_unit": round(m["SQ_INSTS_LDS"] / n, 2), "lds_array_cycles_per_unit": round(m["SQ_LDS_IDX_ACTIVE"] / n, 2),
+               "lds_bank_conflict_cycles_per_unit": round(m["SQ_LDS_BANK_CONFLICT"] / n, 3),
+               "wave_quad_cycles_per_unit": round(m["SQ_WAVE_CYCLES"] / n, 1), "wait_any_quad_cycles_per_unit": round(m["SQ_WAIT_ANY"] / n, 1),
+               "hbm_bytes_per_unit": round((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024 / n, 2),
+               "fetch_size_kb_per_launch": m["FETCH_SIZE"], "write_size_kb_per_launch": m["WRITE_SIZE"]}
+        out["kernels"][key] = rec
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()

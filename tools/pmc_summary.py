@@ -20,7 +20,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
                 acc[k][c].append(v)
 print(f"# mean PMC value per dispatch, from {root}")
 for k in sorted(acc, key=lambda k: -sum(len(v) for v in acc[k].values())):
-    if not any(s in k for s in ("ldpc", "cn_pass", "vn_pass", "demap", "polar_scl", "lmmse")):
+    if not any(s in k for s in ("ldpc", "cn_pass", "vn_pass", "demap", "polar_scl", "lmmse", "tdl", "cir_to")):
         continue
     print(k)
     for c in sorted(acc[k]):
