@@ -256,7 +256,7 @@ def bench_c4(args, short=False):
                              num_guard_carriers=[5, 6], dc_null=True, pilot_pattern="kronecker",
                              pilot_ofdm_symbol_indices=[2, 11])
         osm = o.StreamManagement([[1]], 2)
-        ns = 128 if short else 512
+        ns = min(B, 2048 if short else 8192)
         yc, hc, evc = y[:ns].cpu().numpy(), h_hat[:ns].cpu().numpy(), ev.cpu().numpy()
         t0 = time.perf_counter()
         xo, _ = of32.ofdm_equalize(org, osm, yc, hc, evc, np.float32(float(no)))
@@ -310,8 +310,8 @@ def bench_c5(args, short=False):
     if not args.no_cpu_baseline:
         from oracle import polar as op, polar_c as pc
         code = op.Polar5GCode(k, n)
-        cores = int(os.cpu_count() or 1)
-        ns = min(B, (16 if short else 48) * cores)
+        cores = pc.num_threads()
+        ns = min(B, (32 if short else 96) * cores)
         sample = llr[:ns].cpu().numpy()
         t0 = time.perf_counter()
         ref = pc.polar5g_decode(code, sample, 8)

@@ -33,6 +33,12 @@ def lib():
     return _lib
 
 
+def num_threads():
+    fn = lib().oracle_polar_num_threads
+    fn.restype = C.c_int
+    return int(fn())
+
+
 def scl_list_decode(logits, frozen_pos, n, list_size, use_fast_scl=True, precision="f32", nthreads=0):
     """logits [B, n] float32 -> (uhat_list uint8 [B, 2L, n] in final sorted order, pm float64 [B, 2L])."""
     logits = np.ascontiguousarray(logits, F).reshape(-1, n)

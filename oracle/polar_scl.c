@@ -157,6 +157,14 @@ int oracle_polar_sc_decode(int n, const int32_t* frozen, const float* logits, in
   return 0;
 }
 
+int oracle_polar_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
 /* logits [B][n] -> uhat_list [B][2L][n], pm [B][2L].  Returns 0, or -1 for bad arguments. */
 int oracle_polar_scl_decode(int n, int list_size, const int32_t* frozen, int use_fast_scl, int precision,
                             const float* logits, int batch, uint8_t* uhat_list, double* pm, int nthreads) {
