@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """BER / BLER versus Eb/N0 of config C2 (BG1 k=2816 n=8448, 64-QAM, AWGN, flooding BP
-20 iterations) on the GPU through ``sim_ber``, for the north-star min-sum rule (on-chip engine) and the
-reference's default boxplus-phi rule (HBM-resident engine), plus the oracle cross-check: at every
-SNR point the CPU oracle (oracle/ldpc_bp.c, min-sum) decodes a sample of the SAME device LLRs and
-must agree bit for bit.  Test / evidence tooling (uses oracle/); writes one JSON file.
+20 iterations) on the GPU through ``sim_ber``, for the north-star min-sum rule, offset-min-sum and the
+reference's default boxplus-phi rule (all on their on-chip engines), plus the oracle cross-check: at every
+SNR point the CPU oracle (oracle/ldpc_bp.c) decodes a sample of the SAME device LLRs with the same rule -
+min-sum must agree bit for bit, boxplus-phi states its share of identical hard decisions - and the Eb/N0 gap
+between the rules at BLER 0.1 / 0.01 (log-linear interpolation).  Test / evidence tooling (uses oracle/).
 
-    python tools/ber_curve.py --out profiles/r01_ber_c2.json
+    python tools/ber_curve.py --out profiles/r02_ber_c2.json
 """
 import argparse
 import json
@@ -38,10 +39,10 @@ def main():
     src, mapper = phy.mapping.BinarySource(), phy.mapping.Mapper("qam", m)
     demap, chan = phy.mapping.Demapper("app", "qam", m), phy.channel.AWGN()
     code = LDPC5GCode(k, n, m, "bg1")
-    ebnos = [float(x) for x in np.arange(2.0, 5.01, 0.5)]
+    ebnos = [2.0, 3.0] + [float(x) for x in np.arange(3.5, 5.51, 0.25)]
     res = {"config": "C2: LDPC5G BG1 k=2816 n=8448 (num_bits_per_symbol=6), 64-QAM, AWGN, flooding BP 20 iterations",
            "batch_size": args.batch, "max_mc_iter": args.max_mc_iter, "ebno_db": ebnos, "rules": {}}
-    for cn in ("minsum", "boxplus-phi"):
+    for cn in ("minsum", "offset-minsum", "boxplus-phi"):
         dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=20)
         last = {}
 
@@ -60,18 +61,29 @@ def main():
             r_ber, r_bler = phy.utils.sim_ber(mc, [e], args.batch, args.max_mc_iter, num_target_block_errors=2000,
                                               verbose=False)
             ber.append(float(r_ber[0])); bler.append(float(r_bler[0]))
-            if cn == "minsum":
-                s = args.oracle_sample
-                llr = last["llr"][:s].cpu().numpy()
-                odec = obp.LDPC5GDecoder(code, cn_update="minsum", hard_out=True, num_iter=20)
-                ref = cbind.bp_decode(odec, odec.rate_recover(llr))[:, :k]
-                checks.append(bool(np.array_equal(ref, last["b_hat"][:s].cpu().numpy())))
+            s = args.oracle_sample
+            llr = last["llr"][:s].cpu().numpy()
+            odec = obp.LDPC5GDecoder(code, cn_update=cn, hard_out=True, num_iter=20)
+            ref = cbind.bp_decode(odec, odec.rate_recover(llr))[:, :k]
+            got = last["b_hat"][:s].cpu().numpy()
+            checks.append(bool(np.array_equal(ref, got)) if cn != "boxplus-phi" else float(np.mean(ref == got)))
         torch.cuda.synchronize()
-        res["rules"][cn] = {"engine": "on-chip" if (dec._onchip_ok and dec._cn_mode in (2, 3)) else "generic-hbm",
-                            "ber": ber, "bler": bler, "seconds": round(time.time() - t0, 1)}
-        if cn == "minsum":
-            res["rules"][cn]["oracle_bit_exact_on_sample"] = checks
-            res["rules"][cn]["oracle_sample_codewords_per_point"] = args.oracle_sample
+        res["rules"][cn] = {"engine": "on-chip" if dec._onchip_ok else "generic-hbm",
+                            "ber": ber, "bler": bler, "seconds": round(time.time() - t0, 1),
+                            ("oracle_hard_decisions_equal_on_sample" if cn == "boxplus-phi" else "oracle_bit_exact_on_sample"): checks,
+                            "oracle_sample_codewords_per_point": args.oracle_sample}
+
+    def ebno_at(bler, target):                           # log-linear interpolation of the waterfall
+        pts = [(e, b) for e, b in zip(ebnos, bler) if b > 0]
+        for (e0, b0), (e1, b1) in zip(pts, pts[1:]):
+            if b0 >= target >= b1 and b0 != b1:
+                return e0 + (e1 - e0) * (np.log10(b0) - np.log10(target)) / (np.log10(b0) - np.log10(b1))
+        return None
+    res["ebno_db_at_bler"] = {cn: {str(t): (None if ebno_at(r["bler"], t) is None else round(float(ebno_at(r["bler"], t)), 3))
+                                   for t in (0.1, 0.01)} for cn, r in res["rules"].items()}
+    ref_rule = res["ebno_db_at_bler"]["boxplus-phi"]
+    res["gap_db_to_boxplus_phi"] = {cn: {t: (None if v[t] is None or ref_rule[t] is None else round(v[t] - ref_rule[t], 3)) for t in v}
+                                    for cn, v in res["ebno_db_at_bler"].items() if cn != "boxplus-phi"}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
