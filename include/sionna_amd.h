@@ -166,6 +166,13 @@ int samd_qam_demap_f32(const float* y, const float* no, int64_t no_len, const fl
                        int m, int64_t num_symbols, int method, int hard_out, float* out,
                        void* stream);
 
+/* SymbolDemapper.call  mapping.py:693-792: out [num_symbols, 2^m] = log_softmax over the constellation
+ * points of -|y - c|^2 / no (+ prior log-probabilities, [2^m] or [num_symbols, 2^m], or NULL); with hard_out
+ * instead out_idx [num_symbols] int32 = index of the most likely point (first maximum). */
+int samd_symbol_demap_f32(const float* y, const float* no, int64_t no_len, const float* points, int m,
+                          int64_t num_symbols, const float* prior, int64_t prior_len, int hard_out,
+                          float* out, int32_t* out_idx, void* stream);
+
 /* Demapper.call with prior knowledge on the bits (mapping.py:664-691, 927-967): as samd_qam_demap_f32 with
  * the a-priori term sum_i log_sigmoid(+-prior_i) added to the exponent of every point.  prior DEVICE
  * float LLRs, [m] (shared by all symbols) or [num_symbols, m]. */
@@ -407,6 +414,12 @@ int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const float* err_var
                         int num_undesired, int num_ofdm_symbols, int num_eff_subcarriers,
                         int fft_size, int num_data, int whiten, float* x_hat, float* no_eff,
                         void* stream);
+
+/* TDL spatial correlation  channel/tr38901/tdl.py:474-492: out[b, i, q] = sum_j mat[i][j] a[b, j, q] over the
+ * num_rx_ant * num_tx_ant antenna pairs (rx major); a / out [batch, num_rx_ant * num_tx_ant, inner] complex64
+ * (inner = num_paths * num_time_steps), mat [n, n] complex64 DEVICE (square root of the correlation matrix). */
+int samd_spatial_corr_c64(const float* a, const float* mat, int batch, int num_rx_ant, int num_tx_ant,
+                          int64_t inner, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * precision = "double" (reference block.py:25-52): float64 variants of the blocks whose

@@ -99,3 +99,20 @@ def demapper(y, no, points, method="app", hard_out=False, prior=None):
     if hard_out:
         return (llr > 0).astype(rdtype)
     return llr
+
+
+def symbol_demapper(y, no, points, prior=None, hard_out=False):
+    """SymbolDemapper.call (mapping.py:776-792) in float64: log_softmax over the points of -|y - c|^2 / no (+ prior), or
+    the index of the most likely point."""
+    y = np.asarray(y, np.complex128)
+    d = np.abs(y[..., None] - np.asarray(points, np.complex128))
+    no = np.asarray(no, np.float64)
+    if no.ndim > 0:
+        no = np.broadcast_to(no, y.shape)[..., None]
+    e = -d ** 2 / no
+    if prior is not None:
+        e = e + np.asarray(prior, np.float64)
+    if hard_out:
+        return np.argmax(e, axis=-1).astype(np.int32)
+    mx = np.max(e, axis=-1, keepdims=True)
+    return e - (mx + np.log(np.sum(np.exp(e - mx), axis=-1, keepdims=True)))

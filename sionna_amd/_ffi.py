@@ -51,6 +51,7 @@ _SIGNATURES = {
     "samd_qam_map_c64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "samd_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "samd_qam_demap_prior_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_symbol_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "samd_square_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "samd_binary_source_f32": (_i32, [_u64, _u64, _i64, _vp, _vp]),
     "samd_awgn_c64": (_i32, [_vp, _vp, _i64, _u64, _u64, _i64, _vp, _vp]),
@@ -58,6 +59,7 @@ _SIGNATURES = {
     "samd_gather3": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_tdl_cir_c64": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _f32, _f32, _i32, _f32,
                                 _f32, _vp, _vp]),
+    "samd_spatial_corr_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "samd_cdl_workspace_bytes": (_sz, [_i32, _i32]),
     "samd_cdl_cir_c64": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _f32, _f32, _f32, _f32, _vp, _sz, _vp, _vp]),

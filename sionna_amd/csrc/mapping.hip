@@ -175,6 +175,41 @@ __global__ __launch_bounds__(256) void demap_square_qam_kernel(const float2* __r
   }
 }
 
+// SymbolDemapper.call (mapping.py:693-792): normalised log-probabilities (log-softmax) of the constellation points
+// for every received symbol, or the index of the most likely point.  One lane per symbol, points in LDS, two passes
+// over the points (maximum, then sum of exponentials); prior: log-probabilities [P] or [num_symbols, P].
+__global__ __launch_bounds__(256) void symbol_demap_kernel(const float2* __restrict__ y, const float* __restrict__ no,
+                                                           int64_t no_len, const float2* __restrict__ points, int P,
+                                                           int64_t num_symbols, const float* __restrict__ prior,
+                                                           int64_t prior_len, int hard_out, float* __restrict__ out,
+                                                           int32_t* __restrict__ out_idx) {
+  extern __shared__ float2 lut_dyn[];
+  for (int i = threadIdx.x; i < P; i += blockDim.x) lut_dyn[i] = points[i];
+  __syncthreads();
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < num_symbols; s += (int64_t)gridDim.x * blockDim.x) {
+    const float2 ys = y[s];
+    const float n0 = no_len == 1 ? no[0] : no[s];
+    const float* pr = prior ? (prior_len == P ? prior : prior + s * P) : nullptr;
+    auto expo = [&](int c) -> float {
+      const float dr = ys.x - lut_dyn[c].x, di = ys.y - lut_dyn[c].y;
+      const float d = sqrtf(dr * dr + di * di);                // tf.abs(y - points), then d**2 (mapping.py:780-783)
+      const float e = -(d * d) / n0;
+      return pr ? e + pr[c] : e;
+    };
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int c = 0; c < P; ++c) {
+      const float e = expo(c);
+      if (e > mx) { mx = e; arg = c; }                          // first maximum, like tf.argmax
+    }
+    if (hard_out) { out_idx[s] = arg; continue; }
+    float sum = 0.f;
+    for (int c = 0; c < P; ++c) sum += expf(expo(c) - mx);
+    const float lse = mx + logf(sum);
+    for (int c = 0; c < P; ++c) out[s * P + c] = expo(c) - lse;
+  }
+}
+
 template <bool MAXLOG>
 static int launch_demap(int m, dim3 grid, hipStream_t st, const float2* y, const float* no, int64_t no_len,
                         const float2* pts, int64_t ns, int hard, float* out, const float* prior = nullptr,
@@ -255,5 +290,20 @@ extern "C" int samd_qam_demap_prior_f32(const float* y, const float* no, int64_t
                        : launch_demap<false>(m, grid, (hipStream_t)stream, (const float2*)y, no, no_len, (const float2*)points,
                                              num_symbols, hard_out, out, prior, prior_len);
   if (rc != SAMD_OK) return rc;
+  return launch_status();
+}
+
+extern "C" int samd_symbol_demap_f32(const float* y, const float* no, int64_t no_len, const float* points, int m,
+                                     int64_t num_symbols, const float* prior, int64_t prior_len, int hard_out, float* out,
+                                     int32_t* out_idx, void* stream) {
+  SAMD_REQUIRE(y && no && points, "null argument");
+  SAMD_REQUIRE(hard_out ? out_idx != nullptr : out != nullptr, "output buffer missing");
+  SAMD_REQUIRE(m >= 1 && m <= 10, "num_bits_per_symbol must be in 1..10");
+  SAMD_REQUIRE(num_symbols >= 0 && (no_len == 1 || no_len == num_symbols), "no must be scalar or per symbol");
+  const int P = 1 << m;
+  SAMD_REQUIRE(!prior || prior_len == P || prior_len == num_symbols * P, "prior must be [2^m] or [num_symbols, 2^m]");
+  if (num_symbols == 0) return SAMD_OK;
+  hipLaunchKernelGGL(symbol_demap_kernel, dim3(grid_for(num_symbols, 256)), dim3(256), sizeof(float2) * P, (hipStream_t)stream,
+                     (const float2*)y, no, no_len, (const float2*)points, P, num_symbols, prior, prior_len, hard_out, out, out_idx);
   return launch_status();
 }

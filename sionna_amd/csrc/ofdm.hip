@@ -233,6 +233,30 @@ __global__ __launch_bounds__(256) void ls_gather_scale_kernel(const float2* __re
   }
 }
 
+// TDL spatial correlation (channel/tr38901/tdl.py:474-492): for every (batch, path, time step) the vector of the
+// num_rx_ant x num_tx_ant antenna-pair coefficients (rx major) is multiplied by the square root of the spatial
+// correlation matrix, out[i] = sum_j mat[i][j] a[j] (Kronecker case: mat = sqrt(R_rx) (x) conj(sqrt(R_tx)), built on the
+// host).  a / out [B, 1, RA, 1, TA, inner] with inner = num_paths * num_time_steps; one lane per output element,
+// consecutive lanes are consecutive inner positions (coalesced); ascending-j accumulation.
+__global__ __launch_bounds__(256) void spatial_corr_kernel(const float2* __restrict__ a, const float2* __restrict__ mat, int batch,
+                                                           int ra, int ta, int64_t inner, float2* __restrict__ out) {
+  const int n = ra * ta;
+  const int64_t total = (int64_t)batch * n * inner;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t q = idx % inner;
+    const int i = (int)((idx / inner) % n);
+    const int64_t b = idx / (inner * n);
+    const float2* src = a + b * n * inner + q;
+    float re = 0.f, im = 0.f;
+    for (int j = 0; j < n; ++j) {
+      const float2 m = mat[i * n + j], v = src[(int64_t)j * inner];
+      re += m.x * v.x - m.y * v.y;
+      im += m.x * v.y + m.y * v.x;
+    }
+    out[idx] = make_float2(re, im);
+  }
+}
+
 }  // namespace samd
 
 using namespace samd;
@@ -278,6 +302,16 @@ extern "C" int samd_tdl_cir_c64(uint64_t seed, uint64_t call, int batch, int num
   hipLaunchKernelGGL(tdl_cir_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, seed, call, batch,
                      num_rx_ant, num_tx_ant, num_paths, num_time_steps, num_sinusoids, sampling_frequency, mean_powers,
                      min_doppler, max_doppler, los, los_power, los_aoa, (float2*)a);
+  return launch_status();
+}
+
+extern "C" int samd_spatial_corr_c64(const float* a, const float* mat, int batch, int num_rx_ant, int num_tx_ant, int64_t inner,
+                                     float* out, void* stream) {
+  SAMD_REQUIRE(a && mat && out && a != out, "bad argument (out must not alias a)");
+  SAMD_REQUIRE(batch > 0 && num_rx_ant > 0 && num_tx_ant > 0 && inner > 0, "bad size");
+  const int64_t total = (int64_t)batch * num_rx_ant * num_tx_ant * inner;
+  hipLaunchKernelGGL(spatial_corr_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)a,
+                     (const float2*)mat, batch, num_rx_ant, num_tx_ant, inner, (float2*)out);
   return launch_status();
 }
 

@@ -3,7 +3,7 @@
 
 Constellation tables are built on the host with NumPy (init time); Mapper / Demapper /
 BinarySource call the HIP kernels in ``csrc/mapping.hip`` / ``csrc/channel.hip`` through
-the C-ABI.  Out of scope: SymbolDemapper, LLRs2SymbolLogits,
+the C-ABI.  Out of scope: LLRs2SymbolLogits,
 SymbolLogits2Moments, QAM2PAM, PAM sources, demapping with priors.
 """
 import numpy as np
@@ -315,6 +315,43 @@ class Demapper(Block):
             y.numel(), 0 if self._method == "app" else 1, int(bool(self._hard_out)), _ffi.ptr(out),
             _ffi.stream()), "Demapper")
         return out
+
+
+class SymbolDemapper(Block):
+    """``SymbolDemapper(constellation_type=None, num_bits_per_symbol=None, constellation=None, hard_out=False)``
+    ``(y, no, prior=None)``: normalised logits (log-probabilities) of the constellation points for every received symbol,
+    [..., n, num_points] - or, with ``hard_out``, the index of the most likely point, [..., n] int32 (reference
+    mapping.py:693-792).  ``prior``: log-probabilities [num_points] or [..., n, num_points]."""
+
+    def __init__(self, constellation_type=None, num_bits_per_symbol=None, constellation=None, hard_out=False,
+                 precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._hard_out = hard_out
+        self._constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+
+    constellation = property(lambda self: self._constellation)
+
+    def call(self, y, no, prior=None):
+        self._require_single()
+        m = self._constellation.num_bits_per_symbol
+        npts = 1 << m
+        y = _ffi.to_device(y, torch.complex64)
+        no = _ffi.to_device(no, torch.float32)
+        no = no.reshape(1) if no.numel() == 1 else torch.broadcast_to(no, y.shape).contiguous()
+        if prior is not None:
+            prior = _ffi.to_device(prior, torch.float32)
+            prior = prior.contiguous() if prior.dim() == 1 else torch.broadcast_to(prior, tuple(y.shape) + (npts,)).contiguous()
+            assert prior.shape[-1] == npts, "prior must have num_points entries"
+        hard = bool(self._hard_out)
+        out = None if hard else torch.empty(tuple(y.shape) + (npts,), dtype=torch.float32, device=y.device)
+        idx = torch.empty(tuple(y.shape), dtype=torch.int32, device=y.device) if hard else None
+        _ffi.check(_ffi.lib().samd_symbol_demap_f32(
+            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points()), m, y.numel(),
+            _ffi.ptr(prior), 0 if prior is None else prior.numel(), int(hard), _ffi.ptr(out), _ffi.ptr(idx), _ffi.stream()),
+            "SymbolDemapper")
+        return idx if hard else out
 
 
 class BinarySource(Block):

@@ -6,7 +6,7 @@ import torch
 
 from ... import _ffi
 from ..block import Block, wrap
-from ..mapping import Demapper, Constellation
+from ..mapping import Demapper, SymbolDemapper, Constellation
 from .equalization import lmmse_equalizer, zf_equalizer, mf_equalizer
 
 
@@ -14,8 +14,9 @@ class LinearDetector(Block):
     def __init__(self, equalizer, output, demapping_method, constellation_type=None, num_bits_per_symbol=None,
                  constellation=None, hard_out=False, precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
-        if output != "bit":
-            raise NotImplementedError("LinearDetector: only output='bit' is on the MI355X hot path")
+        assert output in ("bit", "symbol"), "Unknown output"
+        assert demapping_method in ("app", "maxlog"), "Unknown demapping method"
+        self._output = output
         if equalizer in ("lmmse", "zf", "mf"):
             self._equalizer = {"lmmse": lmmse_equalizer, "zf": zf_equalizer, "mf": mf_equalizer}[equalizer]
         elif callable(equalizer):
@@ -25,12 +26,17 @@ class LinearDetector(Block):
         self._constellation = Constellation.check_or_create(
             constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
             constellation=constellation, precision=precision)
-        self._demapper = Demapper(demapping_method, constellation=self._constellation, hard_out=hard_out,
-                                  precision=precision)
+        if output == "bit":
+            self._demapper = Demapper(demapping_method, constellation=self._constellation, hard_out=hard_out,
+                                      precision=precision)
+        else:                                                 # logits / indices of the constellation points (:127-131)
+            self._demapper = SymbolDemapper(constellation=self._constellation, hard_out=hard_out, precision=precision)
 
     def call(self, y, h, s):
         x_hat, no_eff = self._equalizer(y, h, s)
-        z = self._demapper(x_hat, no_eff)                     # [..., K*m]
+        z = self._demapper(x_hat, no_eff)                     # bit: [..., K*m]; symbol: [..., K, num_points] or [..., K]
+        if self._output == "symbol":
+            return z
         m = self._constellation.num_bits_per_symbol
         return z.reshape(tuple(x_hat.shape) + (m,))           # [..., K, m] (detection.py:139-143)
 

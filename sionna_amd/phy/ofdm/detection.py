@@ -7,7 +7,7 @@ import torch
 
 from ... import _ffi
 from ..block import Block, wrap
-from ..mapping import Demapper, Constellation
+from ..mapping import Demapper, SymbolDemapper, Constellation
 from .equalization import LMMSEEqualizer, OFDMEqualizer
 
 
@@ -18,18 +18,20 @@ class LinearDetector(Block):
         super().__init__(precision=precision, **kwargs)
         if equalizer not in ("lmmse", "zf", "mf"):
             raise NotImplementedError(f"LinearDetector: equalizer '{equalizer}' has no HIP path (lmmse / zf / mf)")
-        if output != "bit":
-            raise NotImplementedError("LinearDetector: only output='bit' is on the MI355X hot path")
+        assert output in ("bit", "symbol"), "Unknown output"
         self._eq = OFDMEqualizer(equalizer, resource_grid, stream_management, precision=precision)
         self._constellation = Constellation.check_or_create(
             constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
             constellation=constellation, precision=precision)
-        self._demapper = Demapper(demapping_method, constellation=self._constellation, hard_out=hard_out,
-                                  precision=precision)
+        if output == "bit":
+            self._demapper = Demapper(demapping_method, constellation=self._constellation, hard_out=hard_out,
+                                      precision=precision)
+        else:       # [batch, num_tx, num_streams, num_data_symbols, num_points] logits or [..., num_data_symbols] indices
+            self._demapper = SymbolDemapper(constellation=self._constellation, hard_out=hard_out, precision=precision)
 
     def call(self, y, h_hat, err_var, no):
         x_hat, no_eff = self._eq(y, h_hat, err_var, no)
-        return self._demapper(x_hat, no_eff)          # [batch, num_tx, num_streams, num_data_symbols*m]
+        return self._demapper(x_hat, no_eff)          # bit: [batch, num_tx, num_streams, num_data_symbols*m]
 
 
 class MMSEPICDetector(Block):

@@ -190,9 +190,12 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
                         np.round(rt, 1), status_txt]
         print(row_fmt.format(*row_text), end=end_str)
 
-    # the device counters must be read on the host every iteration only when a rule needs them
-    need_sync = (num_target_bit_errors is not None or num_target_block_errors is not None
-                 or callback is not None or user_verbose)
+    # The device counters must be read on the host (+ all-reduced) EVERY iteration only when a stopping rule or a callback
+    # needs them.  The progress line alone (verbose, the default) gets them after the first and then after every 8th
+    # iteration - a deterministic schedule, so that all ranks take the same decision - instead of a device-to-host
+    # synchronisation and an all-reduce per Monte-Carlo iteration.
+    need_sync = (num_target_bit_errors is not None or num_target_block_errors is not None or callback is not None)
+    progress_sync = user_verbose
     cb_state = sim_ber.CALLBACK_CONTINUE
     i = 0
     try:
@@ -229,7 +232,7 @@ def sim_ber(mc_fun, ebno_dbs, batch_size, max_mc_iter, soft_estimates=False, num
                 bit_n = b.numel()
                 block_n = bit_n // b.shape[-1] if b.dim() > 0 and b.shape[-1] > 0 else bit_n
                 acc[2:] += torch.tensor([bit_n, block_n], dtype=torch.int64).to(acc.device, non_blocking=True)
-                if need_sync:
+                if need_sync or (progress_sync and (ii == 0 or (ii + 1) % 8 == 0)):
                     _flush()
 
                 cb_state = sim_ber.CALLBACK_CONTINUE

@@ -768,3 +768,92 @@ def test_flat_fading_channel(phy):
     assert tuple(phy.channel.ApplyFlatFadingChannel()(x[:7, :2], h3).shape) == (7, 2)
     with pytest.raises(NotImplementedError):
         phy.channel.FlatFadingChannel(2, 2, spatial_corr=object())
+
+
+# ------------------------------------------------------------------ symbol output (SymbolDemapper, LinearDetector(output="symbol"))
+@pytest.mark.parametrize("m", [2, 4, 6])
+def test_symbol_demapper_vs_oracle(phy, m):
+    rng = np.random.default_rng(m)
+    pts = omap.qam(m)
+    idx = rng.integers(0, 2 ** m, (6, 120))
+    y = (pts[idx] + 0.2 * _cplx(rng, (6, 120))).astype(np.complex64)
+    for no in (np.float32(0.3), rng.uniform(0.05, 2.0, (6, 120)).astype(np.float32)):
+        got = _np(phy.mapping.SymbolDemapper("qam", m)(y, no))
+        ref = omap.symbol_demapper(y, no, pts)
+        assert got.shape == (6, 120, 2 ** m)
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(ref).max() * 1e-2))
+        assert np.allclose(np.exp(got.astype(np.float64)).sum(-1), 1.0, atol=1e-5)          # normalised log-probabilities
+        hard = _np(phy.mapping.SymbolDemapper("qam", m, hard_out=True)(y, no))
+        assert hard.dtype == np.int32 and np.array_equal(hard, omap.symbol_demapper(y, no, pts, hard_out=True))
+    prior = rng.normal(size=(2 ** m,)).astype(np.float32)
+    assert np.allclose(_np(phy.mapping.SymbolDemapper("qam", m)(y, 0.3, prior)), omap.symbol_demapper(y, np.float32(0.3), pts, prior),
+                       rtol=1e-5, atol=1e-3)
+    assert np.mean(_np(phy.mapping.SymbolDemapper("qam", m, hard_out=True)(y, 0.05)) == idx) > 0.9
+
+
+@pytest.mark.parametrize("eq", ["lmmse", "zf", "mf"])
+def test_linear_detector_symbol_output(phy, eq):
+    """mimo.LinearDetector / ofdm.LinearDetector with output="symbol" (detection.py:24-143, ofdm/detection.py:740-847):
+    equaliser (bit for bit the float32 oracle) followed by the symbol demapper (float64 oracle at 1e-5)."""
+    rng = np.random.default_rng(5)
+    n, m_ant, k, nb = 300, 4, 2, 4
+    pts = omap.qam(nb)
+    xi = rng.integers(0, 16, (n, k))
+    h = (_cplx(rng, (n, m_ant, k)) / np.sqrt(2)).astype(np.complex64)
+    y = ((h @ pts[xi][..., None])[..., 0] + 0.05 * _cplx(rng, (n, m_ant))).astype(np.complex64)
+    s = (0.01 * np.eye(m_ant)).astype(np.complex64)
+    f32 = {"lmmse": of32.lmmse_equalizer, "zf": of32.zf_equalizer, "mf": of32.mf_equalizer}[eq]
+    xh, ne = f32(y, h, np.broadcast_to(s, (n, m_ant, m_ant)))
+    det = phy.mimo.LinearDetector(eq, "symbol", "app", constellation_type="qam", num_bits_per_symbol=nb)
+    logits = _np(det(y, h, s))
+    ref = omap.symbol_demapper(xh, ne, pts)
+    assert logits.shape == (n, k, 16) and np.allclose(logits, ref, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(ref).max() * 1e-2))
+    hard = _np(phy.mimo.LinearDetector(eq, "symbol", "app", constellation_type="qam", num_bits_per_symbol=nb, hard_out=True)(y, h, s))
+    assert hard.shape == (n, k) and np.array_equal(hard, omap.symbol_demapper(xh, ne, pts, hard_out=True))
+    if eq != "mf":
+        assert np.mean(hard == xi) > 0.95
+    # OFDM variant
+    rg, org = _grids(phy)
+    sm, osm = phy.mimo.StreamManagement([[1]], 2), o.StreamManagement([[1]], 2)
+    B = 3
+    x = omap.qam(2)[rng.integers(0, 4, (B, 1, 2, rg.num_data_symbols))]
+    hf = (_cplx(rng, (B, 1, 4, 1, 2, 14, rg.fft_size)) / np.sqrt(2)).astype(np.complex64)
+    yf = o.apply_ofdm_channel(o.rg_map(org, x), hf)
+    yf = (yf + 0.05 * _cplx(rng, yf.shape)).astype(np.complex64)
+    h_perf = o.remove_nulled(org, hf)
+    odet = phy.ofdm.LinearDetector(eq, "symbol", "maxlog", rg, sm, "qam", 2, hard_out=True)
+    ind = _np(odet(yf, h_perf, 0., 0.005))
+    fx, fne = of32.ofdm_equalize(org, osm, yf, h_perf, np.zeros((1,) * 7, np.float32), np.float32(0.005), eq)
+    assert ind.shape == (B, 1, 2, rg.num_data_symbols) and np.array_equal(ind, omap.symbol_demapper(fx, fne, omap.qam(2), hard_out=True))
+    soft = _np(phy.ofdm.LinearDetector(eq, "symbol", "maxlog", rg, sm, "qam", 2)(yf, h_perf, 0., 0.005))
+    assert soft.shape == (B, 1, 2, rg.num_data_symbols, 4)
+
+
+def test_tdl_spatial_correlation(phy):
+    """TDL(..., spatial_corr_mat / rx_corr_mat / tx_corr_mat) (tdl.py:173-190, 474-492): the correlated taps equal the
+    matrix square root applied to the uncorrelated taps of the same stream, and their covariance over the batch is R."""
+    ra, ta = 4, 2
+    rng = np.random.default_rng(3)
+    expc = lambda n, rho: rho ** np.abs(np.subtract.outer(np.arange(n), np.arange(n))) * np.exp(1j * 0.3 * np.subtract.outer(np.arange(n), np.arange(n)))
+    r_rx, r_tx = expc(ra, 0.7), expc(ta, 0.5)
+    sqrtm = lambda r: (lambda w, v: (v * np.sqrt(w)) @ v.conj().T)(*np.linalg.eigh(r))
+    mk = lambda **kw: phy.channel.tr38901.TDL("A", 300e-9, 3.5e9, min_speed=3., num_rx_ant=ra, num_tx_ant=ta, **kw)
+    phy.config.seed = 9
+    a0, _ = mk()(256, 5, 1e4)
+    a0 = _np(a0)                                                               # [B,1,ra,1,ta,P,T]
+    phy.config.seed = 9
+    a1, tau = mk(rx_corr_mat=r_rx, tx_corr_mat=r_tx)(256, 5, 1e4)
+    ref = np.einsum("ij,bjkpt,lk->bilpt", sqrtm(r_rx), a0[:, 0, :, 0], sqrtm(r_tx).conj())   # sqrt(Rrx) H sqrt(Rtx)^H
+    assert a1.shape == a0.shape and np.allclose(_np(a1)[:, 0, :, 0], ref, rtol=1e-4, atol=1e-5)
+    phy.config.seed = 9
+    r_full = np.kron(r_rx, r_tx.conj())      # covariance of vec_rx-major(sqrt(Rrx) H sqrt(Rtx)^H) for i.i.d. unit-variance H
+    a2, _ = mk(spatial_corr_mat=r_full)(256, 5, 1e4)
+    ref2 = np.einsum("ij,bjpt->bipt", sqrtm(r_full), a0[:, 0, :, 0].reshape(256, ra * ta, a0.shape[5], 5))
+    assert np.allclose(_np(a2)[:, 0, :, 0].reshape(256, ra * ta, a0.shape[5], 5), ref2, rtol=1e-4, atol=1e-5)
+    # statistics: covariance of the antenna-pair vector of the strongest tap, normalised by its power
+    phy.config.seed = 10
+    a3, _ = mk(rx_corr_mat=r_rx, tx_corr_mat=r_tx)(20000, 1, 1e4)
+    v = _np(a3)[:, 0, :, 0, :, 0, 0].reshape(20000, ra * ta)
+    cov = (v.T @ v.conj()) / 20000
+    cov = cov / np.real(np.trace(cov)) * (ra * ta)
+    assert np.allclose(cov, r_full, atol=0.06)
