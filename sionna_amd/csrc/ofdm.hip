@@ -146,57 +146,90 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
   }
 }
 
-// ---- taps -> frequency response.  One workgroup per (b, rx, tx): the P x F phase table
-// e^{-j 2 pi f tau_p} is built once in LDS and reused by all RA*TA*T outputs; the optional
-// normalisation (unit mean energy over ra, ta, t, f) is a deterministic in-block reduction.
+// ---- taps -> frequency response (cir_to_ofdm_channel, channel/utils.py:180-253).  One workgroup per (b, rx, tx).
+// The P x F phase table e^{-j 2 pi f tau_p} is built once per workgroup in LDS; then a thread owns ONE subcarrier f
+// (threads = G groups x F subcarriers) and keeps its column of the table in registers (MAXP complex values), the G
+// groups split the (ra, ta, t) rows, the taps a[.., p, t] of a row are the same address for all lanes of a group
+// (broadcast loads) and every store is a contiguous run of subcarriers.  The first version looped over outputs with
+// the table read from LDS per product, the taps gathered per lane from L1 and unfused multiply / add: 1.06 ms per 8192
+// batch items of config C4; this one 0.84 ms (phase table with sincosf, 46 dependent packed FMAs per output).  The accumulation order over the paths (ascending) is unchanged.
+// The optional normalisation (unit mean energy over ra, ta, t, f) is a deterministic in-block reduction as before.
+typedef float c2o_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int MAXP>
 __global__ __launch_bounds__(256) void cir_to_ofdm_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
                                                           const float* __restrict__ freqs, int RX, int RA, int TX,
                                                           int TA, int P, int T, int F, int normalize,
                                                           float2* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float2 tab[];   // [P][F] phases, then red[256]
-  float* red = reinterpret_cast<float*>(tab + (size_t)P * F);
+  extern __shared__ __attribute__((aligned(16))) float2 tab[];   // [P][F] phases, taps [RA*TA][P][T], red[256]
+  float2* taps = tab + (size_t)P * F;
+  float* red = reinterpret_cast<float*>(taps + (size_t)RA * TA * P * T);
   const int tx = blockIdx.x % TX;
   const int rx = (blockIdx.x / TX) % RX;
   const int b = blockIdx.x / (TX * RX);
   const float* tb = tau + ((size_t)(b * RX + rx) * TX + tx) * P;
-  for (int i = threadIdx.x; i < P * F; i += 256) {
+  const int nt = blockDim.x;
+  for (int i = threadIdx.x; i < P * F; i += nt) {
     const int p = i / F, f = i % F;
-    float s, c;
-    sincosf(-2.f * 3.14159265358979323846f * freqs[f] * tb[p], &s, &c);
-    tab[i] = make_float2(c, s);
+    float sn, cs;
+    sincosf(-2.f * 3.14159265358979323846f * freqs[f] * tb[p], &sn, &cs);
+    tab[i] = make_float2(cs, sn);
+  }
+  // the taps of this (b, rx, tx): RA*TA contiguous runs of P*T values -> LDS (every tap is used by all F subcarriers)
+  const int pt = P * T;
+  for (int i = threadIdx.x; i < RA * TA * pt; i += nt) {
+    const int q = i % pt, ta = (i / pt) % TA, ra = i / (pt * TA);
+    taps[i] = a[((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * (size_t)pt + q];
   }
   __syncthreads();
-  const int per = RA * TA * T * F;
+  const int rows = RA * TA * T;                                   // (ra, ta, t) rows of F outputs each
+  const int G = F <= nt ? nt / F : 1;                             // row groups working side by side
   float energy = 0.f;
-  for (int i = threadIdx.x; i < per; i += 256) {
-    const int f = i % F;
-    const int t = (i / F) % T;
-    const int ta = (i / (F * T)) % TA;
-    const int ra = i / (F * T * TA);
-    const float2* ap = a + ((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * (size_t)P * T;
-    float2 h = make_float2(0.f, 0.f);
-    for (int p = 0; p < P; ++p) {
-      const float2 v = cmul(ap[(size_t)p * T + t], tab[p * F + f]);
-      h.x += v.x; h.y += v.y;
+  for (int f0 = 0; f0 < F; f0 += nt) {                            // one trip unless F > blockDim
+    const int g = F <= nt ? (int)threadIdx.x / F : 0;
+    const int f = F <= nt ? (int)threadIdx.x % F : f0 + (int)threadIdx.x;
+    const bool act = g < G && f < F;
+    float2 ph[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) ph[p] = (act && p < P) ? tab[p * F + f] : make_float2(0.f, 0.f);
+    for (int row = g; act && row < rows; row += G) {
+      const int t = row % T, ta = (row / T) % TA, ra = row / (T * TA);
+      const float2* ap = taps + (size_t)(ra * TA + ta) * pt + t;   // same address for the lanes of a group: LDS broadcast
+      // h += a * ph as two packed fused multiply-adds per path: (h.x, h.y) += a.x * (ph.x, ph.y); += a.y * (-ph.y, ph.x)
+      // (the library is built with -ffp-contract=off for the bit-exact decoders; this kernel is held to 1e-4 against
+      // the float64 oracle, and the fused form is the more accurate one)
+      c2o_f32x2 hv = {0.f, 0.f};
+#pragma unroll
+      for (int p = 0; p < MAXP; ++p)
+        if (p < P) {
+          const float2 av = ap[p * T];
+          hv = __builtin_elementwise_fma(c2o_f32x2{av.x, av.x}, c2o_f32x2{ph[p].x, ph[p].y}, hv);
+          hv = __builtin_elementwise_fma(c2o_f32x2{av.y, av.y}, c2o_f32x2{-ph[p].y, ph[p].x}, hv);
+        }
+      out[(((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * T + t) * F + f] = make_float2(hv.x, hv.y);
+      energy += hv.x * hv.x + hv.y * hv.y;
     }
-    out[(((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * T + t) * F + f] = h;
-    energy += h.x * h.x + h.y * h.y;
+    if (F <= nt) break;
   }
   if (!normalize) return;
+  // (recomputing the sums in a second pass instead of re-reading the result was measured slower: 1.09 vs 0.84 ms -
+  // the workgroup's 68 KB of output are still in L2 when they are scaled)
+  const int per = rows * F;
   red[threadIdx.x] = energy;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    if ((int)threadIdx.x < o && (int)threadIdx.x + o < nt) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
   const float c = sqrtf(red[0] / (float)per);
   const float inv = c > 0.f ? 1.f / c : 0.f;                  // divide_no_nan
-  for (int i = threadIdx.x; i < per; i += 256) {
+  float2* ob = out + ((size_t)(b * RX + rx) * RA) * TX * TA * (size_t)T * F;
+  for (int i = threadIdx.x; i < per; i += nt) {
     const int f = i % F;
     const int t = (i / F) % T;
     const int ta = (i / (F * T)) % TA;
     const int ra = i / (F * T * TA);
-    float2* o = out + (((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * T + t) * F + f;
+    float2* o = ob + ((((size_t)ra * TX + tx) * TA + ta) * T + t) * F + f;
     *o = make_float2(o->x * inv, o->y * inv);
   }
 }
@@ -319,11 +352,26 @@ extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const floa
                                     int num_rx_ant, int num_tx, int num_tx_ant, int num_paths, int num_time_steps,
                                     int num_freqs, int normalize, float* h_freq, void* stream) {
   SAMD_REQUIRE(a && tau && frequencies && h_freq && batch > 0, "bad argument");
-  const size_t lds = (size_t)num_paths * num_freqs * sizeof(float2) + 256 * sizeof(float);
-  SAMD_REQUIRE(lds <= 64 * 1024, "num_paths * fft_size too large for the LDS phase table");
-  hipLaunchKernelGGL(cir_to_ofdm_kernel, dim3(batch * num_rx * num_tx), dim3(256), lds, (hipStream_t)stream,
-                     (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx, num_tx_ant, num_paths,
-                     num_time_steps, num_freqs, normalize, (float2*)h_freq);
+  SAMD_REQUIRE(num_paths >= 1 && num_paths <= 64, "1 <= num_paths <= 64 (the phase column of a subcarrier lives in registers)");
+  const size_t lds = ((size_t)num_paths * num_freqs + (size_t)num_rx_ant * num_tx_ant * num_paths * num_time_steps) * sizeof(float2) +
+                     256 * sizeof(float);
+  SAMD_REQUIRE(lds <= 160 * 1024, "phase table + taps of one (batch, rx, tx) link exceed the LDS");
+  const dim3 grid(batch * num_rx * num_tx), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+#define SAMD_C2O(MAXP)                                                                                              \
+  hipLaunchKernelGGL((cir_to_ofdm_kernel<MAXP>), grid, blk, lds, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant, \
+                     num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq)
+  if (lds > 64 * 1024) {
+    const void* fns[] = {(const void*)cir_to_ofdm_kernel<8>, (const void*)cir_to_ofdm_kernel<16>, (const void*)cir_to_ofdm_kernel<24>,
+                         (const void*)cir_to_ofdm_kernel<32>, (const void*)cir_to_ofdm_kernel<64>};
+    for (const void* fn : fns) SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  if (num_paths <= 8) SAMD_C2O(8);
+  else if (num_paths <= 16) SAMD_C2O(16);
+  else if (num_paths <= 24) SAMD_C2O(24);
+  else if (num_paths <= 32) SAMD_C2O(32);
+  else SAMD_C2O(64);
+#undef SAMD_C2O
   return launch_status();
 }
 

@@ -781,14 +781,15 @@ def test_symbol_demapper_vs_oracle(phy, m):
         got = _np(phy.mapping.SymbolDemapper("qam", m)(y, no))
         ref = omap.symbol_demapper(y, no, pts)
         assert got.shape == (6, 120, 2 ** m)
-        assert np.allclose(got, ref, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(ref).max() * 1e-2))
+        # logits reach -|y - c|^2 / no ~ -1e3: float32 carries ~1e-7 of the largest exponent of a symbol
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-5 + 2e-6 * np.abs(ref).max())
         assert np.allclose(np.exp(got.astype(np.float64)).sum(-1), 1.0, atol=1e-5)          # normalised log-probabilities
         hard = _np(phy.mapping.SymbolDemapper("qam", m, hard_out=True)(y, no))
         assert hard.dtype == np.int32 and np.array_equal(hard, omap.symbol_demapper(y, no, pts, hard_out=True))
     prior = rng.normal(size=(2 ** m,)).astype(np.float32)
     assert np.allclose(_np(phy.mapping.SymbolDemapper("qam", m)(y, 0.3, prior)), omap.symbol_demapper(y, np.float32(0.3), pts, prior),
-                       rtol=1e-5, atol=1e-3)
-    assert np.mean(_np(phy.mapping.SymbolDemapper("qam", m, hard_out=True)(y, 0.05)) == idx) > 0.9
+                       rtol=1e-5, atol=2e-3)
+    assert np.array_equal(_np(phy.mapping.SymbolDemapper("qam", m, hard_out=True)(pts[idx], 0.05)), idx)   # noise-free: the sent point
 
 
 @pytest.mark.parametrize("eq", ["lmmse", "zf", "mf"])
@@ -807,7 +808,7 @@ def test_linear_detector_symbol_output(phy, eq):
     det = phy.mimo.LinearDetector(eq, "symbol", "app", constellation_type="qam", num_bits_per_symbol=nb)
     logits = _np(det(y, h, s))
     ref = omap.symbol_demapper(xh, ne, pts)
-    assert logits.shape == (n, k, 16) and np.allclose(logits, ref, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(ref).max() * 1e-2))
+    assert logits.shape == (n, k, 16) and np.allclose(logits, ref, rtol=1e-5, atol=1e-5 + 2e-6 * np.abs(ref).max())
     hard = _np(phy.mimo.LinearDetector(eq, "symbol", "app", constellation_type="qam", num_bits_per_symbol=nb, hard_out=True)(y, h, s))
     assert hard.shape == (n, k) and np.array_equal(hard, omap.symbol_demapper(xh, ne, pts, hard_out=True))
     if eq != "mf":
