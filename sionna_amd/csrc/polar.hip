@@ -31,20 +31,12 @@
 // stages between paths (lazy copy) is the next step.
 #include "common.h"
 #include "bp_math.h"
-#include "scl_math.h"
-#include <cstdlib>
+#include "polar_scl.h"
 
 namespace samd {
 
 // ------------------------------------------------------------------ CRC
-// parity of the systematic CRC with generator polynomial g(x) of degree len, zero initial state
-// (3GPP 38.212 Sec. 5.1): remainder of u(x) x^len / g(x).  poly = coefficients of x^(len-1)..x^0.
-__device__ __forceinline__ uint32_t crc_step(uint32_t reg, uint32_t bit, uint32_t poly, int len) {
-  const uint32_t fb = ((reg >> (len - 1)) & 1u) ^ bit;
-  reg = (reg << 1) & ((len == 32) ? 0xFFFFFFFFu : ((1u << len) - 1u));
-  return fb ? (reg ^ poly) : reg;
-}
-
+// crc_step: polar_scl.h
 // out [N, k+len] = [bits, parity]  (or only the validity flag when check != 0: bits [N, k] incl. parity)
 __global__ __launch_bounds__(256) void crc_kernel(const float* __restrict__ bits, int64_t n_words, int k, uint32_t poly,
                                                   int len, int check, float* __restrict__ out) {
@@ -79,37 +71,7 @@ __global__ __launch_bounds__(256) void polar_encode_kernel(const float* __restri
   for (int i = threadIdx.x; i < n_out; i += 256) out[(size_t)b * n_out + i] = (float)x[out_idx[i]];
 }
 
-// ------------------------------------------------------------------ SC / SCL decoder
-enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6 };
-constexpr float kPolarLlrMax = 30.f;
-
-// Metric arithmetic: scl_math.h (float32 operations in a defined order, restated by the CPU oracle
-// oracle/polar_scl.c - hard decisions and CRC status are compared bit for bit, tests/test_gpu_polar.py).
-// log(1 + e^x) = max(x, 0) + T(|x|) is evaluated ~3000 times per codeword on a few lanes (19 VALU operations).
-__device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + scl_T(fabsf(x)); }
-__device__ __forceinline__ float cn_op(float x, float y) {  // polar/decoding.py:684-705
-  x = clampf(x, -kPolarLlrMax, kPolarLlrMax);
-  y = clampf(y, -kPolarLlrMax, kPolarLlrMax);
-  const float lse = fmaxf(x, y) + scl_T(fabsf(x - y));
-  return softplus(x + y) - lse;
-}
-
-struct SclArgs {
-  const float* llr_in;     // [B, n] logits
-  float* u_hat;            // [B, k] bits at the information positions of the selected path
-  float* crc_status;       // nullable [B]
-  const int32_t* ops;      // [num_ops] packed: op | stage<<3 | side<<7 | (a2+2048)<<8
-  int num_ops;
-  const int32_t* info_pos; // [k]
-  const int32_t* iil_inv;  // nullable [k] inverse input interleaver applied before the CRC check
-  float* gscratch;         // [grid][L][n - n/2^G] the G top LLR stages of every slot: touched by a handful
-                           // of ops per decode, kept in L2 instead of LDS so that more codewords fit on a CU
-  unsigned char* gbeta;    // [grid][L][n - n/2^G] partial sums of the same top stages
-  int gstages;             // G
-  int batch, n, m, k, L, sc_mode, crc_len;
-  uint32_t crc_poly;
-};
-
+// ------------------------------------------------------------------ SC / SCL decoder (definitions: polar_scl.h)
 // NT = threads per workgroup: 64 (one wave per codeword: the hardware barrier of a single-wave
 // workgroup is free, which is what the ~14k dependent steps per codeword want) or 256.
 // The decoder is a latency-bound dependent chain (measured ~10 cycles per wave instruction with one
@@ -405,15 +367,6 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   }
 }
 
-static int scl_gstages(int n) {
-  // top LLR stages kept in L2 (SAMD_SCL_GSTAGES overrides: 0..3); never more than log2(n) - 2
-  int m = 0;
-  while ((1 << m) < n) ++m;
-  const char* e = getenv("SAMD_SCL_GSTAGES");
-  int g = e ? atoi(e) : 5;
-  return std::max(0, std::min(g, std::min(5, m - 2)));
-}
-
 static size_t scl_lds_bytes(int n, int L, int num_ops) {
   const size_t words = (n + 31) / 32;
   (void)num_ops;
@@ -486,6 +439,8 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   unsigned char* gb = reinterpret_cast<unsigned char*>(gs + (size_t)grid * list_size * n);
   SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n), batch, n, m, k, list_size,
             sc_mode, crc_len, crc_poly};
+  // list decoding with 4..32 paths: the engine whose low stages live in registers (polar_scl_reg.hip)
+  if (scl_reg_supported(n, list_size, sc_mode)) return scl_reg_launch(p, grid, (hipStream_t)stream);
   // one wave per codeword: the block sums of rate-0 / repetition nodes are defined on 64 lanes (scl_math.h)
   hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
   return launch_status();

@@ -1,0 +1,65 @@
+// Shared definitions of the Polar SC / SC-list decoder kernels (polar.hip: generic engine, any list size, SC mode;
+// polar_scl_reg.hip: the list engine whose low decoding stages live in registers).
+#pragma once
+#include "common.h"
+#include "scl_math.h"
+#include <algorithm>
+#include <cstdlib>
+
+namespace samd {
+
+// parity of the systematic CRC with generator polynomial g(x) of degree len, zero initial state
+// (3GPP 38.212 Sec. 5.1): remainder of u(x) x^len / g(x).  poly = coefficients of x^(len-1)..x^0.
+__device__ __forceinline__ uint32_t crc_step(uint32_t reg, uint32_t bit, uint32_t poly, int len) {
+  const uint32_t fb = ((reg >> (len - 1)) & 1u) ^ bit;
+  reg = (reg << 1) & ((len == 32) ? 0xFFFFFFFFu : ((1u << len) - 1u));
+  return fb ? (reg ^ poly) : reg;
+}
+
+
+enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6 };
+constexpr float kPolarLlrMax = 30.f;
+
+// Metric arithmetic: scl_math.h (float32 operations in a defined order, restated by the CPU oracle
+// oracle/polar_scl.c - hard decisions and CRC status are compared bit for bit, tests/test_gpu_polar.py).
+// log(1 + e^x) = max(x, 0) + T(|x|) is evaluated ~3000 times per codeword on a few lanes (19 VALU operations).
+__device__ __forceinline__ float softplus(float x) { return fmaxf(x, 0.f) + scl_T(fabsf(x)); }
+__device__ __forceinline__ float cn_op(float x, float y) {  // polar/decoding.py:684-705
+  x = clampf(x, -kPolarLlrMax, kPolarLlrMax);
+  y = clampf(y, -kPolarLlrMax, kPolarLlrMax);
+  const float lse = fmaxf(x, y) + scl_T(fabsf(x - y));
+  return softplus(x + y) - lse;
+}
+
+struct SclArgs {
+  const float* llr_in;     // [B, n] logits
+  float* u_hat;            // [B, k] bits at the information positions of the selected path
+  float* crc_status;       // nullable [B]
+  const int32_t* ops;      // [num_ops] packed: op | stage<<3 | side<<7 | (a2+2048)<<8
+  int num_ops;
+  const int32_t* info_pos; // [k]
+  const int32_t* iil_inv;  // nullable [k] inverse input interleaver applied before the CRC check
+  float* gscratch;         // [grid][L][n - n/2^G] the G top LLR stages of every slot: touched by a handful
+                           // of ops per decode, kept in L2 instead of LDS so that more codewords fit on a CU
+  unsigned char* gbeta;    // [grid][L][n - n/2^G] partial sums of the same top stages
+  int gstages;             // G
+  int batch, n, m, k, L, sc_mode, crc_len;
+  uint32_t crc_poly;
+};
+
+
+inline int scl_gstages(int n) {
+  // top LLR stages kept in L2 (SAMD_SCL_GSTAGES overrides: 0..5); never more than log2(n) - 2
+  int m = 0;
+  while ((1 << m) < n) ++m;
+  const char* e = getenv("SAMD_SCL_GSTAGES");
+  int g = e ? atoi(e) : 5;
+  return std::max(0, std::min(g, std::min(5, m - 2)));
+}
+
+// polar_scl_reg.hip
+bool scl_reg_supported(int n, int list_size, int sc_mode);
+size_t scl_reg_lds_bytes(int n, int list_size);
+int scl_reg_launch(const SclArgs& p, int grid, hipStream_t stream);
+
+}  // namespace samd

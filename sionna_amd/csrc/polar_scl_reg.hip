@@ -1,0 +1,394 @@
+// Polar SC-list decoder whose low decoding stages live in registers (north-star config C5).
+//
+// Replaces (reference src/sionna/phy/fec/polar/decoding.py): PolarSCLDecoder, default TF path with use_fast_scl
+// (:525-723 metric / boxplus arithmetic, :919-1045 decoding recursion, :1345-1437 final CRC-aided selection).
+// Same schedule, same float32 arithmetic (scl_math.h) and therefore the same bits as the generic engine in
+// polar.hip and as oracle/polar_scl.c; what changes is where the state of the lowest tree levels lives.
+//
+// 7/8 of the ~2800 schedule operations of an n = 1024 code work on the 8-leaf subtrees at the bottom of the
+// decoding tree, on 8..64 numbers each.  The generic engine keeps every stage in LDS behind per-slot pointer
+// tables (lazy path copies), so each of those operations is a chain of 3-4 dependent LDS round trips around a
+// few dozen arithmetic instructions - PMC: half of all wave cycles waiting, as many scalar as vector
+// instructions.  Here a wave still owns one codeword, but lane = slot * W + j (W = 64 / L lanes per list slot):
+//   * the LLRs of stages 0..R (R = log2 W; 2^s values at stage s, in lanes j < 2^s) and the partial sums of
+//     those stages (two bits per stage in one register) are registers of the slot's lanes: f / g / combine
+//     at these stages are a lane shift inside a 16-lane row (DPP) plus the arithmetic, no memory, no pointers;
+//   * block metrics of rate-0 / repetition nodes at these stages are a DPP tree with the summation order of
+//     scl_math.h (lane 0 of the halving tree);
+//   * a fork ranks the 2L candidates with one LDS exchange (W/2 lanes per candidate share the comparisons),
+//     matches dead slots to the second survivors with ballots and a scalar loop, and a dead slot pulls the
+//     R + 3 registers of its new parent with ds_bpermute; path metric and sorted position of a slot are
+//     registers of its first lane;
+//   * stages above R keep the design of the generic engine (LDS for the next stages, L2 scratch for the top
+//     G stages, lazy copies through the pointer tables), iterated by slot - the position order is only needed
+//     for the tie-break of the ranking.
+#include "polar_scl.h"
+#include <type_traits>
+
+namespace samd {
+
+// lane i <- lane i + K inside a row of 16 lanes (lanes past the row read 0)
+template <int K>
+__device__ __forceinline__ int dpp_up_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x100 + K, 0xF, 0xF, true);   // row_shl:K
+}
+template <int K>
+__device__ __forceinline__ float dpp_up(float v) { return __int_as_float(dpp_up_i<K>(__float_as_int(v))); }
+// lane i <- lane i - K inside a row of 16 lanes
+template <int K>
+__device__ __forceinline__ int dpp_down_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x110 + K, 0xF, 0xF, true);   // row_shr:K
+}
+
+// LDS-typed pointers: loads and stores through them are ds_* instructions whatever the optimiser merges
+typedef __attribute__((address_space(3))) float lds_f32;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+
+template <int MAX, class F>
+__device__ __forceinline__ void stage_switch(int s, F&& f) {   // f(integral_constant<s>) for the wave-uniform s <= MAX
+  if constexpr (MAX >= 0) {
+    if (s == MAX) f(std::integral_constant<int, MAX>{});
+    else stage_switch<MAX - 1>(s, f);
+  }
+}
+
+// sum of the 2^S values in lanes j < 2^S of a slot, in the order of scl_math.h's halving tree; result in lane j = 0
+template <int S>
+__device__ __forceinline__ float slot_tree(float v) {
+  if constexpr (S >= 4) v += dpp_up<8>(v);
+  if constexpr (S >= 3) v += dpp_up<4>(v);
+  if constexpr (S >= 2) v += dpp_up<2>(v);
+  if constexpr (S >= 1) v += dpp_up<1>(v);
+  return v;
+}
+
+template <int L>
+struct SclRegLayout {
+  static constexpr int W = 64 / L;                                       // lanes per slot
+  static constexpr int R = W >= 16 ? 4 : W == 8 ? 3 : W == 4 ? 2 : 1;     // register stages 0..R
+  static constexpr int H = 1 << R;                                       // values of stage R (== W)
+};
+
+static inline size_t scl_reg_wstride(int n) { return (size_t)(((n + 31) / 32 + 3) / 4 * 4); }
+
+template <int L>
+__global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
+  constexpr int W = SclRegLayout<L>::W, R = SclRegLayout<L>::R, H = SclRegLayout<L>::H;
+  static_assert(H == W && W >= 2 && W <= 16, "lanes of a slot = values of its top register stage");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = p.n, m = p.m, lane = threadIdx.x;
+  const int slot = lane / W, j = lane % W;
+  const bool head = j == 0;
+  const int top = m - p.gstages;                       // stages (R, top) in LDS, [top, m) in L2 scratch, m = channel
+  const int hn = 1 << top;
+  const int wstride = (((n + 31) / 32 + 3) / 4) * 4, wq = wstride / 4;
+  float* llr = smem;                                                         // [L][hn]  stage s at [2^s, 2^(s+1))
+  unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * hn);   // [L][hn]  bit 0 left, bit 1 right result
+  uint32_t* bits = reinterpret_cast<uint32_t*>(beta + (size_t)L * hn);       // [L][wstride] decided u bits
+  unsigned char* tab = reinterpret_cast<unsigned char*>(bits + (size_t)L * wstride);   // [L][3][16] slot holding the
+  float* cv = reinterpret_cast<float*>(tab + (size_t)L * 48);                // stage-s LLRs / left sums / right sums
+  int* cp = reinterpret_cast<int*>(cv + 2 * L);                              // [L] position of a slot
+  float* pm_s = reinterpret_cast<float*>(cp + L);                            // [L] final metrics by position
+  int* order = reinterpret_cast<int*>(pm_s + L);                             // [L] position -> slot
+  float* blk = reinterpret_cast<float*>(order + L);                          // [2L]
+  lds_f32* llr3 = (lds_f32*)llr;
+  lds_u8* beta3 = (lds_u8*)beta;
+  float* gsc = p.gscratch + (size_t)blockIdx.x * L * (n - hn);
+  unsigned char* gbe = p.gbeta + (size_t)blockIdx.x * L * (n - hn);
+
+  for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
+    const float* llr_ch = p.llr_in + (size_t)b * n;    // logits: negated where they are read (LLR = -logit)
+    // value idx of the stage-s LLRs held by slot sl; every branch is wave-uniform and has its own address space
+    auto ld_llr = [&](int sl, int s, int idx) -> float {
+      if (s == m) return -llr_ch[idx];
+      if (s < top) return llr3[sl * hn + (1 << s) + idx];
+      return gsc[(size_t)sl * (n - hn) + ((1 << s) - hn) + idx];
+    };
+    auto st_llr = [&](int sl, int s, int idx, float v) {
+      if (s < top) llr3[sl * hn + (1 << s) + idx] = v;
+      else gsc[(size_t)sl * (n - hn) + ((1 << s) - hn) + idx] = v;
+    };
+    auto ld_beta = [&](int sl, int s, int idx) -> uint32_t {
+      if (s < top) return beta3[sl * hn + (1 << s) + idx];
+      return gbe[(size_t)sl * (n - hn) + ((1 << s) - hn) + idx];
+    };
+    // result bit `v` of side a1 into byte idx of the stage-s partial sums of slot sl (the other side's bit stays)
+    auto put_beta = [&](int sl, int s, int idx, uint32_t v, int a1) {
+      const uint32_t keep = a1 ? 1u : 2u;
+      if (s < top) {
+        lds_u8* d = beta3 + sl * hn + (1 << s) + idx;
+        *d = (unsigned char)((*d & keep) | (v << a1));
+      } else {
+        unsigned char* d = gbe + (size_t)sl * (n - hn) + ((1 << s) - hn) + idx;
+        *d = (unsigned char)((*d & keep) | (v << a1));
+      }
+    };
+
+    for (int i = lane; i < L * wstride; i += 64) bits[i] = 0u;
+    for (int i = lane; i < L * 48; i += 64) tab[i] = (unsigned char)(i / 48);
+    float A[R + 1];
+#pragma unroll
+    for (int s = 0; s <= R; ++s) A[s] = 0.f;
+    uint32_t bb = 0u;                                   // bit 2s / 2s+1: left / right child result at stage s, position j
+    float pm = slot == 0 ? 0.f : kPolarLlrMax;          // decoding.py:1029-1033 (first lane of the slot)
+    int pos = slot;
+    __syncthreads();
+
+    int next_rec = p.ops[0];
+    for (int ip = 0;; ++ip) {
+      const int rec = next_rec;
+      next_rec = (ip + 1 < p.num_ops) ? p.ops[ip + 1] : (int)OP_END;
+      const int op = rec & 7, s = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = (rec >> 8) - 2048;
+      if (op == OP_END) break;
+      if (op == OP_F || op == OP_G) {
+        // inputs at stage s (2^s values), outputs at stage so = s - 1; g uses the left results of stage so
+        const int so = s - 1;
+        if (so < R) {
+          stage_switch<R - 1>(so, [&](auto S_) {
+            constexpr int S = decltype(S_)::value;
+            const float x = A[S + 1], y = dpp_up<(1 << S)>(x);
+            if (op == OP_F) A[S] = cn_op(x, y);
+            else A[S] = (1.f - 2.f * (float)((bb >> (2 * S)) & 1u)) * x + y;        // vn_op :707-714
+          });
+        } else if (so == R) {
+          const int si = (s == m) ? 0 : (int)tab[slot * 48 + s];
+          const float x = ld_llr(si, s, j), y = ld_llr(si, s, j + H);
+          if (op == OP_F) A[R] = cn_op(x, y);
+          else A[R] = (1.f - 2.f * (float)((bb >> (2 * R)) & 1u)) * x + y;
+        } else {
+          const int half = 1 << so;
+          for (int w = lane; w < L * half; w += 64) {
+            const int sl = w >> so, jj = w & (half - 1);
+            const int si = (s == m) ? 0 : (int)tab[sl * 48 + s];
+            const float x = ld_llr(si, s, jj), y = ld_llr(si, s, jj + half);
+            float r;
+            if (op == OP_F) r = cn_op(x, y);
+            else r = (1.f - 2.f * (float)(ld_beta(tab[sl * 48 + 16 + so], so, jj) & 1u)) * x + y;
+            st_llr(sl, so, jj, r);
+          }
+          if (lane < L) tab[lane * 48 + so] = (unsigned char)lane;
+          __syncthreads();
+        }
+      } else if (op == OP_COMBINE) {
+        // children results at stage s -> this node's result at stage s + 1 on side a1: (l ^ r, r)
+        if (s < R) {
+          stage_switch<R - 1>(s, [&](auto S_) {
+            constexpr int S = decltype(S_)::value, sz = 1 << S;
+            const uint32_t l = (bb >> (2 * S)) & 1u, r = (bb >> (2 * S + 1)) & 1u;
+            const uint32_t hi = (uint32_t)dpp_down_i<sz>((int)r);
+            const uint32_t nb = (j < sz) ? (l ^ r) : hi;
+            const int sh = 2 * (S + 1) + a1;
+            bb = (bb & ~(1u << sh)) | (nb << sh);
+          });
+        } else if (s == R) {
+          const uint32_t l = (bb >> (2 * R)) & 1u, r = (bb >> (2 * R + 1)) & 1u;
+          put_beta(slot, R + 1, j, l ^ r, a1);
+          put_beta(slot, R + 1, H + j, r, a1);
+          if (head) tab[slot * 48 + (a1 ? 32 : 16) + R + 1] = (unsigned char)slot;
+          __syncthreads();
+        } else {
+          const int sz = 1 << s;
+          for (int w = lane; w < L * sz; w += 64) {
+            const int sl = w >> s, jj = w & (sz - 1);
+            const uint32_t l = ld_beta(tab[sl * 48 + 16 + s], s, jj) & 1u;
+            const uint32_t r = (ld_beta(tab[sl * 48 + 32 + s], s, jj) >> 1) & 1u;
+            put_beta(sl, s + 1, jj, l ^ r, a1);
+            put_beta(sl, s + 1, sz + jj, r, a1);
+          }
+          if (lane < L) tab[lane * 48 + (a1 ? 32 : 16) + s + 1] = (unsigned char)lane;
+          __syncthreads();
+        }
+      } else {
+        // ---- leaf / rate-0 / repetition node at stage s, side a1; a2 = (last) bit index (frozen leaf: -1-index)
+        const bool info = (op == OP_REP) || (op == OP_LEAF && a2 >= 0);
+        // block metrics of the slot in its first lane: m0 = sum softplus(-l), m1 = sum softplus(+l)
+        float m0 = 0.f, m1 = 0.f;
+        if (s <= R) {
+          stage_switch<R>(s, [&](auto S_) {
+            constexpr int S = decltype(S_)::value, sz = 1 << S;
+            const float l = clampf(A[S], -kPolarLlrMax, kPolarLlrMax);
+            const float tl = scl_T(fabsf(l));                 // shared by softplus(-l) and softplus(l)
+            float t0 = fmaxf(-l, 0.f) + tl, t1 = fmaxf(l, 0.f) + tl;
+            if (j >= sz) { t0 = 0.f; t1 = 0.f; }
+            m0 = slot_tree<S>(t0);
+            if (info) m1 = slot_tree<S>(t1);
+          });
+        } else {
+          const int sz = 1 << s;
+          for (int sl = 0; sl < L; ++sl) {
+            const int si = (s == m) ? 0 : (int)tab[sl * 48 + s];
+            // scl_math.h order: lane l accumulates terms l, l + 64, ... ascending, then the halving tree over 64 lanes
+            float a0 = 0.f, a1v = 0.f;
+            for (int jj = lane; jj < sz; jj += 64) {
+              const float l = clampf(ld_llr(si, s, jj), -kPolarLlrMax, kPolarLlrMax);
+              const float tl = scl_T(fabsf(l));
+              a0 += fmaxf(-l, 0.f) + tl;
+              a1v += fmaxf(l, 0.f) + tl;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o, 64); a1v += __shfl_xor(a1v, o, 64); }
+            if (slot == sl) { m0 = a0; m1 = a1v; }
+          }
+        }
+        unsigned long long ones = 0ull;                       // slots (bit = first lane) whose decided bit is 1
+        if (!info) {
+          pm += m0;                                           // frozen leaf / rate-0: all-zero block
+        } else {
+          // ---- fork: candidate (u, slot) has metric pm + m_u and sort index u L + position (stable sort, :1345-1390)
+          const float c0 = pm + m0, c1 = pm + m1;
+          if (head) { cv[slot] = c0; cv[L + slot] = c1; cp[slot] = pos; }
+          __syncthreads();
+          constexpr int G2 = W / 2, PER = (2 * L) / G2;       // lanes per candidate, comparisons per lane
+          const int u = j & 1, q = j >> 1;
+          const float me = cv[u * L + slot];
+          const int cme = u * L + cp[slot];
+          int rank = 0;
+          if constexpr (PER == 4) {
+            const float4 v4 = reinterpret_cast<const float4*>(cv)[q];
+            const int4 p4 = reinterpret_cast<const int4*>(cp)[q & (L / 4 - 1)];
+            const float vd[4] = {v4.x, v4.y, v4.z, v4.w};
+            const int pd[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+              const int cd = (q * 4 >= L ? L : 0) + pd[t];
+              rank += (vd[t] < me || (vd[t] == me && cd < cme)) ? 1 : 0;
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < PER; ++t) {
+              const int d = q * PER + t;
+              const float vd = cv[d];
+              const int cd = (d >= L ? L : 0) + cp[d & (L - 1)];
+              rank += (vd < me || (vd == me && cd < cme)) ? 1 : 0;
+            }
+          }
+          if constexpr (W >= 16) rank += dpp_up_i<8>(rank);
+          if constexpr (W >= 8) rank += dpp_up_i<4>(rank);
+          if constexpr (W >= 4) rank += dpp_up_i<2>(rank);
+          const int r0 = rank, r1 = dpp_up_i<1>(rank);        // first lane of the slot: ranks of (0, slot), (1, slot)
+          const bool stay0 = r0 < L, stay1 = r1 < L;
+          unsigned long long md = __ballot(head && !stay0 && !stay1);       // slots without survivor
+          unsigned long long mb = __ballot(head && stay0 && stay1);         // slots with two survivors
+          unsigned long long m1mask = __ballot(head && !stay0 && stay1);    // slots that continue with u = 1
+          float npm = stay0 ? c0 : c1;
+          int npos = stay0 ? r0 : r1;
+          int srcl = lane;
+          const bool any = md != 0ull;
+          while (md != 0ull && mb != 0ull) {                  // the i-th dead slot takes the second child of the i-th
+            const int d = __builtin_ctzll(md), sp = __builtin_ctzll(mb);   // slot with two survivors
+            md &= md - 1ull;
+            mb &= mb - 1ull;
+            if ((lane & ~(W - 1)) == d) srcl = sp + j;
+            m1mask |= 1ull << d;
+          }
+          if (any) {
+            const int addr = srcl << 2;
+#pragma unroll
+            for (int k = 1; k <= R; ++k) A[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(A[k])));
+            bb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bb);
+            const float pc1 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(c1)));
+            const int pr1 = __builtin_amdgcn_ds_bpermute(addr, r1);
+            if (srcl != lane) {
+              npm = pc1;
+              npos = pr1;
+              // decided bits and the pointer tables of the upper stages (lazy copy of everything above stage R)
+              const int ssl = srcl / W;
+              uint4* bw = reinterpret_cast<uint4*>(bits);
+              for (int e = j; e < wq; e += W) bw[slot * wq + e] = bw[ssl * wq + e];
+              uint4* tw = reinterpret_cast<uint4*>(tab);
+              for (int e = j; e < 3; e += W) tw[slot * 3 + e] = tw[ssl * 3 + e];
+            }
+            __syncthreads();
+          }
+          pm = npm;
+          pos = npos;
+          ones = m1mask;
+          if (head && ((ones >> lane) & 1ull)) bits[slot * wstride + (a2 >> 5)] |= 1u << (a2 & 31);   // the node's only information bit is its last
+        }
+        // the node's result: the all-u codeword
+        if (s <= R) {
+          const int sh = 2 * s + a1;
+          const uint32_t nb = (uint32_t)((ones >> (lane & ~(W - 1))) & 1ull);
+          bb = (bb & ~(1u << sh)) | (nb << sh);
+        } else {
+          const int sz = 1 << s;
+          for (int w = lane; w < L * sz; w += 64) {
+            const int sl = w >> s, jj = w & (sz - 1);
+            put_beta(sl, s, jj, (uint32_t)((ones >> (sl * W)) & 1ull), a1);
+          }
+          if (lane < L) tab[lane * 48 + (a1 ? 32 : 16) + s] = (unsigned char)lane;
+        }
+        __syncthreads();
+      }
+    }
+    // ---- final selection (decoding.py:1396-1419): CRC over the info bits of every path, penalty, first min
+    if (head) { pm_s[pos] = pm; order[pos] = slot; }
+    __syncthreads();
+    if (lane < L) {
+      const uint32_t* bw = bits + (size_t)order[lane] * wstride;
+      float pen = 0.f;
+      if (p.crc_len > 0) {
+        uint32_t reg = 0;
+        for (int i = 0; i < p.k; ++i) {
+          const int src = p.iil_inv ? p.iil_inv[i] : i;
+          const int ps = p.info_pos[src];
+          reg = crc_step(reg, (bw[ps >> 5] >> (ps & 31)) & 1u, p.crc_poly, p.crc_len);
+        }
+        blk[lane] = reg == 0 ? 1.f : 0.f;
+        pen = reg == 0 ? 0.f : kPolarLlrMax * (float)p.k;
+      }
+      cv[lane] = pm_s[lane] + pen;
+    }
+    __syncthreads();
+    // first minimum of the penalised metrics in the order of the final stable sort by path metric (:1391, 1415):
+    // among equal penalised metrics the smaller path metric, then the lower position
+    int best = 0;
+    for (int q = 1; q < L; ++q)
+      if (cv[q] < cv[best] || (cv[q] == cv[best] && pm_s[q] < pm_s[best])) best = q;
+    const uint32_t* bw = bits + (size_t)order[best] * wstride;
+    for (int i = lane; i < p.k; i += 64) {
+      const int ps = p.info_pos[i];
+      p.u_hat[(size_t)b * p.k + i] = (float)((bw[ps >> 5] >> (ps & 31)) & 1u);
+    }
+    if (lane == 0 && p.crc_status) p.crc_status[b] = p.crc_len > 0 ? blk[best] : 1.f;
+    __syncthreads();
+  }
+}
+
+bool scl_reg_supported(int n, int list_size, int sc_mode) {
+  if (sc_mode || getenv("SAMD_SCL_GENERIC")) return false;
+  if (list_size != 4 && list_size != 8 && list_size != 16 && list_size != 32) return false;
+  int m = 0;
+  while ((1 << m) < n) ++m;
+  const int w = 64 / list_size, r = w >= 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;
+  return m >= r + 2 && n <= 1024;
+}
+
+size_t scl_reg_lds_bytes(int n, int L) {
+  int m = 0;
+  while ((1 << m) < n) ++m;
+  const size_t hn = (size_t)1 << (m - scl_gstages(n));
+  return (size_t)L * hn * 5 + (size_t)L * scl_reg_wstride(n) * 4 + (size_t)L * 48 + (size_t)L * 4 * 8 + 64;
+}
+
+template <int L>
+static int scl_reg_launch_l(const SclArgs& p, int grid, hipStream_t stream) {
+  const size_t lds = scl_reg_lds_bytes(p.n, L);
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_reg_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+  hipLaunchKernelGGL(polar_scl_reg_kernel<L>, dim3(grid), dim3(64), lds, stream, p);
+  return launch_status();
+}
+
+int scl_reg_launch(const SclArgs& p, int grid, hipStream_t stream) {
+  switch (p.L) {
+    case 4: return scl_reg_launch_l<4>(p, grid, stream);
+    case 8: return scl_reg_launch_l<8>(p, grid, stream);
+    case 16: return scl_reg_launch_l<16>(p, grid, stream);
+    case 32: return scl_reg_launch_l<32>(p, grid, stream);
+  }
+  set_error("list size not supported by the register engine");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+}  // namespace samd
