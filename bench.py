@@ -305,7 +305,7 @@ def bench_c5(args, short=False):
            "config": {"workload": f"C5: Polar5G uplink k=512 n=1024 (CRC11), SCL list 8, QPSK AWGN, batch {B}",
                       "batch": B, "ebno_db": ebno},
            "bler": float((u_hat != u).any(dim=1).float().mean()),
-           "roofline": onchip_roofline("polar_scl", "polar_scl_kernel<64> (one wave per codeword, list state in LDS)", B, ms,
+           "roofline": onchip_roofline("polar_scl", "polar_scl_reg_kernel<8> (one wave per codeword, low stages in registers)", B, ms,
                                        {"compulsory_io_gbps": round((4 * n + 4 * k) * B / (ms * 1e-3) / 1e9, 2)})}
     if not args.no_cpu_baseline:
         from oracle import polar as op, polar_c as pc

@@ -440,7 +440,9 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n), batch, n, m, k, list_size,
             sc_mode, crc_len, crc_poly};
   // list decoding with 4..32 paths: the engine whose low stages live in registers (polar_scl_reg.hip)
-  if (scl_reg_supported(n, list_size, sc_mode)) return scl_reg_launch(p, grid, (hipStream_t)stream);
+  // (it reads four consecutive LLRs per lane: rows of 16-byte aligned inputs, which n >= 32 floats per row preserves)
+  if (scl_reg_supported(n, list_size, sc_mode) && (reinterpret_cast<uintptr_t>(llr) & 15u) == 0)
+    return scl_reg_launch(p, grid, (hipStream_t)stream);
   // one wave per codeword: the block sums of rate-0 / repetition nodes are defined on 64 lanes (scl_math.h)
   hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
   return launch_status();

@@ -43,6 +43,9 @@ __device__ __forceinline__ int dpp_down_i(int v) {
 // LDS-typed pointers: loads and stores through them are ds_* instructions whatever the optimiser merges
 typedef __attribute__((address_space(3))) float lds_f32;
 typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 template <int MAX, class F>
 __device__ __forceinline__ void stage_switch(int s, F&& f) {   // f(integral_constant<s>) for the wave-uniform s <= MAX
@@ -72,25 +75,24 @@ struct SclRegLayout {
 static inline size_t scl_reg_wstride(int n) { return (size_t)(((n + 31) / 32 + 3) / 4 * 4); }
 
 template <int L>
-__global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
+__global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
   constexpr int W = SclRegLayout<L>::W, R = SclRegLayout<L>::R, H = SclRegLayout<L>::H;
   static_assert(H == W && W >= 2 && W <= 16, "lanes of a slot = values of its top register stage");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = p.n, m = p.m, lane = threadIdx.x;
-  const int slot = lane / W, j = lane % W;
-  const bool head = j == 0;
+  const int n = p.n, m = p.m, lane0 = threadIdx.x;
   const int top = m - p.gstages;                       // stages (R, top) in LDS, [top, m) in L2 scratch, m = channel
   const int hn = 1 << top;
   const int wstride = (((n + 31) / 32 + 3) / 4) * 4, wq = wstride / 4;
-  float* llr = smem;                                                         // [L][hn]  stage s at [2^s, 2^(s+1))
-  unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * hn);   // [L][hn]  bit 0 left, bit 1 right result
-  uint32_t* bits = reinterpret_cast<uint32_t*>(beta + (size_t)L * hn);       // [L][wstride] decided u bits
-  unsigned char* tab = reinterpret_cast<unsigned char*>(bits + (size_t)L * wstride);   // [L][3][16] slot holding the
-  float* cv = reinterpret_cast<float*>(tab + (size_t)L * 48);                // stage-s LLRs / left sums / right sums
+  // fixed-size arrays first (compile-time LDS offsets), the arrays sized by n and the L2 split last
+  unsigned char* tab = reinterpret_cast<unsigned char*>(smem);               // [L][3][16] slot holding the stage-s
+  float* cv = reinterpret_cast<float*>(tab + (size_t)L * 48);                // LLRs / left sums / right sums; [2L] candidates
   int* cp = reinterpret_cast<int*>(cv + 2 * L);                              // [L] position of a slot
   float* pm_s = reinterpret_cast<float*>(cp + L);                            // [L] final metrics by position
   int* order = reinterpret_cast<int*>(pm_s + L);                             // [L] position -> slot
   float* blk = reinterpret_cast<float*>(order + L);                          // [2L]
+  uint32_t* bits = reinterpret_cast<uint32_t*>(blk + 2 * L);                 // [L][wstride] decided u bits
+  float* llr = reinterpret_cast<float*>(bits + (size_t)L * wstride);         // [L][hn]  stage s at [2^s, 2^(s+1))
+  unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * hn);   // [L][hn]  bit 0 left, bit 1 right result
   lds_f32* llr3 = (lds_f32*)llr;
   lds_u8* beta3 = (lds_u8*)beta;
   float* gsc = p.gscratch + (size_t)blockIdx.x * L * (n - hn);
@@ -99,21 +101,13 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
     const float* llr_ch = p.llr_in + (size_t)b * n;    // logits: negated where they are read (LLR = -logit)
     // value idx of the stage-s LLRs held by slot sl; every branch is wave-uniform and has its own address space
-    auto ld_llr = [&](int sl, int s, int idx) -> float {
+    auto ld_llr = [&](int sl, int s, int idx) __attribute__((always_inline)) -> float {
       if (s == m) return -llr_ch[idx];
       if (s < top) return llr3[sl * hn + (1 << s) + idx];
       return gsc[(size_t)sl * (n - hn) + ((1 << s) - hn) + idx];
     };
-    auto st_llr = [&](int sl, int s, int idx, float v) {
-      if (s < top) llr3[sl * hn + (1 << s) + idx] = v;
-      else gsc[(size_t)sl * (n - hn) + ((1 << s) - hn) + idx] = v;
-    };
-    auto ld_beta = [&](int sl, int s, int idx) -> uint32_t {
-      if (s < top) return beta3[sl * hn + (1 << s) + idx];
-      return gbe[(size_t)sl * (n - hn) + ((1 << s) - hn) + idx];
-    };
     // result bit `v` of side a1 into byte idx of the stage-s partial sums of slot sl (the other side's bit stays)
-    auto put_beta = [&](int sl, int s, int idx, uint32_t v, int a1) {
+    auto put_beta = [&](int sl, int s, int idx, uint32_t v, int a1) __attribute__((always_inline)) {
       const uint32_t keep = a1 ? 1u : 2u;
       if (s < top) {
         lds_u8* d = beta3 + sl * hn + (1 << s) + idx;
@@ -124,14 +118,54 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
       }
     };
 
-    for (int i = lane; i < L * wstride; i += 64) bits[i] = 0u;
-    for (int i = lane; i < L * 48; i += 64) tab[i] = (unsigned char)(i / 48);
-    float A[R + 1];
-#pragma unroll
-    for (int s = 0; s <= R; ++s) A[s] = 0.f;
+    // four consecutive values (idx a multiple of 4) - the upper stages hold >= 4 values per half
+    auto ld_llr4 = [&](int sl, int s, int idx) __attribute__((always_inline)) -> float4 {
+      if (s == m) {
+        const float4 v = *reinterpret_cast<const float4*>(llr_ch + idx);
+        return make_float4(-v.x, -v.y, -v.z, -v.w);
+      }
+      if (s < top) {
+        const f32x4 v = *(lds_f32x4*)(llr3 + sl * hn + (1 << s) + idx);
+        return make_float4(v.x, v.y, v.z, v.w);
+      }
+      return *reinterpret_cast<const float4*>(gsc + (size_t)sl * (n - hn) + ((1 << s) - hn) + idx);
+    };
+    auto st_llr4 = [&](int sl, int s, int idx, float4 v) __attribute__((always_inline)) {
+      if (s < top) *(lds_f32x4*)(llr3 + sl * hn + (1 << s) + idx) = f32x4{v.x, v.y, v.z, v.w};
+      else *reinterpret_cast<float4*>(gsc + (size_t)sl * (n - hn) + ((1 << s) - hn) + idx) = v;
+    };
+    auto ld_beta4 = [&](int sl, int s, int idx) __attribute__((always_inline)) -> uint32_t {
+      if (s < top) return *(lds_u32*)(beta3 + sl * hn + (1 << s) + idx);
+      return *reinterpret_cast<const uint32_t*>(gbe + (size_t)sl * (n - hn) + ((1 << s) - hn) + idx);
+    };
+    auto put_beta4 = [&](int sl, int s, int idx, uint32_t v, int a1) __attribute__((always_inline)) {   // v: one result bit per byte
+      const uint32_t keep = a1 ? 0x01010101u : 0x02020202u;
+      if (s < top) {
+        lds_u32* d = (lds_u32*)(beta3 + sl * hn + (1 << s) + idx);
+        *d = (*d & keep) | (v << a1);
+      } else {
+        uint32_t* d = reinterpret_cast<uint32_t*>(gbe + (size_t)sl * (n - hn) + ((1 << s) - hn) + idx);
+        *d = (*d & keep) | (v << a1);
+      }
+    };
+
+    for (int i = lane0; i < L * wstride; i += 64) bits[i] = 0u;
+    for (int i = lane0; i < L * 48; i += 64) tab[i] = (unsigned char)(i / 48);
+    // LLRs of the register stages: separate scalars selected by the wave-uniform stage (an indexed array, or
+    // references captured by a lambda, would be placed in scratch memory)
+    float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, A4 = 0.f;
+#define SCL_GETA(s_) ((R >= 4 && (s_) == 4) ? A4 : (R >= 3 && (s_) == 3) ? A3 : (R >= 2 && (s_) == 2) ? A2 : ((s_) == 1) ? A1 : A0)
+#define SCL_SETA(s_, r_)                  \
+  do {                                    \
+    A0 = (s_) == 0 ? (r_) : A0;           \
+    A1 = (s_) == 1 ? (r_) : A1;           \
+    if (R >= 2) A2 = (s_) == 2 ? (r_) : A2; \
+    if (R >= 3) A3 = (s_) == 3 ? (r_) : A3; \
+    if (R >= 4) A4 = (s_) == 4 ? (r_) : A4; \
+  } while (0)
     uint32_t bb = 0u;                                   // bit 2s / 2s+1: left / right child result at stage s, position j
-    float pm = slot == 0 ? 0.f : kPolarLlrMax;          // decoding.py:1029-1033 (first lane of the slot)
-    int pos = slot;
+    float pm = lane0 / W == 0 ? 0.f : kPolarLlrMax;     // decoding.py:1029-1033 (first lane of the slot)
+    int pos = lane0 / W;
     __syncthreads();
 
     int next_rec = p.ops[0];
@@ -140,31 +174,48 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
       next_rec = (ip + 1 < p.num_ops) ? p.ops[ip + 1] : (int)OP_END;
       const int op = rec & 7, s = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = (rec >> 8) - 2048;
       if (op == OP_END) break;
+      // the lane index is made opaque per operation: everything derived from it (slot, position, addresses, lane
+      // predicates) is recomputed with a few VALU operations instead of being hoisted out of the schedule loop into
+      // ~30 registers that live for the whole decode and cost occupancy
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      const int slot = lane / W, j = lane % W;
+      const bool head = j == 0;
       if (op == OP_F || op == OP_G) {
         // inputs at stage s (2^s values), outputs at stage so = s - 1; g uses the left results of stage so
         const int so = s - 1;
-        if (so < R) {
-          stage_switch<R - 1>(so, [&](auto S_) {
-            constexpr int S = decltype(S_)::value;
-            const float x = A[S + 1], y = dpp_up<(1 << S)>(x);
-            if (op == OP_F) A[S] = cn_op(x, y);
-            else A[S] = (1.f - 2.f * (float)((bb >> (2 * S)) & 1u)) * x + y;        // vn_op :707-714
-          });
-        } else if (so == R) {
-          const int si = (s == m) ? 0 : (int)tab[slot * 48 + s];
-          const float x = ld_llr(si, s, j), y = ld_llr(si, s, j + H);
-          if (op == OP_F) A[R] = cn_op(x, y);
-          else A[R] = (1.f - 2.f * (float)((bb >> (2 * R)) & 1u)) * x + y;
+        if (so <= R) {
+          // one instance of the arithmetic for all register stages: only the operand fetch depends on the stage
+          float x = 0.f, y = 0.f;
+          if (so < R) {
+            x = SCL_GETA(s);
+            stage_switch<R - 1>(so, [&](auto S_) __attribute__((always_inline)) { y = dpp_up<(1 << decltype(S_)::value)>(x); });
+          } else {
+            const int si = (int)tab[slot * 48 + s];
+            x = ld_llr(si, s, j);
+            y = ld_llr(si, s, j + H);
+          }
+          float r;
+          if (op == OP_F) r = cn_op(x, y);
+          else r = (1.f - 2.f * (float)((bb >> (2 * so)) & 1u)) * x + y;             // vn_op :707-714
+          SCL_SETA(so, r);
         } else {
           const int half = 1 << so;
-          for (int w = lane; w < L * half; w += 64) {
-            const int sl = w >> so, jj = w & (half - 1);
+          for (int w = lane; w < L * half / 4; w += 64) {     // four outputs per lane
+            const int e = w * 4, sl = e >> so, jj = e & (half - 1);
             const int si = (s == m) ? 0 : (int)tab[sl * 48 + s];
-            const float x = ld_llr(si, s, jj), y = ld_llr(si, s, jj + half);
-            float r;
-            if (op == OP_F) r = cn_op(x, y);
-            else r = (1.f - 2.f * (float)(ld_beta(tab[sl * 48 + 16 + so], so, jj) & 1u)) * x + y;
-            st_llr(sl, so, jj, r);
+            const float4 x = ld_llr4(si, s, jj), y = ld_llr4(si, s, jj + half);
+            float4 r;
+            if (op == OP_F) {
+              r = make_float4(cn_op(x.x, y.x), cn_op(x.y, y.y), cn_op(x.z, y.z), cn_op(x.w, y.w));
+            } else {
+              const uint32_t lb = ld_beta4(tab[sl * 48 + 16 + so], so, jj);
+              r.x = (1.f - 2.f * (float)(lb & 1u)) * x.x + y.x;
+              r.y = (1.f - 2.f * (float)((lb >> 8) & 1u)) * x.y + y.y;
+              r.z = (1.f - 2.f * (float)((lb >> 16) & 1u)) * x.z + y.z;
+              r.w = (1.f - 2.f * (float)((lb >> 24) & 1u)) * x.w + y.w;
+            }
+            st_llr4(sl, so, jj, r);
           }
           if (lane < L) tab[lane * 48 + so] = (unsigned char)lane;
           __syncthreads();
@@ -172,7 +223,7 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
       } else if (op == OP_COMBINE) {
         // children results at stage s -> this node's result at stage s + 1 on side a1: (l ^ r, r)
         if (s < R) {
-          stage_switch<R - 1>(s, [&](auto S_) {
+          stage_switch<R - 1>(s, [&](auto S_) __attribute__((always_inline)) {
             constexpr int S = decltype(S_)::value, sz = 1 << S;
             const uint32_t l = (bb >> (2 * S)) & 1u, r = (bb >> (2 * S + 1)) & 1u;
             const uint32_t hi = (uint32_t)dpp_down_i<sz>((int)r);
@@ -188,12 +239,12 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
           __syncthreads();
         } else {
           const int sz = 1 << s;
-          for (int w = lane; w < L * sz; w += 64) {
-            const int sl = w >> s, jj = w & (sz - 1);
-            const uint32_t l = ld_beta(tab[sl * 48 + 16 + s], s, jj) & 1u;
-            const uint32_t r = (ld_beta(tab[sl * 48 + 32 + s], s, jj) >> 1) & 1u;
-            put_beta(sl, s + 1, jj, l ^ r, a1);
-            put_beta(sl, s + 1, sz + jj, r, a1);
+          for (int w = lane; w < L * sz / 4; w += 64) {       // four positions per lane, one bit per byte
+            const int e = w * 4, sl = e >> s, jj = e & (sz - 1);
+            const uint32_t l = ld_beta4(tab[sl * 48 + 16 + s], s, jj) & 0x01010101u;
+            const uint32_t r = (ld_beta4(tab[sl * 48 + 32 + s], s, jj) >> 1) & 0x01010101u;
+            put_beta4(sl, s + 1, jj, l ^ r, a1);
+            put_beta4(sl, s + 1, sz + jj, r, a1);
           }
           if (lane < L) tab[lane * 48 + (a1 ? 32 : 16) + s + 1] = (unsigned char)lane;
           __syncthreads();
@@ -204,15 +255,16 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
         // block metrics of the slot in its first lane: m0 = sum softplus(-l), m1 = sum softplus(+l)
         float m0 = 0.f, m1 = 0.f;
         if (s <= R) {
-          stage_switch<R>(s, [&](auto S_) {
-            constexpr int S = decltype(S_)::value, sz = 1 << S;
-            const float l = clampf(A[S], -kPolarLlrMax, kPolarLlrMax);
-            const float tl = scl_T(fabsf(l));                 // shared by softplus(-l) and softplus(l)
-            float t0 = fmaxf(-l, 0.f) + tl, t1 = fmaxf(l, 0.f) + tl;
-            if (j >= sz) { t0 = 0.f; t1 = 0.f; }
-            m0 = slot_tree<S>(t0);
-            if (info) m1 = slot_tree<S>(t1);
-          });
+          const float l = clampf(SCL_GETA(s), -kPolarLlrMax, kPolarLlrMax);
+          const float tl = scl_T(fabsf(l));                   // shared by softplus(-l) and softplus(l)
+          m0 = fmaxf(-l, 0.f) + tl;
+          m1 = fmaxf(l, 0.f) + tl;
+          if (j >= (1 << s)) { m0 = 0.f; m1 = 0.f; }
+          // halving tree of scl_math.h over the 2^s lanes of the slot (steps over absent lanes would add zeros)
+          if (R >= 4 && s >= 4) { m0 += dpp_up<8>(m0); m1 += dpp_up<8>(m1); }
+          if (R >= 3 && s >= 3) { m0 += dpp_up<4>(m0); m1 += dpp_up<4>(m1); }
+          if (R >= 2 && s >= 2) { m0 += dpp_up<2>(m0); m1 += dpp_up<2>(m1); }
+          if (s >= 1) { m0 += dpp_up<1>(m0); m1 += dpp_up<1>(m1); }
         } else {
           const int sz = 1 << s;
           for (int sl = 0; sl < L; ++sl) {
@@ -254,7 +306,7 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
               rank += (vd[t] < me || (vd[t] == me && cd < cme)) ? 1 : 0;
             }
           } else {
-#pragma unroll
+#pragma unroll 8
             for (int t = 0; t < PER; ++t) {
               const int d = q * PER + t;
               const float vd = cv[d];
@@ -283,10 +335,13 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
           }
           if (any) {
             const int addr = srcl << 2;
-#pragma unroll
-            for (int k = 1; k <= R; ++k) A[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(A[k])));
+            auto pull = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+            A1 = pull(A1);
+            if (R >= 2) A2 = pull(A2);
+            if (R >= 3) A3 = pull(A3);
+            if (R >= 4) A4 = pull(A4);
             bb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bb);
-            const float pc1 = __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(c1)));
+            const float pc1 = pull(c1);
             const int pr1 = __builtin_amdgcn_ds_bpermute(addr, r1);
             if (srcl != lane) {
               npm = pc1;
@@ -312,9 +367,9 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
           bb = (bb & ~(1u << sh)) | (nb << sh);
         } else {
           const int sz = 1 << s;
-          for (int w = lane; w < L * sz; w += 64) {
-            const int sl = w >> s, jj = w & (sz - 1);
-            put_beta(sl, s, jj, (uint32_t)((ones >> (sl * W)) & 1ull), a1);
+          for (int w = lane; w < L * sz / 4; w += 64) {
+            const int e = w * 4, sl = e >> s, jj = e & (sz - 1);
+            put_beta4(sl, s, jj, (uint32_t)((ones >> (sl * W)) & 1ull) * 0x01010101u, a1);
           }
           if (lane < L) tab[lane * 48 + (a1 ? 32 : 16) + s] = (unsigned char)lane;
         }
@@ -322,7 +377,8 @@ __global__ __launch_bounds__(64) void polar_scl_reg_kernel(SclArgs p) {
       }
     }
     // ---- final selection (decoding.py:1396-1419): CRC over the info bits of every path, penalty, first min
-    if (head) { pm_s[pos] = pm; order[pos] = slot; }
+    const int lane = lane0;
+    if (lane % W == 0) { pm_s[pos] = pm; order[pos] = lane / W; }
     __syncthreads();
     if (lane < L) {
       const uint32_t* bw = bits + (size_t)order[lane] * wstride;
@@ -390,5 +446,8 @@ int scl_reg_launch(const SclArgs& p, int grid, hipStream_t stream) {
   set_error("list size not supported by the register engine");
   return SAMD_ERR_UNSUPPORTED;
 }
+
+#undef SCL_GETA
+#undef SCL_SETA
 
 }  // namespace samd

@@ -20,27 +20,36 @@
 
 namespace samd {
 
+// fma(a, b, K) with the constant as the instruction's literal (v_fmaak_f32): the 15 coefficients of T would
+// otherwise be hoisted into 15 scalar registers of kernels that are already short of them
+template <uint32_t K>
+__device__ __forceinline__ float fma_lit(float a, float b) {
+  float d;
+  asm("v_fmaak_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "n"(K));
+  return d;
+}
+
 __device__ __forceinline__ float scl_T(float a) {
   const float t = a * -1.44269504f;
   const float r = __builtin_rintf(t);
   const float f = t - r;
   float p = __uint_as_float(0x392209c5u);
-  p = __builtin_fmaf(p, f, __uint_as_float(0x3aaf8448u));
-  p = __builtin_fmaf(p, f, __uint_as_float(0x3c1d952au));
-  p = __builtin_fmaf(p, f, __uint_as_float(0x3d6357b6u));
-  p = __builtin_fmaf(p, f, __uint_as_float(0x3e75fdf0u));
-  p = __builtin_fmaf(p, f, __uint_as_float(0x3f317218u));
+  p = fma_lit<0x3aaf8448u>(p, f);
+  p = fma_lit<0x3c1d952au>(p, f);
+  p = fma_lit<0x3d6357b6u>(p, f);
+  p = fma_lit<0x3e75fdf0u>(p, f);
+  p = fma_lit<0x3f317218u>(p, f);
   p = __builtin_fmaf(p, f, 1.0f);
   const float e = __builtin_ldexpf(p, (int)r);
   float q = __uint_as_float(0x3ba7f8dcu);
-  q = __builtin_fmaf(q, e, __uint_as_float(0xbcee2cbcu));
-  q = __builtin_fmaf(q, e, __uint_as_float(0x3d9ec0c1u));
-  q = __builtin_fmaf(q, e, __uint_as_float(0xbe0b497au));
-  q = __builtin_fmaf(q, e, __uint_as_float(0x3e4358e6u));
-  q = __builtin_fmaf(q, e, __uint_as_float(0xbe7e5082u));
-  q = __builtin_fmaf(q, e, __uint_as_float(0x3eaa96bau));
-  q = __builtin_fmaf(q, e, __uint_as_float(0xbeffff46u));
-  q = __builtin_fmaf(q, e, __uint_as_float(0x3f7fffffu));
+  q = fma_lit<0xbcee2cbcu>(q, e);
+  q = fma_lit<0x3d9ec0c1u>(q, e);
+  q = fma_lit<0xbe0b497au>(q, e);
+  q = fma_lit<0x3e4358e6u>(q, e);
+  q = fma_lit<0xbe7e5082u>(q, e);
+  q = fma_lit<0x3eaa96bau>(q, e);
+  q = fma_lit<0xbeffff46u>(q, e);
+  q = fma_lit<0x3f7fffffu>(q, e);
   return e * q;
 }
 

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {   # key -> (substring of the kernel name, unit, source file)
     "ldpc5g_ms": ("ldpc5g_decode_ms_kernel", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
     "ldpc5g_bp": ("ldpc5g_decode_bp_kernel", "decode", "sionna_amd/csrc/ldpc5g_onchip_bp.hip"),
-    "polar_scl": ("polar_scl_kernel", "decode", "sionna_amd/csrc/polar.hip"),
+    "polar_scl": ("polar_scl_reg_kernel", "decode", "sionna_amd/csrc/polar_scl_reg.hip"),
     "ofdm_lmmse": ("ofdm_lmmse_diag_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
 }
 
