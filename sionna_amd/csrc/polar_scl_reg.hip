@@ -79,15 +79,16 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
   constexpr int W = SclRegLayout<L>::W, R = SclRegLayout<L>::R, H = SclRegLayout<L>::H;
   static_assert(H == W && W >= 2 && W <= 16, "lanes of a slot = values of its top register stage");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = p.n, m = p.m, lane0 = threadIdx.x;
+  const int n = p.n, m = p.m;
+  const unsigned lane0 = threadIdx.x;
   const int top = m - p.gstages;                       // stages (R, top) in LDS, [top, m) in L2 scratch, m = channel
   const int hn = 1 << top;
   const int wstride = (((n + 31) / 32 + 3) / 4) * 4, wq = wstride / 4;
   // fixed-size arrays first (compile-time LDS offsets), the arrays sized by n and the L2 split last
   unsigned char* tab = reinterpret_cast<unsigned char*>(smem);               // [L][3][16] slot holding the stage-s
-  float* cv = reinterpret_cast<float*>(tab + (size_t)L * 48);                // LLRs / left sums / right sums; [2L] candidates
-  int* cp = reinterpret_cast<int*>(cv + 2 * L);                              // [L] position of a slot
-  float* pm_s = reinterpret_cast<float*>(cp + L);                            // [L] final metrics by position
+  uint2* ck = reinterpret_cast<uint2*>(tab + (size_t)L * 48);                // LLRs / left sums / right sums; [2L] sort keys
+  float* cv = reinterpret_cast<float*>(ck + 2 * L);                          // [L] penalised final metrics
+  float* pm_s = cv + L;                                                      // [L] final metrics by position
   int* order = reinterpret_cast<int*>(pm_s + L);                             // [L] position -> slot
   float* blk = reinterpret_cast<float*>(order + L);                          // [2L]
   uint32_t* bits = reinterpret_cast<uint32_t*>(blk + 2 * L);                 // [L][wstride] decided u bits
@@ -177,9 +178,9 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
       // the lane index is made opaque per operation: everything derived from it (slot, position, addresses, lane
       // predicates) is recomputed with a few VALU operations instead of being hoisted out of the schedule loop into
       // ~30 registers that live for the whole decode and cost occupancy
-      int lane = lane0;
+      unsigned lane = lane0;
       asm volatile("" : "+v"(lane));
-      const int slot = lane / W, j = lane % W;
+      const unsigned slot = lane / W, j = lane % W;
       const bool head = j == 0;
       if (op == OP_F || op == OP_G) {
         // inputs at stage s (2^s values), outputs at stage so = s - 1; g uses the left results of stage so
@@ -287,31 +288,31 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           pm += m0;                                           // frozen leaf / rate-0: all-zero block
         } else {
           // ---- fork: candidate (u, slot) has metric pm + m_u and sort index u L + position (stable sort, :1345-1390)
+          // The 2L sort keys are exchanged through LDS as 64-bit integers (metric bits : sort index) - metrics are
+          // sums of non-negative terms, so their bit patterns order like the numbers - and one unsigned 64-bit compare
+          // is the "smaller metric, ties by index" rule.
           const float c0 = pm + m0, c1 = pm + m1;
-          if (head) { cv[slot] = c0; cv[L + slot] = c1; cp[slot] = pos; }
+          if (head) {
+            ck[slot] = make_uint2((uint32_t)pos, __float_as_uint(c0));
+            ck[L + slot] = make_uint2((uint32_t)(L + pos), __float_as_uint(c1));
+          }
           __syncthreads();
           constexpr int G2 = W / 2, PER = (2 * L) / G2;       // lanes per candidate, comparisons per lane
-          const int u = j & 1, q = j >> 1;
-          const float me = cv[u * L + slot];
-          const int cme = u * L + cp[slot];
+          const unsigned u = j & 1u, q = j >> 1;
+          const uint2 me2 = ck[u * L + slot];
+          const unsigned long long me = ((unsigned long long)me2.y << 32) | me2.x;
           int rank = 0;
           if constexpr (PER == 4) {
-            const float4 v4 = reinterpret_cast<const float4*>(cv)[q];
-            const int4 p4 = reinterpret_cast<const int4*>(cp)[q & (L / 4 - 1)];
-            const float vd[4] = {v4.x, v4.y, v4.z, v4.w};
-            const int pd[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-              const int cd = (q * 4 >= L ? L : 0) + pd[t];
-              rank += (vd[t] < me || (vd[t] == me && cd < cme)) ? 1 : 0;
-            }
+            const uint4 a = reinterpret_cast<const uint4*>(ck)[2 * q], c = reinterpret_cast<const uint4*>(ck)[2 * q + 1];
+            rank += ((((unsigned long long)a.y << 32) | a.x) < me) ? 1 : 0;
+            rank += ((((unsigned long long)a.w << 32) | a.z) < me) ? 1 : 0;
+            rank += ((((unsigned long long)c.y << 32) | c.x) < me) ? 1 : 0;
+            rank += ((((unsigned long long)c.w << 32) | c.z) < me) ? 1 : 0;
           } else {
 #pragma unroll 8
             for (int t = 0; t < PER; ++t) {
-              const int d = q * PER + t;
-              const float vd = cv[d];
-              const int cd = (d >= L ? L : 0) + cp[d & (L - 1)];
-              rank += (vd < me || (vd == me && cd < cme)) ? 1 : 0;
+              const uint2 d2 = ck[q * PER + t];
+              rank += ((((unsigned long long)d2.y << 32) | d2.x) < me) ? 1 : 0;
             }
           }
           if constexpr (W >= 16) rank += dpp_up_i<8>(rank);
@@ -319,9 +320,9 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           if constexpr (W >= 4) rank += dpp_up_i<2>(rank);
           const int r0 = rank, r1 = dpp_up_i<1>(rank);        // first lane of the slot: ranks of (0, slot), (1, slot)
           const bool stay0 = r0 < L, stay1 = r1 < L;
-          unsigned long long md = __ballot(head && !stay0 && !stay1);       // slots without survivor
-          unsigned long long mb = __ballot(head && stay0 && stay1);         // slots with two survivors
-          unsigned long long m1mask = __ballot(head && !stay0 && stay1);    // slots that continue with u = 1
+          unsigned long long md = __builtin_amdgcn_ballot_w64(head && !stay0 && !stay1);     // slots without survivor
+          unsigned long long mb = __builtin_amdgcn_ballot_w64(head && stay0 && stay1);       // slots with two survivors
+          unsigned long long m1mask = __builtin_amdgcn_ballot_w64(head && !stay0 && stay1);  // slots that continue with u = 1
           float npm = stay0 ? c0 : c1;
           int npos = stay0 ? r0 : r1;
           int srcl = lane;
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
               npm = pc1;
               npos = pr1;
               // decided bits and the pointer tables of the upper stages (lazy copy of everything above stage R)
-              const int ssl = srcl / W;
+              const unsigned ssl = (unsigned)srcl / W;
               uint4* bw = reinterpret_cast<uint4*>(bits);
               for (int e = j; e < wq; e += W) bw[slot * wq + e] = bw[ssl * wq + e];
               uint4* tw = reinterpret_cast<uint4*>(tab);
@@ -424,7 +425,7 @@ size_t scl_reg_lds_bytes(int n, int L) {
   int m = 0;
   while ((1 << m) < n) ++m;
   const size_t hn = (size_t)1 << (m - scl_gstages(n));
-  return (size_t)L * hn * 5 + (size_t)L * scl_reg_wstride(n) * 4 + (size_t)L * 48 + (size_t)L * 4 * 8 + 64;
+  return (size_t)L * hn * 5 + (size_t)L * scl_reg_wstride(n) * 4 + (size_t)L * 48 + (size_t)L * 4 * 10 + 64;
 }
 
 template <int L>
