@@ -464,7 +464,9 @@ int samd_polar_encode_f32(const float* u, const int32_t* info_pos, const int32_t
 /* PolarSCDecoder / PolarSCLDecoder (default TF path, fast SCL)  fec/polar/decoding.py:122-263,
  * 525-723, 919-1045, 1345-1437.  llr [batch,n] logits (n <= 1024); ops DEVICE int32[num_ops]
  * packed decoding schedule built by the host (sionna_amd/phy/fec/polar/decoding.py::
- * build_schedule: op | stage<<3 | side<<7 | (bit_index+2048)<<8); info_pos
+ * build_schedule / pack_schedule: op | stage<<3 | side<<7 | (bit_index+2048)<<8 with op 0 f, 1 g,
+ * 2 leaf, 3 rate-0, 4 repetition, 5 combine, 6 end, 7 = a stage-1 node of two information leaves
+ * (f, leaf bit_index, g, leaf bit_index+1, combine onto `side`) as one operation); info_pos
  * DEVICE int32[k]; iil_inv nullable DEVICE int32[k] (inverse input interleaver applied before the
  * CRC check); sc_mode=1 -> hard SC decisions (list_size must be 1); crc_len=0 disables the
  * CRC-aided selection.  u_hat [batch,k]; crc_status nullable [batch].  workspace: caller-owned

@@ -127,9 +127,25 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
     __syncthreads();
 
     int next_rec = p.ops[0];
-    for (int ip = 0;; ++ip) {
-      const int rec = next_rec;
-      next_rec = (ip + 1 < p.num_ops) ? p.ops[ip + 1] : (int)OP_END;
+    int fused = 0, micro = 0;                               // a fused stage-1 node (OP_NODE2) and its pending parts
+    for (int ip = 0;;) {
+      int rec;
+      if (micro == 0) {
+        rec = next_rec;
+        ++ip;
+        next_rec = (ip < p.num_ops) ? p.ops[ip] : (int)OP_END;
+        if ((rec & 7) == OP_NODE2) { fused = rec; micro = 5; }
+      }
+      if (micro > 0) {
+        // f, leaf (bit a2), g, leaf (bit a2 + 1), combine - the five operations pack_schedule fused
+        const int part = 5 - micro, fa1 = (fused >> 7) & 1, fa2 = (fused >> 8) - 2048;
+        --micro;
+        rec = part == 0   ? (OP_F | (1 << 3))
+              : part == 1 ? (OP_LEAF | ((fa2 + 2048) << 8))
+              : part == 2 ? (OP_G | (1 << 3))
+              : part == 3 ? (OP_LEAF | (1 << 7) | ((fa2 + 1 + 2048) << 8))
+                          : (OP_COMBINE | (fa1 << 7));
+      }
       const int op = rec & 7, a0 = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = (rec >> 8) - 2048;
       if (op == OP_END) break;
       if (op == OP_F || op == OP_G) {

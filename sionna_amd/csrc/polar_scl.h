@@ -17,7 +17,7 @@ __device__ __forceinline__ uint32_t crc_step(uint32_t reg, uint32_t bit, uint32_
 }
 
 
-enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6 };
+enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6, OP_NODE2 = 7 };
 constexpr float kPolarLlrMax = 30.f;
 
 // Metric arithmetic: scl_math.h (float32 operations in a defined order, restated by the CPU oracle

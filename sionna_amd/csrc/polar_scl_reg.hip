@@ -182,7 +182,104 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
       asm volatile("" : "+v"(lane));
       const unsigned slot = lane / W, j = lane % W;
       const bool head = j == 0;
-      if (op == OP_F || op == OP_G) {
+      // ---- fork of every path at an information bit: candidate (u, slot) has metric pm + m_u and sort index
+      // u L + position (stable sort, :1345-1390); returns the slots (bit = first lane) whose decided bit is 1
+      auto fork = [&](float m0, float m1, int bit_index) __attribute__((always_inline)) -> unsigned long long {
+        // The 2L sort keys are exchanged through LDS as 64-bit integers (metric bits : sort index) - metrics are
+        // sums of non-negative terms, so their bit patterns order like the numbers - and one unsigned 64-bit compare
+        // is the "smaller metric, ties by index" rule.
+        const float c0 = pm + m0, c1 = pm + m1;
+        if (head) {
+          ck[slot] = make_uint2((uint32_t)pos, __float_as_uint(c0));
+          ck[L + slot] = make_uint2((uint32_t)(L + pos), __float_as_uint(c1));
+        }
+        __syncthreads();
+        constexpr int G2 = W / 2, PER = (2 * L) / G2;       // lanes per candidate, comparisons per lane
+        const unsigned u = j & 1u, q = j >> 1;
+        const uint2 me2 = ck[u * L + slot];
+        const unsigned long long me = ((unsigned long long)me2.y << 32) | me2.x;
+        int rank = 0;
+        if constexpr (PER == 4) {
+          const uint4 a = reinterpret_cast<const uint4*>(ck)[2 * q], c = reinterpret_cast<const uint4*>(ck)[2 * q + 1];
+          rank += ((((unsigned long long)a.y << 32) | a.x) < me) ? 1 : 0;
+          rank += ((((unsigned long long)a.w << 32) | a.z) < me) ? 1 : 0;
+          rank += ((((unsigned long long)c.y << 32) | c.x) < me) ? 1 : 0;
+          rank += ((((unsigned long long)c.w << 32) | c.z) < me) ? 1 : 0;
+        } else {
+#pragma unroll 8
+          for (int t = 0; t < PER; ++t) {
+            const uint2 d2 = ck[q * PER + t];
+            rank += ((((unsigned long long)d2.y << 32) | d2.x) < me) ? 1 : 0;
+          }
+        }
+        if constexpr (W >= 16) rank += dpp_up_i<8>(rank);
+        if constexpr (W >= 8) rank += dpp_up_i<4>(rank);
+        if constexpr (W >= 4) rank += dpp_up_i<2>(rank);
+        const int r0 = rank, r1 = dpp_up_i<1>(rank);        // first lane of the slot: ranks of (0, slot), (1, slot)
+        const bool stay0 = r0 < L, stay1 = r1 < L;
+        unsigned long long md = __builtin_amdgcn_ballot_w64(head && !stay0 && !stay1);     // slots without survivor
+        unsigned long long mb = __builtin_amdgcn_ballot_w64(head && stay0 && stay1);       // slots with two survivors
+        unsigned long long m1mask = __builtin_amdgcn_ballot_w64(head && !stay0 && stay1);  // slots that continue with u = 1
+        float npm = stay0 ? c0 : c1;
+        int npos = stay0 ? r0 : r1;
+        int srcl = lane;
+        const bool any = md != 0ull;
+        while (md != 0ull && mb != 0ull) {                  // the i-th dead slot takes the second child of the i-th
+          const int d = __builtin_ctzll(md), sp = __builtin_ctzll(mb);   // slot with two survivors
+          md &= md - 1ull;
+          mb &= mb - 1ull;
+          if ((lane & ~(W - 1)) == d) srcl = sp + j;
+          m1mask |= 1ull << d;
+        }
+        if (any) {
+          const int addr = srcl << 2;
+          auto pull = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+          A1 = pull(A1);
+          if (R >= 2) A2 = pull(A2);
+          if (R >= 3) A3 = pull(A3);
+          if (R >= 4) A4 = pull(A4);
+          bb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bb);
+          const float pc1 = pull(c1);
+          const int pr1 = __builtin_amdgcn_ds_bpermute(addr, r1);
+          if (srcl != lane) {
+            npm = pc1;
+            npos = pr1;
+            // decided bits and the pointer tables of the upper stages (lazy copy of everything above stage R)
+            const unsigned ssl = (unsigned)srcl / W;
+            uint4* bw = reinterpret_cast<uint4*>(bits);
+            for (int e = j; e < wq; e += W) bw[slot * wq + e] = bw[ssl * wq + e];
+            uint4* tw = reinterpret_cast<uint4*>(tab);
+            for (int e = j; e < 3; e += W) tw[slot * 3 + e] = tw[ssl * 3 + e];
+          }
+          __syncthreads();
+        }
+        pm = npm;
+        pos = npos;
+        if (head && ((m1mask >> lane) & 1ull)) bits[slot * wstride + (bit_index >> 5)] |= 1u << (bit_index & 31);
+        return m1mask;
+      };
+      if (op == OP_NODE2) {
+        // A stage-1 node with two information leaves: f, leaf, g, leaf, combine in one operation (a2 = index of the
+        // first bit, a1 = side of the node's result) - 44 % of the schedule of a rate-1/2 n = 1024 code is made of
+        // these five-operation groups (pack_schedule fuses them).
+#pragma unroll 1
+        for (int h = 0; h < 2; ++h) {
+          const float x = A1, y = dpp_up<1>(x);             // re-read: the first fork may have replaced the slot's registers
+          float v;
+          if (h == 0) v = cn_op(x, y);
+          else v = (1.f - 2.f * (float)(bb & 1u)) * x + y;                            // vn_op :707-714
+          const float l = clampf(v, -kPolarLlrMax, kPolarLlrMax);
+          const float tl = scl_T(fabsf(l));
+          const unsigned long long ones = fork(fmaxf(-l, 0.f) + tl, fmaxf(l, 0.f) + tl, a2 + h);
+          const uint32_t nb = (uint32_t)((ones >> (lane & ~(W - 1))) & 1ull);
+          bb = (bb & ~(1u << h)) | (nb << h);               // leaf results: bits 0 / 1 (carried by the clones of the 2nd fork)
+        }
+        // (l ^ r, r) at stage 1: position 0 holds l ^ r, position 1 holds r (the leaf bits are per slot, all its lanes
+        // hold them)
+        const uint32_t nb = (j == 0) ? ((bb ^ (bb >> 1)) & 1u) : ((bb >> 1) & 1u);
+        const int sh = 2 + a1;
+        bb = (bb & ~(1u << sh)) | (nb << sh);
+      } else if (op == OP_F || op == OP_G) {
         // inputs at stage s (2^s values), outputs at stage so = s - 1; g uses the left results of stage so
         const int so = s - 1;
         if (so <= R) {
@@ -201,8 +298,10 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           else r = (1.f - 2.f * (float)((bb >> (2 * so)) & 1u)) * x + y;             // vn_op :707-714
           SCL_SETA(so, r);
         } else {
+          // f of the channel LLRs is the same for every path: computed once, all tables point to slot 0
           const int half = 1 << so;
-          for (int w = lane; w < L * half / 4; w += 64) {     // four outputs per lane
+          const bool shared = s == m && op == OP_F;
+          for (int w = lane; w < (shared ? 1 : L) * half / 4; w += 64) {     // four outputs per lane
             const int e = w * 4, sl = e >> so, jj = e & (half - 1);
             const int si = (s == m) ? 0 : (int)tab[sl * 48 + s];
             const float4 x = ld_llr4(si, s, jj), y = ld_llr4(si, s, jj + half);
@@ -218,7 +317,7 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
             }
             st_llr4(sl, so, jj, r);
           }
-          if (lane < L) tab[lane * 48 + so] = (unsigned char)lane;
+          if (lane < L) tab[lane * 48 + so] = (unsigned char)(shared ? 0 : lane);
           __syncthreads();
         }
       } else if (op == OP_COMBINE) {
@@ -287,79 +386,7 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
         if (!info) {
           pm += m0;                                           // frozen leaf / rate-0: all-zero block
         } else {
-          // ---- fork: candidate (u, slot) has metric pm + m_u and sort index u L + position (stable sort, :1345-1390)
-          // The 2L sort keys are exchanged through LDS as 64-bit integers (metric bits : sort index) - metrics are
-          // sums of non-negative terms, so their bit patterns order like the numbers - and one unsigned 64-bit compare
-          // is the "smaller metric, ties by index" rule.
-          const float c0 = pm + m0, c1 = pm + m1;
-          if (head) {
-            ck[slot] = make_uint2((uint32_t)pos, __float_as_uint(c0));
-            ck[L + slot] = make_uint2((uint32_t)(L + pos), __float_as_uint(c1));
-          }
-          __syncthreads();
-          constexpr int G2 = W / 2, PER = (2 * L) / G2;       // lanes per candidate, comparisons per lane
-          const unsigned u = j & 1u, q = j >> 1;
-          const uint2 me2 = ck[u * L + slot];
-          const unsigned long long me = ((unsigned long long)me2.y << 32) | me2.x;
-          int rank = 0;
-          if constexpr (PER == 4) {
-            const uint4 a = reinterpret_cast<const uint4*>(ck)[2 * q], c = reinterpret_cast<const uint4*>(ck)[2 * q + 1];
-            rank += ((((unsigned long long)a.y << 32) | a.x) < me) ? 1 : 0;
-            rank += ((((unsigned long long)a.w << 32) | a.z) < me) ? 1 : 0;
-            rank += ((((unsigned long long)c.y << 32) | c.x) < me) ? 1 : 0;
-            rank += ((((unsigned long long)c.w << 32) | c.z) < me) ? 1 : 0;
-          } else {
-#pragma unroll 8
-            for (int t = 0; t < PER; ++t) {
-              const uint2 d2 = ck[q * PER + t];
-              rank += ((((unsigned long long)d2.y << 32) | d2.x) < me) ? 1 : 0;
-            }
-          }
-          if constexpr (W >= 16) rank += dpp_up_i<8>(rank);
-          if constexpr (W >= 8) rank += dpp_up_i<4>(rank);
-          if constexpr (W >= 4) rank += dpp_up_i<2>(rank);
-          const int r0 = rank, r1 = dpp_up_i<1>(rank);        // first lane of the slot: ranks of (0, slot), (1, slot)
-          const bool stay0 = r0 < L, stay1 = r1 < L;
-          unsigned long long md = __builtin_amdgcn_ballot_w64(head && !stay0 && !stay1);     // slots without survivor
-          unsigned long long mb = __builtin_amdgcn_ballot_w64(head && stay0 && stay1);       // slots with two survivors
-          unsigned long long m1mask = __builtin_amdgcn_ballot_w64(head && !stay0 && stay1);  // slots that continue with u = 1
-          float npm = stay0 ? c0 : c1;
-          int npos = stay0 ? r0 : r1;
-          int srcl = lane;
-          const bool any = md != 0ull;
-          while (md != 0ull && mb != 0ull) {                  // the i-th dead slot takes the second child of the i-th
-            const int d = __builtin_ctzll(md), sp = __builtin_ctzll(mb);   // slot with two survivors
-            md &= md - 1ull;
-            mb &= mb - 1ull;
-            if ((lane & ~(W - 1)) == d) srcl = sp + j;
-            m1mask |= 1ull << d;
-          }
-          if (any) {
-            const int addr = srcl << 2;
-            auto pull = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
-            A1 = pull(A1);
-            if (R >= 2) A2 = pull(A2);
-            if (R >= 3) A3 = pull(A3);
-            if (R >= 4) A4 = pull(A4);
-            bb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bb);
-            const float pc1 = pull(c1);
-            const int pr1 = __builtin_amdgcn_ds_bpermute(addr, r1);
-            if (srcl != lane) {
-              npm = pc1;
-              npos = pr1;
-              // decided bits and the pointer tables of the upper stages (lazy copy of everything above stage R)
-              const unsigned ssl = (unsigned)srcl / W;
-              uint4* bw = reinterpret_cast<uint4*>(bits);
-              for (int e = j; e < wq; e += W) bw[slot * wq + e] = bw[ssl * wq + e];
-              uint4* tw = reinterpret_cast<uint4*>(tab);
-              for (int e = j; e < 3; e += W) tw[slot * 3 + e] = tw[ssl * 3 + e];
-            }
-            __syncthreads();
-          }
-          pm = npm;
-          pos = npos;
-          ones = m1mask;
-          if (head && ((ones >> lane) & 1ull)) bits[slot * wstride + (a2 >> 5)] |= 1u << (a2 & 31);   // the node's only information bit is its last
+          ones = fork(m0, m1, a2);                            // the node's only information bit is its last
         }
         // the node's result: the all-u codeword
         if (s <= R) {

@@ -56,9 +56,32 @@ def build_schedule(frozen_ind, use_fast=True, use_rep=True):
     return np.asarray(ops, np.int32)
 
 
+OP_NODE2 = 7
+
+
+def fuse_schedule(ops):
+    """Replace every stage-1 node with two information leaves - the five records F(1), LEAF(i), G(1), LEAF(i+1),
+    COMBINE(0, side) - by one NODE2 record (a1 = side, a2 = i).  Same operations in the same order; the kernels
+    save four of five schedule dispatches on what is 44 % of the schedule of a rate-1/2 n = 1024 code."""
+    ops = np.asarray(ops, np.int32)
+    out, i, n = [], 0, len(ops)
+    while i < n:
+        w = ops[i:i + 5]
+        if (len(w) == 5 and w[0, 0] == OP_F and w[0, 1] == 1 and w[1, 0] == OP_LEAF and w[1, 3] >= 0 and w[1, 2] == 0
+                and w[2, 0] == OP_G and w[2, 1] == 1 and w[3, 0] == OP_LEAF and w[3, 3] == w[1, 3] + 1 and w[3, 2] == 1
+                and w[4, 0] == OP_COMBINE and w[4, 1] == 0):
+            out.append((OP_NODE2, 1, w[4, 2], w[1, 3]))
+            i += 5
+        else:
+            out.append(tuple(ops[i]))
+            i += 1
+    return np.asarray(out, np.int32)
+
+
 def pack_schedule(ops):
-    """One int32 per operation: op | stage<<3 | side<<7 | (a2+2048)<<8 (the kernel keeps it in LDS)."""
-    ops = np.asarray(ops, np.int64)
+    """One int32 per operation: op | stage<<3 | side<<7 | (a2+2048)<<8, stage-1 nodes of two information leaves
+    fused (:func:`fuse_schedule`)."""
+    ops = np.asarray(fuse_schedule(ops), np.int64)
     a0 = np.where(ops[:, 0] == OP_LEAF, 0, ops[:, 1])
     return (ops[:, 0] | (a0 << 3) | (ops[:, 2] << 7) | ((ops[:, 3] + 2048) << 8)).astype(np.int32)
 
