@@ -465,13 +465,18 @@ int samd_polar_encode_f32(const float* u, const int32_t* info_pos, const int32_t
  * 525-723, 919-1045, 1345-1437.  llr [batch,n] logits (n <= 1024); ops DEVICE int32[num_ops]
  * packed decoding schedule built by the host (sionna_amd/phy/fec/polar/decoding.py::
  * build_schedule / pack_schedule: op | stage<<3 | side<<7 | (bit_index+2048)<<8 with op 0 f, 1 g,
- * 2 leaf, 3 rate-0, 4 repetition, 5 combine, 6 end, 7 = a stage-1 node of two information leaves
- * (f, leaf bit_index, g, leaf bit_index+1, combine onto `side`) as one operation); info_pos
+ * 2 leaf, 3 rate-0, 4 repetition, 5 combine, 6 end, 7 = a complete subtree of `stage` whose first
+ * bit is bit_index, result onto `side`, bit 20 = fast-SCL shortcuts inside it.  Every engine accepts
+ * subtrees of stage 1 with two information leaves; subtrees of stage R are accepted iff
+ * samd_polar_scl_register_stages(n, list_size, sc_mode) == R (-1: none - the generic engine runs;
+ * R >= 1: the engine whose stages 0..R live in registers decodes such a subtree without further
+ * schedule dispatch, from the frozen pattern it derives from info_pos)); info_pos
  * DEVICE int32[k]; iil_inv nullable DEVICE int32[k] (inverse input interleaver applied before the
  * CRC check); sc_mode=1 -> hard SC decisions (list_size must be 1); crc_len=0 disables the
  * CRC-aided selection.  u_hat [batch,k]; crc_status nullable [batch].  workspace: caller-owned
  * device scratch of samd_polar_scl_workspace_bytes() bytes (top LLR stage of the resident
  * codewords; it lives in L2 so that more codewords fit in LDS). */
+int samd_polar_scl_register_stages(int n, int list_size, int sc_mode);
 size_t samd_polar_scl_workspace_bytes(int batch, int n, int list_size);
 int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
                               const int32_t* iil_inv, int batch, int n, int k, int list_size,

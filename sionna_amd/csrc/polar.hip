@@ -127,14 +127,14 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
     __syncthreads();
 
     int next_rec = p.ops[0];
-    int fused = 0, micro = 0;                               // a fused stage-1 node (OP_NODE2) and its pending parts
+    int fused = 0, micro = 0;                               // a fused stage-1 node (OP_SUBTREE) and its pending parts
     for (int ip = 0;;) {
       int rec;
       if (micro == 0) {
         rec = next_rec;
         ++ip;
         next_rec = (ip < p.num_ops) ? p.ops[ip] : (int)OP_END;
-        if ((rec & 7) == OP_NODE2) { fused = rec; micro = 5; }
+        if ((rec & 7) == OP_SUBTREE) { fused = rec; micro = 5; }
       }
       if (micro > 0) {
         // f, leaf (bit a2), g, leaf (bit a2 + 1), combine - the five operations pack_schedule fused
@@ -423,6 +423,11 @@ extern "C" int samd_polar_encode_f32(const float* u, const int32_t* info_pos, co
   return launch_status();
 }
 
+extern "C" int samd_polar_scl_register_stages(int n, int list_size, int sc_mode) {
+  if (n < 8 || (n & (n - 1)) != 0 || list_size < 1) return -1;
+  return scl_reg_stages(n, list_size, sc_mode);
+}
+
 extern "C" size_t samd_polar_scl_workspace_bytes(int batch, int n, int list_size) {
   if (batch <= 0 || n < 8 || list_size < 1) return 0;
   // float + byte scratch of the top stages: n - n/2^G entries per slot, rounded up to n
@@ -456,9 +461,8 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n), batch, n, m, k, list_size,
             sc_mode, crc_len, crc_poly};
   // list decoding with 4..32 paths: the engine whose low stages live in registers (polar_scl_reg.hip)
-  // (it reads four consecutive LLRs per lane: rows of 16-byte aligned inputs, which n >= 32 floats per row preserves)
-  if (scl_reg_supported(n, list_size, sc_mode) && (reinterpret_cast<uintptr_t>(llr) & 15u) == 0)
-    return scl_reg_launch(p, grid, (hipStream_t)stream);
+  // (samd_polar_scl_register_stages() tells the host which engine runs, i.e. which subtree stage its schedule may use)
+  if (scl_reg_supported(n, list_size, sc_mode)) return scl_reg_launch(p, grid, (hipStream_t)stream);
   // one wave per codeword: the block sums of rate-0 / repetition nodes are defined on 64 lanes (scl_math.h)
   hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
   return launch_status();

@@ -17,7 +17,7 @@ __device__ __forceinline__ uint32_t crc_step(uint32_t reg, uint32_t bit, uint32_
 }
 
 
-enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6, OP_NODE2 = 7 };
+enum { OP_F = 0, OP_G = 1, OP_LEAF = 2, OP_RATE0 = 3, OP_REP = 4, OP_COMBINE = 5, OP_END = 6, OP_SUBTREE = 7 };
 constexpr float kPolarLlrMax = 30.f;
 
 // Metric arithmetic: scl_math.h (float32 operations in a defined order, restated by the CPU oracle
@@ -59,6 +59,7 @@ inline int scl_gstages(int n) {
 
 // polar_scl_reg.hip
 bool scl_reg_supported(int n, int list_size, int sc_mode);
+int scl_reg_stages(int n, int list_size, int sc_mode);   // register stages R of the engine, -1: generic engine
 size_t scl_reg_lds_bytes(int n, int list_size);
 int scl_reg_launch(const SclArgs& p, int grid, hipStream_t stream);
 

@@ -91,13 +91,20 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
   float* pm_s = cv + L;                                                      // [L] final metrics by position
   int* order = reinterpret_cast<int*>(pm_s + L);                             // [L] position -> slot
   float* blk = reinterpret_cast<float*>(order + L);                          // [2L]
-  uint32_t* bits = reinterpret_cast<uint32_t*>(blk + 2 * L);                 // [L][wstride] decided u bits
+  uint32_t* fzb = reinterpret_cast<uint32_t*>(blk + 2 * L);                  // [wstride] frozen-bit map of the code
+  uint32_t* bits = fzb + wstride;                                            // [L][wstride] decided u bits
   float* llr = reinterpret_cast<float*>(bits + (size_t)L * wstride);         // [L][hn]  stage s at [2^s, 2^(s+1))
   unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * hn);   // [L][hn]  bit 0 left, bit 1 right result
   lds_f32* llr3 = (lds_f32*)llr;
   lds_u8* beta3 = (lds_u8*)beta;
+  const bool ch_aligned = (reinterpret_cast<uintptr_t>(p.llr_in) & 15u) == 0;   // rows of n >= 32 floats keep it
   float* gsc = p.gscratch + (size_t)blockIdx.x * L * (n - hn);
   unsigned char* gbe = p.gbeta + (size_t)blockIdx.x * L * (n - hn);
+
+  for (int i = lane0; i < wstride; i += 64) fzb[i] = 0xFFFFFFFFu;
+  __syncthreads();
+  for (int i = lane0; i < p.k; i += 64) atomicAnd(&fzb[p.info_pos[i] >> 5], ~(1u << (p.info_pos[i] & 31)));
+  __syncthreads();
 
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
     const float* llr_ch = p.llr_in + (size_t)b * n;    // logits: negated where they are read (LLR = -logit)
@@ -122,6 +129,7 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
     // four consecutive values (idx a multiple of 4) - the upper stages hold >= 4 values per half
     auto ld_llr4 = [&](int sl, int s, int idx) __attribute__((always_inline)) -> float4 {
       if (s == m) {
+        if (!ch_aligned) return make_float4(-llr_ch[idx], -llr_ch[idx + 1], -llr_ch[idx + 2], -llr_ch[idx + 3]);
         const float4 v = *reinterpret_cast<const float4*>(llr_ch + idx);
         return make_float4(-v.x, -v.y, -v.z, -v.w);
       }
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
     for (int ip = 0;; ++ip) {
       const int rec = next_rec;
       next_rec = (ip + 1 < p.num_ops) ? p.ops[ip + 1] : (int)OP_END;
-      const int op = rec & 7, s = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = (rec >> 8) - 2048;
+      const int op = rec & 7, s = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = ((rec >> 8) & 0xFFF) - 2048;
       if (op == OP_END) break;
       // the lane index is made opaque per operation: everything derived from it (slot, position, addresses, lane
       // predicates) is recomputed with a few VALU operations instead of being hoisted out of the schedule loop into
@@ -258,27 +266,65 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
         if (head && ((m1mask >> lane) & 1ull)) bits[slot * wstride + (bit_index >> 5)] |= 1u << (bit_index & 31);
         return m1mask;
       };
-      if (op == OP_NODE2) {
-        // A stage-1 node with two information leaves: f, leaf, g, leaf, combine in one operation (a2 = index of the
-        // first bit, a1 = side of the node's result) - 44 % of the schedule of a rate-1/2 n = 1024 code is made of
-        // these five-operation groups (pack_schedule fuses them).
-#pragma unroll 1
-        for (int h = 0; h < 2; ++h) {
-          const float x = A1, y = dpp_up<1>(x);             // re-read: the first fork may have replaced the slot's registers
-          float v;
-          if (h == 0) v = cn_op(x, y);
-          else v = (1.f - 2.f * (float)(bb & 1u)) * x + y;                            // vn_op :707-714
-          const float l = clampf(v, -kPolarLlrMax, kPolarLlrMax);
+      // ---- a complete subtree of register stage S: the recursion of decoding.py:919-1005 (rate-0 / repetition
+      // shortcuts when `fast`, else f, left child, g, right child, combine) unrolled at compile time - straight-line
+      // code with wave-uniform branches on the frozen pattern fm (bit i = leaf i frozen), no schedule dispatch
+      auto Aref = [&](auto S_) __attribute__((always_inline)) -> float& {
+        constexpr int S = decltype(S_)::value;
+        if constexpr (S == 0) return A0;
+        else if constexpr (S == 1) return A1;
+        else if constexpr (S == 2) return A2;
+        else if constexpr (S == 3) return A3;
+        else return A4;
+      };
+      auto subtree = [&](auto self, auto S_, uint32_t fm, int first, int side, bool fast) __attribute__((always_inline)) -> void {
+        constexpr int S = decltype(S_)::value, nl = 1 << S;
+        constexpr uint32_t all = (1u << nl) - 1u;
+        auto setres = [&](unsigned long long ones) __attribute__((always_inline)) {   // the node's result: the all-u codeword
+          const int sh = 2 * S + side;
+          bb = (bb & ~(1u << sh)) | ((uint32_t)((ones >> (lane & ~(W - 1))) & 1ull) << sh);
+        };
+        if constexpr (S == 0) {
+          const float l = clampf(A0, -kPolarLlrMax, kPolarLlrMax);
           const float tl = scl_T(fabsf(l));
-          const unsigned long long ones = fork(fmaxf(-l, 0.f) + tl, fmaxf(l, 0.f) + tl, a2 + h);
-          const uint32_t nb = (uint32_t)((ones >> (lane & ~(W - 1))) & 1ull);
-          bb = (bb & ~(1u << h)) | (nb << h);               // leaf results: bits 0 / 1 (carried by the clones of the 2nd fork)
+          const float m0 = fmaxf(-l, 0.f) + tl;
+          if (fm & 1u) { pm += m0; setres(0ull); }
+          else setres(fork(m0, fmaxf(l, 0.f) + tl, first));
+        } else {
+          if (fast && (fm == all || fm == (all >> 1))) {
+            const float l = clampf(Aref(S_), -kPolarLlrMax, kPolarLlrMax);
+            const float tl = scl_T(fabsf(l));
+            float t0 = fmaxf(-l, 0.f) + tl, t1 = fmaxf(l, 0.f) + tl;
+            if (j >= (unsigned)nl) { t0 = 0.f; t1 = 0.f; }
+            const float m0 = slot_tree<S>(t0);
+            if (fm == all) { pm += m0; setres(0ull); }                                  // rate-0
+            else setres(fork(m0, slot_tree<S>(t1), first + nl - 1));                    // repetition: the last bit
+          } else {
+            constexpr std::integral_constant<int, S - 1> C_{};
+            {
+              const float x = Aref(S_), y = dpp_up<nl / 2>(x);
+              Aref(C_) = cn_op(x, y);
+            }
+            self(self, C_, fm & (all >> (nl / 2)), first, 0, fast);
+            {
+              const float x = Aref(S_), y = dpp_up<nl / 2>(x);   // re-read: forks replace the registers of dead slots
+              Aref(C_) = (1.f - 2.f * (float)((bb >> (2 * (S - 1))) & 1u)) * x + y;     // vn_op :707-714
+            }
+            self(self, C_, fm >> (nl / 2), first + nl / 2, 1, fast);
+            const uint32_t l = (bb >> (2 * (S - 1))) & 1u, r = (bb >> (2 * (S - 1) + 1)) & 1u;
+            const uint32_t hi = (uint32_t)dpp_down_i<nl / 2>((int)r);
+            const uint32_t nb = (j < (unsigned)(nl / 2)) ? (l ^ r) : hi;
+            const int sh = 2 * S + side;
+            bb = (bb & ~(1u << sh)) | (nb << sh);
+          }
         }
-        // (l ^ r, r) at stage 1: position 0 holds l ^ r, position 1 holds r (the leaf bits are per slot, all its lanes
-        // hold them)
-        const uint32_t nb = (j == 0) ? ((bb ^ (bb >> 1)) & 1u) : ((bb >> 1) & 1u);
-        const int sh = 2 + a1;
-        bb = (bb & ~(1u << sh)) | (nb << sh);
+      };
+      if (op == OP_SUBTREE) {
+        // a2 = index of the subtree's first bit; stage R (pack_schedule for this engine) or 1 (two information leaves)
+        const uint32_t word = fzb[a2 >> 5] >> (a2 & 31);
+        const bool fast = (rec >> 20) & 1;
+        if (s == R) subtree(subtree, std::integral_constant<int, R>{}, word & ((1u << (1 << R)) - 1u), a2, a1, fast);
+        else subtree(subtree, std::integral_constant<int, 1>{}, word & 3u, a2, a1, fast);
       } else if (op == OP_F || op == OP_G) {
         // inputs at stage s (2^s values), outputs at stage so = s - 1; g uses the left results of stage so
         const int so = s - 1;
@@ -439,20 +485,22 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
   }
 }
 
-bool scl_reg_supported(int n, int list_size, int sc_mode) {
-  if (sc_mode || getenv("SAMD_SCL_GENERIC")) return false;
-  if (list_size != 4 && list_size != 8 && list_size != 16 && list_size != 32) return false;
+int scl_reg_stages(int n, int list_size, int sc_mode) {
+  if (sc_mode || getenv("SAMD_SCL_GENERIC")) return -1;
+  if (list_size != 4 && list_size != 8 && list_size != 16 && list_size != 32) return -1;
   int m = 0;
   while ((1 << m) < n) ++m;
   const int w = 64 / list_size, r = w >= 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;
-  return m >= r + 2 && n <= 1024;
+  return (m >= r + 2 && n <= 1024) ? r : -1;
 }
+
+bool scl_reg_supported(int n, int list_size, int sc_mode) { return scl_reg_stages(n, list_size, sc_mode) >= 0; }
 
 size_t scl_reg_lds_bytes(int n, int L) {
   int m = 0;
   while ((1 << m) < n) ++m;
   const size_t hn = (size_t)1 << (m - scl_gstages(n));
-  return (size_t)L * hn * 5 + (size_t)L * scl_reg_wstride(n) * 4 + (size_t)L * 48 + (size_t)L * 4 * 10 + 64;
+  return (size_t)L * hn * 5 + (size_t)L * scl_reg_wstride(n) * 4 + (size_t)L * 48 + (size_t)L * 4 * 10 + scl_reg_wstride(n) * 4 + 64;
 }
 
 template <int L>

@@ -16,10 +16,10 @@ from ...block import Block
 from ..crc import CRCEncoder, CRCDecoder, crc_poly_mask
 from .encoding import Polar5GEncoder, _channel_pattern, _subblock_pattern, _input_pattern
 
-OP_F, OP_G, OP_LEAF, OP_RATE0, OP_REP, OP_COMBINE, OP_END = range(7)
+OP_F, OP_G, OP_LEAF, OP_RATE0, OP_REP, OP_COMBINE, OP_END, OP_SUBTREE = range(8)
 
 
-def build_schedule(frozen_ind, use_fast=True, use_rep=True):
+def build_schedule(frozen_ind, use_fast=True, use_rep=True, subtree_stage=None):
     """Flatten the SC(L) decoding recursion into [num_ops, 4] int32 records (op, a0, a1, a2).
 
     F/G:      a0 = stage s of the inputs (outputs go to stage s-1)
@@ -27,6 +27,9 @@ def build_schedule(frozen_ind, use_fast=True, use_rep=True):
     RATE0:    a0 = stage, a1 = side
     REP:      a0 = stage, a1 = side, a2 = index of the node's only information bit (its last)
     COMBINE:  a0 = stage of the two children, a1 = side of the parent
+    SUBTREE:  a0 = stage, a1 = side, a2 = index of its first bit (+4096 when the fast-SCL shortcuts apply inside):
+              the whole node as ONE record - emitted for every node of stage ``subtree_stage`` (the engine whose low
+              stages live in registers decodes it from the frozen pattern, ``samd_polar_scl_register_stages``)
     """
     frozen_ind = np.asarray(frozen_ind).astype(int)
     ops = []
@@ -37,6 +40,9 @@ def build_schedule(frozen_ind, use_fast=True, use_rep=True):
             ops.append((OP_LEAF, 0, side, -1 - start if frozen_ind[start] else start))
             return
         blk = frozen_ind[start:start + size]
+        if subtree_stage is not None and s == subtree_stage and not root:
+            ops.append((OP_SUBTREE, s, side, start + (4096 if use_fast else 0)))
+            return
         if use_fast:
             if blk.sum() == size:
                 ops.append((OP_RATE0, s, side, 0))
@@ -56,13 +62,11 @@ def build_schedule(frozen_ind, use_fast=True, use_rep=True):
     return np.asarray(ops, np.int32)
 
 
-OP_NODE2 = 7
-
-
 def fuse_schedule(ops):
     """Replace every stage-1 node with two information leaves - the five records F(1), LEAF(i), G(1), LEAF(i+1),
-    COMBINE(0, side) - by one NODE2 record (a1 = side, a2 = i).  Same operations in the same order; the kernels
-    save four of five schedule dispatches on what is 44 % of the schedule of a rate-1/2 n = 1024 code."""
+    COMBINE(0, side) - by one SUBTREE record of stage 1 (a1 = side, a2 = i), which every engine accepts.  Same
+    operations in the same order; the kernels save four of five schedule dispatches on what is 44 % of the schedule
+    of a rate-1/2 n = 1024 code."""
     ops = np.asarray(ops, np.int32)
     out, i, n = [], 0, len(ops)
     while i < n:
@@ -70,7 +74,7 @@ def fuse_schedule(ops):
         if (len(w) == 5 and w[0, 0] == OP_F and w[0, 1] == 1 and w[1, 0] == OP_LEAF and w[1, 3] >= 0 and w[1, 2] == 0
                 and w[2, 0] == OP_G and w[2, 1] == 1 and w[3, 0] == OP_LEAF and w[3, 3] == w[1, 3] + 1 and w[3, 2] == 1
                 and w[4, 0] == OP_COMBINE and w[4, 1] == 0):
-            out.append((OP_NODE2, 1, w[4, 2], w[1, 3]))
+            out.append((OP_SUBTREE, 1, w[4, 2], w[1, 3]))
             i += 5
         else:
             out.append(tuple(ops[i]))
@@ -79,8 +83,8 @@ def fuse_schedule(ops):
 
 
 def pack_schedule(ops):
-    """One int32 per operation: op | stage<<3 | side<<7 | (a2+2048)<<8, stage-1 nodes of two information leaves
-    fused (:func:`fuse_schedule`)."""
+    """One int32 per operation: op | stage<<3 | side<<7 | (a2+2048)<<8 (bit 20 = the +4096 of SUBTREE records),
+    stage-1 nodes of two information leaves fused (:func:`fuse_schedule`)."""
     ops = np.asarray(fuse_schedule(ops), np.int64)
     a0 = np.where(ops[:, 0] == OP_LEAF, 0, ops[:, 1])
     return (ops[:, 0] | (a0 << 3) | (ops[:, 2] << 7) | ((ops[:, 3] + 2048) << 8)).astype(np.int32)
@@ -111,6 +115,7 @@ class _PolarListDecoderBase(Block):
         self._list_size, self._sc_mode = int(list_size), int(sc_mode)
         self._llr_max = 30.
         # the SC decoder of the reference prunes rate-0 sub-trees only (decoding.py:186-190)
+        self._use_fast = bool(use_fast)
         self._ops = build_schedule(self._frozen_ind, use_fast, use_rep=not sc_mode)
         self._crc_len, self._crc_mask = (crc_poly_mask(crc_degree) if crc_degree is not None else (0, 0))
         self._ind_iil_inv = None if ind_iil_inv is None else np.asarray(ind_iil_inv, np.int32)
@@ -125,7 +130,11 @@ class _PolarListDecoderBase(Block):
     def _decode_2d(self, llr, want_status=False):
         if self._dev is None:
             i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
-            self._dev = (i32(pack_schedule(self._ops)), i32(self._info_pos),
+            # the engine that will run says which subtree stage it decodes without schedule dispatch
+            r = _ffi.lib().samd_polar_scl_register_stages(self._n, self._list_size, self._sc_mode)
+            ops = self._ops if r < 1 else build_schedule(self._frozen_ind, self._use_fast, use_rep=not self._sc_mode,
+                                                         subtree_stage=r)
+            self._dev = (i32(pack_schedule(ops)), i32(self._info_pos),
                          i32(self._ind_iil_inv) if self._ind_iil_inv is not None else None)
         ops, info, iil = self._dev
         b = llr.shape[0]
