@@ -161,7 +161,17 @@ def ptr(t):
     if t is None:
         return None
     assert t.is_cuda and t.is_contiguous()
+    if t.numel() == 0:
+        # an empty tensor has no storage (data_ptr() == 0), but the C entry points reject NULL before they look at the
+        # sizes: hand them a valid address that a zero-sized operation never dereferences
+        global _EMPTY
+        if _EMPTY is None or _EMPTY.device != t.device:
+            _EMPTY = torch.zeros(64, dtype=torch.float32, device=t.device)
+        return C.c_void_p(_EMPTY.data_ptr())
     return C.c_void_p(t.data_ptr())
+
+
+_EMPTY = None
 
 
 def to_device(x, dtype):

@@ -287,9 +287,11 @@ class Polar5GDecoder(Block):
         sub_inv = np.argsort(_subblock_pattern(npol))
         self._fill = 0.0
         if n >= npol:                       # repetition: positions 0..n_rep-1 are received twice
+            # (n > 2 n_polar: like the reference, whose concat / gather keeps llr[j] + llr[n_polar + j] for every j
+            # and drops further repetitions, decoding.py:2027-2034 + 2052)
             n_rep = n - npol
-            a = np.concatenate([np.arange(n_rep), np.arange(n_rep, npol)])
-            b = np.concatenate([np.arange(npol, n), np.full(npol - n_rep, -1)])
+            a = np.arange(npol)
+            b = np.where(np.arange(npol) < n_rep, npol + np.arange(npol), -1)
         elif self._k_polar / n <= 7 / 16:   # puncturing: first n_polar-n positions unknown (LLR 0)
             a = np.concatenate([np.full(npol - n, -1), np.arange(n)])
             b = np.full(npol, -1)

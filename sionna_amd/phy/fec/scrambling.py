@@ -18,6 +18,8 @@ _CALL = 1337          # the reference seeds with (1337, seed), scrambling.py:124
 def _apply(x, seq, period, binary):
     x = _ffi.to_device(x, torch.float32)
     out = torch.empty_like(x)
+    if x.numel() == 0:
+        return wrap(out)
     _ffi.check(_ffi.lib().samd_scramble_f32(_ffi.ptr(x), _ffi.ptr(seq), x.numel(), int(period), int(bool(binary)),
                                             _ffi.ptr(out), _ffi.stream()), "scramble")
     return wrap(out)
