@@ -375,8 +375,10 @@ __device__ __forceinline__ bool load_re(const OfdmEqArgs& p, int brx_i, int re, 
 
 // The same equaliser when no undesired stream exists (U = 0) and whitening is on: the covariance is diagonal,
 // only its M diagonal entries are formed (load as in load_re).
+// (occupancy bound: without it the scheduler hoists every load and spends 162 registers on <4, 2> - 3 waves per SIMD
+// for a kernel that streams 128 B per resource element; with it 68 registers and no spill)
 template <int M, int K>
-__global__ __launch_bounds__(128) void ofdm_lmmse_diag_kernel(OfdmEqArgs p) {
+__global__ __launch_bounds__(128, (M * K <= 8) ? 6 : 1) void ofdm_lmmse_diag_kernel(OfdmEqArgs p) {
   const int re_i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (re_i >= p.T * p.F) return;
   const int brx_i = p.brx0 + (int)blockIdx.y;
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(128) void ofdm_lmmse_diag_kernel(OfdmEqArgs p) {
 }
 
 template <int M, int K>
-__global__ __launch_bounds__(128) void ofdm_lmmse_kernel(OfdmEqArgs p) {
+__global__ __launch_bounds__(128, (M * K <= 4) ? 4 : 1) void ofdm_lmmse_kernel(OfdmEqArgs p) {
   const int re_i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (re_i >= p.T * p.F) return;
   const int brx_i = p.brx0 + (int)blockIdx.y;

@@ -390,8 +390,9 @@ static size_t scl_lds_bytes(int n, int L, int num_ops) {
          (size_t)L * 4 * 5 + 256 * 4 + 3 * (size_t)L * 16 + 64;
 }
 
-static int scl_grid(int batch, int n, int L) {
-  const size_t lds = scl_lds_bytes(n, L, 0);
+// resident workgroups (= codewords in flight): as many as the list state of the engine that runs lets a CU hold
+static int scl_grid(int batch, int n, int L, bool reg_engine) {
+  const size_t lds = reg_engine ? scl_reg_lds_bytes(n, L) : scl_lds_bytes(n, L, 0);
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -431,7 +432,10 @@ extern "C" int samd_polar_scl_register_stages(int n, int list_size, int sc_mode)
 extern "C" size_t samd_polar_scl_workspace_bytes(int batch, int n, int list_size) {
   if (batch <= 0 || n < 8 || list_size < 1) return 0;
   // float + byte scratch of the top stages: n - n/2^G entries per slot, rounded up to n
-  return (size_t)scl_grid(batch, n, list_size) * list_size * (size_t)n * (sizeof(float) + 1) + 512;
+  // (the engine is chosen at decode time - sc_mode is not known here: room for either)
+  const int grid = std::max(scl_grid(batch, n, list_size, false),
+                            scl_reg_supported(n, list_size, 0) ? scl_grid(batch, n, list_size, true) : 0);
+  return (size_t)grid * list_size * (size_t)n * (sizeof(float) + 1) + 512;
 }
 
 extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
@@ -455,14 +459,15 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int m = 0;
   while ((1 << m) < n) ++m;
-  const int grid = scl_grid(batch, n, list_size);
+  const bool reg_engine = scl_reg_supported(n, list_size, sc_mode);
+  const int grid = scl_grid(batch, n, list_size, reg_engine);
   float* gs = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
   unsigned char* gb = reinterpret_cast<unsigned char*>(gs + (size_t)grid * list_size * n);
-  SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n), batch, n, m, k, list_size,
+  SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n, reg_engine), batch, n, m, k, list_size,
             sc_mode, crc_len, crc_poly};
   // list decoding with 4..32 paths: the engine whose low stages live in registers (polar_scl_reg.hip)
   // (samd_polar_scl_register_stages() tells the host which engine runs, i.e. which subtree stage its schedule may use)
-  if (scl_reg_supported(n, list_size, sc_mode)) return scl_reg_launch(p, grid, (hipStream_t)stream);
+  if (reg_engine) return scl_reg_launch(p, grid, (hipStream_t)stream);
   // one wave per codeword: the block sums of rate-0 / repetition nodes are defined on 64 lanes (scl_math.h)
   hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
   return launch_status();

@@ -499,7 +499,7 @@ bool scl_reg_supported(int n, int list_size, int sc_mode) { return scl_reg_stage
 size_t scl_reg_lds_bytes(int n, int L) {
   int m = 0;
   while ((1 << m) < n) ++m;
-  const size_t hn = (size_t)1 << (m - scl_gstages(n));
+  const size_t hn = (size_t)1 << (m - scl_gstages(n, true));
   return (size_t)L * hn * 5 + (size_t)L * scl_reg_wstride(n) * 4 + (size_t)L * 48 + (size_t)L * 4 * 10 + scl_reg_wstride(n) * 4 + 64;
 }
 

@@ -55,6 +55,8 @@ class OFDMEqualizer(Block):
             i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
             self._dev = (i32(rg.effective_subcarrier_ind), i32(desired), i32(undesired) if undesired.size else None,
                          i32(data_pos), undesired.shape[1])
+            # every stream detected by some receiver: the kernel writes every output element, no zero fill needed
+            self._covers_all = np.array_equal(np.unique(desired), all_ids)
         return self._dev
 
     def _prepare(self, y, h_hat, err_var, no):
@@ -91,8 +93,9 @@ class OFDMEqualizer(Block):
         rg = self._rg
         keep, head, tabs, dims = self._prepare(y, h_hat, err_var, no)
         b, nd, dev = dims[0], rg.num_data_symbols, keep[0].device
-        x_hat = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.complex64, device=dev)
-        no_eff = torch.zeros((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.float32, device=dev)
+        alloc = torch.empty if self._covers_all else torch.zeros
+        x_hat = alloc((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.complex64, device=dev)
+        no_eff = alloc((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.float32, device=dev)
         _ffi.check(_ffi.lib().samd_ofdm_lmmse_c64(*head, *tabs, *dims, int(self._mode), _ffi.ptr(x_hat),
                                                   _ffi.ptr(no_eff), _ffi.stream()), "LMMSEEqualizer")
         return x_hat, no_eff
