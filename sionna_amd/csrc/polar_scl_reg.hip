@@ -241,6 +241,16 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
         }
         if (any) {
           const int addr = srcl << 2;
+          const bool moved = srcl != (int)lane;
+          const unsigned ssl = (unsigned)srcl / W;
+          // the lazy copy of everything above stage R (decided bits, pointer tables of the upper stages) is requested
+          // first, the register pulls next: one wait covers both
+          uint4* bw = reinterpret_cast<uint4*>(bits);
+          uint4* tw = reinterpret_cast<uint4*>(tab);
+          const bool cw = moved && (int)j < wq, ct = moved && j < 3u;
+          uint4 wv = make_uint4(0u, 0u, 0u, 0u), tv = wv;
+          if (cw) wv = bw[ssl * wq + j];
+          if (ct) tv = tw[ssl * 3 + j];
           auto pull = [&](float v) __attribute__((always_inline)) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
           A1 = pull(A1);
           if (R >= 2) A2 = pull(A2);
@@ -249,17 +259,16 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           bb = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)bb);
           const float pc1 = pull(c1);
           const int pr1 = __builtin_amdgcn_ds_bpermute(addr, r1);
-          if (srcl != lane) {
+          if (cw) bw[slot * wq + j] = wv;
+          if (ct) tw[slot * 3 + j] = tv;
+          if (moved) {
             npm = pc1;
             npos = pr1;
-            // decided bits and the pointer tables of the upper stages (lazy copy of everything above stage R)
-            const unsigned ssl = (unsigned)srcl / W;
-            uint4* bw = reinterpret_cast<uint4*>(bits);
-            for (int e = j; e < wq; e += W) bw[slot * wq + e] = bw[ssl * wq + e];
-            uint4* tw = reinterpret_cast<uint4*>(tab);
-            for (int e = j; e < 3; e += W) tw[slot * 3 + e] = tw[ssl * 3 + e];
+            for (int e = j + W; e < wq; e += W) bw[slot * wq + e] = bw[ssl * wq + e];      // W < 8 lanes per slot
+            for (int e = j + W; e < 3; e += W) tw[slot * 3 + e] = tw[ssl * 3 + e];
           }
-          __syncthreads();
+          // LDS executes a wave's operations in order: later readers of these words need no wait, only program order
+          asm volatile("" ::: "memory");
         }
         pm = npm;
         pos = npos;
