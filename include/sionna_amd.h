@@ -467,7 +467,7 @@ int samd_polar_encode_f32(const float* u, const int32_t* info_pos, const int32_t
  * build_schedule / pack_schedule: op | stage<<3 | side<<7 | (bit_index+2048)<<8 with op 0 f, 1 g,
  * 2 leaf, 3 rate-0, 4 repetition, 5 combine, 6 end, 7 = a complete subtree of `stage` whose first
  * bit is bit_index, result onto `side`, bit 20 = fast-SCL shortcuts inside it.  Every engine accepts
- * subtrees of stage 1 with two information leaves; subtrees of stage R are accepted iff
+ * subtrees of stage 1 with two information leaves; subtrees of stage R and R + 1 are accepted iff
  * samd_polar_scl_register_stages(n, list_size, sc_mode) == R (-1: none - the generic engine runs;
  * R >= 1: the engine whose stages 0..R live in registers decodes such a subtree without further
  * schedule dispatch, from the frozen pattern it derives from info_pos)); info_pos

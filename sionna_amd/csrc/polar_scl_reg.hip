@@ -181,8 +181,19 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
     for (int ip = 0;; ++ip) {
       const int rec = next_rec;
       next_rec = (ip + 1 < p.num_ops) ? p.ops[ip + 1] : (int)OP_END;
-      const int op = rec & 7, s = (rec >> 3) & 15, a1 = (rec >> 7) & 1, a2 = ((rec >> 8) & 0xFFF) - 2048;
+      int op = rec & 7, a2 = ((rec >> 8) & 0xFFF) - 2048;
+      const int s = (rec >> 3) & 15, a1 = (rec >> 7) & 1;
       if (op == OP_END) break;
+      uint32_t fm = 0u;                                     // frozen pattern of a SUBTREE record (bit i = leaf i frozen)
+      if (op == OP_SUBTREE) {
+        const uint32_t word = fzb[a2 >> 5] >> (a2 & 31);
+        fm = (s >= 5) ? word : (word & ((1u << (1 << s)) - 1u));
+        if (s == R + 1 && ((rec >> 20) & 1)) {              // a node above the register stages that the fast-SCL rules
+          const uint32_t all = (R + 1 >= 5) ? 0xFFFFFFFFu : ((1u << (1 << (R + 1))) - 1u);   // replace as a whole
+          if (fm == all) op = OP_RATE0;
+          else if (fm == (all >> 1)) { op = OP_REP; a2 += (1 << (R + 1)) - 1; }
+        }
+      }
       // the lane index is made opaque per operation: everything derived from it (slot, position, addresses, lane
       // predicates) is recomputed with a few VALU operations instead of being hoisted out of the schedule loop into
       // ~30 registers that live for the whole decode and cost occupancy
@@ -329,11 +340,35 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
         }
       };
       if (op == OP_SUBTREE) {
-        // a2 = index of the subtree's first bit; stage R (pack_schedule for this engine) or 1 (two information leaves)
-        const uint32_t word = fzb[a2 >> 5] >> (a2 & 31);
+        // a2 = index of the subtree's first bit.  Stage R + 1 (what pack_schedule emits for this engine): f / g from
+        // the stage-(R+1) LLRs in memory around the two register-stage subtrees, then the combine into memory; stage R:
+        // one register-stage subtree; stage 1: two information leaves.  ONE call site of the unrolled recursion.
         const bool fast = (rec >> 20) & 1;
-        if (s == R) subtree(subtree, std::integral_constant<int, R>{}, word & ((1u << (1 << R)) - 1u), a2, a1, fast);
-        else subtree(subtree, std::integral_constant<int, 1>{}, word & 3u, a2, a1, fast);
+        if (s >= R) {
+          const int halves = (s == R) ? 1 : 2;
+#pragma unroll 1
+          for (int h = 0; h < halves; ++h) {
+            if (s == R + 1) {
+              const int si = (int)tab[slot * 48 + s];
+              const float x = ld_llr(si, s, j), y = ld_llr(si, s, j + H);
+              float r;
+              if (h == 0) r = cn_op(x, y);
+              else r = (1.f - 2.f * (float)((bb >> (2 * R)) & 1u)) * x + y;         // vn_op :707-714
+              SCL_SETA(R, r);
+            }
+            const uint32_t fh = (s == R) ? fm : ((h ? (fm >> H) : fm) & ((1u << H) - 1u));
+            subtree(subtree, std::integral_constant<int, R>{}, fh, a2 + h * H, (s == R) ? a1 : h, fast);
+          }
+          if (s == R + 1) {
+            const uint32_t l = (bb >> (2 * R)) & 1u, r = (bb >> (2 * R + 1)) & 1u;
+            put_beta(slot, R + 1, j, l ^ r, a1);
+            put_beta(slot, R + 1, H + j, r, a1);
+            if (head) tab[slot * 48 + (a1 ? 32 : 16) + R + 1] = (unsigned char)slot;
+            __syncthreads();
+          }
+        } else {
+          subtree(subtree, std::integral_constant<int, 1>{}, fm & 3u, a2, a1, fast);
+        }
       } else if (op == OP_F || op == OP_G) {
         // inputs at stage s (2^s values), outputs at stage so = s - 1; g uses the left results of stage so
         const int so = s - 1;

@@ -130,10 +130,11 @@ class _PolarListDecoderBase(Block):
     def _decode_2d(self, llr, want_status=False):
         if self._dev is None:
             i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
-            # the engine that will run says which subtree stage it decodes without schedule dispatch
+            # the engine that will run says which stages it keeps in registers: it decodes a whole node one stage above
+            # them (f / g from memory around two register-stage subtrees) without further schedule dispatch
             r = _ffi.lib().samd_polar_scl_register_stages(self._n, self._list_size, self._sc_mode)
             ops = self._ops if r < 1 else build_schedule(self._frozen_ind, self._use_fast, use_rep=not self._sc_mode,
-                                                         subtree_stage=r)
+                                                         subtree_stage=r + 1)
             self._dev = (i32(pack_schedule(ops)), i32(self._info_pos),
                          i32(self._ind_iil_inv) if self._ind_iil_inv is not None else None)
         ops, info, iil = self._dev

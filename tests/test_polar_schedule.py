@@ -53,8 +53,8 @@ def test_fused_records_expand_to_the_plain_schedule(k, n, fast):
     fused = pd.fuse_schedule(plain)
     assert np.array_equal(_expand(fused, ind), plain)
     assert len(fused) <= len(plain)
-    for r in (1, 2, 3, 4):
-        if n < (1 << (r + 2)):
+    for r in (1, 2, 3, 4, 5):
+        if n < (1 << (r + 1)):
             continue
         sub = pd.build_schedule(ind, use_fast=fast, subtree_stage=r)
         assert np.array_equal(_expand(sub, ind), plain), (r, fast)
@@ -65,7 +65,7 @@ def test_fused_records_expand_to_the_plain_schedule(k, n, fast):
 
 def test_packing_round_trip():
     ind = _frozen(523, 1024)
-    sub = pd.build_schedule(ind, subtree_stage=3)
+    sub = pd.build_schedule(ind, subtree_stage=4)
     packed = pd.pack_schedule(sub)
     assert packed.dtype == np.int32 and len(packed) == len(pd.fuse_schedule(sub))
     op, stage, side = packed & 7, (packed >> 3) & 15, (packed >> 7) & 1
@@ -76,5 +76,6 @@ def test_packing_round_trip():
     assert np.array_equal(stage[m], sub[m, 1]) and np.array_equal(a2[m], sub[m, 3] & 4095) and np.all(flag[m] == 1)
     assert np.array_equal(a2[~m], sub[~m, 3]) and np.all(flag[~m] == 0)
     assert op[-1] == pd.OP_END
-    # the rate-1/2 n = 1024 schedule: 2161 plain operations, 385 with stage-3 subtrees
-    assert len(pd.build_schedule(ind)) == 2161 and len(sub) == 385
+    # the rate-1/2 n = 1024 schedule: 2161 plain operations, 385 with stage-3 subtrees, 213 with stage-4 subtrees
+    assert len(pd.build_schedule(ind)) == 2161 and len(pd.build_schedule(ind, subtree_stage=3)) == 385
+    assert len(sub) == 213
