@@ -69,15 +69,17 @@ template <int L>
 struct SclRegLayout {
   static constexpr int W = 64 / L;                                       // lanes per slot
   static constexpr int R = W >= 16 ? 4 : W == 8 ? 3 : W == 4 ? 2 : 1;     // register stages 0..R
-  static constexpr int H = 1 << R;                                       // values of stage R (== W)
-};
+  static constexpr int H = 1 << R;                                       // values of stage R: the lanes j < H of a slot
+};                                                                        // hold register stages (H == W for L >= 4)
 
 static inline size_t scl_reg_wstride(int n) { return (size_t)(((n + 31) / 32 + 3) / 4 * 4); }
 
-template <int L>
+// SC: PolarSCDecoder (one path, hard decisions by the sign of the leaf LLR, rate-0 shortcut only - decoding.py:122-263):
+// no metrics, no forks.  List sizes 1 and 2 use 16 of their 64 / 32 lanes per slot for the register stages.
+template <int L, bool SC>
 __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
   constexpr int W = SclRegLayout<L>::W, R = SclRegLayout<L>::R, H = SclRegLayout<L>::H;
-  static_assert(H == W && W >= 2 && W <= 16, "lanes of a slot = values of its top register stage");
+  static_assert(H <= W && W >= 2 && (!SC || L == 1), "register stages live in the first H lanes of a slot");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = p.n, m = p.m;
   const unsigned lane0 = threadIdx.x;
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
         if (s == R + 1 && ((rec >> 20) & 1)) {              // a node above the register stages that the fast-SCL rules
           const uint32_t all = (R + 1 >= 5) ? 0xFFFFFFFFu : ((1u << (1 << (R + 1))) - 1u);   // replace as a whole
           if (fm == all) op = OP_RATE0;
-          else if (fm == (all >> 1)) { op = OP_REP; a2 += (1 << (R + 1)) - 1; }
+          else if (!SC && fm == (all >> 1)) { op = OP_REP; a2 += (1 << (R + 1)) - 1; }
         }
       }
       // the lane index is made opaque per operation: everything derived from it (slot, position, addresses, lane
@@ -213,7 +215,8 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           ck[L + slot] = make_uint2((uint32_t)(L + pos), __float_as_uint(c1));
         }
         __syncthreads();
-        constexpr int G2 = W / 2, PER = (2 * L) / G2;       // lanes per candidate, comparisons per lane
+        constexpr int G2 = W / 2;                           // lanes per candidate
+        constexpr int PER = (2 * L >= G2) ? (2 * L) / G2 : 1;     // comparisons per lane (lists of 1, 2: lanes q < 2L only)
         const unsigned u = j & 1u, q = j >> 1;
         const uint2 me2 = ck[u * L + slot];
         const unsigned long long me = ((unsigned long long)me2.y << 32) | me2.x;
@@ -227,8 +230,9 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
         } else {
 #pragma unroll 8
           for (int t = 0; t < PER; ++t) {
-            const uint2 d2 = ck[q * PER + t];
-            rank += ((((unsigned long long)d2.y << 32) | d2.x) < me) ? 1 : 0;
+            const unsigned d = q * PER + t;
+            const uint2 d2 = ck[d < 2u * L ? d : 0u];
+            rank += (d < 2u * L && (((unsigned long long)d2.y << 32) | d2.x) < me) ? 1 : 0;
           }
         }
         if constexpr (W >= 16) rank += dpp_up_i<8>(rank);
@@ -305,13 +309,22 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           bb = (bb & ~(1u << sh)) | ((uint32_t)((ones >> (lane & ~(W - 1))) & 1ull) << sh);
         };
         if constexpr (S == 0) {
-          const float l = clampf(A0, -kPolarLlrMax, kPolarLlrMax);
-          const float tl = scl_T(fabsf(l));
-          const float m0 = fmaxf(-l, 0.f) + tl;
-          if (fm & 1u) { pm += m0; setres(0ull); }
-          else setres(fork(m0, fmaxf(l, 0.f) + tl, first));
+          if constexpr (SC) {
+            // u = 0.5 (1 - sign(l)), an exact zero decides 1 (decoding.py:208-212); frozen: 0
+            const unsigned long long ones = (fm & 1u) ? 0ull : __builtin_amdgcn_ballot_w64(head && A0 <= 0.f);
+            if (head && (ones & 1ull)) bits[first >> 5] |= 1u << (first & 31);
+            setres(ones);
+          } else {
+            const float l = clampf(A0, -kPolarLlrMax, kPolarLlrMax);
+            const float tl = scl_T(fabsf(l));
+            const float m0 = fmaxf(-l, 0.f) + tl;
+            if (fm & 1u) { pm += m0; setres(0ull); }
+            else setres(fork(m0, fmaxf(l, 0.f) + tl, first));
+          }
         } else {
-          if (fast && (fm == all || fm == (all >> 1))) {
+          if (SC && fast && fm == all) {
+            setres(0ull);                                                               // rate-0, no metric to keep
+          } else if (!SC && fast && (fm == all || fm == (all >> 1))) {
             const float l = clampf(Aref(S_), -kPolarLlrMax, kPolarLlrMax);
             const float tl = scl_T(fabsf(l));
             float t0 = fmaxf(-l, 0.f) + tl, t1 = fmaxf(l, 0.f) + tl;
@@ -350,7 +363,8 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           for (int h = 0; h < halves; ++h) {
             if (s == R + 1) {
               const int si = (int)tab[slot * 48 + s];
-              const float x = ld_llr(si, s, j), y = ld_llr(si, s, j + H);
+              const int jm = (int)(j & (H - 1));      // lanes past the register stages repeat the first H (no stray reads)
+              const float x = ld_llr(si, s, jm), y = ld_llr(si, s, jm + H);
               float r;
               if (h == 0) r = cn_op(x, y);
               else r = (1.f - 2.f * (float)((bb >> (2 * R)) & 1u)) * x + y;         // vn_op :707-714
@@ -361,8 +375,10 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           }
           if (s == R + 1) {
             const uint32_t l = (bb >> (2 * R)) & 1u, r = (bb >> (2 * R + 1)) & 1u;
-            put_beta(slot, R + 1, j, l ^ r, a1);
-            put_beta(slot, R + 1, H + j, r, a1);
+            if (j < (unsigned)H) {
+              put_beta(slot, R + 1, j, l ^ r, a1);
+              put_beta(slot, R + 1, H + j, r, a1);
+            }
             if (head) tab[slot * 48 + (a1 ? 32 : 16) + R + 1] = (unsigned char)slot;
             __syncthreads();
           }
@@ -380,8 +396,9 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
             stage_switch<R - 1>(so, [&](auto S_) __attribute__((always_inline)) { y = dpp_up<(1 << decltype(S_)::value)>(x); });
           } else {
             const int si = (int)tab[slot * 48 + s];
-            x = ld_llr(si, s, j);
-            y = ld_llr(si, s, j + H);
+            const int jm = (int)(j & (H - 1));
+            x = ld_llr(si, s, jm);
+            y = ld_llr(si, s, jm + H);
           }
           float r;
           if (op == OP_F) r = cn_op(x, y);
@@ -423,8 +440,10 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           });
         } else if (s == R) {
           const uint32_t l = (bb >> (2 * R)) & 1u, r = (bb >> (2 * R + 1)) & 1u;
-          put_beta(slot, R + 1, j, l ^ r, a1);
-          put_beta(slot, R + 1, H + j, r, a1);
+          if (j < (unsigned)H) {
+            put_beta(slot, R + 1, j, l ^ r, a1);
+            put_beta(slot, R + 1, H + j, r, a1);
+          }
           if (head) tab[slot * 48 + (a1 ? 32 : 16) + R + 1] = (unsigned char)slot;
           __syncthreads();
         } else {
@@ -444,7 +463,9 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
         const bool info = (op == OP_REP) || (op == OP_LEAF && a2 >= 0);
         // block metrics of the slot in its first lane: m0 = sum softplus(-l), m1 = sum softplus(+l)
         float m0 = 0.f, m1 = 0.f;
-        if (s <= R) {
+        if constexpr (SC) {
+          // hard decisions only
+        } else if (s <= R) {
           const float l = clampf(SCL_GETA(s), -kPolarLlrMax, kPolarLlrMax);
           const float tl = scl_T(fabsf(l));                   // shared by softplus(-l) and softplus(l)
           m0 = fmaxf(-l, 0.f) + tl;
@@ -473,7 +494,12 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
           }
         }
         unsigned long long ones = 0ull;                       // slots (bit = first lane) whose decided bit is 1
-        if (!info) {
+        if constexpr (SC) {
+          if (info) {                                         // a leaf (the SC schedule has no repetition nodes)
+            ones = __builtin_amdgcn_ballot_w64(head && A0 <= 0.f);
+            if (head && (ones & 1ull)) bits[a2 >> 5] |= 1u << (a2 & 31);
+          }
+        } else if (!info) {
           pm += m0;                                           // frozen leaf / rate-0: all-zero block
         } else {
           ones = fork(m0, m1, a2);                            // the node's only information bit is its last
@@ -530,8 +556,9 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
 }
 
 int scl_reg_stages(int n, int list_size, int sc_mode) {
-  if (sc_mode || getenv("SAMD_SCL_GENERIC")) return -1;
-  if (list_size != 4 && list_size != 8 && list_size != 16 && list_size != 32) return -1;
+  if (getenv("SAMD_SCL_GENERIC")) return -1;
+  if (list_size != 1 && list_size != 2 && list_size != 4 && list_size != 8 && list_size != 16 && list_size != 32) return -1;
+  if (sc_mode && list_size != 1) return -1;
   int m = 0;
   while ((1 << m) < n) ++m;
   const int w = 64 / list_size, r = w >= 16 ? 4 : w == 8 ? 3 : w == 4 ? 2 : 1;
@@ -547,21 +574,23 @@ size_t scl_reg_lds_bytes(int n, int L) {
   return (size_t)L * hn * 5 + (size_t)L * scl_reg_wstride(n) * 4 + (size_t)L * 48 + (size_t)L * 4 * 10 + scl_reg_wstride(n) * 4 + 64;
 }
 
-template <int L>
+template <int L, bool SC>
 static int scl_reg_launch_l(const SclArgs& p, int grid, hipStream_t stream) {
   const size_t lds = scl_reg_lds_bytes(p.n, L);
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_reg_kernel<L>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_reg_kernel<L, SC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                      160 * 1024));
-  hipLaunchKernelGGL(polar_scl_reg_kernel<L>, dim3(grid), dim3(64), lds, stream, p);
+  hipLaunchKernelGGL((polar_scl_reg_kernel<L, SC>), dim3(grid), dim3(64), lds, stream, p);
   return launch_status();
 }
 
 int scl_reg_launch(const SclArgs& p, int grid, hipStream_t stream) {
   switch (p.L) {
-    case 4: return scl_reg_launch_l<4>(p, grid, stream);
-    case 8: return scl_reg_launch_l<8>(p, grid, stream);
-    case 16: return scl_reg_launch_l<16>(p, grid, stream);
-    case 32: return scl_reg_launch_l<32>(p, grid, stream);
+    case 1: return p.sc_mode ? scl_reg_launch_l<1, true>(p, grid, stream) : scl_reg_launch_l<1, false>(p, grid, stream);
+    case 2: return scl_reg_launch_l<2, false>(p, grid, stream);
+    case 4: return scl_reg_launch_l<4, false>(p, grid, stream);
+    case 8: return scl_reg_launch_l<8, false>(p, grid, stream);
+    case 16: return scl_reg_launch_l<16, false>(p, grid, stream);
+    case 32: return scl_reg_launch_l<32, false>(p, grid, stream);
   }
   set_error("list size not supported by the register engine");
   return SAMD_ERR_UNSUPPORTED;

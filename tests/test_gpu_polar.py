@@ -80,7 +80,9 @@ def test_sc_and_scl1_golden(phy, name):
 @pytest.mark.parametrize("n,k,L,crc,fast", [(128, 64, 8, None, True), (128, 64, 4, "CRC11", True), (256, 100, 8, "CRC11", False),
                                             (64, 40, 2, "CRC6", True), (1024, 523, 8, "CRC11", True), (512, 300, 16, "CRC24C", True),
                                             (256, 128, 32, "CRC11", True), (64, 30, 16, None, True), (32, 16, 8, None, True),
-                                            (1024, 200, 4, "CRC24C", True), (512, 400, 8, "CRC16", True)])
+                                            (1024, 200, 4, "CRC24C", True), (512, 400, 8, "CRC16", True),
+                                            (256, 128, 2, "CRC11", True), (512, 200, 1, None, True), (128, 80, 2, None, False),
+                                            (1024, 700, 2, "CRC24C", True), (1024, 512, 1, "CRC11", False)])
 def test_scl_vs_oracle(phy, n, k, L, crc, fast):
     """List decoding against the C oracle in the float32 specification arithmetic (oracle/polar_scl.c, the decoder
     whose float64 instantiation reproduces the reference's own NumPy twin): hard decisions and CRC status bit for
