@@ -465,7 +465,7 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   unsigned char* gb = reinterpret_cast<unsigned char*>(gs + (size_t)grid * list_size * n);
   SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, scl_gstages(n, reg_engine), batch, n, m, k, list_size,
             sc_mode, crc_len, crc_poly};
-  // list decoding with 4..32 paths: the engine whose low stages live in registers (polar_scl_reg.hip)
+  // SC and list decoding with 1..32 paths of codes with n >= 64: the engine whose low stages live in registers (polar_scl_reg.hip)
   // (samd_polar_scl_register_stages() tells the host which engine runs, i.e. which subtree stage its schedule may use)
   if (reg_engine) return scl_reg_launch(p, grid, (hipStream_t)stream);
   // one wave per codeword: the block sums of rate-0 / repetition nodes are defined on 64 lanes (scl_math.h)
