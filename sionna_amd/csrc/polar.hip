@@ -6,29 +6,24 @@
 //   PolarSCDecoder                        polar/decoding.py:122-263
 //   PolarSCLDecoder (default TF path, use_fast_scl) polar/decoding.py:525-723, 919-1045, 1345-1437
 //
-// MI355X design of the decoder: the reference unrolls the whole decoding tree into a TF graph
-// whose every leaf step re-concatenates a [batch, 2L, log2(n)+1, n] float state (1.44 MB per
-// codeword at n=1024, L=8) and itself recommends a NumPy fallback for n > 128.  Here ONE
-// workgroup owns one codeword and its complete list state lives in LDS (53 KB at n=1024, L=8):
-//   * LLR memory per path is the compact n-1 floats (stage s = 2^s values), the channel LLRs are
-//     shared by all paths; partial sums are two byte banks (left / right child results) per path;
-//   * only the L live paths are stored: at an information bit each path forks into (u=0, u=1), the
-//     2L candidates are ranked by a stable parallel rank (position order breaks ties - the
-//     behaviour of the reference's sort + duplicate), survivors whose parent also survives are
-//     cloned into the slots of dead parents;
-//   * the decoding schedule (f / g / leaf / rate-0 / repetition / combine operations, exactly the
-//     recursion of polar/decoding.py:919-1005 including the fast-SCL shortcuts) is a flat op list
-//     built once on the host and interpreted by the kernel - no recursion, no divergence;
-//   * CRC-aided selection (penalty llr_max*k on CRC failures, first minimum) runs in the same
-//     kernel; the f-operation is the exact boxplus softplus(x+y) - logsumexp(x,y) with the +-30
-//     clip of the reference.
-// The kernel is instruction-issue / latency bound, not bandwidth bound (4n bytes in, 4k bytes out
-// per codeword): ~2200 dependent operations per codeword at n=1024 with at most 64 independent
-// work items each, i.e. ~1e6 wave-instructions on ONE wave per codeword (measured: 64- and
-// 256-thread workgroups run at the same rate; skipping the clone copies or the CRC changes
-// nothing, a free f-operation gains 19 %).  Throughput therefore scales with the number of
-// codewords resident per CU, which the 53 KB list state limits to 2-3: sharing the upper LLR
-// stages between paths (lazy copy) is the next step.
+// MI355X design of the decoder: the reference unrolls the whole decoding tree into a TF graph whose every leaf step
+// re-concatenates a [batch, 2L, log2(n)+1, n] float state (1.44 MB per codeword at n=1024, L=8) and itself recommends
+// a NumPy fallback for n > 128.  Here ONE wave owns one codeword, 32 codewords per CU:
+//   * the decoding schedule (f / g / leaf / rate-0 / repetition / combine operations, exactly the recursion of
+//     polar/decoding.py:919-1005 including the fast-SCL shortcuts) is a flat list built once on the host and
+//     interpreted by the kernel - no recursion, no divergence;
+//   * only the L live paths are stored: at an information bit each path forks into (u=0, u=1), the 2L candidates are
+//     ranked by a stable parallel rank (position order breaks ties - the behaviour of the reference's sort +
+//     duplicate), survivors whose parent also survives are cloned into the slots of dead parents; clones are lazy
+//     (per-slot pointer tables say which slot holds a stage's data);
+//   * CRC-aided selection (penalty llr_max*k on CRC failures, first minimum) runs in the same kernel; the f-operation
+//     is the exact boxplus softplus(x+y) - logsumexp(x,y) with the +-30 clip of the reference, in the defined float32
+//     arithmetic of scl_math.h (bit-exact against oracle/polar_scl.c).
+// Two engines share these definitions (polar_scl.h).  polar_scl_reg.hip - SC and list sizes 1..32 at n >= 64 - keeps
+// the low tree stages in registers and is the one the benchmarks run (5.1 M SCL-8 decodes/s at C5).  The kernel in
+// THIS file is the generic engine for everything else (short codes, other list sizes): every stage in LDS / L2
+// scratch behind the pointer tables, 1.3 M SCL-8 decodes/s at C5 - instruction-issue and scalar-dispatch bound at
+// ~2200 dependent operations per codeword with at most 64 independent work items each.
 #include "common.h"
 #include "bp_math.h"
 #include "polar_scl.h"
