@@ -42,6 +42,7 @@ struct SclArgs {
   float* gscratch;         // [grid][L][n - n/2^G] the G top LLR stages of every slot: touched by a handful
                            // of ops per decode, kept in L2 instead of LDS so that more codewords fit on a CU
   unsigned char* gbeta;    // [grid][L][n - n/2^G] partial sums of the same top stages
+  const uint32_t* crc_tab; // nullable [k]: remainder contributed by bit i of the CRC-checked sequence (register engine)
   int gstages;             // G
   int batch, n, m, k, L, sc_mode, crc_len;
   uint32_t crc_poly;

@@ -524,20 +524,25 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
     const int lane = lane0;
     if (lane % W == 0) { pm_s[pos] = pm; order[pos] = lane / W; }
     __syncthreads();
-    if (lane < L) {
-      const uint32_t* bw = bits + (size_t)order[lane] * wstride;
-      float pen = 0.f;
-      if (p.crc_len > 0) {
-        uint32_t reg = 0;
-        for (int i = 0; i < p.k; ++i) {
+    if (p.crc_len > 0) {
+      // parallel CRC of every path: remainder = XOR of the table entries of its set bits (linear over GF(2))
+      for (int q = 0; q < L; ++q) {
+        const uint32_t* bw = bits + (size_t)order[q] * wstride;
+        uint32_t acc = 0u;
+        for (int i = lane; i < p.k; i += 64) {
           const int src = p.iil_inv ? p.iil_inv[i] : i;
           const int ps = p.info_pos[src];
-          reg = crc_step(reg, (bw[ps >> 5] >> (ps & 31)) & 1u, p.crc_poly, p.crc_len);
+          if ((bw[ps >> 5] >> (ps & 31)) & 1u) acc ^= p.crc_tab[i];
         }
-        blk[lane] = reg == 0 ? 1.f : 0.f;
-        pen = reg == 0 ? 0.f : kPolarLlrMax * (float)p.k;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc ^= (uint32_t)__shfl_xor((int)acc, o, 64);
+        if (lane == 0) {
+          blk[q] = acc == 0u ? 1.f : 0.f;
+          cv[q] = pm_s[q] + (acc == 0u ? 0.f : kPolarLlrMax * (float)p.k);
+        }
       }
-      cv[lane] = pm_s[lane] + pen;
+    } else if (lane < L) {
+      cv[lane] = pm_s[lane];
     }
     __syncthreads();
     // first minimum of the penalised metrics in the order of the final stable sort by path metric (:1391, 1415):
