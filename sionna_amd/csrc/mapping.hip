@@ -142,6 +142,17 @@ __global__ __launch_bounds__(256) void demap_square_qam_kernel(const float2* __r
       float e[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) { const float d = ya - lev[j]; e[j] = -(d * d) / n0; }
+      // app: every level's exponential is evaluated ONCE, relative to the axis maximum M, and shared by the NB bit
+      // positions (2^NB instead of NB 2^NB exponentials per axis): logsumexp over a set = M + log(sum of its shares),
+      // and M cancels in the difference of the two sets.  A set whose best member lies more than 80 below M would
+      // lose its terms to underflow - that bit position (rare below ~25 dB of SNR) takes the per-set maximum instead.
+      float mall = -INFINITY, ex[L];
+      if constexpr (!MAXLOG) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) mall = fmaxf(mall, e[j]);
+#pragma unroll
+        for (int j = 0; j < L; ++j) ex[j] = exp_core_f32(e[j] - mall);
+      }
 #pragma unroll
       for (int t = 0; t < NB; ++t) {
         float mx0 = -INFINITY, mx1 = -INFINITY;
@@ -156,11 +167,18 @@ __global__ __launch_bounds__(256) void demap_square_qam_kernel(const float2* __r
           float s0 = 0.f, s1 = 0.f;
 #pragma unroll
           for (int j = 0; j < L; ++j) {
-            if ((j >> (NB - 1 - t)) & 1) s1 += exp_core_f32(e[j] - mx1); else s0 += exp_core_f32(e[j] - mx0);
+            if ((j >> (NB - 1 - t)) & 1) s1 += ex[j]; else s0 += ex[j];
           }
-          // arguments <= 0 and sums in [1, 2^(NB-1)]: the special-case free exp / log of bp_math.h give the libm's
-          // bits (terms that underflow differ by < 1e-38)
-          r = (log_core_f32(s1) + mx1) - (log_core_f32(s0) + mx0);
+          // sums in [e^-80, 2^(NB-1)]: normal numbers, the special-case free log of bp_math.h applies
+          r = log_core_f32(s1) - log_core_f32(s0);
+          if (mall - fminf(mx0, mx1) > 80.f) {
+            s0 = 0.f; s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < L; ++j) {
+              if ((j >> (NB - 1 - t)) & 1) s1 += exp_core_f32(e[j] - mx1); else s0 += exp_core_f32(e[j] - mx0);
+            }
+            r = (log_core_f32(s1) + mx1) - (log_core_f32(s0) + mx0);
+          }
         }
         llr[2 * t + ax] = r;
       }
