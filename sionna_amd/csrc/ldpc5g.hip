@@ -403,6 +403,13 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
     if (use_spill_boxplus(h))                                             // ... the last rows' messages in L2
       return launch_onchip_mss(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits,
                                workspace, workspace_bytes, (hipStream_t)stream);
+    // the explicit-message engine with the boxplus node update (pair items, fused degree-1 columns, prefetched
+    // descriptors - ldpc5g_onchip_ms.hip); SAMD_BP_ENGINE=1 keeps the first boxplus kernel (ldpc5g_onchip_bp.hip)
+    if (use_explicit_minsum(h) && !getenv("SAMD_BP_ENGINE")) {
+      const int rc = launch_onchip_ms(h, llr, out, batch, num_iter, cn_mode, llr_max, 0.f, hard_out, return_infobits,
+                                      workspace, workspace_bytes, (hipStream_t)stream);
+      if (rc != SAMD_ERR_UNSUPPORTED) return rc;
+    }
     return launch_onchip_bp(h, llr, out, batch, num_iter, cn_mode, llr_max, hard_out, return_infobits, workspace,
                             workspace_bytes, (hipStream_t)stream);
   }

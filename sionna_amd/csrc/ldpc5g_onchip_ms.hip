@@ -22,6 +22,7 @@
 // column runs an instantiation for its exact degree, table entries are wave-uniform scalars that feed
 // the VALU operations directly (no scalar unpacking per edge).
 #include "ldpc5g.h"
+#include "bp_math.h"
 
 namespace samd {
 
@@ -40,7 +41,10 @@ __device__ __forceinline__ float ms_med3(float a, float b, float c) { return __b
 // FUSE1: the row's last edge goes to a degree-1 variable node of the same lane (identity block of the base
 // graph's extension part).  Its VN update - x = c2v + llr, v2c = clip(x - c2v) - is done right here, so
 // these columns (42 of C2's 68) never appear in the VN phase; llr_v points at that VN's channel LLR.
-template <int D, int NCH, bool FUSE1>
+// MODE: SAMD_CN_MINSUM (min-sum and, through `offset`, offset-min-sum: the arithmetic below) or one of the boxplus
+// rules (bp_math.h's cn_update_col on the D messages of a chunk - the same function, hence the same bits, as the HBM
+// engine and ldpc5g_onchip_bp.hip).
+template <int D, int NCH, bool FUSE1, int MODE>
 __device__ __forceinline__ void ms_cn_row(unsigned a0, unsigned z4, float llr_max, float offset,
                                           float* __restrict__ llr_v, bool last) {
   float v[NCH][D];
@@ -53,6 +57,26 @@ __device__ __forceinline__ void ms_cn_row(unsigned a0, unsigned z4, float llr_ma
     a[i] = i ? a[i - 1] + z4 : a0;
 #pragma unroll
     for (int h = 0; h < NCH; ++h) v[h][i] = lds_ld(a[i] + 256u * h);
+  }
+  if constexpr (MODE != SAMD_CN_MINSUM) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) cn_update_col<MODE, D>(v[h], D, llr_max, 0.f);    // in place: v[h][i] = c2v
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      float c2v[NCH];
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) {
+        c2v[h] = v[h][i];
+        if (FUSE1 && i == D - 1) {
+          const float x = c2v[h] + lf[h];
+          if (last) llr_v[64 * h] = x;
+          c2v[h] = ms_med3(x - c2v[h], -llr_max, llr_max);
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) lds_st(a[i] + 256u * h, c2v[h]);
+    }
+    return;
   }
   float m1[NCH], m2[NCH];
   unsigned sx[NCH];
@@ -180,7 +204,7 @@ __device__ unsigned long long* g_ms_trace = nullptr;
 #define SAMD_TRACE_MARK(slot)
 #endif
 
-template <bool POW2, int NW, bool LLRG>
+template <bool POW2, int NW, bool LLRG, int MODE>
 __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ llr_ws, RateMatch p, int n_cn,
     int nbu, int batch, int num_iter, float llr_max, float offset, int hard_out, int return_infobits,
@@ -250,10 +274,10 @@ __global__ __launch_bounds__(NW * 64) void ldpc5g_decode_ms_kernel(
           const unsigned a0 = (ro & 0x3FFFFu) + 4u * zz;
           if (((ro >> 24) & 1u) || (zz < z && (unsigned)r * z + zz < (unsigned)n_cn)) {
             float* lv = llr + ((d1 >> 16) & 0xFF) * (int)z + (int)zz;   // channel LLR of the fused degree-1 VN
-#define SAMD_MS_CN(D) case D: ms_cn_row<D, 1, false>(a0, z4, llr_max, offset, lv, last); break
-#define SAMD_MS_CNF(D) case 32 + D: ms_cn_row<D, 1, true>(a0, z4, llr_max, offset, lv, last); break
-#define SAMD_MS_CN2(D) case 64 + D: ms_cn_row<D, 2, false>(a0, z4, llr_max, offset, lv, last); break
-#define SAMD_MS_CNF2(D) case 96 + D: ms_cn_row<D, 2, true>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CN(D) case D: ms_cn_row<D, 1, false, MODE>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CNF(D) case 32 + D: ms_cn_row<D, 1, true, MODE>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CN2(D) case 64 + D: ms_cn_row<D, 2, false, MODE>(a0, z4, llr_max, offset, lv, last); break
+#define SAMD_MS_CNF2(D) case 96 + D: ms_cn_row<D, 2, true, MODE>(a0, z4, llr_max, offset, lv, last); break
             switch (ro >> 18) {                                      // degree | fused << 5 | pair << 6
               SAMD_MS_CN(3); SAMD_MS_CN(4); SAMD_MS_CN(5); SAMD_MS_CN(6); SAMD_MS_CN(7); SAMD_MS_CN(8); SAMD_MS_CN(9);
               SAMD_MS_CN(10); SAMD_MS_CN(19);
@@ -352,10 +376,14 @@ int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const bool pow2 = (h->z & (h->z - 1)) == 0;
   typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, int, float, float, int, int, int,
                          const int32_t*, const int32_t*, const int2*, const int32_t*, const int2*);
-#define SAMD_MS_K(NWV, G) ldpc5g_decode_ms_kernel<false, NWV, G>, ldpc5g_decode_ms_kernel<true, NWV, G>
-  static const kern_t kerns[12] = {SAMD_MS_K(16, false), SAMD_MS_K(8, false), SAMD_MS_K(4, false),
-                                   SAMD_MS_K(2, false),  SAMD_MS_K(1, false), SAMD_MS_K(16, true)};
+#define SAMD_MS_K(NWV, G, M) ldpc5g_decode_ms_kernel<false, NWV, G, M>, ldpc5g_decode_ms_kernel<true, NWV, G, M>
+#define SAMD_MS_TAB(M) {SAMD_MS_K(16, false, M), SAMD_MS_K(8, false, M), SAMD_MS_K(4, false, M), \
+                        SAMD_MS_K(2, false, M),  SAMD_MS_K(1, false, M), SAMD_MS_K(16, true, M)}
+  static const kern_t kerns_all[3][12] = {SAMD_MS_TAB(SAMD_CN_MINSUM), SAMD_MS_TAB(SAMD_CN_BOXPLUS_PHI),
+                                          SAMD_MS_TAB(SAMD_CN_BOXPLUS)};
+#undef SAMD_MS_TAB
 #undef SAMD_MS_K
+  const kern_t* kerns = kerns_all[cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : cn_mode == SAMD_CN_BOXPLUS ? 2 : 0];
   const int nw = h->bp_waves;
   const int wi = h->bp_llr_global ? 5 : (nw == 16 ? 0 : nw == 8 ? 1 : nw == 4 ? 2 : nw == 2 ? 3 : 4);
   const int ki = 2 * wi + (pow2 ? 1 : 0);
