@@ -356,7 +356,7 @@ def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms):
         minsum = cn_update in ("minsum", "offset-minsum")
         key = "ldpc5g_ms" if minsum else "ldpc5g_bp"
         name = ("ldpc5g_decode_ms_kernel (on-chip min-sum, one float per edge in LDS, channel LLRs in an L2 workspace row)"
-                if minsum else "ldpc5g_decode_bp_kernel (on-chip boxplus, one float per edge in LDS)")
+                if minsum else "ldpc5g_decode_ms_kernel<..., boxplus> (the same engine with bp_math's boxplus node update)")
         return onchip_roofline(key, name, B, dec_ms, {"hbm_resident_equiv": equiv, **io})
     ach = bytes_alg / (dec_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
