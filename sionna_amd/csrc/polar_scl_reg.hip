@@ -1,7 +1,8 @@
-// Polar SC-list decoder whose low decoding stages live in registers (north-star config C5).
+// Polar SC / SC-list decoder whose low decoding stages live in registers (north-star config C5).
 //
 // Replaces (reference src/sionna/phy/fec/polar/decoding.py): PolarSCLDecoder, default TF path with use_fast_scl
-// (:525-723 metric / boxplus arithmetic, :919-1045 decoding recursion, :1345-1437 final CRC-aided selection).
+// (:525-723 metric / boxplus arithmetic, :919-1045 decoding recursion, :1345-1437 final CRC-aided selection), list
+// sizes 1..32, and PolarSCDecoder (:122-263) - codes with n >= 64; the generic engine of polar.hip takes the rest.
 // Same schedule, same float32 arithmetic (scl_math.h) and therefore the same bits as the generic engine in
 // polar.hip and as oracle/polar_scl.c; what changes is where the state of the lowest tree levels lives.
 //
@@ -21,7 +22,14 @@
 //     registers of its first lane;
 //   * stages above R keep the design of the generic engine (LDS for the next stages, L2 scratch for the top
 //     G stages, lazy copies through the pointer tables), iterated by slot - the position order is only needed
-//     for the tie-break of the ranking.
+//     for the tie-break of the ranking;
+//   * the schedule hands over whole nodes of stage R + 1 as ONE record (SUBTREE): f / g from LDS around the two
+//     register-stage subtrees, whose recursion is unrolled at compile time into straight-line code with
+//     wave-uniform branches on the frozen pattern - the scalar unit (one per CU, shared by the 32 resident waves)
+//     dispatches 213 instead of 2161 operations per n = 1024 decode, which was worth more than everything above
+//     (3.0 -> 5.2 M decodes/s at C5).
+// Measured at C5 (n = 1024, k = 512 + CRC11, L = 8, batch 32768): 5.3 M decodes/s against 1.3 M of the generic
+// engine; 113 k vector + 47 k scalar instructions per decode (247 k + 237 k before), VALU issue 0.49 of peak.
 #include "polar_scl.h"
 #include <type_traits>
 
