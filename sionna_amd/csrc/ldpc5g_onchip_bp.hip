@@ -260,14 +260,39 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // (measured at C2 with tools/ms_sweep.py: a fixed cost of ~20 edges per item balances best)
   const int cn_ovh = getenv("SAMD_MS_CN_OVH") ? atoi(getenv("SAMD_MS_CN_OVH")) : 400;
   const int vn_ovh = getenv("SAMD_MS_VN_OVH") ? atoi(getenv("SAMD_MS_VN_OVH")) : 200;
+  // Z not a multiple of 64: the last chunk of a row has `tail` < 64 lifted copies.  With tail <= 32 the tails of
+  // 64 / gw rows of the same degree (and fused flag) are packed into one item (lane group g works for row g) - at
+  // Z = 80 the 16-lane tails of four rows share a pass instead of running at 25 % lane utilisation each
+  const int tail = z - 64 * (chunks - 1);
+  int gw = 64;
+  while (gw / 2 >= tail && gw > 8) gw /= 2;
+  if (getenv("SAMD_MS_NOPACK")) gw = 64;
+  const int groups = 64 / gw;
+  int tail_sh = 0;
+  while ((1 << tail_sh) < gw) ++tail_sh;
+  std::vector<std::vector<int>> packed;                       // rows of every packed-tail item
+  std::vector<int> packed_key;                                // degree | fused << 5 of the item
+  {
+    std::vector<std::vector<int>> bucket(64);
+    if (groups >= 2)
+      for (int r = 0; r < ncu; ++r) bucket[(int)by_row[r].size() | ((fused_col[r] >= 0) << 5)].push_back(r);
+    for (int key = 0; key < 64; ++key)
+      for (size_t i = 0; i < bucket[key].size(); i += groups) {
+        packed.emplace_back(bucket[key].begin() + i, bucket[key].begin() + std::min(bucket[key].size(), i + groups));
+        packed_key.push_back(key);
+      }
+  }
   for (int r = 0; r < ncu; ++r)
     for (int q = 0; q < chunks; ++q) {
       const int d = (int)by_row[r].size();                    // chunks of pruned check nodes only still get an item (it zeroes their slots)
+      if (groups >= 2 && q == chunks - 1) continue;           // the tail goes into a packed item
       const bool pair = (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn &&
                         (fused_col[r] < 0 || fused_col[r] * z + (q + 2) * 64 <= h->n_vn);
       if (pair) { ci2.push_back({18 * d + cn_ovh, r | (q << 8) | (1 << 24)}); ++q; }
       else ci2.push_back({9 * d + cn_ovh, r | (q << 8)});
     }
+  for (size_t i = 0; i < packed.size(); ++i)
+    ci2.push_back({9 * (packed_key[i] & 31) + cn_ovh, (int32_t)i | (1 << 25)});
   for (int c = 0; c < nbu; ++c)
     for (int q = 0; q < chunks; ++q) {
       if (c * z + q * 64 >= h->n_vn) continue;
@@ -291,8 +316,28 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   lpt_schedule(vf2, h->bp_waves, &mfp, &mfl);
   for (int32_t o : mfp) mvp.push_back(o + (int32_t)mvl.size());
   mvl.insert(mvl.end(), mfl.begin(), mfl.end());
+  std::vector<int32_t> tail_tab;
+  for (size_t i = 0; i < packed.size(); ++i)
+    for (int g = 0; g < groups; ++g) {
+      if (g < (int)packed[i].size()) {
+        const int r = packed[i][g];
+        tail_tab.push_back(row_off[r] & 0x3FFFF);
+        tail_tab.push_back(r | ((fused_col[r] >= 0 ? fused_col[r] : 0) << 16));
+      } else {
+        tail_tab.push_back(0);
+        tail_tab.push_back(0xFF);
+      }
+    }
+  tail_tab.resize(tail_tab.size() + 2, 0);
+  h->ms_tail_sh = tail_sh;
   for (size_t j = 0; j < mcl.size(); ++j) {
     const int32_t d = mcl[j];
+    if ((d >> 25) & 1) {                                      // packed tails: table base | key, last chunk | flag
+      const int i = d & 0xFFFF;
+      cl2.push_back((int32_t)(i * groups) | (packed_key[i] << 18));
+      cl2.push_back(((chunks - 1) << 8) | (1 << 26) | (cprio[j] << 24));
+      continue;
+    }
     const int r = d & 0xFF, f = fused_col[r] >= 0, pr = (d >> 24) & 1;
     cl2.push_back((row_off[r] & 0x3FFFF) | (((int)by_row[r].size() | (f << 5) | (pr << 6)) << 18));
     cl2.push_back((d & 0xFFFF) | ((f ? fused_col[r] : 0) << 16) | (cprio[j] << 24));
@@ -311,6 +356,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   if (rc == SAMD_OK) rc = upload(&h->ms_vn_ptr, mvp.data(), mvp.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_cn_list, cl2.data(), cl2.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_vn_list, vl2.data(), vl2.size());
+  if (rc == SAMD_OK) rc = upload(&h->ms_tail_tab, tail_tab.data(), tail_tab.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_col_deg, col_deg.data(), col_deg.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_cn_ptr, cp.data(), cp.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_cn_list, cl.data(), cl.size());
@@ -321,7 +367,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
 }
 
 void free_onchip_bp_tables(samd_ldpc5g* h) {
-  (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg); (void)hipFree(h->ms_col_ent); (void)hipFree(h->ms_cn_list); (void)hipFree(h->ms_cn_ptr); (void)hipFree(h->ms_vn_ptr); (void)hipFree(h->ms_vn_list);
+  (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg); (void)hipFree(h->ms_col_ent); (void)hipFree(h->ms_cn_list); (void)hipFree(h->ms_cn_ptr); (void)hipFree(h->ms_vn_ptr); (void)hipFree(h->ms_vn_list); (void)hipFree(h->ms_tail_tab);
   (void)hipFree(h->bp_cn_ptr); (void)hipFree(h->bp_cn_list); (void)hipFree(h->bp_vn_ptr); (void)hipFree(h->bp_vn_list);
 }
 
