@@ -42,6 +42,7 @@ struct samd_ldpc5g {
   int32_t* ms_vn_list = nullptr;   // [2 items]  c | chunk<<8 | degree<<16,  dword offset into ms_col_ent
   int32_t* ms_tail_tab = nullptr;  // [2 x groups] packed-tail items: row block byte offset, r | fused column<<16 (r = 0xFF: no row)
   int ms_tail_sh = 6;              // log2 of the lane-group width of a packed-tail item
+  int32_t* ms_vtail_tab = nullptr; // [2 x groups] packed-tail VN items: dword offset of the column's edge table, c (0xFF: no column)
   int32_t* bp_col_deg = nullptr;   // [nb]
   int32_t* bp_cn_ptr = nullptr; int32_t* bp_cn_list = nullptr;     // per-wave item lists (LPT balanced)
   int32_t* bp_vn_ptr = nullptr; int32_t* bp_vn_list = nullptr;

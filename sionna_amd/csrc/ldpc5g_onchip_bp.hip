@@ -293,14 +293,31 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     }
   for (size_t i = 0; i < packed.size(); ++i)
     ci2.push_back({9 * (packed_key[i] & 31) + cn_ovh, (int32_t)i | (1 << 25)});
+  // the same packing for the tails of the (not fused) columns, by column degree
+  std::vector<std::vector<int>> vpacked;
+  std::vector<int> vpacked_deg;
+  {
+    std::vector<std::vector<int>> bucket(64);
+    if (groups >= 2)
+      for (int c = 0; c < nbu; ++c)
+        if (!col_fused[c] && c * z + (chunks - 1) * 64 < h->n_vn && col_deg[c] >= 1 && col_deg[c] <= 30)
+          bucket[col_deg[c]].push_back(c);
+    for (int dg = 0; dg < 64; ++dg)
+      for (size_t i = 0; i < bucket[dg].size(); i += groups) {
+        vpacked.emplace_back(bucket[dg].begin() + i, bucket[dg].begin() + std::min(bucket[dg].size(), i + groups));
+        vpacked_deg.push_back(dg);
+      }
+  }
   for (int c = 0; c < nbu; ++c)
     for (int q = 0; q < chunks; ++q) {
       if (c * z + q * 64 >= h->n_vn) continue;
+      if (groups >= 2 && q == chunks - 1 && !col_fused[c] && col_deg[c] >= 1 && col_deg[c] <= 30) continue;   // packed below
       const bool pair = col_deg[c] <= 12 && (q + 2) * 64 <= z && c * z + (q + 2) * 64 <= h->n_vn;
       auto& dst = col_fused[c] ? vf2 : vi2;
       if (pair) { dst.push_back({10 * col_deg[c] + vn_ovh, c | (q << 8) | (1 << 24)}); ++q; }
       else dst.push_back({5 * col_deg[c] + vn_ovh, c | (q << 8)});
     }
+  for (size_t i = 0; i < vpacked.size(); ++i) vi2.push_back({5 * vpacked_deg[i] + vn_ovh, (int32_t)i | (1 << 25)});
   std::vector<int32_t> mcp, mcl, mvp, mvl, mfp, mfl;
   // wave w runs on SIMD w % 4 as its (w / 4)-th oldest wave: optional capacities by age class (SAMD_MS_CAP="a,b,c,d")
   std::vector<double> cap(h->bp_waves, 1.0);
@@ -342,8 +359,22 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     cl2.push_back((row_off[r] & 0x3FFFF) | (((int)by_row[r].size() | (f << 5) | (pr << 6)) << 18));
     cl2.push_back((d & 0xFFFF) | ((f ? fused_col[r] : 0) << 16) | (cprio[j] << 24));
   }
+  std::vector<int32_t> vtail_tab;
+  for (size_t i = 0; i < vpacked.size(); ++i)
+    for (int g = 0; g < groups; ++g) {
+      const bool has = g < (int)vpacked[i].size();
+      vtail_tab.push_back(has ? col_start[vpacked[i][g]] : 0);
+      vtail_tab.push_back(has ? vpacked[i][g] : 0xFF);
+    }
+  vtail_tab.resize(vtail_tab.size() + 2, 0);
   for (size_t j = 0; j < mvl.size(); ++j) {
     const int32_t d = mvl[j];
+    if ((d >> 25) & 1) {                                      // packed tails: last chunk | degree | flag, table base
+      const int i = d & 0xFFFF;
+      vl2.push_back(((chunks - 1) << 8) | (vpacked_deg[i] << 16) | (1 << 22) | ((j < vprio.size() ? vprio[j] : 0) << 24));
+      vl2.push_back(i * groups);
+      continue;
+    }
     const int c = d & 0xFF, pr = (d >> 24) & 1;
     vl2.push_back((d & 0xFFFF) | ((col_deg[c] | (pr << 5)) << 16) | ((j < vprio.size() ? vprio[j] : 0) << 24));
     vl2.push_back(col_start[c]);
@@ -357,6 +388,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   if (rc == SAMD_OK) rc = upload(&h->ms_cn_list, cl2.data(), cl2.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_vn_list, vl2.data(), vl2.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_tail_tab, tail_tab.data(), tail_tab.size());
+  if (rc == SAMD_OK) rc = upload(&h->ms_vtail_tab, vtail_tab.data(), vtail_tab.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_col_deg, col_deg.data(), col_deg.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_cn_ptr, cp.data(), cp.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_cn_list, cl.data(), cl.size());
@@ -367,7 +399,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
 }
 
 void free_onchip_bp_tables(samd_ldpc5g* h) {
-  (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg); (void)hipFree(h->ms_col_ent); (void)hipFree(h->ms_cn_list); (void)hipFree(h->ms_cn_ptr); (void)hipFree(h->ms_vn_ptr); (void)hipFree(h->ms_vn_list); (void)hipFree(h->ms_tail_tab);
+  (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg); (void)hipFree(h->ms_col_ent); (void)hipFree(h->ms_cn_list); (void)hipFree(h->ms_cn_ptr); (void)hipFree(h->ms_vn_ptr); (void)hipFree(h->ms_vn_list); (void)hipFree(h->ms_tail_tab); (void)hipFree(h->ms_vtail_tab);
   (void)hipFree(h->bp_cn_ptr); (void)hipFree(h->bp_cn_list); (void)hipFree(h->bp_vn_ptr); (void)hipFree(h->bp_vn_list);
 }
 

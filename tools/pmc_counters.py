@@ -19,8 +19,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {   # key -> (substring of the kernel name, unit, source file)
     # the explicit-message engine, by its last template argument: the check-node rule (2 min-sum, 1 boxplus-phi)
-    "ldpc5g_ms": ("ldpc5g_decode_ms_kernel<true, 16, true, 2>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
-    "ldpc5g_bp": ("ldpc5g_decode_ms_kernel<true, 16, true, 1>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
+    "ldpc5g_ms": ("ldpc5g_decode_ms_kernel<true, 16, true, 2, false>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
+    "ldpc5g_bp": ("ldpc5g_decode_ms_kernel<true, 16, true, 1, false>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
     "polar_scl": ("polar_scl_reg_kernel", "decode", "sionna_amd/csrc/polar_scl_reg.hip"),
     "ofdm_lmmse": ("ofdm_lmmse_diag_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
 }
