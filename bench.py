@@ -306,7 +306,10 @@ def bench_c5(args, short=False):
                       "batch": B, "ebno_db": ebno},
            "bler": float((u_hat != u).any(dim=1).float().mean()),
            "roofline": onchip_roofline("polar_scl", "polar_scl_reg_kernel<8> (one wave per codeword, low stages in registers)", B, ms,
-                                       {"compulsory_io_gbps": round((4 * n + 4 * k) * B / (ms * 1e-3) / 1e9, 2)})}
+                                       {"compulsory_io_gbps": round((4 * n + 4 * k) * B / (ms * 1e-3) / 1e9, 2),
+                                        "traffic_note": "traffic = the L2 scratch of the top tree stages (40 KB per resident "
+                                                        "codeword x 8192 codewords exceed L2 + MALL and stream through HBM), "
+                                                        "not re-reads of the 4n + 4k compulsory bytes"})}
     if not args.no_cpu_baseline:
         from oracle import polar as op, polar_c as pc
         code = op.Polar5GCode(k, n)
