@@ -3,9 +3,11 @@
 
 The decoding tree of the reference's recursion (decoding.py:919-1005, with the fast-SCL
 rate-0 / repetition shortcuts of :525-599) is flattened ONCE on the host into a list of operations
-that the HIP kernel ``samd_polar_scl_decode_f32`` interprets with one workgroup per codeword and the
-whole list state in LDS (csrc/polar.hip).  BP decoding and the hybrid SC/NumPy-SCL mode are outside
-the hot path."""
+that ``samd_polar_scl_decode_f32`` interprets with one wave per codeword: the engine of
+csrc/polar_scl_reg.hip (SC and list sizes 1..32 at n >= 64: low tree stages in registers, whole sub-trees as
+one schedule record) or the generic engine of csrc/polar.hip (everything in LDS / L2 scratch).  The hybrid
+mode runs SC first and the list decoder on the words whose CRC fails, like the reference; BP decoding is
+outside the hot path."""
 import numbers
 
 import numpy as np
