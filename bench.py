@@ -124,6 +124,30 @@ def reduce_max(value, world, device):
     return float(t.item())
 
 
+def self_launch_argv(n_gpus, argv=None, port=None):
+    """Command line that runs this file as N ranks of ONE node (one process per GPU, RCCL over xGMI) - exactly the
+    launch the driver uses for N > 1; `python bench.py --gpus N` from a plain shell re-executes itself as this."""
+    import socket
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv)
+
+
+def self_launch(n_gpus):
+    """`bench.py --gpus N` without WORLD_SIZE: replace this process by the N-rank launch (rank 0 prints the ONE line)."""
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if os.environ.get("SAMD_BENCH_BACKEND", "nccl") == "nccl" and have < n_gpus and "--dry-dist" not in sys.argv:
+        print(f"bench.py: --gpus {n_gpus} but only {have} GPU(s) visible (SAMD_BENCH_BACKEND=gloo shares devices "
+              "between ranks for a code-path check)", file=sys.stderr)
+        sys.exit(2)
+    argv = self_launch_argv(n_gpus)
+    sys.stdout.flush()
+    os.execv(sys.executable, argv)
+
+
 def timed_steps(step, steps, warmup, world, device, device_sync, counters=None):
     """W untimed steps, then EXACTLY `steps` steps bracketed by barrier + device synchronisation on both sides;
     returns (max-over-ranks wall seconds, sum-over-ranks counters)."""
@@ -367,6 +391,32 @@ def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms):
             "algorithmic_bytes_per_decode": b_msg(num_iter, k), "decoder_ms_per_launch_set": round(dec_ms, 3), **io}
 
 
+def dry_dist(args, world, rank):
+    """--dry-dist: the N-rank control path of this file (self-launch, env rendezvous, counted_step, barrier-bracketed
+    timing, MAX over ranks, SUM of the counters, rank 0 prints ONE line) with a stand-in decoder on host tensors."""
+    import torch.distributed as dist
+    B, k = min(args.batch, 256), 64
+    g = torch.Generator().manual_seed(1000 + rank)
+    u = torch.randint(0, 2, (B, k), generator=g).float()
+    flips = (torch.rand((B, k), generator=g) < 0.01).float()
+
+    def count_into(b, b_hat, acc):
+        acc[0] += int((b != b_hat).sum())
+        acc[1] += int((b != b_hat).any(dim=1).sum())
+
+    counters = torch.zeros(4, dtype=torch.int64)
+    step = counted_step(lambda: (u + flips) % 2, u, counters, count_into, world)
+    t_wall, c = timed_steps(step, args.steps, args.warmup, world, torch.device("cpu"), lambda: None, counters)
+    if rank == 0:
+        print(json.dumps({"metric": "dry-dist (control path only, no kernels)", "value": round(B * world * args.steps / t_wall, 1),
+                          "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(t_wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "data": "synthetic", "config": {"workload": "dry-dist", "parallelism": f"dp{world}", "batch_per_gpu": B},
+                          "counters": [int(x) for x in c], "local_bits_per_rank": B * k * args.steps}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -381,6 +431,9 @@ def main():
     ap.add_argument("--also", default="boxplus-phi", help="second CN rule timed with fewer steps ('none' disables)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the short C4 / C5 sub-lines")
+    ap.add_argument("--dry-dist", action="store_true",
+                    help="launch / rendezvous / step / reduce logic only, on host tensors over gloo (no GPU, no kernels): "
+                         "what tests/test_bench_dist.py runs through the real `--gpus N` self-launch")
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2 = headline LDPC decode (default); c4 = OFDM 4x2 LMMSE pass; c5 = Polar SCL-8 (single GPU)")
     args = ap.parse_args()
@@ -390,22 +443,24 @@ def main():
         return print(json.dumps(bench_c5(args)))
 
     world, rank, local_rank = world_info()
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs a torch.distributed.run launch", file=sys.stderr)
-        sys.exit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args.gpus)       # not started as a rank: become the launcher of N ranks (never returns)
     import torch.distributed as dist
     # SAMD_BENCH_BACKEND=gloo: code-path check of the N>1 logic on a box with fewer GPUs than ranks
     # (ranks then share devices); the driver's runs use the default, RCCL.
-    backend = os.environ.get("SAMD_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
+    backend = "gloo" if args.dry_dist else os.environ.get("SAMD_BENCH_BACKEND", "nccl")
+    if not args.dry_dist:
+        if backend != "nccl":
+            local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+    if args.dry_dist:
+        return dry_dist(args, world, rank)
 
     import sionna_amd.phy as phy
     from sionna_amd import _ffi

@@ -73,15 +73,112 @@ def get_throughput(batch_size, ebno_db, model, repetitions=1):
 
 # ---------------------------------------------------------------------------------- sim_ber
 def _dist_world(distribute):
-    """(enabled, world_size) for the requested ``distribute`` mode."""
+    """(enabled, world_size) for the requested ``distribute`` mode.
+
+    The reference fans out from ONE process over every visible GPU (misc.py:616-655).  Here a rank is a process, so
+    ``distribute`` means "all ranks of the initialised process group".  Asked for in a process that was NOT launched as
+    a rank while several GPUs are visible, it raises instead of silently simulating on one GPU; with at most one GPU
+    visible it is off, like the reference with a single logical device (misc.py:620-622)."""
     import torch.distributed as dist
     if distribute is None:
         return False, 1
-    if not (dist.is_available() and dist.is_initialized()):
-        return False, 1                                     # like misc.py:620-622: no devices -> off
-    if distribute == "all" or distribute is True or isinstance(distribute, (tuple, list)):
+    if not (distribute == "all" or distribute is True or isinstance(distribute, (tuple, list))):
+        raise ValueError("Unknown value for distribute.")
+    if dist.is_available() and dist.is_initialized():
         return True, dist.get_world_size()
-    raise ValueError("Unknown value for distribute.")
+    n_vis = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if isinstance(distribute, (tuple, list)):
+        n_vis = len([i for i in distribute if i < n_vis])
+    if n_vis > 1:
+        raise RuntimeError(
+            f"sim_ber(distribute={distribute!r}): {n_vis} GPUs are visible but this process is not a rank of a "
+            "torch.distributed process group, and a rank is one process per GPU here. Start the script with "
+            f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node={n_vis} --master-addr 127.0.0.1 script.py` "
+            "(+ sionna_amd.phy.utils.init_distributed() at its top), or call "
+            "sionna_amd.phy.utils.spawn_sim_ber(make_mc_fun, ...) which starts the ranks itself.")
+    return False, 1
+
+
+def init_distributed(backend=None):
+    """Join the process group described by the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*):
+    binds the rank to ``cuda:LOCAL_RANK`` and initialises RCCL (backend "nccl"), or gloo when no GPU is visible.
+    Returns ``(rank, world_size)``; a process that was not launched as a rank gets ``(0, 1)`` and nothing happens."""
+    import os
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    have_gpu = torch.cuda.is_available() and torch.cuda.device_count() > 0
+    if backend is None:
+        backend = "nccl" if have_gpu else "gloo"
+    if have_gpu:
+        local_rank %= torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def _spawn_rank(rank, world, port, backend, make_mc_fun, make_args, sim_kwargs, queue):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    init_distributed(backend)
+    try:
+        mc_fun = make_mc_fun(*make_args)
+        ber, bler = sim_ber(mc_fun, distribute="all", **sim_kwargs)
+        if rank == 0:
+            queue.put((np.asarray(ber.cpu()), np.asarray(bler.cpu())))
+    finally:
+        dist.destroy_process_group()
+
+
+def spawn_sim_ber(make_mc_fun, ebno_dbs, batch_size, max_mc_iter, *, make_args=(), nprocs=None, backend=None, **kwargs):
+    """``sim_ber(..., distribute="all")`` from a process that is not a rank (a notebook): starts one process per
+    visible GPU (``nprocs``; RCCL, or gloo without GPUs), each builds its own model with the importable, module-level
+    ``make_mc_fun(*make_args)`` (device handles cannot be pickled across processes, a factory can), runs ``sim_ber`` on
+    its own Philox stream, and rank 0's ``(ber, bler)`` - the all-reduced, global figures - are returned.  The
+    single-process fan-out of the reference (misc.py:616-655, ``strategy.run`` :541-548) becomes this."""
+    import socket
+    import torch.multiprocessing as mp
+    if nprocs is None:
+        nprocs = torch.cuda.device_count() if torch.cuda.is_available() else 1
+    nprocs = max(int(nprocs), 1)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    queue = ctx.Queue()
+    sim_kwargs = dict(ebno_dbs=np.asarray(ebno_dbs), batch_size=batch_size, max_mc_iter=max_mc_iter, **kwargs)
+    procs = [ctx.Process(target=_spawn_rank, args=(r, nprocs, port, backend, make_mc_fun, tuple(make_args), sim_kwargs, queue))
+             for r in range(nprocs)]
+    for p in procs:
+        p.start()
+    res = None
+    try:
+        while res is None:
+            try:
+                res = queue.get(timeout=1.0)
+            except Exception:  # pylint: disable=broad-except  (queue.Empty: keep waiting while the ranks live)
+                if any(p.exitcode not in (None, 0) for p in procs):
+                    raise RuntimeError("spawn_sim_ber: a rank exited with an error (see its traceback above)") from None
+                if all(p.exitcode is not None for p in procs):
+                    raise RuntimeError("spawn_sim_ber: the ranks exited without a result") from None
+    finally:
+        for p in procs:
+            p.join(timeout=120 if res is not None else 5)
+            if p.is_alive():
+                p.terminate()
+    from ..block import wrap
+    rdtype = dtypes[kwargs.get("precision") or config.precision]["torch"]["rdtype"]
+    return wrap(torch.from_numpy(res[0]).to(rdtype)), wrap(torch.from_numpy(res[1]).to(rdtype))
 
 
 def _all_reduce_counters(vec):

@@ -76,3 +76,28 @@ def test_bench_roofline_helpers():
         if rec:
             rf = bench.c2_roofline("minsum", True, 65536, 2816, 20, 30.0)
             assert 0 < rf["frac"] < 1 and rf["unit"] == "G wave64-inst/s" and rf["hbm_resident_equiv"]["algorithmic_bytes_per_decode"] == 13684736
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_self_launches_its_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE) re-executes itself as a 2-rank torch.distributed.run
+    launch and rank 0 prints ONE line with n_gpus 2 and the SUM of both ranks' counters (--dry-dist: control path on host
+    tensors over gloo; the GPU run of the same path is `SAMD_BENCH_BACKEND=gloo python bench.py --gpus 2` on a 1-GPU box)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-dist", "--steps", "4", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                # rank 0 only
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["steps"] == 4
+    assert rec["counters"][2] == 2 * rec["local_bits_per_rank"]      # counters = 2 x the single-rank ones
+
+
+def test_bench_self_launch_command_line():
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = bench.self_launch_argv(8, ["--gpus", "8", "--steps", "3"], port=29511)
+    assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[-4:] == ["--gpus", "8", "--steps", "3"]

@@ -78,3 +78,47 @@ def test_sim_ber_two_ranks_gloo():
     assert abs(ber0[0] - 1 / 16) < 0.01 and ber0[1] == 0.0 and ber0[2] == 0.0
     # early stop on the GLOBAL counter: 300 errors need ~300/(1/16*5000*2) -> 1 iteration per rank
     assert m0 == m1 and m0 <= 2
+
+
+def make_injector(p_err_num):
+    """module-level factory for spawn_sim_ber: every rank builds its own mc_fun (here an error injector on the rank's
+    own Philox stream)"""
+    sys.path.insert(0, ROOT)
+    from sionna_amd.phy.config import PhiloxGenerator
+    from oracle import utils as outil
+    gen = PhiloxGenerator(77)
+
+    def mc_fun(batch_size, ebno_db):
+        n = batch_size * 64
+        u = outil.random_bits(gen.seed, gen.next_call(), n).reshape(batch_size, 64)
+        flip = outil.random_bits(gen.seed, gen.next_call(), p_err_num * n).reshape(p_err_num, batch_size, 64)
+        err = (flip.sum(0) == p_err_num).astype(np.float32) if ebno_db < 3 else np.zeros_like(u)
+        return torch.from_numpy(u), torch.from_numpy(np.abs(u - err).astype(np.float32))
+    return mc_fun
+
+
+@pytest.mark.timeout(300)
+def test_spawn_sim_ber_fans_out_from_a_plain_process():
+    """sim_ber(distribute="all") from a process that is not a rank: spawn_sim_ber starts the ranks itself (gloo here,
+    RCCL on a GPU node) and returns the all-reduced result - the reference's single-process fan-out (misc.py:616-655)."""
+    from sionna_amd.phy.utils import spawn_sim_ber
+    ber, bler = spawn_sim_ber(make_injector, np.array([0.0, 10.0]), batch_size=100, max_mc_iter=8, make_args=(3,),
+                              nprocs=2, backend="gloo", verbose=False, early_stop=False)
+    assert abs(float(ber[0]) - 1 / 8) < 0.01 and float(ber[1]) == 0.0 and float(bler[0]) > 0.99
+
+
+def test_distribute_all_never_silently_single_gpu(monkeypatch):
+    """not a rank + several GPUs visible -> sim_ber(distribute="all") raises; one GPU / none -> off like the reference"""
+    from sionna_amd.phy.utils import misc
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    with pytest.raises(RuntimeError, match="8 GPUs are visible"):
+        misc._dist_world("all")
+    assert misc._dist_world([0]) == (False, 1)            # a single selected device
+    with pytest.raises(RuntimeError):
+        misc._dist_world([0, 3])
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    assert misc._dist_world("all") == (False, 1)
+    assert misc._dist_world(None) == (False, 1)
+    with pytest.raises(ValueError):
+        misc._dist_world("some")
