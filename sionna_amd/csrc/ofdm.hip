@@ -156,14 +156,18 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
 // The optional normalisation (unit mean energy over ra, ta, t, f) is a deterministic in-block reduction as before.
 typedef float c2o_f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MAXP>
+// TAPS_LDS = false: the taps of a link do not fit beside the phase table (many antenna pairs / clusters / symbols) and
+// are read from global memory (the lanes of a group read the same address: one L1 broadcast).  MAXP = 0: more than 64
+// paths - the phase column stays in LDS and the path loop has a run-time trip count.  Same products, same ascending
+// order: the variants return identical values (tests/test_gpu_ofdm.py::test_cir_to_ofdm_large_links).
+template <int MAXP, bool TAPS_LDS>
 __global__ __launch_bounds__(256) void cir_to_ofdm_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
                                                           const float* __restrict__ freqs, int RX, int RA, int TX,
                                                           int TA, int P, int T, int F, int normalize,
                                                           float2* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) float2 tab[];   // [P][F] phases, taps [RA*TA][P][T], red[256]
   float2* taps = tab + (size_t)P * F;
-  float* red = reinterpret_cast<float*>(taps + (size_t)RA * TA * P * T);
+  float* red = reinterpret_cast<float*>(taps + (TAPS_LDS ? (size_t)RA * TA * P * T : 0));
   const int tx = blockIdx.x % TX;
   const int rx = (blockIdx.x / TX) % RX;
   const int b = blockIdx.x / (TX * RX);
@@ -177,10 +181,11 @@ __global__ __launch_bounds__(256) void cir_to_ofdm_kernel(const float2* __restri
   }
   // the taps of this (b, rx, tx): RA*TA contiguous runs of P*T values -> LDS (every tap is used by all F subcarriers)
   const int pt = P * T;
-  for (int i = threadIdx.x; i < RA * TA * pt; i += nt) {
-    const int q = i % pt, ta = (i / pt) % TA, ra = i / (pt * TA);
-    taps[i] = a[((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * (size_t)pt + q];
-  }
+  if (TAPS_LDS)
+    for (int i = threadIdx.x; i < RA * TA * pt; i += nt) {
+      const int q = i % pt, ta = (i / pt) % TA, ra = i / (pt * TA);
+      taps[i] = a[((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * (size_t)pt + q];
+    }
   __syncthreads();
   const int rows = RA * TA * T;                                   // (ra, ta, t) rows of F outputs each
   const int G = F <= nt ? nt / F : 1;                             // row groups working side by side
@@ -189,23 +194,33 @@ __global__ __launch_bounds__(256) void cir_to_ofdm_kernel(const float2* __restri
     const int g = F <= nt ? (int)threadIdx.x / F : 0;
     const int f = F <= nt ? (int)threadIdx.x % F : f0 + (int)threadIdx.x;
     const bool act = g < G && f < F;
-    float2 ph[MAXP];
+    float2 ph[MAXP > 0 ? MAXP : 1];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) ph[p] = (act && p < P) ? tab[p * F + f] : make_float2(0.f, 0.f);
     for (int row = g; act && row < rows; row += G) {
       const int t = row % T, ta = (row / T) % TA, ra = row / (T * TA);
-      const float2* ap = taps + (size_t)(ra * TA + ta) * pt + t;   // same address for the lanes of a group: LDS broadcast
+      // same address for the lanes of a group: LDS (or L1) broadcast
+      const float2* ap = TAPS_LDS ? taps + (size_t)(ra * TA + ta) * pt + t
+                                  : a + ((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * (size_t)pt + t;
       // h += a * ph as two packed fused multiply-adds per path: (h.x, h.y) += a.x * (ph.x, ph.y); += a.y * (-ph.y, ph.x)
       // (the library is built with -ffp-contract=off for the bit-exact decoders; this kernel is held to 1e-4 against
       // the float64 oracle, and the fused form is the more accurate one)
       c2o_f32x2 hv = {0.f, 0.f};
+      if constexpr (MAXP > 0) {
 #pragma unroll
-      for (int p = 0; p < MAXP; ++p)
-        if (p < P) {
-          const float2 av = ap[p * T];
-          hv = __builtin_elementwise_fma(c2o_f32x2{av.x, av.x}, c2o_f32x2{ph[p].x, ph[p].y}, hv);
-          hv = __builtin_elementwise_fma(c2o_f32x2{av.y, av.y}, c2o_f32x2{-ph[p].y, ph[p].x}, hv);
+        for (int p = 0; p < MAXP; ++p)
+          if (p < P) {
+            const float2 av = ap[p * T];
+            hv = __builtin_elementwise_fma(c2o_f32x2{av.x, av.x}, c2o_f32x2{ph[p].x, ph[p].y}, hv);
+            hv = __builtin_elementwise_fma(c2o_f32x2{av.y, av.y}, c2o_f32x2{-ph[p].y, ph[p].x}, hv);
+          }
+      } else {
+        for (int p = 0; p < P; ++p) {
+          const float2 av = ap[p * T], pv = tab[p * F + f];
+          hv = __builtin_elementwise_fma(c2o_f32x2{av.x, av.x}, c2o_f32x2{pv.x, pv.y}, hv);
+          hv = __builtin_elementwise_fma(c2o_f32x2{av.y, av.y}, c2o_f32x2{-pv.y, pv.x}, hv);
         }
+      }
       out[(((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * T + t) * F + f] = make_float2(hv.x, hv.y);
       energy += hv.x * hv.x + hv.y * hv.y;
     }
@@ -352,26 +367,29 @@ extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const floa
                                     int num_rx_ant, int num_tx, int num_tx_ant, int num_paths, int num_time_steps,
                                     int num_freqs, int normalize, float* h_freq, void* stream) {
   SAMD_REQUIRE(a && tau && frequencies && h_freq && batch > 0, "bad argument");
-  SAMD_REQUIRE(num_paths >= 1 && num_paths <= 64, "1 <= num_paths <= 64 (the phase column of a subcarrier lives in registers)");
-  const size_t lds = ((size_t)num_paths * num_freqs + (size_t)num_rx_ant * num_tx_ant * num_paths * num_time_steps) * sizeof(float2) +
-                     256 * sizeof(float);
-  SAMD_REQUIRE(lds <= 160 * 1024, "phase table + taps of one (batch, rx, tx) link exceed the LDS");
+  SAMD_REQUIRE(num_paths >= 1 && num_freqs >= 1 && num_time_steps >= 1, "bad size");
+  const size_t tab_b = (size_t)num_paths * num_freqs * sizeof(float2) + 256 * sizeof(float);
+  const size_t taps_b = (size_t)num_rx_ant * num_tx_ant * num_paths * num_time_steps * sizeof(float2);
+  SAMD_REQUIRE(tab_b <= 160 * 1024, "phase table (num_paths x num_freqs) exceeds the LDS");
+  const bool taps_lds = tab_b + taps_b <= 160 * 1024;      // else the taps are read from global memory (L1 broadcast)
+  const size_t lds = tab_b + (taps_lds ? taps_b : 0);
   const dim3 grid(batch * num_rx * num_tx), blk(256);
   hipStream_t st = (hipStream_t)stream;
-#define SAMD_C2O(MAXP)                                                                                              \
-  hipLaunchKernelGGL((cir_to_ofdm_kernel<MAXP>), grid, blk, lds, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant, \
-                     num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq)
+  typedef void (*kern_t)(const float2*, const float*, const float*, int, int, int, int, int, int, int, int, float2*);
+#define SAMD_C2O_K(MAXP) {cir_to_ofdm_kernel<MAXP, false>, cir_to_ofdm_kernel<MAXP, true>}
+  static const kern_t kerns[6][2] = {SAMD_C2O_K(8), SAMD_C2O_K(16), SAMD_C2O_K(24), SAMD_C2O_K(32), SAMD_C2O_K(64), SAMD_C2O_K(0)};
+#undef SAMD_C2O_K
+  const int ki = num_paths <= 8 ? 0 : num_paths <= 16 ? 1 : num_paths <= 24 ? 2 : num_paths <= 32 ? 3 : num_paths <= 64 ? 4 : 5;
+  const kern_t kern = kerns[ki][taps_lds ? 1 : 0];
   if (lds > 64 * 1024) {
-    const void* fns[] = {(const void*)cir_to_ofdm_kernel<8>, (const void*)cir_to_ofdm_kernel<16>, (const void*)cir_to_ofdm_kernel<24>,
-                         (const void*)cir_to_ofdm_kernel<32>, (const void*)cir_to_ofdm_kernel<64>};
-    for (const void* fn : fns) SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    static bool attr_set[6][2] = {};                         // once per kernel (one device per process)
+    if (!attr_set[ki][taps_lds ? 1 : 0]) {
+      SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set[ki][taps_lds ? 1 : 0] = true;
+    }
   }
-  if (num_paths <= 8) SAMD_C2O(8);
-  else if (num_paths <= 16) SAMD_C2O(16);
-  else if (num_paths <= 24) SAMD_C2O(24);
-  else if (num_paths <= 32) SAMD_C2O(32);
-  else SAMD_C2O(64);
-#undef SAMD_C2O
+  hipLaunchKernelGGL(kern, grid, blk, lds, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx, num_tx_ant,
+                     num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq);
   return launch_status();
 }
 

@@ -175,7 +175,12 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         rec = next_rec;
         ++ip;
         next_rec = (ip < p.num_ops) ? p.ops[ip] : (int)OP_END;
-        if ((rec & 7) == OP_SUBTREE) { fused = rec; micro = 5; }
+        if ((rec & 7) == OP_SUBTREE) {
+          // this engine expands stage-1 records only; a schedule built for the register engine (stage R / R + 1
+          // records) must never be decoded here with silently wrong bits: fail the launch
+          if (((rec >> 3) & 15) != 1) __builtin_trap();
+          fused = rec; micro = 5;
+        }
       }
       if (micro > 0) {
         // f, leaf (bit a2), g, leaf (bit a2 + 1), combine - the five operations pack_schedule fused

@@ -101,7 +101,9 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
   float* pm_s = cv + L;                                                      // [L] final metrics by position
   int* order = reinterpret_cast<int*>(pm_s + L);                             // [L] position -> slot
   float* blk = reinterpret_cast<float*>(order + L);                          // [2L]
-  uint32_t* fzb = reinterpret_cast<uint32_t*>(blk + 2 * L);                  // [wstride] frozen-bit map of the code
+  // the header is 84 L bytes: round it up to 16 so that fzb / bits / llr keep the alignment their 128-bit accesses want
+  // for L = 1, 2 as well (scl_reg_lds_bytes reserves 88 L + 64)
+  uint32_t* fzb = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(smem) + (((size_t)L * 84 + 15) & ~(size_t)15));   // [wstride] frozen-bit map
   uint32_t* bits = fzb + wstride;                                            // [L][wstride] decided u bits
   float* llr = reinterpret_cast<float*>(bits + (size_t)L * wstride);         // [L][hn]  stage s at [2^s, 2^(s+1))
   unsigned char* beta = reinterpret_cast<unsigned char*>(llr + (size_t)L * hn);   // [L][hn]  bit 0 left, bit 1 right result
@@ -569,7 +571,10 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
 }
 
 int scl_reg_stages(int n, int list_size, int sc_mode) {
-  if (getenv("SAMD_SCL_GENERIC")) return -1;
+  // read once: the host caches a schedule built for the engine this function announced, so the decision must not
+  // change during the life of the process
+  static const bool force_generic = getenv("SAMD_SCL_GENERIC") != nullptr;
+  if (force_generic) return -1;
   if (list_size != 1 && list_size != 2 && list_size != 4 && list_size != 8 && list_size != 16 && list_size != 32) return -1;
   if (sc_mode && list_size != 1) return -1;
   int m = 0;

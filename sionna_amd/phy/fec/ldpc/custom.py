@@ -197,6 +197,13 @@ class CustomBPEngine:
         d = self._tables(llr.device)
         llr_t = -1.0 * torch.clamp(llr, -llr_max, llr_max).transpose(0, 1)       # [N, B]   decoding.py:552-565
         v2c = llr_t[d["vn_idx"]] if msg_v2c is None else -1.0 * msg_v2c
+        if self.v2c_callbacks:
+            # decoding.py:583-594: every v2c callback sees the initial (or state-in) messages once, iteration 0, with the
+            # channel LLRs as third argument - weighted BP weights them, an EXIT callback records mi[0]
+            vrag = RaggedMessages(v2c, d["vn_splits"], d["vn_idx"])
+            for cb in self.v2c_callbacks:
+                vrag = cb(vrag, 0, llr_t)
+            v2c = vrag.flat_values
         c2v = torch.zeros_like(v2c)
         x_hat = llr_t
         for it in range(int(num_iter)):

@@ -101,6 +101,7 @@ class Constellation(Block):
             raise ValueError("You must provide a value for `points`")
         self._points = None
         self._dev = None
+        self._dev64 = None
         if constellation_type == "qam":
             points = qam(self._num_bits_per_symbol, normalize=True, precision=self.precision)
         elif constellation_type == "pam":
@@ -120,6 +121,7 @@ class Constellation(Block):
         assert isinstance(value, bool), "`normalize` must be boolean"
         self._normalize = value
         self._dev = None
+        self._dev64 = None
 
     @property
     def center(self):
@@ -130,6 +132,7 @@ class Constellation(Block):
         assert isinstance(value, bool), "`center` must be boolean"
         self._center = value
         self._dev = None
+        self._dev64 = None
 
     @property
     def points(self):
@@ -147,6 +150,7 @@ class Constellation(Block):
             raise ValueError("`points` must have shape [2**num_bits_per_symbol]")
         self._points = v.astype(dtypes[self.precision]["np"]["cdtype"])
         self._dev = None
+        self._dev64 = None
 
     def _host_points(self):
         x = self._points

@@ -59,12 +59,13 @@ def test_callbacks_and_weighted_bp_gradient():
     eng = _engine(ref, "boxplus", c2v=[stats, lambda m, it: (seen.append(("c2v", it, m.shape)), m)[1]],
                   v2c=[exit_cb, lambda m, it, x_hat: (seen.append(("v2c", it, tuple(x_hat.shape))), m)[1]])
     x, _ = eng.decode(llr, 5, 20.0)
-    assert [s[1] for s in seen if s[0] == "c2v"] == [0, 1, 2, 3, 4] and [s[1] for s in seen if s[0] == "v2c"] == [1, 2, 3, 4, 5]
-    assert seen[0][2] == (10, None, 64) and seen[1][2] == (24, 64)
+    assert [s[1] for s in seen if s[0] == "c2v"] == [0, 1, 2, 3, 4] and [s[1] for s in seen if s[0] == "v2c"] == [0, 1, 2, 3, 4, 5]
+    # decoding.py:583-594: the v2c callbacks run once before the first iteration (it = 0, third argument = channel LLRs)
+    assert seen[0] == ("v2c", 0, (24, 64)) and seen[1][2] == (10, None, 64) and seen[2][2] == (24, 64)
     assert np.all(stats.num_samples == 64) and np.all(np.diff(stats.success_rate) >= 0) and stats.success_rate[-1] > 0.5
     assert 0 < stats.avg_number_iterations <= 5
-    mi = exit_cb.mi[1:]
-    assert np.all(np.isfinite(mi)) and mi[-1] > mi[0]
+    mi = exit_cb.mi
+    assert np.all(np.isfinite(mi)) and mi[-1] > mi[1] > 0 and mi[0] > 0          # mi[0]: the channel messages
     # callbacks that return the messages unchanged do not change the result
     x0, _ = _engine(ref, "boxplus").decode(llr, 5, 20.0)
     assert torch.equal(x, x0)
