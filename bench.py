@@ -381,7 +381,7 @@ def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms):
     io = {"compulsory_io_gbps": round((4 * N_CW + 4 * k) * B / (dec_ms * 1e-3) / 1e9, 1)}
     if onchip:
         minsum = cn_update in ("minsum", "offset-minsum")
-        key = "ldpc5g_ms" if minsum else "ldpc5g_bp"
+        key = "ldpc5g_ms" if minsum else ("ldpc5g_bp_fast" if cn_update == "boxplus-phi-fast" else "ldpc5g_bp")
         name = ("ldpc5g_decode_ms_kernel (on-chip min-sum, one float per edge in LDS, channel LLRs in an L2 workspace row)"
                 if minsum else "ldpc5g_decode_ms_kernel<..., boxplus> (the same engine with bp_math's boxplus node update)")
         return onchip_roofline(key, name, B, dec_ms, {"hbm_resident_equiv": equiv, **io})
@@ -424,7 +424,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=65536, help="codewords per GPU")
     ap.add_argument("--num-iter", type=int, default=20)
-    ap.add_argument("--cn-update", default="minsum", choices=["minsum", "offset-minsum", "boxplus-phi", "boxplus"])
+    ap.add_argument("--cn-update", default="minsum", choices=["minsum", "offset-minsum", "boxplus-phi", "boxplus-phi-fast", "boxplus"])
     ap.add_argument("--engine", default="auto", choices=["auto", "generic"],
                     help="generic forces the HBM-resident decoder also for min-sum")
     ap.add_argument("--ebno-db", type=float, default=4.5)
@@ -539,6 +539,17 @@ def main():
                        "ms_per_step": round(t2 / steps2 * 1e3, 3), "ber": float(c2[0] / max(c2[2], 1)),
                        "bler": float(c2[1] / max(c2[3], 1)),
                        "roofline": c2_roofline(args.also, on2, B, k, args.num_iter, ms2)}
+
+        if args.also == "boxplus-phi":
+            # the same rule on the GPU's transcendental unit (SAMD_CN_BOXPLUS_PHI_FAST): not bit-defined, reported beside
+            dec3 = make_dec("boxplus-phi-fast")
+            t3, ms3, c3 = run(dec3, steps2, 1)
+            out["also"]["fast_math"] = {"cn_update": "boxplus-phi-fast", "value": round(B * world * steps2 / t3, 1),
+                                        "unit": "codewords/s", "ms_per_step": round(t3 / steps2 * 1e3, 3),
+                                        "ber": float(c3[0] / max(c3[2], 1)), "bler": float(c3[1] / max(c3[3], 1)),
+                                        "note": "v_exp_f32 / v_log_f32 instead of the defined exp / log; soft outputs "
+                                                "are not bit-identical to the oracle (tests keep the round-2 tolerance bars)"}
+            del dec3
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c2(llr, k, n, m, args.cn_update, args.num_iter, dec, 12.0, B)

@@ -27,7 +27,30 @@ def lib():
                                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                                C.c_int, C.c_int]
         _lib.oracle_num_threads.restype = C.c_int
+        for fn in (_lib.oracle_phi_f32, _lib.oracle_spec_exp_f32, _lib.oracle_spec_log_f32):
+            fn.restype = None
+            fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
     return _lib
+
+
+def _elementwise(fn, x):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.empty_like(x)
+    fn(x.ctypes.data, y.ctypes.data, x.size)
+    return y
+
+
+def phi_f32(x):
+    """phi of the boxplus-phi rule on the DEFINED float32 exp / log (ldpc_bp.c: Cephes / Eigen restatement)."""
+    return _elementwise(lib().oracle_phi_f32, x)
+
+
+def spec_exp_f32(x):
+    return _elementwise(lib().oracle_spec_exp_f32, x)
+
+
+def spec_log_f32(x):
+    return _elementwise(lib().oracle_spec_log_f32, x)
 
 
 def bp_decode(dec, llr, num_iter=None, hard_out=None, offset=0.5, nthreads=0):

@@ -136,7 +136,10 @@ def cn_update_tanh(r, msg, llr_clipping=None):
 def _phi(x):
     """decoding.py:1092-1120 (literal form, dtype dependent clip)."""
     if x.dtype == np.float32:
-        x = np.clip(x, _F32(8.5e-8), _F32(16.635532))
+        # float32: the defined exp / log (Cephes / Eigen restatement in oracle/ldpc_bp.c; NumPy has no fused
+        # multiply-add, so the element-wise function is the C oracle's) - one bit-level definition for both oracles
+        from . import cbind
+        return cbind.phi_f32(x)
     elif x.dtype == np.float64:
         x = np.clip(x, 1e-12, 28.324079)
     else:

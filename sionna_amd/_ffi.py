@@ -16,7 +16,10 @@ LIB_PATH = os.environ.get("SAMD_LIB") or os.path.join(_HERE, "lib", "libsionna_a
 HEADER_PATH = os.path.join(_HERE, "..", "include", "sionna_amd.h")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
-CN_MODES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2, "min": 2, "offset-minsum": 3}
+# "boxplus-phi-fast": the same rule on the GPU's transcendental unit (SAMD_CN_BOXPLUS_PHI_FAST, include/sionna_amd.h) -
+# an addition to the reference's rule names; "boxplus-phi" evaluates phi on the defined float32 exp / log and is
+# bit-identical to the CPU oracle
+CN_MODES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2, "min": 2, "offset-minsum": 3, "boxplus-phi-fast": 4}
 
 _lib = None
 

@@ -6,6 +6,7 @@
 
 namespace samd {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr float kLargeVal = 100000.f;  // decoding.py:807
 
 __device__ __forceinline__ float sign_nz(float x) { return x < 0.f ? -1.f : 1.f; }  // sign(0) := +1
@@ -53,7 +54,6 @@ __device__ __forceinline__ float phi_fast_f32(float x) {
 // Two phi evaluations at once: the same operations as phi_fast_f32 per component, with every
 // multiply / add / fma issued as a packed-fp32 instruction (v_pk_mul/add/fma_f32: two IEEE results
 // per issue slot) - 17 instead of 25 VALU operations per phi, identical bits.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 log_core2_f32(f32x2 x) {
   const f32x2 y = {__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
   const float c = __uint_as_float(0x3f317217u), cl = __uint_as_float(0x3377d1cfu);
@@ -78,6 +78,73 @@ __device__ __forceinline__ f32x2 phi_fast2_f32(float x0, float x1) {
   res.x = (x.x == 16.635532f) ? 0.f : res.x;
   res.y = (x.y == 16.635532f) ? 0.f : res.y;
   return res;
+}
+
+// ---- the DEFINED float32 arithmetic of phi (round 3; SAMD_CN_BOXPLUS_PHI) ------------------------------------------
+// TensorFlow-CPU evaluates decoding.py:1120 with Eigen's pexp / plog.  Their published algorithm - Cephes expf / logf:
+// m = floor(x log2(e) + 1/2), r = x - m ln2 in two parts, degree-5 polynomial, 2^m scaling; frexp to
+// [sqrt(1/2), sqrt(2)), degree-8 polynomial in three interleaved parts, e ln2 added last; fused multiply-adds - is one
+// fixed sequence of IEEE operations (fma, mul, add, floor, frexp, ldexp: all exact or correctly rounded on gfx950 and on
+// any host), so the rule has a bit-level definition: oracle/ldpc_bp.c states it, these functions follow it operation
+// for operation, and boxplus-phi soft outputs are compared with array_equal (tests/test_gpu_parity.py).  No hardware
+// transcendental (v_exp_f32 / v_log_f32 are 1-ulp approximations without a specification) is involved.  phi(16.635532)
+// = 0 and phi(8.5e-8) = 16.6355324 come out exactly, no pinned point.  The price: 14 operations per exp and 23 per log
+// against 3 quarter-rate transcendentals - the hardware form stays available as SAMD_CN_BOXPLUS_PHI_FAST.
+__device__ __forceinline__ f32x2 spec_exp2_f32(f32x2 x) {
+  const f32x2 t = __builtin_elementwise_fma(x, f32x2{1.44269504088896341f, 1.44269504088896341f}, f32x2{0.5f, 0.5f});
+  const f32x2 m = {__builtin_floorf(t.x), __builtin_floorf(t.y)};
+  f32x2 r = __builtin_elementwise_fma(m, f32x2{-0.693359375f, -0.693359375f}, x);
+  r = __builtin_elementwise_fma(m, f32x2{2.12194440e-4f, 2.12194440e-4f}, r);
+  const f32x2 z = r * r;
+  f32x2 y = {1.9875691500E-4f, 1.9875691500E-4f};
+  y = __builtin_elementwise_fma(y, r, f32x2{1.3981999507E-3f, 1.3981999507E-3f});
+  y = __builtin_elementwise_fma(y, r, f32x2{8.3334519073E-3f, 8.3334519073E-3f});
+  y = __builtin_elementwise_fma(y, r, f32x2{4.1665795894E-2f, 4.1665795894E-2f});
+  y = __builtin_elementwise_fma(y, r, f32x2{1.6666665459E-1f, 1.6666665459E-1f});
+  y = __builtin_elementwise_fma(y, r, f32x2{5.0000001201E-1f, 5.0000001201E-1f});
+  y = __builtin_elementwise_fma(y, z, r);
+  y = y + f32x2{1.f, 1.f};
+  return f32x2{__builtin_ldexpf(y.x, (int)m.x), __builtin_ldexpf(y.y, (int)m.y)};
+}
+__device__ __forceinline__ f32x2 spec_log2_f32(f32x2 x) {     // normal positive arguments
+  f32x2 f = {__builtin_amdgcn_frexp_mantf(x.x), __builtin_amdgcn_frexp_mantf(x.y)};          // [0.5, 1)
+  f32x2 ef = {(float)__builtin_amdgcn_frexp_expf(x.x), (float)__builtin_amdgcn_frexp_expf(x.y)};
+  const bool lt0 = f.x < 0.707106781186547524f, lt1 = f.y < 0.707106781186547524f;
+  const f32x2 tmp = {lt0 ? f.x : 0.f, lt1 ? f.y : 0.f};
+  f = f - f32x2{1.f, 1.f};
+  ef = ef - f32x2{lt0 ? 1.f : 0.f, lt1 ? 1.f : 0.f};
+  f = f + tmp;
+  const f32x2 x2 = f * f, x3 = x2 * f;
+  f32x2 y = __builtin_elementwise_fma(f32x2{7.0376836292E-2f, 7.0376836292E-2f}, f, f32x2{-1.1514610310E-1f, -1.1514610310E-1f});
+  f32x2 y1 = __builtin_elementwise_fma(f32x2{-1.2420140846E-1f, -1.2420140846E-1f}, f, f32x2{1.4249322787E-1f, 1.4249322787E-1f});
+  f32x2 y2 = __builtin_elementwise_fma(f32x2{2.0000714765E-1f, 2.0000714765E-1f}, f, f32x2{-2.4999993993E-1f, -2.4999993993E-1f});
+  y = __builtin_elementwise_fma(y, f, f32x2{1.1676998740E-1f, 1.1676998740E-1f});
+  y1 = __builtin_elementwise_fma(y1, f, f32x2{-1.6668057665E-1f, -1.6668057665E-1f});
+  y2 = __builtin_elementwise_fma(y2, f, f32x2{3.3333331174E-1f, 3.3333331174E-1f});
+  y = __builtin_elementwise_fma(y, x3, y1);
+  y = __builtin_elementwise_fma(y, x3, y2);
+  y = y * x3;
+  y = __builtin_elementwise_fma(f32x2{-0.5f, -0.5f}, x2, y);
+  f = f + y;
+  return __builtin_elementwise_fma(ef, f32x2{0.69314718055994530942f, 0.69314718055994530942f}, f);
+}
+__device__ __forceinline__ f32x2 phi_spec2_f32(float x0, float x1) {
+  const f32x2 x = {clampf(x0, 8.5e-8f, 16.635532f), clampf(x1, 8.5e-8f, 16.635532f)};
+  const f32x2 e = spec_exp2_f32(x), one = {1.f, 1.f};
+  return spec_log2_f32(e + one) - spec_log2_f32(e - one);
+}
+__device__ __forceinline__ float phi_spec_f32(float x) { return phi_spec2_f32(x, x).x; }
+
+// phi of a rule: the defined arithmetic for SAMD_CN_BOXPLUS_PHI, the hardware transcendentals for ..._PHI_FAST
+template <int MODE>
+__device__ __forceinline__ f32x2 phi2_f32(float x0, float x1) {
+  if constexpr (MODE == SAMD_CN_BOXPLUS_PHI_FAST) return phi_fast2_f32(x0, x1);
+  else return phi_spec2_f32(x0, x1);
+}
+template <int MODE>
+__device__ __forceinline__ float phi1_f32(float x) {
+  if constexpr (MODE == SAMD_CN_BOXPLUS_PHI_FAST) return phi_fast_f32(x);
+  else return phi_spec_f32(x);
 }
 
 // ---- check-node update on one batch column; v[0..d) in CN edge order, in place.
@@ -115,7 +182,7 @@ __device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr
         m = fmaxf(m - offset, 0.f);
         v[i] = clampf((sgn[i] * node_sign) * m, -llr_max, llr_max);
       }
-  } else if constexpr (MODE == SAMD_CN_BOXPLUS_PHI) {
+  } else if constexpr (MODE == SAMD_CN_BOXPLUS_PHI || MODE == SAMD_CN_BOXPLUS_PHI_FAST) {
     // signs as bits: sign_nz(v) = -1 <=> v < 0 (a -0 counts as +), (s_i * node_sign) * q = q with the
     // sign bit s_i ^ node, clip(+-q, +-llr_max) = +-min(q, llr_max) for q >= 0; edges two at a time (phi_fast2)
     unsigned sg[MAXD];
@@ -127,25 +194,25 @@ __device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr
         sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
         sg[i + 1] = (v[i + 1] < 0.f) ? 0x80000000u : 0u;
         node ^= sg[i] ^ sg[i + 1];
-        const f32x2 p = phi_fast2_f32(fabsf(v[i]), fabsf(v[i + 1]));
+        const f32x2 p = phi2_f32<MODE>(fabsf(v[i]), fabsf(v[i + 1]));
         v[i] = p.x; v[i + 1] = p.y;
         sum += p.x;
         sum += p.y;
       } else if (i < d) {
         sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
         node ^= sg[i];
-        v[i] = phi_fast_f32(fabsf(v[i]));
+        v[i] = phi1_f32<MODE>(fabsf(v[i]));
         sum += v[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < MAXD; i += 2) {
       if (i + 1 < MAXD && i + 1 < d) {
-        const f32x2 q = phi_fast2_f32(-1.f * v[i] + sum, -1.f * v[i + 1] + sum);
+        const f32x2 q = phi2_f32<MODE>(-1.f * v[i] + sum, -1.f * v[i + 1] + sum);
         v[i] = __uint_as_float(__float_as_uint(fminf(q.x, llr_max)) ^ (sg[i] ^ node));
         v[i + 1] = __uint_as_float(__float_as_uint(fminf(q.y, llr_max)) ^ (sg[i + 1] ^ node));
       } else if (i < d) {
-        const float q = phi_fast_f32(-1.f * v[i] + sum);
+        const float q = phi1_f32<MODE>(-1.f * v[i] + sum);
         v[i] = __uint_as_float(__float_as_uint(fminf(q, llr_max)) ^ (sg[i] ^ node));
       }
     }

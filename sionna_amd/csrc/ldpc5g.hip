@@ -378,7 +378,7 @@ static bool use_spill_boxplus(const samd_ldpc5g* h) { return !h->bp_ok && h->sp_
 extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode) {
   // 0 when the whole state fits in LDS; larger codes keep part of it in this (L2-resident) scratch
   if (!h) return 0;
-  const bool boxplus = cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI;
+  const bool boxplus = cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || cn_mode == SAMD_CN_BOXPLUS_PHI_FAST;
   if (boxplus && use_spill_boxplus(h)) return onchip_mss_workspace_bytes(h, batch);
   if (boxplus || use_explicit_minsum(h)) return onchip_bp_workspace_bytes(h, batch);
   if (use_spill_minsum(h)) return onchip_mss_workspace_bytes(h, batch);
@@ -387,7 +387,8 @@ extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int
 
 extern "C" int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode) {
   if (!h) return 0;
-  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) return h->bp_ok ? 2 : (use_spill_boxplus(h) ? 3 : 0);
+  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || cn_mode == SAMD_CN_BOXPLUS_PHI_FAST)
+    return h->bp_ok ? 2 : (use_spill_boxplus(h) ? 3 : 0);
   if (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM) return 0;
   if (use_explicit_minsum(h)) return 2;
   if (use_spill_minsum(h)) return 3;
@@ -398,7 +399,7 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
                                       int cn_mode, float llr_max, float offset, int hard_out, int return_infobits,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   SAMD_REQUIRE(h && llr && out && batch > 0 && num_iter >= 0, "bad argument");
-  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI) {   // one float per edge in LDS
+  if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || cn_mode == SAMD_CN_BOXPLUS_PHI_FAST) {   // one float per edge in LDS
     SAMD_REQUIRE(llr_max >= 0.f, "bad argument");
     if (use_spill_boxplus(h))                                             // ... the last rows' messages in L2
       return launch_onchip_mss(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits,
@@ -410,8 +411,9 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
                                       workspace, workspace_bytes, (hipStream_t)stream);
       if (rc != SAMD_ERR_UNSUPPORTED) return rc;
     }
-    return launch_onchip_bp(h, llr, out, batch, num_iter, cn_mode, llr_max, hard_out, return_infobits, workspace,
-                            workspace_bytes, (hipStream_t)stream);
+    // (the first boxplus kernel has the defined phi only: "fast" permits the hardware transcendentals, it does not demand them)
+    return launch_onchip_bp(h, llr, out, batch, num_iter, cn_mode == SAMD_CN_BOXPLUS_PHI_FAST ? SAMD_CN_BOXPLUS_PHI : cn_mode,
+                            llr_max, hard_out, return_infobits, workspace, workspace_bytes, (hipStream_t)stream);
   }
   if (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM) {
     set_error("unknown cn_mode");

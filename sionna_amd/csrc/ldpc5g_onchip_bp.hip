@@ -413,7 +413,11 @@ int onchip_bp_grid(const samd_ldpc5g* h, int batch) {
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   const size_t per_cu = std::min<size_t>((size_t)(kDecWaves / h->bp_waves), std::max<size_t>(1, (160 * 1024) / onchip_bp_lds_bytes(h)));
-  return (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+  size_t grid = std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
+  // SAMD_ONCHIP_GRID=<n>: fewer workgroups than the chip holds (test hook: every workgroup then decodes several
+  // codewords in sequence, which exercises the grid-stride loop and the reuse of its workspace row on small batches)
+  if (const char* e = getenv("SAMD_ONCHIP_GRID")) grid = std::min<size_t>(grid, (size_t)std::max(1, atoi(e)));
+  return (int)grid;
 }
 
 size_t onchip_bp_workspace_bytes(const samd_ldpc5g* h, int batch) {

@@ -29,12 +29,18 @@ namespace samd {
 int launch_onchip_ms_phi(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                          float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
                          size_t workspace_bytes, hipStream_t st);     // ldpc5g_onchip_ms_phi.hip
+int launch_onchip_ms_phi_fast(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                              float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
+                              size_t workspace_bytes, hipStream_t st);     // ldpc5g_onchip_ms_phi_fast.hip
 int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
                      size_t workspace_bytes, hipStream_t st) {
   if (cn_mode == SAMD_CN_BOXPLUS_PHI)
     return launch_onchip_ms_phi(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, workspace,
                                 workspace_bytes, st);
+  if (cn_mode == SAMD_CN_BOXPLUS_PHI_FAST)
+    return launch_onchip_ms_phi_fast(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, workspace,
+                                     workspace_bytes, st);
   if (cn_mode == SAMD_CN_BOXPLUS) {
     // the tanh rule stays on the first boxplus kernel (ldpc5g_onchip_bp.hip): this engine gains it 5 %, and its 12
     // kernels with the inlined tanh / atanh cost three minutes of compile time

@@ -469,10 +469,11 @@ int launch_onchip_mss(const samd_ldpc5g* h, const float* llr, float* out, int ba
   const bool pow2 = (h->z & (h->z - 1)) == 0;
   typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, int, float, float, int, int, int,
                          const int32_t*, const int32_t*, const int2*, const int32_t*, const int2*);
-  static const kern_t kerns[6] = {ldpc5g_decode_mss_kernel<false, SAMD_CN_MINSUM>, ldpc5g_decode_mss_kernel<true, SAMD_CN_MINSUM>,
+  static const kern_t kerns[8] = {ldpc5g_decode_mss_kernel<false, SAMD_CN_MINSUM>, ldpc5g_decode_mss_kernel<true, SAMD_CN_MINSUM>,
                                   ldpc5g_decode_mss_kernel<false, SAMD_CN_BOXPLUS_PHI>, ldpc5g_decode_mss_kernel<true, SAMD_CN_BOXPLUS_PHI>,
-                                  ldpc5g_decode_mss_kernel<false, SAMD_CN_BOXPLUS>, ldpc5g_decode_mss_kernel<true, SAMD_CN_BOXPLUS>};
-  const int mi = cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : cn_mode == SAMD_CN_BOXPLUS ? 2 : 0;
+                                  ldpc5g_decode_mss_kernel<false, SAMD_CN_BOXPLUS>, ldpc5g_decode_mss_kernel<true, SAMD_CN_BOXPLUS>,
+                                  ldpc5g_decode_mss_kernel<false, SAMD_CN_BOXPLUS_PHI_FAST>, ldpc5g_decode_mss_kernel<true, SAMD_CN_BOXPLUS_PHI_FAST>};
+  const int mi = cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : cn_mode == SAMD_CN_BOXPLUS ? 2 : cn_mode == SAMD_CN_BOXPLUS_PHI_FAST ? 3 : 0;
   const kern_t fn = kerns[2 * mi + (pow2 ? 1 : 0)];
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;

@@ -122,17 +122,17 @@ __global__ __launch_bounds__(256) void cn_pass_bigdeg_kernel(
       m = fmaxf(m - offset, 0.f);
       msg[(size_t)cn_edge[e0 + i] * stride + b] = clampf((sign_nz(x) * node_sign) * m, -llr_max, llr_max);
     }
-  } else if constexpr (MODE == SAMD_CN_BOXPLUS_PHI) {
+  } else if constexpr (MODE == SAMD_CN_BOXPLUS_PHI || MODE == SAMD_CN_BOXPLUS_PHI_FAST) {
     float node_sign = 1.f, sum = 0.f;
     for (int i = 0; i < d; ++i) {
       const float x = load(i);
       node_sign *= sign_nz(x);
-      sum += phi_fast_f32(fabsf(x));
+      sum += phi1_f32<MODE>(fabsf(x));
     }
     for (int i = 0; i < d; ++i) {
       const float x = load(i);
-      const float e = -1.f * phi_fast_f32(fabsf(x)) + sum;
-      msg[(size_t)cn_edge[e0 + i] * stride + b] = clampf((sign_nz(x) * node_sign) * phi_fast_f32(e), -llr_max, llr_max);
+      const float e = -1.f * phi1_f32<MODE>(fabsf(x)) + sum;
+      msg[(size_t)cn_edge[e0 + i] * stride + b] = clampf((sign_nz(x) * node_sign) * phi1_f32<MODE>(e), -llr_max, llr_max);
     }
   } else {
     float prod = 1.f;
@@ -372,6 +372,7 @@ static int launch_cn_mode(const samd_ldpc_graph* g, int mode, float* msg, const 
   switch (mode) {
     case SAMD_CN_BOXPLUS: launch_cn<SAMD_CN_BOXPLUS, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, offset, st); break;
     case SAMD_CN_BOXPLUS_PHI: launch_cn<SAMD_CN_BOXPLUS_PHI, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, offset, st); break;
+    case SAMD_CN_BOXPLUS_PHI_FAST: launch_cn<SAMD_CN_BOXPLUS_PHI_FAST, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, offset, st); break;
     case SAMD_CN_MINSUM: launch_cn<SAMD_CN_MINSUM, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, 0.f, st); break;
     case SAMD_CN_OFFSET_MINSUM: launch_cn<SAMD_CN_OFFSET_MINSUM, SRC>(g, msg, aux, node_list, n_nodes, bs, llr_max, offset, st); break;
     default: set_error("unknown cn_mode"); return SAMD_ERR_INVALID;
@@ -462,7 +463,7 @@ extern "C" int samd_ldpc_bp_decode_f32(const samd_ldpc_graph_t* g, const float* 
   SAMD_REQUIRE(batch > 0 && num_iter >= 0, "bad batch / num_iter");
   SAMD_REQUIRE(out_cols > 0 && out_cols <= g->num_vn, "bad out_cols");
   SAMD_REQUIRE(!(state_in || state_out) || state, "state pointer missing");
-  SAMD_REQUIRE(cn_mode >= 0 && cn_mode <= 3, "unknown cn_mode");
+  SAMD_REQUIRE(cn_mode >= 0 && cn_mode <= 4, "unknown cn_mode");
   if (workspace_bytes < samd_ldpc_bp_workspace_bytes(g, batch) || !workspace) {
     set_error("workspace too small");
     return SAMD_ERR_WORKSPACE;
@@ -559,7 +560,7 @@ extern "C" int samd_ldpc_bp_decode_scheduled_f32(const samd_ldpc_graph_t* g, con
   SAMD_REQUIRE(batch > 0 && num_iter >= 0, "bad batch / num_iter");
   SAMD_REQUIRE(out_cols > 0 && out_cols <= g->num_vn, "bad out_cols");
   SAMD_REQUIRE(!(state_in || state_out) || state, "state pointer missing");
-  SAMD_REQUIRE(cn_mode >= 0 && cn_mode <= 3, "unknown cn_mode");
+  SAMD_REQUIRE(cn_mode >= 0 && cn_mode <= 4, "unknown cn_mode");
   if (workspace_bytes < samd_ldpc_bp_workspace_bytes(g, batch) || !workspace) {
     set_error("workspace too small");
     return SAMD_ERR_WORKSPACE;

@@ -155,7 +155,7 @@ def cn_update_phi(msg, llr_clipping=None):
     return msg.with_flat_values(_clip(out, llr_clipping))
 
 
-BUILTIN_CN = {"boxplus": cn_update_tanh, "boxplus-phi": cn_update_phi, "minsum": cn_update_minsum,
+BUILTIN_CN = {"boxplus": cn_update_tanh, "boxplus-phi": cn_update_phi, "boxplus-phi-fast": cn_update_phi, "minsum": cn_update_minsum,
               "min": cn_update_minsum, "offset-minsum": cn_update_offset_minsum, "identity": cn_node_update_identity}
 BUILTIN_VN = {"sum": vn_update_sum, "identity": vn_node_update_identity}
 # exported functions given as ``cn_update=`` select the HIP rule of the same name

@@ -276,7 +276,8 @@ class LDPCBPDecoder(Block):
         ws, ws_bytes = self._ws.get(lib.samd_ldpc_bp_workspace_bytes_f64(g, batch))
         _ffi.check(lib.samd_ldpc_bp_decode_f64(g, sched, _ffi.ptr(llr), _ffi.ptr(out), out_cols, _ffi.ptr(state),
                                                int(msg_v2c is not None), int(self._return_state), batch, int(num_iter),
-                                               self._cn_mode, self._llr_max, self._offset, int(bool(hard)), _ffi.ptr(ws),
+                                               1 if self._cn_mode == 4 else self._cn_mode,   # float64 has one phi form
+                                               self._llr_max, self._offset, int(bool(hard)), _ffi.ptr(ws),
                                                ws_bytes, _ffi.stream()), "LDPCBPDecoder(double)")
         return out, (state if self._return_state else None)
 
@@ -403,7 +404,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
         batch = llr2d.shape[0]
         out_shape = shape[:-1] + ((enc.k,) if self._return_infobits else (enc.n,))
 
-        use_onchip = (self._onchip_ok and not double and not self._custom and self._cn_mode in (0, 1, 2, 3) and not self._return_state
+        use_onchip = (self._onchip_ok and not double and not self._custom and self._cn_mode in (0, 1, 2, 3, 4) and not self._return_state
                       and msg_v2c is None and batch > 0 and self._scheduling == "flooding")
         if use_onchip:
             out = self._try_onchip(llr2d, num_iter)

@@ -38,8 +38,10 @@ def test_c_oracle_equals_numpy_oracle(k, n, m, bg, batch, iters, ebno):
         ref = dec.decode(llr_full)                                        # NumPy, literal restatement, [B, N_vn]
         got = cbind.bp_decode(dec, llr_full)                              # C, OpenMP
         assert got.shape == ref.shape
-        if cn in ("minsum", "offset-minsum"):
-            assert np.array_equal(got, ref), cn                           # same defined order: bit for bit
+        if cn in ("minsum", "offset-minsum", "boxplus-phi"):
+            # same defined order - and, for boxplus-phi since round 3, the same DEFINED float32 exp / log (Cephes /
+            # Eigen restatement, oracle/ldpc_bp.c) in both oracles: bit for bit
+            assert np.array_equal(got, ref), cn
         else:
             # transcendental rules: glibc vs NumPy SIMD libm differ in the last bits and phi amplifies that on
             # saturating messages (DESIGN.md "phi conditioning"): after ONE iteration the two agree to 1e-4, after all
@@ -89,3 +91,24 @@ def test_ebnodb2no_with_resource_grid():
         want = 1 / (10 ** (db / 10) * r * m / es)
         assert got == ref and abs(got - want) < 2e-6 * want
     assert rg.num_data_symbols == org.num_data_symbols == 14 * 64 and rg.num_effective_subcarriers == 64
+
+
+def test_phi_spec_exp_log_accuracy_and_endpoints():
+    """The defined float32 exp / log of the boxplus-phi rule (oracle/ldpc_bp.c): within ~1 ulp of float64 on a dense
+    sample of the clipped domain (the full sweep of all 2.3e8 floats - exp 1.005 ulp, log 0.90 ulp - is quoted in the
+    source), the endpoints the reference's own test needs come out exactly ("all-erasure -> zeros",
+    test_ldpc_decoding.py:279-291), and phi follows -log(tanh(x/2)) where that is well conditioned."""
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.exp(rng.uniform(np.log(8.5e-8), np.log(16.635532), 400000)), np.linspace(8.5e-8, 16.635532, 100001)]).astype(np.float32)
+    ulp = lambda v: np.spacing(np.abs(v).astype(np.float32)).astype(np.float64)
+    e = cbind.spec_exp_f32(x)
+    t = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(e - t) / ulp(t)) < 1.1
+    for a in (e + np.float32(1), e - np.float32(1)):
+        a = a[a > 0]
+        l, tl = cbind.spec_log_f32(a), np.log(a.astype(np.float64))
+        assert np.max(np.abs(l - tl) / ulp(tl)) < 1.0
+    ends = cbind.phi_f32(np.array([16.635532, 20.0, 8.5e-8, 0.0, 16.6], np.float32))
+    assert ends[0] == 0 and ends[1] == 0 and ends[2] == np.float32(16.635532) and ends[3] == np.float32(16.635532) and ends[4] == 0
+    xs = np.linspace(0.05, 6, 2000).astype(np.float32)
+    assert np.allclose(cbind.phi_f32(xs), -np.log(np.tanh(xs.astype(np.float64) / 2)), rtol=2e-5, atol=1e-6)
