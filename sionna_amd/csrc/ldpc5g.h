@@ -43,6 +43,11 @@ struct samd_ldpc5g {
   int32_t* ms_tail_tab = nullptr;  // [2 x groups] packed-tail items: row block byte offset, r | fused column<<16 (r = 0xFF: no row)
   int ms_tail_sh = 6;              // log2 of the lane-group width of a packed-tail item
   int32_t* ms_vtail_tab = nullptr; // [2 x groups] packed-tail VN items: dword offset of the column's edge table, c (0xFF: no column)
+  // grouped dispatch of the same items (ldpc5g_decode_msg_kernel): items of a wave sorted by body type
+  int ms_g_ok = 0;
+  int32_t* ms_g_ptr = nullptr;     // [2 (NW+1)] group offsets per wave: CN groups, then VN groups
+  int32_t* ms_g_cn = nullptr; int32_t* ms_g_vn = nullptr;   // [2 groups] body type, first item | (last + 1) << 16
+  int32_t* ms_i_cn = nullptr; int32_t* ms_i_vn = nullptr;   // [2 items]  see ldpc5g_onchip_ms.inc
   int32_t* bp_col_deg = nullptr;   // [nb]
   int32_t* bp_cn_ptr = nullptr; int32_t* bp_cn_list = nullptr;     // per-wave item lists (LPT balanced)
   int32_t* bp_vn_ptr = nullptr; int32_t* bp_vn_list = nullptr;

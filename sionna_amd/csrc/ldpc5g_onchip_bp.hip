@@ -380,7 +380,100 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     vl2.push_back(col_start[c]);
   }
   cl2.resize(cl2.size() + 2, 0); vl2.resize(vl2.size() + 2, 0);
+  // ---- grouped dispatch (ldpc5g_decode_msg_kernel): the items of every wave sorted by body type.  Only for codes whose
+  // items are all full chunk pairs (Z a multiple of 128, no partially pruned base row) on 16 waves.
+  std::vector<int32_t> g_ptr, g_cn, g_vn, i_cn, i_vn;
+  h->ms_g_ok = 0;
+  if (z % 128 == 0 && h->n_cn % z == 0 && h->n_vn % z == 0 && h->bp_waves == 16 && groups < 2) {
+    bool ok = true;
+    struct It { int cost, key; int32_t x, y; };
+    auto cost_in = [](const std::vector<std::pair<int, int32_t>>& items, int32_t id) {
+      for (auto& it : items)
+        if (it.second == id) return it.first;
+      return 0;
+    };
+    const int nwv = h->bp_waves;
+    for (int phase = 0; phase < 2 && ok; ++phase) {
+      const std::vector<int32_t>& lp = phase ? mvp : mcp;
+      const std::vector<int32_t>& ll = phase ? mvl : mcl;
+      std::vector<std::vector<It>> per(nwv);
+      double longest = 1.0;
+      for (int wv = 0; wv < nwv; ++wv) {
+        double tot = 0.0;
+        for (int j = lp[wv]; j < lp[wv + 1]; ++j) {
+          const int32_t d = ll[j];
+          if ((d >> 25) & 1) { ok = false; break; }
+          const int idx = d & 0xFF, q = (d >> 8) & 0xFF, pr = (d >> 24) & 1;
+          It it;
+          it.cost = cost_in(phase ? vi2 : ci2, d) + 3;
+          if (!phase) {
+            if (!pr) { ok = false; break; }
+            const int f = fused_col[idx] >= 0;
+            it.key = (int)by_row[idx].size() | (f << 5);
+            it.x = (row_off[idx] & 0x3FFFF) + 256 * q;
+            it.y = f ? fused_col[idx] * z + q * 64 : 0;
+          } else {
+            it.key = col_deg[idx] | (pr << 5);
+            it.x = (idx * z + q * 64) | (pr << 23);
+            it.y = col_start[idx] | (q << 20);
+            if (col_start[idx] >= (1 << 20) || idx * z + q * 64 >= (1 << 23)) ok = false;
+          }
+          tot += it.cost;
+          per[wv].push_back(it);
+        }
+        longest = std::max(longest, tot);
+      }
+      if (!ok) break;
+      std::vector<int32_t>& gl = phase ? g_vn : g_cn;
+      std::vector<int32_t>& il = phase ? i_vn : i_cn;
+      for (int wv = 0; wv < nwv; ++wv) {
+        g_ptr.push_back((int32_t)gl.size() / 2);
+        // groups by type, the type with the most expensive items first; the group order is rotated by the wave's index
+        // on its SIMD so that the four waves of a SIMD start a phase in different bodies (cf. SAMD_MS_ORDER above)
+        std::stable_sort(per[wv].begin(), per[wv].end(), [](const It& a, const It& b) {
+          return a.cost != b.cost ? a.cost > b.cost : a.key > b.key; });
+        std::vector<std::vector<It>> grp;
+        for (const It& it : per[wv]) {
+          if (grp.empty() || grp.back().front().key != it.key) {
+            size_t k2 = 0;
+            for (; k2 < grp.size(); ++k2)
+              if (grp[k2].front().key == it.key) break;
+            if (k2 == grp.size()) grp.emplace_back();
+            grp[k2].push_back(it);
+          } else {
+            grp.back().push_back(it);
+          }
+        }
+        if (grp.size() > 1 && !getenv("SAMD_MS_NOROT")) std::rotate(grp.begin(), grp.begin() + ((wv >> 2) % grp.size()), grp.end());
+        double rem = 0.0;
+        for (auto& gq : grp)
+          for (auto& it : gq) rem += it.cost;
+        for (auto& gq : grp) {
+          const size_t first = il.size() / 2;
+          for (auto& it : gq) {
+            const int prio = getenv("SAMD_MS_NOPRIO") ? 0 : std::max(0, std::min(3, (int)std::ceil(4.0 * rem / longest) - 1));
+            rem -= it.cost;
+            il.push_back(it.x | (prio << 24));
+            il.push_back(it.y);
+          }
+          gl.push_back(gq.front().key);
+          gl.push_back((int32_t)(first | ((il.size() / 2) << 16)));
+        }
+      }
+      g_ptr.push_back((int32_t)gl.size() / 2);
+      if (il.size() / 2 >= 65536) ok = false;
+    }
+    h->ms_g_ok = ok && g_ptr.size() == (size_t)(2 * (nwv + 1)) ? 1 : 0;
+    g_cn.resize(g_cn.size() + 2, 0); g_vn.resize(g_vn.size() + 2, 0);
+    i_cn.resize(i_cn.size() + 4, 0); i_vn.resize(i_vn.size() + 4, 0);
+    if (!h->ms_g_ok) g_ptr.assign(2 * (nwv + 1), 0);
+  }
   int rc = upload(&h->bp_row_off, row_off.data(), row_off.size());
+  if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_g_ptr, g_ptr.data(), g_ptr.size());
+  if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_g_cn, g_cn.data(), g_cn.size());
+  if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_g_vn, g_vn.data(), g_vn.size());
+  if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_i_cn, i_cn.data(), i_cn.size());
+  if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_i_vn, i_vn.data(), i_vn.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_col_ent, col_ent.data(), col_ent.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_col_ent, col_ent2.data(), col_ent2.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_cn_ptr, mcp.data(), mcp.size());
@@ -400,6 +493,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
 
 void free_onchip_bp_tables(samd_ldpc5g* h) {
   (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg); (void)hipFree(h->ms_col_ent); (void)hipFree(h->ms_cn_list); (void)hipFree(h->ms_cn_ptr); (void)hipFree(h->ms_vn_ptr); (void)hipFree(h->ms_vn_list); (void)hipFree(h->ms_tail_tab); (void)hipFree(h->ms_vtail_tab);
+  (void)hipFree(h->ms_g_ptr); (void)hipFree(h->ms_g_cn); (void)hipFree(h->ms_g_vn); (void)hipFree(h->ms_i_cn); (void)hipFree(h->ms_i_vn);
   (void)hipFree(h->bp_cn_ptr); (void)hipFree(h->bp_cn_list); (void)hipFree(h->bp_vn_ptr); (void)hipFree(h->bp_vn_list);
 }
 
