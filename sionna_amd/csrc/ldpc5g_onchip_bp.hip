@@ -260,6 +260,12 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // (measured at C2 with tools/ms_sweep.py: a fixed cost of ~20 edges per item balances best)
   const int cn_ovh = getenv("SAMD_MS_CN_OVH") ? atoi(getenv("SAMD_MS_CN_OVH")) : 400;
   const int vn_ovh = getenv("SAMD_MS_VN_OVH") ? atoi(getenv("SAMD_MS_VN_OVH")) : 200;
+  // cost per edge of a pair item / of a single-chunk item, and the fixed cost of a single-chunk VN item.  Round 3, item
+  // trace of the grouped kernel (tools/ms_itrace.py, profiles/r03b/ms_itrace_r03d.txt): a CN pair item takes
+  // 127 d + 1790 cycles, a VN pair item 115 d + 2240, a single-chunk VN item 111 d + 1040 - one chunk has one dependency
+  // chain, so its edges cost what a pair's edge PAIRS cost.
+  const int cn_slope = getenv("SAMD_MS_CN_SLOPE") ? atoi(getenv("SAMD_MS_CN_SLOPE")) : 36;   // 18: r02 model; 36: +1.7 % at C2 (profiles/r03b/ms_cost_r03f.txt)
+  const int vn_single = getenv("SAMD_MS_VN_SINGLE") ? atoi(getenv("SAMD_MS_VN_SINGLE")) : 0;   // 1: 10 d + vn_ovh / 2
   // Z not a multiple of 64: the last chunk of a row has `tail` < 64 lifted copies.  With tail <= 32 the tails of
   // 64 / gw rows of the same degree (and fused flag) are packed into one item (lane group g works for row g) - at
   // Z = 80 the 16-lane tails of four rows share a pass instead of running at 25 % lane utilisation each
@@ -288,8 +294,8 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       if (groups >= 2 && q == chunks - 1) continue;           // the tail goes into a packed item
       const bool pair = (q + 2) * 64 <= z && r * z + (q + 2) * 64 <= h->n_cn &&
                         (fused_col[r] < 0 || fused_col[r] * z + (q + 2) * 64 <= h->n_vn);
-      if (pair) { ci2.push_back({18 * d + cn_ovh, r | (q << 8) | (1 << 24)}); ++q; }
-      else ci2.push_back({9 * d + cn_ovh, r | (q << 8)});
+      if (pair) { ci2.push_back({cn_slope * d + cn_ovh, r | (q << 8) | (1 << 24)}); ++q; }
+      else ci2.push_back({cn_slope / 2 * d + cn_ovh, r | (q << 8)});
     }
   for (size_t i = 0; i < packed.size(); ++i)
     ci2.push_back({9 * (packed_key[i] & 31) + cn_ovh, (int32_t)i | (1 << 25)});
@@ -315,6 +321,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       const bool pair = col_deg[c] <= 12 && (q + 2) * 64 <= z && c * z + (q + 2) * 64 <= h->n_vn;
       auto& dst = col_fused[c] ? vf2 : vi2;
       if (pair) { dst.push_back({10 * col_deg[c] + vn_ovh, c | (q << 8) | (1 << 24)}); ++q; }
+      else if (vn_single) dst.push_back({10 * col_deg[c] + vn_ovh / 2, c | (q << 8)});
       else dst.push_back({5 * col_deg[c] + vn_ovh, c | (q << 8)});
     }
   for (size_t i = 0; i < vpacked.size(); ++i) vi2.push_back({5 * vpacked_deg[i] + vn_ovh, (int32_t)i | (1 << 25)});
