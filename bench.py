@@ -224,7 +224,26 @@ def bench_c4(args, short=False):
         e0.record(); eq(y, h_hat, ev, no); e1.record()
     torch.cuda.synchronize()
     t_wall = time.perf_counter() - t0
-    ms = float(np.mean([a.elapsed_time(c) for a, c in ev_t]))
+    ms_call = float(np.mean([a.elapsed_time(c) for a, c in ev_t]))     # one Block-API call: host work + launch + kernel
+    # kernel time: 20 launches through the C-ABI with prepared arguments between ONE pair of HIP events on the launch
+    # stream - the queue stays full (a C-ABI launch costs ~10 us of host time, the kernel ~190 us), so elapsed / 20 is the
+    # kernel's own duration (rocprofv3: profiles/*kernel_stats*), which the host-bound per-call figure above hides
+    keep, head, tabs, dims = eq._prepare(y, h_hat, ev, no)
+    xk = torch.empty((B, rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols), dtype=torch.complex64, device=y.device)
+    nk = torch.empty((B, rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols), dtype=torch.float32, device=y.device)
+    lib, st, reps_k = _ffi.lib(), _ffi.stream(), 20
+    def launch():
+        return lib.samd_ofdm_lmmse_c64(*head, *tabs, *dims, int(eq._mode), _ffi.ptr(xk), _ffi.ptr(nk), st)
+    launch(); launch()
+    torch.cuda.synchronize()
+    k0, k1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    k0.record()
+    for _ in range(reps_k):
+        launch()
+    k1.record()
+    torch.cuda.synchronize()
+    ms = k0.elapsed_time(k1) / reps_k
+    del keep
     n_data_re = B * rg.num_data_symbols
     ach = n_data_re * 120 / (ms * 1e-3) / 1e9
     t0 = time.perf_counter()
@@ -245,8 +264,10 @@ def bench_c4(args, short=False):
                         "frac": round(ach / HBM_PEAK_GBPS, 4),
                         "traffic": int(rec["hbm_bytes_per_unit"] * n_data_re) if rec else None,
                         "kernel": "ofdm_lmmse_diag_kernel<4,2> (whole OFDMEqualizer.call in one launch)",
-                        "algorithmic_bytes_per_re": 120, "ms_per_launch": round(ms, 3),
-                        "note": "HIP events around one launch of ~0.3 ms: launch overhead is inside the figure"},
+                        "algorithmic_bytes_per_re": 120, "ms_per_launch": round(ms, 4),
+                        "ms_per_block_api_call": round(ms_call, 4), "host_overhead_ms": round(ms_call - ms, 4),
+                        "note": "ms_per_launch = 20 back-to-back C-ABI launches between one pair of HIP events (queue "
+                                "full); the Block-API call adds the host overhead reported beside it"},
            "end_to_end": {"codewords_per_s": round(2 * B / t_e2e, 1), "ms_per_batch": round(t_e2e * 1e3, 2)}}
     if not short:
         # time-domain variant of the same chain: OFDMModulator (rocFFT) -> TimeChannel -> OFDMDemodulator (rocFFT)

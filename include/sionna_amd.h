@@ -140,6 +140,19 @@ size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int
  * min-sum while at most ~27 % of the edges spill - beyond that engine 1 is faster). */
 int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode);
 
+/* LDPC5GDecoder(cn_schedule="layered").call on chip (decoding.py:1383-1389: one sub-iteration per base row; _bp_iter
+ * with an array schedule :463-520): rate recovery + num_iter layered iterations + output mapping in ONE kernel, the
+ * sent check-node messages and the variable-node totals resident in LDS, channel LLRs and the state of the fused
+ * degree-1 columns in `workspace` (samd_ldpc5g_decode_layered_workspace_bytes).  min-sum / offset-min-sum, codes with Z
+ * a multiple of 128 and no partially pruned base row whose state fits in LDS (config C2); ..._supported() tells - the
+ * scheduled HBM-resident engine (samd_ldpc_bp_decode_scheduled_f32) takes everything else.  Same bits as that engine and
+ * as the oracle's literal "update every variable node after every layer". */
+int samd_ldpc5g_decode_layered_supported(const samd_ldpc5g_t* h, int cn_mode);
+size_t samd_ldpc5g_decode_layered_workspace_bytes(const samd_ldpc5g_t* h, int batch);
+int samd_ldpc5g_decode_layered_f32(const samd_ldpc5g_t* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                                   float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
+                                   size_t workspace_bytes, void* stream);
+
 /* Whole LDPC5GDecoder.call on chip: rate recovery + num_iter flooding BP iterations +
  * output mapping in ONE kernel, one codeword per workgroup, messages resident in LDS.
  *   One float per edge in LDS (engine 2) when the code's E messages x 4 B fit in 160 KB - n=8448 rate 1/3

@@ -20,6 +20,7 @@ struct samd_ldpc5g {
   int32_t* col_ptr = nullptr;  // [nb+1]
   int32_t* col_ent = nullptr;  // [nnz]  row | shift<<8 | pos<<20  (pos = index of the edge inside its row)
   // work items for the decoder, longest first: (index | chunk<<16)
+  uint16_t* enc_out_idx = nullptr;   // [n] bit-packed encoder (Z % 32 == 0): output position -> position in the full codeword
   int32_t* cn_items = nullptr; int n_cn_items = 0;
   int32_t* vn_items = nullptr; int n_vn_items = 0;
   // ---- tables of the statically scheduled on-chip decoder (csrc/ldpc5g_onchip.hip)
@@ -55,6 +56,10 @@ struct samd_ldpc5g {
   int sp_ok = 0, sp_lds_bytes = 0, sp_g_floats = 0, sp_spill_pct = 0;   // sp_spill_pct: share of the edges in L2
   int32_t* sp_col_ent = nullptr; int32_t* sp_cn_ptr = nullptr; int32_t* sp_vn_ptr = nullptr;
   int32_t* sp_cn_list = nullptr; int32_t* sp_vn_list = nullptr;
+  // on-chip layered decoder (ldpc5g_onchip_ly.hip): record lists per wave, row / column edge tables
+  int ly_ok = 0, ly_lds_bytes = 0, ly_msg_floats = 0, ly_n_ext = 0, ly_groups = 0;
+  int32_t* ly_rec_ptr = nullptr; int32_t* ly_recs = nullptr; int32_t* ly_row_ent = nullptr; int32_t* ly_col_ent = nullptr;
+  int32_t* ly_xt_index = nullptr;
   int dec_waves = 16;          // waves per workgroup of the on-chip decoder (16 / 8 / 4: small codes share a CU)
   int llr_global = 0;          // 1: channel LLRs in the caller's workspace (L2) instead of LDS (larger codes fit)
 };
@@ -85,6 +90,11 @@ size_t onchip_mss_workspace_bytes(const samd_ldpc5g* h, int batch);
 int launch_onchip_mss(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                       float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
                       size_t workspace_bytes, hipStream_t st);
+int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
+void free_onchip_ly_tables(samd_ldpc5g* h);
+size_t onchip_ly_workspace_bytes(const samd_ldpc5g* h, int batch);
+int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode, float llr_max,
+                     float offset, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes, hipStream_t st);
 int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
                      size_t workspace_bytes, hipStream_t st);

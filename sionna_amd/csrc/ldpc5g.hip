@@ -91,6 +91,119 @@ __global__ __launch_bounds__(256) void ldpc5g_encode_kernel(
   for (int i = tid; i < p.n; i += 256) o[i] = (float)cw[short_to_full(p, out_to_short(p, i))];
 }
 
+// Bit-packed encoder for lifting sizes that are multiples of 32 (round 3; C2: Z = 128).  One WAVE per codeword, four
+// codewords per workgroup, no workgroup barrier.  The codeword lives in LDS as n_ldpc / 32 words (bit j of word w of
+// block c = variable node c Z + 32 w + j), 1 KB instead of 8.5 KB: a lifted block rotated by shift s is, per output word,
+// two word reads and one v_alignbit (the bit offset s mod 32 is the same for every word of the block, the word offset
+// is (w + s / 32) mod (Z / 32)) - the byte-per-bit kernel above spent 43 % of its LDS cycles on bank conflicts of byte
+// stores.  Information bits are packed with one ballot per 64 floats; the rate-matched, interleaved output is one table
+// look-up per element (out_idx[i] = position in the full codeword of output i: short_to_full(out_to_short(i)), built
+// once per code on the host - the kernel above divides by the run-time modulation order for every output element).
+// Same GF(2) arithmetic as above (RU method in closed form, encoding.py:559-668), hence the same bits; HBM traffic is
+// the compulsory 4 (k + n) bytes per codeword.
+__device__ __forceinline__ uint32_t enc_rot_word(const uint32_t* __restrict__ blk, int wq, int w, int s) {
+  int a = w + (s >> 5);
+  a = a >= wq ? a - wq : a;
+  int a2 = a + 1;
+  a2 = a2 >= wq ? 0 : a2;
+  return __builtin_amdgcn_alignbit(blk[a2], blk[a], (uint32_t)(s & 31));
+}
+
+__global__ __launch_bounds__(256) void ldpc5g_encode_packed_kernel(
+    const float* __restrict__ bits, float* __restrict__ out, RateMatch p, int batch, int mb, int k_b, int bg, int s_a,
+    int s_b, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ row_ent,
+    const uint16_t* __restrict__ out_idx) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t cww[];      // 4 x ([n_ldpc / 32] codeword + [4 wq] lambda), tables
+  const int z = p.z, wq = z >> 5;
+  const int nw = (mb + k_b) * wq;                                    // words of the full codeword
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint32_t* cw = cww + (size_t)wv * (nw + 4 * wq);
+  uint32_t* lam = cw + nw;
+  // the base graph (row pointers, entries) once per workgroup in LDS: the row loops below read an entry per edge
+  int32_t* rp = reinterpret_cast<int32_t*>(cww + 4 * (size_t)(nw + 4 * wq));
+  int32_t* re = rp + mb + 1;
+  for (int i = threadIdx.x; i <= mb; i += 256) rp[i] = row_ptr[i];
+  for (int i = threadIdx.x; i < row_ptr[mb]; i += 256) re[i] = row_ent[i];
+  __syncthreads();
+  row_ptr = rp;
+  row_ent = re;
+  const auto wave_sync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+  for (int b = blockIdx.x * 4 + wv; b < batch; b += gridDim.x * 4) {
+    const float* u = bits + (size_t)b * p.k;
+    // information bits -> words (filler bits = 0, encoding.py:637): one ballot per 64 floats
+    // (eight loads in flight per lane before the first ballot: a wave is the only owner of its codeword's latency)
+    for (int i0 = 0; i0 < p.k_ldpc; i0 += 512) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + 64 * j + lane;
+        v[j] = i < p.k ? u[i] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(((int)v[j]) & 1);
+        if (lane < 2 && i0 + 64 * j < p.k_ldpc) cw[((i0 + 64 * j) >> 5) + lane] = (uint32_t)(m >> (32 * lane));
+      }
+    }
+    wave_sync();
+    // lambda_r = sum_j P(a_rj) s_j for the 4 core rows (columns < k_b only): lane = (row, word)
+    for (int i = lane; i < 4 * wq; i += 64) {
+      const int r = i / wq, w = i - r * wq;
+      uint32_t acc = 0u;
+      for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
+        const int c = row_ent[e] & 0xFFFF, s = row_ent[e] >> 16;
+        if (c >= k_b) break;
+        acc ^= enc_rot_word(cw + c * wq, wq, w, s);
+      }
+      lam[i] = acc;
+    }
+    wave_sync();
+    uint32_t* pa = cw + k_b * wq;
+    // p0 = P_B^-1 (lambda0 + lambda1 + lambda2 + lambda3): rotation by -s_b
+    if (lane < wq) {
+      const int sb = s_b ? z - s_b : 0;
+      pa[lane] = enc_rot_word(lam, wq, lane, sb) ^ enc_rot_word(lam + wq, wq, lane, sb) ^ enc_rot_word(lam + 2 * wq, wq, lane, sb) ^
+                 enc_rot_word(lam + 3 * wq, wq, lane, sb);
+    }
+    wave_sync();
+    if (lane < wq) {
+      const uint32_t ap0 = enc_rot_word(pa, wq, lane, s_a);           // (P_A p0)
+      const uint32_t p1 = lam[lane] ^ ap0;                            // core row 0:  P_A p0 + p1 = lambda0
+      const uint32_t p3 = lam[3 * wq + lane] ^ ap0;                   // core row 3:  P_A p0 + p3 = lambda3
+      const uint32_t p2 = (bg == 1) ? (lam[2 * wq + lane] ^ p3) : (lam[wq + lane] ^ p1);
+      pa[wq + lane] = p1; pa[2 * wq + lane] = p2; pa[3 * wq + lane] = p3;
+    }
+    wave_sync();
+    // extension rows: p_b = C1 s + C2 p_a  (encoding.py:579-581): lane = (row, word)
+    for (int i = lane; i < (mb - 4) * wq; i += 64) {
+      const int r = 4 + i / wq, w = i % wq;
+      uint32_t acc = 0u;
+      for (int e = row_ptr[r]; e < row_ptr[r + 1]; ++e) {
+        const int c = row_ent[e] & 0xFFFF, s = row_ent[e] >> 16;
+        if (c >= k_b + 4) break;
+        acc ^= enc_rot_word(cw + c * wq, wq, w, s);
+      }
+      cw[(k_b + 4) * wq + i] = acc;
+    }
+    wave_sync();
+    float* o = out + (size_t)b * p.n;
+    for (int i0 = 0; i0 < p.n; i0 += 512) {
+      unsigned t[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + 64 * j + lane;
+        t[j] = i < p.n ? out_idx[i] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + 64 * j + lane;
+        if (i < p.n) o[i] = (float)((cw[t[j] >> 5] >> (t[j] & 31)) & 1u);
+      }
+    }
+    wave_sync();                                                     // the next codeword overwrites cw
+  }
+}
+
 __global__ void ldpc5g_rate_recover_kernel(const float* __restrict__ llr, float* __restrict__ out, RateMatch p,
                                            float llr_max) {
   const int b = blockIdx.y;
@@ -311,9 +424,21 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   if (rc == SAMD_OK) rc = upload(&h->col_ent, col_ent.data(), col_ent.size());
   if (rc == SAMD_OK) rc = upload(&h->cn_items, cn_items.data(), cn_items.size());
   if (rc == SAMD_OK) rc = upload(&h->vn_items, vn_items.data(), vn_items.size());
+  if (rc == SAMD_OK && z % 32 == 0 && h->n_ldpc < 65536) {
+    // output position -> position in the full codeword (output interleaver and puncturing / filler removal folded)
+    std::vector<uint16_t> oi(n);
+    for (int i = 0; i < n; ++i) {
+      int t = i;
+      if (h->m_int > 0) t = (i % h->m_int) * (n / h->m_int) + i / h->m_int;   // out_to_short
+      const int uu = t + 2 * z;                                                // short_to_full
+      oi[i] = (uint16_t)(uu < k ? uu : uu + (h->k_ldpc - k));
+    }
+    rc = upload(&h->enc_out_idx, oi.data(), oi.size());
+  }
   if (rc == SAMD_OK) rc = build_onchip_tables(h, by_row);
   if (rc == SAMD_OK) rc = build_onchip_bp_tables(h, by_row);
   if (rc == SAMD_OK) rc = build_onchip_mss_tables(h, by_row);
+  if (rc == SAMD_OK) rc = build_onchip_ly_tables(h, by_row);
   if (rc != SAMD_OK) { samd_ldpc5g_destroy(h); return rc; }
   *out = h;
   return SAMD_OK;
@@ -322,15 +447,25 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
 extern "C" void samd_ldpc5g_destroy(samd_ldpc5g_t* h) {
   if (!h) return;
   (void)hipFree(h->row_ptr); (void)hipFree(h->row_ent); (void)hipFree(h->col_ptr); (void)hipFree(h->col_ent);
-  (void)hipFree(h->cn_items); (void)hipFree(h->vn_items);
+  (void)hipFree(h->cn_items); (void)hipFree(h->vn_items); (void)hipFree(h->enc_out_idx);
   free_onchip_tables(h);
   free_onchip_bp_tables(h);
   free_onchip_mss_tables(h);
+  free_onchip_ly_tables(h);
   delete h;
 }
 
 extern "C" int samd_ldpc5g_encode_f32(const samd_ldpc5g_t* h, const float* bits, float* out, int batch, void* stream) {
   SAMD_REQUIRE(h && bits && out && batch > 0, "bad argument");
+  if (h->enc_out_idx && h->z % 32 == 0 && !getenv("SAMD_ENC_BYTES")) {
+    // lifting sizes that are multiples of 32: the bit-packed kernel, one wave per codeword
+    const int wq = h->z / 32;
+    const size_t lds_p = (4 * (size_t)((h->mb + h->k_b) * wq + 4 * wq) + (size_t)h->mb + 1 + (size_t)h->nnz) * sizeof(uint32_t);
+    const int grid = std::min((batch + 3) / 4, 256 * 8 * 4);
+    hipLaunchKernelGGL(ldpc5g_encode_packed_kernel, dim3(grid), dim3(256), lds_p, (hipStream_t)stream, bits, out, make_rm(h),
+                       batch, h->mb, h->k_b, h->bg, h->s_a, h->s_b, h->row_ptr, h->row_ent, h->enc_out_idx);
+    return launch_status();
+  }
   const size_t lds = (size_t)h->n_ldpc + 4 * (size_t)h->z;
   // set on every launch: the attribute is per device and a process may drive several
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc5g_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -383,6 +518,23 @@ extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int
   if (boxplus || use_explicit_minsum(h)) return onchip_bp_workspace_bytes(h, batch);
   if (use_spill_minsum(h)) return onchip_mss_workspace_bytes(h, batch);
   return onchip_workspace_bytes(h, batch);
+}
+
+// ---- layered schedule (one sub-iteration per base row) on chip: ldpc5g_onchip_ly.hip
+extern "C" int samd_ldpc5g_decode_layered_supported(const samd_ldpc5g_t* h, int cn_mode) {
+  return (h && h->ly_ok && (cn_mode == SAMD_CN_MINSUM || cn_mode == SAMD_CN_OFFSET_MINSUM) && !getenv("SAMD_NO_ONCHIP_LAYERED")) ? 1 : 0;
+}
+
+extern "C" size_t samd_ldpc5g_decode_layered_workspace_bytes(const samd_ldpc5g_t* h, int batch) {
+  return h ? onchip_ly_workspace_bytes(h, batch) : 0;
+}
+
+extern "C" int samd_ldpc5g_decode_layered_f32(const samd_ldpc5g_t* h, const float* llr, float* out, int batch, int num_iter,
+                                              int cn_mode, float llr_max, float offset, int hard_out, int return_infobits,
+                                              void* workspace, size_t workspace_bytes, void* stream) {
+  SAMD_REQUIRE(h && llr && out && batch > 0 && num_iter >= 0, "bad argument");
+  return launch_onchip_ly(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, workspace,
+                          workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode) {

@@ -357,6 +357,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
         else:
             self._nb_pruned_nodes = 0
             self._n_pruned = encoder.n_ldpc
+        self._layered5g = isinstance(cn_schedule, str) and cn_schedule == "layered"
         if isinstance(cn_schedule, str) and cn_schedule == "layered":       # decoding.py:1383-1389
             z = encoder.z
             cn_schedule = np.stack([np.arange(z) + i * z for i in range(pcm.shape[0] // z)], axis=0)
@@ -391,6 +392,23 @@ class LDPC5GDecoder(LDPCBPDecoder):
         _ffi.check(rc, "LDPC5GDecoder(on-chip)")
         return out
 
+    def _try_onchip_layered(self, llr2d, num_iter):
+        """Whole layered decode in one kernel (csrc/ldpc5g_onchip_ly.hip); None when the code is not covered."""
+        enc = self._encoder
+        lib, h = _ffi.lib(), enc._handle(self._nb_pruned_nodes)
+        if not lib.samd_ldpc5g_decode_layered_supported(h, self._cn_mode):
+            return None
+        out_cols = enc.k if self._return_infobits else enc.n
+        out = torch.empty((llr2d.shape[0], out_cols), dtype=torch.float32, device=llr2d.device)
+        ws, ws_bytes = self._ws.get(lib.samd_ldpc5g_decode_layered_workspace_bytes(h, llr2d.shape[0]))
+        rc = lib.samd_ldpc5g_decode_layered_f32(
+            h, _ffi.ptr(llr2d), _ffi.ptr(out), llr2d.shape[0], int(num_iter), self._cn_mode, self._llr_max, self._offset,
+            int(self._hard_out), int(self._return_infobits), _ffi.ptr(ws), ws_bytes, _ffi.stream())
+        if rc == _ffi.ERR_UNSUPPORTED:
+            return None
+        _ffi.check(rc, "LDPC5GDecoder(on-chip layered)")
+        return out
+
     def call(self, llr_ch, /, *, num_iter=None, msg_v2c=None):
         enc = self._encoder
         if num_iter is None:
@@ -408,6 +426,12 @@ class LDPC5GDecoder(LDPCBPDecoder):
                       and msg_v2c is None and batch > 0 and self._scheduling == "flooding")
         if use_onchip:
             out = self._try_onchip(llr2d, num_iter)
+            if out is not None:
+                return out.reshape(out_shape)
+        # cn_schedule="layered" (one sub-iteration per base row): the on-chip layered engine when the code is covered
+        if (self._layered5g and self._onchip_ok and not double and not self._custom and self._cn_mode in (2, 3)
+                and not self._return_state and msg_v2c is None and batch > 0):
+            out = self._try_onchip_layered(llr2d, num_iter)
             if out is not None:
                 return out.reshape(out_shape)
 

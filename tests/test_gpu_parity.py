@@ -144,6 +144,29 @@ def test_encoder_vs_oracle_interleaved(phy, k, n, bg, m):
     assert np.array_equal(_np(enc(u)), LDPC5GCode(k, n, m, bg).encode(u))
 
 
+@pytest.mark.parametrize("k,n,bg,m", [(2816, 8448, "bg1", 6), (1408, 2816, "bg1", None), (704, 1500, "bg1", 2),
+                                      (8448, 12672, "bg1", 4), (5632, 16896, "bg1", 6), (1280, 3840, "bg2", 4),
+                                      (2560, 5120, "bg2", None)])
+def test_encoder_bit_packed_vs_oracle_and_byte_kernel(phy, k, n, bg, m):
+    """Lifting sizes that are multiples of 32 (C2: Z = 128) run the bit-packed encoder (one wave per codeword, rotated
+    blocks as v_alignbit of two words, output through the folded interleaver / puncturing table): same bits as the
+    oracle and as the byte-per-bit kernel (SAMD_ENC_BYTES=1), odd batch sizes included (four codewords per workgroup)."""
+    import os
+    code = LDPC5GCode(k, n, m, bg)
+    assert code.z % 32 == 0, code.z
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    rng = np.random.default_rng(n)
+    for batch in (1, 7, 130):
+        u = rng.integers(0, 2, (batch, k)).astype(np.float32)
+        got = _np(enc(u))
+        assert np.array_equal(got, code.encode(u)), (k, n, batch)
+        os.environ["SAMD_ENC_BYTES"] = "1"
+        try:
+            assert np.array_equal(_np(enc(u)), got)
+        finally:
+            os.environ.pop("SAMD_ENC_BYTES", None)
+
+
 # ------------------------------------------------------------------ generic BP decoder
 def _example_pcm(i):
     ex = np.load(os.path.join(GOLD, "example_pcms.npz"))
@@ -337,6 +360,43 @@ def test_layered_5g_vs_oracle_and_convergence(phy):
     assert 0 < bler[("flooding", 16)] < 0.5
     assert np.isclose(bler[("layered", 8)], bler[("flooding", 16)], rtol=0.7)
     assert bler[("flooding", 8)] > bler[("layered", 8)]
+
+
+@pytest.mark.parametrize("k,n,bg,m", [(2816, 8448, "bg1", 6), (1280, 3840, "bg2", 4), (2816, 5632, "bg1", None)])
+def test_layered_on_chip_bit_exact(phy, k, n, bg, m):
+    """cn_schedule="layered" on the on-chip layered engine (csrc/ldpc5g_onchip_ly.hip: c2v and variable-node totals in
+    LDS, one kernel for the whole decode) - min-sum and offset-min-sum soft outputs bit for bit against the oracle's
+    literal form (check-node update of the layer, then EVERY variable node) and against the HBM-resident scheduled engine;
+    codeword output, hard output and a grid of few workgroups (several codewords per workgroup) included."""
+    import os
+    code = LDPC5GCode(k, n, m, bg)
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    u, c, llr = _noisy_llr(code, 6, k + 3 * n, sigma=0.7)
+    llr[0, :9] = 0
+    llr[1] = np.round(llr[1])
+    for cn in ("minsum", "offset-minsum"):
+        for it, infobits in ((1, True), (3, False)):
+            kw = dict(cn_update=cn, cn_schedule="layered", num_iter=it, hard_out=False, return_infobits=infobits)
+            dec = phy.fec.ldpc.LDPC5GDecoder(enc, **kw)
+            from sionna_amd import _ffi
+            assert _ffi.lib().samd_ldpc5g_decode_layered_supported(enc._handle(dec._nb_pruned_nodes), dec._cn_mode) == 1
+            got = _np(dec(llr))
+            ref = obp.LDPC5GDecoder(code, **kw).decode5g(llr)
+            assert np.array_equal(got, ref), f"{cn} it={it}: {np.mean(got != ref):.3e} differ, max {np.max(np.abs(got - ref))}"
+            os.environ["SAMD_NO_ONCHIP_LAYERED"] = "1"
+            try:
+                assert np.array_equal(_np(dec(llr)), ref)                  # the scheduled HBM-resident engine
+            finally:
+                os.environ.pop("SAMD_NO_ONCHIP_LAYERED", None)
+    big = np.tile(llr, (11, 1))
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", cn_schedule="layered", num_iter=4)
+    full = _np(dec(big))
+    os.environ["SAMD_ONCHIP_GRID"] = "5"
+    try:
+        assert np.array_equal(_np(dec(big)), full)
+    finally:
+        os.environ.pop("SAMD_ONCHIP_GRID", None)
+    assert np.array_equal(full[:6], full[6:12])
 
 
 # ------------------------------------------------------------------ 5G decoder (both engines)
