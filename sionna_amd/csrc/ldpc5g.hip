@@ -112,7 +112,7 @@ __device__ __forceinline__ uint32_t enc_rot_word(const uint32_t* __restrict__ bl
 __global__ __launch_bounds__(256) void ldpc5g_encode_packed_kernel(
     const float* __restrict__ bits, float* __restrict__ out, RateMatch p, int batch, int mb, int k_b, int bg, int s_a,
     int s_b, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ row_ent,
-    const uint16_t* __restrict__ out_idx) {
+    const uint16_t* __restrict__ out_idx, int dbg) {
   extern __shared__ __attribute__((aligned(16))) uint32_t cww[];      // 4 x ([n_ldpc / 32] codeword + [4 wq] lambda), tables
   const int z = p.z, wq = z >> 5;
   const int nw = (mb + k_b) * wq;                                    // words of the full codeword
@@ -122,8 +122,15 @@ __global__ __launch_bounds__(256) void ldpc5g_encode_packed_kernel(
   // the base graph (row pointers, entries) once per workgroup in LDS: the row loops below read an entry per edge
   int32_t* rp = reinterpret_cast<int32_t*>(cww + 4 * (size_t)(nw + 4 * wq));
   int32_t* re = rp + mb + 1;
+  // ... and the output table: the output loop must not hold a global LOAD - loads and stores share the in-order vmcnt
+  // counter, so waiting for a batch's table entries meant waiting for the previous batch's stores to reach memory
+  // (measured at C2: input + rows 0.29 ms, output 0.42 ms, but 1.08 ms together)
+  const int nnz_l = row_ptr[mb];
+  uint16_t* oi = reinterpret_cast<uint16_t*>(re + nnz_l);
   for (int i = threadIdx.x; i <= mb; i += 256) rp[i] = row_ptr[i];
-  for (int i = threadIdx.x; i < row_ptr[mb]; i += 256) re[i] = row_ent[i];
+  for (int i = threadIdx.x; i < nnz_l; i += 256) re[i] = row_ent[i];
+  for (int i = threadIdx.x; 2 * i < p.n; i += 256)
+    reinterpret_cast<uint32_t*>(oi)[i] = reinterpret_cast<const uint32_t*>(out_idx)[i];   // table padded to an even length
   __syncthreads();
   row_ptr = rp;
   row_ent = re;
@@ -131,22 +138,23 @@ __global__ __launch_bounds__(256) void ldpc5g_encode_packed_kernel(
   for (int b = blockIdx.x * 4 + wv; b < batch; b += gridDim.x * 4) {
     const float* u = bits + (size_t)b * p.k;
     // information bits -> words (filler bits = 0, encoding.py:637): one ballot per 64 floats
-    // (eight loads in flight per lane before the first ballot: a wave is the only owner of its codeword's latency)
-    for (int i0 = 0; i0 < p.k_ldpc; i0 += 512) {
-      float v[8];
+    // (16 loads in flight per lane before the first ballot: a wave is the only owner of its codeword's latency)
+    for (int i0 = 0; i0 < p.k_ldpc && !(dbg & 1); i0 += 1024) {
+      float v[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const int i = i0 + 64 * j + lane;
         v[j] = i < p.k ? u[i] : 0.f;
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(((int)v[j]) & 1);
         if (lane < 2 && i0 + 64 * j < p.k_ldpc) cw[((i0 + 64 * j) >> 5) + lane] = (uint32_t)(m >> (32 * lane));
       }
     }
     wave_sync();
     // lambda_r = sum_j P(a_rj) s_j for the 4 core rows (columns < k_b only): lane = (row, word)
+    if (!(dbg & 2))
     for (int i = lane; i < 4 * wq; i += 64) {
       const int r = i / wq, w = i - r * wq;
       uint32_t acc = 0u;
@@ -175,6 +183,7 @@ __global__ __launch_bounds__(256) void ldpc5g_encode_packed_kernel(
     }
     wave_sync();
     // extension rows: p_b = C1 s + C2 p_a  (encoding.py:579-581): lane = (row, word)
+    if (!(dbg & 2))
     for (int i = lane; i < (mb - 4) * wq; i += 64) {
       const int r = 4 + i / wq, w = i % wq;
       uint32_t acc = 0u;
@@ -187,12 +196,12 @@ __global__ __launch_bounds__(256) void ldpc5g_encode_packed_kernel(
     }
     wave_sync();
     float* o = out + (size_t)b * p.n;
-    for (int i0 = 0; i0 < p.n; i0 += 512) {
+    for (int i0 = 0; i0 < p.n && !(dbg & 4); i0 += 512) {
       unsigned t[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int i = i0 + 64 * j + lane;
-        t[j] = i < p.n ? out_idx[i] : 0u;
+        t[j] = i < p.n ? oi[i] : 0u;
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -426,7 +435,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   if (rc == SAMD_OK) rc = upload(&h->vn_items, vn_items.data(), vn_items.size());
   if (rc == SAMD_OK && z % 32 == 0 && h->n_ldpc < 65536) {
     // output position -> position in the full codeword (output interleaver and puncturing / filler removal folded)
-    std::vector<uint16_t> oi(n);
+    std::vector<uint16_t> oi(n + 2, 0);                    // (+ padding: the kernel copies the table in 32-bit words)
     for (int i = 0; i < n; ++i) {
       int t = i;
       if (h->m_int > 0) t = (i % h->m_int) * (n / h->m_int) + i / h->m_int;   // out_to_short
@@ -460,10 +469,17 @@ extern "C" int samd_ldpc5g_encode_f32(const samd_ldpc5g_t* h, const float* bits,
   if (h->enc_out_idx && h->z % 32 == 0 && !getenv("SAMD_ENC_BYTES")) {
     // lifting sizes that are multiples of 32: the bit-packed kernel, one wave per codeword
     const int wq = h->z / 32;
-    const size_t lds_p = (4 * (size_t)((h->mb + h->k_b) * wq + 4 * wq) + (size_t)h->mb + 1 + (size_t)h->nnz) * sizeof(uint32_t);
-    const int grid = std::min((batch + 3) / 4, 256 * 8 * 4);
+    const size_t lds_p = (4 * (size_t)((h->mb + h->k_b) * wq + 4 * wq) + (size_t)h->mb + 1 + (size_t)h->nnz) * sizeof(uint32_t) +
+                         (size_t)(h->n + 2) * sizeof(uint16_t);
+    if (lds_p > 64 * 1024)
+      SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc5g_encode_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    // one codeword per wave and launch slot: a wave that went on to a second codeword would wait for its own output
+    // stores before the next input arrives (loads and stores share the in-order vmcnt counter) - measured 1.12 ms
+    // against 0.28 ms (input + rows) + 0.42 ms (output) for the separate phases at C2
+    const int grid = getenv("SAMD_ENC_PERSIST") ? std::min((batch + 3) / 4, 256 * 8 * 4) : (batch + 3) / 4;
     hipLaunchKernelGGL(ldpc5g_encode_packed_kernel, dim3(grid), dim3(256), lds_p, (hipStream_t)stream, bits, out, make_rm(h),
-                       batch, h->mb, h->k_b, h->bg, h->s_a, h->s_b, h->row_ptr, h->row_ent, h->enc_out_idx);
+                       batch, h->mb, h->k_b, h->bg, h->s_a, h->s_b, h->row_ptr, h->row_ent, h->enc_out_idx,
+                       getenv("SAMD_ENC_DBG") ? atoi(getenv("SAMD_ENC_DBG")) : 0);
     return launch_status();
   }
   const size_t lds = (size_t)h->n_ldpc + 4 * (size_t)h->z;

@@ -163,7 +163,10 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
         const int cy = __builtin_amdgcn_readfirstlane(cur.y), cz = __builtin_amdgcn_readfirstlane(cur.z);
         const int cw = __builtin_amdgcn_readfirstlane(cur.w);
         if (kind == LY_BARRIER) {
-          __syncthreads();
+          // LDS traffic only: wait for this wave's LDS operations, not for its global ones (__syncthreads would also wait
+          // for the next record's operands, just requested from L2, and for the fused-column stores - 64 exposed L2
+          // round trips per iteration)
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else if (kind == LY_CN) {
           float* ce = cext + (cw >> 16) * (int)z + lane;
 #define SAMD_LY_CN(KEY, D, F) case KEY: ly_cn_row<D, F, POW2, MODE>((unsigned)cy + lane4, z4, row_ent + cz, lane4, zwv, llr_max, offset, ce, pa0, pa1, pb0, pb1); break;
