@@ -61,16 +61,29 @@ def _sha16(path):
         return None
 
 
+def _load_json(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 def load_counters(kernel_key):
     """Per-unit PMC counters of one kernel from profiles/counters.json (None if absent)."""
     try:
         with open(COUNTERS) as f:
-            rec = json.load(f)["kernels"].get(kernel_key)
+            allc = json.load(f)
+        rec = allc["kernels"].get(kernel_key)
     except (OSError, ValueError, KeyError):
         return None
     if rec:
         rec = dict(rec)
         rec["stale"] = bool(rec.get("source") and _sha16(rec["source"]) != rec.get("source_sha16"))
+        rec["collected_on"] = allc.get("collected_on")
+        # static VALU mix x measured issue times (tools/valu_mix.py) and the ablation shares (tools/gpu_ablation.sh)
+        rec["mix"] = _load_json("r03_valu_mix.json").get("kernels", {}).get(kernel_key)
+        rec["ablation"] = _load_json("r03_ablation.json").get(kernel_key)
     return rec
 
 
@@ -88,7 +101,23 @@ def onchip_roofline(kernel_key, kernel_name, units, ms, extra=None):
             "traffic": int(rec["hbm_bytes_per_unit"] * units),
             "counters": {"file": "profiles/counters.json", "from": rec.get("from"), "per_unit": rec.get("unit"),
                          "valu_insts_per_unit": rec["valu_insts_per_unit"], "measured_units_per_launch": rec.get("units_per_launch"),
-                         "stale": rec["stale"]}})
+                         "stale": rec["stale"], "collected_on": rec.get("collected_on")}})
+        # WHY the fraction is what it is: shares of a wave's resident cycles (PMC), the barrier share (ablation build
+        # without the two workgroup barriers), and the VALU pipe's busy share under the instruction mix's own issue
+        # times (no instruction of these kernels issues at the nominal 2 cycles: tools/valu_mix.py)
+        for kf in ("wait_frac", "issue_stall_frac", "active_frac"):
+            if rec.get(kf) is not None:
+                out[kf] = rec[kf]
+        if rec.get("ablation"):
+            out["barrier_frac"] = rec["ablation"].get("barrier_frac")
+            out["ablation"] = {k_: rec["ablation"][k_] for k_ in ("node_arithmetic_frac", "lds_frac_of_time", "lds_plus_barriers_frac",
+                                                                  "fixed_per_codeword_frac", "from") if k_ in rec["ablation"]}
+        if rec.get("mix"):
+            ns = rec["mix"]["ns_per_valu_inst_est"]
+            out["valu_busy_est"] = round(rec["valu_insts_per_unit"] * units * ns * 1e-9 / (NUM_SIMD * ms * 1e-3), 4)
+            out["valu_mix"] = {"ns_per_inst_est": ns, "class_counts": rec["mix"]["class_counts"],
+                               "note": "static mix of the kernel x issue times measured by tools/ubench/valu_rate.hip "
+                                       "(profiles/r03b/valu_rate_r03b.txt); peak under this mix = 1024 SIMDs / ns_per_inst"}
     else:
         out["note"] = "profiles/counters.json has no entry for this kernel: run tools/gpu_pmc.sh + tools/pmc_counters.py"
     if extra:
@@ -403,8 +432,9 @@ def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms):
     if onchip:
         minsum = cn_update in ("minsum", "offset-minsum")
         key = "ldpc5g_ms" if minsum else ("ldpc5g_bp_fast" if cn_update == "boxplus-phi-fast" else "ldpc5g_bp")
-        name = ("ldpc5g_decode_ms_kernel (on-chip min-sum, one float per edge in LDS, channel LLRs in an L2 workspace row)"
-                if minsum else "ldpc5g_decode_ms_kernel<..., boxplus> (the same engine with bp_math's boxplus node update)")
+        name = ("ldpc5g_decode_msg_kernel (on-chip min-sum, one float per edge in LDS, channel LLRs in an L2 workspace row, "
+                "grouped dispatch)" if minsum else
+                "ldpc5g_decode_msg_kernel<..., boxplus> (the same engine with bp_math's boxplus node update)")
         return onchip_roofline(key, name, B, dec_ms, {"hbm_resident_equiv": equiv, **io})
     ach = bytes_alg / (dec_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),

@@ -31,17 +31,19 @@ enum { LY_END = 0, LY_BARRIER = 1, LY_CN = 2, LY_VN = 3 };
 
 // check nodes (row r, lifted copies lane and lane + 64): D edges, the last one fused when F.
 // ent: (byte offset of the column's xtot block, 4 shift) per non-fused edge; a0 = row block byte offset + 4 lane
-template <int D, bool F, bool POW2, int MODE>
+// NCH = 2: both 64-lane chunks in one item (two dependency chains per wave); NCH = 1: one chunk - the row's two chunks
+// then run on two waves side by side (the check-node update of a layer is the serial part of a group)
+template <int D, bool F, bool POW2, int MODE, int NCH>
 __device__ __forceinline__ void ly_cn_row(unsigned a0, unsigned z4, const int32_t* __restrict__ ent, unsigned lane4,
                                           unsigned zwv, float llr_max, float offset, float* __restrict__ cext,
                                           float co0, float co1, float lf0, float lf1) {
   constexpr int NF = F ? D - 1 : D;
-  float v[2][D];
+  float v[NCH][D];
   float co[2] = {co0, co1};
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NCH; ++h) {
       const unsigned t = lane4 + 256u * h + (unsigned)ent[2 * i + 1];
       const unsigned ax = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t - zwv) + (unsigned)ent[2 * i]);
       const float x = lds_ld(ax);
@@ -51,22 +53,25 @@ __device__ __forceinline__ void ly_cn_row(unsigned a0, unsigned z4, const int32_
   }
   if constexpr (F) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NCH; ++h) {
       const float x = co[h] + (h ? lf1 : lf0);                          // (0 + c2v) + llr of the degree-1 node
       v[h][D - 1] = ms_med3(x - co[h], -llr_max, llr_max);
     }
   }
   if constexpr (MODE == SAMD_CN_MINSUM) {
-    ms_minsum_inplace<D, 2, 1>(v, llr_max, offset);
+    ms_minsum_inplace<D, NCH, 1>(v, llr_max, offset);
   } else {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) cn_update_col<MODE, D>(v[h], D, llr_max, 0.f);
+    for (int h = 0; h < NCH; ++h) cn_update_col<MODE, D>(v[h], D, llr_max, 0.f);
   }
 #pragma unroll
   for (int i = 0; i < NF; ++i)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) lds_st(a0 + (unsigned)i * z4 + 256u * h, v[h][i]);
-  if constexpr (F) { cext[0] = v[0][D - 1]; cext[64] = v[1][D - 1]; }
+    for (int h = 0; h < NCH; ++h) lds_st(a0 + (unsigned)i * z4 + 256u * h, v[h][i]);
+  if constexpr (F) {
+    cext[0] = v[0][D - 1];
+    if constexpr (NCH == 2) cext[64] = v[1][D - 1];
+  }
 }
 
 // variable nodes of column c (lifted copies of chunk(s)): re-sum of all D messages + channel LLR -> xtot.
@@ -142,10 +147,13 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
         const int kind = __builtin_amdgcn_readfirstlane(rc.x) & 0xFF;
         const int wv = __builtin_amdgcn_readfirstlane(rc.w);
         if (kind == LY_CN) {
-          if ((__builtin_amdgcn_readfirstlane(rc.x) >> 13) & 1) {       // fused: c2v of the fused edge, its channel LLR
-            const float* ce = cext + (wv >> 16) * (int)z + lane;
-            const float* le = llr + (wv & 0xFFFF) * (int)z + lane;
-            a0 = ce[0]; a1 = ce[64]; b0 = le[0]; b1 = le[64];
+          const int rx = __builtin_amdgcn_readfirstlane(rc.x);
+          if ((rx >> 13) & 1) {                                         // fused: c2v of the fused edge, its channel LLR
+            const int q64 = ((rx >> 16) & 0xFF) * 64;
+            const float* ce = cext + (wv >> 16) * (int)z + q64 + lane;
+            const float* le = llr + (wv & 0xFFFF) * (int)z + q64 + lane;
+            a0 = ce[0]; b0 = le[0];
+            if ((rx >> 14) & 1) { a1 = ce[64]; b1 = le[64]; }
           }
         } else if (kind == LY_VN) {
           a0 = llr[wv + lane];
@@ -168,9 +176,12 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
           // round trips per iteration)
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else if (kind == LY_CN) {
-          float* ce = cext + (cw >> 16) * (int)z + lane;
-#define SAMD_LY_CN(KEY, D, F) case KEY: ly_cn_row<D, F, POW2, MODE>((unsigned)cy + lane4, z4, row_ent + cz, lane4, zwv, llr_max, offset, ce, pa0, pa1, pb0, pb1); break;
-          switch ((cx >> 8) & 63) {
+          const unsigned zq4 = ((unsigned)(cx >> 16) & 0xFFu) * 256u + lane4;      // 4 (64 chunk + lane)
+          float* ce = cext + (cw >> 16) * (int)z + (int)(zq4 >> 2);
+#define SAMD_LY_CN(KEY, D, F)                                                                                          \
+  case KEY: ly_cn_row<D, F, POW2, MODE, 2>((unsigned)cy + zq4, z4, row_ent + cz, zq4, zwv, llr_max, offset, ce, pa0, pa1, pb0, pb1); break; \
+  case 64 + KEY: ly_cn_row<D, F, POW2, MODE, 1>((unsigned)cy + zq4, z4, row_ent + cz, zq4, zwv, llr_max, offset, ce, pa0, pa1, pb0, pb1); break;
+          switch (((cx >> 8) & 63) | (((cx >> 14) & 1) ? 0 : 64)) {
             SAMD_LY_CN(3, 3, false) SAMD_LY_CN(4, 4, false) SAMD_LY_CN(5, 5, false) SAMD_LY_CN(6, 6, false)
             SAMD_LY_CN(7, 7, false) SAMD_LY_CN(8, 8, false) SAMD_LY_CN(9, 9, false) SAMD_LY_CN(10, 10, false)
             SAMD_LY_CN(19, 19, false)
@@ -314,15 +325,33 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   for (auto& g : groups) {
     // CN items: one per row, on consecutive waves starting at a rotating position (so that the serial part does not
     // always load the same SIMD)
+    // (SAMD_LY_CN_SPLIT=0: one item for both chunks; default: the chunks of a row as separate items on different waves)
+    const bool cn_split = !(getenv("SAMD_LY_CN_SPLIT") && atoi(getenv("SAMD_LY_CN_SPLIT")) == 0);
+    int slot = 0;
     for (size_t j = 0; j < g.size(); ++j) {
       const int r = g[j], d = (int)by_row[r].size(), f = fused_col[r] >= 0;
-      const int wv = (rot + (int)j) % NW;                     // consecutive waves sit on different SIMDs
-      per[wv].push_back({LY_CN | ((d | (f << 5)) << 8), row_off[r], row_start[r], f ? (fused_col[r] | (ext_of_row[r] << 16)) : 0});
+      const int32_t wcol = f ? (fused_col[r] | (ext_of_row[r] << 16)) : 0;
+      for (int q = 0; q < z / 64; q += 2) {
+        if (cn_split) {
+          per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | (q << 16), row_off[r], row_start[r], wcol});
+          per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | ((q + 1) << 16), row_off[r], row_start[r], wcol});
+        } else {
+          per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | (1 << 14) | (q << 16), row_off[r], row_start[r], wcol});
+        }
+      }
     }
     for (int wv = 0; wv < NW; ++wv) per[wv].push_back({LY_BARRIER, 0, 0, 0});
     // VN items of the columns the group touched, longest first onto the least loaded wave
     std::vector<std::pair<int, std::array<int32_t, 4>>> items;
     std::vector<char> seen(h->nb, 0);
+    int ncols = 0;
+    for (int r : g)
+      for (auto& e : by_row[r])
+        if (!col_fused[e.first] && !seen[e.first]) { seen[e.first] = 1; ++ncols; }
+    std::fill(seen.begin(), seen.end(), 0);
+    // few columns: single-chunk items spread over more waves (an item's time is mostly its fixed latency)
+    const int single_max = getenv("SAMD_LY_VN_SINGLE_MAX") ? atoi(getenv("SAMD_LY_VN_SINGLE_MAX")) : 0;   // measured at C2: 0 -> 369 k, 10 -> 362 k, 32 -> 354 k decodes/s
+    const bool all_single = ncols * (z / 64) <= 2 * single_max;
     for (int r : g)
       for (auto& e : by_row[r]) {
         const int c = e.first;
@@ -330,7 +359,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
         seen[c] = 1;
         const int dg = col_deg[c], chunks = z / 64;
         for (int q = 0; q < chunks; ++q) {
-          const bool pair = dg <= 12;
+          const bool pair = dg <= 12 && !all_single;
           items.push_back({(pair ? 10 : 10) * dg + (pair ? 200 : 100),
                            {LY_VN | ((dg | ((pair ? 1 : 0) << 5)) << 8) | (q << 16), xt_base + xt_of_col[c] * z * 4, col_start[c], c * z + q * 64}});
           if (pair) ++q;

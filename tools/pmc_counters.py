@@ -19,8 +19,12 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = {   # key -> (substring of the kernel name, unit, source file)
     # the explicit-message engine, by its last template argument: the check-node rule (2 min-sum, 1 boxplus-phi)
-    "ldpc5g_ms": ("ldpc5g_decode_ms_kernel<true, 16, true, 2, false>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
-    "ldpc5g_bp": ("ldpc5g_decode_ms_kernel<true, 16, true, 1, false>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.hip"),
+    # (round 3: the grouped-dispatch kernel <ZM = 2 (Z = 128), LLRG, rule, VAR>; rule 2 min-sum, 1 boxplus-phi on the
+    # defined exp / log, 4 boxplus-phi on the hardware transcendentals)
+    "ldpc5g_ms": ("ldpc5g_decode_msg_kernel<2, true, 2, 1>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
+    "ldpc5g_bp": ("ldpc5g_decode_msg_kernel<2, true, 1, 0>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
+    "ldpc5g_bp_fast": ("ldpc5g_decode_msg_kernel<2, true, 4, 0>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
+    "ldpc5g_layered": ("ldpc5g_decode_ly_kernel", "decode", "sionna_amd/csrc/ldpc5g_onchip_ly.hip"),
     "polar_scl": ("polar_scl_reg_kernel", "decode", "sionna_amd/csrc/polar_scl_reg.hip"),
     "ofdm_lmmse": ("ofdm_lmmse_diag_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
 }
@@ -44,8 +48,15 @@ def main():
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else os.path.basename(root.rstrip("/"))
     units = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[2:] if "=" in a}
     means = per_kernel_means(root)
+    import subprocess
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    collected = sys.argv[sys.argv.index("--collected-on") + 1] if "--collected-on" in sys.argv else head
     out = {"_comment": "per-unit PMC counters of the dominant kernels (tools/pmc_counters.py); bench.py multiplies them by the "
-                       "units of a launch and divides by the launch time it measures", "tag": tag, "kernels": {}}
+                       "units of a launch and divides by the launch time it measures", "tag": tag,
+           "collected_on": collected, "kernels": {}}
     for key, (sub, unit, src) in KERNELS.items():
         if key not in units:
             continue
@@ -66,6 +77,10 @@ def main():
                "lds_insts_per_unit": round(m["SQ_INSTS_LDS"] / n, 2), "lds_array_cycles_per_unit": round(m["SQ_LDS_IDX_ACTIVE"] / n, 2),
                "lds_bank_conflict_cycles_per_unit": round(m["SQ_LDS_BANK_CONFLICT"] / n, 3),
                "wave_quad_cycles_per_unit": round(m["SQ_WAVE_CYCLES"] / n, 1), "wait_any_quad_cycles_per_unit": round(m["SQ_WAIT_ANY"] / n, 1),
+               # shares of a wave's resident cycles: parked on s_waitcnt / s_barrier, stalled at issue, issuing
+               "wait_frac": round(m["SQ_WAIT_ANY"] / max(m["SQ_WAVE_CYCLES"], 1), 4),
+               "issue_stall_frac": round(m["SQ_WAIT_INST_ANY"] / max(m["SQ_WAVE_CYCLES"], 1), 4),
+               "active_frac": round(m["SQ_ACTIVE_INST_ANY"] / max(m["SQ_WAVE_CYCLES"], 1), 4),
                "hbm_bytes_per_unit": round((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024 / n, 2),
                "fetch_size_kb_per_launch": m["FETCH_SIZE"], "write_size_kb_per_launch": m["WRITE_SIZE"]}
         out["kernels"][key] = rec
