@@ -465,6 +465,13 @@ int samd_qam_demap_f64(const double* y, const double* no, int64_t no_len, const 
                        int m, int64_t num_symbols, const double* prior, int64_t prior_len,
                        int method, int hard_out, double* out, void* stream);
 
+/* lmmse_equalizer / zf_equalizer / mf_equalizer in complex128 (precision = "double", reference block.py:25-52;
+ * mimo/equalization.py:101-470): y [n, M], h [n, M, K], s [n, M, M] complex128 -> x_hat [n, K] complex128, no_eff
+ * [n, K] float64; mode 0 LMMSE without whitening, 1 LMMSE, 2 ZF, 3 MF; K <= 8, K <= M <= 16.  OFDMEqualizer.call with
+ * precision="double" builds the per-resource-element inputs on the device and calls this. */
+int samd_lmmse_equalizer_c128(const double* y, const double* h, const double* s, int64_t n, int m, int k, int mode,
+                              double* x_hat, double* no_eff, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * CRC and Polar codes (config C5 of the north star).
  * ---------------------------------------------------------------------------------- */

@@ -42,6 +42,7 @@ _SIGNATURES = {
                                        C.c_double, _i32, _vp, _sz, _vp]),
     "samd_ldpc5g_rate_recover_f64": (_i32, [_vp, _vp, _vp, _i32, C.c_double, _vp]),
     "samd_ldpc5g_extract_codeword_f64": (_i32, [_vp, _vp, _vp, _i32, _vp]),
+    "samd_lmmse_equalizer_c128": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "samd_qam_demap_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "samd_ldpc5g_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "samd_ldpc5g_destroy": (None, [_vp]),

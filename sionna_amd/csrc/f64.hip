@@ -257,6 +257,166 @@ __global__ __launch_bounds__(256) void demap64_kernel(const double2* __restrict_
 }  // namespace
 }  // namespace samd
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// precision = "double" of lmmse_equalizer / zf_equalizer / mf_equalizer (reference src/sionna/phy/mimo/equalization.py:
+// 101-233, 235-298, 300-470) and, through them, of OFDMEqualizer.call (ofdm/equalization.py:107-230): one lane per
+// item, complex128, run-time M <= 16 and K <= 8 (the analysis path: no unrolling, arrays in scratch).  Cholesky of the
+// covariance, forward substitutions for L^-1 y and L^-1 H, Cholesky of the K x K Gramian + I - the formulas of the
+// reference; results are held to the complex128 NumPy oracle at 1e-9 (tests/test_gpu_double.py).
+namespace samd {
+namespace {
+struct c64 { double re, im; };
+__device__ __forceinline__ c64 C64(double r, double i) { return c64{r, i}; }
+__device__ __forceinline__ c64 operator+(c64 a, c64 b) { return C64(a.re + b.re, a.im + b.im); }
+__device__ __forceinline__ c64 operator-(c64 a, c64 b) { return C64(a.re - b.re, a.im - b.im); }
+__device__ __forceinline__ c64 operator*(c64 a, c64 b) { return C64(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+__device__ __forceinline__ c64 mulcj(c64 a, c64 b) { return C64(a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im); }   // a conj(b)
+__device__ __forceinline__ c64 cjm(c64 a, c64 b) { return C64(a.re * b.re + a.im * b.im, a.re * b.im - a.im * b.re); }    // conj(a) b
+__device__ __forceinline__ c64 sc(c64 a, double t) { return C64(a.re * t, a.im * t); }
+
+constexpr int kEqM = 16, kEqK = 8;
+
+// in-place Cholesky factor (lower) of the Hermitian n x n matrix a (row stride ld)
+__device__ void chol64(c64* a, int n, int ld) {
+  for (int j = 0; j < n; ++j) {
+    double d = a[j * ld + j].re;
+    for (int q = 0; q < j; ++q) d -= a[j * ld + q].re * a[j * ld + q].re + a[j * ld + q].im * a[j * ld + q].im;
+    d = sqrt(d);
+    a[j * ld + j] = C64(d, 0.0);
+    for (int i = j + 1; i < n; ++i) {
+      c64 v = a[i * ld + j];
+      for (int q = 0; q < j; ++q) v = v - mulcj(a[i * ld + q], a[j * ld + q]);
+      a[i * ld + j] = sc(v, 1.0 / d);
+    }
+    for (int i = 0; i < j; ++i) a[i * ld + j] = C64(0.0, 0.0);
+  }
+}
+// x <- L^-1 x for `cols` right-hand sides stored as x[row * ldx + col]
+__device__ void fwd64(const c64* l, int n, int ld, c64* x, int ldx, int cols) {
+  for (int c = 0; c < cols; ++c)
+    for (int i = 0; i < n; ++i) {
+      c64 v = x[i * ldx + c];
+      for (int q = 0; q < i; ++q) v = v - l[i * ld + q] * x[q * ldx + c];
+      x[i * ldx + c] = sc(v, 1.0 / l[i * ld + i].re);
+    }
+}
+// x <- L^-H x
+__device__ void bwd64(const c64* l, int n, int ld, c64* x, int ldx, int cols) {
+  for (int c = 0; c < cols; ++c)
+    for (int i = n - 1; i >= 0; --i) {
+      c64 v = x[i * ldx + c];
+      for (int q = i + 1; q < n; ++q) v = v - cjm(l[q * ld + i], x[q * ldx + c]);
+      x[i * ldx + c] = sc(v, 1.0 / l[i * ld + i].re);
+    }
+}
+
+// mode: 0 LMMSE without whitening, 1 LMMSE with whitening, 2 ZF, 3 MF
+__global__ __launch_bounds__(64) void equalize_items_f64_kernel(const double2* __restrict__ y, const double2* __restrict__ h,
+                                                               const double2* __restrict__ s, int64_t n, int M, int K,
+                                                               int mode, double2* __restrict__ x_hat, double* __restrict__ no_eff) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= n) return;
+  c64 Y[kEqM], H[kEqM * kEqK], S[kEqM * kEqM], G[kEqK * kEqM], A[kEqM * kEqM];
+  for (int i = 0; i < M; ++i) { const double2 v = y[it * M + i]; Y[i] = C64(v.x, v.y); }
+  for (int i = 0; i < M * K; ++i) { const double2 v = h[it * M * K + i]; H[i] = C64(v.x, v.y); }        // H[i * K + k]
+  for (int i = 0; i < M * M; ++i) { const double2 v = s[it * M * M + i]; S[i] = C64(v.x, v.y); }
+  if (mode == 1) {
+    // whitening: S = L L^H, y <- L^-1 y, H <- L^-1 H; G = (H^H H + I)^-1 H^H
+    chol64(S, M, M);
+    fwd64(S, M, M, Y, 1, 1);
+    fwd64(S, M, M, H, K, K);
+    for (int a = 0; a < K; ++a)
+      for (int b = 0; b < K; ++b) {
+        c64 v = C64(a == b ? 1.0 : 0.0, 0.0);
+        for (int i = 0; i < M; ++i) v = v + cjm(H[i * K + a], H[i * K + b]);
+        A[a * K + b] = v;
+      }
+    chol64(A, K, K);
+    for (int a = 0; a < K; ++a)
+      for (int i = 0; i < M; ++i) G[a * M + i] = C64(H[i * K + a].re, -H[i * K + a].im);    // H^H
+    fwd64(A, K, K, G, M, M);
+    bwd64(A, K, K, G, M, M);
+  } else if (mode == 0) {
+    // G = H^H (H H^H + S)^-1  ->  G^H = (H H^H + S)^-1 H (the matrix is Hermitian)
+    for (int a = 0; a < M; ++a)
+      for (int b = 0; b < M; ++b) {
+        c64 v = S[a * M + b];
+        for (int k = 0; k < K; ++k) v = v + mulcj(H[a * K + k], H[b * K + k]);
+        A[a * M + b] = v;
+      }
+    chol64(A, M, M);
+    c64 X[kEqM * kEqK];
+    for (int i = 0; i < M * K; ++i) X[i] = H[i];
+    fwd64(A, M, M, X, K, K);
+    bwd64(A, M, M, X, K, K);                                    // X = (H H^H + S)^-1 H = G^H
+    for (int a = 0; a < K; ++a)
+      for (int i = 0; i < M; ++i) G[a * M + i] = C64(X[i * K + a].re, -X[i * K + a].im);
+  } else {
+    // ZF: G = (H^H H)^-1 H^H; MF: G = diag(H^H H)^-1 H^H
+    for (int a = 0; a < K; ++a)
+      for (int b = 0; b < K; ++b) {
+        c64 v = C64(0.0, 0.0);
+        for (int i = 0; i < M; ++i) v = v + cjm(H[i * K + a], H[i * K + b]);
+        A[a * K + b] = v;
+      }
+    for (int a = 0; a < K; ++a)
+      for (int i = 0; i < M; ++i) G[a * M + i] = C64(H[i * K + a].re, -H[i * K + a].im);
+    if (mode == 2) {
+      chol64(A, K, K);
+      fwd64(A, K, K, G, M, M);
+      bwd64(A, K, K, G, M, M);
+    } else {
+      for (int a = 0; a < K; ++a)
+        for (int i = 0; i < M; ++i) G[a * M + i] = sc(G[a * M + i], 1.0 / A[a * K + a].re);
+    }
+  }
+  for (int a = 0; a < K; ++a) {
+    c64 gy = C64(0.0, 0.0), d = C64(0.0, 0.0);
+    for (int i = 0; i < M; ++i) { gy = gy + G[a * M + i] * Y[i]; d = d + G[a * M + i] * H[i * K + a]; }
+    if (mode <= 1) {
+      // x_hat = (G y) / diag(G H), no_eff = real(1 / d - 1)   (equalization.py:213-231)
+      const double dn = d.re * d.re + d.im * d.im;
+      const c64 inv = C64(d.re / dn, -d.im / dn);
+      const c64 xv = gy * inv;
+      x_hat[it * K + a] = make_double2(xv.re, xv.im);
+      no_eff[it * K + a] = inv.re - 1.0;
+    } else {
+      x_hat[it * K + a] = make_double2(gy.re, gy.im);
+      // ZF: diag(G S G^H); MF: |diag((I - G H)(I - G H)^H + G S G^H)|
+      c64 acc = C64(0.0, 0.0);
+      for (int i = 0; i < M; ++i) {
+        c64 t = C64(0.0, 0.0);
+        for (int j = 0; j < M; ++j) t = t + G[a * M + j] * S[j * M + i];
+        acc = acc + mulcj(t, G[a * M + i]);
+      }
+      if (mode == 3) {
+        for (int b = 0; b < K; ++b) {
+          c64 e = C64(a == b ? 1.0 : 0.0, 0.0);
+          for (int i = 0; i < M; ++i) e = e - G[a * M + i] * H[i * K + b];
+          acc = acc + mulcj(e, e);
+        }
+        no_eff[it * K + a] = sqrt(acc.re * acc.re + acc.im * acc.im);
+      } else {
+        no_eff[it * K + a] = acc.re;
+      }
+    }
+  }
+}
+}  // namespace
+}  // namespace samd
+
+extern "C" int samd_lmmse_equalizer_c128(const double* y, const double* h, const double* s, int64_t n, int m, int k, int mode,
+                                         double* x_hat, double* no_eff, void* stream) {
+  SAMD_REQUIRE(y && h && s && x_hat && no_eff && n >= 0, "null argument");
+  SAMD_REQUIRE(m >= 1 && m <= samd::kEqM && k >= 1 && k <= samd::kEqK && k <= m, "float64 equaliser: 1 <= K <= 8, K <= M <= 16");
+  SAMD_REQUIRE(mode >= 0 && mode <= 3, "mode: 0 LMMSE, 1 LMMSE with whitening, 2 ZF, 3 MF");
+  if (n == 0) return SAMD_OK;
+  hipLaunchKernelGGL(samd::equalize_items_f64_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     (const double2*)y, (const double2*)h, (const double2*)s, n, m, k, mode, (double2*)x_hat, no_eff);
+  return samd::launch_status();
+}
+
 using namespace samd;
 
 extern "C" size_t samd_ldpc_bp_workspace_bytes_f64(const samd_ldpc_graph_t* g, int batch) {

@@ -8,8 +8,9 @@ from ..block import wrap
 
 
 def _equalize(y, h, s, mode, precision, name):
-    if precision not in (None, "single"):
-        raise NotImplementedError(f"{name}: the MI355X kernels implement precision='single' only")
+    from ..config import config
+    if (precision or config.precision) == "double":
+        return _equalize_f64(y, h, s, mode, name)
     y = _ffi.to_device(y, torch.complex64)
     h = _ffi.to_device(h, torch.complex64)
     s = _ffi.to_device(s, torch.complex64)
@@ -22,6 +23,23 @@ def _equalize(y, h, s, mode, precision, name):
     no_eff = torch.empty(lead + (k,), dtype=torch.float32, device=y.device)
     _ffi.check(_ffi.lib().samd_lmmse_equalizer_c64(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), n, m, k, int(mode),
                                                   _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.stream()), name)
+    return wrap(x_hat), wrap(no_eff)
+
+
+def _equalize_f64(y, h, s, mode, name):
+    """precision="double" (block.py:25-52): the complex128 kernel samd_lmmse_equalizer_c128 (csrc/f64.hip)."""
+    y = _ffi.to_device(y, torch.complex128)
+    h = _ffi.to_device(h, torch.complex128)
+    s = _ffi.to_device(s, torch.complex128)
+    m, k = h.shape[-2], h.shape[-1]
+    lead = tuple(h.shape[:-2])
+    y = torch.broadcast_to(y, lead + (m,)).contiguous()
+    s = torch.broadcast_to(s, lead + (m, m)).contiguous()
+    n = y.numel() // m
+    x_hat = torch.empty(lead + (k,), dtype=torch.complex128, device=y.device)
+    no_eff = torch.empty(lead + (k,), dtype=torch.float64, device=y.device)
+    _ffi.check(_ffi.lib().samd_lmmse_equalizer_c128(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), n, m, k, int(mode),
+                                                   _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.stream()), name + "(double)")
     return wrap(x_hat), wrap(no_eff)
 
 

@@ -88,8 +88,54 @@ class OFDMEqualizer(Block):
         dims = (b, rx, m, s, sm.num_streams_per_rx, n_und, t, f, rg.fft_size, rg.num_data_symbols)
         return keep, head, tabs, dims
 
+    def _call_double(self, y, h_hat, err_var, no):
+        """precision="double": the steps of the reference's call (ofdm/equalization.py:107-275) as device tensor
+        operations in complex128 around the complex128 equaliser kernel (the single-precision path fuses them into
+        one launch; this one exists for analysis runs)."""
+        from ..mimo.equalization import _equalize_f64
+        rg, sm = self._rg, self._sm
+        dev = _ffi.device()
+        y = _ffi.to_device(y, torch.complex128)
+        h_hat = _ffi.to_device(h_hat, torch.complex128)
+        ev = _ffi.to_device(err_var, torch.float64) if not _is_host_zero(err_var) else torch.zeros((), dtype=torch.float64, device=dev)
+        no = _ffi.to_device(no, torch.float64)
+        sc = torch.as_tensor(np.asarray(rg.effective_subcarrier_ind), dtype=torch.int64, device=dev)
+        y_eff = y.index_select(-1, sc)                                            # remove nulled subcarriers
+        y_dt = y_eff.permute(0, 1, 3, 4, 2)                                        # [B,rx,T,F,M]
+        ev = torch.broadcast_to(ev, h_hat.shape).permute(0, 1, 5, 6, 2, 3, 4)
+        ev = ev.reshape(tuple(ev.shape[:5]) + (-1,))                               # [B,rx,T,F,M,tx*s]
+        h_dt = h_hat.permute(1, 3, 4, 0, 2, 5, 6)
+        h_dt = h_dt.reshape((-1,) + tuple(h_dt.shape[3:]))                         # [rx*tx*s,B,M,T,F]
+        ind_d = torch.as_tensor(np.asarray(sm.detection_desired_ind), dtype=torch.int64, device=dev)
+        ind_u = torch.as_tensor(np.asarray(sm.detection_undesired_ind), dtype=torch.int64, device=dev)
+        hd = h_dt.index_select(0, ind_d).reshape((sm.num_rx, sm.num_streams_per_rx) + tuple(h_dt.shape[1:]))
+        hd = hd.permute(2, 0, 4, 5, 3, 1)                                          # [B,rx,T,F,M,K]
+        m = y_dt.shape[-1]
+        no_dt = no.reshape(tuple(no.shape) + (1,) * (3 - no.dim()))
+        no_dt = torch.broadcast_to(no_dt, tuple(y.shape[:3]))[..., None, None]
+        no_dt = torch.broadcast_to(no_dt, tuple(y_eff.shape)).permute(0, 1, 3, 4, 2)   # [B,rx,T,F,M]
+        eye = torch.eye(m, dtype=torch.float64, device=dev)
+        s = (no_dt[..., None] * eye + ev.sum(-1)[..., None] * eye).to(torch.complex128)
+        if ind_u.numel() > 0:
+            hu = h_dt.index_select(0, ind_u).reshape((sm.num_rx, -1) + tuple(h_dt.shape[1:])).permute(2, 0, 4, 5, 3, 1)
+            s = s + hu @ hu.conj().transpose(-1, -2)
+        x_hat, no_eff = _equalize_f64(y_dt.contiguous(), hd.contiguous(), s.contiguous(), int(self._mode), type(self).__name__)
+
+        def extract(z):                                                            # [B,rx,T,F,K] -> [B,tx,s,num_data]
+            z = z.as_subclass(torch.Tensor).permute(1, 4, 2, 3, 0)                 # [rx,K,T,F,B]
+            z = z.reshape((-1,) + tuple(z.shape[2:]))
+            z = z.index_select(0, torch.as_tensor(np.asarray(sm.stream_ind), dtype=torch.int64, device=dev))
+            z = z.reshape((rg.num_tx, rg.num_streams_per_tx, -1, z.shape[-1]))     # [tx,s,T*F,B]
+            di = torch.as_tensor(np.asarray(rg._data_ind_eff()), dtype=torch.int64, device=dev)   # [tx*s, num_data]
+            di = di.reshape(rg.num_tx, rg.num_streams_per_tx, -1)
+            z = torch.gather(z, 2, di[..., None].expand(-1, -1, -1, z.shape[-1]))  # [tx,s,ND,B]
+            return z.permute(3, 0, 1, 2).contiguous()
+        from ..block import wrap
+        return wrap(extract(x_hat)), wrap(extract(no_eff))
+
     def call(self, y, h_hat, err_var, no):
-        self._require_single()
+        if self.precision == "double":
+            return self._call_double(y, h_hat, err_var, no)
         rg = self._rg
         keep, head, tabs, dims = self._prepare(y, h_hat, err_var, no)
         b, nd, dev = dims[0], rg.num_data_symbols, keep[0].device

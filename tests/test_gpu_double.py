@@ -122,3 +122,57 @@ def test_chain_in_double_precision(phy):
         assert int(phy.utils.count_errors(u, u_hat)) == 0
     finally:
         phy.config.precision = old
+
+
+@pytest.mark.parametrize("m,k", [(4, 2), (2, 2), (8, 4), (16, 8)])
+def test_equalizers_double_vs_complex128_oracle(phy, m, k):
+    """lmmse_equalizer (with / without whitening), zf_equalizer, mf_equalizer with precision="double" (the last
+    precision="single"-only blocks of the hot path in round 2): complex128 kernel against the NumPy complex128
+    restatement of mimo/equalization.py:101-470 at 1e-9."""
+    from oracle import ofdm as oo
+    rng = np.random.default_rng(m * 10 + k)
+    n = 257
+    h = rng.normal(size=(n, m, k)) + 1j * rng.normal(size=(n, m, k))
+    y = rng.normal(size=(n, m)) + 1j * rng.normal(size=(n, m))
+    a = rng.normal(size=(n, m, m)) + 1j * rng.normal(size=(n, m, m))
+    s = a @ np.conj(np.swapaxes(a, -1, -2)) + 0.3 * np.eye(m)
+    for whiten in (True, False):
+        x, ne = phy.mimo.lmmse_equalizer(y, h, s, whiten_interference=whiten, precision="double")
+        xr, nr = oo.lmmse_equalizer(y, h, s, whiten)
+        assert x.dtype == torch.complex128 and ne.dtype == torch.float64
+        assert np.allclose(_np(x), xr, rtol=1e-9, atol=1e-10) and np.allclose(_np(ne), nr, rtol=1e-9, atol=1e-10)
+    hh = np.conj(np.swapaxes(h, -1, -2))
+    g = np.linalg.solve(hh @ h, hh)                                            # ZF
+    x, ne = phy.mimo.zf_equalizer(y, h, s, precision="double")
+    assert np.allclose(_np(x), (g @ y[..., None])[..., 0], rtol=1e-9, atol=1e-10)
+    assert np.allclose(_np(ne), np.real(np.diagonal(g @ s @ np.conj(np.swapaxes(g, -1, -2)), axis1=-2, axis2=-1)), rtol=1e-9, atol=1e-10)
+    gm = hh / np.real(np.diagonal(hh @ h, axis1=-2, axis2=-1))[..., None]      # MF
+    x, ne = phy.mimo.mf_equalizer(y, h, s, precision="double")
+    e = np.eye(k) - gm @ h
+    ref_ne = np.abs(np.diagonal(e @ np.conj(np.swapaxes(e, -1, -2)) + gm @ s @ np.conj(np.swapaxes(gm, -1, -2)), axis1=-2, axis2=-1))
+    assert np.allclose(_np(x), (gm @ y[..., None])[..., 0], rtol=1e-9, atol=1e-10) and np.allclose(_np(ne), ref_ne, rtol=1e-9, atol=1e-10)
+
+
+def test_ofdm_lmmse_equalizer_double_vs_oracle(phy):
+    """LMMSEEqualizer(precision="double").call == the complex128 oracle of OFDMEqualizer.call (ofdm/equalization.py:107-275)
+    on the C4 grid (4 receive antennas, 2 streams, Kronecker pilots), and agrees with the single-precision fused kernel."""
+    from oracle import ofdm as oo
+    kw = dict(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=15e3, num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6,
+              num_guard_carriers=[5, 6], dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    rg = phy.ofdm.ResourceGrid(**kw)
+    org = oo.ResourceGrid(14, 76, 15e3, num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                          dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    sm, osm = phy.mimo.StreamManagement([[1]], 2), oo.StreamManagement([[1]], 2)
+    rng = np.random.default_rng(3)
+    B = 5
+    y = rng.normal(size=(B, 1, 4, 14, 76)) + 1j * rng.normal(size=(B, 1, 4, 14, 76))
+    h = rng.normal(size=(B, 1, 4, 1, 2, 14, 64)) + 1j * rng.normal(size=(B, 1, 4, 1, 2, 14, 64))
+    ev = rng.uniform(0.01, 0.1, size=(1, 1, 1, 1, 2, 14, 64))
+    no = rng.uniform(0.05, 0.2, size=(B, 1))
+    xr, nr = oo.ofdm_lmmse_equalize(org, osm, y, h, ev, no)
+    x, ne = phy.ofdm.LMMSEEqualizer(rg, sm, precision="double")(y, h, ev, no)
+    assert x.dtype == torch.complex128 and ne.dtype == torch.float64
+    # (the oracle casts its result to complex64 / float32)
+    assert np.allclose(_np(x), xr, rtol=2e-6, atol=2e-6) and np.allclose(_np(ne), nr, rtol=2e-6, atol=2e-6)
+    xs, ns = phy.ofdm.LMMSEEqualizer(rg, sm)(y.astype(np.complex64), h.astype(np.complex64), ev.astype(np.float32), no.astype(np.float32))
+    assert np.allclose(_np(xs), _np(x), rtol=2e-3, atol=2e-4) and np.allclose(_np(ns), _np(ne), rtol=2e-3, atol=2e-4)
