@@ -139,6 +139,9 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
     for (int i = tid; i < n_ext * (int)z; i += NT) cext[i] = 0.f;
     __syncthreads();
 
+    // Records are wave-uniform: scalar loads, one record ahead.  (Vector loads three ahead were tried: they share the
+    // in-order vmcnt counter with the fused-column stores, so waiting for a record meant waiting for those stores to
+    // reach L2 - 47.1 instead of 44.4 ms per 16384 decodes, profiles/r03b/layered_abl_r03t.txt.)
     for (int it = 0; it < num_iter; ++it) {
       int t = r0;
       int4 cur = recs[t];
@@ -173,8 +176,8 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
         if (kind == LY_BARRIER) {
           // LDS traffic only: wait for this wave's LDS operations, not for its global ones (__syncthreads would also wait
           // for the next record's operands, just requested from L2, and for the fused-column stores - 64 exposed L2
-          // round trips per iteration)
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          // round trips per iteration).  cy = number of barriers in a row (a wave without items in a group)
+          for (int q = 0; q < cy; ++q) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         } else if (kind == LY_CN) {
           const unsigned zq4 = ((unsigned)(cx >> 16) & 0xFFu) * 256u + lane4;      // 4 (64 chunk + lane)
           float* ce = cext + (cw >> 16) * (int)z + (int)(zq4 >> 2);
@@ -379,12 +382,21 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     for (int wv = 0; wv < NW; ++wv) per[wv].push_back({LY_BARRIER, 0, 0, 0});
     rot = (rot + 1) % NW;
   }
+  // SAMD_LY_ABL (development, wrong results): 1 = lists without the VN re-sum items, 2 = without the CN items, 3 = barriers only
+  const int abl = getenv("SAMD_LY_ABL") ? atoi(getenv("SAMD_LY_ABL")) : 0;
   std::vector<int32_t> rec_ptr, recs;
   for (int wv = 0; wv < NW; ++wv) {
     rec_ptr.push_back((int32_t)(recs.size() / 4));
-    for (auto& rc : per[wv]) recs.insert(recs.end(), rc.begin(), rc.end());
-    recs.insert(recs.end(), {LY_END, 0, 0, 0});
-    recs.insert(recs.end(), {LY_END, 0, 0, 0});             // the walker reads one record ahead
+    int last_barrier = -1;                                  // index (in recs) of a barrier record that can take one more
+    for (auto& rc : per[wv]) {
+      const int kind = rc[0] & 0xFF;
+      if ((kind == LY_VN && (abl & 1)) || (kind == LY_CN && (abl & 2))) continue;
+      if (kind == LY_BARRIER && last_barrier >= 0) { ++recs[last_barrier + 1]; continue; }   // barriers in a row: one record
+      if (kind == LY_BARRIER) { last_barrier = (int)recs.size(); recs.insert(recs.end(), {LY_BARRIER, 1, 0, 0}); continue; }
+      last_barrier = -1;
+      recs.insert(recs.end(), rc.begin(), rc.end());
+    }
+    for (int q = 0; q < 4; ++q) recs.insert(recs.end(), {LY_END, 0, 0, 0});   // the walker reads three records ahead
   }
   rec_ptr.push_back((int32_t)(recs.size() / 4));
   h->ly_lds_bytes = (int)lds;
