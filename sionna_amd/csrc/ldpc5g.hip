@@ -538,7 +538,9 @@ extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int
 
 // ---- layered schedule (one sub-iteration per base row) on chip: ldpc5g_onchip_ly.hip
 extern "C" int samd_ldpc5g_decode_layered_supported(const samd_ldpc5g_t* h, int cn_mode) {
-  return (h && h->ly_ok && (cn_mode == SAMD_CN_MINSUM || cn_mode == SAMD_CN_OFFSET_MINSUM) && !getenv("SAMD_NO_ONCHIP_LAYERED")) ? 1 : 0;
+  const bool rule = cn_mode == SAMD_CN_MINSUM || cn_mode == SAMD_CN_OFFSET_MINSUM || cn_mode == SAMD_CN_BOXPLUS_PHI ||
+                    cn_mode == SAMD_CN_BOXPLUS_PHI_FAST;
+  return (h && h->ly_ok && rule && !getenv("SAMD_NO_ONCHIP_LAYERED")) ? 1 : 0;
 }
 
 extern "C" size_t samd_ldpc5g_decode_layered_workspace_bytes(const samd_ldpc5g_t* h, int batch) {

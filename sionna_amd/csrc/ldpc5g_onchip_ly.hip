@@ -61,6 +61,7 @@ __device__ __forceinline__ void ly_cn_row(unsigned a0, unsigned z4, const int32_
   if constexpr (MODE == SAMD_CN_MINSUM) {
     ms_minsum_inplace<D, NCH, 1>(v, llr_max, offset);
   } else {
+    // boxplus rules: bp_math.h's node update on the D messages of a chunk - the function of every other engine
 #pragma unroll
     for (int h = 0; h < NCH; ++h) cn_update_col<MODE, D>(v[h], D, llr_max, 0.f);
   }
@@ -435,11 +436,13 @@ size_t onchip_ly_workspace_bytes(const samd_ldpc5g* h, int batch) {
 
 int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode, float llr_max,
                      float offset, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  if (!h->ly_ok || (cn_mode != SAMD_CN_MINSUM && cn_mode != SAMD_CN_OFFSET_MINSUM)) {
+  const bool minsum = cn_mode == SAMD_CN_MINSUM || cn_mode == SAMD_CN_OFFSET_MINSUM;
+  const bool phi = cn_mode == SAMD_CN_BOXPLUS_PHI || cn_mode == SAMD_CN_BOXPLUS_PHI_FAST;
+  if (!h->ly_ok || !(minsum || phi)) {
     set_error("layered on-chip engine: code or rule not covered (the HBM-resident scheduled engine takes it)");
     return SAMD_ERR_UNSUPPORTED;
   }
-  if (h->max_dc > 27 || !(llr_max >= 0.f) || (double)h->max_dc * 2.0 * (double)llr_max >= 99999.0) {
+  if (minsum && (h->max_dc > 27 || !(llr_max >= 0.f) || (double)h->max_dc * 2.0 * (double)llr_max >= 99999.0)) {
     set_error("code / llr_max outside the on-chip decoder's envelope");
     return SAMD_ERR_UNSUPPORTED;
   }
@@ -451,8 +454,10 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const bool pow2 = (h->z & (h->z - 1)) == 0;
   typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, float, float, int, int, int, int,
                          const int32_t*, const int4*, const int32_t*, const int32_t*, const int32_t*);
-  static const kern_t kerns[2] = {ldpc5g_decode_ly_kernel<false, SAMD_CN_MINSUM>, ldpc5g_decode_ly_kernel<true, SAMD_CN_MINSUM>};
-  const kern_t fn = kerns[pow2 ? 1 : 0];
+  static const kern_t kerns[6] = {ldpc5g_decode_ly_kernel<false, SAMD_CN_MINSUM>, ldpc5g_decode_ly_kernel<true, SAMD_CN_MINSUM>,
+                                  ldpc5g_decode_ly_kernel<false, SAMD_CN_BOXPLUS_PHI>, ldpc5g_decode_ly_kernel<true, SAMD_CN_BOXPLUS_PHI>,
+                                  ldpc5g_decode_ly_kernel<false, SAMD_CN_BOXPLUS_PHI_FAST>, ldpc5g_decode_ly_kernel<true, SAMD_CN_BOXPLUS_PHI_FAST>};
+  const kern_t fn = kerns[(minsum ? 0 : cn_mode == SAMD_CN_BOXPLUS_PHI ? 2 : 4) + (pow2 ? 1 : 0)];
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};

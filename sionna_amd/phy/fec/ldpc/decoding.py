@@ -429,7 +429,7 @@ class LDPC5GDecoder(LDPCBPDecoder):
             if out is not None:
                 return out.reshape(out_shape)
         # cn_schedule="layered" (one sub-iteration per base row): the on-chip layered engine when the code is covered
-        if (self._layered5g and self._onchip_ok and not double and not self._custom and self._cn_mode in (2, 3)
+        if (self._layered5g and self._onchip_ok and not double and not self._custom and self._cn_mode in (1, 2, 3, 4)
                 and not self._return_state and msg_v2c is None and batch > 0):
             out = self._try_onchip_layered(llr2d, num_iter)
             if out is not None:

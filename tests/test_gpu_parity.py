@@ -374,7 +374,7 @@ def test_layered_on_chip_bit_exact(phy, k, n, bg, m):
     u, c, llr = _noisy_llr(code, 6, k + 3 * n, sigma=0.7)
     llr[0, :9] = 0
     llr[1] = np.round(llr[1])
-    for cn in ("minsum", "offset-minsum"):
+    for cn in ("minsum", "offset-minsum", "boxplus-phi"):
         for it, infobits in ((1, True), (3, False)):
             kw = dict(cn_update=cn, cn_schedule="layered", num_iter=it, hard_out=False, return_infobits=infobits)
             dec = phy.fec.ldpc.LDPC5GDecoder(enc, **kw)
