@@ -264,7 +264,10 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // trace of the grouped kernel (tools/ms_itrace.py, profiles/r03b/ms_itrace_r03d.txt): a CN pair item takes
   // 127 d + 1790 cycles, a VN pair item 115 d + 2240, a single-chunk VN item 111 d + 1040 - one chunk has one dependency
   // chain, so its edges cost what a pair's edge PAIRS cost.
-  const int cn_slope = getenv("SAMD_MS_CN_SLOPE") ? atoi(getenv("SAMD_MS_CN_SLOPE")) : 36;   // 18: r02 model; 36: +1.7 % at C2 (profiles/r03b/ms_cost_r03f.txt)
+  // 18: r02 model; 36 for the codes of the grouped kernel: +1.7 % at C2 (profiles/r03b/ms_cost_r03f.txt) - the other
+  // lifting sizes lose 2-3 % with it (profiles/r03b/ldpc_sweep_r03_s36.json vs ..._s18.json)
+  const bool grouped_code = z % 128 == 0 && h->n_cn % z == 0 && h->n_vn % z == 0;
+  const int cn_slope = getenv("SAMD_MS_CN_SLOPE") ? atoi(getenv("SAMD_MS_CN_SLOPE")) : (grouped_code ? 36 : 18);
   const int vn_single = getenv("SAMD_MS_VN_SINGLE") ? atoi(getenv("SAMD_MS_VN_SINGLE")) : 0;   // 1: 10 d + vn_ovh / 2
   // Z not a multiple of 64: the last chunk of a row has `tail` < 64 lifted copies.  With tail <= 32 the tails of
   // 64 / gw rows of the same degree (and fused flag) are packed into one item (lane group g works for row g) - at
