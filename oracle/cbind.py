@@ -26,6 +26,8 @@ def lib():
         _lib.oracle_ldpc_bp_decode.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                                C.c_int, C.c_int]
+        _lib.oracle_ldpc_bp_decode_simd.restype = C.c_int
+        _lib.oracle_ldpc_bp_decode_simd.argtypes = _lib.oracle_ldpc_bp_decode.argtypes
         _lib.oracle_num_threads.restype = C.c_int
         for fn in (_lib.oracle_phi_f32, _lib.oracle_spec_exp_f32, _lib.oracle_spec_log_f32):
             fn.restype = None
@@ -53,9 +55,10 @@ def spec_log_f32(x):
     return _elementwise(lib().oracle_spec_log_f32, x)
 
 
-def bp_decode(dec, llr, num_iter=None, hard_out=None, offset=0.5, nthreads=0):
+def bp_decode(dec, llr, num_iter=None, hard_out=None, offset=0.5, nthreads=0, simd=False):
     """Run the C oracle on the graph of ``dec`` (an oracle.ldpc_bp.LDPCBPDecoder).
-    llr [B, N_vn] logits -> [B, N_vn]."""
+    llr [B, N_vn] logits -> [B, N_vn].  simd=True: the 8-codewords-at-a-time form of the same decoder (bit-identical
+    outputs; bench.py's CPU baseline) - min-sum, offset-min-sum, boxplus-phi."""
     llr = np.ascontiguousarray(llr, np.float32)
     assert llr.ndim == 2 and llr.shape[1] == dec.num_vns
     cn = np.ascontiguousarray(dec.cn_idx, np.int32)
@@ -63,7 +66,8 @@ def bp_decode(dec, llr, num_iter=None, hard_out=None, offset=0.5, nthreads=0):
     out = np.empty_like(llr)
     mode = CN_MODES[[k for k, v in __import__("oracle.ldpc_bp", fromlist=["_CN"])._CN.items()
                      if v is dec._cn_update][0]]
-    rc = lib().oracle_ldpc_bp_decode(dec.num_edges, dec.num_cns, dec.num_vns, cn.ctypes.data, vn.ctypes.data,
+    fn = lib().oracle_ldpc_bp_decode_simd if simd else lib().oracle_ldpc_bp_decode
+    rc = fn(dec.num_edges, dec.num_cns, dec.num_vns, cn.ctypes.data, vn.ctypes.data,
                                      llr.ctypes.data, out.ctypes.data, llr.shape[0],
                                      dec.num_iter if num_iter is None else num_iter, mode, float(dec.llr_max),
                                      float(offset), int(dec.hard_out if hard_out is None else hard_out), nthreads)

@@ -219,6 +219,209 @@ int oracle_ldpc_bp_decode(int E, int N_cn, int N_vn, const int* cn_idx, const in
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * The same decoder, W codewords at a time (bench.py's CPU baseline since round 3; the scalar function above stays the
+ * checker).  Round 2's baseline was the scalar loop - 8 codewords/s per thread - which made the GPU / CPU ratio soft.
+ * Here the messages of W = 8 codewords sit side by side (msg[e][W]) and every node update is a loop over the W lanes
+ * that gcc vectorises (-O3 -mavx2 -mfma); each lane executes the scalar function's operations in the scalar function's
+ * order, so the outputs are bit-identical (tests/test_oracle_pins.py).  exp / log of the boxplus-phi rule use the
+ * integer forms of frexp / ldexp / floor, which equal the library forms on the clipped domain (normal positive
+ * arguments, 0 <= m <= 24).  min-sum, offset-min-sum and boxplus-phi; the tanh rule stays scalar. */
+#define SW 8
+/* min / max / clamp as comparisons + selects (vminps / vmaxps / blends): fminf / fmaxf are library calls under
+ * -fno-fast-math and keep the lane loops scalar; for the values of this decoder (no NaN; magnitudes are never -0) both
+ * forms return the same bits */
+static inline float vminf(float a, float b) { return a < b ? a : b; }
+static inline float vmaxf(float a, float b) { return a > b ? a : b; }
+static inline float vclampf(float x, float lo, float hi) { return vminf(vmaxf(x, lo), hi); }
+static inline float spec_expf_v(float x) {
+  const float m = (float)(int)fmaf(x, 1.44269504088896341f, 0.5f);          /* floor of a non-negative number */
+  float r = fmaf(m, -0.693359375f, x);
+  float y = 1.9875691500E-4f, z;
+  union { float f; int i; } u;
+  r = fmaf(m, 2.12194440e-4f, r);
+  z = r * r;
+  y = fmaf(y, r, 1.3981999507E-3f);
+  y = fmaf(y, r, 8.3334519073E-3f);
+  y = fmaf(y, r, 4.1665795894E-2f);
+  y = fmaf(y, r, 1.6666665459E-1f);
+  y = fmaf(y, r, 5.0000001201E-1f);
+  y = fmaf(y, z, r);
+  u.f = y + 1.0f;
+  u.i += ((int)m) << 23;                                                       /* ldexp(y, m): exponent field + m */
+  return u.f;
+}
+static inline float spec_logf_v(float x) {
+  union { float f; int i; } u;
+  float f, ef, x2, x3, y, y1, y2, tmp, dec;
+  u.f = x;
+  ef = (float)(((u.i >> 23) & 0xff) - 126);                                    /* frexp: x = f 2^e, f in [0.5, 1) */
+  u.i = (u.i & 0x007fffff) | 0x3f000000;
+  f = u.f;
+  tmp = (f < 0.707106781186547524f) ? f : 0.f;
+  dec = (f < 0.707106781186547524f) ? 1.0f : 0.f;
+  f = f - 1.0f;
+  ef = ef - dec;
+  f = f + tmp;
+  x2 = f * f;
+  x3 = x2 * f;
+  y = fmaf(7.0376836292E-2f, f, -1.1514610310E-1f);
+  y1 = fmaf(-1.2420140846E-1f, f, 1.4249322787E-1f);
+  y2 = fmaf(2.0000714765E-1f, f, -2.4999993993E-1f);
+  y = fmaf(y, f, 1.1676998740E-1f);
+  y1 = fmaf(y1, f, -1.6668057665E-1f);
+  y2 = fmaf(y2, f, 3.3333331174E-1f);
+  y = fmaf(y, x3, y1);
+  y = fmaf(y, x3, y2);
+  y = y * x3;
+  y = fmaf(-0.5f, x2, y);
+  f = f + y;
+  return fmaf(ef, 0.69314718055994530942f, f);
+}
+static inline float phi_v(float x) {
+  float e;
+  x = vclampf(x, 8.5e-8f, 16.635532f);
+  e = spec_expf_v(x);
+  return spec_logf_v(e + 1.f) - spec_logf_v(e - 1.f);
+}
+
+/* node update of one check node for SW codewords: v / sg [d][SW] */
+static void cn_update_w(float* v, float* sg, int d, int mode, float llr_max, float offset) {
+  int i, j;
+  if (mode == 2 || mode == 3) {
+    float node_sign[SW], min1[SW], min2[SW], node_sum[SW];
+    if (mode == 2) offset = 0.f;
+    for (j = 0; j < SW; ++j) { node_sign[j] = 1.f; min1[j] = INFINITY; min2[j] = INFINITY; node_sum[j] = 0.f; }
+    for (i = 0; i < d; ++i)
+#pragma omp simd
+      for (j = 0; j < SW; ++j) {
+        const float x = vclampf(v[i * SW + j], -LARGE_VAL, LARGE_VAL);
+        const float s = x < 0.f ? -1.f : 1.f;
+        sg[i * SW + j] = s;
+        node_sign[j] *= s;
+        v[i * SW + j] = fabsf(x);
+        min1[j] = vminf(min1[j], fabsf(x));
+      }
+    for (i = 0; i < d; ++i)
+#pragma omp simd
+      for (j = 0; j < SW; ++j) {
+        const float t = v[i * SW + j] - min1[j];
+        const float r = (t == 0.f) ? LARGE_VAL : t;
+        v[i * SW + j] = r;
+        min2[j] = vminf(min2[j], r);
+        node_sum[j] += r;
+      }
+    for (i = 0; i < d; ++i)
+#pragma omp simd
+      for (j = 0; j < SW; ++j) {
+        const float ns = node_sum[j] - (2.f * LARGE_VAL - 1.f);
+        const float sg3 = ns > 0.f ? 1.f : (ns < 0.f ? -1.f : 0.f);
+        const float dm = 0.5f * (1.f - sg3);
+        const float min_e = (1.f - dm) * min1[j] + dm * (min2[j] + min1[j]);
+        float m = (v[i * SW + j] == LARGE_VAL) ? min_e : min1[j];
+        m = vmaxf(m - offset, 0.f);
+        v[i * SW + j] = vclampf((sg[i * SW + j] * node_sign[j]) * m, -llr_max, llr_max);
+      }
+  } else {
+    float node_sign[SW], sum[SW];
+    for (j = 0; j < SW; ++j) { node_sign[j] = 1.f; sum[j] = 0.f; }
+    for (i = 0; i < d; ++i)
+#pragma omp simd
+      for (j = 0; j < SW; ++j) {
+        const float x = v[i * SW + j];
+        const float s = x < 0.f ? -1.f : 1.f;
+        const float ph = phi_v(fabsf(x));
+        sg[i * SW + j] = s;
+        node_sign[j] *= s;
+        v[i * SW + j] = ph;
+        sum[j] += ph;
+      }
+    for (i = 0; i < d; ++i)
+#pragma omp simd
+      for (j = 0; j < SW; ++j) {
+        const float e = -1.f * v[i * SW + j] + sum[j];
+        v[i * SW + j] = vclampf((sg[i * SW + j] * node_sign[j]) * phi_v(e), -llr_max, llr_max);
+      }
+  }
+}
+
+int oracle_ldpc_bp_decode_simd(int E, int N_cn, int N_vn, const int* cn_idx, const int* vn_idx, const float* llr,
+                               float* out, int B, int num_iter, int cn_mode, float llr_max, float offset, int hard_out,
+                               int nthreads) {
+  graph_t g;
+  int e, c, v, max_dc = 0, groups = (B + SW - 1) / SW;
+  int* fill;
+  if (cn_mode < 1 || cn_mode > 3) return -2;
+  g.E = E; g.N_cn = N_cn; g.N_vn = N_vn;
+  g.cn_ptr = (int*)calloc((size_t)N_cn + 1, sizeof(int));
+  g.vn_ptr = (int*)calloc((size_t)N_vn + 1, sizeof(int));
+  g.cn_edge = (int*)malloc((size_t)E * sizeof(int));
+  fill = (int*)malloc((size_t)N_cn * sizeof(int));
+  if (!g.cn_ptr || !g.vn_ptr || !g.cn_edge || !fill) return -1;
+  for (e = 0; e < E; ++e) { g.cn_ptr[cn_idx[e] + 1]++; g.vn_ptr[vn_idx[e] + 1]++; }
+  for (c = 0; c < N_cn; ++c) { if (g.cn_ptr[c + 1] > max_dc) max_dc = g.cn_ptr[c + 1]; g.cn_ptr[c + 1] += g.cn_ptr[c]; }
+  for (v = 0; v < N_vn; ++v) g.vn_ptr[v + 1] += g.vn_ptr[v];
+  memcpy(fill, g.cn_ptr, (size_t)N_cn * sizeof(int));
+  for (e = 0; e < E; ++e) g.cn_edge[fill[cn_idx[e]]++] = e;
+  free(fill);
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+  {
+    float* msg = (float*)aligned_alloc(64, (size_t)E * SW * sizeof(float));
+    float* l = (float*)aligned_alloc(64, (size_t)N_vn * SW * sizeof(float));
+    float* xh = (float*)aligned_alloc(64, (size_t)N_vn * SW * sizeof(float));
+    float* tmp = (float*)aligned_alloc(64, (size_t)(max_dc > 0 ? max_dc : 1) * SW * sizeof(float));
+    float* sg = (float*)aligned_alloc(64, (size_t)(max_dc > 0 ? max_dc : 1) * SW * sizeof(float));
+    int gi;
+#pragma omp for schedule(dynamic, 1)
+    for (gi = 0; gi < groups; ++gi) {
+      int it, i, j, cc, vv;
+      for (vv = 0; vv < N_vn; ++vv)
+        for (j = 0; j < SW; ++j) {
+          const int b = gi * SW + j;
+          const float in = b < B ? llr[(size_t)b * N_vn + vv] : 0.f;
+          l[vv * SW + j] = -1.f * vclampf(in, -llr_max, llr_max);
+          xh[vv * SW + j] = l[vv * SW + j];
+        }
+      for (i = 0; i < E; ++i)
+        for (j = 0; j < SW; ++j) msg[i * SW + j] = l[vn_idx[i] * SW + j];
+      for (it = 0; it < num_iter; ++it) {
+        for (cc = 0; cc < N_cn; ++cc) {
+          const int e0 = g.cn_ptr[cc], d = g.cn_ptr[cc + 1] - e0;
+          for (i = 0; i < d; ++i) memcpy(tmp + i * SW, msg + (size_t)g.cn_edge[e0 + i] * SW, SW * sizeof(float));
+          cn_update_w(tmp, sg, d, cn_mode, llr_max, offset);
+          for (i = 0; i < d; ++i) memcpy(msg + (size_t)g.cn_edge[e0 + i] * SW, tmp + i * SW, SW * sizeof(float));
+        }
+        for (vv = 0; vv < N_vn; ++vv) {
+          const int e0 = g.vn_ptr[vv], e1 = g.vn_ptr[vv + 1];
+          float x[SW];
+          for (j = 0; j < SW; ++j) x[j] = 0.f;
+          for (i = e0; i < e1; ++i)
+#pragma omp simd
+            for (j = 0; j < SW; ++j) x[j] += msg[i * SW + j];
+#pragma omp simd
+          for (j = 0; j < SW; ++j) x[j] += l[vv * SW + j];
+          for (i = e0; i < e1; ++i)
+#pragma omp simd
+            for (j = 0; j < SW; ++j) msg[i * SW + j] = vclampf(-1.f * msg[i * SW + j] + x[j], -llr_max, llr_max);
+#pragma omp simd
+          for (j = 0; j < SW; ++j) xh[vv * SW + j] = vclampf(x[j], -llr_max, llr_max);
+        }
+      }
+      for (vv = 0; vv < N_vn; ++vv)
+        for (j = 0; j < SW; ++j) {
+          const int b = gi * SW + j;
+          if (b < B) out[(size_t)b * N_vn + vv] = hard_out ? ((0.f >= xh[vv * SW + j]) ? 1.f : 0.f) : -1.f * xh[vv * SW + j];
+        }
+    }
+    free(msg); free(l); free(xh); free(tmp); free(sg);
+  }
+  free(g.cn_ptr); free(g.vn_ptr); free(g.cn_edge);
+  return 0;
+}
+
 int oracle_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

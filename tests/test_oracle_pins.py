@@ -112,3 +112,16 @@ def test_phi_spec_exp_log_accuracy_and_endpoints():
     assert ends[0] == 0 and ends[1] == 0 and ends[2] == np.float32(16.635532) and ends[3] == np.float32(16.635532) and ends[4] == 0
     xs = np.linspace(0.05, 6, 2000).astype(np.float32)
     assert np.allclose(cbind.phi_f32(xs), -np.log(np.tanh(xs.astype(np.float64) / 2)), rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,n,m,bg,batch,iters,ebno", [(1024, 2048, 2, "bg1", 19, 10, 1.5), (2816, 8448, 6, "bg1", 9, 20, 4.5)])
+def test_simd_c_baseline_equals_scalar_c_oracle(k, n, m, bg, batch, iters, ebno):
+    """bench.py's CPU baseline (8 codewords per vector, oracle_ldpc_bp_decode_simd) returns the scalar C oracle's soft
+    outputs bit for bit for the three rules it covers, batches that are not multiples of 8 included."""
+    code = LDPC5GCode(k, n, m, bg)
+    u, llr = _noisy_llr(code, m, batch, ebno, k + 1)
+    for cn in ("minsum", "offset-minsum", "boxplus-phi"):
+        dec = bp.LDPC5GDecoder(code, cn_update=cn, num_iter=iters, hard_out=False)
+        llr_full = dec.rate_recover(llr)
+        assert np.array_equal(cbind.bp_decode(dec, llr_full, simd=True), cbind.bp_decode(dec, llr_full)), cn
+        assert np.array_equal(cbind.bp_decode(dec, llr_full, simd=True, hard_out=True), cbind.bp_decode(dec, llr_full, hard_out=True))
