@@ -174,6 +174,9 @@ def self_launch(n_gpus):
         sys.exit(2)
     argv = self_launch_argv(n_gpus)
     sys.stdout.flush()
+    os.environ["SAMD_BENCH_CHILD"] = "1"    # the ranks must not launch again (e.g. a launcher that gave them WORLD_SIZE=1)
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k_, None)
     os.execv(sys.executable, argv)
 
 
@@ -495,8 +498,8 @@ def main():
         return print(json.dumps(bench_c5(args)))
 
     world, rank, local_rank = world_info()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return self_launch(args.gpus)       # not started as a rank: become the launcher of N ranks (never returns)
+    if args.gpus > 1 and world == 1 and not os.environ.get("SAMD_BENCH_CHILD"):
+        return self_launch(args.gpus)       # not started as one of N ranks: become the launcher of N ranks (never returns)
     import torch.distributed as dist
     # SAMD_BENCH_BACKEND=gloo: code-path check of the N>1 logic on a box with fewer GPUs than ranks
     # (ranks then share devices); the driver's runs use the default, RCCL.
