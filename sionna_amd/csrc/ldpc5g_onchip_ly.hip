@@ -2,7 +2,7 @@
 //
 // Replaces LDPC5GDecoder(cn_schedule="layered").call (reference src/sionna/phy/fec/ldpc/decoding.py:1383-1389: one
 // sub-iteration per base row = Z check nodes; _bp_iter with an array schedule :463-520: check-node update of the layer,
-// then the variable-node update) for the codes of the explicit-message engine's grouped kernel (Z a multiple of 128, no
+// then the variable-node update) for codes like those of the explicit-message engine's grouped kernel (Z a multiple of 64, no
 // partially pruned base row, messages in LDS).  Until round 3 the schedule ran on the HBM-resident engine with two
 // launches per layer: 920 launches and 79 k decodes/s for 10 iterations at config C2.
 //
@@ -250,7 +250,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   h->ly_ok = 0;
   const int z = h->z, NW = 16;
   const int ncu = (h->n_cn + z - 1) / z, nbu = (h->n_vn + z - 1) / z;
-  if (z % 128 != 0 || h->n_cn % z != 0 || h->n_vn % z != 0 || h->mb > 255 || h->nb > 255 || nbu > 0xFFFF) return SAMD_OK;
+  if (z % 64 != 0 || h->n_cn % z != 0 || h->n_vn % z != 0 || h->mb > 255 || h->nb > 255 || nbu > 0xFFFF) return SAMD_OK;
   static const int degs[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
   std::vector<int> col_deg(h->nb, 0);
   for (int r = 0; r < ncu; ++r)
@@ -335,12 +335,12 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     for (size_t j = 0; j < g.size(); ++j) {
       const int r = g[j], d = (int)by_row[r].size(), f = fused_col[r] >= 0;
       const int32_t wcol = f ? (fused_col[r] | (ext_of_row[r] << 16)) : 0;
-      for (int q = 0; q < z / 64; q += 2) {
-        if (cn_split) {
+      for (int q = 0; q < z / 64; ++q) {
+        if (cn_split || q + 1 >= z / 64) {                    // (an odd last chunk is a single-chunk item in any case)
           per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | (q << 16), row_off[r], row_start[r], wcol});
-          per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | ((q + 1) << 16), row_off[r], row_start[r], wcol});
         } else {
           per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | (1 << 14) | (q << 16), row_off[r], row_start[r], wcol});
+          ++q;
         }
       }
     }
@@ -363,7 +363,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
         seen[c] = 1;
         const int dg = col_deg[c], chunks = z / 64;
         for (int q = 0; q < chunks; ++q) {
-          const bool pair = dg <= 12 && !all_single;
+          const bool pair = dg <= 12 && !all_single && q + 1 < chunks;
           items.push_back({(pair ? 10 : 10) * dg + (pair ? 200 : 100),
                            {LY_VN | ((dg | ((pair ? 1 : 0) << 5)) << 8) | (q << 16), xt_base + xt_of_col[c] * z * 4, col_start[c], c * z + q * 64}});
           if (pair) ++q;
