@@ -11,106 +11,154 @@
 //                     lifted copy - the message a check node SENT last; it stays until the row's next update
 //         xtot[c][z]  the unclipped total of every variable node of a non-fused column (sum of its c2v in ascending
 //                     check-node order, channel LLR last - vn_update_sum, decoding.py:681-732)
-//   L2 workspace row  channel LLRs of all columns, and cext[r][z]: the c2v of a row's fused edge (the degree-1 column of
-//                     the base graph's extension part, private to its row)
+//   VGPRs of the wave that OWNS an item (the item -> wave map is the same in every iteration):
+//         check-node item (row, chunk) with a fused edge: the c2v of that edge (the degree-1 column of the base graph's
+//                     extension part, private to its row) and the channel LLR of its variable node
+//         variable-node unit (column, chunk): the channel LLRs and the PREFIX of the running total - the sum of the
+//                     column's messages whose rows were already updated in this iteration, in check-node order
+//   L2 workspace row  channel LLRs of all columns (read once per codeword into the owners' registers, and by the
+//                     output phase) and the final c2v of the fused edges (written once for the output phase)
 // v2c messages are never stored: v2c_e = clip(xtot[v] - c2v_e) is what the reference's variable-node update leaves on an
 // edge (decoding.py:724-731), recomputed when the row is updated.  After a layer, the reference updates EVERY variable
 // node; only the nodes of the layer's columns see a changed input, so re-summing those - all their edges, in the defined
 // order - gives the same bits (min-sum: bit-identical to oracle/ldpc_bp.py's literal form; boxplus rules: same function).
+// Rows are updated in ascending order, so the messages of a column's edges ABOVE the updated row are final for this
+// iteration: their left-to-right sum (the prefix) is kept, and a re-sum is prefix + new message + the edges below + LLR -
+// the same additions in the same order as summing everything again, half the LDS reads on average.
 // Consecutive base rows that share no column are one group (BG1: 32 groups instead of 46 layers): their updates commute.
 //
-// Every wave walks a linear record list built on the host: CN items (row, both 64-lane chunks), a workgroup barrier, VN
-// re-sum items (column; pairs of chunks for degree <= 12), a barrier, next group.  The operands a record needs from the
-// L2 workspace (fused state, channel LLRs) are requested while the previous record runs.
+// Every wave walks a linear record list built on the host: its CN items of the group (one 64-lane chunk of a row), a
+// workgroup barrier, its VN re-sum items (column; pairs of chunks for degree <= 12), a barrier, next group.  No global
+// memory operand inside the iteration loop: until round 3x the fused state and the channel LLRs came from the L2
+// workspace one record ahead, and every record then lasted at least one L2 round trip (~1.6 k cycles measured per item,
+// profiles/r03b/ly_itrace_r03x.txt, against ~30 cycles per edge of actual work).
 #include <array>
 #include "ldpc5g_onchip_ms.inc"
 
 namespace samd {
 
-enum { LY_END = 0, LY_BARRIER = 1, LY_CN = 2, LY_VN = 3 };
+// A record = one body (or none) followed by `nb` workgroup barriers.  Word x: bits 0-1 body kind, 2-7 body key (CN: row
+// degree | fused << 5; VN: reads / 4 | pair << 4), 8-13 nb, 14 VN `first`, 15 last record of the list, 16-23 chunk;
+// y: LDS byte offset (row block / xtot block); z: byte offset of the body's (byte offset, 4 shift) entries in the entry
+// table; w: where the item's private state sits in the wave's register file.  One record per step and wave instead of
+// separate item and barrier records: a lone wave issues an instruction every 6-7 cycles (the other 15 wait at the
+// barrier), so a record costs what its instruction count says - the walker's share is ~60 instructions.
+enum { LY_NOP = 0, LY_CN = 2, LY_VN = 3, LY_LAST = 1 << 15, LY_MAX_NB = 63 };
 
-// check nodes (row r, lifted copies lane and lane + 64): D edges, the last one fused when F.
-// ent: (byte offset of the column's xtot block, 4 shift) per non-fused edge; a0 = row block byte offset + 4 lane
-// NCH = 2: both 64-lane chunks in one item (two dependency chains per wave); NCH = 1: one chunk - the row's two chunks
-// then run on two waves side by side (the check-node update of a layer is the serial part of a group)
-template <int D, bool F, bool POW2, int MODE, int NCH>
-__device__ __forceinline__ void ly_cn_row(unsigned a0, unsigned z4, const int32_t* __restrict__ ent, unsigned lane4,
-                                          unsigned zwv, float llr_max, float offset, float* __restrict__ cext,
-                                          float co0, float co1, float lf0, float lf1) {
+#ifdef SAMD_LY_TRACE
+// Development aid (tools/ly_itrace.py, `make -C sionna_amd/csrc lytrace`; not part of the product build): iteration 3 of
+// workgroup 0, per wave one (record word, s_memtime) pair at the start of every record and one at the end of the list.
+__device__ unsigned long long* g_ly_trace = nullptr;
+__device__ unsigned long long* g_ly_sub = nullptr;      // 4 times inside the item that precedes a 0xF0 record
+#define SAMD_LY_MARK(tag)                                                                                  \
+  if (g_ly_trace && blockIdx.x == 0 && it == 3 && lane == 0 && tr_slot < 512) {                              \
+    g_ly_trace[(w * 512 + tr_slot) * 2] = (unsigned long long)(unsigned)(tag);                               \
+    g_ly_trace[(w * 512 + tr_slot) * 2 + 1] = __builtin_readcyclecounter();                                  \
+    ++tr_slot;                                                                                             \
+  }
+#define SAMD_LY_SUB(i) tm[i] = __builtin_readcyclecounter();
+#else
+#define SAMD_LY_MARK(tag)
+#define SAMD_LY_SUB(i)
+#endif
+
+// per-wave register file of the items' private state: [0, 8) c2v of the fused edge of the wave's CN items, [8, 16) channel
+// LLR of their degree-1 nodes, [16, 24) prefixes of the wave's VN units, [24, 32) their channel LLRs.  One 32-wide vector:
+// a dynamic (wave-uniform) index becomes s_set_gpr_idx / v_mov, 3 instructions, where four 8-wide vectors became chains
+// of 8 compares + 8 v_cndmask per access (~70 instructions in front of every re-sum body).
+typedef float ly_f32x32 __attribute__((ext_vector_type(32)));
+enum { LY_CN_SLOTS = 8, LY_VN_SLOTS = 8, LY_SLOT_INTS = 2 * LY_CN_SLOTS + LY_VN_SLOTS };
+enum { LY_ST_CO = 0, LY_ST_LF = 8, LY_ST_P = 16, LY_ST_L = 24 };
+
+// One record of a wave's list = 4 dwords (x, LDS byte offset, offset of the body's entries in the entry table, extra);
+// the (byte offset, 4 shift) entries of a body come from ONE table shared by all records: a row's list, or a column's
+// list from edge j on.  Records (~450 x 16 B per iteration at C2) + table (~5 KB) stay in the 16 KB scalar data cache.
+// (Records with their entries inline - one 64-byte line per record, one s_load_dwordx16 a record ahead - were tried:
+// 110 KB per iteration stream through the scalar cache, every record load is a miss, and since scalar loads return
+// out of order the body's first LDS wait (lgkmcnt(0)) waits for that miss: ~1 k cycles per record whatever its size,
+// profiles/r03b/layered_abl_r03zb.txt.)
+#define LY_ENT(i, k) ent[2 * (i) + (k)]
+
+// check nodes (row r, lifted copies 64 chunk + lane): D edges, the last one fused when F.
+// entries: (byte offset of the column's xtot block, 4 shift) per non-fused edge; a0 = row block byte offset + 4 (64 chunk + lane)
+// co: c2v of the fused edge (in: the one sent last, out: the new one), lf: channel LLR of the fused degree-1 node
+template <int D, bool F, bool POW2, int MODE>
+__device__ __forceinline__ void ly_cn_row(unsigned a0, unsigned z4, const int32_t* __restrict__ ent, unsigned lane4, unsigned zwv, float llr_max, float offset, float& co, float lf,
+                                          [[maybe_unused]] unsigned long long* tm) {
   constexpr int NF = F ? D - 1 : D;
-  float v[NCH][D];
-  float co[2] = {co0, co1};
+  float v[1][D];
+  SAMD_LY_SUB(0)
 #pragma unroll
   for (int i = 0; i < NF; ++i) {
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      const unsigned t = lane4 + 256u * h + (unsigned)ent[2 * i + 1];
-      const unsigned ax = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t - zwv) + (unsigned)ent[2 * i]);
-      const float x = lds_ld(ax);
-      const float c = lds_ld(a0 + (unsigned)i * z4 + 256u * h);
-      v[h][i] = ms_med3(x - c, -llr_max, llr_max);                     // the v2c the last variable-node update left
-    }
+    const unsigned t = lane4 + (unsigned)LY_ENT(i, 1);
+    const unsigned ax = POW2 ? ((t & zwv) | (unsigned)LY_ENT(i, 0)) : (min(t, t - zwv) + (unsigned)LY_ENT(i, 0));
+    const float x = lds_ld(ax);
+    const float c = lds_ld(a0 + (unsigned)i * z4);
+    v[0][i] = ms_med3(x - c, -llr_max, llr_max);                       // the v2c the last variable-node update left
   }
   if constexpr (F) {
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      const float x = co[h] + (h ? lf1 : lf0);                          // (0 + c2v) + llr of the degree-1 node
-      v[h][D - 1] = ms_med3(x - co[h], -llr_max, llr_max);
-    }
+    const float x = co + lf;                                            // (0 + c2v) + llr of the degree-1 node
+    v[0][D - 1] = ms_med3(x - co, -llr_max, llr_max);
   }
+  SAMD_LY_SUB(1)
   if constexpr (MODE == SAMD_CN_MINSUM) {
-    ms_minsum_inplace<D, NCH, 1>(v, llr_max, offset);
+    ms_minsum_inplace<D, 1, 1>(v, llr_max, offset);
   } else {
     // boxplus rules: bp_math.h's node update on the D messages of a chunk - the function of every other engine
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) cn_update_col<MODE, D>(v[h], D, llr_max, 0.f);
+    cn_update_col<MODE, D>(v[0], D, llr_max, 0.f);
   }
+  SAMD_LY_SUB(2)
 #pragma unroll
-  for (int i = 0; i < NF; ++i)
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) lds_st(a0 + (unsigned)i * z4 + 256u * h, v[h][i]);
-  if constexpr (F) {
-    cext[0] = v[0][D - 1];
-    if constexpr (NCH == 2) cext[64] = v[1][D - 1];
-  }
+  for (int i = 0; i < NF; ++i) lds_st(a0 + (unsigned)i * z4, v[0][i]);
+  if constexpr (F) co = v[0][D - 1];
+  SAMD_LY_SUB(3)
 }
 
-// variable nodes of column c (lifted copies of chunk(s)): re-sum of all D messages + channel LLR -> xtot.
-// ent: (edge block byte offset, 4 shift) per edge, rows ascending; ax = byte address of xtot[c][64 chunk + lane]
-template <int D, int NCH, bool POW2>
-__device__ __forceinline__ void ly_vn_col(const int32_t* __restrict__ ent, unsigned zz4, unsigned zwv, unsigned ax,
-                                          float l0, float l1) {
-  float c[NCH][D];
+// variable nodes of column c (lifted copies of chunk(s)) after the update of the row of its edge j: 1 + the number of
+// edges below j reads, padded to NL (a multiple of 4) with entries that point at a block of zeros (x + 0 = x exactly,
+// and no total is ever -0) - few bodies, hence a shallow dispatch tree.  entries: (edge block byte offset, 4 shift) of
+// edge j and the edges below it, rows ascending; ax = byte address of xtot[c][64 chunk + lane]; p = prefix (sum of the
+// edges above j; 0 when j is the column's first edge), l = channel LLR (added last)
+template <int NL, int NCH, bool POW2>
+__device__ __forceinline__ void ly_vn_col(const int32_t* __restrict__ ent, unsigned zz4, unsigned zwv, unsigned ax, float& p0, float& p1, float l0, float l1,
+                                          [[maybe_unused]] unsigned long long* tm) {
+  float c[NCH][NL];
+  SAMD_LY_SUB(0)
 #pragma unroll
-  for (int i = 0; i < D; ++i)
+  for (int i = 0; i < NL; ++i)
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      const unsigned t = zz4 + 256u * h - (unsigned)ent[2 * i + 1];
-      const unsigned a = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t + zwv) + (unsigned)ent[2 * i]);
+      const unsigned t = zz4 + 256u * h - (unsigned)LY_ENT(i, 1);
+      const unsigned a = POW2 ? ((t & zwv) | (unsigned)LY_ENT(i, 0)) : (min(t, t + zwv) + (unsigned)LY_ENT(i, 0));
       c[h][i] = lds_ld(a);
     }
+  SAMD_LY_SUB(1)
   if constexpr (NCH == 2) {
-    ms_f32x2 xv = {0.f, 0.f};
+    ms_f32x2 xv = ms_f32x2{p0, p1} + ms_f32x2{c[0][0], c[1][0]};
+    p0 = xv.x;
+    p1 = xv.y;
 #pragma unroll
-    for (int i = 0; i < D; ++i) xv += ms_f32x2{c[0][i], c[1][i]};
+    for (int i = 1; i < NL; ++i) xv += ms_f32x2{c[0][i], c[1][i]};
     xv += ms_f32x2{l0, l1};
     lds_st(ax, xv.x);
     lds_st(ax + 256u, xv.y);
   } else {
-    float x = 0.f;
+    float x = p0 + c[0][0];
+    p0 = x;
 #pragma unroll
-    for (int i = 0; i < D; ++i) x += c[0][i];
+    for (int i = 1; i < NL; ++i) x += c[0][i];
     x += l0;
     lds_st(ax, x);
   }
+  SAMD_LY_SUB(3)
 }
 
 template <bool POW2, int MODE>
 __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ ws, RateMatch p, int nbu, int batch,
     int num_iter, float llr_max, float offset, int hard_out, int return_infobits, int msg_floats, int n_ext,
-    const int32_t* __restrict__ rec_ptr, const int4* __restrict__ recs, const int32_t* __restrict__ row_ent,
-    const int32_t* __restrict__ col_ent, const int32_t* __restrict__ xt_index) {
+    int zero_off, const int32_t* __restrict__ rec_ptr, const int4* __restrict__ recs, const int32_t* __restrict__ ent_tab,
+    const int32_t* __restrict__ xt_index, const int32_t* __restrict__ slot_tab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((unsigned)(size_t)(lds_f32*)smem != 0u) __builtin_trap();      // LDS addressed by plain byte offsets (lds_ld)
   constexpr int NT = 1024;
@@ -126,6 +174,7 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
   const unsigned lane4 = 4u * (unsigned)lane;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = rec_ptr[w];
+  const int32_t* slots = slot_tab + w * LY_SLOT_INTS;
 
   for (int b = blockIdx.x; b < batch; b += gridDim.x) {
     const float* row = llr_in + (size_t)b * p.n;
@@ -137,55 +186,61 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
       if (xi >= 0) xtot[xi * (int)z + v % (int)z] = l;                 // total of a node without messages = its LLR
     }
     for (int i = tid; i < msg_floats; i += NT) smem[i] = 0.f;
-    for (int i = tid; i < n_ext * (int)z; i += NT) cext[i] = 0.f;
+    for (int i = tid; i < (int)z; i += NT) smem[zero_off + i] = 0.f;   // the block the padded re-sum entries read
     __syncthreads();
+    // the registers of the items this wave owns: channel LLRs; c2v of the fused edges and the prefixes start at 0
+    ly_f32x32 st;
+#pragma unroll
+    for (int q = 0; q < LY_CN_SLOTS; ++q) {
+      const int li = slots[q];
+      st[LY_ST_CO + q] = 0.f;
+      st[LY_ST_LF + q] = (li >= 0) ? llr[li + lane] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < LY_VN_SLOTS; ++q) {
+      const int li = slots[2 * LY_CN_SLOTS + q];
+      st[LY_ST_P + q] = 0.f;
+      st[LY_ST_L + q] = (li >= 0) ? llr[li + lane] : 0.f;
+    }
 
-    // Records are wave-uniform: scalar loads, one record ahead.  (Vector loads three ahead were tried: they share the
-    // in-order vmcnt counter with the fused-column stores, so waiting for a record meant waiting for those stores to
-    // reach L2 - 47.1 instead of 44.4 ms per 16384 decodes, profiles/r03b/layered_abl_r03t.txt.)
+    // Records are wave-uniform: scalar loads, one record ahead.
     for (int it = 0; it < num_iter; ++it) {
-      int t = r0;
-      int4 cur = recs[t];
-      float pa0 = 0.f, pa1 = 0.f, pb0 = 0.f, pb1 = 0.f;                // prefetched operands of `cur`
-      auto fetch = [&](int4 rc, float& a0, float& a1, float& b0, float& b1) __attribute__((always_inline)) {
-        const int kind = __builtin_amdgcn_readfirstlane(rc.x) & 0xFF;
-        const int wv = __builtin_amdgcn_readfirstlane(rc.w);
-        if (kind == LY_CN) {
-          const int rx = __builtin_amdgcn_readfirstlane(rc.x);
-          if ((rx >> 13) & 1) {                                         // fused: c2v of the fused edge, its channel LLR
-            const int q64 = ((rx >> 16) & 0xFF) * 64;
-            const float* ce = cext + (wv >> 16) * (int)z + q64 + lane;
-            const float* le = llr + (wv & 0xFFFF) * (int)z + q64 + lane;
-            a0 = ce[0]; b0 = le[0];
-            if ((rx >> 14) & 1) { a1 = ce[64]; b1 = le[64]; }
-          }
-        } else if (kind == LY_VN) {
-          a0 = llr[wv + lane];
-          if ((__builtin_amdgcn_readfirstlane(rc.x) >> 13) & 1) a1 = llr[wv + lane + 64];
-        }
-      };
-      fetch(cur, pa0, pa1, pb0, pb1);
+      const int4* rp = recs + r0;
+      [[maybe_unused]] int tr_slot = 0;
+      int4 cur = rp[0];
       for (;;) {
-        const int cx = __builtin_amdgcn_readfirstlane(cur.x);
-        const int kind = cx & 0xFF;
-        if (kind == LY_END) break;
-        const int4 nxt = recs[t + 1];
-        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-        fetch(nxt, na0, na1, nb0, nb1);
-        const int cy = __builtin_amdgcn_readfirstlane(cur.y), cz = __builtin_amdgcn_readfirstlane(cur.z);
-        const int cw = __builtin_amdgcn_readfirstlane(cur.w);
-        if (kind == LY_BARRIER) {
-          // LDS traffic only: wait for this wave's LDS operations, not for its global ones (__syncthreads would also wait
-          // for the next record's operands, just requested from L2, and for the fused-column stores - 64 exposed L2
-          // round trips per iteration).  cy = number of barriers in a row (a wave without items in a group)
-          for (int q = 0; q < cy; ++q) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        } else if (kind == LY_CN) {
-          const unsigned zq4 = ((unsigned)(cx >> 16) & 0xFFu) * 256u + lane4;      // 4 (64 chunk + lane)
-          float* ce = cext + (cw >> 16) * (int)z + (int)(zq4 >> 2);
-#define SAMD_LY_CN(KEY, D, F)                                                                                          \
-  case KEY: ly_cn_row<D, F, POW2, MODE, 2>((unsigned)cy + zq4, z4, row_ent + cz, zq4, zwv, llr_max, offset, ce, pa0, pa1, pb0, pb1); break; \
-  case 64 + KEY: ly_cn_row<D, F, POW2, MODE, 1>((unsigned)cy + zq4, z4, row_ent + cz, zq4, zwv, llr_max, offset, ce, pa0, pa1, pb0, pb1); break;
-          switch (((cx >> 8) & 63) | (((cx >> 14) & 1) ? 0 : 64)) {
+        const int cx = cur.x, cy = cur.y;
+        SAMD_LY_MARK(cx)
+        const int4 nxt = rp[1];                                          // (a list ends with one spare record)
+        const int32_t* ent = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(ent_tab) + cur.z);
+        const unsigned zq4 = ((unsigned)(cx >> 16) & 0xFFu) * 256u + lane4;      // 4 (64 chunk + lane)
+        [[maybe_unused]] unsigned long long tm[4] = {0, 0, 0, 0};
+        // The body's private state: four indexed reads in front of the dispatch, two indexed writes behind it, in ONE
+        // place each (reads / writes inside the branches made the compiler copy the 32 registers once per path).
+        // VN: s0, s1 = prefixes of the unit's chunk(s), s2, s3 = their channel LLRs; CN: s0 = c2v of the fused edge,
+        // s2 = its channel LLR.  A body that does not use a value leaves it as read, so writing it back is harmless.
+        // (w = the indices i0 | i1 << 8 of s0 / s1 in the register file; s2 / s3 are 8 above)
+        const bool is_vn = (cx & 3) == LY_VN;
+        const int i0 = cur.w & 31, i1 = (cur.w >> 8) & 31;
+        float s0 = st[i0], s1 = st[i1], s2 = st[i0 + 8], s3 = st[i1 + 8];
+        if (is_vn) {
+          const unsigned ax = (unsigned)cy + zq4;
+          if ((cx >> 14) & 1) {                                          // the column's first edge: the prefix restarts
+            s0 = 0.f;
+            if ((cx >> 6) & 1) s1 = 0.f;
+          }
+#define SAMD_LY_VN(KEY, NL, NCHV) case KEY: ly_vn_col<NL, NCHV, POW2>(ent, zq4, zwv, ax, s0, s1, s2, s3, tm); break;
+          switch ((cx >> 2) & 63) {
+            SAMD_LY_VN(1, 4, 1) SAMD_LY_VN(2, 8, 1) SAMD_LY_VN(3, 12, 1) SAMD_LY_VN(4, 16, 1) SAMD_LY_VN(5, 20, 1)
+            SAMD_LY_VN(6, 24, 1) SAMD_LY_VN(7, 28, 1) SAMD_LY_VN(8, 32, 1)
+            SAMD_LY_VN(17, 4, 2) SAMD_LY_VN(18, 8, 2) SAMD_LY_VN(19, 12, 2)
+            default: break;
+          }
+#undef SAMD_LY_VN
+        } else if ((cx & 3) == LY_CN) {
+#define SAMD_LY_CN(KEY, D, F) \
+  case KEY: ly_cn_row<D, F, POW2, MODE>((unsigned)cy + zq4, z4, ent, zq4, zwv, llr_max, offset, s0, s2, tm); break;
+          switch ((cx >> 2) & 63) {
             SAMD_LY_CN(3, 3, false) SAMD_LY_CN(4, 4, false) SAMD_LY_CN(5, 5, false) SAMD_LY_CN(6, 6, false)
             SAMD_LY_CN(7, 7, false) SAMD_LY_CN(8, 8, false) SAMD_LY_CN(9, 9, false) SAMD_LY_CN(10, 10, false)
             SAMD_LY_CN(19, 19, false)
@@ -194,29 +249,28 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
             default: break;
           }
 #undef SAMD_LY_CN
-        } else {
-          const unsigned chunk = (unsigned)(cx >> 16) & 0xFFu;
-          const unsigned zz4 = chunk * 256u + lane4;
-          const unsigned ax = (unsigned)cy + zz4;
-#define SAMD_LY_VN(KEY, D, NCHV) case KEY: ly_vn_col<D, NCHV, POW2>(col_ent + cz, zz4, zwv, ax, pa0, pa1); break;
-          switch ((cx >> 8) & 63) {
-            SAMD_LY_VN(1, 1, 1) SAMD_LY_VN(2, 2, 1) SAMD_LY_VN(3, 3, 1) SAMD_LY_VN(4, 4, 1) SAMD_LY_VN(5, 5, 1)
-            SAMD_LY_VN(6, 6, 1) SAMD_LY_VN(7, 7, 1) SAMD_LY_VN(8, 8, 1) SAMD_LY_VN(9, 9, 1) SAMD_LY_VN(10, 10, 1)
-            SAMD_LY_VN(11, 11, 1) SAMD_LY_VN(12, 12, 1) SAMD_LY_VN(13, 13, 1) SAMD_LY_VN(14, 14, 1)
-            SAMD_LY_VN(15, 15, 1) SAMD_LY_VN(16, 16, 1) SAMD_LY_VN(17, 17, 1) SAMD_LY_VN(18, 18, 1)
-            SAMD_LY_VN(19, 19, 1) SAMD_LY_VN(20, 20, 1) SAMD_LY_VN(21, 21, 1) SAMD_LY_VN(22, 22, 1)
-            SAMD_LY_VN(23, 23, 1) SAMD_LY_VN(24, 24, 1) SAMD_LY_VN(25, 25, 1) SAMD_LY_VN(26, 26, 1)
-            SAMD_LY_VN(27, 27, 1) SAMD_LY_VN(28, 28, 1) SAMD_LY_VN(29, 29, 1) SAMD_LY_VN(30, 30, 1)
-            SAMD_LY_VN(33, 1, 2) SAMD_LY_VN(34, 2, 2) SAMD_LY_VN(35, 3, 2) SAMD_LY_VN(36, 4, 2) SAMD_LY_VN(37, 5, 2)
-            SAMD_LY_VN(38, 6, 2) SAMD_LY_VN(39, 7, 2) SAMD_LY_VN(40, 8, 2) SAMD_LY_VN(41, 9, 2) SAMD_LY_VN(42, 10, 2)
-            SAMD_LY_VN(43, 11, 2) SAMD_LY_VN(44, 12, 2)
-            default: break;
-          }
-#undef SAMD_LY_VN
         }
-        ++t;
-        cur = nxt; pa0 = na0; pa1 = na1; pb0 = nb0; pb1 = nb1;
+        st[i1] = s1;
+        st[i0] = s0;
+#ifdef SAMD_LY_TRACE
+        if ((cx & 3) >= LY_CN) {
+          SAMD_LY_MARK(0xF0)                                             // end of the body; its inner times beside it
+          if (g_ly_trace && blockIdx.x == 0 && it == 3 && lane == 0 && tr_slot <= 512)
+            for (int q = 0; q < 4; ++q) g_ly_sub[(w * 512 + tr_slot - 1) * 4 + q] = tm[q];
+        }
+#endif
+        // LDS traffic only: wait for this wave's LDS operations, then the barrier(s) (several: steps without a body)
+        for (int q = (cx >> 8) & 63; q > 0; --q) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (cx & LY_LAST) break;
+        ++rp;
+        cur = nxt;
       }
+    }
+    // the final c2v of the fused edges, for the output phase
+#pragma unroll
+    for (int q = 0; q < LY_CN_SLOTS; ++q) {
+      const int ci = slots[LY_CN_SLOTS + q];
+      if (ci >= 0) cext[ci + lane] = st[LY_ST_CO + q];
     }
     __syncthreads();
     // ---------------- output (decoding.py:620-626, 1486-1531): marginal of a non-fused column = xtot, of a fused
@@ -268,43 +322,6 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     const int c = by_row[r][d - 1].first, sft = by_row[r][d - 1].second;
     if (col_deg[c] == 1 && sft == 0 && d >= 3 && d <= 10) { fused_col[r] = c; col_fused[c] = 1; ext_of_row[r] = n_ext++; }
   }
-  // LDS layout: edge blocks of the non-fused edges, row-major; then xtot of the non-fused columns that have edges
-  std::vector<int> row_off(ncu, 0), xt_of_col(h->nb, -0x7FFFFFFF);
-  int edges = 0, ncore = 0;
-  for (int r = 0; r < ncu; ++r) { row_off[r] = edges * z * 4; edges += (int)by_row[r].size() - (fused_col[r] >= 0 ? 1 : 0); }
-  for (int c = 0; c < nbu; ++c) {
-    if (col_fused[c]) continue;
-    if (col_deg[c] == 0) continue;
-    if (col_deg[c] > 30) return SAMD_OK;
-    xt_of_col[c] = ncore++;
-  }
-  const size_t lds = ((size_t)edges + (size_t)ncore) * z * 4;
-  if (lds > 160 * 1024) return SAMD_OK;
-  const int xt_base = edges * z * 4;
-  std::vector<int32_t> xt_index(h->nb, -0x7FFFFFFF);
-  for (int c = 0; c < nbu; ++c) xt_index[c] = xt_of_col[c];
-  for (int r = 0; r < ncu; ++r)
-    if (fused_col[r] >= 0) xt_index[fused_col[r]] = -1 - ext_of_row[r];
-  // per-row tables (xtot byte offset of the column, 4 shift) and per-column tables (edge block byte offset, 4 shift)
-  std::vector<int32_t> row_ent, row_start(ncu, 0), col_ent, col_start(h->nb, 0);
-  std::vector<std::vector<std::pair<int, int>>> col_edges(h->nb);       // (block byte offset, 4 shift), rows ascending
-  for (int r = 0; r < ncu; ++r) {
-    row_start[r] = (int32_t)row_ent.size();
-    const int nf = (int)by_row[r].size() - (fused_col[r] >= 0 ? 1 : 0);
-    for (int i = 0; i < nf; ++i) {
-      const int c = by_row[r][i].first, s = by_row[r][i].second;
-      if (xt_of_col[c] < 0) return SAMD_OK;
-      row_ent.push_back(xt_base + xt_of_col[c] * z * 4);
-      row_ent.push_back(4 * s);
-      col_edges[c].push_back({row_off[r] + i * z * 4, 4 * s});
-    }
-  }
-  row_ent.resize(row_ent.size() + 64, 0);
-  for (int c = 0; c < nbu; ++c) {
-    col_start[c] = (int32_t)col_ent.size();
-    for (auto& e : col_edges[c]) { col_ent.push_back(e.first); col_ent.push_back(e.second); }
-  }
-  col_ent.resize(col_ent.size() + 64, 0);
   // groups of consecutive rows that share no non-fused column
   std::vector<std::vector<int>> groups;
   {
@@ -323,99 +340,255 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     }
     if (!cur.empty()) groups.push_back(cur);
   }
-  // per-wave record lists: CN items of the group, barrier, VN items, barrier
-  std::vector<std::vector<std::array<int32_t, 4>>> per(NW);
-  int rot = 0;
-  for (auto& g : groups) {
-    // CN items: one per row, on consecutive waves starting at a rotating position (so that the serial part does not
-    // always load the same SIMD)
-    // (SAMD_LY_CN_SPLIT=0: one item for both chunks; default: the chunks of a row as separate items on different waves)
-    const bool cn_split = !(getenv("SAMD_LY_CN_SPLIT") && atoi(getenv("SAMD_LY_CN_SPLIT")) == 0);
-    int slot = 0;
-    for (size_t j = 0; j < g.size(); ++j) {
-      const int r = g[j], d = (int)by_row[r].size(), f = fused_col[r] >= 0;
-      const int32_t wcol = f ? (fused_col[r] | (ext_of_row[r] << 16)) : 0;
-      for (int q = 0; q < z / 64; ++q) {
-        if (cn_split || q + 1 >= z / 64) {                    // (an odd last chunk is a single-chunk item in any case)
-          per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | (q << 16), row_off[r], row_start[r], wcol});
-        } else {
-          per[(rot + slot++) % NW].push_back({LY_CN | ((d | (f << 5)) << 8) | (1 << 14) | (q << 16), row_off[r], row_start[r], wcol});
-          ++q;
-        }
-      }
-    }
-    for (int wv = 0; wv < NW; ++wv) per[wv].push_back({LY_BARRIER, 0, 0, 0});
-    // VN items of the columns the group touched, longest first onto the least loaded wave
-    std::vector<std::pair<int, std::array<int32_t, 4>>> items;
-    std::vector<char> seen(h->nb, 0);
-    int ncols = 0;
-    for (int r : g)
+  const int G = (int)groups.size();
+  std::vector<std::vector<char>> in_group(G, std::vector<char>(h->nb, 0));
+  for (int g = 0; g < G; ++g)
+    for (int r : groups[g])
       for (auto& e : by_row[r])
-        if (!col_fused[e.first] && !seen[e.first]) { seen[e.first] = 1; ++ncols; }
-    std::fill(seen.begin(), seen.end(), 0);
-    // few columns: single-chunk items spread over more waves (an item's time is mostly its fixed latency)
-    const int single_max = getenv("SAMD_LY_VN_SINGLE_MAX") ? atoi(getenv("SAMD_LY_VN_SINGLE_MAX")) : 0;   // measured at C2: 0 -> 369 k, 10 -> 362 k, 32 -> 354 k decodes/s
-    const bool all_single = ncols * (z / 64) <= 2 * single_max;
-    for (int r : g)
-      for (auto& e : by_row[r]) {
-        const int c = e.first;
-        if (col_fused[c] || seen[c]) continue;
-        seen[c] = 1;
-        const int dg = col_deg[c], chunks = z / 64;
-        for (int q = 0; q < chunks; ++q) {
-          const bool pair = dg <= 12 && !all_single && q + 1 < chunks;
-          items.push_back({(pair ? 10 : 10) * dg + (pair ? 200 : 100),
-                           {LY_VN | ((dg | ((pair ? 1 : 0) << 5)) << 8) | (q << 16), xt_base + xt_of_col[c] * z * 4, col_start[c], c * z + q * 64}});
-          if (pair) ++q;
-        }
-      }
-    std::stable_sort(items.begin(), items.end(), [](auto& a, auto& b) { return a.first > b.first; });
-    std::vector<int> load(NW, 0);
-    for (auto& it : items) {
-      int wv = rot % NW;
-      for (int q = 1; q < NW; ++q) {
-        const int a = (rot + q) % NW;
-        if (load[a] < load[wv]) wv = a;
-      }
-      per[wv].push_back(it.second);
-      load[wv] += it.first;
-    }
-    for (int wv = 0; wv < NW; ++wv) per[wv].push_back({LY_BARRIER, 0, 0, 0});
-    rot = (rot + 1) % NW;
+        if (!col_fused[e.first]) in_group[g][e.first] = 1;
+  // LDS layout: edge blocks of the non-fused edges, row-major; xtot of the non-fused columns that have edges; one block of
+  // zeros (padding of the re-sums)
+  std::vector<int> row_off(ncu, 0), xt_of_col(h->nb, -0x7FFFFFFF);
+  int edges = 0, ncore = 0;
+  for (int r = 0; r < ncu; ++r) { row_off[r] = edges * z * 4; edges += (int)by_row[r].size() - (fused_col[r] >= 0 ? 1 : 0); }
+  for (int c = 0; c < nbu; ++c) {
+    if (col_fused[c]) continue;
+    if (col_deg[c] == 0) continue;
+    if (col_deg[c] > 30) return SAMD_OK;
+    xt_of_col[c] = ncore++;
   }
-  // SAMD_LY_ABL (development, wrong results): 1 = lists without the VN re-sum items, 2 = without the CN items, 3 = barriers only
+  const size_t lds = ((size_t)edges + (size_t)ncore + 1) * z * 4;
+  if (lds > 160 * 1024) return SAMD_OK;
+  const int xt_base = edges * z * 4, zero_base = (edges + ncore) * z * 4;
+  std::vector<int32_t> xt_index(h->nb, -0x7FFFFFFF);
+  for (int c = 0; c < nbu; ++c) xt_index[c] = xt_of_col[c];
+  for (int r = 0; r < ncu; ++r)
+    if (fused_col[r] >= 0) xt_index[fused_col[r]] = -1 - ext_of_row[r];
+  // per-row entries (xtot byte offset of the column, 4 shift) and per-column entries (edge block byte offset, 4 shift)
+  std::vector<std::vector<int32_t>> row_ent(ncu);
+  std::vector<std::vector<std::pair<int, int>>> col_edges(h->nb);       // (block byte offset, 4 shift), rows ascending
+  for (int r = 0; r < ncu; ++r) {
+    const int nf = (int)by_row[r].size() - (fused_col[r] >= 0 ? 1 : 0);
+    for (int i = 0; i < nf; ++i) {
+      const int c = by_row[r][i].first, s = by_row[r][i].second;
+      if (xt_of_col[c] < 0) return SAMD_OK;
+      row_ent[r].push_back(xt_base + xt_of_col[c] * z * 4);
+      row_ent[r].push_back(4 * s);
+      col_edges[c].push_back({row_off[r] + i * z * 4, 4 * s});
+    }
+  }
+  // the entry table: the rows' lists, then the columns' lists, each column's followed by three reads of the zero block (a
+  // re-sum reads from edge j on, rounded up to a multiple of 4 entries)
+  std::vector<int32_t> ent_tab, row_start(ncu, 0), col_start(h->nb, 0);
+  for (int r = 0; r < ncu; ++r) {
+    row_start[r] = (int32_t)ent_tab.size();
+    ent_tab.insert(ent_tab.end(), row_ent[r].begin(), row_ent[r].end());
+  }
+  for (int c = 0; c < nbu; ++c) {
+    col_start[c] = (int32_t)ent_tab.size();
+    for (auto& e : col_edges[c]) { ent_tab.push_back(e.first); ent_tab.push_back(e.second); }
+    for (int q = 0; q < 3; ++q) { ent_tab.push_back(zero_base); ent_tab.push_back(0); }
+  }
+  ent_tab.resize(ent_tab.size() + 64, 0);
+  // ---- ownership.  A check-node item (row, chunk) and a variable-node unit (column, chunk or pair of chunks) run on
+  // the same wave in every iteration, which keeps their private state in that wave's registers.
+  const int chunks = z / 64;
+  // CN items: the waves of a group's step are distinct; among those the one with the fewest fused slots, then the
+  // least check-node work so far
+  std::vector<std::vector<std::array<int, 3>>> cn_of_group(groups.size());      // (row, chunk, wave)
+  std::vector<int> cn_slots(NW, 0), cn_work(NW, 0);
+  std::vector<std::vector<int>> cn_slot_llr(NW), cn_slot_ext(NW);
+  std::vector<std::vector<int>> cn_slot_of(ncu, std::vector<int>(chunks, 0));
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    std::vector<char> taken(NW, 0);
+    int ntaken = 0;
+    for (int r : groups[gi])
+      for (int q = 0; q < chunks; ++q) {
+        if (ntaken == NW) { std::fill(taken.begin(), taken.end(), 0); ntaken = 0; }
+        const int f = fused_col[r] >= 0;
+        int best = -1;
+        for (int k2 = 0; k2 < NW; ++k2) {
+          const int wv = (int)((gi + (size_t)k2) % NW);
+          if (taken[wv] || (f && cn_slots[wv] >= LY_CN_SLOTS)) continue;
+          if (best < 0 || std::make_pair(f ? cn_slots[wv] : 0, cn_work[wv]) < std::make_pair(f ? cn_slots[best] : 0, cn_work[best])) best = wv;
+        }
+        if (best < 0) return SAMD_OK;                                     // more fused items than slots
+        taken[best] = 1; ++ntaken;
+        cn_work[best] += 10 + (int)by_row[r].size();
+        if (f) {
+          cn_slot_of[r][q] = cn_slots[best]++;
+          cn_slot_llr[best].push_back(fused_col[r] * z + q * 64);
+          cn_slot_ext[best].push_back(ext_of_row[r] * z + q * 64);
+        }
+        cn_of_group[gi].push_back({r, q, best});
+      }
+  }
+  // ---- steps, separated by workgroup barriers: one per group for its check-node items, and behind it one for the re-sums
+  // the next group waits for (the columns both groups touch: at least one, or the rows would be one group).
+  std::vector<std::vector<std::pair<int, int>>> touch(h->nb);              // per column: (group, index j of the edge)
+  {
+    std::vector<int> next_edge(h->nb, 0);
+    for (int g = 0; g < G; ++g)
+      for (int r : groups[g])
+        for (auto& e : by_row[r])
+          if (!col_fused[e.first]) touch[e.first].push_back({g, next_edge[e.first]++});
+  }
+  std::vector<int> cn_step(G, 0);
+  int nsteps = 0;
+  for (int g = 0; g < G; ++g) {
+    cn_step[g] = nsteps++;
+    bool need = false;
+    for (int c = 0; c < nbu; ++c)
+      if (in_group[g][c] && (g + 1 == G || in_group[g + 1][c])) need = true;
+    if (need || getenv("SAMD_LY_NODEFER")) ++nsteps;
+  }
+  // VN units: a column's chunk (or pair of chunks for degree <= 12); its item after the update of edge j reads 1 + (the
+  // edges below j) messages.  Units go, heaviest first, to the wave where they add least to the sum over the groups of
+  // the squared load.
+  struct Unit { int c, q, pair, wave, slot; long cost; };
+  std::vector<Unit> units;
+  auto item_cost = [&](int c, int j, int pair) { return (pair ? 36L : 18L) * ((col_deg[c] - j + 3) / 4 * 4) + 250; };
+  const int pair_max = getenv("SAMD_LY_PAIR_MAX") ? atoi(getenv("SAMD_LY_PAIR_MAX")) : 12;
+  for (int c = 0; c < nbu; ++c) {
+    if (xt_of_col[c] < 0) continue;
+    for (int q = 0; q < chunks; ++q) {
+      const int pair = (col_deg[c] <= std::min(12, pair_max) && q + 1 < chunks) ? 1 : 0;
+      long cost = 0;
+      for (auto& tj : touch[c]) cost += item_cost(c, tj.second, pair);
+      units.push_back({c, q, pair, -1, -1, cost});
+      if (pair) ++q;
+    }
+  }
+  std::vector<int> order(units.size());
+  for (size_t i = 0; i < units.size(); ++i) order[i] = (int)i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return units[x].cost > units[y].cost; });
+  std::vector<std::vector<long>> load(groups.size(), std::vector<long>(NW, 0));
+  std::vector<int> vn_slots(NW, 0);
+  std::vector<std::vector<int>> vn_slot_llr(NW);
+  for (int ui : order) {
+    Unit& u = units[ui];
+    int best = -1;
+    long best_inc = 0;
+    for (int wv = 0; wv < NW; ++wv) {
+      if (vn_slots[wv] + 1 + u.pair > LY_VN_SLOTS) continue;
+      long inc = 0;
+      for (auto& tj : touch[u.c]) {
+        const long cst = item_cost(u.c, tj.second, u.pair), l0 = load[tj.first][wv];
+        inc += (l0 + cst) * (l0 + cst) - l0 * l0;
+      }
+      if (best < 0 || inc < best_inc) { best = wv; best_inc = inc; }
+    }
+    if (best < 0) return SAMD_OK;                                         // more units than slots
+    u.wave = best;
+    u.slot = vn_slots[best];
+    vn_slots[best] += 1 + u.pair;
+    vn_slot_llr[best].push_back(u.c * z + u.q * 64);
+    if (u.pair) vn_slot_llr[best].push_back(u.c * z + (u.q + 1) * 64);
+    for (auto& tj : touch[u.c]) load[tj.first][best] += item_cost(u.c, tj.second, u.pair);
+  }
+  std::vector<int32_t> slot_tab((size_t)NW * LY_SLOT_INTS, -1);
+  for (int wv = 0; wv < NW; ++wv) {
+    for (size_t i = 0; i < cn_slot_llr[wv].size(); ++i) {
+      slot_tab[(size_t)wv * LY_SLOT_INTS + i] = cn_slot_llr[wv][i];
+      slot_tab[(size_t)wv * LY_SLOT_INTS + LY_CN_SLOTS + i] = cn_slot_ext[wv][i];
+    }
+    for (size_t i = 0; i < vn_slot_llr[wv].size(); ++i) slot_tab[(size_t)wv * LY_SLOT_INTS + 2 * LY_CN_SLOTS + i] = vn_slot_llr[wv][i];
+  }
+  // ---- schedule of the re-sums.  The re-sum of column c after its edge j (row in
+  // group g) is needed by the next row that touches c (group g' > g) and by nothing else, and nothing it reads or writes
+  // is touched by the groups in between - so it may run in any step behind group g's and before group g''s, also beside
+  // the check-node items of other rows, where it fills waves that would wait at the barrier.  Items with the smallest
+  // window are placed first, each into the step of its window where it lengthens the step least (a step lasts as long as
+  // its busiest wave).
+  struct Item { long key; int32_t x, y, zz, w; };
+  std::vector<std::vector<std::vector<Item>>> step_items(nsteps, std::vector<std::vector<Item>>(NW));
+  std::vector<std::vector<long>> sload(nsteps, std::vector<long>(NW, 0));
+  std::vector<long> smax(nsteps, 0);
+  for (int g = 0; g < G; ++g)
+    for (auto& it : cn_of_group[g]) {
+      const int r = it[0], q = it[1], wv = it[2], d = (int)by_row[r].size(), f = fused_col[r] >= 0, st = cn_step[g];
+      step_items[st][wv].push_back({1L << 40, LY_CN | ((d | (f << 5)) << 2) | (q << 16), row_off[r], 4 * row_start[r],
+                                    (LY_ST_CO + cn_slot_of[r][q]) | ((LY_ST_CO + ((cn_slot_of[r][q] + 1) & 7)) << 8)});
+      sload[st][wv] += 300 + 60L * d;
+      smax[st] = std::max(smax[st], sload[st][wv]);
+    }
+  struct VTask { int unit, j, lo, hi; long cost; };
+  std::vector<VTask> vt;
+  const bool defer = !(getenv("SAMD_LY_NODEFER") && atoi(getenv("SAMD_LY_NODEFER")));
+  for (size_t ui = 0; ui < units.size(); ++ui) {
+    const Unit& u = units[ui];
+    for (size_t k2 = 0; k2 < touch[u.c].size(); ++k2) {
+      const int g0 = touch[u.c][k2].first, j = touch[u.c][k2].second;
+      const int hi = (k2 + 1 < touch[u.c].size()) ? cn_step[touch[u.c][k2 + 1].first] - 1 : nsteps - 1;
+      if (hi < cn_step[g0] + 1) return SAMD_ERR_UNSUPPORTED;               // (cannot happen: such a column got a step)
+      vt.push_back({(int)ui, j, cn_step[g0] + 1, defer ? hi : cn_step[g0] + 1, item_cost(u.c, j, u.pair)});
+    }
+  }
+  std::stable_sort(vt.begin(), vt.end(), [](const VTask& x, const VTask& y) {
+    return (x.hi - x.lo) != (y.hi - y.lo) ? (x.hi - x.lo) < (y.hi - y.lo) : x.cost > y.cost;
+  });
+  for (auto& tk : vt) {
+    const Unit& u = units[tk.unit];
+    int best = -1;
+    long best_inc = 0, best_load = 0;
+    for (int st = tk.lo; st <= tk.hi; ++st) {
+      const long after = sload[st][u.wave] + tk.cost, inc = std::max(0L, after - smax[st]);
+      if (best < 0 || inc < best_inc || (inc == best_inc && after < best_load)) { best = st; best_inc = inc; best_load = after; }
+    }
+    const int nl4 = (col_deg[u.c] - tk.j + 3) / 4 * 4;
+    // (sort key inside a wave's step: the check-node item first, then the re-sums in the order of their columns' edges)
+    step_items[best][u.wave].push_back({((long)u.c << 8) | tk.j,
+        LY_VN | (((nl4 / 4) | (u.pair << 4)) << 2) | ((tk.j == 0 ? 1 : 0) << 14) | (u.q << 16),
+        xt_base + xt_of_col[u.c] * z * 4, 4 * (col_start[u.c] + 2 * tk.j), (LY_ST_P + u.slot) | ((LY_ST_P + ((u.slot + 1) & 7)) << 8)});
+    sload[best][u.wave] += tk.cost;
+    smax[best] = std::max(smax[best], sload[best][u.wave]);
+  }
+  // SAMD_LY_ABL (development, wrong results): 1 = lists without the re-sum items, 2 = without the CN items, 3 = barriers only
   const int abl = getenv("SAMD_LY_ABL") ? atoi(getenv("SAMD_LY_ABL")) : 0;
-  std::vector<int32_t> rec_ptr, recs;
+  std::vector<int32_t> rec_ptr, recs;                      // recs: 4 dwords each
   for (int wv = 0; wv < NW; ++wv) {
     rec_ptr.push_back((int32_t)(recs.size() / 4));
-    int last_barrier = -1;                                  // index (in recs) of a barrier record that can take one more
-    for (auto& rc : per[wv]) {
-      const int kind = rc[0] & 0xFF;
-      if ((kind == LY_VN && (abl & 1)) || (kind == LY_CN && (abl & 2))) continue;
-      if (kind == LY_BARRIER && last_barrier >= 0) { ++recs[last_barrier + 1]; continue; }   // barriers in a row: one record
-      if (kind == LY_BARRIER) { last_barrier = (int)recs.size(); recs.insert(recs.end(), {LY_BARRIER, 1, 0, 0}); continue; }
-      last_barrier = -1;
-      recs.insert(recs.end(), rc.begin(), rc.end());
+    long last = -1;                                         // position of the wave's last record
+    auto push = [&](int32_t x, int32_t y, int32_t zz, int32_t w) {
+      last = (long)recs.size();
+      recs.insert(recs.end(), {x, y, zz, w});
+    };
+    for (int st = 0; st < nsteps; ++st) {
+      auto& its = step_items[st][wv];
+      std::stable_sort(its.begin(), its.end(), [](const Item& x, const Item& y) {
+        const bool cx2 = x.key >= (1L << 40), cy2 = y.key >= (1L << 40);
+        return cx2 != cy2 ? cx2 : x.key < y.key;
+      });
+      for (auto& it : its) {
+        const int kind = it.x & 3;
+        if ((kind == LY_VN && (abl & 1)) || (kind == LY_CN && (abl & 2))) continue;
+        push(it.x, it.y, it.zz, it.w);
+      }
+      // the step's barrier: one more after the wave's last record
+      if (last < 0 || ((recs[last] >> 8) & 63) == LY_MAX_NB) push(LY_NOP, 0, 0, 0);
+      recs[last] += 1 << 8;
     }
-    for (int q = 0; q < 4; ++q) recs.insert(recs.end(), {LY_END, 0, 0, 0});   // the walker reads three records ahead
+    recs[last] |= LY_LAST;
+    push(LY_NOP | LY_LAST, 0, 0, 0);                        // the walker reads one record ahead
   }
   rec_ptr.push_back((int32_t)(recs.size() / 4));
   h->ly_lds_bytes = (int)lds;
+  h->ly_zero_off = zero_base / 4;
   h->ly_msg_floats = edges * z;
   h->ly_n_ext = n_ext;
   h->ly_groups = (int)groups.size();
   int rc = upload(&h->ly_rec_ptr, rec_ptr.data(), rec_ptr.size());
   if (rc == SAMD_OK) rc = upload(&h->ly_recs, recs.data(), recs.size());
-  if (rc == SAMD_OK) rc = upload(&h->ly_row_ent, row_ent.data(), row_ent.size());
-  if (rc == SAMD_OK) rc = upload(&h->ly_col_ent, col_ent.data(), col_ent.size());
+  if (rc == SAMD_OK) rc = upload(&h->ly_ent_tab, ent_tab.data(), ent_tab.size());
   if (rc == SAMD_OK) rc = upload(&h->ly_xt_index, xt_index.data(), xt_index.size());
+  if (rc == SAMD_OK) rc = upload(&h->ly_slot_tab, slot_tab.data(), slot_tab.size());
   if (rc == SAMD_OK) h->ly_ok = 1;
   return rc;
 }
 
 void free_onchip_ly_tables(samd_ldpc5g* h) {
-  (void)hipFree(h->ly_rec_ptr); (void)hipFree(h->ly_recs); (void)hipFree(h->ly_row_ent); (void)hipFree(h->ly_col_ent);
-  (void)hipFree(h->ly_xt_index);
+  (void)hipFree(h->ly_rec_ptr); (void)hipFree(h->ly_recs); (void)hipFree(h->ly_ent_tab);
+  (void)hipFree(h->ly_xt_index); (void)hipFree(h->ly_slot_tab);
 }
 
 static int ly_grid(const samd_ldpc5g* h, int batch) {
@@ -452,7 +625,7 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   }
   float* ws = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
   const bool pow2 = (h->z & (h->z - 1)) == 0;
-  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, float, float, int, int, int, int,
+  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, float, float, int, int, int, int, int,
                          const int32_t*, const int4*, const int32_t*, const int32_t*, const int32_t*);
   static const kern_t kerns[6] = {ldpc5g_decode_ly_kernel<false, SAMD_CN_MINSUM>, ldpc5g_decode_ly_kernel<true, SAMD_CN_MINSUM>,
                                   ldpc5g_decode_ly_kernel<false, SAMD_CN_BOXPLUS_PHI>, ldpc5g_decode_ly_kernel<true, SAMD_CN_BOXPLUS_PHI>,
@@ -463,9 +636,18 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;
   hipLaunchKernelGGL(fn, dim3(ly_grid(h, batch)), dim3(1024), (size_t)h->ly_lds_bytes, st, llr, out, ws, rm, nbu, batch, num_iter,
-                     llr_max, off, hard_out, return_infobits, h->ly_msg_floats, h->ly_n_ext, h->ly_rec_ptr,
-                     reinterpret_cast<const int4*>(h->ly_recs), h->ly_row_ent, h->ly_col_ent, h->ly_xt_index);
+                     llr_max, off, hard_out, return_infobits, h->ly_msg_floats, h->ly_n_ext,
+                     h->ly_zero_off, h->ly_rec_ptr,
+                     reinterpret_cast<const int4*>(h->ly_recs), h->ly_ent_tab, h->ly_xt_index, h->ly_slot_tab);
   return launch_status();
 }
 
 }  // namespace samd
+
+#ifdef SAMD_LY_TRACE
+extern "C" int samd_debug_set_ly_trace(unsigned long long* p) {
+  unsigned long long* q = p ? p + 16 * 512 * 2 : nullptr;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(samd::g_ly_sub), &q, sizeof(q)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(samd::g_ly_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
