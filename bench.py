@@ -606,6 +606,21 @@ def main():
                                                 "are not bit-identical to the oracle (tests keep the round-2 tolerance bars)"}
             del dec3
 
+    if args.also and args.also != "none":
+        # cn_schedule="layered" (one sub-iteration per base row), half the iterations, on its own
+        # on-chip engine (csrc/ldpc5g_onchip_ly.hip); same batch, same rule as the headline
+        decl = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=args.cn_update, cn_schedule="layered", num_iter=max(1, args.num_iter // 2),
+                                          hard_out=True, return_infobits=True)
+        stepsl = max(2, args.steps // 3)
+        tl, msl, cl = run(decl, stepsl, 1)
+        out.setdefault("also", {})["layered"] = {
+            "cn_schedule": "layered", "cn_update": args.cn_update, "num_iter": max(1, args.num_iter // 2),
+            "engine": "on-chip layered" if _ffi.lib().samd_ldpc5g_decode_layered_supported(
+                enc._handle(decl._nb_pruned_nodes), decl._cn_mode) else "generic-hbm scheduled",
+            "value": round(B * world * stepsl / tl, 1), "unit": "codewords/s", "steps": stepsl,
+            "ms_per_step": round(tl / stepsl * 1e3, 3), "ber": float(cl[0] / max(cl[2], 1)), "bler": float(cl[1] / max(cl[3], 1))}
+        del decl
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c2(llr, k, n, m, args.cn_update, args.num_iter, dec, 12.0, B)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -73,10 +73,12 @@ enum { LY_ST_CO = 0, LY_ST_LF = 8, LY_ST_P = 16, LY_ST_L = 24 };
 // One record of a wave's list = 4 dwords (x, LDS byte offset, offset of the body's entries in the entry table, extra);
 // the (byte offset, 4 shift) entries of a body come from ONE table shared by all records: a row's list, or a column's
 // list from edge j on.  Records (~450 x 16 B per iteration at C2) + table (~5 KB) stay in the 16 KB scalar data cache.
-// (Records with their entries inline - one 64-byte line per record, one s_load_dwordx16 a record ahead - were tried:
-// 110 KB per iteration stream through the scalar cache, every record load is a miss, and since scalar loads return
-// out of order the body's first LDS wait (lgkmcnt(0)) waits for that miss: ~1 k cycles per record whatever its size,
-// profiles/r03b/layered_abl_r03zb.txt.)
+// (Tried and dropped, profiles/r03b: records with their entries inline - one 64-byte line per record, 110 KB per
+// iteration, every record load a scalar-cache miss that the body's first LDS wait, lgkmcnt(0), has to sit out: 555 k
+// decodes/s against 635 k, layered_abl_r03zb/zc.txt; the first entries of the next record requested a record ahead:
+// 12 more scalar moves per record, 596 k against 657 k, layered_abl_r03zg.txt; the re-sums of columns 0 / 1 run by the
+// check-node wave itself behind its item, which saves the re-sum step but puts three dependent records on one wave:
+// 497 k, layered_abl_r03zc.txt.)
 #define LY_ENT(i, k) ent[2 * (i) + (k)]
 
 // check nodes (row r, lifted copies 64 chunk + lane): D edges, the last one fused when F.
@@ -542,6 +544,21 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
         xt_base + xt_of_col[u.c] * z * 4, 4 * (col_start[u.c] + 2 * tk.j), (LY_ST_P + u.slot) | ((LY_ST_P + ((u.slot + 1) & 7)) << 8)});
     sload[best][u.wave] += tk.cost;
     smax[best] = std::max(smax[best], sload[best][u.wave]);
+  }
+  if (getenv("SAMD_LY_DUMP")) {                             // development (tools/ly_dump.py): the schedule, estimated cycles
+    long total = 0;
+    for (int st = 0; st < nsteps; ++st) {
+      fprintf(stderr, "step %3d max %5ld |", st, smax[st]);
+      for (int wv = 0; wv < NW; ++wv) {
+        fprintf(stderr, " w%d:", wv);
+        for (auto& it : step_items[st][wv])
+          fprintf(stderr, "%s%d%s", (it.x & 3) == LY_CN ? "C" : "V", (it.x & 3) == LY_CN ? ((it.x >> 2) & 31) : 4 * ((it.x >> 2) & 15),
+                  (it.x & 3) == LY_VN && ((it.x >> 6) & 1) ? "p," : ",");
+      }
+      fprintf(stderr, "\n");
+      total += smax[st];
+    }
+    fprintf(stderr, "sum of step maxima %ld\n", total);
   }
   // SAMD_LY_ABL (development, wrong results): 1 = lists without the re-sum items, 2 = without the CN items, 3 = barriers only
   const int abl = getenv("SAMD_LY_ABL") ? atoi(getenv("SAMD_LY_ABL")) : 0;
