@@ -60,6 +60,7 @@ struct samd_ldpc5g {
   int ly_ok = 0, ly_lds_bytes = 0, ly_msg_floats = 0, ly_n_ext = 0, ly_groups = 0, ly_zero_off = 0;
   int32_t* ly_rec_ptr = nullptr; int32_t* ly_recs = nullptr; int32_t* ly_ent_tab = nullptr;
   int32_t* ly_xt_index = nullptr; int32_t* ly_slot_tab = nullptr;
+  int32_t* ly_bp_rec_ptr = nullptr; int32_t* ly_bp_recs = nullptr; int32_t* ly_bp_slot_tab = nullptr; int ly_bp_lds_bytes = 0;
   int dec_waves = 16;          // waves per workgroup of the on-chip decoder (16 / 8 / 4: small codes share a CU)
   int llr_global = 0;          // 1: channel LLRs in the caller's workspace (L2) instead of LDS (larger codes fit)
 };

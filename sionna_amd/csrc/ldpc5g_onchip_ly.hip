@@ -27,11 +27,13 @@
 // the same additions in the same order as summing everything again, half the LDS reads on average.
 // Consecutive base rows that share no column are one group (BG1: 32 groups instead of 46 layers): their updates commute.
 //
-// Every wave walks a linear record list built on the host: its CN items of the group (one 64-lane chunk of a row), a
-// workgroup barrier, its VN re-sum items (column; pairs of chunks for degree <= 12), a barrier, next group.  No global
-// memory operand inside the iteration loop: until round 3x the fused state and the channel LLRs came from the L2
-// workspace one record ahead, and every record then lasted at least one L2 round trip (~1.6 k cycles measured per item,
-// profiles/r03b/ly_itrace_r03x.txt, against ~30 cycles per edge of actual work).
+// Every wave walks a linear record list built on the host.  A step = the records between two workgroup barriers: the
+// check-node items of a group (one 64-lane chunk of a row per wave; for the boxplus rules cut into parts of 2 or 4 edges
+// on different waves, ly_cns_part), then the re-sums the next group waits for (column; pairs of chunks for degree <= 12);
+// re-sums nobody waits for yet fill idle waves of later steps.  No global memory operand inside the iteration loop:
+// until round 3x the fused state and the channel LLRs came from the L2 workspace one record ahead, and every record then
+// lasted at least one L2 round trip (~1.6 k cycles measured per item, profiles/r03b/ly_itrace_r03x_before.txt, against
+// ~30 cycles per edge of actual work).
 #include <array>
 #include "ldpc5g_onchip_ms.inc"
 
@@ -43,7 +45,7 @@ namespace samd {
 // table; w: where the item's private state sits in the wave's register file.  One record per step and wave instead of
 // separate item and barrier records: a lone wave issues an instruction every 6-7 cycles (the other 15 wait at the
 // barrier), so a record costs what its instruction count says - the walker's share is ~60 instructions.
-enum { LY_NOP = 0, LY_CN = 2, LY_VN = 3, LY_LAST = 1 << 15, LY_MAX_NB = 63 };
+enum { LY_NOP = 0, LY_CNS = 1, LY_CN = 2, LY_VN = 3, LY_LAST = 1 << 15, LY_MAX_NB = 63 };
 
 #ifdef SAMD_LY_TRACE
 // Development aid (tools/ly_itrace.py, `make -C sionna_amd/csrc lytrace`; not part of the product build): iteration 3 of
@@ -114,6 +116,76 @@ __device__ __forceinline__ void ly_cn_row(unsigned a0, unsigned z4, const int32_
   for (int i = 0; i < NF; ++i) lds_st(a0 + (unsigned)i * z4, v[0][i]);
   if constexpr (F) co = v[0][D - 1];
   SAMD_LY_SUB(3)
+}
+
+// PART of a check-node item for the boxplus rules: E consecutive edges (from edge e0) of the D edges of (row, chunk), the
+// last one fused when F.  A step works one or two waves and a boxplus-phi edge costs ~100 instructions (two exp, four
+// log), so the edges of a row are spread over several waves: every part computes phi of its own incoming messages and
+// leaves them (sign of the message in the sign bit - phi is positive) in a scratch block, one workgroup barrier, then
+// every part sums ALL D values in edge order - the order of cn_update_col, so the same bits - and finishes its own edges.
+// The other waves of the workgroup pass the same barrier from their record lists.  scr = byte address of the item's
+// scratch slot 0 for this lane; zero_a = address of a zero for this lane (reads past D).
+template <int E, bool F, bool POW2, int MODE>
+__device__ __forceinline__ void ly_cns_part(unsigned a0, unsigned z4, const int32_t* __restrict__ ent, unsigned lane4,
+                                            unsigned zwv, float llr_max, float& co, float lf, unsigned scr, int e0, int D,
+                                            unsigned zero_a) {
+  constexpr int NF = F ? E - 1 : E;
+  float v[E];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) {
+    const unsigned t = lane4 + (unsigned)ent[2 * i + 1];
+    const unsigned ax = POW2 ? ((t & zwv) | (unsigned)ent[2 * i]) : (min(t, t - zwv) + (unsigned)ent[2 * i]);
+    const float x = lds_ld(ax);
+    const float c = lds_ld(a0 + (unsigned)i * z4);
+    v[i] = ms_med3(x - c, -llr_max, llr_max);
+  }
+  if constexpr (F) {
+    const float x = co + lf;
+    v[E - 1] = ms_med3(x - co, -llr_max, llr_max);
+  }
+  unsigned sg[E];
+#pragma unroll
+  for (int i = 0; i < E; i += 2) {
+    if (i + 1 < E) {
+      sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
+      sg[i + 1] = (v[i + 1] < 0.f) ? 0x80000000u : 0u;
+      const f32x2 ph = phi2_f32<MODE>(fabsf(v[i]), fabsf(v[i + 1]));
+      v[i] = ph.x; v[i + 1] = ph.y;
+    } else {
+      sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
+      v[i] = phi1_f32<MODE>(fabsf(v[i]));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; ++i) lds_st(scr + (unsigned)(e0 + i) * 256u, __uint_as_float(__float_as_uint(v[i]) | sg[i]));
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  float sum = 0.f;
+  unsigned node = 0u;
+  for (int b = 0; b < D; b += 4) {                                       // (wave-uniform trip count)
+    float w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w[q] = lds_ld((b + q < D) ? scr + (unsigned)(b + q) * 256u : zero_a);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned u = __float_as_uint(w[q]);
+      node ^= u & 0x80000000u;
+      sum += __uint_as_float(u & 0x7FFFFFFFu);                           // (reads past D add +0: exact)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < E; i += 2) {
+    if (i + 1 < E) {
+      const f32x2 q = phi2_f32<MODE>(-1.f * v[i] + sum, -1.f * v[i + 1] + sum);
+      v[i] = __uint_as_float(__float_as_uint(fminf(q.x, llr_max)) ^ (sg[i] ^ node));
+      v[i + 1] = __uint_as_float(__float_as_uint(fminf(q.y, llr_max)) ^ (sg[i + 1] ^ node));
+    } else {
+      const float q = phi1_f32<MODE>(-1.f * v[i] + sum);
+      v[i] = __uint_as_float(__float_as_uint(fminf(q, llr_max)) ^ (sg[i] ^ node));
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NF; ++i) lds_st(a0 + (unsigned)i * z4, v[i]);
+  if constexpr (F) co = v[E - 1];
 }
 
 // variable nodes of column c (lifted copies of chunk(s)) after the update of the row of its edge j: 1 + the number of
@@ -239,6 +311,21 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
             default: break;
           }
 #undef SAMD_LY_VN
+        } else if ((cx & 3) == LY_CNS) {
+          if constexpr (MODE != SAMD_CN_MINSUM) {
+            // w: bits 16-23 D, 24-31 first edge; x bits 24-31: the item's scratch area, in 256-byte slots
+            const unsigned scr = 4u * (unsigned)zero_off + z4 + 256u * ((unsigned)cx >> 24) + lane4;
+            const unsigned zero_a = 4u * (unsigned)zero_off + lane4;
+            const int dd = (cur.w >> 16) & 255, e0 = (cur.w >> 24) & 255;
+#define SAMD_LY_CNS(KEY, E, F) \
+  case KEY: ly_cns_part<E, F, POW2, MODE>((unsigned)cy + zq4, z4, ent, zq4, zwv, llr_max, s0, s2, scr, e0, dd, zero_a); break;
+            switch ((cx >> 2) & 63) {
+              SAMD_LY_CNS(1, 1, false) SAMD_LY_CNS(2, 2, false) SAMD_LY_CNS(3, 3, false) SAMD_LY_CNS(4, 4, false)
+              SAMD_LY_CNS(9, 1, true) SAMD_LY_CNS(10, 2, true) SAMD_LY_CNS(11, 3, true) SAMD_LY_CNS(12, 4, true)
+              default: break;
+            }
+#undef SAMD_LY_CNS
+          }
         } else if ((cx & 3) == LY_CN) {
 #define SAMD_LY_CN(KEY, D, F) \
   case KEY: ly_cn_row<D, F, POW2, MODE>((unsigned)cy + zq4, z4, ent, zq4, zwv, llr_max, offset, s0, s2, tm); break;
@@ -392,38 +479,65 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     for (int q = 0; q < 3; ++q) { ent_tab.push_back(zero_base); ent_tab.push_back(0); }
   }
   ent_tab.resize(ent_tab.size() + 64, 0);
-  // ---- ownership.  A check-node item (row, chunk) and a variable-node unit (column, chunk or pair of chunks) run on
-  // the same wave in every iteration, which keeps their private state in that wave's registers.
   const int chunks = z / 64;
+  struct Lists { std::vector<int32_t> rec_ptr, recs, slot_tab; int scratch_bytes = 0; };
+  // SAMD_LY_ABL (development, wrong results): 1 = lists without the re-sum items, 2 = without the CN items, 3 = barriers only
+  const int abl = getenv("SAMD_LY_ABL") ? atoi(getenv("SAMD_LY_ABL")) : 0;
+  // The lists are built twice: whole check-node items (min-sum: ~13 instructions per edge), and - `split` - items cut into
+  // parts of 2 (row degree <= 10) or 4 edges for the boxplus rules (~100 instructions per edge), see ly_cns_part.
+  // Returns 1 when the code does not fit the engine.
+  auto build_lists = [&](bool split, Lists& L) -> int {
+  // ---- ownership.  A check-node item (row, chunk) - or each of its parts - and a variable-node unit (column, chunk or pair
+  // of chunks) run on the same wave in every iteration, which keeps their private state in that wave's registers.
   // CN items: the waves of a group's step are distinct; among those the one with the fewest fused slots, then the
   // least check-node work so far
-  std::vector<std::vector<std::array<int, 3>>> cn_of_group(groups.size());      // (row, chunk, wave)
+  struct Part { int r, q, e0, ne, wave, scr; };                             // edges [e0, e0 + ne) of (row, chunk)
+  std::vector<std::vector<Part>> cn_of_group(groups.size());
+  std::vector<char> group_split(groups.size(), 0);
   std::vector<int> cn_slots(NW, 0), cn_work(NW, 0);
   std::vector<std::vector<int>> cn_slot_llr(NW), cn_slot_ext(NW);
   std::vector<std::vector<int>> cn_slot_of(ncu, std::vector<int>(chunks, 0));
+  const int free_lds = 160 * 1024 - (int)lds;
   for (size_t gi = 0; gi < groups.size(); ++gi) {
-    std::vector<char> taken(NW, 0);
-    int ntaken = 0;
+    // parts of the group's items; the group is split only if its parts fit the 16 waves and its scratch the free LDS
+    std::vector<Part> parts;
+    int scr = 0;
     for (int r : groups[gi])
       for (int q = 0; q < chunks; ++q) {
-        if (ntaken == NW) { std::fill(taken.begin(), taken.end(), 0); ntaken = 0; }
-        const int f = fused_col[r] >= 0;
-        int best = -1;
-        for (int k2 = 0; k2 < NW; ++k2) {
-          const int wv = (int)((gi + (size_t)k2) % NW);
-          if (taken[wv] || (f && cn_slots[wv] >= LY_CN_SLOTS)) continue;
-          if (best < 0 || std::make_pair(f ? cn_slots[wv] : 0, cn_work[wv]) < std::make_pair(f ? cn_slots[best] : 0, cn_work[best])) best = wv;
-        }
-        if (best < 0) return SAMD_OK;                                     // more fused items than slots
-        taken[best] = 1; ++ntaken;
-        cn_work[best] += 10 + (int)by_row[r].size();
-        if (f) {
-          cn_slot_of[r][q] = cn_slots[best]++;
-          cn_slot_llr[best].push_back(fused_col[r] * z + q * 64);
-          cn_slot_ext[best].push_back(ext_of_row[r] * z + q * 64);
-        }
-        cn_of_group[gi].push_back({r, q, best});
+        const int d = (int)by_row[r].size(), pe = d <= 10 ? 2 : 4;
+        for (int e0 = 0; e0 < d; e0 += pe) parts.push_back({r, q, e0, std::min(pe, d - e0), -1, scr});
+        scr += d * 256;
       }
+    if (split && (int)parts.size() <= NW && scr <= free_lds) {
+      group_split[gi] = 1;
+      L.scratch_bytes = std::max(L.scratch_bytes, scr);
+    } else {
+      parts.clear();
+      for (int r : groups[gi])
+        for (int q = 0; q < chunks; ++q) parts.push_back({r, q, 0, (int)by_row[r].size(), -1, 0});
+    }
+    std::vector<char> taken(NW, 0);
+    int ntaken = 0;
+    for (auto& pt : parts) {
+      if (ntaken == NW) { std::fill(taken.begin(), taken.end(), 0); ntaken = 0; }
+      const int f = fused_col[pt.r] >= 0 && pt.e0 + pt.ne == (int)by_row[pt.r].size();   // the part with the fused edge
+      int best = -1;
+      for (int k2 = 0; k2 < NW; ++k2) {
+        const int wv = (int)((gi + (size_t)k2) % NW);
+        if (taken[wv] || (f && cn_slots[wv] >= LY_CN_SLOTS)) continue;
+        if (best < 0 || std::make_pair(f ? cn_slots[wv] : 0, cn_work[wv]) < std::make_pair(f ? cn_slots[best] : 0, cn_work[best])) best = wv;
+      }
+      if (best < 0) return 1;                                             // more fused items than slots
+      taken[best] = 1; ++ntaken;
+      cn_work[best] += 10 + pt.ne;
+      if (f) {
+        cn_slot_of[pt.r][pt.q] = cn_slots[best]++;
+        cn_slot_llr[best].push_back(fused_col[pt.r] * z + pt.q * 64);
+        cn_slot_ext[best].push_back(ext_of_row[pt.r] * z + pt.q * 64);
+      }
+      pt.wave = best;
+      cn_of_group[gi].push_back(pt);
+    }
   }
   // ---- steps, separated by workgroup barriers: one per group for its check-node items, and behind it one for the re-sums
   // the next group waits for (the columns both groups touch: at least one, or the rows would be one group).
@@ -480,7 +594,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       }
       if (best < 0 || inc < best_inc) { best = wv; best_inc = inc; }
     }
-    if (best < 0) return SAMD_OK;                                         // more units than slots
+    if (best < 0) return 1;                                               // more units than slots
     u.wave = best;
     u.slot = vn_slots[best];
     vn_slots[best] += 1 + u.pair;
@@ -488,7 +602,8 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     if (u.pair) vn_slot_llr[best].push_back(u.c * z + (u.q + 1) * 64);
     for (auto& tj : touch[u.c]) load[tj.first][best] += item_cost(u.c, tj.second, u.pair);
   }
-  std::vector<int32_t> slot_tab((size_t)NW * LY_SLOT_INTS, -1);
+  std::vector<int32_t>& slot_tab = L.slot_tab;
+  slot_tab.assign((size_t)NW * LY_SLOT_INTS, -1);
   for (int wv = 0; wv < NW; ++wv) {
     for (size_t i = 0; i < cn_slot_llr[wv].size(); ++i) {
       slot_tab[(size_t)wv * LY_SLOT_INTS + i] = cn_slot_llr[wv][i];
@@ -507,11 +622,18 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::vector<std::vector<long>> sload(nsteps, std::vector<long>(NW, 0));
   std::vector<long> smax(nsteps, 0);
   for (int g = 0; g < G; ++g)
-    for (auto& it : cn_of_group[g]) {
-      const int r = it[0], q = it[1], wv = it[2], d = (int)by_row[r].size(), f = fused_col[r] >= 0, st = cn_step[g];
-      step_items[st][wv].push_back({1L << 40, LY_CN | ((d | (f << 5)) << 2) | (q << 16), row_off[r], 4 * row_start[r],
-                                    (LY_ST_CO + cn_slot_of[r][q]) | ((LY_ST_CO + ((cn_slot_of[r][q] + 1) & 7)) << 8)});
-      sload[st][wv] += 300 + 60L * d;
+    for (auto& pt : cn_of_group[g]) {
+      const int r = pt.r, q = pt.q, wv = pt.wave, d = (int)by_row[r].size(), st = cn_step[g];
+      const int f = fused_col[r] >= 0 && pt.e0 + pt.ne == d;
+      const int sidx = (LY_ST_CO + cn_slot_of[r][q]) | ((LY_ST_CO + ((cn_slot_of[r][q] + 1) & 7)) << 8);
+      if (group_split[g]) {
+        step_items[st][wv].push_back({1L << 40, LY_CNS | ((pt.ne | (f << 3)) << 2) | (q << 16) | (int32_t)((unsigned)(pt.scr / 256) << 24),
+                                      row_off[r] + pt.e0 * z * 4, 4 * (row_start[r] + 2 * pt.e0), sidx | (d << 16) | (pt.e0 << 24)});
+        sload[st][wv] += 500 + 350L * ((pt.ne + 1) / 2) + 8L * d;
+      } else {
+        step_items[st][wv].push_back({1L << 40, LY_CN | ((d | (f << 5)) << 2) | (q << 16), row_off[r], 4 * row_start[r], sidx});
+        sload[st][wv] += split ? 300 + 330L * ((d + 1) / 2) : 300 + 60L * d;
+      }
       smax[st] = std::max(smax[st], sload[st][wv]);
     }
   struct VTask { int unit, j, lo, hi; long cost; };
@@ -522,7 +644,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     for (size_t k2 = 0; k2 < touch[u.c].size(); ++k2) {
       const int g0 = touch[u.c][k2].first, j = touch[u.c][k2].second;
       const int hi = (k2 + 1 < touch[u.c].size()) ? cn_step[touch[u.c][k2 + 1].first] - 1 : nsteps - 1;
-      if (hi < cn_step[g0] + 1) return SAMD_ERR_UNSUPPORTED;               // (cannot happen: such a column got a step)
+      if (hi < cn_step[g0] + 1) return 1;                                  // (cannot happen: such a column got a step)
       vt.push_back({(int)ui, j, cn_step[g0] + 1, defer ? hi : cn_step[g0] + 1, item_cost(u.c, j, u.pair)});
     }
   }
@@ -546,13 +668,15 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     smax[best] = std::max(smax[best], sload[best][u.wave]);
   }
   if (getenv("SAMD_LY_DUMP")) {                             // development (tools/ly_dump.py): the schedule, estimated cycles
+    fprintf(stderr, "%s check-node items\n", split ? "split" : "whole");
     long total = 0;
     for (int st = 0; st < nsteps; ++st) {
       fprintf(stderr, "step %3d max %5ld |", st, smax[st]);
       for (int wv = 0; wv < NW; ++wv) {
         fprintf(stderr, " w%d:", wv);
         for (auto& it : step_items[st][wv])
-          fprintf(stderr, "%s%d%s", (it.x & 3) == LY_CN ? "C" : "V", (it.x & 3) == LY_CN ? ((it.x >> 2) & 31) : 4 * ((it.x >> 2) & 15),
+          fprintf(stderr, "%s%d%s", (it.x & 3) == LY_CN ? "C" : (it.x & 3) == LY_CNS ? "P" : "V",
+                  (it.x & 3) == LY_CN ? ((it.x >> 2) & 31) : (it.x & 3) == LY_CNS ? ((it.x >> 2) & 7) : 4 * ((it.x >> 2) & 15),
                   (it.x & 3) == LY_VN && ((it.x >> 6) & 1) ? "p," : ",");
       }
       fprintf(stderr, "\n");
@@ -560,9 +684,10 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     }
     fprintf(stderr, "sum of step maxima %ld\n", total);
   }
-  // SAMD_LY_ABL (development, wrong results): 1 = lists without the re-sum items, 2 = without the CN items, 3 = barriers only
-  const int abl = getenv("SAMD_LY_ABL") ? atoi(getenv("SAMD_LY_ABL")) : 0;
-  std::vector<int32_t> rec_ptr, recs;                      // recs: 4 dwords each
+  std::vector<int32_t>& rec_ptr = L.rec_ptr;
+  std::vector<int32_t>& recs = L.recs;                     // 4 dwords each
+  std::vector<char> split_step(nsteps, 0);
+  for (int g = 0; g < G; ++g) split_step[cn_step[g]] = group_split[g];
   for (int wv = 0; wv < NW; ++wv) {
     rec_ptr.push_back((int32_t)(recs.size() / 4));
     long last = -1;                                         // position of the wave's last record
@@ -570,35 +695,51 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       last = (long)recs.size();
       recs.insert(recs.end(), {x, y, zz, w});
     };
+    auto barrier = [&]() {                                  // one more barrier behind the wave's last record
+      if (last < 0 || ((recs[last] >> 8) & 63) == LY_MAX_NB) push(LY_NOP, 0, 0, 0);
+      recs[last] += 1 << 8;
+    };
     for (int st = 0; st < nsteps; ++st) {
       auto& its = step_items[st][wv];
       std::stable_sort(its.begin(), its.end(), [](const Item& x, const Item& y) {
         const bool cx2 = x.key >= (1L << 40), cy2 = y.key >= (1L << 40);
         return cx2 != cy2 ? cx2 : x.key < y.key;
       });
+      // a step with split check-node items has a barrier in its middle (inside ly_cns_part); a wave without a part passes
+      // it from its list, BEFORE its re-sums of the step (they then run beside the parts' second half)
+      bool has_part = false;
+      for (auto& it : its) has_part = has_part || (it.x & 3) == LY_CNS;
+      if (split_step[st] && !has_part) barrier();
       for (auto& it : its) {
         const int kind = it.x & 3;
-        if ((kind == LY_VN && (abl & 1)) || (kind == LY_CN && (abl & 2))) continue;
+        if ((kind == LY_VN && (abl & 1)) || ((kind == LY_CN || kind == LY_CNS) && (abl & 2))) continue;
         push(it.x, it.y, it.zz, it.w);
       }
-      // the step's barrier: one more after the wave's last record
-      if (last < 0 || ((recs[last] >> 8) & 63) == LY_MAX_NB) push(LY_NOP, 0, 0, 0);
-      recs[last] += 1 << 8;
+      barrier();                                            // the step's barrier
     }
     recs[last] |= LY_LAST;
     push(LY_NOP | LY_LAST, 0, 0, 0);                        // the walker reads one record ahead
   }
   rec_ptr.push_back((int32_t)(recs.size() / 4));
+  return 0;
+  };   // build_lists
+  Lists whole, parts;
+  if (build_lists(false, whole)) return SAMD_OK;
+  const bool have_parts = abl == 0 && !getenv("SAMD_LY_NOSPLIT") && build_lists(true, parts) == 0 && parts.scratch_bytes > 0;
   h->ly_lds_bytes = (int)lds;
   h->ly_zero_off = zero_base / 4;
   h->ly_msg_floats = edges * z;
   h->ly_n_ext = n_ext;
   h->ly_groups = (int)groups.size();
-  int rc = upload(&h->ly_rec_ptr, rec_ptr.data(), rec_ptr.size());
-  if (rc == SAMD_OK) rc = upload(&h->ly_recs, recs.data(), recs.size());
+  h->ly_bp_lds_bytes = have_parts ? (int)lds + parts.scratch_bytes : 0;
+  int rc = upload(&h->ly_rec_ptr, whole.rec_ptr.data(), whole.rec_ptr.size());
+  if (rc == SAMD_OK) rc = upload(&h->ly_recs, whole.recs.data(), whole.recs.size());
+  if (rc == SAMD_OK && have_parts) rc = upload(&h->ly_bp_rec_ptr, parts.rec_ptr.data(), parts.rec_ptr.size());
+  if (rc == SAMD_OK && have_parts) rc = upload(&h->ly_bp_recs, parts.recs.data(), parts.recs.size());
+  if (rc == SAMD_OK && have_parts) rc = upload(&h->ly_bp_slot_tab, parts.slot_tab.data(), parts.slot_tab.size());
   if (rc == SAMD_OK) rc = upload(&h->ly_ent_tab, ent_tab.data(), ent_tab.size());
   if (rc == SAMD_OK) rc = upload(&h->ly_xt_index, xt_index.data(), xt_index.size());
-  if (rc == SAMD_OK) rc = upload(&h->ly_slot_tab, slot_tab.data(), slot_tab.size());
+  if (rc == SAMD_OK) rc = upload(&h->ly_slot_tab, whole.slot_tab.data(), whole.slot_tab.size());
   if (rc == SAMD_OK) h->ly_ok = 1;
   return rc;
 }
@@ -606,6 +747,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
 void free_onchip_ly_tables(samd_ldpc5g* h) {
   (void)hipFree(h->ly_rec_ptr); (void)hipFree(h->ly_recs); (void)hipFree(h->ly_ent_tab);
   (void)hipFree(h->ly_xt_index); (void)hipFree(h->ly_slot_tab);
+  (void)hipFree(h->ly_bp_rec_ptr); (void)hipFree(h->ly_bp_recs); (void)hipFree(h->ly_bp_slot_tab);
 }
 
 static int ly_grid(const samd_ldpc5g* h, int batch) {
@@ -652,10 +794,13 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;
-  hipLaunchKernelGGL(fn, dim3(ly_grid(h, batch)), dim3(1024), (size_t)h->ly_lds_bytes, st, llr, out, ws, rm, nbu, batch, num_iter,
-                     llr_max, off, hard_out, return_infobits, h->ly_msg_floats, h->ly_n_ext,
-                     h->ly_zero_off, h->ly_rec_ptr,
-                     reinterpret_cast<const int4*>(h->ly_recs), h->ly_ent_tab, h->ly_xt_index, h->ly_slot_tab);
+  // the boxplus rules walk the lists with split check-node items where the code has them (more LDS: the parts' scratch)
+  const bool parts = !minsum && h->ly_bp_lds_bytes > 0;
+  hipLaunchKernelGGL(fn, dim3(ly_grid(h, batch)), dim3(1024), (size_t)(parts ? h->ly_bp_lds_bytes : h->ly_lds_bytes), st, llr, out, ws,
+                     rm, nbu, batch, num_iter, llr_max, off, hard_out, return_infobits, h->ly_msg_floats, h->ly_n_ext,
+                     h->ly_zero_off, parts ? h->ly_bp_rec_ptr : h->ly_rec_ptr,
+                     reinterpret_cast<const int4*>(parts ? h->ly_bp_recs : h->ly_recs), h->ly_ent_tab, h->ly_xt_index,
+                     parts ? h->ly_bp_slot_tab : h->ly_slot_tab);
   return launch_status();
 }
 

@@ -62,13 +62,13 @@ def main():
         for n, (tag, ts, _) in enumerate(recs[:-1]):
             if tag == 0xF0:
                 continue
-            if (tag & 3) >= 2:
+            if (tag & 3) >= 1:
                 te = recs[n + 1][1]
-                kind = "C" if (tag & 3) == 2 else "V"
-                key = (tag >> 2) & 31 if kind == "C" else 4 * ((tag >> 2) & 15)
-                flag = ("f" if (tag >> 7) & 1 else "") if kind == "C" else ("p" if (tag >> 6) & 1 else "")
+                kind = {1: "P", 2: "C", 3: "V"}[tag & 3]
+                key = (tag >> 2) & 31 if kind == "C" else (tag >> 2) & 7 if kind == "P" else 4 * ((tag >> 2) & 15)
+                flag = ("f" if (tag >> 7) & 1 else "") if kind == "C" else ("f" if (tag >> 5) & 1 else "") if kind == "P" else ("p" if (tag >> 6) & 1 else "")
                 steps.setdefault(st, {}).setdefault(w, []).append((f"{kind}{key}{flag}", ts, te))
-            st += (tag >> 8) & 63
+            st += ((tag >> 8) & 63) + (1 if (tag & 3) == 1 else 0)            # (a split check-node part has a barrier inside)
     prev_end = 0
     for st in sorted(steps):
         ws = steps[st]
