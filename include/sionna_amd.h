@@ -143,8 +143,9 @@ int samd_ldpc5g_decode_engine(const samd_ldpc5g_t* h, int cn_mode);
 /* LDPC5GDecoder(cn_schedule="layered").call on chip (decoding.py:1383-1389: one sub-iteration per base row; _bp_iter
  * with an array schedule :463-520): rate recovery + num_iter layered iterations + output mapping in ONE kernel, the
  * sent check-node messages and the variable-node totals resident in LDS, channel LLRs and the state of the fused
- * degree-1 columns in `workspace` (samd_ldpc5g_decode_layered_workspace_bytes).  min-sum / offset-min-sum / boxplus-phi, codes with Z
- * a multiple of 64 and no partially pruned base row whose state fits in LDS (config C2); ..._supported() tells - the
+ * degree-1 columns in `workspace` (samd_ldpc5g_decode_layered_workspace_bytes).  min-sum / offset-min-sum / boxplus-phi,
+ * codes of any lifting size without a partially pruned base row whose state fits in LDS (config C2 does);
+ * ..._supported() tells - the
  * scheduled HBM-resident engine (samd_ldpc_bp_decode_scheduled_f32) takes everything else.  Same bits as that engine and
  * as the oracle's literal "update every variable node after every layer". */
 int samd_ldpc5g_decode_layered_supported(const samd_ldpc5g_t* h, int cn_mode);

@@ -2,8 +2,8 @@
 //
 // Replaces LDPC5GDecoder(cn_schedule="layered").call (reference src/sionna/phy/fec/ldpc/decoding.py:1383-1389: one
 // sub-iteration per base row = Z check nodes; _bp_iter with an array schedule :463-520: check-node update of the layer,
-// then the variable-node update) for codes like those of the explicit-message engine's grouped kernel (Z a multiple of 64, no
-// partially pruned base row, messages in LDS).  Until round 3 the schedule ran on the HBM-resident engine with two
+// then the variable-node update) for the codes without a partially pruned base row whose messages fit in LDS (any lifting
+// size; a chunk = 64 lifted copies, the last one partly filled when Z is not a multiple of 64).  Until round 3 the schedule ran on the HBM-resident engine with two
 // launches per layer: 920 launches and 79 k decodes/s for 10 iterations at config C2.
 //
 // State of one codeword (one workgroup, 16 waves):
@@ -227,7 +227,10 @@ __device__ __forceinline__ void ly_vn_col(const int32_t* __restrict__ ent, unsig
   SAMD_LY_SUB(3)
 }
 
-template <bool POW2, int MODE>
+// PART: the lifting size is not a multiple of 64 - the last 64-lane chunk of a row / column is partly filled, and the
+// bodies of its items run under `lane < Z - 64 chunk` (a template flag: the full-chunk codes, C2 among them, keep a
+// walker without the exec mask).
+template <bool POW2, int MODE, bool PART>
 __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ ws, RateMatch p, int nbu, int batch,
     int num_iter, float llr_max, float offset, int hard_out, int return_infobits, int msg_floats, int n_ext,
@@ -268,13 +271,13 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
     for (int q = 0; q < LY_CN_SLOTS; ++q) {
       const int li = slots[q];
       st[LY_ST_CO + q] = 0.f;
-      st[LY_ST_LF + q] = (li >= 0) ? llr[li + lane] : 0.f;
+      st[LY_ST_LF + q] = (li >= 0) ? llr[min(li + lane, nx - 1)] : 0.f;   // (lanes past a partial chunk: never used)
     }
 #pragma unroll
     for (int q = 0; q < LY_VN_SLOTS; ++q) {
       const int li = slots[2 * LY_CN_SLOTS + q];
       st[LY_ST_P + q] = 0.f;
-      st[LY_ST_L + q] = (li >= 0) ? llr[li + lane] : 0.f;
+      st[LY_ST_L + q] = (li >= 0) ? llr[min(li + lane, nx - 1)] : 0.f;
     }
 
     // Records are wave-uniform: scalar loads, one record ahead.
@@ -294,10 +297,14 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
         // VN: s0, s1 = prefixes of the unit's chunk(s), s2, s3 = their channel LLRs; CN: s0 = c2v of the fused edge,
         // s2 = its channel LLR.  A body that does not use a value leaves it as read, so writing it back is harmless.
         // (w = the indices i0 | i1 << 8 of s0 / s1 in the register file; s2 / s3 are 8 above)
+        const bool act = !PART || (zq4 >> 2) < z;                        // lifted copy 64 chunk + lane exists
         const bool is_vn = (cx & 3) == LY_VN;
         const int i0 = cur.w & 31, i1 = (cur.w >> 8) & 31;
         float s0 = st[i0], s1 = st[i1], s2 = st[i0 + 8], s3 = st[i1 + 8];
-        if (is_vn) {
+        if (!act) {
+          // (a lane past the lifting size: no body; the barrier of a split check-node part is executed by the wave's
+          // active lanes)
+        } else if (is_vn) {
           const unsigned ax = (unsigned)cy + zq4;
           if ((cx >> 14) & 1) {                                          // the column's first edge: the prefix restarts
             s0 = 0.f;
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
 #pragma unroll
     for (int q = 0; q < LY_CN_SLOTS; ++q) {
       const int ci = slots[LY_CN_SLOTS + q];
-      if (ci >= 0) cext[ci + lane] = st[LY_ST_CO + q];
+      if (ci >= 0 && (!PART || ci % (int)z + lane < (int)z)) cext[ci + lane] = st[LY_ST_CO + q];
     }
     __syncthreads();
     // ---------------- output (decoding.py:620-626, 1486-1531): marginal of a non-fused column = xtot, of a fused
@@ -393,7 +400,9 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   h->ly_ok = 0;
   const int z = h->z, NW = 16;
   const int ncu = (h->n_cn + z - 1) / z, nbu = (h->n_vn + z - 1) / z;
-  if (z % 64 != 0 || h->n_cn % z != 0 || h->n_vn % z != 0 || h->mb > 255 || h->nb > 255 || nbu > 0xFFFF) return SAMD_OK;
+  // (lifting sizes below 40 stay on the HBM-resident engine: one codeword per CU on a single chunk with half of its lanes
+  // idle loses to many codewords side by side - Z = 26: 1.55 against 2.58 M decodes/s, layered_rate_codes_r03z.txt)
+  if (h->n_cn % z != 0 || h->n_vn % z != 0 || h->mb > 255 || h->nb > 255 || nbu > 0xFFFF || z < 40 || z > 64 * 255) return SAMD_OK;
   static const int degs[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
   std::vector<int> col_deg(h->nb, 0);
   for (int r = 0; r < ncu; ++r)
@@ -479,7 +488,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     for (int q = 0; q < 3; ++q) { ent_tab.push_back(zero_base); ent_tab.push_back(0); }
   }
   ent_tab.resize(ent_tab.size() + 64, 0);
-  const int chunks = z / 64;
+  const int chunks = (z + 63) / 64;                          // (the last one partly filled when Z is not a multiple of 64)
   struct Lists { std::vector<int32_t> rec_ptr, recs, slot_tab; int scratch_bytes = 0; };
   // SAMD_LY_ABL (development, wrong results): 1 = lists without the re-sum items, 2 = without the CN items, 3 = barriers only
   const int abl = getenv("SAMD_LY_ABL") ? atoi(getenv("SAMD_LY_ABL")) : 0;
@@ -568,7 +577,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   for (int c = 0; c < nbu; ++c) {
     if (xt_of_col[c] < 0) continue;
     for (int q = 0; q < chunks; ++q) {
-      const int pair = (col_deg[c] <= std::min(12, pair_max) && q + 1 < chunks) ? 1 : 0;
+      const int pair = (col_deg[c] <= std::min(12, pair_max) && z - 64 * (q + 1) >= 64) ? 1 : 0;   // two FULL chunks
       long cost = 0;
       for (auto& tj : touch[c]) cost += item_cost(c, tj.second, pair);
       units.push_back({c, q, pair, -1, -1, cost});
@@ -786,10 +795,11 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const bool pow2 = (h->z & (h->z - 1)) == 0;
   typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, float, float, int, int, int, int, int,
                          const int32_t*, const int4*, const int32_t*, const int32_t*, const int32_t*);
-  static const kern_t kerns[6] = {ldpc5g_decode_ly_kernel<false, SAMD_CN_MINSUM>, ldpc5g_decode_ly_kernel<true, SAMD_CN_MINSUM>,
-                                  ldpc5g_decode_ly_kernel<false, SAMD_CN_BOXPLUS_PHI>, ldpc5g_decode_ly_kernel<true, SAMD_CN_BOXPLUS_PHI>,
-                                  ldpc5g_decode_ly_kernel<false, SAMD_CN_BOXPLUS_PHI_FAST>, ldpc5g_decode_ly_kernel<true, SAMD_CN_BOXPLUS_PHI_FAST>};
-  const kern_t fn = kerns[(minsum ? 0 : cn_mode == SAMD_CN_BOXPLUS_PHI ? 2 : 4) + (pow2 ? 1 : 0)];
+#define SAMD_LY_K(M) {{ldpc5g_decode_ly_kernel<false, M, false>, ldpc5g_decode_ly_kernel<true, M, false>}, \
+                      {ldpc5g_decode_ly_kernel<false, M, true>, ldpc5g_decode_ly_kernel<true, M, true>}}
+  static const kern_t kerns[3][2][2] = {SAMD_LY_K(SAMD_CN_MINSUM), SAMD_LY_K(SAMD_CN_BOXPLUS_PHI), SAMD_LY_K(SAMD_CN_BOXPLUS_PHI_FAST)};
+#undef SAMD_LY_K
+  const kern_t fn = kerns[minsum ? 0 : cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : 2][h->z % 64 != 0 ? 1 : 0][pow2 ? 1 : 0];
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};

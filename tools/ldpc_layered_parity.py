@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stress check of the on-chip LAYERED decoder (csrc/ldpc5g_onchip_ly.hip; evidence / development aid, uses oracle/):
-random 5G code sizes whose lifting size is a multiple of 64, both base graphs, rates 1/5 ... 0.9; cn_schedule="layered"
+random 5G code sizes (first argument: how many; "any" as second argument: every lifting size, default: multiples of
+64), both base graphs, rates 1/5 ... 0.9; cn_schedule="layered"
 soft outputs for min-sum and boxplus-phi must equal the oracle's literal form (check-node update of the layer, then every
 variable node) bit for bit - on the on-chip engine where it takes the code (reported per row), else on the scheduled
 HBM-resident engine.
@@ -19,11 +20,13 @@ from oracle import ldpc_bp as obp
 
 _ffi.device()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+ANY = len(sys.argv) > 2 and sys.argv[2] == "any"
+ALL_Z = sorted({a * 2 ** j for a in (2, 3, 5, 7, 9, 11, 13, 15) for j in range(8) if a * 2 ** j <= 384})
 rng = np.random.default_rng(2027)
 rows, bad, tried = [], 0, 0
 while len(rows) < N and tried < 40 * N:
     tried += 1
-    z = int(rng.choice([64, 128, 192, 256, 320, 384]))
+    z = int(rng.choice(ALL_Z)) if ANY else int(rng.choice([64, 128, 192, 256, 320, 384]))
     bg = str(rng.choice(["bg1", "bg2"]))
     kb = 22 if bg == "bg1" else 10
     k = kb * z - int(rng.integers(0, 16))                      # (a few filler bits)
