@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B of two builds of the library on one box: decode-only C2 bench (min-sum), alternating, 3 rounds
+# usage: bash tools/lib_ab.sh <libA> <libB>
+for r in 1 2 3; do
+  for L in "$1" "$2"; do
+    echo "$(basename $L) $(SAMD_LIB=$PWD/$L timeout 300 python bench.py --steps 10 --warmup 2 --no-extra --also none --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["ber"])')"
+  done
+done
