@@ -730,6 +730,16 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     push(LY_NOP | LY_LAST, 0, 0, 0);                        // the walker reads one record ahead
   }
   rec_ptr.push_back((int32_t)(recs.size() / 4));
+  // every wave must pass the same number of workgroup barriers per iteration (a split check-node part has one inside):
+  // a list that does not is a deadlock on the GPU, so it is checked here and the code left to the HBM-resident engine
+  long want = -1;
+  for (int wv = 0; wv < NW; ++wv) {
+    long nbar = 0;
+    for (int32_t t = rec_ptr[wv]; t < rec_ptr[wv + 1]; ++t)
+      nbar += ((recs[4 * (size_t)t] >> 8) & 63) + ((recs[4 * (size_t)t] & 3) == LY_CNS ? 1 : 0);
+    if (want < 0) want = nbar;
+    if (nbar != want) return 1;
+  }
   return 0;
   };   // build_lists
   Lists whole, parts;

@@ -1,0 +1,6 @@
+#!/bin/bash
+# decode-only C2 bench (min-sum) under the LPT cost-model / priority knobs of the explicit-message engine (one box)
+run() { echo "[$1] $(env $1 timeout 300 python bench.py --steps 10 --warmup 2 --no-extra --also none --no-cpu-baseline 2>/dev/null | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"], d["ber"])')"; }
+run "A=0"
+for v in "SAMD_MS_CN_SLOPE=28" "SAMD_MS_CN_SLOPE=44" "SAMD_MS_CN_OVH=300" "SAMD_MS_CN_OVH=500" "SAMD_MS_VN_OVH=150" "SAMD_MS_VN_OVH=300" "SAMD_MS_NOPRIO=1" "SAMD_MS_NOROT=1" "SAMD_MS_LDSBAR=1" "SAMD_MS_VN_SINGLE=1"; do run "$v"; done
+run "A=0"
