@@ -57,7 +57,7 @@ struct samd_ldpc5g {
   int32_t* sp_col_ent = nullptr; int32_t* sp_cn_ptr = nullptr; int32_t* sp_vn_ptr = nullptr;
   int32_t* sp_cn_list = nullptr; int32_t* sp_vn_list = nullptr;
   // on-chip layered decoder (ldpc5g_onchip_ly.hip): record lists per wave, row / column edge tables
-  int ly_ok = 0, ly_lds_bytes = 0, ly_msg_floats = 0, ly_n_ext = 0, ly_groups = 0, ly_zero_off = 0;
+  int ly_ok = 0, ly_lds_bytes = 0, ly_msg_floats = 0, ly_n_ext = 0, ly_groups = 0, ly_zero_off = 0, ly_waves = 16;
   int32_t* ly_rec_ptr = nullptr; int32_t* ly_recs = nullptr; int32_t* ly_ent_tab = nullptr;
   int32_t* ly_xt_index = nullptr; int32_t* ly_slot_tab = nullptr;
   int32_t* ly_bp_rec_ptr = nullptr; int32_t* ly_bp_recs = nullptr; int32_t* ly_bp_slot_tab = nullptr; int ly_bp_lds_bytes = 0;

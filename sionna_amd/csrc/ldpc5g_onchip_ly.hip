@@ -234,11 +234,11 @@ template <bool POW2, int MODE, bool PART>
 __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
     const float* __restrict__ llr_in, float* __restrict__ out, float* __restrict__ ws, RateMatch p, int nbu, int batch,
     int num_iter, float llr_max, float offset, int hard_out, int return_infobits, int msg_floats, int n_ext,
-    int zero_off, const int32_t* __restrict__ rec_ptr, const int4* __restrict__ recs, const int32_t* __restrict__ ent_tab,
+    int zero_off, int nt, const int32_t* __restrict__ rec_ptr, const int4* __restrict__ recs, const int32_t* __restrict__ ent_tab,
     const int32_t* __restrict__ xt_index, const int32_t* __restrict__ slot_tab) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   if ((unsigned)(size_t)(lds_f32*)smem != 0u) __builtin_trap();      // LDS addressed by plain byte offsets (lds_ld)
-  constexpr int NT = 1024;
+  const int NT = nt;                                                   // threads per codeword: 16, 8 or 4 waves
   const unsigned z = (unsigned)p.z, z4 = 4u * z;
   const unsigned zw = POW2 ? z4 - 1u : z4;
   unsigned zwv;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
 // ------------------------------------------------------------------------------------------------ host tables
 int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row) {
   h->ly_ok = 0;
-  const int z = h->z, NW = 16;
+  const int z = h->z;
   const int ncu = (h->n_cn + z - 1) / z, nbu = (h->n_vn + z - 1) / z;
   // (lifting sizes below 40 stay on the HBM-resident engine: one codeword per CU on a single chunk with half of its lanes
   // idle loses to many codewords side by side - Z = 26: 1.55 against 2.58 M decodes/s, layered_rate_codes_r03z.txt)
@@ -495,7 +495,8 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // The lists are built twice: whole check-node items (min-sum: ~13 instructions per edge), and - `split` - items cut into
   // parts of 2 (row degree <= 10) or 4 edges for the boxplus rules (~100 instructions per edge), see ly_cns_part.
   // Returns 1 when the code does not fit the engine.
-  auto build_lists = [&](bool split, Lists& L) -> int {
+  auto build_lists = [&](bool split, int NW, Lists& L) -> int {
+  L = Lists();
   // ---- ownership.  A check-node item (row, chunk) - or each of its parts - and a variable-node unit (column, chunk or pair
   // of chunks) run on the same wave in every iteration, which keeps their private state in that wave's registers.
   // CN items: the waves of a group's step are distinct; among those the one with the fewest fused slots, then the
@@ -742,9 +743,25 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   }
   return 0;
   };   // build_lists
+  // Waves per codeword: 16 waves are resident per CU (128 registers each); a codeword whose state is small shares the CU
+  // with others - 2 workgroups of 8 waves or 4 of 4 - instead of leaving most of 16 waves waiting at its barriers (a step
+  // works one to four waves).  The footprint counts the scratch of the split check-node items.
+  int max_scr = 0;
+  for (auto& g : groups) {
+    int scr = 0;
+    for (int r : g) scr += (int)by_row[r].size() * 256 * chunks;
+    max_scr = std::max(max_scr, scr);
+  }
   Lists whole, parts;
-  if (build_lists(false, whole)) return SAMD_OK;
-  const bool have_parts = abl == 0 && !getenv("SAMD_LY_NOSPLIT") && build_lists(true, parts) == 0 && parts.scratch_bytes > 0;
+  int NW = 0;
+  for (int nw : {4, 8, 16}) {
+    if (const char* e = getenv("SAMD_LY_WAVES")) { if (atoi(e) != nw) continue; }
+    else if (nw < 16 && ((int)lds + max_scr) * (16 / nw) > 160 * 1024) continue;
+    if (build_lists(false, nw, whole) == 0) { NW = nw; break; }
+  }
+  if (NW == 0) return SAMD_OK;
+  const bool have_parts = abl == 0 && !getenv("SAMD_LY_NOSPLIT") && build_lists(true, NW, parts) == 0 && parts.scratch_bytes > 0;
+  h->ly_waves = NW;
   h->ly_lds_bytes = (int)lds;
   h->ly_zero_off = zero_base / 4;
   h->ly_msg_floats = edges * z;
@@ -773,8 +790,7 @@ static int ly_grid(const samd_ldpc5g* h, int batch) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const int per_cu = std::max(1, (int)((160 * 1024) / std::max(1, h->ly_lds_bytes)));
-  int grid = std::min(batch, cus * std::min(per_cu, 1));
+  int grid = std::min(batch, cus * (16 / std::max(4, h->ly_waves)));
   if (const char* e = getenv("SAMD_ONCHIP_GRID")) grid = std::min(grid, std::max(1, atoi(e)));
   return grid;
 }
@@ -803,7 +819,7 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   }
   float* ws = reinterpret_cast<float*>(align_up((size_t)workspace, 256));
   const bool pow2 = (h->z & (h->z - 1)) == 0;
-  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, float, float, int, int, int, int, int,
+  typedef void (*kern_t)(const float*, float*, float*, RateMatch, int, int, int, float, float, int, int, int, int, int, int,
                          const int32_t*, const int4*, const int32_t*, const int32_t*, const int32_t*);
 #define SAMD_LY_K(M) {{ldpc5g_decode_ly_kernel<false, M, false>, ldpc5g_decode_ly_kernel<true, M, false>}, \
                       {ldpc5g_decode_ly_kernel<false, M, true>, ldpc5g_decode_ly_kernel<true, M, true>}}
@@ -816,9 +832,9 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;
   // the boxplus rules walk the lists with split check-node items where the code has them (more LDS: the parts' scratch)
   const bool parts = !minsum && h->ly_bp_lds_bytes > 0;
-  hipLaunchKernelGGL(fn, dim3(ly_grid(h, batch)), dim3(1024), (size_t)(parts ? h->ly_bp_lds_bytes : h->ly_lds_bytes), st, llr, out, ws,
+  hipLaunchKernelGGL(fn, dim3(ly_grid(h, batch)), dim3(64 * h->ly_waves), (size_t)(parts ? h->ly_bp_lds_bytes : h->ly_lds_bytes), st, llr, out, ws,
                      rm, nbu, batch, num_iter, llr_max, off, hard_out, return_infobits, h->ly_msg_floats, h->ly_n_ext,
-                     h->ly_zero_off, parts ? h->ly_bp_rec_ptr : h->ly_rec_ptr,
+                     h->ly_zero_off, 64 * h->ly_waves, parts ? h->ly_bp_rec_ptr : h->ly_rec_ptr,
                      reinterpret_cast<const int4*>(parts ? h->ly_bp_recs : h->ly_recs), h->ly_ent_tab, h->ly_xt_index,
                      parts ? h->ly_bp_slot_tab : h->ly_slot_tab);
   return launch_status();
