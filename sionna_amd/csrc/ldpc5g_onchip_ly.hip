@@ -400,9 +400,11 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   h->ly_ok = 0;
   const int z = h->z;
   const int ncu = (h->n_cn + z - 1) / z, nbu = (h->n_vn + z - 1) / z;
-  // (lifting sizes below 40 stay on the HBM-resident engine: one codeword per CU on a single chunk with half of its lanes
-  // idle loses to many codewords side by side - Z = 26: 1.55 against 2.58 M decodes/s, layered_rate_codes_r03z.txt)
-  if (h->n_cn % z != 0 || h->n_vn % z != 0 || h->mb > 255 || h->nb > 255 || nbu > 0xFFFF || z < 40 || z > 64 * 255) return SAMD_OK;
+  // (lifting sizes below 16 stay on the HBM-resident engine, which runs many codewords side by side: Z = 11 is a tie,
+  // 7.8 against 8.1 M decodes/s; from Z = 18 on the on-chip engine with 4 waves per codeword wins, 5.2 against 3.9 M -
+  // layered_rate_smallz_r03z.txt)
+  if (h->n_cn % z != 0 || h->n_vn % z != 0 || h->mb > 255 || h->nb > 255 || nbu > 0xFFFF ||
+      z < (getenv("SAMD_LY_MINZ") ? atoi(getenv("SAMD_LY_MINZ")) : 16) || z > 64 * 255) return SAMD_OK;
   static const int degs[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
   std::vector<int> col_deg(h->nb, 0);
   for (int r = 0; r < ncu; ++r)

@@ -364,7 +364,7 @@ def test_layered_5g_vs_oracle_and_convergence(phy):
 
 @pytest.mark.parametrize("k,n,bg,m", [(2816, 8448, "bg1", 6), (1280, 3840, "bg2", 4), (2816, 5632, "bg1", None),
                                       (1408, 4224, "bg1", None), (1920, 5760, "bg2", 2),           # Z = 128, 128, 128, 64, 192
-                                      (768, 1536, None, 2), (1024, 2048, "bg1", None), (480, 1440, None, 2),   # Z = 80, 48, 60
+                                      (768, 1536, None, 2), (1024, 2048, "bg1", None), (480, 1440, None, 2), (200, 600, None, 2),   # Z = 80, 48, 60, 26
                                       (3000, 6000, "bg1", None)])                                  # Z = 144 (partly filled chunks)
 def test_layered_on_chip_bit_exact(phy, k, n, bg, m):
     """cn_schedule="layered" on the on-chip layered engine (csrc/ldpc5g_onchip_ly.hip: c2v and variable-node totals in
