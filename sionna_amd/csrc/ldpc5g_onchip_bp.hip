@@ -337,6 +337,53 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     const int per_simd = std::max(1, h->bp_waves / 4);
     for (int wv = 0; wv < h->bp_waves; ++wv) cap[wv] = cls[std::min(3, (wv / 4) * 4 / per_simd)];
   }
+  // Granularity: C2 has 29 variable-node items for 16 waves - the four single-chunk items of the degree-30 / 28 columns
+  // are a wave's whole phase and leave it under-loaded, the other waves carry two pair items.  A pair item of the busiest
+  // wave is cut into its two single-chunk items (a little more work in total: one dependency chain each) as long as
+  // that shortens the longest wave under the LPT rule (SAMD_MS_VN_REFINE = number of cuts tried, 0 = off): +0.5 % at C2,
+  // profiles/r03b/ms_refine_r03z.txt.  A half costs half the pair + `extra` (item trace: V12 pair 3.6 k cycles, a
+  // single-chunk item of that degree ~2.4 k).
+  // Lifting sizes of two chunks only (Z = 128: +1.3 % at C2, +1.1 % at k=2816 n=5632; codes of three or four chunks have
+  // enough items per wave and lose 5 % - ms_refine_codes_r03z.txt).
+  if (const int tries = getenv("SAMD_MS_VN_REFINE") ? atoi(getenv("SAMD_MS_VN_REFINE")) : (chunks == 2 ? 8 : 0)) {
+    const int extra = getenv("SAMD_MS_VN_REFINE_COST") ? atoi(getenv("SAMD_MS_VN_REFINE_COST")) : 40;
+    auto makespan = [&](const std::vector<std::pair<int, int32_t>>& items, std::vector<int>* owner) {
+      std::vector<size_t> order(items.size());
+      std::iota(order.begin(), order.end(), 0);
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].first > items[b].first; });
+      std::vector<double> load(h->bp_waves, 0.0);
+      if (owner) owner->assign(items.size(), 0);
+      for (size_t i : order) {
+        int w = 0;
+        for (int q = 1; q < h->bp_waves; ++q)
+          if ((load[q] + items[i].first + 3) / cap[q] < (load[w] + items[i].first + 3) / cap[w]) w = q;
+        load[w] += items[i].first + 3;
+        if (owner) (*owner)[i] = w;
+      }
+      int mw = 0;
+      for (int q = 1; q < h->bp_waves; ++q) if (load[q] > load[mw]) mw = q;
+      return std::make_pair(load[mw], mw);
+    };
+    for (int t = 0; t < tries; ++t) {
+      std::vector<int> owner;
+      const auto base = makespan(vi2, &owner);
+      int best = -1;
+      double best_m = base.first;
+      for (size_t i = 0; i < vi2.size(); ++i) {
+        if (owner[i] != base.second || !((vi2[i].second >> 24) & 1)) continue;
+        auto trial = vi2;
+        const int c = trial[i].second & 0xFF, q = (trial[i].second >> 8) & 0xFF, half = trial[i].first / 2 + extra;
+        trial[i] = {half, c | (q << 8)};
+        trial.push_back({half, c | ((q + 1) << 8)});
+        const double m = makespan(trial, nullptr).first;
+        if (m < best_m) { best_m = m; best = (int)i; }
+      }
+      if (best < 0) break;
+      const int c = vi2[best].second & 0xFF, q = (vi2[best].second >> 8) & 0xFF, half = vi2[best].first / 2 + extra;
+      vi2[best] = {half, c | (q << 8)};
+      vi2.push_back({half, c | ((q + 1) << 8)});
+    }
+  }
   lpt_schedule(ci2, h->bp_waves, &mcp, &mcl, &cap);
   lpt_schedule(vi2, h->bp_waves, &mvp, &mvl, &cap);
   const std::vector<int> cprio = item_priorities(ci2, mcp, mcl), vprio = item_priorities(vi2, mvp, mvl);
