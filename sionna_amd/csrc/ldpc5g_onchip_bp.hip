@@ -345,19 +345,18 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // single-chunk item of that degree ~2.4 k).
   // Lifting sizes of two chunks only (Z = 128: +1.3 % at C2, +1.1 % at k=2816 n=5632; codes of three or four chunks have
   // enough items per wave and lose 5 % - ms_refine_codes_r03z.txt).
-  if (const int tries = getenv("SAMD_MS_VN_REFINE") ? atoi(getenv("SAMD_MS_VN_REFINE")) : (chunks == 2 ? 8 : 0)) {
-    const int extra = getenv("SAMD_MS_VN_REFINE_COST") ? atoi(getenv("SAMD_MS_VN_REFINE_COST")) : 40;
-    auto makespan = [&](const std::vector<std::pair<int, int32_t>>& items, std::vector<int>* owner) {
-      std::vector<size_t> order(items.size());
+  auto refine = [&](std::vector<std::pair<int, int32_t>>& items, int tries, int extra, auto&& may_cut) {
+    auto makespan = [&](const std::vector<std::pair<int, int32_t>>& its, std::vector<int>* owner) {
+      std::vector<size_t> order(its.size());
       std::iota(order.begin(), order.end(), 0);
-      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return items[a].first > items[b].first; });
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return its[a].first > its[b].first; });
       std::vector<double> load(h->bp_waves, 0.0);
-      if (owner) owner->assign(items.size(), 0);
+      if (owner) owner->assign(its.size(), 0);
       for (size_t i : order) {
         int w = 0;
         for (int q = 1; q < h->bp_waves; ++q)
-          if ((load[q] + items[i].first + 3) / cap[q] < (load[w] + items[i].first + 3) / cap[w]) w = q;
-        load[w] += items[i].first + 3;
+          if ((load[q] + its[i].first + 3) / cap[q] < (load[w] + its[i].first + 3) / cap[w]) w = q;
+        load[w] += its[i].first + 3;
         if (owner) (*owner)[i] = w;
       }
       int mw = 0;
@@ -366,12 +365,12 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     };
     for (int t = 0; t < tries; ++t) {
       std::vector<int> owner;
-      const auto base = makespan(vi2, &owner);
+      const auto base = makespan(items, &owner);
       int best = -1;
       double best_m = base.first;
-      for (size_t i = 0; i < vi2.size(); ++i) {
-        if (owner[i] != base.second || !((vi2[i].second >> 24) & 1)) continue;
-        auto trial = vi2;
+      for (size_t i = 0; i < items.size(); ++i) {
+        if (owner[i] != base.second || !((items[i].second >> 24) & 1) || !may_cut(items[i].second & 0xFF)) continue;
+        auto trial = items;
         const int c = trial[i].second & 0xFF, q = (trial[i].second >> 8) & 0xFF, half = trial[i].first / 2 + extra;
         trial[i] = {half, c | (q << 8)};
         trial.push_back({half, c | ((q + 1) << 8)});
@@ -379,11 +378,19 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
         if (m < best_m) { best_m = m; best = (int)i; }
       }
       if (best < 0) break;
-      const int c = vi2[best].second & 0xFF, q = (vi2[best].second >> 8) & 0xFF, half = vi2[best].first / 2 + extra;
-      vi2[best] = {half, c | (q << 8)};
-      vi2.push_back({half, c | ((q + 1) << 8)});
+      const int c = items[best].second & 0xFF, q = (items[best].second >> 8) & 0xFF, half = items[best].first / 2 + extra;
+      items[best] = {half, c | (q << 8)};
+      items.push_back({half, c | ((q + 1) << 8)});
     }
-  }
+  };
+  refine(vi2, getenv("SAMD_MS_VN_REFINE") ? atoi(getenv("SAMD_MS_VN_REFINE")) : (chunks == 2 ? 8 : 0),
+         getenv("SAMD_MS_VN_REFINE_COST") ? atoi(getenv("SAMD_MS_VN_REFINE_COST")) : 40, [](int) { return true; });
+  // the same for the check-node pair items (the grouped kernel has the single-chunk bodies under key + 64)
+  // (C2: +2 %, profiles/r03b/ms_refine_cn3_r03z.txt; rows of degree 5 / 6 with a fused column only - every further
+  // single-chunk body in the kernel slows the items that do not use it: all 17 bodies -2 %, four -1.4 %, two -0.3 %)
+  refine(ci2, getenv("SAMD_MS_CN_REFINE") ? atoi(getenv("SAMD_MS_CN_REFINE")) : (chunks == 2 ? 4 : 0),
+         getenv("SAMD_MS_CN_REFINE_COST") ? atoi(getenv("SAMD_MS_CN_REFINE_COST")) : 150,
+         [&](int r) { const int d = (int)by_row[r].size(); return fused_col[r] >= 0 && d >= 5 && d <= 6; });
   lpt_schedule(ci2, h->bp_waves, &mcp, &mcl, &cap);
   lpt_schedule(vi2, h->bp_waves, &mvp, &mvl, &cap);
   const std::vector<int> cprio = item_priorities(ci2, mcp, mcl), vprio = item_priorities(vi2, mvp, mvl);
@@ -464,9 +471,8 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
           It it;
           it.cost = cost_in(phase ? vi2 : ci2, d) + 3;
           if (!phase) {
-            if (!pr) { ok = false; break; }
             const int f = fused_col[idx] >= 0;
-            it.key = (int)by_row[idx].size() | (f << 5);
+            it.key = (int)by_row[idx].size() | (f << 5) | (pr ? 0 : 64);      // (64: a single chunk of the row)
             it.x = (row_off[idx] & 0x3FFFF) + 256 * q;
             it.y = f ? fused_col[idx] * z + q * 64 : 0;
           } else {

@@ -1,5 +1,5 @@
-"""Flooding min-sum decode rate (20 iterations) of a few 5G code sizes with and without the variable-node item refinement
-(SAMD_MS_VN_REFINE=0); handles are created per setting."""
+"""Flooding min-sum decode rate (20 iterations) of a few 5G code sizes with and without the item refinement
+(SAMD_MS_VN_REFINE=0 SAMD_MS_CN_REFINE=0); handles are created per setting."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,10 +10,11 @@ for k, n, bg in ((2816, 8448, "bg1"), (2816, 5632, "bg1"), (1408, 4224, "bg1"), 
     B = 16384
     res = []
     for env in ("0", None):
-        if env is None:
-            os.environ.pop("SAMD_MS_VN_REFINE", None)
-        else:
-            os.environ["SAMD_MS_VN_REFINE"] = env
+        for name in ("SAMD_MS_VN_REFINE", "SAMD_MS_CN_REFINE"):
+            if env is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = env
         enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=2, bg=bg)
         u = phy.mapping.BinarySource()([B, k])
         no = phy.utils.ebnodb2no(2.0, 2, k / n)
