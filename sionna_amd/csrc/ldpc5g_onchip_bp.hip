@@ -384,7 +384,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     }
   };
   refine(vi2, getenv("SAMD_MS_VN_REFINE") ? atoi(getenv("SAMD_MS_VN_REFINE")) : (chunks == 2 ? 8 : 0),
-         getenv("SAMD_MS_VN_REFINE_COST") ? atoi(getenv("SAMD_MS_VN_REFINE_COST")) : 40, [](int) { return true; });
+         getenv("SAMD_MS_VN_REFINE_COST") ? atoi(getenv("SAMD_MS_VN_REFINE_COST")) : 70, [](int) { return true; });
   // the same for the check-node pair items (the grouped kernel has the single-chunk bodies under key + 64)
   // (C2: +2 %, profiles/r03b/ms_refine_cn3_r03z.txt; rows of degree 5 / 6 with a fused column only - every further
   // single-chunk body in the kernel slows the items that do not use it: all 17 bodies -2 %, four -1.4 %, two -0.3 %)
