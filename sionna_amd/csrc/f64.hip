@@ -472,7 +472,7 @@ extern "C" int samd_ldpc_bp_decode_f64(const samd_ldpc_graph_t* g, const samd_ld
 extern "C" int samd_ldpc5g_rate_recover_f64(const samd_ldpc5g_t* h, const double* llr, double* out, int batch, double llr_max,
                                             void* stream) {
   SAMD_REQUIRE(h && llr && out && batch > 0, "bad argument");
-  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  const RateMatch rm = make_rate_match(h);
   hipLaunchKernelGGL(rate_recover64_kernel, dim3((h->n_vn + 255) / 256, ygrid(batch)), dim3(256), 0, (hipStream_t)stream, llr, out,
                      rm, llr_max, batch);
   return launch_status();
@@ -480,7 +480,7 @@ extern "C" int samd_ldpc5g_rate_recover_f64(const samd_ldpc5g_t* h, const double
 
 extern "C" int samd_ldpc5g_extract_codeword_f64(const samd_ldpc5g_t* h, const double* x_hat, double* out, int batch, void* stream) {
   SAMD_REQUIRE(h && x_hat && out && batch > 0, "bad argument");
-  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  const RateMatch rm = make_rate_match(h);
   hipLaunchKernelGGL(extract64_kernel, dim3((h->n + 255) / 256, ygrid(batch)), dim3(256), 0, (hipStream_t)stream, x_hat, out, rm,
                      batch);
   return launch_status();

@@ -194,7 +194,20 @@ __device__ __forceinline__ void onchip_setprio(int p) {
 // ------------------------------------------------------------------ index maps (shared)
 struct RateMatch {
   int k, n, z, k_ldpc, n_vn, m_int;
+  // q = n / m_int (rows of the output interleaver) and ceil(2^30 / q): t / q = umulhi(4 t, q_magic) exactly for t, q < 2^15
+  // (t (q_magic q - 2^30) < t q < 2^30) - the two integer divisions of rate recovery cost ~80 instructions per LLR, a third
+  // of the fixed cost per codeword of the on-chip decoders.  0: divide.
+  int q = 0;
+  unsigned q_magic = 0;
 };
+inline RateMatch make_rate_match(const samd_ldpc5g* h) {
+  RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  if (h->m_int > 0 && h->n < (1 << 15)) {
+    rm.q = h->n / h->m_int;
+    rm.q_magic = (unsigned)(((1ull << 30) + (unsigned long long)rm.q - 1ull) / (unsigned long long)rm.q);
+  }
+  return rm;
+}
 
 // position t of c_short / x_short (before the output interleaver) for output index o
 // (encoding.py:238-244: out[o] = c_short[perm[o]], perm[i + j*m] = i*(n/m) + j)
@@ -220,8 +233,13 @@ __device__ __forceinline__ float recover_llr(const RateMatch& p, const float* __
   if (t < 0 || t >= p.n) return 0.f;               // punctured
   int o = t;
   if (p.m_int > 0) {                               // out_int_inv[t]
-    const int q = p.n / p.m_int;
-    o = (t / q) + (t % q) * p.m_int;
+    if (p.q_magic) {
+      const int tq = (int)__umulhi((unsigned)t << 2, p.q_magic);
+      o = tq + (t - tq * p.q) * p.m_int;
+    } else {
+      const int q = p.n / p.m_int;
+      o = (t / q) + (t % q) * p.m_int;
+    }
   }
   return llr_row[o];
 }

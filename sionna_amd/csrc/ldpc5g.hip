@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kDecThreads) void ldpc5g_decode_kernel(
 }
 
 static RateMatch make_rm(const samd_ldpc5g* h) {
-  return RateMatch{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  return make_rate_match(h);
 }
 
 static size_t decode_lds_bytes(const samd_ldpc5g* h) {

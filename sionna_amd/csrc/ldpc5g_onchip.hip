@@ -495,7 +495,7 @@ int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int bat
   // set on every launch: the attribute is per device and a process may drive several
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int grid = onchip_grid(h, batch);
-  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  const RateMatch rm = make_rate_match(h);
   hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(nw * 64), lds, st, llr, out, llr_ws, rm, h->n_cn, h->ncu, h->nbu, batch,
                      num_iter, llr_max, (off ? offset : 0.f), hard_out, return_infobits, h->row_pad, h->row_deg,
                      h->col_pad, h->col_cls, h->cn_sched_ptr, h->cn_sched, h->vn_sched_ptr, h->vn_sched);

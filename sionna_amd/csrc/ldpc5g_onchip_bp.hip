@@ -618,7 +618,7 @@ int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int bat
   // set on every launch: the attribute is per device and a process may drive several
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;
-  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  const RateMatch rm = make_rate_match(h);
   hipLaunchKernelGGL(kerns[ki], dim3(onchip_bp_grid(h, batch)), dim3(nw * 64), onchip_bp_lds_bytes(h), st, llr, out, llr_ws, rm,
                      h->n_cn, nbu, batch, num_iter, llr_max, hard_out, return_infobits, h->bp_edges * h->z,
                      h->bp_row_off, h->bp_col_ent, h->bp_col_deg, h->bp_cn_ptr, h->bp_cn_list,

@@ -830,7 +830,7 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const kern_t fn = kerns[minsum ? 0 : cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : 2][h->z % 64 != 0 ? 1 : 0][pow2 ? 1 : 0];
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;
-  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  const RateMatch rm = make_rate_match(h);
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;
   // the boxplus rules walk the lists with split check-node items where the code has them (more LDS: the parts' scratch)
   const bool parts = !minsum && h->ly_bp_lds_bytes > 0;

@@ -477,7 +477,7 @@ int launch_onchip_mss(const samd_ldpc5g* h, const float* llr, float* out, int ba
   const kern_t fn = kerns[2 * mi + (pow2 ? 1 : 0)];
   SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int nbu = (h->n_vn + h->z - 1) / h->z;
-  const RateMatch rm{h->k, h->n, h->z, h->k_ldpc, h->n_vn, h->m_int};
+  const RateMatch rm = make_rate_match(h);
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;
   hipLaunchKernelGGL(fn, dim3(mss_grid(h, batch)), dim3(1024), h->sp_lds_bytes, st, llr, out, ws, rm, h->n_cn, nbu, batch,
                      num_iter, llr_max, off, hard_out, return_infobits, h->sp_g_floats, h->sp_col_ent, h->sp_cn_ptr,
