@@ -345,6 +345,15 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // single-chunk item of that degree ~2.4 k).
   // Lifting sizes of two chunks only (Z = 128: +1.3 % at C2, +1.1 % at k=2816 n=5632; codes of three or four chunks have
   // enough items per wave and lose 5 % - ms_refine_codes_r03z.txt).
+  // development (tools/ms_autotune.py): item costs perturbed by +-SAMD_MS_PERTURB_PCT % from a seeded generator - a
+  // search over LPT assignments near the model's by measurement
+  if (const char* e = getenv("SAMD_MS_PERTURB")) {
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(atoll(e) + 1);
+    const int pct = getenv("SAMD_MS_PERTURB_PCT") ? atoi(getenv("SAMD_MS_PERTURB_PCT")) : 8;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+    for (auto* items : {&ci2, &vi2})
+      for (auto& it : *items) it.first = std::max(1, (int)std::lround(it.first * (1.0 + pct / 100.0 * (2.0 * rnd() - 1.0))));
+  }
   auto refine = [&](std::vector<std::pair<int, int32_t>>& items, int tries, int extra, auto&& may_cut) {
     auto makespan = [&](const std::vector<std::pair<int, int32_t>>& its, std::vector<int>* owner) {
       std::vector<size_t> order(its.size());
