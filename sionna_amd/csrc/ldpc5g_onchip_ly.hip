@@ -29,7 +29,7 @@
 //
 // Every wave walks a linear record list built on the host.  A step = the records between two workgroup barriers: the
 // check-node items of a group (one 64-lane chunk of a row per wave; for the boxplus rules cut into parts of 2 or 4 edges
-// on different waves, ly_cns_part), then the re-sums the next group waits for (column; pairs of chunks for degree <= 12);
+// on different waves, ly_cns_part), then the re-sums the next group waits for (column; pairs of chunks for small degrees);
 // re-sums nobody waits for yet fill idle waves of later steps.  No global memory operand inside the iteration loop:
 // until round 3x the fused state and the channel LLRs came from the L2 workspace one record ahead, and every record then
 // lasted at least one L2 round trip (~1.6 k cycles measured per item, profiles/r03b/ly_itrace_r03x_before.txt, against
@@ -570,13 +570,20 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       if (in_group[g][c] && (g + 1 == G || in_group[g + 1][c])) need = true;
     if (need || getenv("SAMD_LY_NODEFER")) ++nsteps;
   }
-  // VN units: a column's chunk (or pair of chunks for degree <= 12); its item after the update of edge j reads 1 + (the
+  // VN units: a column's chunk (or pair of chunks for degree <= 8 / 12); its item after the update of edge j reads 1 + (the
   // edges below j) messages.  Units go, heaviest first, to the wave where they add least to the sum over the groups of
   // the squared load.
   struct Unit { int c, q, pair, wave, slot; long cost; };
   std::vector<Unit> units;
-  auto item_cost = [&](int c, int j, int pair) { return (pair ? 36L : 18L) * ((col_deg[c] - j + 3) / 4 * 4) + 250; };
-  const int pair_max = getenv("SAMD_LY_PAIR_MAX") ? atoi(getenv("SAMD_LY_PAIR_MAX")) : 12;
+  // (cost model of the schedule, in cycles of a lone wave; development knobs for tools/ly_grid.py)
+  const long ly_vn_slope = getenv("SAMD_LY_VN_SLOPE") ? atol(getenv("SAMD_LY_VN_SLOPE")) : 18;
+  const long ly_vn_ovh = getenv("SAMD_LY_VN_OVH") ? atol(getenv("SAMD_LY_VN_OVH")) : 250;
+  const long ly_cn_slope = getenv("SAMD_LY_CN_SLOPE") ? atol(getenv("SAMD_LY_CN_SLOPE")) : 60;
+  const long ly_cn_ovh = getenv("SAMD_LY_CN_OVH") ? atol(getenv("SAMD_LY_CN_OVH")) : 300;
+  auto item_cost = [&](int c, int j, int pair) { return (pair ? 2 : 1) * ly_vn_slope * ((col_deg[c] - j + 3) / 4 * 4) + ly_vn_ovh; };
+  // (two-chunk lifting sizes: 8 is +0.9 % over 12 at C2, ly_grid_r03z.txt; with more chunks 12 stays - k=3000 n=6000,
+  // Z = 320, loses 2 % (boxplus-phi 7 %) with 8)
+  const int pair_max = getenv("SAMD_LY_PAIR_MAX") ? atoi(getenv("SAMD_LY_PAIR_MAX")) : (chunks == 2 ? 8 : 12);
   for (int c = 0; c < nbu; ++c) {
     if (xt_of_col[c] < 0) continue;
     for (int q = 0; q < chunks; ++q) {
@@ -644,7 +651,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
         sload[st][wv] += 500 + 350L * ((pt.ne + 1) / 2) + 8L * d;
       } else {
         step_items[st][wv].push_back({1L << 40, LY_CN | ((d | (f << 5)) << 2) | (q << 16), row_off[r], 4 * row_start[r], sidx});
-        sload[st][wv] += split ? 300 + 330L * ((d + 1) / 2) : 300 + 60L * d;
+        sload[st][wv] += split ? 300 + 330L * ((d + 1) / 2) : ly_cn_ovh + ly_cn_slope * d;
       }
       smax[st] = std::max(smax[st], sload[st][wv]);
     }
