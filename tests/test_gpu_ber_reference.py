@@ -1,0 +1,37 @@
+"""BER/BLER of the MI355X path against the reference's PUBLISHED numbers (second half of BASELINE.json's metric:
+"BER@Eb/N0 vs reference ... curves overlapping the reference within 0.05 dB").
+
+The reference's tutorial notebooks are committed with the tables their ``sim_ber`` runs printed;
+``tools/extract_notebook_tables.py`` extracted them into ``tests/golden/notebook_ber.json`` and
+``tests/notebook_curves.py`` rebuilds every model from ``sionna_amd.phy`` blocks.  Each test simulates the
+reference's Eb/N0 points with MULT x the reference's error events per point (bounded per point) through the product's
+own ``sim_ber`` and applies the criteria documented in ``notebook_curves`` (per-point z <= 4 sigma, chi-square over the
+curve, Eb/N0 at BLER/BER 1e-1 and 1e-2 within 0.05 dB + 3 sigma of the Monte-Carlo uncertainty of both curves).
+A curve that misses is a parity failure - nothing here is tuned to pass."""
+import json
+import os
+
+import pytest
+
+import notebook_curves as nc
+
+pytestmark = pytest.mark.gpu
+
+MULT = 2.0                    # error events per point relative to the reference's (tools/ber_vs_reference.py: 4 x, profiles/)
+MAX_WORK = 6e10               # bounds the deep points: the whole module runs in about two minutes
+TABLES = nc.load_tables()
+
+
+@pytest.mark.parametrize("curve", nc.CURVES, ids=[c.key for c in nc.CURVES])
+def test_curve_overlaps_reference(curve):
+    ref = TABLES[curve.key]["rows"]
+    ours = nc.run_curve(curve, ref, mult=MULT, max_work=MAX_WORK)
+    res = nc.evaluate(curve, ref, ours)
+    detail = json.dumps({k: res[k] for k in ("max_abs_z", "n_z", "n_beyond_3sigma", "chi2_p", "crossings") if k in res},
+                        default=float)
+    assert res["n_z"] >= 2, f"{curve.name}: too few comparable points: {detail}"
+    assert res["ok_points"], f"{curve.name}: a point is beyond {nc.Z_POINT} sigma of the reference: {detail}"
+    assert res["ok_chi2"], f"{curve.name}: chi-square over the curve rejects agreement: {detail}"
+    assert res["ok_crossings"], f"{curve.name}: Eb/N0 offset beyond 0.05 dB (+3 sigma MC): {detail}"
+    if "ok_ber_crossings" in res:
+        assert res["ok_ber_crossings"], f"{curve.name}: BER-curve offset beyond tolerance: {json.dumps(res['ber_crossings'], default=float)}"

@@ -1,0 +1,125 @@
+"""Import reference modules UNMODIFIED from /root/reference under stand-ins for ``tensorflow`` (tools/ref_exec/tf_numpy.py)
+and for the ``sionna.phy`` package scaffolding (Block/Object/config/dtypes), so that the reference's own algorithms run
+here.  Only the files named in ``load()`` calls are executed; the package ``__init__`` files of the reference (which import
+everything, including Keras-dependent code) are replaced by empty namespace packages.
+
+    from tools.ref_exec.loader import reference
+    ref = reference()                       # installs the stand-ins into sys.modules (idempotent)
+    dec = ref.load("sionna.phy.fec.ldpc.decoding")
+    dec.cn_update_minsum(...)
+"""
+import contextlib
+import importlib.util
+import os
+import pathlib
+import sys
+import types
+
+import numpy as np
+
+from . import tf_numpy
+
+REF_SRC = "/root/reference/src"
+
+
+class _Block:
+    """Stand-in for sionna.phy.Block / Object (reference src/sionna/phy/block.py:13-155): precision bookkeeping and the
+    build-once-then-call protocol; inputs are converted to float32/complex64 tensors of the stand-in."""
+
+    def __init__(self, *args, precision=None, **kwargs):
+        self._precision = precision or "single"
+        self._built = False
+
+    precision = property(lambda self: self._precision)
+    rdtype = property(lambda self: np.dtype("float32") if self._precision == "single" else np.dtype("float64"))
+    cdtype = property(lambda self: np.dtype("complex64") if self._precision == "single" else np.dtype("complex128"))
+    built = property(lambda self: self._built)
+
+    def _conv(self, v):
+        if isinstance(v, tf_numpy.RaggedTensor) or v is None or isinstance(v, (str, bool)):
+            return v
+        a = np.array(v)                                            # copy: the reference mutates its inputs in place
+        if a.dtype.kind == "f":
+            a = a.astype(self.rdtype)
+        elif a.dtype.kind == "c":
+            a = a.astype(self.cdtype)
+        return a.view(tf_numpy.Tensor)
+
+    def build(self, *a, **k):
+        pass
+
+    def __call__(self, *args, **kwargs):
+        args = [self._conv(a) for a in args]
+        kwargs = {k: self._conv(v) for k, v in kwargs.items()}
+        if not self._built:
+            shapes = [tuple(a.shape) if hasattr(a, "shape") else () for a in args]
+            self.build(*shapes, **{k: (tuple(v.shape) if hasattr(v, "shape") else ()) for k, v in kwargs.items()})
+            self._built = True
+        return self.call(*args, **kwargs)
+
+
+class Reference:
+    def __init__(self):
+        self.tf = tf_numpy.make_tf()
+        self._installed = {}
+
+    def install(self):
+        if "tensorflow" in sys.modules and getattr(sys.modules["tensorflow"], "__doc__", "") != self.tf.__doc__:
+            raise RuntimeError("a real tensorflow is imported; the stand-in must not shadow it")
+        sys.modules["tensorflow"] = self.tf
+        ir = types.ModuleType("importlib_resources")
+        ir.files = lambda pkg: pathlib.Path(list(pkg.__path__)[0])
+        ir.as_file = lambda p: contextlib.nullcontext(p)
+        sys.modules["importlib_resources"] = ir
+        for name in ("sionna", "sionna.phy", "sionna.phy.fec", "sionna.phy.fec.ldpc", "sionna.phy.fec.polar", "sionna.phy.mimo",
+                     "sionna.phy.utils", "sionna.phy.ofdm", "sionna.phy.channel"):
+            if name not in sys.modules:
+                m = types.ModuleType(name)
+                m.__path__ = []                                    # namespace stub: nothing is importable implicitly
+                m.__package__ = name
+                sys.modules[name] = m
+                parent, _, child = name.rpartition(".")
+                if parent:
+                    setattr(sys.modules[parent], child, m)
+        phy = sys.modules["sionna.phy"]
+        phy.Block, phy.Object = _Block, _Block
+        dt = {"single": {"tf": {"rdtype": np.dtype("float32"), "cdtype": np.dtype("complex64")},
+                         "np": {"rdtype": np.float32, "cdtype": np.complex64}},
+              "double": {"tf": {"rdtype": np.dtype("float64"), "cdtype": np.dtype("complex128")},
+                         "np": {"rdtype": np.float64, "cdtype": np.complex128}}}
+        phy.dtypes = dt
+        phy.config = types.SimpleNamespace(precision="single", tf_rdtype=np.dtype("float32"), tf_cdtype=np.dtype("complex64"),
+                                           np_rdtype=np.float32, np_cdtype=np.complex64)
+        cfg = types.ModuleType("sionna.phy.config")
+        cfg.config, cfg.dtypes = phy.config, dt
+        sys.modules["sionna.phy.config"] = cfg
+        return self
+
+    def load(self, modname, package_dir=False):
+        """Execute the reference file for ``modname`` (e.g. 'sionna.phy.fec.ldpc.decoding') and register it."""
+        if modname in self._installed:
+            return self._installed[modname]
+        rel = modname.replace(".", os.sep)
+        path = os.path.join(REF_SRC, rel, "__init__.py") if package_dir else os.path.join(REF_SRC, rel + ".py")
+        spec = importlib.util.spec_from_file_location(
+            modname, path, submodule_search_locations=[os.path.dirname(path)] if package_dir else None)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[modname] = mod
+        parent, _, child = modname.rpartition(".")
+        if parent in sys.modules:
+            setattr(sys.modules[parent], child, mod)
+        spec.loader.exec_module(mod)
+        self._installed[modname] = mod
+        return mod
+
+
+_REF = None
+
+
+def reference():
+    global _REF
+    if _REF is None:
+        if not os.path.isdir(REF_SRC):
+            raise RuntimeError(f"{REF_SRC} is not present: fixtures are generated in the build container only")
+        _REF = Reference().install()
+    return _REF
