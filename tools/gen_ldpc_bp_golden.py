@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ldpc_bp_ref_golden.npz by EXECUTING the reference's own LDPC code:
+``/root/reference/src/sionna/phy/fec/ldpc/decoding.py`` (vn_update_sum :681-732, cn_update_offset_minsum :755-909,
+cn_update_minsum :911-953, cn_update_tanh :955-1043, cn_update_phi :1045-1166, LDPCBPDecoder :13-637 incl. ``_bp_iter``
+:416-524, LDPC5GDecoder :1169-1536) and ``encoding.py`` (LDPC5GEncoder :14-668), imported UNMODIFIED under the NumPy
+stand-in for TensorFlow in tools/ref_exec (TensorFlow is not installed here).
+
+What the fixture pins (see tools/ref_exec/tf_numpy.py for the stand-in's numerical contract):
+  * vn_update_sum / min-sum / offset-min-sum / whole min-sum decoders use only IEEE-exact float32 operations and the
+    TF-CPU segment-reduction order -> the oracle must reproduce them BIT FOR BIT (tests/test_oracle_ref_exec.py);
+  * boxplus (tanh) and boxplus-phi go through exp/log/tanh/atanh, where NumPy's float32 routines stand for Eigen's ->
+    compared at 1e-5 per node update; additionally the oracle with ITS exp/log swapped for NumPy's must be bit-identical
+    (proves that everything around the transcendental - clips, literal phi form, subtraction order, signs - is the
+    reference's).
+
+One documented choice: the reference orders edges with ``np.argsort`` of the default (unstable) kind
+(decoding.py:286, 329), so the order of edges inside a node - and with it the float32 summation order - depends on the
+NumPy build.  The module's ``np`` is therefore replaced by a proxy whose ``argsort`` defaults to kind="stable" (the
+source file itself is untouched): that is one of the orders the reference can produce, and the one SURVEY.md A.8 /
+oracle/ldpc_bp.py fix ("VN-major, ascending CN inside a VN").
+
+Run here (needs /root/reference); the fixture travels.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden", "ldpc_bp_ref_golden.npz")
+RULES = ("minsum", "offset-minsum", "boxplus", "boxplus-phi")
+
+
+class _StableNp:
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def argsort(a, *args, **kw):
+        kw.setdefault("kind", "stable")
+        return np.argsort(a, *args, **kw)
+
+
+def load_reference():
+    from tools.ref_exec.loader import reference
+    ref = reference()
+    ref.load("sionna.phy.fec.ldpc.codes", package_dir=True)
+    enc = ref.load("sionna.phy.fec.ldpc.encoding")
+    dec = ref.load("sionna.phy.fec.ldpc.decoding")
+    dec.np = _StableNp()
+    return ref, enc, dec
+
+
+def sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def nasty_messages(rng, shape, llr_max=20.0):
+    """v2c/c2v test messages: Gaussian, with exact zeros, exact duplicates of |minimum| inside nodes, +-llr_max, tiny values."""
+    x = (rng.normal(size=shape) * 6).astype(np.float32)
+    x = np.clip(x, -llr_max, llr_max)
+    m = rng.random(shape)
+    x[m < 0.03] = 0.0
+    x[(m >= 0.03) & (m < 0.06)] = np.float32(llr_max)
+    x[(m >= 0.06) & (m < 0.08)] = np.float32(-llr_max)
+    x[(m >= 0.08) & (m < 0.10)] = np.float32(1e-6)
+    q = (m >= 0.10) & (m < 0.30)                                   # coarse grid -> many exact ties
+    x[q] = np.round(x[q] * 2) / 2
+    return x
+
+
+def main():
+    ref, enc_m, dec_m = load_reference()
+    tf = ref.tf
+    RT = tf.RaggedTensor
+    rng = np.random.default_rng(20240924)
+    out = {}
+
+    # ---------------------------------------------------------------- graphs: the 5 reference example PCMs + two 5G graphs
+    pcms = np.load("/root/reference/src/sionna/phy/fec/ldpc/codes/example_codes.npy", allow_pickle=True)
+    graphs = {f"ex{i}": np.array(pcms[i]) for i in range(5)}
+
+    # ---------------------------------------------------------------- (1) node functions on every graph
+    for name, pcm in graphs.items():
+        d = dec_m.LDPCBPDecoder(pcm, cn_update="minsum", num_iter=1, hard_out=False)
+        E, B = d._num_edges, 6
+        v2c_cn = nasty_messages(rng, (E, B))                       # messages in CN-sorted order
+        rag_cn = RT.from_value_rowids(v2c_cn, d._cn_idx[np.asarray(d._v2c_perm.flat_values)], nrows=d._num_cns)
+        out[f"node_{name}_cn_in"] = v2c_cn
+        llr_max = tf.cast(20., tf.float32)
+        out[f"node_{name}_minsum"] = np.asarray(dec_m.cn_update_minsum(rag_cn, llr_max).flat_values)
+        out[f"node_{name}_offset"] = np.asarray(dec_m.cn_update_offset_minsum(rag_cn, llr_max).flat_values)
+        out[f"node_{name}_offset03_noclip"] = np.asarray(dec_m.cn_update_offset_minsum(rag_cn, None, offset=0.3).flat_values)
+        out[f"node_{name}_tanh"] = np.asarray(dec_m.cn_update_tanh(rag_cn, llr_max).flat_values)
+        out[f"node_{name}_phi"] = np.asarray(dec_m.cn_update_phi(rag_cn, llr_max).flat_values)
+        c2v_vn = nasty_messages(rng, (E, B))                       # messages in VN-sorted order
+        llr_ch = nasty_messages(rng, (d._num_vns, B))
+        rag_vn = RT.from_value_rowids(c2v_vn, d._vn_idx, nrows=d._num_vns)
+        xe, xtot = dec_m.vn_update_sum(rag_vn, llr_ch, llr_max)
+        out[f"node_{name}_vn_c2v"], out[f"node_{name}_vn_llr"] = c2v_vn, llr_ch
+        out[f"node_{name}_vn_xe"], out[f"node_{name}_vn_xtot"] = np.asarray(xe.flat_values), np.asarray(xtot)
+        xe2, xtot2 = dec_m.vn_update_sum(rag_vn, llr_ch, None)
+        out[f"node_{name}_vn_xe_noclip"], out[f"node_{name}_vn_xtot_noclip"] = np.asarray(xe2.flat_values), np.asarray(xtot2)
+        out[f"node_{name}_edges"] = np.stack([d._cn_idx, d._vn_idx]).astype(np.int32)
+
+    # ---------------------------------------------------------------- (2) whole LDPCBPDecoder loops on the example PCMs
+    for name, pcm in graphs.items():
+        n = pcm.shape[1]
+        B = 8
+        sigma = {"ex0": 0.7, "ex1": 0.6, "ex2": 0.55, "ex3": 0.8, "ex4": 0.75}[name]
+        y = 1.0 + sigma * rng.normal(size=(B, n))                  # all-zero codeword, BPSK +1
+        logits = (-2 * y / sigma ** 2).astype(np.float32)          # logit = log p(1)/p(0)
+        out[f"bp_{name}_llr"] = logits
+        for rule in RULES:
+            for it in ((1, 5) if name != "ex4" else (5,)):
+                d = dec_m.LDPCBPDecoder(pcm, cn_update=rule, num_iter=it, hard_out=False, return_state=True)
+                x, st = d(logits)
+                out[f"bp_{name}_{rule}_it{it}_x"] = np.asarray(x)
+                out[f"bp_{name}_{rule}_it{it}_state_sha"] = sha(np.asarray(st))
+        # hard output and state passing (two calls of 3 iterations == the reference's IDD usage)
+        d = dec_m.LDPCBPDecoder(pcm, cn_update="minsum", num_iter=3, hard_out=True, return_state=True)
+        x1, st1 = d(logits)
+        x2, st2 = d(logits, msg_v2c=st1)
+        out[f"bp_{name}_minsum_hard3"] = np.asarray(x1).astype(np.uint8)
+        out[f"bp_{name}_minsum_hard3_resumed"] = np.asarray(x2).astype(np.uint8)
+        out[f"bp_{name}_minsum_resumed_state"] = np.asarray(st2) if name in ("ex0", "ex1") else sha(np.asarray(st2))
+
+    # ---------------------------------------------------------------- (3) 5G chain: reference encoder + decoder
+    # C1 = BASELINE configs[0] (BG1 k=1024 n=2048, BP-10), 3 seeds x Eb/N0 0..3 dB; plus a BG2 code, an interleaved one,
+    # and the layered schedule
+    cases = [("c1", 1024, 2048, "bg1", None, 10, 12, (0.0, 1.0, 2.0, 3.0)),
+             ("bg2s", 64, 128, None, None, 20, 16, (1.0, 3.0)),
+             ("bg2m", 500, 1000, None, 4, 10, 8, (1.0, 2.5)),
+             ("bg1r", 2000, 2400, "bg1", 2, 10, 4, (4.0,))]
+    for tag, k, n, bg, m, iters, B, ebnos in cases:
+        enc = enc_m.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+        u = rng.integers(0, 2, (B * len(ebnos), k)).astype(np.float32)
+        c = np.asarray(enc(u))
+        out[f"g5_{tag}_meta"] = np.array([k, n, {"bg1": 1, "bg2": 2}[enc._bg], enc._z, m or 0, iters], np.int32)
+        out[f"g5_{tag}_u"] = u.astype(np.uint8)
+        out[f"g5_{tag}_c"] = c.astype(np.uint8)
+        sig = np.repeat([np.sqrt(1.0 / (2 * (k / n) * 10 ** (e / 10))) for e in ebnos], B)[:, None]
+        y = (1 - 2 * c) + sig * rng.normal(size=c.shape)
+        logits = (-2 * y / sig ** 2).astype(np.float32)
+        out[f"g5_{tag}_llr"] = logits
+        for rule in RULES:
+            d = dec_m.LDPC5GDecoder(enc, cn_update=rule, num_iter=iters, hard_out=False, return_infobits=False, return_state=True)
+            x, st = d(logits)
+            out[f"g5_{tag}_{rule}_x"] = np.asarray(x)
+            out[f"g5_{tag}_{rule}_state_sha"] = sha(np.asarray(st))
+            d = dec_m.LDPC5GDecoder(enc, cn_update=rule, num_iter=iters, hard_out=True, return_infobits=True)
+            out[f"g5_{tag}_{rule}_uhat"] = np.asarray(d(logits)).astype(np.uint8)
+            print(f"{tag} {rule}: BER {np.mean(out[f'g5_{tag}_{rule}_uhat'] != u):.4f}")
+        if tag in ("c1", "bg2s"):
+            d = dec_m.LDPC5GDecoder(enc, cn_update="minsum", cn_schedule="layered", num_iter=max(2, iters // 2), hard_out=False,
+                                    return_infobits=False)
+            out[f"g5_{tag}_layered_minsum_x"] = np.asarray(d(logits))
+            d = dec_m.LDPC5GDecoder(enc, cn_update="boxplus-phi", cn_schedule="layered", num_iter=max(2, iters // 2), hard_out=False,
+                                    return_infobits=False)
+            out[f"g5_{tag}_layered_phi_x"] = np.asarray(d(logits))
+
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    main()
