@@ -152,18 +152,23 @@ class Constellation(Block):
         self._dev = None
         self._dev64 = None
 
-    def _host_points(self):
+    def _host_points(self, raw=False):
         x = self._points
-        if self._constellation_type == "custom":
+        if self._constellation_type == "custom" and not raw:
             if self._center:
                 x = x - np.mean(x)
             if self._normalize:
                 x = x / np.sqrt(np.mean(np.abs(x) ** 2)).astype(x.real.dtype)
         return x.astype(self._points.dtype)
 
-    def pam_levels(self):
+    def _raw_differs(self):
+        return self._constellation_type == "custom" and (self._center or self._normalize)
+
+    def pam_levels(self, raw=False):
         """Device float32[2^(m/2)] PAM levels if the constellation is a square QAM whose label
-        interleaves two identical PAM axes (true for ``qam()``), else None."""
+        interleaves two identical PAM axes (true for ``qam()``), else None.  ``raw``: see ``device_points``."""
+        if raw and self._raw_differs():
+            return None                          # custom points: the generic 2^m-point kernel on the raw points
         if getattr(self, "_pam_valid", False) and self._dev is not None:
             return self._pam_dev
         self._pam_dev, self._pam_valid = None, True
@@ -183,9 +188,17 @@ class Constellation(Block):
             self._pam_dev = _ffi.to_device(lev, torch.float32)
         return self._pam_dev
 
-    def device_points(self, double=False):
+    def device_points(self, double=False, raw=False):
         """Device copy (complex64, or complex128 for precision="double") used by the kernels; rebuilt after a
-        setter call."""
+        setter call.  ``raw=True``: the stored ``points`` WITHOUT centring / normalisation - what the reference's
+        ``Demapper`` and ``SymbolDemapper`` measure distances to (mapping.py:667-668, 777: ``constellation.points``),
+        while its ``Mapper`` transmits ``constellation()`` (mapping.py:514).  They differ only for a "custom"
+        constellation with ``normalize`` or ``center`` set."""
+        if raw and self._raw_differs():
+            pts = self._host_points(raw=True)
+            if double:
+                return _ffi.to_device(np.asarray(pts, np.complex128), torch.complex128)
+            return _ffi.to_device(pts.astype(np.complex64), torch.complex64)
         if double:
             if getattr(self, "_dev64", None) is None or self._dev is None:
                 self._dev64 = _ffi.to_device(np.asarray(self._host_points(), np.complex128), torch.complex128)
@@ -279,7 +292,7 @@ class Demapper(Block):
             else:
                 prior = torch.broadcast_to(prior, tuple(y.shape) + (m,)).contiguous()
         _ffi.check(_ffi.lib().samd_qam_demap_f64(
-            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points(double=True)), m, y.numel(),
+            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points(double=True, raw=True)), m, y.numel(),
             _ffi.ptr(prior), 0 if prior is None else prior.numel(), 0 if self._method == "app" else 1,
             int(bool(self._hard_out)), _ffi.ptr(out), _ffi.stream()), "Demapper(double)")
         return out
@@ -303,11 +316,11 @@ class Demapper(Block):
             else:
                 prior = torch.broadcast_to(prior, tuple(y.shape) + (m,)).contiguous()
             _ffi.check(_ffi.lib().samd_qam_demap_prior_f32(
-                _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points()), m, y.numel(),
+                _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points(raw=True)), m, y.numel(),
                 _ffi.ptr(prior), prior.numel(), 0 if self._method == "app" else 1, int(bool(self._hard_out)), _ffi.ptr(out),
                 _ffi.stream()), "Demapper(prior)")
             return out
-        lev = self._constellation.pam_levels() if self._separable else None
+        lev = self._constellation.pam_levels(raw=True) if self._separable else None
         if lev is not None:
             _ffi.check(_ffi.lib().samd_square_qam_demap_f32(
                 _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(lev), m, y.numel(),
@@ -315,7 +328,7 @@ class Demapper(Block):
                 "Demapper")
             return out
         _ffi.check(_ffi.lib().samd_qam_demap_f32(
-            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points()), m,
+            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points(raw=True)), m,
             y.numel(), 0 if self._method == "app" else 1, int(bool(self._hard_out)), _ffi.ptr(out),
             _ffi.stream()), "Demapper")
         return out
@@ -352,7 +365,7 @@ class SymbolDemapper(Block):
         out = None if hard else torch.empty(tuple(y.shape) + (npts,), dtype=torch.float32, device=y.device)
         idx = torch.empty(tuple(y.shape), dtype=torch.int32, device=y.device) if hard else None
         _ffi.check(_ffi.lib().samd_symbol_demap_f32(
-            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points()), m, y.numel(),
+            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points(raw=True)), m, y.numel(),
             _ffi.ptr(prior), 0 if prior is None else prior.numel(), int(hard), _ffi.ptr(out), _ffi.ptr(idx), _ffi.stream()),
             "SymbolDemapper")
         return idx if hard else out

@@ -124,6 +124,32 @@ def test_demapper_custom_constellation(phy):
     assert x.shape == (2, 10)
 
 
+def test_demapper_measures_against_raw_points_like_the_reference(phy):
+    """Reference-EXECUTED pin (tests/golden/phy_ref_golden.npz, tools/gen_phy_ref_golden.py): for a "custom" constellation
+    with normalize=center=True the reference's Mapper transmits ``constellation()`` (mapping.py:514) while its Demapper and
+    SymbolDemapper measure distances to the stored, un-normalised ``constellation.points`` (mapping.py:667-668, 777)."""
+    g = np.load(os.path.join(GOLD, "phy_ref_golden.npz"))
+    const = phy.mapping.Constellation("custom", 3, points=g["custom3_in"], normalize=True, center=True)
+    assert np.allclose(np.asarray(const()), g["custom3_points"], rtol=1e-6, atol=1e-7)
+    got = _np(phy.mapping.Demapper("app", constellation=const)(g["custom3_y"], 0.3))
+    assert np.allclose(got, g["custom3_app"], rtol=1e-5, atol=1e-4), np.abs(got - g["custom3_app"]).max()
+    sd = _np(phy.mapping.SymbolDemapper(constellation=const)(g["custom3_y"], 0.3))
+    ref = omap.symbol_demapper(g["custom3_y"], 0.3, g["custom3_in"])
+    assert np.allclose(sd, ref, rtol=1e-4, atol=1e-4)
+    # reference-executed QAM demapper outputs, straight against the kernels (both the per-axis and the generic one)
+    for m in (2, 4, 6, 8):
+        for meth in ("app", "maxlog"):
+            for no in (0.5, 0.05):
+                ref = g[f"qam{m}_{meth}_no{no}"]
+                y = g[f"qam{m}_y_no{no}"]
+                for sep in (True, False):
+                    got = _np(phy.mapping.Demapper(meth, "qam", m, separable=sep)(y, no))
+                    scale = max(np.abs(ref).max(), np.abs(y).max() ** 2 / no)
+                    assert np.abs(got - ref).max() <= 1e-5 * scale, (m, meth, no, sep, np.abs(got - ref).max())
+            got = _np(phy.mapping.Demapper(meth, "qam", m)(g[f"qam{m}_y_t"], g[f"qam{m}_no_t"], g[f"qam{m}_prior"]))
+            assert np.allclose(got, g[f"qam{m}_{meth}_prior"], rtol=1e-5, atol=2e-4)
+
+
 # ------------------------------------------------------------------ encoder
 G = np.load(os.path.join(GOLD, "ldpc_enc_golden.npz"))
 

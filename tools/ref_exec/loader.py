@@ -31,8 +31,8 @@ class _Block:
         self._built = False
 
     precision = property(lambda self: self._precision)
-    rdtype = property(lambda self: np.dtype("float32") if self._precision == "single" else np.dtype("float64"))
-    cdtype = property(lambda self: np.dtype("complex64") if self._precision == "single" else np.dtype("complex128"))
+    rdtype = property(lambda self: tf_numpy.DType("float32" if self._precision == "single" else "float64"))
+    cdtype = property(lambda self: tf_numpy.DType("complex64" if self._precision == "single" else "complex128"))
     built = property(lambda self: self._built)
 
     def _conv(self, v):
@@ -83,13 +83,22 @@ class Reference:
                     setattr(sys.modules[parent], child, m)
         phy = sys.modules["sionna.phy"]
         phy.Block, phy.Object = _Block, _Block
-        dt = {"single": {"tf": {"rdtype": np.dtype("float32"), "cdtype": np.dtype("complex64")},
+        D = tf_numpy.DType
+        dt = {"single": {"tf": {"rdtype": D("float32"), "cdtype": D("complex64")},
                          "np": {"rdtype": np.float32, "cdtype": np.complex64}},
-              "double": {"tf": {"rdtype": np.dtype("float64"), "cdtype": np.dtype("complex128")},
+              "double": {"tf": {"rdtype": D("float64"), "cdtype": D("complex128")},
                          "np": {"rdtype": np.float64, "cdtype": np.complex128}}}
         phy.dtypes = dt
-        phy.config = types.SimpleNamespace(precision="single", tf_rdtype=np.dtype("float32"), tf_cdtype=np.dtype("complex64"),
+        phy.config = types.SimpleNamespace(precision="single", tf_rdtype=D("float32"), tf_cdtype=D("complex64"),
                                            np_rdtype=np.float32, np_cdtype=np.complex64)
+        blk = types.ModuleType("sionna.phy.block")
+        blk.Block, blk.Object = _Block, _Block
+        sys.modules["sionna.phy.block"] = blk
+        tnp = types.ModuleType("tensorflow.experimental.numpy")
+        tnp.log10 = lambda x: tf_numpy._t(np.log10(np.asarray(x)))
+        tnp.log2 = lambda x: tf_numpy._t(np.log2(np.asarray(x)))
+        sys.modules["tensorflow.experimental"] = types.ModuleType("tensorflow.experimental")
+        sys.modules["tensorflow.experimental.numpy"] = tnp
         cfg = types.ModuleType("sionna.phy.config")
         cfg.config, cfg.dtypes = phy.config, dt
         sys.modules["sionna.phy.config"] = cfg
@@ -111,6 +120,18 @@ class Reference:
         spec.loader.exec_module(mod)
         self._installed[modname] = mod
         return mod
+
+
+    def load_utils(self):
+        """The reference's ``sionna.phy.utils`` star-imports its sub-modules (utils/__init__.py:5-10); load the ones the hot
+        path uses and merge their public names into the stub package the same way."""
+        pkg = sys.modules["sionna.phy.utils"]
+        for sub in ("tensors", "metrics", "linalg", "misc"):
+            m = self.load(f"sionna.phy.utils.{sub}")
+            for k, v in vars(m).items():
+                if not k.startswith("_"):
+                    setattr(pkg, k, v)
+        return pkg
 
 
 _REF = None

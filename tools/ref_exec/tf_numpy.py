@@ -22,16 +22,65 @@ import types
 import numpy as np
 
 
-class _Shape(tuple):
+class _Shape(list):
+    """TensorShape stand-in: list-like (``[1]*rank + x.shape`` works), with ``rank`` and ``as_list``."""
+    rank = property(len)
+    ndims = property(len)
+
     def as_list(self):
         return list(self)
+
+    def __hash__(self):
+        return hash(tuple(self))
+
+
+class DType:
+    """tf.DType stand-in; NumPy accepts it wherever a dtype is expected (through the ``dtype`` attribute)."""
+
+    def __init__(self, name):
+        self._np = np.dtype(name)
+        self.name = self._np.name
+
+    dtype = property(lambda self: self._np)
+    as_numpy_dtype = property(lambda self: self._np.type)
+    is_complex = property(lambda self: self._np.kind == "c")
+    is_floating = property(lambda self: self._np.kind == "f")
+    is_integer = property(lambda self: self._np.kind in "iu")
+    size = property(lambda self: self._np.itemsize)
+
+    @property
+    def real_dtype(self):
+        return DType({"complex64": "float32", "complex128": "float64"}.get(self.name, self.name))
+
+    def __eq__(self, other):
+        try:
+            return np.dtype(other._np if isinstance(other, DType) else other) == self._np
+        except TypeError:
+            return False
+
+    def __ne__(self, other):
+        return not self == other
+
+    def __hash__(self):
+        return hash(self._np)
+
+    def __repr__(self):
+        return f"tf.{self.name}"
 
 
 class Tensor(np.ndarray):
     """ndarray with the few tf.Tensor methods the reference calls."""
 
+    @property
+    def shape(self):
+        return _Shape(np.ndarray.shape.__get__(self))
+
+    @property
+    def dtype(self):
+        return DType(np.ndarray.dtype.__get__(self))
+
     def get_shape(self):
-        return _Shape(self.shape)
+        return self.shape
 
     def numpy(self):
         return np.asarray(self)
@@ -133,7 +182,8 @@ def make_tf():
     tf.__doc__ = "NumPy stand-in (tools/ref_exec/tf_numpy.py)"
     tf.Tensor, tf.RaggedTensor = Tensor, RaggedTensor
     for name in ("float16", "float32", "float64", "int8", "int16", "int32", "int64", "uint8", "complex64", "complex128", "bool"):
-        setattr(tf, name, np.dtype(name))
+        setattr(tf, name, DType(name))
+    tf.DType, tf.dtypes = DType, types.SimpleNamespace(DType=DType)
     tf.newaxis = None
 
     # ---- construction / casting
@@ -150,17 +200,30 @@ def make_tf():
     tf.ones = lambda shape, dtype=np.float32, name=None: _t(np.ones([int(s) for s in np.atleast_1d(shape)], dtype))
     tf.zeros_like = _elementwise(np.zeros_like)
     tf.ones_like = _elementwise(np.ones_like)
-    tf.eye = lambda n, m=None, dtype=np.float32, **k: _t(np.eye(int(n), None if m is None else int(m), dtype=dtype))
+    def eye(num_rows, num_columns=None, batch_shape=None, dtype=np.float32, name=None):
+        e = np.eye(int(num_rows), None if num_columns is None else int(num_columns), dtype=dtype)
+        if batch_shape is not None and len(batch_shape):
+            e = np.broadcast_to(e, [int(b) for b in batch_shape] + list(e.shape)).copy()
+        return _t(e)
+    tf.eye = eye
     tf.range = lambda *a, dtype=None, **k: _t(np.arange(*[int(x) for x in a], dtype=dtype or np.int32))
     tf.is_tensor = lambda x: isinstance(x, (Tensor, RaggedTensor))
     tf.shape = lambda x, **k: _t(np.array(np.asarray(x).shape, dtype=np.int32))
-    tf.rank = lambda x: np.asarray(x).ndim
+    tf.rank = lambda x, **k: np.asarray(x).ndim
+    tf.executing_eagerly = lambda: True
     tf.size = lambda x: np.asarray(x).size
     tf.identity = lambda x, **k: x
     tf.stop_gradient = lambda x: x
     tf.ensure_shape = lambda x, shape, **k: x
-    tf.complex = lambda re, im: _t(np.asarray(re) + 1j * np.asarray(im)).astype(
-        np.complex64 if np.asarray(re).dtype == np.float32 else np.complex128).view(Tensor)
+    def _complex(re, im, name=None):
+        re, im = np.asarray(re), np.asarray(im)
+        out = np.empty(np.broadcast(re, im).shape, np.complex64 if re.dtype == np.float32 else np.complex128)
+        out.real, out.imag = re, im
+        return _t(out)
+    tf.complex = _complex
+    tf.split = lambda value, num_or_size_splits, axis=0, **k: [_t(a) for a in (
+        np.split(np.asarray(value), num_or_size_splits, axis=axis) if np.isscalar(num_or_size_splits)
+        else np.split(np.asarray(value), np.cumsum(num_or_size_splits)[:-1], axis=axis))]
 
     # ---- shape manipulation (copies: the reference mutates with *= afterwards)
     tf.reshape = lambda x, shape, name=None: _t(np.reshape(np.asarray(x), [int(s) for s in np.atleast_1d(shape)]).copy())
@@ -223,6 +286,18 @@ def make_tf():
         sqrt=tf.sqrt, square=tf.square, real=_elementwise(np.real), imag=_elementwise(np.imag), conj=_elementwise(np.conj),
         reduce_logsumexp=None, log1p=_elementwise(np.log1p), softplus=None,
         divide_no_nan=lambda a, b: _t(np.where(np.asarray(b) == 0, 0, np.asarray(a) / np.where(np.asarray(b) == 0, 1, np.asarray(b))).astype(np.asarray(a).dtype)))
+    def _lse(x, axis=None, keepdims=False, name=None):
+        x = np.asarray(x)
+        m = np.max(x, axis=axis, keepdims=True)
+        m = np.where(np.isfinite(m), m, 0).astype(x.dtype)
+        r = np.log(np.sum(np.exp(x - m), axis=axis, keepdims=True)) + m     # tf.reduce_logsumexp (math_ops.py): same form
+        return _t(r if keepdims else np.squeeze(r, axis=axis))
+    tf.reduce_logsumexp = tf.math.reduce_logsumexp = _lse
+    tf.math.log_sigmoid = _elementwise(lambda x: -np.logaddexp(np.zeros_like(x), -x))      # -softplus(-x)
+    tf.math.softplus = _elementwise(lambda x: np.logaddexp(np.zeros_like(x), x))
+    tf.math.softmax = lambda x, axis=-1, **k: _t(np.exp(np.asarray(x) - _lse(x, axis=axis, keepdims=True)))
+    tf.nn = types.SimpleNamespace(log_softmax=lambda x, axis=-1, **k: _t(np.asarray(x) - _lse(x, axis=axis, keepdims=True)),
+                                  softmax=tf.math.softmax, relu=_elementwise(lambda x: np.maximum(x, 0)))
     tf.math.mod = lambda a, b: _t(np.mod(np.asarray(a), b))
     tf.math.floormod = tf.math.mod
 
@@ -249,7 +324,10 @@ def make_tf():
     tf.logical_or = _binary(np.logical_or)
     tf.logical_and = _binary(np.logical_and)
     tf.pow = _binary(lambda a, b: a ** b)
-    tf.bitwise = types.SimpleNamespace(bitwise_and=_binary(np.bitwise_and), bitwise_xor=_binary(np.bitwise_xor))
+    tf.bitwise = types.SimpleNamespace(bitwise_and=_binary(np.bitwise_and), bitwise_xor=_binary(np.bitwise_xor),
+                                       left_shift=_binary(np.left_shift), right_shift=_binary(np.right_shift))
+    tf.math.maximum, tf.math.minimum, tf.math.pow = tf.maximum, tf.minimum, tf.pow
+    tf.math.multiply, tf.math.add, tf.math.subtract, tf.math.divide = tf.multiply, tf.add, tf.subtract, tf.divide
 
     def where(cond, x=None, y=None, name=None):
         c = _dense(cond)
@@ -305,10 +383,17 @@ def make_tf():
     def function(func=None, **k):
         return (lambda f: f) if func is None else func
     tf.function = function
-    tf.debugging = types.SimpleNamespace(
-        assert_equal=lambda a, b, message=None, **k: None if np.all(np.asarray(a) == np.asarray(b)) else (_ for _ in ()).throw(
-            AssertionError(message or "assert_equal")),
-        assert_greater_equal=lambda *a, **k: None, assert_less=lambda *a, **k: None, assert_type=lambda *a, **k: None)
+    class _Debugging:
+        @staticmethod
+        def assert_equal(a, b, message=None, **k):
+            if not np.all(np.asarray(a) == np.asarray(b)):
+                raise AssertionError(message or "assert_equal")
+
+        def __getattr__(self, name):                                # the other tf.debugging.assert_* are argument checks
+            if name.startswith("assert_"):
+                return lambda *a, **k: None
+            raise AttributeError(name)
+    tf.debugging = _Debugging()
     tf.linalg = types.SimpleNamespace(
         cholesky=lambda a: _t(np.linalg.cholesky(np.asarray(a))),
         matmul=lambda a, b, adjoint_a=False, adjoint_b=False, transpose_a=False, transpose_b=False, **k: tf.matmul(
@@ -317,7 +402,9 @@ def make_tf():
         diag=lambda d: _t(np.asarray(d)[..., None] * np.eye(np.asarray(d).shape[-1], dtype=np.asarray(d).dtype)),
         adjoint=lambda a: _t(np.conj(np.swapaxes(np.asarray(a), -1, -2))),
         inv=lambda a: _t(np.linalg.inv(np.asarray(a))),
-        triangular_solve=None, eye=tf.eye, matvec=lambda a, b, **k: _t(np.einsum("...ij,...j->...i", np.asarray(a), np.asarray(b))))
+        triangular_solve=lambda matrix, rhs, lower=True, adjoint=False, **k: _t(_tri_solve(np.asarray(matrix), np.asarray(rhs), lower, adjoint)),
+        cholesky_solve=lambda chol, rhs, **k: _t(_tri_solve(np.asarray(chol), _tri_solve(np.asarray(chol), np.asarray(rhs), True, False), True, True)),
+        eye=tf.eye, matvec=lambda a, b, **k: _t(np.einsum("...ij,...j->...i", np.asarray(a), np.asarray(b))))
 
     def matmul(a, b, transpose_a=False, transpose_b=False, adjoint_a=False, adjoint_b=False, **k):
         a, b = np.asarray(a), np.asarray(b)
@@ -328,11 +415,37 @@ def make_tf():
         return _t(np.matmul(a, b))
     tf.matmul = matmul
     tf.name_scope = lambda *a, **k: _NullCtx()
-    tf.Variable = lambda initial_value, *a, dtype=None, **k: _t(np.array(initial_value, dtype=dtype))
+    class Variable(Tensor):
+        """tf.Variable stand-in (an ndarray view; ``isinstance(x, tf.Variable)`` is False for plain tensors)."""
+        def __new__(cls, initial_value, *a, dtype=None, **k):
+            return np.array(initial_value, dtype=dtype).view(cls)
+    tf.Variable = Variable
     tf.keras = types.SimpleNamespace(layers=types.SimpleNamespace(Layer=object))
     tf.config = types.SimpleNamespace(list_physical_devices=lambda *a: [])
     tf.random = types.SimpleNamespace()
+    for _n in ("greater", "greater_equal", "less", "less_equal", "equal", "not_equal", "logical_or", "logical_and"):
+        setattr(tf.math, _n, getattr(tf, _n))
+    for _n in ("reduce_sum", "reduce_prod", "reduce_min", "reduce_max", "reduce_mean", "reduce_any", "reduce_all", "argmax", "argmin"):
+        if hasattr(tf, _n):
+            setattr(tf.math, _n, getattr(tf, _n))
     return tf
+
+
+def _tri_solve(l, rhs, lower, adjoint):
+    """Batched triangular solve by substitution in the matrices' own dtype (TF: MatrixTriangularSolve -> Eigen
+    triangularView.solve; same recurrences, accumulation order may differ in the last bit)."""
+    if adjoint:
+        l, lower = np.conj(np.swapaxes(l, -1, -2)), not lower
+    n = l.shape[-1]
+    x = np.zeros(np.broadcast_shapes(l.shape[:-2], rhs.shape[:-2]) + rhs.shape[-2:], dtype=np.result_type(l, rhs))
+    order = range(n) if lower else range(n - 1, -1, -1)
+    for i in order:
+        acc = rhs[..., i, :].astype(x.dtype)
+        js = range(i) if lower else range(n - 1, i, -1)
+        for j in js:
+            acc = acc - l[..., i, j, None] * x[..., j, :]
+        x[..., i, :] = acc / l[..., i, i, None]
+    return x
 
 
 class _NullCtx:
