@@ -130,15 +130,24 @@ def world_info():
     return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 
 
-def barrier(world, device_sync):
+def _grouped(world):
+    """Collectives run when there is more than one rank - or when a launcher started this process as the single rank of a
+    one-member group (`torch.distributed.run --nproc-per-node 1 bench.py --gpus 1`: the RCCL path end to end on one GPU)."""
     if world > 1:
+        return True
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
+def barrier(world, device_sync):
+    if _grouped(world):
         import torch.distributed as dist
         dist.barrier()
     device_sync()
 
 
 def reduce_sum(t, world):
-    if world > 1:
+    if _grouped(world):
         import torch.distributed as dist
         t = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -147,7 +156,7 @@ def reduce_sum(t, world):
 
 def reduce_max(value, world, device):
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if world > 1:
+    if _grouped(world):
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
@@ -508,7 +517,7 @@ def main():
         if backend != "nccl":
             local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):   # launched as a rank (also as the only one)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -638,9 +647,11 @@ def main():
             except Exception as e:  # pylint: disable=broad-except  (a secondary workload must not lose the headline line)
                 out["extra"][name] = {"error": f"{type(e).__name__}: {e}"}
 
+    if _grouped(world):
+        out["collectives"] = {"backend": dist.get_backend(), "group_size": dist.get_world_size()}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if _grouped(world):
         dist.destroy_process_group()
 
 

@@ -54,6 +54,16 @@ int samd_version(void);
 /* number of visible HIP devices, or a negative error */
 int samd_device_count(void);
 
+/* Development switches (csrc/options.h).  The library never calls getenv on a compute path: the SAMD_* variables of
+ * the process environment are copied into a registry once, when the library is loaded; this entry changes one value
+ * afterwards (value NULL removes the key).  A switch affects handles CREATED after the call - a handle keeps the
+ * options it was built with for its whole life, so handles built under different options can run concurrently from
+ * several host threads - and the few handle-less entry points from their next call on.  Tests and the tools/ scripts
+ * use it instead of setenv; a product integration never needs it.  Keys must start with "SAMD_". */
+int samd_debug_set_option(const char* key, const char* value);
+/* incremented by every samd_debug_set_option (host-side caches of handles key on it) */
+int samd_debug_options_generation(void);
+
 /* ------------------------------------------------------------------------------------
  * Generic LDPC flooding BP decoder (any parity-check matrix).
  * Replaces LDPCBPDecoder.call + _bp_iter      fec/ldpc/decoding.py:544-637, 416-524

@@ -101,6 +101,8 @@ _SIGNATURES = {
     "samd_polar_scl_decode_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i32, _vp, _vp,
                                          _vp, _sz, _vp]),
     "samd_count_errors_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "samd_debug_set_option": (_i32, [C.c_char_p, C.c_char_p]),
+    "samd_debug_options_generation": (_i32, []),
 }
 
 
@@ -130,6 +132,32 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
+
+
+def set_option(key, value=None):
+    """Development switch of the library (include/sionna_amd.h ``samd_debug_set_option``): ``value=None`` removes it.
+    Takes effect for handles created afterwards - the Python blocks key their handle caches on the options generation,
+    so the next call of a block builds a fresh handle."""
+    check(lib().samd_debug_set_option(key.encode(), None if value is None else str(value).encode()), "samd_debug_set_option")
+
+
+class option:
+    """``with _ffi.option("SAMD_X", 1): ...`` - set a development switch for the duration of a block."""
+
+    def __init__(self, key, value="1"):
+        self.key, self.value = key, value
+
+    def __enter__(self):
+        set_option(self.key, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.key, None)
+        return False
+
+
+def options_generation():
+    return int(lib().samd_debug_options_generation())
 
 
 def check(rc, what=""):

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/sionna_amd.h"
@@ -45,6 +46,26 @@ inline int upload(T** dst, const T* src, size_t n) {
   SAMD_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
   return SAMD_OK;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel: set it the first time a (kernel,
+// device, size) triple is launched from this process instead of on every launch.  Lock-free: a hash collision or a race
+// between two host threads only repeats the (idempotent) runtime call.
+inline int set_max_dynamic_lds(const void* fn, int bytes) {
+  static std::atomic<uint64_t> seen[512];
+  int dev = 0;
+  SAMD_HIP_CHECK(hipGetDevice(&dev));
+  const uint64_t key = ((uint64_t)(uintptr_t)fn << 12) ^ ((uint64_t)bytes << 8) ^ (uint64_t)(dev + 1);
+  std::atomic<uint64_t>& slot = seen[(key * 0x9E3779B97F4A7C15ull) >> 55];
+  if (slot.load(std::memory_order_acquire) == key) return SAMD_OK;
+  SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  slot.store(key, std::memory_order_release);
+  return SAMD_OK;
+}
+#define SAMD_SET_MAX_LDS(fn, bytes)                                                  \
+  do {                                                                              \
+    const int _rc = samd::set_max_dynamic_lds((const void*)(fn), (bytes));          \
+    if (_rc != SAMD_OK) return _rc;                                                 \
+  } while (0)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1,6 +1,7 @@
 // Shared declarations of the 5G-NR QC-LDPC kernels (handle layout, rate-matching index maps).
 #pragma once
 #include "common.h"
+#include "options.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -8,7 +9,29 @@
 #include <utility>
 #include <vector>
 
+// Development switches a handle captured when it was created (options.h): its launch paths read these, never the
+// environment, so a handle behaves the same for its whole life.
+struct samd_ldpc5g_opt {
+  bool enc_bytes = false, enc_persist = false, onchip_compressed = false, force_spill = false, no_spill = false;
+  bool no_onchip_layered = false, bp_engine = false, onchip_v1 = false, ms_nogroup = false, ms_noz128 = false;
+  int ms_var = 1, ms_ldsbar = 0, onchip_grid = 0, enc_dbg = 0;
+  void capture() {
+    using samd::opt_set; using samd::opt_int;
+    enc_bytes = opt_set("SAMD_ENC_BYTES"); enc_persist = opt_set("SAMD_ENC_PERSIST");
+    onchip_compressed = opt_set("SAMD_ONCHIP_COMPRESSED"); force_spill = opt_set("SAMD_FORCE_SPILL");
+    no_spill = opt_set("SAMD_NO_SPILL"); no_onchip_layered = opt_set("SAMD_NO_ONCHIP_LAYERED");
+    bp_engine = opt_set("SAMD_BP_ENGINE"); onchip_v1 = opt_set("SAMD_ONCHIP_V1");
+    ms_nogroup = opt_set("SAMD_MS_NOGROUP"); ms_noz128 = opt_set("SAMD_MS_NOZ128");
+    ms_var = (int)opt_int("SAMD_MS_VAR", 1) & 1; ms_ldsbar = (int)opt_int("SAMD_MS_LDSBAR", 0);
+    onchip_grid = (int)opt_int("SAMD_ONCHIP_GRID", 0);
+#ifdef SAMD_DEV
+    enc_dbg = (int)opt_int("SAMD_ENC_DBG", 0);        // skips encoder phases: wrong results, development builds only
+#endif
+  }
+};
+
 struct samd_ldpc5g {
+  samd_ldpc5g_opt opt;
   int bg = 0, z = 0, k = 0, n = 0, m_int = 0, nb_pruned = 0;
   int mb = 0, nb = 0, k_b = 0, k_ldpc = 0, n_ldpc = 0, n_vn = 0, n_cn = 0;
   int s_a = 0, s_b = 0;  // shifts of the core entries P_A, P_B (encoding.py:476-481)
@@ -130,7 +153,7 @@ inline void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, int 
   // order of a wave's items (SAMD_MS_ORDER; default 2: +2.5 % at C2 - the four waves of a SIMD start a phase on items of
   // different size instead of all on their largest): 0 = largest first on every wave; 1 = odd waves
   // smallest first; 2 = rotated by the wave's index on its SIMD; 3 = waves 2, 3 (mod 4) smallest first
-  static const int order_mode = getenv("SAMD_MS_ORDER") ? atoi(getenv("SAMD_MS_ORDER")) : 2;
+  const int order_mode = (int)opt_int("SAMD_MS_ORDER", 2);       // handle-build time
   for (int w = 0; w < nw && order_mode; ++w) {
     if (per[w].size() < 2) continue;
     if ((order_mode == 1 && (w & 1)) || (order_mode == 3 && (w & 2))) std::reverse(per[w].begin(), per[w].end());
@@ -159,7 +182,7 @@ inline void lpt_schedule(const std::vector<std::pair<int, int32_t>>& items, int 
 inline std::vector<int> item_priorities(const std::vector<std::pair<int, int32_t>>& items, const std::vector<int32_t>& ptr,
                                         const std::vector<int32_t>& list) {
   std::vector<int> prio(list.size(), 0);
-  if (getenv("SAMD_MS_NOPRIO")) return prio;
+  if (opt_set("SAMD_MS_NOPRIO")) return prio;
   auto cost_of = [&](int32_t id) {
     for (auto& it : items)
       if (it.second == id) return it.first + 3;

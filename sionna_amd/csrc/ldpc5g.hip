@@ -375,6 +375,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   SAMD_REQUIRE(bg == 1 || bg == 2, "bg must be 1 or 2");
   SAMD_REQUIRE(z >= 2 && z <= 384 && num_entries > 0, "bad lifting size");
   auto* h = new samd_ldpc5g();
+  h->opt.capture();                                        // development switches: read once, here (options.h)
   h->bg = bg; h->z = z; h->k = k; h->n = n; h->m_int = num_bits_per_symbol; h->nb_pruned = nb_pruned;
   h->mb = bg == 1 ? 46 : 42; h->nb = bg == 1 ? 68 : 52; h->k_b = bg == 1 ? 22 : 10;
   h->k_ldpc = h->k_b * z; h->n_ldpc = h->nb * z;
@@ -466,25 +467,23 @@ extern "C" void samd_ldpc5g_destroy(samd_ldpc5g_t* h) {
 
 extern "C" int samd_ldpc5g_encode_f32(const samd_ldpc5g_t* h, const float* bits, float* out, int batch, void* stream) {
   SAMD_REQUIRE(h && bits && out && batch > 0, "bad argument");
-  if (h->enc_out_idx && h->z % 32 == 0 && !getenv("SAMD_ENC_BYTES")) {
+  if (h->enc_out_idx && h->z % 32 == 0 && !h->opt.enc_bytes) {
     // lifting sizes that are multiples of 32: the bit-packed kernel, one wave per codeword
     const int wq = h->z / 32;
     const size_t lds_p = (4 * (size_t)((h->mb + h->k_b) * wq + 4 * wq) + (size_t)h->mb + 1 + (size_t)h->nnz) * sizeof(uint32_t) +
                          (size_t)(h->n + 2) * sizeof(uint16_t);
-    if (lds_p > 64 * 1024)
-      SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc5g_encode_packed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    if (lds_p > 64 * 1024) SAMD_SET_MAX_LDS(ldpc5g_encode_packed_kernel, 160 * 1024);
     // one codeword per wave and launch slot: a wave that went on to a second codeword would wait for its own output
     // stores before the next input arrives (loads and stores share the in-order vmcnt counter) - measured 1.12 ms
     // against 0.28 ms (input + rows) + 0.42 ms (output) for the separate phases at C2
-    const int grid = getenv("SAMD_ENC_PERSIST") ? std::min((batch + 3) / 4, 256 * 8 * 4) : (batch + 3) / 4;
+    const int grid = h->opt.enc_persist ? std::min((batch + 3) / 4, 256 * 8 * 4) : (batch + 3) / 4;
     hipLaunchKernelGGL(ldpc5g_encode_packed_kernel, dim3(grid), dim3(256), lds_p, (hipStream_t)stream, bits, out, make_rm(h),
                        batch, h->mb, h->k_b, h->bg, h->s_a, h->s_b, h->row_ptr, h->row_ent, h->enc_out_idx,
-                       getenv("SAMD_ENC_DBG") ? atoi(getenv("SAMD_ENC_DBG")) : 0);
+                       h->opt.enc_dbg);
     return launch_status();
   }
   const size_t lds = (size_t)h->n_ldpc + 4 * (size_t)h->z;
-  // set on every launch: the attribute is per device and a process may drive several
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)ldpc5g_encode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  SAMD_SET_MAX_LDS(ldpc5g_encode_kernel, 64 * 1024);
   hipLaunchKernelGGL(ldpc5g_encode_kernel, dim3(batch), dim3(256), lds, (hipStream_t)stream, bits, out, make_rm(h),
                      h->mb, h->k_b, h->bg, h->s_a, h->s_b, h->row_ptr, h->row_ent);
   return launch_status();
@@ -514,17 +513,17 @@ extern "C" int samd_ldpc5g_extract_codeword_f32(const samd_ldpc5g_t* h, const fl
 
 // min-sum family: explicit messages (ldpc5g_onchip_ms.hip) when they fit in LDS, else the compressed
 // check-node state (ldpc5g_onchip.hip, every 5G code).  SAMD_ONCHIP_COMPRESSED=1 forces the latter.
-static bool use_explicit_minsum(const samd_ldpc5g* h) { return h->bp_ok && h->ms_cn_list && h->ms_vn_list && !getenv("SAMD_ONCHIP_COMPRESSED"); }
+static bool use_explicit_minsum(const samd_ldpc5g* h) { return h->bp_ok && h->ms_cn_list && h->ms_vn_list && !h->opt.onchip_compressed; }
 // ... or explicit messages with the last base rows' blocks in the L2 workspace row (ldpc5g_onchip_mss.hip)
 // measured (tools/sweep_ldpc.py): up to about a quarter of the edges in L2 this beats the compressed state engine
 // (+16 % at 4 %, +9 % at 26 %, even at 28 %); beyond that the L2 round trips of the VN phase dominate
 static bool use_spill_minsum(const samd_ldpc5g* h) {
-  return !h->bp_ok && h->sp_ok && (h->sp_spill_pct <= 27 || getenv("SAMD_FORCE_SPILL")) &&
-         !getenv("SAMD_ONCHIP_COMPRESSED") && !getenv("SAMD_NO_SPILL");
+  return !h->bp_ok && h->sp_ok && (h->sp_spill_pct <= 27 || h->opt.force_spill) &&
+         !h->opt.onchip_compressed && !h->opt.no_spill;
 }
 // boxplus rules on codes whose messages exceed LDS: the alternative is the HBM-resident engine, and the phi / tanh
 // arithmetic (VALU bound) hides the L2 round trips - any spill share
-static bool use_spill_boxplus(const samd_ldpc5g* h) { return !h->bp_ok && h->sp_ok && !getenv("SAMD_NO_SPILL"); }
+static bool use_spill_boxplus(const samd_ldpc5g* h) { return !h->bp_ok && h->sp_ok && !h->opt.no_spill; }
 
 extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int batch, int cn_mode) {
   // 0 when the whole state fits in LDS; larger codes keep part of it in this (L2-resident) scratch
@@ -540,7 +539,7 @@ extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int
 extern "C" int samd_ldpc5g_decode_layered_supported(const samd_ldpc5g_t* h, int cn_mode) {
   const bool rule = cn_mode == SAMD_CN_MINSUM || cn_mode == SAMD_CN_OFFSET_MINSUM || cn_mode == SAMD_CN_BOXPLUS_PHI ||
                     cn_mode == SAMD_CN_BOXPLUS_PHI_FAST;
-  return (h && h->ly_ok && rule && !getenv("SAMD_NO_ONCHIP_LAYERED")) ? 1 : 0;
+  return (h && h->ly_ok && rule && !h->opt.no_onchip_layered) ? 1 : 0;
 }
 
 extern "C" size_t samd_ldpc5g_decode_layered_workspace_bytes(const samd_ldpc5g_t* h, int batch) {
@@ -576,7 +575,7 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
                                workspace, workspace_bytes, (hipStream_t)stream);
     // the explicit-message engine with the boxplus node update (pair items, fused degree-1 columns, prefetched
     // descriptors - ldpc5g_onchip_ms.hip); SAMD_BP_ENGINE=1 keeps the first boxplus kernel (ldpc5g_onchip_bp.hip)
-    if (use_explicit_minsum(h) && !getenv("SAMD_BP_ENGINE")) {
+    if (use_explicit_minsum(h) && !h->opt.bp_engine) {
       const int rc = launch_onchip_ms(h, llr, out, batch, num_iter, cn_mode, llr_max, 0.f, hard_out, return_infobits,
                                       workspace, workspace_bytes, (hipStream_t)stream);
       if (rc != SAMD_ERR_UNSUPPORTED) return rc;
@@ -606,7 +605,7 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
                                      workspace, workspace_bytes, (hipStream_t)stream);
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
-  if (h->v2_ok && !getenv("SAMD_ONCHIP_V1")) {   // statically scheduled, unrolled engine
+  if (h->v2_ok && !h->opt.onchip_v1) {   // statically scheduled, unrolled engine
     const int rc = launch_onchip_v2(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out,
                                     return_infobits, workspace, workspace_bytes, (hipStream_t)stream);
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
@@ -617,8 +616,7 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   }
   const bool off = (cn_mode == SAMD_CN_OFFSET_MINSUM);
   const void* fn = off ? (const void*)ldpc5g_decode_kernel<true> : (const void*)ldpc5g_decode_kernel<false>;
-  // set on every launch: the attribute is per device and a process may drive several
-  SAMD_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SAMD_SET_MAX_LDS(fn, 160 * 1024);
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);

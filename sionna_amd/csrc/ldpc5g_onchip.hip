@@ -399,17 +399,19 @@ int build_onchip_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pair<
   if (lds > 160 * 1024 && ((size_t)h->nbu + (size_t)3 * (h->ncu + 1)) * z * 4 <= 160 * 1024) {
     h->llr_global = 1;                                          // channel LLRs move to the workspace (L2)
     lds = ((size_t)h->nbu + (size_t)3 * (h->ncu + 1)) * z * 4;
-  } else if (lds > 160 * 1024 && (size_t)3 * (h->ncu + 1) * z * 4 <= 160 * 1024 && !getenv("SAMD_NO_XTG")) {
+  } else if (lds > 160 * 1024 && (size_t)3 * (h->ncu + 1) * z * 4 <= 160 * 1024 && !opt_set("SAMD_NO_XTG")) {
     h->llr_global = 2;                                          // x_tot as well: LDS = check-node state only
     lds = (size_t)3 * (h->ncu + 1) * z * 4;
-  } else if (lds > 160 * 1024 && (size_t)2 * (h->ncu + 1) * z * 4 <= 160 * 1024 && !getenv("SAMD_NO_XTG")) {
+  } else if (lds > 160 * 1024 && (size_t)2 * (h->ncu + 1) * z * 4 <= 160 * 1024 && !opt_set("SAMD_NO_XTG")) {
     h->llr_global = 3;                                          // ... and the sign words: LDS = (M1, M2)
     lds = (size_t)2 * (h->ncu + 1) * z * 4;
   }
   h->dec_waves = 16;
   for (int nwc : {8, 4, 2, 1})
     if (lds * (size_t)(kDecWaves / nwc) <= 160 * 1024) h->dec_waves = nwc;
-  if (const char* e = getenv("SAMD_ONCHIP_WAVES")) {
+  if (opt_set("SAMD_ONCHIP_WAVES")) {
+    const std::string e_s = opt_str("SAMD_ONCHIP_WAVES");
+    const char* e = e_s.c_str();
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) h->dec_waves = v;      // experiments: force a workgroup size
   }
@@ -493,7 +495,7 @@ int launch_onchip_v2(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const int ki = h->llr_global ? 8 + 2 * h->llr_global + (pow2 ? 1 : 0)
                                : ((nw == 16 ? 0 : nw == 8 ? 2 : nw == 4 ? 4 : nw == 2 ? 6 : 8) | (pow2 ? 1 : 0));
   // set on every launch: the attribute is per device and a process may drive several
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SAMD_SET_MAX_LDS(kerns[ki], 160 * 1024);
   const int grid = onchip_grid(h, batch);
   const RateMatch rm = make_rate_match(h);
   hipLaunchKernelGGL(kerns[ki], dim3(grid), dim3(nw * 64), lds, st, llr, out, llr_ws, rm, h->n_cn, h->ncu, h->nbu, batch,

@@ -210,7 +210,9 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   if (!h->bp_llr_global)
     for (int nwc : {8, 4, 2, 1})
       if (lds * (size_t)(kDecWaves / nwc) <= 160 * 1024) h->bp_waves = nwc;
-  if (const char* e = getenv("SAMD_ONCHIP_BP_WAVES")) {
+  if (opt_set("SAMD_ONCHIP_BP_WAVES")) {
+    const std::string e_s = opt_str("SAMD_ONCHIP_BP_WAVES");
+    const char* e = e_s.c_str();
     const int v = atoi(e);
     if (!h->bp_llr_global && (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) && lds * (size_t)(kDecWaves / v) <= 160 * 1024)
       h->bp_waves = v;
@@ -258,8 +260,8 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::vector<std::pair<int, int32_t>> ci2, vi2, vf2;
   // development knobs: per-item overhead of the cost model, capacities by wave launch order
   // (measured at C2 with tools/ms_sweep.py: a fixed cost of ~20 edges per item balances best)
-  const int cn_ovh = getenv("SAMD_MS_CN_OVH") ? atoi(getenv("SAMD_MS_CN_OVH")) : 400;
-  const int vn_ovh = getenv("SAMD_MS_VN_OVH") ? atoi(getenv("SAMD_MS_VN_OVH")) : 200;
+  const int cn_ovh = (int)opt_int("SAMD_MS_CN_OVH", 400);
+  const int vn_ovh = (int)opt_int("SAMD_MS_VN_OVH", 200);
   // cost per edge of a pair item / of a single-chunk item, and the fixed cost of a single-chunk VN item.  Round 3, item
   // trace of the grouped kernel (tools/ms_itrace.py, profiles/r03b/ms_itrace_r03d.txt): a CN pair item takes
   // 127 d + 1790 cycles, a VN pair item 115 d + 2240, a single-chunk VN item 111 d + 1040 - one chunk has one dependency
@@ -267,15 +269,15 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // 18: r02 model; 36 for the codes of the grouped kernel: +1.7 % at C2 (profiles/r03b/ms_cost_r03f.txt) - the other
   // lifting sizes lose 2-3 % with it (profiles/r03b/ldpc_sweep_r03_s36.json vs ..._s18.json)
   const bool grouped_code = z % 128 == 0 && h->n_cn % z == 0 && h->n_vn % z == 0;
-  const int cn_slope = getenv("SAMD_MS_CN_SLOPE") ? atoi(getenv("SAMD_MS_CN_SLOPE")) : (grouped_code ? 36 : 18);
-  const int vn_single = getenv("SAMD_MS_VN_SINGLE") ? atoi(getenv("SAMD_MS_VN_SINGLE")) : 0;   // 1: 10 d + vn_ovh / 2
+  const int cn_slope = (int)opt_int("SAMD_MS_CN_SLOPE", (grouped_code ? 36 : 18));
+  const int vn_single = (int)opt_int("SAMD_MS_VN_SINGLE", 0);   // 1: 10 d + vn_ovh / 2
   // Z not a multiple of 64: the last chunk of a row has `tail` < 64 lifted copies.  With tail <= 32 the tails of
   // 64 / gw rows of the same degree (and fused flag) are packed into one item (lane group g works for row g) - at
   // Z = 80 the 16-lane tails of four rows share a pass instead of running at 25 % lane utilisation each
   const int tail = z - 64 * (chunks - 1);
   int gw = 64;
   while (gw / 2 >= tail && gw > 8) gw /= 2;
-  if (getenv("SAMD_MS_NOPACK")) gw = 64;
+  if (opt_set("SAMD_MS_NOPACK")) gw = 64;
   const int groups = 64 / gw;
   int tail_sh = 0;
   while ((1 << tail_sh) < gw) ++tail_sh;
@@ -333,7 +335,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::vector<double> cap(h->bp_waves, 1.0);
   {
     double cls[4] = {1.0, 1.0, 1.0, 1.0};
-    if (const char* e = getenv("SAMD_MS_CAP")) sscanf(e, "%lf,%lf,%lf,%lf", &cls[0], &cls[1], &cls[2], &cls[3]);
+    if (opt_set("SAMD_MS_CAP")) sscanf(opt_str("SAMD_MS_CAP").c_str(), "%lf,%lf,%lf,%lf", &cls[0], &cls[1], &cls[2], &cls[3]);
     const int per_simd = std::max(1, h->bp_waves / 4);
     for (int wv = 0; wv < h->bp_waves; ++wv) cap[wv] = cls[std::min(3, (wv / 4) * 4 / per_simd)];
   }
@@ -347,13 +349,15 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // enough items per wave and lose 5 % - ms_refine_codes_r03z.txt).
   // development (tools/ms_autotune.py): item costs perturbed by +-SAMD_MS_PERTURB_PCT % from a seeded generator - a
   // search over LPT assignments near the model's by measurement
-  if (const char* e = getenv("SAMD_MS_PERTURB")) {
-    unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(atoll(e) + 1);
-    const int pct = getenv("SAMD_MS_PERTURB_PCT") ? atoi(getenv("SAMD_MS_PERTURB_PCT")) : 8;
+#ifdef SAMD_DEV                                               // changes the schedule search, not for product builds
+  if (opt_set("SAMD_MS_PERTURB")) {
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (unsigned long long)(opt_int("SAMD_MS_PERTURB", 0) + 1);
+    const int pct = (int)opt_int("SAMD_MS_PERTURB_PCT", 8);
     auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
     for (auto* items : {&ci2, &vi2})
       for (auto& it : *items) it.first = std::max(1, (int)std::lround(it.first * (1.0 + pct / 100.0 * (2.0 * rnd() - 1.0))));
   }
+#endif
   auto refine = [&](std::vector<std::pair<int, int32_t>>& items, int tries, int extra, auto&& may_cut) {
     auto makespan = [&](const std::vector<std::pair<int, int32_t>>& its, std::vector<int>* owner) {
       std::vector<size_t> order(its.size());
@@ -392,13 +396,13 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       items.push_back({half, c | ((q + 1) << 8)});
     }
   };
-  refine(vi2, getenv("SAMD_MS_VN_REFINE") ? atoi(getenv("SAMD_MS_VN_REFINE")) : (chunks == 2 ? 8 : 0),
-         getenv("SAMD_MS_VN_REFINE_COST") ? atoi(getenv("SAMD_MS_VN_REFINE_COST")) : 70, [](int) { return true; });
+  refine(vi2, (int)opt_int("SAMD_MS_VN_REFINE", (chunks == 2 ? 8 : 0)),
+         (int)opt_int("SAMD_MS_VN_REFINE_COST", 70), [](int) { return true; });
   // the same for the check-node pair items (the grouped kernel has the single-chunk bodies under key + 64)
   // (C2: +2 %, profiles/r03b/ms_refine_cn3_r03z.txt; rows of degree 5 / 6 with a fused column only - every further
   // single-chunk body in the kernel slows the items that do not use it: all 17 bodies -2 %, four -1.4 %, two -0.3 %)
-  refine(ci2, getenv("SAMD_MS_CN_REFINE") ? atoi(getenv("SAMD_MS_CN_REFINE")) : (chunks == 2 ? 4 : 0),
-         getenv("SAMD_MS_CN_REFINE_COST") ? atoi(getenv("SAMD_MS_CN_REFINE_COST")) : 150,
+  refine(ci2, (int)opt_int("SAMD_MS_CN_REFINE", (chunks == 2 ? 4 : 0)),
+         (int)opt_int("SAMD_MS_CN_REFINE_COST", 150),
          [&](int r) { const int d = (int)by_row[r].size(); return fused_col[r] >= 0 && d >= 5 && d <= 6; });
   lpt_schedule(ci2, h->bp_waves, &mcp, &mcl, &cap);
   lpt_schedule(vi2, h->bp_waves, &mvp, &mvl, &cap);
@@ -490,6 +494,17 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
             it.y = col_start[idx] | (q << 20);
             if (col_start[idx] >= (1 << 20) || idx * z + q * 64 >= (1 << 23)) ok = false;
           }
+          // every key must have a compiled body in ldpc5g_decode_msg_kernel (its switches end in `default: break`, which
+          // would skip the item silently): CN degrees 3..10 and 19, plain or with a fused degree-1 column (+32, up to 10),
+          // single-chunk CN items only as 64+37 / 64+38; VN degrees 1..30, chunk pairs (+32) up to degree 12
+          if (!phase) {
+            const int dgr = it.key & 31, fz = (it.key >> 5) & 1, single = (it.key >> 6) & 1;
+            const bool body = single ? (fz && (dgr == 5 || dgr == 6)) : ((dgr >= 3 && dgr <= 10) || (dgr == 19 && !fz));
+            if (!body) ok = false;
+          } else {
+            const int dgr = it.key & 31, pair = (it.key >> 5) & 1;
+            if (dgr < 1 || dgr > 30 || (pair && dgr > 12)) ok = false;
+          }
           tot += it.cost;
           per[wv].push_back(it);
         }
@@ -516,14 +531,14 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
             grp.back().push_back(it);
           }
         }
-        if (grp.size() > 1 && !getenv("SAMD_MS_NOROT")) std::rotate(grp.begin(), grp.begin() + ((wv >> 2) % grp.size()), grp.end());
+        if (grp.size() > 1 && !opt_set("SAMD_MS_NOROT")) std::rotate(grp.begin(), grp.begin() + ((wv >> 2) % grp.size()), grp.end());
         double rem = 0.0;
         for (auto& gq : grp)
           for (auto& it : gq) rem += it.cost;
         for (auto& gq : grp) {
           const size_t first = il.size() / 2;
           for (auto& it : gq) {
-            const int prio = getenv("SAMD_MS_NOPRIO") ? 0 : std::max(0, std::min(3, (int)std::ceil(4.0 * rem / longest) - 1));
+            const int prio = opt_set("SAMD_MS_NOPRIO") ? 0 : std::max(0, std::min(3, (int)std::ceil(4.0 * rem / longest) - 1));
             rem -= it.cost;
             il.push_back(it.x | (prio << 24));
             il.push_back(it.y);
@@ -582,7 +597,7 @@ int onchip_bp_grid(const samd_ldpc5g* h, int batch) {
   size_t grid = std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
   // SAMD_ONCHIP_GRID=<n>: fewer workgroups than the chip holds (test hook: every workgroup then decodes several
   // codewords in sequence, which exercises the grid-stride loop and the reuse of its workspace row on small batches)
-  if (const char* e = getenv("SAMD_ONCHIP_GRID")) grid = std::min<size_t>(grid, (size_t)std::max(1, atoi(e)));
+  if (h->opt.onchip_grid > 0) grid = std::min<size_t>(grid, (size_t)h->opt.onchip_grid);
   return (int)grid;
 }
 
@@ -625,7 +640,7 @@ int launch_onchip_bp(const samd_ldpc5g* h, const float* llr, float* out, int bat
   const int wi = h->bp_llr_global ? 5 : (nw == 16 ? 0 : nw == 8 ? 1 : nw == 4 ? 2 : nw == 2 ? 3 : 4);
   const int ki = (phi ? 0 : 12) + 2 * wi + (pow2 ? 1 : 0);
   // set on every launch: the attribute is per device and a process may drive several
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SAMD_SET_MAX_LDS(kerns[ki], 160 * 1024);
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm = make_rate_match(h);
   hipLaunchKernelGGL(kerns[ki], dim3(onchip_bp_grid(h, batch)), dim3(nw * 64), onchip_bp_lds_bytes(h), st, llr, out, llr_ws, rm,

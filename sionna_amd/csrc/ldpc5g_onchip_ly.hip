@@ -404,7 +404,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   // 7.8 against 8.1 M decodes/s; from Z = 18 on the on-chip engine with 4 waves per codeword wins, 5.2 against 3.9 M -
   // layered_rate_smallz_r03z.txt)
   if (h->n_cn % z != 0 || h->n_vn % z != 0 || h->mb > 255 || h->nb > 255 || nbu > 0xFFFF ||
-      z < (getenv("SAMD_LY_MINZ") ? atoi(getenv("SAMD_LY_MINZ")) : 16) || z > 64 * 255) return SAMD_OK;
+      z < ((int)opt_int("SAMD_LY_MINZ", 16)) || z > 64 * 255) return SAMD_OK;
   static const int degs[] = {3, 4, 5, 6, 7, 8, 9, 10, 19};
   std::vector<int> col_deg(h->nb, 0);
   for (int r = 0; r < ncu; ++r)
@@ -430,7 +430,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     for (int r = 0; r < ncu; ++r) {
       bool clash = false;
       for (auto& e : by_row[r]) clash = clash || (!col_fused[e.first] && used[e.first]);
-      if ((clash && !cur.empty()) || getenv("SAMD_LY_NOGROUP")) {
+      if ((clash && !cur.empty()) || opt_set("SAMD_LY_NOGROUP")) {
         if (!cur.empty()) groups.push_back(cur);
         cur.clear();
         std::fill(used.begin(), used.end(), 0);
@@ -493,7 +493,11 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   const int chunks = (z + 63) / 64;                          // (the last one partly filled when Z is not a multiple of 64)
   struct Lists { std::vector<int32_t> rec_ptr, recs, slot_tab; int scratch_bytes = 0; };
   // SAMD_LY_ABL (development, wrong results): 1 = lists without the re-sum items, 2 = without the CN items, 3 = barriers only
-  const int abl = getenv("SAMD_LY_ABL") ? atoi(getenv("SAMD_LY_ABL")) : 0;
+#ifdef SAMD_DEV
+  const int abl = (int)opt_int("SAMD_LY_ABL", 0);
+#else
+  const int abl = 0;                                         // wrong results by construction: development builds only
+#endif
   // The lists are built twice: whole check-node items (min-sum: ~13 instructions per edge), and - `split` - items cut into
   // parts of 2 (row degree <= 10) or 4 edges for the boxplus rules (~100 instructions per edge), see ly_cns_part.
   // Returns 1 when the code does not fit the engine.
@@ -568,7 +572,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     bool need = false;
     for (int c = 0; c < nbu; ++c)
       if (in_group[g][c] && (g + 1 == G || in_group[g + 1][c])) need = true;
-    if (need || getenv("SAMD_LY_NODEFER")) ++nsteps;
+    if (need || opt_set("SAMD_LY_NODEFER")) ++nsteps;
   }
   // VN units: a column's chunk (or pair of chunks for degree <= 8 / 12); its item after the update of edge j reads 1 + (the
   // edges below j) messages.  Units go, heaviest first, to the wave where they add least to the sum over the groups of
@@ -576,14 +580,14 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   struct Unit { int c, q, pair, wave, slot; long cost; };
   std::vector<Unit> units;
   // (cost model of the schedule, in cycles of a lone wave; development knobs for tools/ly_grid.py)
-  const long ly_vn_slope = getenv("SAMD_LY_VN_SLOPE") ? atol(getenv("SAMD_LY_VN_SLOPE")) : 18;
-  const long ly_vn_ovh = getenv("SAMD_LY_VN_OVH") ? atol(getenv("SAMD_LY_VN_OVH")) : 250;
-  const long ly_cn_slope = getenv("SAMD_LY_CN_SLOPE") ? atol(getenv("SAMD_LY_CN_SLOPE")) : 60;
-  const long ly_cn_ovh = getenv("SAMD_LY_CN_OVH") ? atol(getenv("SAMD_LY_CN_OVH")) : 300;
+  const long ly_vn_slope = opt_int("SAMD_LY_VN_SLOPE", 18);
+  const long ly_vn_ovh = opt_int("SAMD_LY_VN_OVH", 250);
+  const long ly_cn_slope = opt_int("SAMD_LY_CN_SLOPE", 60);
+  const long ly_cn_ovh = opt_int("SAMD_LY_CN_OVH", 300);
   auto item_cost = [&](int c, int j, int pair) { return (pair ? 2 : 1) * ly_vn_slope * ((col_deg[c] - j + 3) / 4 * 4) + ly_vn_ovh; };
   // (two-chunk lifting sizes: 8 is +0.9 % over 12 at C2, ly_grid_r03z.txt; with more chunks 12 stays - k=3000 n=6000,
   // Z = 320, loses 2 % (boxplus-phi 7 %) with 8)
-  const int pair_max = getenv("SAMD_LY_PAIR_MAX") ? atoi(getenv("SAMD_LY_PAIR_MAX")) : (chunks == 2 ? 8 : 12);
+  const int pair_max = (int)opt_int("SAMD_LY_PAIR_MAX", (chunks == 2 ? 8 : 12));
   for (int c = 0; c < nbu; ++c) {
     if (xt_of_col[c] < 0) continue;
     for (int q = 0; q < chunks; ++q) {
@@ -657,7 +661,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     }
   struct VTask { int unit, j, lo, hi; long cost; };
   std::vector<VTask> vt;
-  const bool defer = !(getenv("SAMD_LY_NODEFER") && atoi(getenv("SAMD_LY_NODEFER")));
+  const bool defer = !(opt_int("SAMD_LY_NODEFER", 0));
   for (size_t ui = 0; ui < units.size(); ++ui) {
     const Unit& u = units[ui];
     for (size_t k2 = 0; k2 < touch[u.c].size(); ++k2) {
@@ -686,7 +690,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     sload[best][u.wave] += tk.cost;
     smax[best] = std::max(smax[best], sload[best][u.wave]);
   }
-  if (getenv("SAMD_LY_DUMP")) {                             // development (tools/ly_dump.py): the schedule, estimated cycles
+  if (opt_set("SAMD_LY_DUMP")) {                             // development (tools/ly_dump.py): the schedule, estimated cycles
     fprintf(stderr, "%s check-node items\n", split ? "split" : "whole");
     long total = 0;
     for (int st = 0; st < nsteps; ++st) {
@@ -740,6 +744,18 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     push(LY_NOP | LY_LAST, 0, 0, 0);                        // the walker reads one record ahead
   }
   rec_ptr.push_back((int32_t)(recs.size() / 4));
+  // every record's key must have a compiled body in ldpc5g_decode_ly_kernel (its switches end in `default: break`, which
+  // would skip the record silently and decode wrong LLRs): LY_VN re-sums of 1..8 lanes-of-4 (chunk pairs: 1..3), split
+  // check-node parts of 1..4 edges (plain / fused), whole rows of degree 3..10 and 19 (plain) or 3..10 (fused)
+  for (size_t t = 0; t < recs.size() / 4; ++t) {
+    const int32_t x = recs[4 * t];
+    const int kind = x & 3, key = (x >> 2) & 63;
+    bool body = true;
+    if (kind == LY_VN) body = (key >= 1 && key <= 8) || (key >= 17 && key <= 19);
+    else if (kind == LY_CNS) body = (key >= 1 && key <= 4) || (key >= 9 && key <= 12);
+    else if (kind == LY_CN) body = (key >= 3 && key <= 10) || key == 19 || (key >= 35 && key <= 42);
+    if (!body) return 1;
+  }
   // every wave must pass the same number of workgroup barriers per iteration (a split check-node part has one inside):
   // a list that does not is a deadlock on the GPU, so it is checked here and the code left to the HBM-resident engine
   long want = -1;
@@ -764,12 +780,12 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   Lists whole, parts;
   int NW = 0;
   for (int nw : {4, 8, 16}) {
-    if (const char* e = getenv("SAMD_LY_WAVES")) { if (atoi(e) != nw) continue; }
+    if (opt_set("SAMD_LY_WAVES") && (int)opt_int("SAMD_LY_WAVES", 0) != nw) continue;
     else if (nw < 16 && ((int)lds + max_scr) * (16 / nw) > 160 * 1024) continue;
     if (build_lists(false, nw, whole) == 0) { NW = nw; break; }
   }
   if (NW == 0) return SAMD_OK;
-  const bool have_parts = abl == 0 && !getenv("SAMD_LY_NOSPLIT") && build_lists(true, NW, parts) == 0 && parts.scratch_bytes > 0;
+  const bool have_parts = abl == 0 && !opt_set("SAMD_LY_NOSPLIT") && build_lists(true, NW, parts) == 0 && parts.scratch_bytes > 0;
   h->ly_waves = NW;
   h->ly_lds_bytes = (int)lds;
   h->ly_zero_off = zero_base / 4;
@@ -800,7 +816,7 @@ static int ly_grid(const samd_ldpc5g* h, int batch) {
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   int grid = std::min(batch, cus * (16 / std::max(4, h->ly_waves)));
-  if (const char* e = getenv("SAMD_ONCHIP_GRID")) grid = std::min(grid, std::max(1, atoi(e)));
+  if (h->opt.onchip_grid > 0) grid = std::min(grid, h->opt.onchip_grid);
   return grid;
 }
 
@@ -835,7 +851,7 @@ int launch_onchip_ly(const samd_ldpc5g* h, const float* llr, float* out, int bat
   static const kern_t kerns[3][2][2] = {SAMD_LY_K(SAMD_CN_MINSUM), SAMD_LY_K(SAMD_CN_BOXPLUS_PHI), SAMD_LY_K(SAMD_CN_BOXPLUS_PHI_FAST)};
 #undef SAMD_LY_K
   const kern_t fn = kerns[minsum ? 0 : cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : 2][h->z % 64 != 0 ? 1 : 0][pow2 ? 1 : 0];
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SAMD_SET_MAX_LDS(fn, 160 * 1024);
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm = make_rate_match(h);
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;

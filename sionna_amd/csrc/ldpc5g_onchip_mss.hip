@@ -475,7 +475,7 @@ int launch_onchip_mss(const samd_ldpc5g* h, const float* llr, float* out, int ba
                                   ldpc5g_decode_mss_kernel<false, SAMD_CN_BOXPLUS_PHI_FAST>, ldpc5g_decode_mss_kernel<true, SAMD_CN_BOXPLUS_PHI_FAST>};
   const int mi = cn_mode == SAMD_CN_BOXPLUS_PHI ? 1 : cn_mode == SAMD_CN_BOXPLUS ? 2 : cn_mode == SAMD_CN_BOXPLUS_PHI_FAST ? 3 : 0;
   const kern_t fn = kerns[2 * mi + (pow2 ? 1 : 0)];
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SAMD_SET_MAX_LDS(fn, 160 * 1024);
   const int nbu = (h->n_vn + h->z - 1) / h->z;
   const RateMatch rm = make_rate_match(h);
   const float off = (cn_mode == SAMD_CN_OFFSET_MINSUM) ? offset : 0.f;

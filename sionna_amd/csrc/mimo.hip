@@ -19,6 +19,7 @@
 // Gramian) are far below one MFMA tile per RE, so the matrix cores are not used: the kernel is
 // HBM-streaming (arithmetic intensity ~6 flop/B).
 #include "common.h"
+#include "options.h"
 
 namespace samd {
 
@@ -1039,7 +1040,8 @@ extern "C" int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const flo
   const int64_t total = (int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers;
   if (total == 0) return SAMD_OK;
   const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 127) / 128, brx_total = batch * num_rx;
-  const bool diag = num_undesired == 0 && whiten == 1 && !getenv("SAMD_LMMSE_GENERAL");   // diagonal covariance
+  static samd::CachedOpt lmmse_general_opt("SAMD_LMMSE_GENERAL");   // development: force the general-covariance kernel
+  const bool diag = num_undesired == 0 && whiten == 1 && !lmmse_general_opt.is_set();   // diagonal covariance
 #define X(M, K)                                                                                            \
   if (num_rx_ant == M && streams_per_rx == K) {                                                            \
     if (diag) for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 65535)                                                   \

@@ -381,13 +381,7 @@ extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const floa
 #undef SAMD_C2O_K
   const int ki = num_paths <= 8 ? 0 : num_paths <= 16 ? 1 : num_paths <= 24 ? 2 : num_paths <= 32 ? 3 : num_paths <= 64 ? 4 : 5;
   const kern_t kern = kerns[ki][taps_lds ? 1 : 0];
-  if (lds > 64 * 1024) {
-    static bool attr_set[6][2] = {};                         // once per kernel (one device per process)
-    if (!attr_set[ki][taps_lds ? 1 : 0]) {
-      SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set[ki][taps_lds ? 1 : 0] = true;
-    }
-  }
+  if (lds > 64 * 1024) SAMD_SET_MAX_LDS(kern, 160 * 1024);     // once per (kernel, device): common.h
   hipLaunchKernelGGL(kern, grid, blk, lds, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx, num_tx_ant,
                      num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq);
   return launch_status();

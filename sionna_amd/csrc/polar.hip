@@ -442,8 +442,8 @@ static int scl_grid(int batch, int n, int L, bool reg_engine) {
   int dev = 0, cus = 256;
   (void)hipGetDevice(&dev);
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  const char* e = getenv("SAMD_SCL_PER_CU");
-  const size_t cap = e ? (size_t)std::max(1, atoi(e)) : 32;   // one wave per workgroup: 8 per SIMD
+  static CachedOpt per_cu_opt("SAMD_SCL_PER_CU");
+  const size_t cap = (size_t)std::max<long>(1, per_cu_opt.get(32));   // one wave per workgroup: 8 per SIMD
   const size_t per_cu = std::min<size_t>(cap, std::max<size_t>(1, (160 * 1024) / lds));
   return (int)std::min<size_t>((size_t)batch, (size_t)cus * per_cu);
 }
@@ -457,7 +457,7 @@ extern "C" int samd_crc_f32(const float* bits, int64_t n_words, int k, uint32_t 
   SAMD_REQUIRE(bits && out && n_words >= 0 && k > 0 && crc_len > 0 && crc_len <= 32, "bad argument");
   if (n_words == 0) return SAMD_OK;
   if ((size_t)k * sizeof(uint32_t) <= 128 * 1024) {
-    SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)crc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    SAMD_SET_MAX_LDS(crc_kernel, 160 * 1024);
     const unsigned grid = (unsigned)std::min<int64_t>((n_words + 3) / 4, 256 * 8);
     hipLaunchKernelGGL(crc_kernel, dim3(grid), dim3(256), (size_t)k * sizeof(uint32_t), (hipStream_t)stream, bits, n_words, k,
                        poly, crc_len, check, out);
@@ -508,8 +508,7 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
     set_error("list state does not fit in LDS (reduce list_size or n)");
     return SAMD_ERR_UNSUPPORTED;
   }
-  // set on every launch: the attribute is per device and a process may drive several
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SAMD_SET_MAX_LDS(polar_scl_kernel<64>, 160 * 1024);
   int m = 0;
   while ((1 << m) < n) ++m;
   const bool reg_engine = scl_reg_supported(n, list_size, sc_mode);

@@ -2,6 +2,7 @@
 // polar_scl_reg.hip: the list engine whose low decoding stages live in registers).
 #pragma once
 #include "common.h"
+#include "options.h"
 #include "scl_math.h"
 #include <algorithm>
 #include <cstdlib>
@@ -55,8 +56,8 @@ inline int scl_gstages(int n, bool reg_engine = false) {
   // at C5: 4.96 M decodes/s with 4, 4.85 M with 5, 3.4 M with 3 - the 7 KB of list state then cost occupancy)
   int m = 0;
   while ((1 << m) < n) ++m;
-  const char* e = getenv("SAMD_SCL_GSTAGES");
-  int g = e ? atoi(e) : (reg_engine ? 4 : 5);
+  static CachedOpt gstages_opt("SAMD_SCL_GSTAGES");
+  int g = (int)gstages_opt.get(reg_engine ? 4 : 5);
   return std::max(0, std::min(g, std::min(5, m - 2)));
 }
 

@@ -573,7 +573,8 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
 int scl_reg_stages(int n, int list_size, int sc_mode) {
   // read once: the host caches a schedule built for the engine this function announced, so the decision must not
   // change during the life of the process
-  static const bool force_generic = getenv("SAMD_SCL_GENERIC") != nullptr;
+  static CachedOpt scl_generic_opt("SAMD_SCL_GENERIC");
+  const bool force_generic = scl_generic_opt.is_set();
   if (force_generic) return -1;
   if (list_size != 1 && list_size != 2 && list_size != 4 && list_size != 8 && list_size != 16 && list_size != 32) return -1;
   if (sc_mode && list_size != 1) return -1;
@@ -595,8 +596,7 @@ size_t scl_reg_lds_bytes(int n, int L) {
 template <int L, bool SC>
 static int scl_reg_launch_l(const SclArgs& p, int grid, hipStream_t stream) {
   const size_t lds = scl_reg_lds_bytes(p.n, L);
-  SAMD_HIP_CHECK(hipFuncSetAttribute((const void*)polar_scl_reg_kernel<L, SC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
+  SAMD_SET_MAX_LDS((polar_scl_reg_kernel<L, SC>), 160 * 1024);
   hipLaunchKernelGGL((polar_scl_reg_kernel<L, SC>), dim3(grid), dim3(64), lds, stream, p);
   return launch_status();
 }

@@ -146,6 +146,11 @@ class LDPC5GEncoder(Block):
     # ------------------------------------------------------------ C-ABI handle
     def _handle(self, nb_pruned=0):
         """samd_ldpc5g_t for this code (one per pruning variant used by a decoder)."""
+        gen = _ffi.options_generation()
+        if getattr(self, "_handles_gen", gen) != gen:             # a development switch changed: handles capture them at creation
+            self._retired = getattr(self, "_retired", []) + list(self._handles.values())   # may still be in flight: freed in __del__
+            self._handles = {}
+        self._handles_gen = gen
         if nb_pruned not in self._handles:
             h = C.c_void_p()
             m = 0 if self._num_bits_per_symbol is None else int(self._num_bits_per_symbol)
@@ -160,7 +165,7 @@ class LDPC5GEncoder(Block):
 
     def __del__(self):
         try:
-            for h in self._handles.values():
+            for h in list(self._handles.values()) + getattr(self, "_retired", []):
                 _ffi.lib().samd_ldpc5g_destroy(h)
         except Exception:  # pylint: disable=broad-except
             pass

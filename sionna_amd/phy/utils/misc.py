@@ -102,11 +102,14 @@ def _dist_world(distribute):
 def init_distributed(backend=None):
     """Join the process group described by the launcher's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*):
     binds the rank to ``cuda:LOCAL_RANK`` and initialises RCCL (backend "nccl"), or gloo when no GPU is visible.
-    Returns ``(rank, world_size)``; a process that was not launched as a rank gets ``(0, 1)`` and nothing happens."""
+    Returns ``(rank, world_size)``; a process that was not launched as a rank gets ``(0, 1)`` and nothing happens.  A
+    launcher that started exactly ONE rank (``torch.distributed.run --nproc-per-node 1``, ``spawn_sim_ber(nprocs=1)``)
+    still gets a real one-member group: the same RCCL initialisation, device binding and int64 all-reduce as on 8 GPUs."""
     import os
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world <= 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if world <= 1 and not launched:
         return 0, 1
     if dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -130,14 +133,15 @@ def _spawn_rank(rank, world, port, backend, make_mc_fun, make_args, sim_kwargs, 
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
-    init_distributed(backend)
     try:
+        init_distributed(backend)
         mc_fun = make_mc_fun(*make_args)
         ber, bler = sim_ber(mc_fun, distribute="all", **sim_kwargs)
         if rank == 0:
             queue.put((np.asarray(ber.cpu()), np.asarray(bler.cpu())))
     finally:
-        dist.destroy_process_group()
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 def spawn_sim_ber(make_mc_fun, ebno_dbs, batch_size, max_mc_iter, *, make_args=(), nprocs=None, backend=None, **kwargs):

@@ -142,3 +142,26 @@ def test_tensor_shape_helpers():
     assert float(u.db(100.)) == 20.0 and float(u.log2(8.)) == 3.0 and float(u.log10(1000.)) == 3.0
     with pytest.raises(AssertionError):
         u.flatten_dims(x, 1, 0)
+
+
+def test_library_never_calls_getenv_and_option_registry_works():
+    """VERDICT r3 / SURVEY 8(b): no hidden global state on the C-ABI's compute paths.  The library copies SAMD_* from the
+    environment once at load; the source holds no getenv call at all, and the registry entry works without a GPU."""
+    import glob
+    import os
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = glob.glob(os.path.join(ROOT, "sionna_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "sionna_amd", "csrc", "*.inc")) + \
+        glob.glob(os.path.join(ROOT, "sionna_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "sionna_amd", "csrc", "*.cpp"))
+    assert len(srcs) > 20
+    for path in srcs:
+        code = "\n".join(ln.split("//")[0] for ln in open(path).read().splitlines())
+        assert "getenv" not in code, path
+        if not path.endswith("common.h"):
+            assert "hipFuncSetAttribute" not in code, f"{path}: use SAMD_SET_MAX_LDS (once per kernel and device)"
+    g = _ffi.options_generation()
+    _ffi.set_option("SAMD_TEST_KEY", 7)
+    _ffi.set_option("SAMD_TEST_KEY", None)
+    assert _ffi.options_generation() == g + 2
+    import pytest
+    with pytest.raises(ValueError):
+        _ffi.set_option("HOME", "x")

@@ -107,6 +107,32 @@ def test_spawn_sim_ber_fans_out_from_a_plain_process():
     assert abs(float(ber[0]) - 1 / 8) < 0.01 and float(ber[1]) == 0.0 and float(bler[0]) > 0.99
 
 
+@pytest.mark.timeout(300)
+def test_spawn_sim_ber_single_rank_runs_a_real_one_member_group():
+    """nprocs=1 (the default on a 1-GPU or CPU-only box): the child is a rank of a ONE-member process group, so the
+    all-reduce path executes; the child tears down only what it initialised and exits 0 (round-3 advisor finding: it used
+    to raise in destroy_process_group after delivering the result)."""
+    from sionna_amd.phy.utils import spawn_sim_ber
+    ber1, bler1 = spawn_sim_ber(make_injector, np.array([0.0, 10.0]), batch_size=100, max_mc_iter=8, make_args=(3,),
+                                nprocs=1, backend="gloo", verbose=False, early_stop=False)
+    # same stream, same answer from a plain in-process run
+    from sionna_amd.phy.utils import sim_ber
+    ber0, bler0 = sim_ber(make_injector(3), np.array([0.0, 10.0]), batch_size=100, max_mc_iter=8, verbose=False, early_stop=False)
+    assert np.array_equal(np.asarray(ber1), np.asarray(ber0)) and np.array_equal(np.asarray(bler1), np.asarray(bler0))
+
+
+def _failing_factory():
+    raise ValueError("model construction failed on purpose")
+
+
+@pytest.mark.timeout(120)
+def test_spawn_sim_ber_reports_a_failing_rank(capfd):
+    from sionna_amd.phy.utils import spawn_sim_ber
+    with pytest.raises(RuntimeError, match="a rank exited with an error"):
+        spawn_sim_ber(_failing_factory, np.array([0.0]), batch_size=10, max_mc_iter=1, nprocs=1, backend="gloo", verbose=False)
+    assert "model construction failed on purpose" in capfd.readouterr().err     # the real error is visible, not a teardown one
+
+
 def test_distribute_all_never_silently_single_gpu(monkeypatch):
     """not a rank + several GPUs visible -> sim_ber(distribute="all") raises; one GPU / none -> off like the reference"""
     from sionna_amd.phy.utils import misc

@@ -227,11 +227,9 @@ def test_fused_ofdm_lmmse_vs_oracle(phy, cfg):
     assert np.allclose(_np(xh), rxh, rtol=3e-4, atol=3e-5) and np.allclose(_np(ne), rne, rtol=3e-4)   # complex128 witness
     # without undesired streams the covariance is diagonal and a leaner kernel runs; it performs the general
     # kernel's operations minus products with exact zeros
-    os.environ["SAMD_LMMSE_GENERAL"] = "1"
-    try:
+    from sionna_amd import _ffi
+    with _ffi.option("SAMD_LMMSE_GENERAL"):
         xg, ng = phy.ofdm.LMMSEEqualizer(rg, sm)(y, h_perf, 0., no)
-    finally:
-        del os.environ["SAMD_LMMSE_GENERAL"]
     assert np.array_equal(_np(xh), _np(xg)) and np.array_equal(_np(ne), _np(ng))
     # LS + nearest neighbour with its error variance table; per-batch noise
     no_b = rng.uniform(0.02, 0.1, size=(B,)).astype(np.float32)

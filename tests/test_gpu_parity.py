@@ -15,6 +15,12 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+def _ffi_option(key, value="1"):
+    """development switch through the C entry samd_debug_set_option (the library never reads the environment after load)"""
+    from sionna_amd import _ffi
+    return _ffi.option(key, value)
+
 from oracle.ldpc5g import LDPC5GCode
 from oracle import ldpc_bp as obp, mapping as omap, utils as outil, cbind
 
@@ -186,11 +192,8 @@ def test_encoder_bit_packed_vs_oracle_and_byte_kernel(phy, k, n, bg, m):
         u = rng.integers(0, 2, (batch, k)).astype(np.float32)
         got = _np(enc(u))
         assert np.array_equal(got, code.encode(u)), (k, n, batch)
-        os.environ["SAMD_ENC_BYTES"] = "1"
-        try:
+        with _ffi_option("SAMD_ENC_BYTES"):                      # a fresh handle is built under the switch
             assert np.array_equal(_np(enc(u)), got)
-        finally:
-            os.environ.pop("SAMD_ENC_BYTES", None)
 
 
 # ------------------------------------------------------------------ generic BP decoder
@@ -412,19 +415,13 @@ def test_layered_on_chip_bit_exact(phy, k, n, bg, m):
             got = _np(dec(llr))
             ref = obp.LDPC5GDecoder(code, **kw).decode5g(llr)
             assert np.array_equal(got, ref), f"{cn} it={it}: {np.mean(got != ref):.3e} differ, max {np.max(np.abs(got - ref))}"
-            os.environ["SAMD_NO_ONCHIP_LAYERED"] = "1"
-            try:
+            with _ffi_option("SAMD_NO_ONCHIP_LAYERED"):
                 assert np.array_equal(_np(dec(llr)), ref)                  # the scheduled HBM-resident engine
-            finally:
-                os.environ.pop("SAMD_NO_ONCHIP_LAYERED", None)
     big = np.tile(llr, (11, 1))
     dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", cn_schedule="layered", num_iter=4)
     full = _np(dec(big))
-    os.environ["SAMD_ONCHIP_GRID"] = "5"
-    try:
+    with _ffi_option("SAMD_ONCHIP_GRID", 5):
         assert np.array_equal(_np(dec(big)), full)
-    finally:
-        os.environ.pop("SAMD_ONCHIP_GRID", None)
     assert np.array_equal(full[:6], full[6:12])
 
 
@@ -465,11 +462,8 @@ def test_5g_minsum_bit_exact_both_engines(phy, k, n, bg, m, cn):
         got_onchip = _np(dec(llr))
         assert dec._onchip_ok, "on-chip engine should accept this code"
         assert np.array_equal(got_onchip, ref), f"on-chip {cn} it={it}"
-        os.environ["SAMD_ONCHIP_COMPRESSED"] = "1"              # compressed check-node state engine (every code size)
-        try:
+        with _ffi_option("SAMD_ONCHIP_COMPRESSED"):             # compressed check-node state engine (every code size)
             got_compressed = _np(dec(llr))
-        finally:
-            del os.environ["SAMD_ONCHIP_COMPRESSED"]
         assert dec._onchip_ok and np.array_equal(got_compressed, ref), f"on-chip (compressed state) {cn} it={it}"
         dec._onchip_ok = False                                  # force the HBM-resident engine
         got_generic = _np(dec(llr))
@@ -500,20 +494,14 @@ def test_5g_random_codes_all_engines(phy, k, n):
     ref = cbind.bp_decode(odec, odec.rate_recover(llr), num_iter=6, hard_out=0)[:, :k]
     dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", hard_out=False, num_iter=6)
     assert np.array_equal(_np(dec(llr)), ref) and dec._onchip_ok
-    os.environ["SAMD_ONCHIP_COMPRESSED"] = "1"
-    try:
+    with _ffi_option("SAMD_ONCHIP_COMPRESSED"):
         assert np.array_equal(_np(dec(llr)), ref)
-    finally:
-        del os.environ["SAMD_ONCHIP_COMPRESSED"]
     # explicit messages with the last rows in L2, also beyond the size range where the library selects it
     # (the handle caches its tables, so a fresh encoder / handle is built under the flag)
-    os.environ["SAMD_FORCE_SPILL"] = "1"
-    try:
+    with _ffi_option("SAMD_FORCE_SPILL"):
         enc2 = phy.fec.ldpc.LDPC5GEncoder(k, n)
         dec2 = phy.fec.ldpc.LDPC5GDecoder(enc2, cn_update="minsum", hard_out=False, num_iter=6)
         assert np.array_equal(_np(dec2(llr)), ref)
-    finally:
-        del os.environ["SAMD_FORCE_SPILL"]
     dec._onchip_ok = False
     assert np.array_equal(_np(dec(llr)), ref)
     for cn, infobits in (("boxplus-phi", True), ("boxplus", False)):
@@ -654,11 +642,10 @@ def test_c2_minsum_soft_outputs_at_scale_bit_exact(phy, ebno):
         assert dec._onchip_ok
         for grid in (None, "64"):
             if grid:
-                os.environ["SAMD_ONCHIP_GRID"] = grid
-            try:
+                with _ffi_option("SAMD_ONCHIP_GRID", grid):
+                    got = _np(dec(llr))
+            else:
                 got = _np(dec(llr))
-            finally:
-                os.environ.pop("SAMD_ONCHIP_GRID", None)
             assert np.array_equal(got, ref), f"{cn} grid={grid}: {np.mean(got != ref):.3e} differ"
     frac_err = np.mean(np.any((ref > 0) != (_np(u) > 0), axis=1))
     assert 0.0 < frac_err < 1.0                                     # the waterfall: some words fail, some decode

@@ -1,0 +1,67 @@
+"""RCCL on the hardware that IS available: a one-member process group on the single leased MI355X (Next 4).
+
+Proves before any 8-GPU run that librccl loads, ``init_distributed`` binds ``cuda:LOCAL_RANK``, and the int64 SUM
+all-reduce of the error counters (the path's only collective, reference utils/misc.py:616-655) executes on gfx950 -
+through ``spawn_sim_ber`` / ``sim_ber(distribute="all")`` and through ``bench.py`` launched exactly the way the driver
+launches it for N > 1 (``python -m torch.distributed.run --nproc-per-node N ...``), with N = 1."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_ldpc_link(k, n, ebno_offset):
+    """module-level factory (spawn_sim_ber pickles it by name): QPSK + AWGN + 5G LDPC min-sum BP-10"""
+    sys.path.insert(0, ROOT)
+    import sionna_amd.phy as phy
+    phy.config.seed = 99
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=10)
+    src, mapper, demap, chan = phy.mapping.BinarySource(), phy.mapping.Mapper("qam", 2), phy.mapping.Demapper("app", "qam", 2), phy.channel.AWGN()
+
+    def mc_fun(batch_size, ebno_db):
+        no = phy.utils.ebnodb2no(ebno_db + ebno_offset, 2, k / n)
+        u = src([batch_size, k])
+        return u, dec(demap(chan(mapper(enc(u)), no), no))
+    return mc_fun
+
+
+@pytest.mark.timeout(600)
+def test_one_member_rccl_group_reduces_the_error_counters():
+    import torch
+    import torch.distributed as dist
+    assert dist.is_nccl_available()
+    from sionna_amd.phy.utils import sim_ber, spawn_sim_ber
+    ebno = np.array([1.0, 2.0, 3.0])
+    kw = dict(batch_size=2000, max_mc_iter=6, verbose=False, early_stop=False, num_target_block_errors=500)
+    ber_r, bler_r = spawn_sim_ber(make_ldpc_link, ebno, make_args=(200, 400, 0.0), nprocs=1, backend="nccl", **kw)
+    ber_p, bler_p = sim_ber(make_ldpc_link(200, 400, 0.0), ebno, **kw)
+    assert np.array_equal(np.asarray(ber_r), np.asarray(ber_p)) and np.array_equal(np.asarray(bler_r), np.asarray(bler_p))
+    assert float(bler_p[0]) > float(bler_p[2]) > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_the_drivers_launcher_with_one_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "8192", "--also", "none", "--no-cpu-baseline", "--no-extra"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["collectives"] == {"backend": "nccl", "group_size": 1}
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["bler"] < 1.0
