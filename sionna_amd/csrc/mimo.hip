@@ -20,6 +20,7 @@
 // HBM-streaming (arithmetic intensity ~6 flop/B).
 #include "common.h"
 #include "options.h"
+#include <algorithm>
 
 namespace samd {
 
@@ -310,6 +311,110 @@ __global__ __launch_bounds__(128) void lmmse_items_kernel(const float2* __restri
   else lmmse_solve<M, K>(yy, hh, ss, whiten != 0, xh, ne);
 #pragma unroll
   for (int k = 0; k < K; ++k) { x_hat[i * K + k] = make_float2(xh[k].re, xh[k].im); no_eff[i * K + k] = ne[k]; }
+}
+
+// ---- lmmse_equalizer for ANY (M, K): one lane per item, every per-item matrix in LDS laid out [element][lane]
+// (consecutive lanes -> consecutive banks), runtime loops.  The operation order is lmmse_solve<M, K>'s (= oracle/mimo_f32.py),
+// element for element, so the results are bit-identical to the unrolled kernels where both exist
+// (tests/test_gpu_ofdm.py); used for the shapes outside SAMD_MK_LIST, e.g. the 16 x 4 link of the reference's
+// Simple_MIMO_Simulation notebook.  mimo/equalization.py:101-233, mimo/utils.py:292-356, utils/linalg.py:8-58.
+__global__ __launch_bounds__(64) void lmmse_items_any_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                             const float2* __restrict__ s, int64_t n, int M, int K, int whiten,
+                                                             float2* __restrict__ x_hat, float* __restrict__ no_eff) {
+  extern __shared__ float2 any_sm[];
+  const int T = blockDim.x, tid = threadIdx.x;
+  const int64_t it = (int64_t)blockIdx.x * T + tid;
+  if (it >= n) return;                                               // no workgroup barrier below
+  auto ld = [&](int e) { const float2 v = any_sm[e * T + tid]; return C(v.x, v.y); };
+  auto st = [&](int e, c32 v) { any_sm[e * T + tid] = make_float2(v.re, v.im); };
+  const int oS = 0, oH = oS + M * (M + 1) / 2, oY = oH + M * K, oG = oY + M, oA = oG + K * M, oZ = oA + K * (K + 1) / 2,
+            oT = oZ + (M > K ? M : K);
+  auto S = [&](int i, int j) { return oS + i * (i + 1) / 2 + j; };   // lower triangle, j <= i
+  auto H = [&](int m, int c) { return oH + m * K + c; };
+  auto G = [&](int k, int m) { return oG + k * M + m; };
+  auto A = [&](int i, int j) { return oA + i * (i + 1) / 2 + j; };
+  for (int m = 0; m < M; ++m) {
+    const float2 v = y[it * M + m];
+    st(oY + m, C(v.x, v.y));
+    for (int k = 0; k < K; ++k) { const float2 w = h[(it * M + m) * K + k]; st(H(m, k), C(w.x, w.y)); }
+    for (int j = 0; j <= m; ++j) { const float2 w = s[(it * M + m) * M + j]; st(S(m, j), C(w.x, w.y)); }
+  }
+  // in-place lower Cholesky of the triangle at `at` (cholesky<N> above, same order)
+  auto chol = [&](auto at, int N) {
+    for (int j = 0; j < N; ++j) {
+      float d = ld(at(j, j)).re;
+      for (int k = 0; k < j; ++k) { const c32 a = ld(at(j, k)); d -= a.re * a.re + a.im * a.im; }
+      const float l = sqrtf(d);
+      st(at(j, j), C(l, 0.f));
+      const float inv = 1.f / l;
+      for (int i = j + 1; i < N; ++i) {
+        c32 v = ld(at(i, j));
+        for (int k = 0; k < j; ++k) v = v - mulc(ld(at(i, k)), ld(at(j, k)));
+        st(at(i, j), scale(v, inv));
+      }
+    }
+  };
+  if (whiten) {
+    chol(S, M);
+    for (int i = 0; i < M; ++i) {
+      const float inv = 1.f / ld(S(i, i)).re;
+      c32 v = ld(oY + i);
+      for (int k = 0; k < i; ++k) v = v - ld(S(i, k)) * ld(oY + k);
+      st(oY + i, scale(v, inv));
+      for (int c = 0; c < K; ++c) {
+        c32 w = ld(H(i, c));
+        for (int k = 0; k < i; ++k) w = w - ld(S(i, k)) * ld(H(k, c));
+        st(H(i, c), scale(w, inv));
+      }
+    }
+    for (int i = 0; i < K; ++i)
+      for (int j = 0; j <= i; ++j) {
+        c32 v = C(i == j ? 1.f : 0.f, 0.f);
+        for (int m = 0; m < M; ++m) v = v + mulc(ld(H(m, j)), ld(H(m, i)));
+        st(A(i, j), v);
+      }
+    chol(A, K);
+    for (int m = 0; m < M; ++m) {
+      for (int i = 0; i < K; ++i) {
+        c32 v = cj(ld(H(m, i)));
+        for (int k = 0; k < i; ++k) v = v - ld(A(i, k)) * ld(oZ + k);
+        st(oZ + i, scale(v, 1.f / ld(A(i, i)).re));
+      }
+      for (int i = K - 1; i >= 0; --i) {
+        c32 v = ld(oZ + i);
+        for (int k = i + 1; k < K; ++k) v = v - cj(ld(A(k, i))) * ld(G(k, m));
+        st(G(i, m), scale(v, 1.f / ld(A(i, i)).re));
+      }
+    }
+  } else {
+    for (int i = 0; i < M; ++i)
+      for (int j = 0; j <= i; ++j) {
+        c32 v = ld(S(i, j));
+        for (int c = 0; c < K; ++c) v = v + mulc(ld(H(i, c)), ld(H(j, c)));
+        st(S(i, j), v);
+      }
+    chol(S, M);
+    for (int c = 0; c < K; ++c) {
+      for (int i = 0; i < M; ++i) {
+        c32 v = ld(H(i, c));
+        for (int k = 0; k < i; ++k) v = v - ld(S(i, k)) * ld(oZ + k);
+        st(oZ + i, scale(v, 1.f / ld(S(i, i)).re));
+      }
+      for (int i = M - 1; i >= 0; --i) {
+        c32 v = ld(oZ + i);
+        for (int k = i + 1; k < M; ++k) v = v - cj(ld(S(k, i))) * ld(oT + k);
+        st(oT + i, scale(v, 1.f / ld(S(i, i)).re));
+      }
+      for (int i = 0; i < M; ++i) st(G(c, i), cj(ld(oT + i)));
+    }
+  }
+  for (int k = 0; k < K; ++k) {
+    c32 gy = C(0.f, 0.f), d = C(0.f, 0.f);
+    for (int m = 0; m < M; ++m) { const c32 g = ld(G(k, m)); gy = gy + g * ld(oY + m); d = d + g * ld(H(m, k)); }
+    const c32 xh = cdiv(gy, d);
+    x_hat[it * K + k] = make_float2(xh.re, xh.im);
+    no_eff[it * K + k] = cdiv(C(1.f, 0.f), d).re - 1.f;
+  }
 }
 
 // ---- fused OFDM LMMSE equaliser: one lane per (b, rx, t, f_eff)
@@ -1013,14 +1118,27 @@ extern "C" int samd_lmmse_equalizer_c64(const float* y, const float* h, const fl
   SAMD_REQUIRE(y && h && s && x_hat && no_eff && n >= 0, "bad argument");
   if (n == 0) return SAMD_OK;
   const dim3 grid((unsigned)((n + 127) / 128));
+  static samd::CachedOpt any_opt("SAMD_LMMSE_ANY");                    // development: force the any-shape kernel
+  const bool force_any = any_opt.is_set() && whiten <= 1;
 #define X(M, K)                                                                                                    \
-  if (m == M && k == K) {                                                                                          \
+  if (m == M && k == K && !force_any) {                                                                            \
     hipLaunchKernelGGL((lmmse_items_kernel<M, K>), grid, dim3(128), 0, (hipStream_t)stream, (const float2*)y,     \
                        (const float2*)h, (const float2*)s, n, whiten, (float2*)x_hat, no_eff);                     \
     return launch_status();                                                                                        \
   }
   SAMD_MK_LIST(X)
 #undef X
+  if ((whiten == 0 || whiten == 1) && m >= 1 && k >= 1 && k <= m) {        // any other shape: the LDS-resident form
+    const size_t elems = (size_t)m * (m + 1) / 2 + (size_t)2 * m * k + 2 * (size_t)m + (size_t)k * (k + 1) / 2 + (size_t)std::max(m, k);
+    const int t = (int)std::min<size_t>(64, (160 * 1024) / (elems * sizeof(float2)));
+    if (t >= 1) {
+      SAMD_SET_MAX_LDS(lmmse_items_any_kernel, 160 * 1024);
+      hipLaunchKernelGGL(lmmse_items_any_kernel, dim3((unsigned)((n + t - 1) / t)), dim3(t), elems * sizeof(float2) * t,
+                         (hipStream_t)stream, (const float2*)y, (const float2*)h, (const float2*)s, n, m, k, whiten,
+                         (float2*)x_hat, no_eff);
+      return launch_status();
+    }
+  }
   set_error("lmmse_equalizer: unsupported (num_rx_ant, num_streams) combination");
   return SAMD_ERR_UNSUPPORTED;
 }

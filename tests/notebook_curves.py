@@ -316,6 +316,97 @@ class _BicmGa:
         return u, self.decoder(self.ga([batch_size, self.n], no))
 
 
+class _CdlModel:
+    """``Model`` of MIMO_OFDM_Transmissions_over_CDL.ipynb cell 65 (uplink): 4-antenna UT -> 8-antenna BS over CDL, dual
+    cross-polarised 38.901 arrays, fft 72 with guards [5, 6] and DC null, 14 symbols, Kronecker pilots, QPSK, 5G LDPC rate
+    1/2 (default decoder), frequency- or time-domain channel, perfect CSI or LS + nearest neighbour, LMMSE equaliser.
+    Four codewords (one per stream) share every channel realisation."""
+
+    def __init__(self, domain, cdl_model, perfect_csi, speed, cyclic_prefix_length, pilot_ofdm_symbol_indices,
+                 delay_spread=100e-9, subcarrier_spacing=15e3):
+        phy = _phy()
+        t = phy.channel.tr38901
+        self.domain, self.perfect_csi = domain, perfect_csi
+        self.fc, self.cp = 2.6e9, cyclic_prefix_length
+        self.n_ut, self.n_bs, self.m, self.coderate = 4, 8, 2, 0.5
+        self.sm = phy.mimo.StreamManagement(np.array([[1]]), self.n_ut)
+        self.rg = phy.ofdm.ResourceGrid(num_ofdm_symbols=14, fft_size=72, subcarrier_spacing=subcarrier_spacing, num_tx=1,
+                                        num_streams_per_tx=self.n_ut, cyclic_prefix_length=cyclic_prefix_length,
+                                        num_guard_carriers=[5, 6], dc_null=True, pilot_pattern="kronecker",
+                                        pilot_ofdm_symbol_indices=pilot_ofdm_symbol_indices)
+        self.n = int(self.rg.num_data_symbols * self.m)
+        self.k = int(self.n * self.coderate)
+        ut = t.AntennaArray(num_rows=1, num_cols=self.n_ut // 2, polarization="dual", polarization_type="cross",
+                            antenna_pattern="38.901", carrier_frequency=self.fc)
+        bs = t.AntennaArray(num_rows=1, num_cols=self.n_bs // 2, polarization="dual", polarization_type="cross",
+                            antenna_pattern="38.901", carrier_frequency=self.fc)
+        self.cdl = t.CDL(model=cdl_model, delay_spread=delay_spread, carrier_frequency=self.fc, ut_array=ut, bs_array=bs,
+                         direction="uplink", min_speed=speed)
+        self.freqs = phy.channel.subcarrier_frequencies(self.rg.fft_size, self.rg.subcarrier_spacing)
+        if domain == "freq":
+            self.channel_freq = phy.channel.ApplyOFDMChannel(add_awgn=True)
+        else:
+            self.l_min, self.l_max = phy.channel.time_lag_discrete_time_channel(self.rg.bandwidth)
+            self.l_tot = self.l_max - self.l_min + 1
+            self.channel_time = phy.channel.ApplyTimeChannel(self.rg.num_time_samples, l_tot=self.l_tot, add_awgn=True)
+            self.modulator = phy.ofdm.OFDMModulator(cyclic_prefix_length)
+            self.demodulator = phy.ofdm.OFDMDemodulator(72, self.l_min, cyclic_prefix_length)
+        self.source = phy.mapping.BinarySource()
+        self.encoder = phy.fec.ldpc.LDPC5GEncoder(self.k, self.n)
+        self.mapper = phy.mapping.Mapper("qam", self.m)
+        self.rg_mapper = phy.ofdm.ResourceGridMapper(self.rg)
+        self.ls_est = phy.ofdm.LSChannelEstimator(self.rg, interpolation_type="nn")
+        self.lmmse = phy.ofdm.LMMSEEqualizer(self.rg, self.sm)
+        self.demapper = phy.mapping.Demapper("app", "qam", self.m)
+        self.decoder = phy.fec.ldpc.LDPC5GDecoder(self.encoder, hard_out=True)
+        self.remove_nulled = phy.ofdm.RemoveNulledSubcarriers(self.rg)
+
+    def __call__(self, batch_size, ebno_db):
+        phy = _phy()
+        rg = self.rg
+        no = phy.utils.ebnodb2no(ebno_db, self.m, self.coderate, rg)
+        b = self.source([batch_size, 1, self.n_ut, self.k])
+        x_rg = self.rg_mapper(self.mapper(self.encoder(b)))
+        if self.domain == "time":
+            a, tau = self.cdl(batch_size, rg.num_time_samples + self.l_tot - 1, rg.bandwidth)
+            h_time = phy.channel.cir_to_time_channel(rg.bandwidth, a, tau, l_min=self.l_min, l_max=self.l_max, normalize=True)
+            a_freq = a[..., rg.cyclic_prefix_length:-1:(rg.fft_size + rg.cyclic_prefix_length)]
+            a_freq = a_freq[..., :rg.num_ofdm_symbols]
+            h_freq = phy.channel.cir_to_ofdm_channel(self.freqs, a_freq, tau, normalize=True)
+            y = self.demodulator(self.channel_time(self.modulator(x_rg), h_time, no))
+        else:
+            a, tau = self.cdl(batch_size, rg.num_ofdm_symbols, 1 / rg.ofdm_symbol_duration)
+            h_freq = phy.channel.cir_to_ofdm_channel(self.freqs, a, tau, normalize=True)
+            y = self.channel_freq(x_rg, h_freq, no)
+        if self.perfect_csi:
+            h_hat, err_var = self.remove_nulled(h_freq), 0.0
+        else:
+            h_hat, err_var = self.ls_est(y, no)
+        x_hat, no_eff = self.lmmse(y, h_hat, err_var, no)
+        return b, self.decoder(self.demapper(x_hat, no_eff))
+
+
+def _cdl(**kw):
+    return lambda: _CdlModel(**kw)
+
+
+class _Part1Uncoded:
+    """``UncodedSystemAWGN`` of Sionna_tutorial_part1.ipynb cell 37: returns (bits, LLRs) - sim_ber(soft_estimates=True)."""
+    soft = True
+
+    def __init__(self, m=2, block_length=1024):
+        phy = _phy()
+        self.m, self.n = m, block_length
+        self.mapper, self.demapper = phy.mapping.Mapper("qam", m), phy.mapping.Demapper("app", "qam", m)
+        self.source, self.channel = phy.mapping.BinarySource(), phy.channel.AWGN()
+
+    def __call__(self, batch_size, ebno_db):
+        phy = _phy()
+        no = phy.utils.ebnodb2no(ebno_db, num_bits_per_symbol=self.m, coderate=1.0)
+        bits = self.source([batch_size, self.n])
+        return bits, self.demapper(self.channel(self.mapper(bits), no), no)
+
+
 class Curve:
     """One published table: ``key`` into notebook_ber.json, the cell's true Eb/N0 grid, and the model builder.
     ``use_bits``: the statistic is the BIT error count (uncoded links: independent bit errors, BLER is 1 everywhere);
@@ -354,12 +445,41 @@ CURVES = [
     # --- Bit_Interleaved_Coded_Modulation.ipynb (k=600, n=1200; these cells stop on 1000..2000 BIT errors, so few block errors)
     Curve(f"{BICM}/c26/t0", "BICM all-zero QPSK, boxplus BP-20", lambda: _BicmLdpc(2, use_allzero=True), np.arange(0, 5, 0.25), bits_per_block=600, cite="cell 26"),
     Curve(f"{BICM}/c31/t0", "BICM Gaussian-approximated LLRs, boxplus-phi BP-20", _BicmGa, np.arange(0, 5, 0.25), bits_per_block=600, cite="ipynb:916-932"),
+    *[Curve(f"{BICM}/c{c}/t0", name, (lambda kw=kw: _BicmLdpc(4, **kw)), np.arange(*grid), bits_per_block=600, cite=f"cell {c}")
+      for c, name, kw, grid in (
+          (35, "BICM baseline 16-QAM, boxplus BP-20", {}, (0, 5, 0.25)),
+          (37, "BICM all-zero 16-QAM WITHOUT scrambler (the notebook's deliberately wrong curve)", {"use_allzero": True}, (0, 5, 0.25)),
+          (39, "BICM all-zero 16-QAM with scrambler", {"use_allzero": True, "use_scrambler": True}, (0, 5, 0.25)),
+          (41, "BICM 16-QAM with the 5G output interleaver", {"use_ldpc_output_interleaver": True}, (0, 5, 0.25)),
+          (47, "BICM 16-QAM, demapper noise estimate x0.15, boxplus", {"no_est_mismatch": 0.15}, (0, 7, 0.5)),
+          (48, "BICM 16-QAM, min-sum BP-20", {"cn_update": "minsum"}, (0, 7, 0.5)),
+          (49, "BICM 16-QAM, min-sum, demapper noise estimate x0.15", {"cn_update": "minsum", "no_est_mismatch": 0.15}, (0, 7, 0.5)))],
+    # --- Sionna_tutorial_part1.ipynb cells 37/41 (uncoded QPSK, LLR outputs) and 53/54/65 (LDPC (1024,2048), default decoder)
+    Curve("Sionna_tutorial_part1/c41/t0", "Uncoded QPSK, soft outputs (1024 bit blocks)", _Part1Uncoded, np.linspace(-3, 5, 20),
+          bits_per_block=1024, use_bits=True, work=1024, cite="cell 41"),
+    Curve("Sionna_tutorial_part1/c54/t0", "5G LDPC BP-20 (1024,2048)", _ldpc(1024, 2048), np.linspace(-3, 5, 15), bits_per_block=1024, cite="cell 54"),
+    Curve("Sionna_tutorial_part1/c65/t0", "5G LDPC BP-20 (1024,2048), second run", _ldpc(1024, 2048), np.linspace(-3, 5, 12), bits_per_block=1024, cite="cell 65"),
+    # --- MIMO_OFDM_Transmissions_over_CDL.ipynb: cell 67 (uplink, CDL-A..E, perfect CSI), cell 73 (CDL-D, pilots on symbol 0,
+    #     perfect / LS CSI x 0 / 20 m/s), cell 76 (CDL-C, LS CSI, cyclic prefix 20 / 2 x frequency / time domain); 1000 block errors
+    *[Curve(f"MIMO_OFDM_Transmissions_over_CDL/c67/t{i}", f"8x4 uplink CDL-{mdl}, perfect CSI, LMMSE, QPSK LDPC r=1/2",
+            _cdl(domain="freq", cdl_model=mdl, perfect_csi=True, speed=0.0, cyclic_prefix_length=6, pilot_ofdm_symbol_indices=[2, 11]),
+            np.arange(-5, 20, 4.0), bits_per_block=768, corr=4.0, group="cdl", max_batch=4096, cite="ipynb:1835-1880")
+      for i, mdl in enumerate("ABCDE")],
+    *[Curve(f"MIMO_OFDM_Transmissions_over_CDL/c73/t{i}", f"8x4 uplink CDL-D, {'perfect' if pc else 'LS-NN'} CSI, {sp:.0f} m/s, pilots on symbol 0",
+            _cdl(domain="freq", cdl_model="D", perfect_csi=pc, speed=sp, cyclic_prefix_length=6, pilot_ofdm_symbol_indices=[0]),
+            np.arange(0, 32, 2.0), bits_per_block=832, corr=4.0, group="cdl", max_batch=4096, cite="ipynb:2183-2240")
+      for i, (pc, sp) in enumerate(((True, 0.0), (True, 20.0), (False, 0.0), (False, 20.0)))],
+    *[Curve(f"MIMO_OFDM_Transmissions_over_CDL/c76/t{i}", f"8x4 uplink CDL-C, LS-NN CSI, 3 m/s, CP {cp}, {dom} domain",
+            _cdl(domain=dom, cdl_model="C", perfect_csi=False, speed=3.0, cyclic_prefix_length=cp, pilot_ofdm_symbol_indices=[2, 11]),
+            np.arange(0, 17, 2.0), bits_per_block=768, corr=4.0, group="cdl_time" if dom == "time" else "cdl", max_batch=1024,
+            cite="ipynb:2375-2425")
+      for i, (cp, dom) in enumerate(((20, "freq"), (20, "time"), (2, "freq"), (2, "time")))],
     # --- Discover_Sionna.ipynb cells 31/33/42 (500 block errors per point, one codeword per channel realisation)
     Curve("Discover_Sionna/c42/t0", "OFDM 1x1 TDL-A LS-NN LMMSE 16-QAM LDPC(6144,12288) boxplus BP-20", _DiscoverE2E,
           np.arange(0, 15, 1.), bits_per_block=6144, group="ofdm", max_batch=2048, cite="ipynb:1118-1134"),
     # --- Simple_MIMO_Simulation.ipynb cells 40/43 (100 block errors per point; 4 codewords per example but a fresh channel per symbol)
     Curve("Simple_MIMO_Simulation/c43/t0", "4x16 i.i.d. flat fading, lmmse_equalizer, 16-QAM LDPC(512,1024)", _SimpleMimo,
-          np.arange(-2.5, 0.25, 0.25), bits_per_block=512, group="mimo", max_batch=16384, cite="ipynb:821-832"),
+          np.arange(-2.5, 0.25, 0.25), bits_per_block=512, group="mimo", max_batch=2048, cite="ipynb:821-832"),
 ]
 
 
@@ -409,7 +529,7 @@ def run_curve(curve, ref_rows, mult=4.0, max_work=2.5e11, max_blocks=8_000_000, 
             return None
 
         kw = {"num_target_bit_errors": target} if curve.use_bits else {"num_target_block_errors": target}
-        phy.utils.sim_ber(model, [float(x)], batch_size=batch, max_mc_iter=iters, soft_estimates=False, early_stop=False,
+        phy.utils.sim_ber(model, [float(x)], batch_size=batch, max_mc_iter=iters, soft_estimates=bool(getattr(model, "soft", False)), early_stop=False,
                           verbose=False, callback=cb, **kw)
         got["ebno_db"] = float(x)
         got["ber"] = got["bit_errors"] / max(got["num_bits"], 1)

@@ -183,6 +183,39 @@ def test_lmmse_equalizer_vs_oracle(phy, m, k, whiten):
     assert np.all(_np(ne) > 0)
 
 
+@pytest.mark.parametrize("m,k", [(16, 4), (3, 2), (5, 5), (12, 1), (32, 8), (4, 2), (8, 4)])
+@pytest.mark.parametrize("whiten", [True, False])
+def test_lmmse_equalizer_any_shape(phy, m, k, whiten):
+    """Shapes outside the unrolled list run the LDS-resident any-shape kernel (csrc/mimo.hip lmmse_items_any_kernel): the
+    float32 spec's operation order, so bit-exact against oracle/mimo_f32.py and - for listed shapes, forced through it with
+    SAMD_LMMSE_ANY - against the unrolled kernel.  Plus the reference-EXECUTED 16 x 4 outputs (phy_ref_golden.npz)."""
+    from sionna_amd import _ffi
+    rng = np.random.default_rng(m * 100 + k)
+    n = 257
+    h = (rng.normal(size=(n, m, k)) + 1j * rng.normal(size=(n, m, k))).astype(np.complex64) / np.sqrt(2)
+    q = (rng.normal(size=(n, m, m)) + 1j * rng.normal(size=(n, m, m))).astype(np.complex64)
+    s = (0.1 * q @ np.conj(np.swapaxes(q, -1, -2)) / m + 0.05 * np.eye(m)).astype(np.complex64)
+    x = omap.qam(4)[rng.integers(0, 16, (n, k))]
+    y = ((h @ x[..., None])[..., 0] + 0.1 * (rng.normal(size=(n, m)) + 1j * rng.normal(size=(n, m)))).astype(np.complex64)
+    with _ffi.option("SAMD_LMMSE_ANY"):
+        xh, ne = phy.mimo.lmmse_equalizer(y, h, s, whiten)
+        xh, ne = _np(xh), _np(ne)
+    fx, fn = of32.lmmse_equalizer(y, h, s, whiten)
+    _same_f32(xh, fx) and _same_f32(ne, fn)
+    if (m, k) in ((4, 2), (8, 4)):
+        xu, nu = phy.mimo.lmmse_equalizer(y, h, s, whiten)
+        assert np.array_equal(xh.view(np.float32), _np(xu).view(np.float32)) and np.array_equal(ne, _np(nu))
+    rx, rn = o.lmmse_equalizer(y, h, s, whiten)
+    assert np.allclose(xh, rx, rtol=1e-3, atol=1e-4) and np.allclose(ne, rn, rtol=1e-3)
+    if (m, k) == (16, 4):
+        g = np.load(os.path.join(os.path.dirname(__file__), "golden", "phy_ref_golden.npz"))
+        for tag in ("col", "wht"):
+            p_ = f"mimo16x4_{tag}_"
+            gx, gn = phy.mimo.lmmse_equalizer(g[p_ + "y"], g[p_ + "h"], g[p_ + "s"], whiten)
+            assert np.allclose(_np(gx), g[p_ + f"lmmse_w{int(whiten)}_x"], rtol=2e-3, atol=2e-4)
+            assert np.allclose(_np(gn), g[p_ + f"lmmse_w{int(whiten)}_no"], rtol=2e-3, atol=1e-5)
+
+
 def test_lmmse_error_statistics(phy):
     # test_mimo_equalizers.py:55-102: unbiased estimate, error variance == no_eff
     rng = np.random.default_rng(3)
