@@ -247,6 +247,7 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
   float* llr = ws + (size_t)blockIdx.x * (size_t)(nx + n_ext * (int)z);
   float* cext = llr + nx;
   float* xtot = smem + msg_floats;
+  const int n_xt = zero_off - msg_floats;                              // floats of the xtot blocks
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned lane4 = 4u * (unsigned)lane;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -256,11 +257,20 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
   for (int b = blockIdx.x; b < batch; b += gridDim.x) {
     const float* row = llr_in + (size_t)b * p.n;
     // decoding.py:552-565 (clip, logits -> LLR; + 0.f: no -0 anywhere), messages start at 0 (:575-578)
+    // A channel LLR is kept where it is used: a non-fused column's in its xtot block (LDS; its owner copies it into
+    // registers below), a fused degree-1 node's in its owner's registers (read from the input row below).  Only the
+    // codeword output (return_infobits = 0) needs the LLRs of the columns without an xtot block once more, and only then
+    // are they written to the workspace row: until round 4 every LLR went through it (and every final fused c2v), 45 KB
+    // per codeword written and read back through L2 - 6.7 GB per launch at C2 on the memory-side counters against
+    // 2.95 GB of compulsory input + output (profiles/r03zy_pmc).
+    auto chan_llr = [&](int v) __attribute__((always_inline)) -> float {
+      return (v < p.n_vn) ? (-1.f * clampf(recover_llr(p, row, v, llr_max), -llr_max, llr_max)) + 0.f : 0.f;
+    };
     for (int v = tid; v < nx; v += NT) {
-      const float l = (v < p.n_vn) ? (-1.f * clampf(recover_llr(p, row, v, llr_max), -llr_max, llr_max)) + 0.f : 0.f;
-      llr[v] = l;
+      const float l = chan_llr(v);
       const int xi = xt_index[v / (int)z];
       if (xi >= 0) xtot[xi * (int)z + v % (int)z] = l;                 // total of a node without messages = its LLR
+      else if (!return_infobits) llr[v] = l;
     }
     for (int i = tid; i < msg_floats; i += NT) smem[i] = 0.f;
     for (int i = tid; i < (int)z; i += NT) smem[zero_off + i] = 0.f;   // the block the padded re-sum entries read
@@ -271,13 +281,13 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
     for (int q = 0; q < LY_CN_SLOTS; ++q) {
       const int li = slots[q];
       st[LY_ST_CO + q] = 0.f;
-      st[LY_ST_LF + q] = (li >= 0) ? llr[min(li + lane, nx - 1)] : 0.f;   // (lanes past a partial chunk: never used)
+      st[LY_ST_LF + q] = (li >= 0) ? chan_llr(min(li + lane, nx - 1)) : 0.f;   // (lanes past a partial chunk: never used)
     }
 #pragma unroll
     for (int q = 0; q < LY_VN_SLOTS; ++q) {
       const int li = slots[2 * LY_CN_SLOTS + q];
       st[LY_ST_P + q] = 0.f;
-      st[LY_ST_L + q] = (li >= 0) ? llr[min(li + lane, nx - 1)] : 0.f;
+      st[LY_ST_L + q] = (li >= 0) ? xtot[min(li + lane, n_xt - 1)] : 0.f;   // li: float index into xtot (host: xt block * Z + 64 chunk)
     }
 
     // Records are wave-uniform: scalar loads, one record ahead.
@@ -366,7 +376,7 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
 #pragma unroll
     for (int q = 0; q < LY_CN_SLOTS; ++q) {
       const int ci = slots[LY_CN_SLOTS + q];
-      if (ci >= 0 && (!PART || ci % (int)z + lane < (int)z)) cext[ci + lane] = st[LY_ST_CO + q];
+      if (!return_infobits && ci >= 0 && (!PART || ci % (int)z + lane < (int)z)) cext[ci + lane] = st[LY_ST_CO + q];
     }
     __syncthreads();
     // ---------------- output (decoding.py:620-626, 1486-1531): marginal of a non-fused column = xtot, of a fused
@@ -621,8 +631,9 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     u.wave = best;
     u.slot = vn_slots[best];
     vn_slots[best] += 1 + u.pair;
-    vn_slot_llr[best].push_back(u.c * z + u.q * 64);
-    if (u.pair) vn_slot_llr[best].push_back(u.c * z + (u.q + 1) * 64);
+    if (xt_of_col[u.c] < 0) return 1;                                     // a unit's column keeps its total in LDS
+    vn_slot_llr[best].push_back(xt_of_col[u.c] * z + u.q * 64);          // float index into the xtot blocks
+    if (u.pair) vn_slot_llr[best].push_back(xt_of_col[u.c] * z + (u.q + 1) * 64);
     for (auto& tj : touch[u.c]) load[tj.first][best] += item_cost(u.c, tj.second, u.pair);
   }
   std::vector<int32_t>& slot_tab = L.slot_tab;

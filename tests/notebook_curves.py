@@ -323,7 +323,7 @@ class _CdlModel:
     Four codewords (one per stream) share every channel realisation."""
 
     def __init__(self, domain, cdl_model, perfect_csi, speed, cyclic_prefix_length, pilot_ofdm_symbol_indices,
-                 delay_spread=100e-9, subcarrier_spacing=15e3):
+                 delay_spread=100e-9, subcarrier_spacing=15e3, l_min_override=None, cn_update=None):
         phy = _phy()
         t = phy.channel.tr38901
         self.domain, self.perfect_csi = domain, perfect_csi
@@ -347,6 +347,8 @@ class _CdlModel:
             self.channel_freq = phy.channel.ApplyOFDMChannel(add_awgn=True)
         else:
             self.l_min, self.l_max = phy.channel.time_lag_discrete_time_channel(self.rg.bandwidth)
+            if l_min_override is not None:                             # probes of the ISI regime only (tools/probe_cp2.py)
+                self.l_min = l_min_override
             self.l_tot = self.l_max - self.l_min + 1
             self.channel_time = phy.channel.ApplyTimeChannel(self.rg.num_time_samples, l_tot=self.l_tot, add_awgn=True)
             self.modulator = phy.ofdm.OFDMModulator(cyclic_prefix_length)
@@ -358,7 +360,8 @@ class _CdlModel:
         self.ls_est = phy.ofdm.LSChannelEstimator(self.rg, interpolation_type="nn")
         self.lmmse = phy.ofdm.LMMSEEqualizer(self.rg, self.sm)
         self.demapper = phy.mapping.Demapper("app", "qam", self.m)
-        self.decoder = phy.fec.ldpc.LDPC5GDecoder(self.encoder, hard_out=True)
+        self.decoder = (phy.fec.ldpc.LDPC5GDecoder(self.encoder, hard_out=True) if cn_update is None else
+                        phy.fec.ldpc.LDPC5GDecoder(self.encoder, hard_out=True, cn_update=cn_update))   # (probes only)
         self.remove_nulled = phy.ofdm.RemoveNulledSubcarriers(self.rg)
 
     def __call__(self, batch_size, ebno_db):
@@ -384,6 +387,44 @@ class _CdlModel:
             h_hat, err_var = self.ls_est(y, no)
         x_hat, no_eff = self.lmmse(y, h_hat, err_var, no)
         return b, self.decoder(self.demapper(x_hat, no_eff))
+
+
+class _Part3Ofdm:
+    """``OFDMSystem`` of Sionna_tutorial_part3.ipynb cell 40: single-antenna UT -> 4-antenna BS (dual cross-polarised)
+    uplink over CDL-C (100 ns, 2.6 GHz, 10 m/s), fft 76, 30 kHz, CP 6, pilots on symbols 2 and 11, QPSK, 5G LDPC rate 1/2,
+    ``OFDMChannel(normalize_channel=True)``, LS + nearest neighbour or perfect CSI, LMMSE equaliser."""
+
+    def __init__(self, perfect_csi):
+        phy = _phy()
+        t = phy.channel.tr38901
+        self.perfect_csi, self.m, self.coderate = perfect_csi, 2, 0.5
+        self.sm = phy.mimo.StreamManagement(np.array([[1]]), 1)
+        self.rg = phy.ofdm.ResourceGrid(num_ofdm_symbols=14, fft_size=76, subcarrier_spacing=30e3, num_tx=1, num_streams_per_tx=1,
+                                        cyclic_prefix_length=6, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+        ut = t.Antenna(polarization="single", polarization_type="V", antenna_pattern="38.901", carrier_frequency=2.6e9)
+        bs = t.AntennaArray(num_rows=1, num_cols=2, polarization="dual", polarization_type="cross", antenna_pattern="38.901",
+                            carrier_frequency=2.6e9)
+        cdl = t.CDL("C", 100e-9, 2.6e9, ut, bs, "uplink", min_speed=10.0)
+        n = int(self.rg.num_data_symbols * self.m)
+        self.k = int(n * self.coderate)
+        self.source = phy.mapping.BinarySource()
+        self.encoder = phy.fec.ldpc.LDPC5GEncoder(self.k, n)
+        self.mapper = phy.mapping.Mapper("qam", self.m)
+        self.rg_mapper = phy.ofdm.ResourceGridMapper(self.rg)
+        self.channel = phy.channel.OFDMChannel(cdl, self.rg, add_awgn=True, normalize_channel=True, return_channel=True)
+        self.ls_est = phy.ofdm.LSChannelEstimator(self.rg, interpolation_type="nn")
+        self.lmmse = phy.ofdm.LMMSEEqualizer(self.rg, self.sm)
+        self.demapper = phy.mapping.Demapper("app", "qam", self.m)
+        self.decoder = phy.fec.ldpc.LDPC5GDecoder(self.encoder, hard_out=True)
+
+    def __call__(self, batch_size, ebno_db):
+        phy = _phy()
+        no = phy.utils.ebnodb2no(ebno_db, num_bits_per_symbol=self.m, coderate=self.coderate, resource_grid=self.rg)
+        bits = self.source([batch_size, 1, 1, self.k])
+        y, h_freq = self.channel(self.rg_mapper(self.mapper(self.encoder(bits))), no)
+        h_hat, err_var = (h_freq, 0.) if self.perfect_csi else self.ls_est(y, no)
+        x_hat, no_eff = self.lmmse(y, h_hat, err_var, no)
+        return bits, self.decoder(self.demapper(x_hat, no_eff))
 
 
 def _cdl(**kw):
@@ -474,6 +515,11 @@ CURVES = [
             np.arange(0, 17, 2.0), bits_per_block=768, corr=4.0, group="cdl_time" if dom == "time" else "cdl", max_batch=1024,
             cite="ipynb:2375-2425")
       for i, (cp, dom) in enumerate(((20, "freq"), (20, "time"), (2, "freq"), (2, "time")))],
+    # --- Sionna_tutorial_part3.ipynb cells 40/41 (1x4 SIMO uplink CDL-C, 100 block errors per point)
+    Curve("Sionna_tutorial_part3/c41/t0", "1x4 uplink CDL-C 10 m/s, LS-NN CSI, LMMSE, QPSK LDPC(912,1824)", lambda: _Part3Ofdm(False),
+          np.linspace(-8, 3, 20), bits_per_block=912, group="cdl", max_batch=8192, cite="cell 41"),
+    Curve("Sionna_tutorial_part3/c41/t1", "1x4 uplink CDL-C 10 m/s, perfect CSI, LMMSE, QPSK LDPC(912,1824)", lambda: _Part3Ofdm(True),
+          np.linspace(-8, 3, 20), bits_per_block=912, group="cdl", max_batch=8192, cite="cell 41"),
     # --- Discover_Sionna.ipynb cells 31/33/42 (500 block errors per point, one codeword per channel realisation)
     Curve("Discover_Sionna/c42/t0", "OFDM 1x1 TDL-A LS-NN LMMSE 16-QAM LDPC(6144,12288) boxplus BP-20", _DiscoverE2E,
           np.arange(0, 15, 1.), bits_per_block=6144, group="ofdm", max_batch=2048, cite="ipynb:1118-1134"),

@@ -515,6 +515,34 @@ def test_cir_to_time_channel_vs_oracle(phy, normalize):
         assert np.allclose(e, 1.0, atol=1e-4)
 
 
+@pytest.mark.parametrize("tag", ["cp2", "cp20", "c4", "small"])
+def test_time_domain_kernels_match_reference_execution(phy, tag):
+    """The HIP kernels against outputs of the reference's OWN modulator / cir_to_time_channel / ApplyTimeChannel /
+    demodulator / cir_to_ofdm_channel code (tests/golden/ofdm_time_ref_golden.npz, tools/gen_ofdm_time_ref_golden.py),
+    including the fft 72, l_min -6 ... l_max 10, cyclic prefix 2 configuration (the ISI regime)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ofdm_time_ref_golden.npz"))
+    fft, nsym, cp, l_min, l_max, B, nrx, nra, ntx, nta, P = (int(v) for v in g[f"{tag}_meta"])
+    bw = fft * float(g[f"{tag}_scs"])
+    assert phy.channel.time_lag_discrete_time_channel(bw) == (l_min, l_max)
+    close = lambda a, b, tol=1e-5: np.abs(a - b).max() <= 4 * tol * np.abs(b).max()
+    x, a, tau = g[f"{tag}_x"], g[f"{tag}_a"], g[f"{tag}_tau"]
+    xt = phy.ofdm.OFDMModulator(cp)(x)
+    assert close(_np(xt), g[f"{tag}_x_time"])
+    for norm in (True, False):
+        h = phy.channel.cir_to_time_channel(bw, a, tau, l_min, l_max, normalize=norm)
+        assert close(_np(h), g[f"{tag}_h_time_n{int(norm)}"]), norm
+    N = nsym * (fft + cp)
+    y = phy.channel.ApplyTimeChannel(N, l_max - l_min + 1)(g[f"{tag}_x_time"].reshape(B, ntx, nta, -1), g[f"{tag}_h_time_n1"])
+    assert close(_np(y), g[f"{tag}_y_time"])
+    assert close(_np(phy.ofdm.OFDMDemodulator(fft, l_min, cp)(g[f"{tag}_y_time"])), g[f"{tag}_y_rg"])
+    f = phy.channel.subcarrier_frequencies(fft, float(g[f"{tag}_scs"]))
+    assert np.array_equal(_np(f), g[f"{tag}_freqs"])
+    a_f = np.ascontiguousarray(a[..., cp:-1:(fft + cp)][..., :nsym])
+    for norm in (True, False):
+        hf = phy.channel.cir_to_ofdm_channel(f, a_f, tau, normalize=norm)
+        assert close(_np(hf), g[f"{tag}_h_freq_n{int(norm)}"], 2e-5), norm
+
+
 def test_time_domain_chain_matches_frequency_response(phy):
     """Reference test_channel_utils.py:83-135 restated: mod -> TimeChannel (static TDL-A) -> demod
     equals H[k] x[k] with H the DFT of the taps, for taps inside the cyclic prefix."""

@@ -72,7 +72,7 @@ class Reference:
         ir.as_file = lambda p: contextlib.nullcontext(p)
         sys.modules["importlib_resources"] = ir
         for name in ("sionna", "sionna.phy", "sionna.phy.fec", "sionna.phy.fec.ldpc", "sionna.phy.fec.polar", "sionna.phy.mimo",
-                     "sionna.phy.utils", "sionna.phy.ofdm", "sionna.phy.channel"):
+                     "sionna.phy.utils", "sionna.phy.ofdm", "sionna.phy.channel", "sionna.phy.signal"):
             if name not in sys.modules:
                 m = types.ModuleType(name)
                 m.__path__ = []                                    # namespace stub: nothing is importable implicitly
@@ -83,6 +83,7 @@ class Reference:
                     setattr(sys.modules[parent], child, m)
         phy = sys.modules["sionna.phy"]
         phy.Block, phy.Object = _Block, _Block
+        phy.PI = np.pi
         D = tf_numpy.DType
         dt = {"single": {"tf": {"rdtype": D("float32"), "cdtype": D("complex64")},
                          "np": {"rdtype": np.float32, "cdtype": np.complex64}},
@@ -97,7 +98,13 @@ class Reference:
         tnp = types.ModuleType("tensorflow.experimental.numpy")
         tnp.log10 = lambda x: tf_numpy._t(np.log10(np.asarray(x)))
         tnp.log2 = lambda x: tf_numpy._t(np.log2(np.asarray(x)))
+        tnp.swapaxes = self.tf.experimental.numpy.swapaxes
+        tnp.sinc = self.tf.experimental.numpy.sinc
         sys.modules["tensorflow.experimental"] = types.ModuleType("tensorflow.experimental")
+        sig = types.ModuleType("tensorflow.signal")
+        for _n in ("fft", "ifft", "fftshift", "ifftshift"):
+            setattr(sig, _n, getattr(self.tf.signal, _n))
+        sys.modules["tensorflow.signal"] = sig
         sys.modules["tensorflow.experimental.numpy"] = tnp
         cfg = types.ModuleType("sionna.phy.config")
         cfg.config, cfg.dtypes = phy.config, dt
@@ -131,6 +138,16 @@ class Reference:
             for k, v in vars(m).items():
                 if not k.startswith("_"):
                     setattr(pkg, k, v)
+        return pkg
+
+
+    def load_signal(self):
+        """sionna.phy.signal: only utils.py (fft / ifft / convolve), merged like the package's __init__ does"""
+        pkg = sys.modules["sionna.phy.signal"]
+        m = self.load("sionna.phy.signal.utils")
+        for k, v in vars(m).items():
+            if not k.startswith("_"):
+                setattr(pkg, k, v)
         return pkg
 
 

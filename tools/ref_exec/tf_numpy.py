@@ -206,7 +206,17 @@ def make_tf():
             e = np.broadcast_to(e, [int(b) for b in batch_shape] + list(e.shape)).copy()
         return _t(e)
     tf.eye = eye
-    tf.range = lambda *a, dtype=None, **k: _t(np.arange(*[int(x) for x in a], dtype=dtype or np.int32))
+    def _range(*a, start=None, limit=None, delta=None, dtype=None, name=None):
+        a = list(a)
+        if start is not None or limit is not None:
+            a = [0 if start is None else start, limit] + ([delta] if delta is not None else [])
+        elif delta is not None:
+            a = (a + [None, None])[:2] + [delta] if len(a) == 2 else [0, a[0], delta]
+        isf = any(isinstance(v, (float, np.floating)) or (hasattr(v, "dtype") and np.asarray(v).dtype.kind == "f") for v in a)
+        if dtype is None:
+            dtype = np.float32 if isf else np.int32
+        return _t(np.arange(*[np.asarray(v).item() for v in a]).astype(dtype))
+    tf.range = _range
     tf.is_tensor = lambda x: isinstance(x, (Tensor, RaggedTensor))
     tf.shape = lambda x, **k: _t(np.array(np.asarray(x).shape, dtype=np.int32))
     tf.rank = lambda x, **k: np.asarray(x).ndim
@@ -298,6 +308,10 @@ def make_tf():
     tf.math.softmax = lambda x, axis=-1, **k: _t(np.exp(np.asarray(x) - _lse(x, axis=axis, keepdims=True)))
     tf.nn = types.SimpleNamespace(log_softmax=lambda x, axis=-1, **k: _t(np.asarray(x) - _lse(x, axis=axis, keepdims=True)),
                                   softmax=tf.math.softmax, relu=_elementwise(lambda x: np.maximum(x, 0)))
+    tf.math.ceil = _elementwise(np.ceil)
+    tf.math.floor = _elementwise(np.floor)
+    tf.math.cos, tf.math.sin = _elementwise(np.cos), _elementwise(np.sin)
+    tf.cos, tf.sin = tf.math.cos, tf.math.sin
     tf.math.mod = lambda a, b: _t(np.mod(np.asarray(a), b))
     tf.math.floormod = tf.math.mod
 
@@ -414,6 +428,25 @@ def make_tf():
         if adjoint_b: b = np.conj(np.swapaxes(b, -1, -2))
         return _t(np.matmul(a, b))
     tf.matmul = matmul
+    # ---- signal / misc array ops used by the OFDM time-domain path
+    tf.signal = types.SimpleNamespace(
+        fft=lambda x, **k: _t(np.fft.fft(np.asarray(x), axis=-1).astype(np.asarray(x).dtype)),
+        ifft=lambda x, **k: _t(np.fft.ifft(np.asarray(x), axis=-1).astype(np.asarray(x).dtype)),
+        fftshift=lambda x, axes=None, **k: _t(np.fft.fftshift(np.asarray(x), axes=axes)),
+        ifftshift=lambda x, axes=None, **k: _t(np.fft.ifftshift(np.asarray(x), axes=axes)))
+
+    def pad(tensor, paddings, mode="CONSTANT", constant_values=0, name=None):
+        return _t(np.pad(np.asarray(tensor), [(int(a), int(b)) for a, b in np.asarray(paddings)], constant_values=constant_values))
+    tf.pad = pad
+    tf.repeat = lambda x, repeats, axis=None, **k: _t(np.repeat(np.asarray(x), repeats, axis=axis))
+    tf.reverse = lambda x, axis, **k: _t(np.flip(np.asarray(x), axis=tuple(int(a) for a in np.atleast_1d(axis))))
+    tf.linspace = lambda start, stop, num, **k: _t(np.linspace(start, stop, int(num)).astype(
+        np.asarray(start).dtype if np.asarray(start).dtype.kind == "f" and not isinstance(start, float) else np.float32))
+    tf.math.cumsum = tf.cumsum = lambda x, axis=0, **k: _t(np.cumsum(np.asarray(x), axis=axis))
+    tf.experimental = types.SimpleNamespace(numpy=types.SimpleNamespace(
+        swapaxes=lambda x, a, b: _t(np.swapaxes(np.asarray(x), a, b)),
+        sinc=_elementwise(lambda x: np.sinc(x).astype(x.dtype)),
+        log10=_elementwise(np.log10), log2=_elementwise(np.log2)))
     tf.name_scope = lambda *a, **k: _NullCtx()
     class Variable(Tensor):
         """tf.Variable stand-in (an ndarray view; ``isinstance(x, tf.Variable)`` is False for plain tensors)."""
