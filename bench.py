@@ -285,6 +285,32 @@ def bench_c4(args, short=False):
     torch.cuda.synchronize()
     ms = k0.elapsed_time(k1) / reps_k
     del keep
+    # the receiver front end LS-NN -> LMMSE -> demapper: three launches through the separate blocks (estimator with
+    # defer=False) against ONE launch of the fused kernel that LinearDetector runs on the estimator's deferred h_hat
+    est_e = phy.ofdm.LSChannelEstimator(rg, defer=False)
+    det = phy.ofdm.LinearDetector("lmmse", "bit", "app", rg, sm, constellation_type="qam", num_bits_per_symbol=m)
+
+    def rx_separate():
+        hh, evv = est_e(y, no)
+        xx, nn = eq(y, hh, evv, no)
+        return demap(xx, nn)
+
+    def rx_fused():
+        hh, evv = est(y, no)
+        return det(y, hh, evv, no)
+
+    def timed(fn, reps_=10):
+        fn(); fn()
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(reps_):
+            fn()
+        a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / reps_
+    same_bits = bool(torch.equal(rx_separate(), rx_fused()))
+    ms_sep, ms_fused = timed(rx_separate), timed(rx_fused)
     n_data_re = B * rg.num_data_symbols
     ach = n_data_re * 120 / (ms * 1e-3) / 1e9
     t0 = time.perf_counter()
@@ -309,6 +335,15 @@ def bench_c4(args, short=False):
                         "ms_per_block_api_call": round(ms_call, 4), "host_overhead_ms": round(ms_call - ms, 4),
                         "note": "ms_per_launch = 20 back-to-back C-ABI launches between one pair of HIP events (queue "
                                 "full); the Block-API call adds the host overhead reported beside it"},
+           "receiver_front_end": {
+               "stages": "LSChannelEstimator(nn) -> LMMSEEqualizer -> Demapper(app)", "ms_three_launches": round(ms_sep, 4),
+               "ms_fused_one_launch": round(ms_fused, 4), "bit_identical": same_bits,
+               "kernel": "ofdm_lsnn_lmmse_kernel<4,2,1,app> (h_hat deferred, never written)",
+               "algorithmic_GBps_at_120B_per_RE": round(n_data_re * 120 / (ms_fused * 1e-3) / 1e9, 1),
+               "frac_of_hbm_peak_at_120B_per_RE": round(n_data_re * 120 / (ms_fused * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3),
+               "note": "SURVEY 8(d)'s 120 B/RE assume h_hat (64 B/RE) is read from HBM; the fused kernel reads y (32 B/RE + "
+                       "pilot rows from L2) and writes 16 B/RE of LLRs, so this fraction may exceed what an h_hat-reading "
+                       "kernel can reach - it is reported for comparison with the separate-kernel figure above"},
            "end_to_end": {"codewords_per_s": round(2 * B / t_e2e, 1), "ms_per_batch": round(t_e2e * 1e3, 2)}}
     if not short:
         # time-domain variant of the same chain: OFDMModulator (rocFFT) -> TimeChannel -> OFDMDemodulator (rocFFT)

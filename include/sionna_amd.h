@@ -446,6 +446,25 @@ int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const float* err_var
                         int fft_size, int num_data, int whiten, float* x_hat, float* no_eff,
                         void* stream);
 
+/* LSChannelEstimator(interpolation_type="nn").call + LMMSEEqualizer.call (+ Demapper.call) in one launch
+ *   ofdm/channel_estimation.py:175-285 (LS at the pilots) and :323-435 (nearest-neighbour interpolation),
+ *   ofdm/equalization.py:107-275, ofdm/detection.py:740-847 (LinearDetector), mapping.py:664-691.
+ * No interfering streams (num_interfering_streams_per_rx = 0), whitened LMMSE.  h_hat is never materialised: at every
+ * RE it is y_ls[b, rx, m, ls_src[s, re]] * ls_coef[s, re] (the estimator's own product), the estimation-error variance
+ * max(no_ls * ls_ev[s, re], 0).  y, y_ls [B,RX,M,T,FFT] complex64 (y_ls = the grid the estimator saw, normally y itself);
+ * ls_src int32 / ls_coef complex64 / ls_ev float32 [S, T*F] DEVICE tables over the effective grid; no_ls: 1 or B*RX*M
+ * values; no [B,RX,M]; the other tables as for samd_ofdm_lmmse_c64.
+ * num_bits_per_symbol = 0: outputs x_hat, no_eff [B,S,num_data] (llr may be NULL).
+ * num_bits_per_symbol = 2,4,6,8 (square QAM, pam_levels DEVICE float[2^(m/2)]): output llr [B,S,num_data*m]
+ * (logits, or hard decisions when hard_out), x_hat / no_eff may be NULL.  Bit-identical to the three separate entries. */
+int samd_ofdm_lsnn_lmmse_c64(const float* y, const float* y_ls, const int32_t* ls_src, const float* ls_coef,
+                             const float* ls_ev, const float* no_ls, int64_t no_ls_len, const float* no,
+                             const int32_t* sc_ind, const int32_t* desired, const int32_t* data_pos, int batch,
+                             int num_rx, int num_rx_ant, int num_streams_total, int streams_per_rx,
+                             int num_ofdm_symbols, int num_eff_subcarriers, int fft_size, int num_data,
+                             int num_bits_per_symbol, int maxlog, int hard_out, const float* pam_levels,
+                             float* x_hat, float* no_eff, float* llr, void* stream);
+
 /* TDL spatial correlation  channel/tr38901/tdl.py:474-492: out[b, i, q] = sum_j mat[i][j] a[b, j, q] over the
  * num_rx_ant * num_tx_ant antenna pairs (rx major); a / out [batch, num_rx_ant * num_tx_ant, inner] complex64
  * (inner = num_paths * num_time_steps), mat [n, n] complex64 DEVICE (square root of the correlation matrix). */

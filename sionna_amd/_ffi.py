@@ -101,6 +101,8 @@ _SIGNATURES = {
     "samd_polar_scl_decode_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i32, _vp, _vp,
                                          _vp, _sz, _vp]),
     "samd_count_errors_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "samd_ofdm_lsnn_lmmse_c64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                        _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "samd_debug_set_option": (_i32, [C.c_char_p, C.c_char_p]),
     "samd_debug_options_generation": (_i32, []),
 }
@@ -195,6 +197,9 @@ def ptr(t):
     """Device pointer of a contiguous tensor (or None)."""
     if t is None:
         return None
+    if "_samd_pending" in getattr(t, "__dict__", ()):          # a deferred block output: fill it before its address is used
+        from .phy.block import materialize
+        materialize(t)
     assert t.is_cuda and t.is_contiguous()
     if t.numel() == 0:
         # an empty tensor has no storage (data_ptr() == 0), but the C entry points reject NULL before they look at the

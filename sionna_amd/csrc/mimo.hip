@@ -20,6 +20,7 @@
 // HBM-streaming (arithmetic intensity ~6 flop/B).
 #include "common.h"
 #include "options.h"
+#include "demap_core.h"
 #include <algorithm>
 
 namespace samd {
@@ -1107,6 +1108,95 @@ __global__ __launch_bounds__(64) void ofdm_mmse_pic_kernel(OfdmEqArgs p, const f
     }
 }
 
+// ---- LSChannelEstimator(interpolation_type="nn") + LMMSEEqualizer (+ Demapper) in ONE pass over the received grid.
+// With nearest-neighbour interpolation h_hat holds, at every resource element, a copy of the LS estimate of the nearest
+// pilot: 8 M K bytes per RE that the estimator writes and the equaliser reads back (64 of config C4's 120 B per RE).  This
+// kernel forms that value where it is used - h = y_ls[pilot RE] * (1 / pilot), the estimator's own product (ofdm.hip
+// ls_gather_scale_kernel), so the bits are those of the two-launch path - and the error variance from the estimator's
+// table: err = max(no_ls * ev[q][re], 0).  The gathered pilot rows of a (batch, receiver) are re-read by the lanes of
+// ~6 OFDM symbols each: L1 / L2 hits, not HBM traffic.  NB > 0: the equalised symbols are demapped in registers with the
+// standalone demapper's function (demap_core.h) and only the LLRs are written.
+// ofdm/channel_estimation.py:175-285, 323-435; ofdm/equalization.py:107-275; ofdm/detection.py:740-847; mapping.py:664-691
+struct OfdmLsEqArgs {
+  OfdmEqArgs e;            // y, no, tables, outputs as for ofdm_lmmse_diag_kernel (h_hat / err_var unused)
+  const float2* y_ls;      // [B, RX, M, T, FFT] the grid the estimator was called with (normally == e.y)
+  const int32_t* ls_src;   // [S, T*F] index into the full grid of the nearest pilot RE of stream s
+  const float2* ls_coef;   // [S, T*F] 1 / pilot value (divide_no_nan)
+  const float* ls_ev;      // [S, T*F] 1 / |pilot|^2
+  const float* no_ls;      // [no_ls_len] noise variance the estimator was called with: 1 value or [B, RX, M]
+  int64_t no_ls_len;
+  const float* levels;     // [2^NB] PAM levels of one axis (NB > 0)
+  float* llr;              // [B, S, ND * 2 NB]
+  int hard_out;
+};
+
+template <int M, int K, int NB, bool MAXLOG>
+__global__ __launch_bounds__(128, (M * K <= 8) ? 6 : 1) void ofdm_lsnn_lmmse_kernel(OfdmLsEqArgs a) {
+  const OfdmEqArgs& p = a.e;
+  [[maybe_unused]] __shared__ float lev[NB > 0 ? (1 << NB) : 1];
+  if constexpr (NB > 0) {
+    if (threadIdx.x < (1 << NB)) lev[threadIdx.x] = a.levels[threadIdx.x];
+    __syncthreads();
+  }
+  const int re = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (re >= p.T * p.F) return;
+  const int brx_i = p.brx0 + (int)blockIdx.y;
+  const int TF = p.T * p.F;
+  const int t = (int)((unsigned)re / (unsigned)p.F), f = re - t * p.F;
+  const int rx = (int)((unsigned)brx_i % (unsigned)p.RX);
+  const int64_t b = (int64_t)((unsigned)brx_i / (unsigned)p.RX);
+  int dpos[K], sid[K];
+  bool any = false;
+#pragma unroll
+  for (int k = 0; k < K; ++k) { sid[k] = p.desired[rx * K + k]; dpos[k] = p.data_pos[(int64_t)sid[k] * TF + re]; any |= dpos[k] >= 0; }
+  if (!any) return;                                           // pilot-only resource element
+  const int64_t brx = b * p.RX + rx;
+  c32 y[M], h[M][K], xh[K];
+  float d[M], ne[K];
+  const int bin = p.sc_ind[f];
+  int src[K];
+  float2 coef[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) { src[k] = a.ls_src[(int64_t)sid[k] * TF + re]; coef[k] = a.ls_coef[(int64_t)sid[k] * TF + re]; }
+  float evs = 0.f;                                            // (only for no_ls_len == 1: the same sum for every antenna)
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int64_t row = (brx * M + m) * p.T * (int64_t)p.FFT;
+    const float2 v = p.y[row + (int64_t)t * p.FFT + bin];
+    y[m] = C(v.x, v.y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const float2 yp = a.y_ls[row + src[k]];
+      h[m][k] = C(yp.x * coef[k].x - yp.y * coef[k].y, yp.x * coef[k].y + yp.y * coef[k].x);     // cmul(y, 1 / pilot)
+    }
+    const float nl = a.no_ls[a.no_ls_len == 1 ? 0 : brx * M + m];
+    float dg = p.no[brx * M + m];                             // thermal noise + estimation error of ALL streams, q ascending
+    for (int q = 0; q < p.S; ++q) dg += fmaxf(nl * a.ls_ev[(int64_t)q * TF + re], 0.f);
+    d[m] = dg;
+  }
+  (void)evs;
+  lmmse_solve_diag<M, K>(y, h, d, xh, ne);
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (dpos[k] >= 0) {
+      const int64_t o = (b * p.S + sid[k]) * p.ND + dpos[k];
+      if constexpr (NB == 0) {
+        p.x_hat[o] = make_float2(xh[k].re, xh[k].im);
+        p.no_eff[o] = ne[k];
+      } else {
+        float llr[2 * NB];
+        square_qam_llr<NB, MAXLOG>(make_float2(xh[k].re, xh[k].im), ne[k], lev, llr);
+        float* op = a.llr + o * (2 * NB);
+#pragma unroll
+        for (int i = 0; i < 2 * NB; i += 2) {
+          float2 v2 = make_float2(llr[i], llr[i + 1]);
+          if (a.hard_out) v2 = make_float2(v2.x > 0.f ? 1.f : 0.f, v2.y > 0.f ? 1.f : 0.f);
+          *reinterpret_cast<float2*>(op + i) = v2;
+        }
+      }
+    }
+}
+
 }  // namespace samd
 
 using namespace samd;
@@ -1173,6 +1263,45 @@ extern "C" int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const flo
   SAMD_MK_LIST(X)
 #undef X
   set_error("ofdm_lmmse: unsupported (num_rx_ant, streams_per_rx) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_ofdm_lsnn_lmmse_c64(const float* y, const float* y_ls, const int32_t* ls_src, const float* ls_coef,
+                                        const float* ls_ev, const float* no_ls, int64_t no_ls_len, const float* no,
+                                        const int32_t* sc_ind, const int32_t* desired, const int32_t* data_pos, int batch,
+                                        int num_rx, int num_rx_ant, int num_streams_total, int streams_per_rx,
+                                        int num_ofdm_symbols, int num_eff_subcarriers, int fft_size, int num_data,
+                                        int num_bits_per_symbol, int maxlog, int hard_out, const float* pam_levels,
+                                        float* x_hat, float* no_eff, float* llr, void* stream) {
+  SAMD_REQUIRE(y && y_ls && ls_src && ls_coef && ls_ev && no_ls && no && sc_ind && desired && data_pos, "null argument");
+  SAMD_REQUIRE(no_ls_len == 1 || no_ls_len == (int64_t)batch * num_rx * num_rx_ant, "no_ls must have 1 or batch * num_rx * num_rx_ant entries");
+  SAMD_REQUIRE(num_bits_per_symbol == 0 ? (x_hat && no_eff) : (llr && pam_levels), "missing output buffer");
+  SAMD_REQUIRE(num_bits_per_symbol >= 0 && num_bits_per_symbol <= 8 && num_bits_per_symbol % 2 == 0, "square QAM only");
+  OfdmLsEqArgs a{OfdmEqArgs{(const float2*)y, nullptr, nullptr, no, sc_ind, desired, nullptr, data_pos, (float2*)x_hat, no_eff,
+                            batch, num_rx, num_streams_total, num_ofdm_symbols, num_eff_subcarriers, fft_size, 0, num_data, 0, 1},
+                 (const float2*)y_ls, ls_src, (const float2*)ls_coef, ls_ev, no_ls, no_ls_len, pam_levels, llr, hard_out};
+  if ((int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers == 0) return SAMD_OK;
+  const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 127) / 128, brx_total = batch * num_rx;
+  const int nb = num_bits_per_symbol / 2;
+#define LAUNCH(M, K, NB, ML)                                                                                         \
+  for (a.e.brx0 = 0; a.e.brx0 < brx_total; a.e.brx0 += 65535)                                                        \
+    hipLaunchKernelGGL((ofdm_lsnn_lmmse_kernel<M, K, NB, ML>), dim3(tf_blocks, std::min(brx_total - a.e.brx0, 65535)), \
+                       dim3(128), 0, (hipStream_t)stream, a);                                                         \
+  return launch_status();
+#define X(M, K)                                                                                                      \
+  if (num_rx_ant == M && streams_per_rx == K) {                                                                      \
+    switch (nb * 2 + (maxlog ? 1 : 0)) {                                                                             \
+      case 0: case 1: { LAUNCH(M, K, 0, false) }                                                                     \
+      case 2: { LAUNCH(M, K, 1, false) } case 3: { LAUNCH(M, K, 1, true) }                                           \
+      case 4: { LAUNCH(M, K, 2, false) } case 5: { LAUNCH(M, K, 2, true) }                                           \
+      case 6: { LAUNCH(M, K, 3, false) } case 7: { LAUNCH(M, K, 3, true) }                                           \
+      case 8: { LAUNCH(M, K, 4, false) } case 9: { LAUNCH(M, K, 4, true) }                                           \
+    }                                                                                                                \
+  }
+  SAMD_MK_LIST(X)
+#undef X
+#undef LAUNCH
+  set_error("ofdm_lsnn_lmmse: unsupported (num_rx_ant, streams_per_rx) combination");
   return SAMD_ERR_UNSUPPORTED;
 }
 

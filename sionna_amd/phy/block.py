@@ -4,6 +4,7 @@
 calls ``build(*shapes)`` exactly once, then ``call(*args)`` (block.py:144-155).  Unknown
 constructor kwargs are accepted and ignored like in the reference (block.py:25).
 """
+import weakref
 from abc import ABC, abstractmethod
 
 import numpy as np
@@ -12,15 +13,91 @@ import torch
 from .config import config, dtypes
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Deferred block outputs.  Some blocks of the reference exist only to hand a large tensor to the next block (the
+# nearest-neighbour-interpolated channel estimate: 64 of config C4's 120 bytes per resource element, written by
+# LSChannelEstimator and read back by LMMSEEqualizer).  Such a block returns its output tensor with allocated but UNFILLED
+# storage and a ``Pending`` record saying how to fill it.  A consumer that can work from the recipe (the fused
+# LS + LMMSE (+ demapper) kernel) does so and the tensor is never filled; ANY other use - a torch operation, ``.numpy()``,
+# the C-ABI pointer of ``_ffi.ptr`` - fills it first (``__torch_function__`` below), so the tensor behaves like an
+# ordinary one.  This is how the HIP path fuses across the reference's block boundaries without a tracing compiler.
+# The recipe keeps references to its inputs; they must not be modified in place before the tensor is used.
+# ---------------------------------------------------------------------------------------------------------------------
+_PENDING = set()          # id() of every live deferred tensor (entries leave on fill or garbage collection)
+# property getters / methods that only look at a tensor's metadata and therefore do not fill a deferred tensor
+_META_GET = {"shape", "dtype", "device", "is_cuda", "ndim", "requires_grad", "layout", "names", "is_sparse", "is_quantized",
+             "is_meta", "grad_fn", "is_leaf", "itemsize", "nbytes", "is_cpu", "is_nested", "grad", "output_nr", "_version"}
+_META_FN = {"dim", "size", "numel", "is_contiguous", "stride", "element_size", "ndimension", "is_floating_point", "is_complex",
+            "nelement", "get_device", "storage_offset", "is_pinned", "type", "__len__", "__hash__", "__repr__", "is_shared",
+            "has_names", "is_same_size", "is_signed", "is_inference", "is_conj", "is_neg", "requires_grad_", "__class__",
+            "untyped_storage", "_is_view", "is_set_to", "data_ptr"}
+
+
+class Pending:
+    """How to fill a deferred tensor: ``fill(plain_tensor)`` launches the kernel(s) that write its storage; ``kind`` and
+    the keyword attributes let a fusing consumer recognise the recipe."""
+
+    def __init__(self, kind, fill, **info):
+        self.kind, self.fill = kind, fill
+        self.__dict__.update(info)
+
+
+def pending_of(t):
+    """The Pending record of a deferred tensor, else None (plain tensors, numpy arrays, scalars)."""
+    return t.__dict__.get("_samd_pending") if isinstance(t, Tensor) else None
+
+
+def materialize(t):
+    """Fill a deferred tensor now (no-op for everything else); returns ``t``."""
+    p = pending_of(t)
+    if p is not None:
+        del t.__dict__["_samd_pending"]
+        _PENDING.discard(id(t))
+        p.fill(torch.Tensor._make_subclass(torch.Tensor, t) if type(t) is not torch.Tensor else t)
+    return t
+
+
+def defer(t, pending):
+    """Mark the (unfilled) tensor ``t`` as deferred; returns it as a ``Tensor``."""
+    t = t if type(t) is Tensor else t.as_subclass(Tensor)
+    t.__dict__["_samd_pending"] = pending
+    _PENDING.add(id(t))
+    weakref.finalize(t, _PENDING.discard, id(t))
+    return t
+
+
+def _fill_all(objs):
+    for o in objs:
+        if isinstance(o, Tensor):
+            if "_samd_pending" in o.__dict__:
+                materialize(o)
+        elif isinstance(o, (list, tuple)):
+            _fill_all(o)
+
+
 class Tensor(torch.Tensor):
-    """torch.Tensor whose ``.numpy()`` also works for device tensors (notebooks call
-    ``x.numpy()`` on block outputs)."""
+    """torch.Tensor whose ``.numpy()`` also works for device tensors (notebooks call ``x.numpy()`` on block outputs) and
+    whose storage may be filled on first use (see ``Pending``)."""
 
     def numpy(self, *args, **kwargs):  # pylint: disable=arguments-differ
+        materialize(self)
         return self.as_subclass(torch.Tensor).detach().cpu().numpy(*args, **kwargs)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if _PENDING:                                   # some tensor somewhere is deferred: is one of the operands?
+            name = getattr(func, "__name__", "")
+            meta = name in _META_FN or (name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", "") in _META_GET)
+            if not meta:
+                _fill_all(args)
+                if kwargs:
+                    _fill_all(kwargs.values())
+        return super().__torch_function__(func, types, args, kwargs or {})
 
 
 def wrap(t):
+    if type(t) is Tensor:
+        return t
     return t.as_subclass(Tensor) if isinstance(t, torch.Tensor) else t
 
 

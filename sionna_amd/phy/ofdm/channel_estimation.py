@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from ... import _ffi
-from ..block import Block, Object, wrap
+from ..block import Block, Object, wrap, Pending, defer
 
 
 class NearestNeighborInterpolator(Object):
@@ -170,6 +170,7 @@ class LSChannelEstimator(Block):
         self._src = (t * resource_grid.fft_size + sc[f]).astype(np.int32)      # index into the full grid
         self._inv, self._ev = inv, ev
         self._dev = None
+        self._defer = bool(kwargs.get("defer", True))          # defer=False: always materialise h_hat (tests compare the two)
 
     def call(self, y, no):
         self._require_single()
@@ -184,13 +185,30 @@ class LSChannelEstimator(Block):
         s, n_out = src.shape
         rows = y.shape[0] * y.shape[1] * y.shape[2]
         h_hat = torch.empty(tuple(y.shape[:3]) + self._out_shape, dtype=torch.complex64, device=y.device)
-        _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(y), _ffi.ptr(src), _ffi.ptr(inv), rows, s, n_out,
-                                                       rg.num_ofdm_symbols * rg.fft_size, _ffi.ptr(h_hat),
-                                                       _ffi.stream()), "LSChannelEstimator")
+
+        def fill_h(out):
+            _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(y), _ffi.ptr(src), _ffi.ptr(inv), rows, s, n_out,
+                                                           rg.num_ofdm_symbols * rg.fft_size, _ffi.ptr(out),
+                                                           _ffi.stream()), "LSChannelEstimator")
         # err_var = no / |pilot|^2, broadcastable to h_hat (channel_estimation.py:276-283); `no` has the
         # first n <= 3 dims of [batch, num_rx, num_rx_ant] - a handful of elements, plain broadcasting
         no = _ffi.to_device(no, torch.float32)
-        no = no.reshape(tuple(no.shape) + (1,) * (3 - no.dim()) + (1,) * len(self._out_shape))
+        no3 = no.reshape(tuple(no.shape) + (1,) * (3 - no.dim()))
+        no = no3.reshape(tuple(no3.shape) + (1,) * len(self._out_shape))
+        if self._interpolation_type == "nn" and self._defer:
+            # nearest-neighbour interpolation: h_hat is a gather of the LS estimates at the pilots.  It is returned DEFERRED
+            # (block.py): the fused LS + LMMSE (+ demapper) kernel of LMMSEEqualizer / LinearDetector works from the
+            # recipe and never materialises it; any other use fills it with the gather kernel first.
+            if no3.numel() == 1:
+                err_var = torch.clamp_min(no * ev.reshape(self._out_shape), 0.)           # [.., S.., T, F] table: a few KB
+            else:
+                shape = tuple(torch.broadcast_shapes(tuple(no.shape), self._out_shape))
+                err_var = defer(torch.empty(shape, dtype=torch.float32, device=y.device),
+                                Pending("ls_err_var", lambda out: torch.clamp_min(no * ev.reshape(self._out_shape), 0., out=out)))
+            rec = Pending("ls_nn", fill_h, y=y, src=src, coef=inv, ev=ev, no=no3.reshape(-1) if no3.numel() == 1 else
+                          torch.broadcast_to(no3, tuple(y.shape[:3])).contiguous().reshape(-1), rg=rg, err_var=err_var)
+            return defer(h_hat, rec), err_var
+        fill_h(h_hat)
         err_var = no * ev.reshape(self._out_shape)
         if self._lin is not None:
             err_var = torch.broadcast_to(err_var, tuple(err_var.shape[:3]) + self._out_shape)

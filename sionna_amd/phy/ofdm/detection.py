@@ -30,6 +30,16 @@ class LinearDetector(Block):
             self._demapper = SymbolDemapper(constellation=self._constellation, hard_out=hard_out, precision=precision)
 
     def call(self, y, h_hat, err_var, no):
+        dm = self._demapper
+        if isinstance(dm, Demapper) and dm.precision == "single" and dm._separable:
+            # a square QAM and a channel estimate still deferred by LSChannelEstimator("nn"): estimate, equalise and demap
+            # in one launch (equalization.py _fused_lsnn); the LLRs are those of the three separate blocks, bit for bit
+            lev = self._constellation.pam_levels(raw=True)
+            if lev is not None:
+                llr = self._eq._fused_lsnn(y, h_hat, err_var, no, demap=(self._constellation.num_bits_per_symbol,
+                                                                        dm._method == "maxlog", bool(dm._hard_out), lev))
+                if llr is not None:
+                    return llr
         x_hat, no_eff = self._eq(y, h_hat, err_var, no)
         return self._demapper(x_hat, no_eff)          # bit: [batch, num_tx, num_streams, num_data_symbols*m]
 

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from ... import _ffi
-from ..block import Block
+from ..block import Block, pending_of
 
 
 # kernel modes of samd_ofdm_lmmse_c64 / samd_lmmse_equalizer_c64 (csrc/mimo.hip)
@@ -133,9 +133,52 @@ class OFDMEqualizer(Block):
         from ..block import wrap
         return wrap(extract(x_hat)), wrap(extract(no_eff))
 
+    def _fused_lsnn(self, y, h_hat, err_var, no, demap=None):
+        """``h_hat`` still deferred by ``LSChannelEstimator(interpolation_type="nn")`` of the same resource grid, its own
+        ``err_var``, LMMSE, no interfering streams: ONE launch of samd_ofdm_lsnn_lmmse_c64 forms the estimate where it
+        is used (the estimator's own product, hence the bits of the separate launches) and h_hat is never written.
+        ``demap`` = (num_bits_per_symbol, maxlog, hard_out, pam_levels): the LLRs instead of (x_hat, no_eff).
+        Returns None when the recipe does not apply (the caller then takes the general path, which fills h_hat)."""
+        pend = pending_of(h_hat)
+        if (pend is None or pend.kind != "ls_nn" or pend.rg is not self._rg or self._mode != MODE_LMMSE
+                or self.precision != "single" or err_var is not pend.err_var):
+            return None
+        rg, sm = self._rg, self._sm
+        sc_ind, desired, undesired, data_pos, n_und = self._tables()
+        if n_und:
+            return None
+        y = _ffi.to_device(y, torch.complex64)
+        b, rx, m = y.shape[:3]
+        if tuple(y.shape) != tuple(pend.y.shape):
+            return None
+        no = _ffi.to_device(no, torch.float32)
+        no = torch.broadcast_to(no.reshape(tuple(no.shape) + (1,) * (3 - no.dim())), (b, rx, m)).contiguous()
+        s, nd = rg.num_tx * rg.num_streams_per_tx, rg.num_data_symbols
+        alloc = torch.empty if self._covers_all else torch.zeros
+        x_hat = no_eff = llr = None
+        if demap is None:
+            nbits, maxlog, hard, lev = 0, 0, 0, None
+            x_hat = alloc((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.complex64, device=y.device)
+            no_eff = alloc((b, rg.num_tx, rg.num_streams_per_tx, nd), dtype=torch.float32, device=y.device)
+        else:
+            nbits, maxlog, hard, lev = demap
+            llr = alloc((b, rg.num_tx, rg.num_streams_per_tx, nd * nbits), dtype=torch.float32, device=y.device)
+        rc = _ffi.lib().samd_ofdm_lsnn_lmmse_c64(
+            _ffi.ptr(y), _ffi.ptr(pend.y), _ffi.ptr(pend.src), _ffi.ptr(pend.coef), _ffi.ptr(pend.ev), _ffi.ptr(pend.no),
+            pend.no.numel(), _ffi.ptr(no), _ffi.ptr(sc_ind), _ffi.ptr(desired), _ffi.ptr(data_pos), b, rx, m, s,
+            sm.num_streams_per_rx, rg.num_ofdm_symbols, rg.num_effective_subcarriers, rg.fft_size, nd, int(nbits), int(maxlog),
+            int(hard), _ffi.ptr(lev), _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.ptr(llr), _ffi.stream())
+        if rc == _ffi.ERR_UNSUPPORTED:
+            return None
+        _ffi.check(rc, type(self).__name__ + "(fused LS-NN)")
+        return llr if demap is not None else (x_hat, no_eff)
+
     def call(self, y, h_hat, err_var, no):
         if self.precision == "double":
             return self._call_double(y, h_hat, err_var, no)
+        fused = self._fused_lsnn(y, h_hat, err_var, no)
+        if fused is not None:
+            return fused
         rg = self._rg
         keep, head, tabs, dims = self._prepare(y, h_hat, err_var, no)
         b, nd, dev = dims[0], rg.num_data_symbols, keep[0].device

@@ -287,6 +287,58 @@ def test_fused_ofdm_lmmse_vs_oracle(phy, cfg):
         assert _llr_close(_np(llr), ref_llr), np.max(np.abs(_np(llr) - ref_llr))
 
 
+@pytest.mark.parametrize("cfg", ["c4_4x2", "siso", "two_tx_4x1", "cdl_8x4"])
+def test_fused_ls_nn_lmmse_demap_is_bit_identical_to_the_separate_blocks(phy, cfg):
+    """``LSChannelEstimator("nn")`` returns h_hat DEFERRED (block.py Pending); LMMSEEqualizer / LinearDetector then run
+    samd_ofdm_lsnn_lmmse_c64 - estimate, equalise (and demap) in one launch, h_hat never written.  Same bits as the three
+    separate launches (estimator with defer=False), for equaliser and LLR outputs, scalar and per-antenna noise variance;
+    the deferred tensors still behave like tensors afterwards; everything the recipe does not cover takes the general path."""
+    from sionna_amd.phy.block import pending_of
+    nra, ns, num_tx, fft, guards = {"c4_4x2": (4, 2, 1, 76, (5, 6)), "siso": (1, 1, 1, 76, (5, 6)), "two_tx_4x1": (4, 1, 2, 76, (5, 6)),
+                                    "cdl_8x4": (8, 4, 1, 72, (5, 6))}[cfg]
+    rg, org = _grids(phy, num_tx=num_tx, ns=ns, fft=fft, guards=guards)
+    sm = phy.mimo.StreamManagement([[1] * num_tx], ns)
+    rng = np.random.default_rng(7)
+    B = 37
+    for m in (2, 4, 6):
+        x = omap.qam(m)[rng.integers(0, 2 ** m, (B, num_tx, ns, rg.num_data_symbols))]
+        grid = o.rg_map(org, x)
+        h = ((rng.normal(size=(B, 1, nra, num_tx, ns, 14, rg.fft_size)) + 1j * rng.normal(size=(B, 1, nra, num_tx, ns, 14, rg.fft_size))) / np.sqrt(2)).astype(np.complex64)
+        y = o.apply_ofdm_channel(grid, h)
+        no_s = 0.03
+        y = (y + np.sqrt(no_s / 2) * (rng.normal(size=y.shape) + 1j * rng.normal(size=y.shape))).astype(np.complex64)
+        for no in (no_s, (no_s * (0.5 + rng.random((B, 1, nra)))).astype(np.float32), (no_s * (0.5 + rng.random(B))).astype(np.float32)):
+            est_l, est_e = phy.ofdm.LSChannelEstimator(rg, "nn"), phy.ofdm.LSChannelEstimator(rg, "nn", defer=False)
+            eq = phy.ofdm.LMMSEEqualizer(rg, sm)
+            hh_e, ev_e = est_e(y, no)
+            assert pending_of(hh_e) is None
+            xe, ne = eq(y, hh_e, ev_e, no)
+            hh_l, ev_l = est_l(y, no)
+            assert pending_of(hh_l) is not None and tuple(hh_l.shape) == tuple(hh_e.shape) and hh_l.dtype == hh_e.dtype
+            xl, nl = eq(y, hh_l, ev_l, no)
+            assert pending_of(hh_l) is not None, "the fused launch must not fill h_hat"
+            _same_f32(_np(xl), _np(xe)) and _same_f32(_np(nl), _np(ne))
+            for meth in ("app", "maxlog"):
+                for hard in (False, True):
+                    det = phy.ofdm.LinearDetector("lmmse", "bit", meth, rg, sm, constellation_type="qam", num_bits_per_symbol=m, hard_out=hard)
+                    ref = _np(det(y, hh_e, ev_e, no))
+                    got = det(y, hh_l, ev_l, no)
+                    assert pending_of(hh_l) is not None
+                    _same_f32(_np(got), ref)
+            # the deferred tensors are ordinary tensors for everybody else
+            assert np.array_equal(_np(ev_l), _np(ev_e))
+            assert np.array_equal(_np(hh_l + 0), _np(hh_e)) and pending_of(hh_l) is None
+    # outside the recipe: a different err_var, ZF equaliser, another resource grid -> general path, still correct
+    hh_l, ev_l = phy.ofdm.LSChannelEstimator(rg, "nn")(y, no_s)
+    x0, n0 = phy.ofdm.LMMSEEqualizer(rg, sm)(y, hh_l, 0., no_s)
+    assert pending_of(hh_l) is None
+    xr, nr = phy.ofdm.LMMSEEqualizer(rg, sm)(y, hh_e if np.isscalar(no) else est_e(y, no_s)[0], 0., no_s)
+    _same_f32(_np(x0), _np(xr)) and _same_f32(_np(n0), _np(nr))
+    hh_l, ev_l = phy.ofdm.LSChannelEstimator(rg, "nn")(y, no_s)
+    xz, _ = phy.ofdm.ZFEqualizer(rg, sm)(y, hh_l, ev_l, no_s)
+    assert pending_of(hh_l) is None and np.isfinite(_np(xz)).all()
+
+
 def test_c4_chain_high_snr_is_error_free(phy):
     """Config C4 end to end (TDL-A 300 ns, 4x2, LS-NN + LMMSE + LDPC) at 25 dB: BER == 0
     (the reference's own bar for this chain, test_mimo_ofdm_estimation_detection.py:183-195)."""
