@@ -2,17 +2,21 @@
 ``sionna.phy.fec.ldpc.LDPCBPDecoder`` / ``LDPC5GDecoder``
 (reference src/sionna/phy/fec/ldpc/decoding.py:13-637, 1169-1536).
 
-Two HIP engines sit behind the same Block API:
+HIP engines behind the same Block API (the library picks per code and rule, ``samd_ldpc5g_decode_engine``):
 
-* generic (any parity-check matrix, all four check-node rules, IDD state in/out):
-  ``samd_ldpc_bp_decode_f32`` - messages HBM-resident, batch-last, two fused passes per
-  iteration (csrc/ldpc_bp_generic.hip);
-* 5G on-chip (min-sum family on a 5G code that fits in LDS): ``samd_ldpc5g_decode_f32`` -
-  rate recovery + all iterations + output mapping in one kernel (csrc/ldpc5g.hip).
+* generic (any parity-check matrix, all check-node rules, array schedules, IDD state in / out):
+  ``samd_ldpc_bp_decode_f32`` - messages HBM-resident, batch-last, two fused passes per iteration
+  (csrc/ldpc_bp_generic.hip);
+* 5G on-chip, flooding: ``samd_ldpc5g_decode_f32`` - rate recovery + all iterations + output mapping in ONE kernel
+  with the messages in LDS (explicit messages csrc/ldpc5g_onchip_ms.inc, compressed check-node state
+  csrc/ldpc5g_onchip.hip, part of the messages in L2 csrc/ldpc5g_onchip_mss.hip; min-sum family and boxplus rules);
+* 5G on-chip, ``cn_schedule="layered"``: ``samd_ldpc5g_decode_layered_f32`` (csrc/ldpc5g_onchip_ly.hip).
 
-Both use the arithmetic and summation order of oracle/ldpc_bp.py.  Python callables for
-node updates and message callbacks have no HIP path and raise
-``NotImplementedError`` (there is deliberately no CPU fallback).
+All use the arithmetic and summation order of oracle/ldpc_bp.py / oracle/ldpc_bp.c, which tests/test_oracle_ref_exec.py
+pins to the reference's own decoding.py executed under a NumPy stand-in for TensorFlow (min-sum family and VN update
+bit for bit).  Python callables for node updates (``cn_update=fn`` / ``vn_update=fn``) and the message callbacks
+(``v2c_callbacks`` / ``c2v_callbacks``) run on the device through the torch engine of ``custom.py`` (ragged messages
+as padded device tensors): same interface as the reference's, slower than the built-in rules, still no CPU fallback.
 """
 import ctypes as C
 import types

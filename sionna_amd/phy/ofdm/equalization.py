@@ -28,6 +28,13 @@ def _is_host_zero(err_var):
     return False
 
 
+def _same_tensor(a, b):
+    """``a`` is (a view-free alias of) the tensor ``b``: a block's ``__call__`` re-wraps its outputs, so identity of the
+    Python objects is too strict; the storage address, shape and dtype identify the estimator's own err_var."""
+    return (isinstance(a, torch.Tensor) and isinstance(b, torch.Tensor) and a.shape == b.shape and a.dtype == b.dtype
+            and a.device == b.device and a.data_ptr() == b.data_ptr())
+
+
 class OFDMEqualizer(Block):
     """Base class kept for API parity.  Only the LMMSE equaliser has a HIP path; a user-supplied
     ``equalizer`` callable would have to run per resource element on the host, which this build
@@ -141,7 +148,7 @@ class OFDMEqualizer(Block):
         Returns None when the recipe does not apply (the caller then takes the general path, which fills h_hat)."""
         pend = pending_of(h_hat)
         if (pend is None or pend.kind != "ls_nn" or pend.rg is not self._rg or self._mode != MODE_LMMSE
-                or self.precision != "single" or err_var is not pend.err_var):
+                or self.precision != "single" or not _same_tensor(err_var, pend.err_var)):
             return None
         rg, sm = self._rg, self._sm
         sc_ind, desired, undesired, data_pos, n_und = self._tables()
