@@ -14,7 +14,7 @@
 struct samd_ldpc5g_opt {
   bool enc_bytes = false, enc_persist = false, onchip_compressed = false, force_spill = false, no_spill = false;
   bool no_onchip_layered = false, bp_engine = false, onchip_v1 = false, ms_nogroup = false, ms_noz128 = false;
-  int ms_var = 1, ms_ldsbar = 0, onchip_grid = 0, enc_dbg = 0;
+  int ms_var = 1, ms_ldsbar = 0, onchip_grid = 0, enc_dbg = 0, ms_dataflow = 0;
   void capture() {
     using samd::opt_set; using samd::opt_int;
     enc_bytes = opt_set("SAMD_ENC_BYTES"); enc_persist = opt_set("SAMD_ENC_PERSIST");
@@ -24,6 +24,7 @@ struct samd_ldpc5g_opt {
     ms_nogroup = opt_set("SAMD_MS_NOGROUP"); ms_noz128 = opt_set("SAMD_MS_NOZ128");
     ms_var = (int)opt_int("SAMD_MS_VAR", 1) & 1; ms_ldsbar = (int)opt_int("SAMD_MS_LDSBAR", 0);
     onchip_grid = (int)opt_int("SAMD_ONCHIP_GRID", 0);
+    ms_dataflow = (int)opt_int("SAMD_MS_DATAFLOW", 0);
 #ifdef SAMD_DEV
     enc_dbg = (int)opt_int("SAMD_ENC_DBG", 0);        // skips encoder phases: wrong results, development builds only
 #endif
@@ -72,6 +73,8 @@ struct samd_ldpc5g {
   int32_t* ms_g_ptr = nullptr;     // [2 (NW+1)] group offsets per wave: CN groups, then VN groups
   int32_t* ms_g_cn = nullptr; int32_t* ms_g_vn = nullptr;   // [2 groups] body type, first item | (last + 1) << 16
   int32_t* ms_i_cn = nullptr; int32_t* ms_i_vn = nullptr;   // [2 items]  see ldpc5g_onchip_ms.inc
+  int ms_df_ok = 0;                // dataflow readiness instead of the two barriers per iteration (SAMD_MS_DATAFLOW)
+  int32_t* ms_d_cn = nullptr; int32_t* ms_d_vn = nullptr;   // [4 items]  need mask lo / hi, own counter byte offset, increment
   int32_t* bp_col_deg = nullptr;   // [nb]
   int32_t* bp_cn_ptr = nullptr; int32_t* bp_cn_list = nullptr;     // per-wave item lists (LPT balanced)
   int32_t* bp_vn_ptr = nullptr; int32_t* bp_vn_list = nullptr;

@@ -459,11 +459,30 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   cl2.resize(cl2.size() + 2, 0); vl2.resize(vl2.size() + 2, 0);
   // ---- grouped dispatch (ldpc5g_decode_msg_kernel): the items of every wave sorted by body type.  Only for codes whose
   // items are all full chunk pairs (Z a multiple of 128, no partially pruned base row) on 16 waves.
-  std::vector<int32_t> g_ptr, g_cn, g_vn, i_cn, i_vn;
+  std::vector<int32_t> g_ptr, g_cn, g_vn, i_cn, i_vn, d_cn, d_vn;      // d_*: dataflow records, 4 ints per item (see below)
   h->ms_g_ok = 0;
+  h->ms_df_ok = 0;
+  // dataflow readiness (ldpc5g_decode_msg_kernel, experiment of round 4): instead of two workgroup barriers per iteration,
+  // every item waits for the items it reads from and publishes its own completion through monotone counters in LDS -
+  // rowcnt[r] / colcnt[compact c] count the 64-lane chunks of row r / column c updated so far (`chunks` per iteration).
+  // A check-node item of row r in iteration `it` needs colcnt[c] >= chunks it for the non-fused columns c of its row, a
+  // variable-node item of column c needs rowcnt[r] >= chunks (it + 1) for the rows r of its column: the masks over at most
+  // 64 counters travel in the item's record {need lo, need hi, byte offset of the own counter, increment}.
+  std::vector<int> col_compact(h->nb, -1);
+  int n_compact = 0;
+  for (int c = 0; c < nbu; ++c)
+    if (!col_fused[c] && col_deg[c] > 0) col_compact[c] = n_compact++;
+  std::vector<unsigned long long> row_need(ncu, 0ull), col_need(h->nb, 0ull);
+  for (int r = 0; r < ncu; ++r)
+    for (auto& e : by_row[r]) {
+      const int c = e.first;
+      if (c < nbu && col_compact[c] >= 0 && col_compact[c] < 64) row_need[r] |= 1ull << col_compact[c];
+      if (c < nbu && r < 64) col_need[c] |= 1ull << r;
+    }
+  const bool df_shape = n_compact <= 64 && ncu <= 64;
   if (z % 128 == 0 && h->n_cn % z == 0 && h->n_vn % z == 0 && h->bp_waves == 16 && groups < 2) {
     bool ok = true;
-    struct It { int cost, key; int32_t x, y; };
+    struct It { int cost, key; int32_t x, y; int idx, pr; };
     auto cost_in = [](const std::vector<std::pair<int, int32_t>>& items, int32_t id) {
       for (auto& it : items)
         if (it.second == id) return it.first;
@@ -482,6 +501,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
           if ((d >> 25) & 1) { ok = false; break; }
           const int idx = d & 0xFF, q = (d >> 8) & 0xFF, pr = (d >> 24) & 1;
           It it;
+          it.idx = idx; it.pr = pr;
           it.cost = cost_in(phase ? vi2 : ci2, d) + 3;
           if (!phase) {
             const int f = fused_col[idx] >= 0;
@@ -513,6 +533,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       if (!ok) break;
       std::vector<int32_t>& gl = phase ? g_vn : g_cn;
       std::vector<int32_t>& il = phase ? i_vn : i_cn;
+      std::vector<int32_t>& dl = phase ? d_vn : d_cn;
       for (int wv = 0; wv < nwv; ++wv) {
         g_ptr.push_back((int32_t)gl.size() / 2);
         // groups by type, the type with the most expensive items first; the group order is rotated by the wave's index
@@ -542,6 +563,11 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
             rem -= it.cost;
             il.push_back(it.x | (prio << 24));
             il.push_back(it.y);
+            const unsigned long long need = phase ? col_need[it.idx] : row_need[it.idx];
+            dl.push_back((int32_t)(unsigned)(need & 0xFFFFFFFFull));
+            dl.push_back((int32_t)(unsigned)(need >> 32));
+            dl.push_back(phase ? 8 * col_compact[it.idx] + 4 : 8 * it.idx);   // counters interleaved: {rowcnt[i], colcnt[i]} per lane
+            dl.push_back(it.pr ? 2 : 1);
           }
           gl.push_back(gq.front().key);
           gl.push_back((int32_t)(first | ((il.size() / 2) << 16)));
@@ -553,6 +579,9 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     h->ms_g_ok = ok && g_ptr.size() == (size_t)(2 * (nwv + 1)) ? 1 : 0;
     g_cn.resize(g_cn.size() + 2, 0); g_vn.resize(g_vn.size() + 2, 0);
     i_cn.resize(i_cn.size() + 4, 0); i_vn.resize(i_vn.size() + 4, 0);
+    d_cn.resize(d_cn.size() + 8, 0); d_vn.resize(d_vn.size() + 8, 0);
+    // every item of a row / column a full chunk pair's worth per iteration, the counters fit beside the messages
+    h->ms_df_ok = (h->ms_g_ok && df_shape && onchip_bp_lds_bytes(h) + 512 <= 160 * 1024) ? 1 : 0;
     if (!h->ms_g_ok) g_ptr.assign(2 * (nwv + 1), 0);
   }
   int rc = upload(&h->bp_row_off, row_off.data(), row_off.size());
@@ -561,6 +590,8 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_g_vn, g_vn.data(), g_vn.size());
   if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_i_cn, i_cn.data(), i_cn.size());
   if (rc == SAMD_OK && h->ms_g_ok) rc = upload(&h->ms_i_vn, i_vn.data(), i_vn.size());
+  if (rc == SAMD_OK && h->ms_df_ok) rc = upload(&h->ms_d_cn, d_cn.data(), d_cn.size());
+  if (rc == SAMD_OK && h->ms_df_ok) rc = upload(&h->ms_d_vn, d_vn.data(), d_vn.size());
   if (rc == SAMD_OK) rc = upload(&h->bp_col_ent, col_ent.data(), col_ent.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_col_ent, col_ent2.data(), col_ent2.size());
   if (rc == SAMD_OK) rc = upload(&h->ms_cn_ptr, mcp.data(), mcp.size());
@@ -581,6 +612,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
 void free_onchip_bp_tables(samd_ldpc5g* h) {
   (void)hipFree(h->bp_row_off); (void)hipFree(h->bp_col_ent); (void)hipFree(h->bp_col_deg); (void)hipFree(h->ms_col_ent); (void)hipFree(h->ms_cn_list); (void)hipFree(h->ms_cn_ptr); (void)hipFree(h->ms_vn_ptr); (void)hipFree(h->ms_vn_list); (void)hipFree(h->ms_tail_tab); (void)hipFree(h->ms_vtail_tab);
   (void)hipFree(h->ms_g_ptr); (void)hipFree(h->ms_g_cn); (void)hipFree(h->ms_g_vn); (void)hipFree(h->ms_i_cn); (void)hipFree(h->ms_i_vn);
+  (void)hipFree(h->ms_d_cn); (void)hipFree(h->ms_d_vn);
   (void)hipFree(h->bp_cn_ptr); (void)hipFree(h->bp_cn_list); (void)hipFree(h->bp_vn_ptr); (void)hipFree(h->bp_vn_list);
 }
 

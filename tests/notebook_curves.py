@@ -431,6 +431,42 @@ def _cdl(**kw):
     return lambda: _CdlModel(**kw)
 
 
+class _WeightedBPUntrained:
+    """``WeightedBP`` / ``WeightedBP5G`` of Weighted_BP_Algorithm.ipynb cells 6 / 25 BEFORE training (all edge weights 1 =
+    plain BP): ``num_iter`` calls of a ONE-iteration decoder that hands its v2c state to the next call (``return_state``,
+    ``msg_v2c=``), tanh rule, all-zero codeword with ``GaussianPriorSource`` LLRs, soft outputs.  ``callback=True`` keeps
+    the notebook's ``WeightedBPCallback`` registered (the decoder then runs on the device torch engine of custom.py)."""
+    soft = True
+
+    def __init__(self, pcm_id=None, k=None, n=None, num_iter=10, callback=False):
+        phy = _phy()
+        ld = phy.fec.ldpc
+        if pcm_id is not None:
+            pcm, self.k, self.n, self.rate = phy.fec.utils.load_parity_check_examples(pcm_id)
+            kw = {"v2c_callbacks": [ld.WeightedBPCallback(num_edges=int(np.sum(pcm)))]} if callback else {}
+            self.decoder = ld.LDPCBPDecoder(pcm, num_iter=1, return_state=True, hard_out=False, cn_update="boxplus", **kw)
+            self.n_out = self.n
+        else:
+            enc = ld.LDPC5GEncoder(k, n)
+            kw = {"v2c_callbacks": [ld.WeightedBPCallback(num_edges=int(np.sum(enc.pcm)))]} if callback else {}
+            self.decoder = ld.LDPC5GDecoder(enc, num_iter=1, return_state=True, hard_out=False, prune_pcm=False, cn_update="boxplus", **kw)
+            self.k, self.n, self.rate, self.n_out = k, n, k / n, k
+        self.source = phy.fec.utils.GaussianPriorSource()
+        self.num_iter = num_iter
+
+    def __call__(self, batch_size, ebno_db):
+        import torch
+        from sionna_amd import _ffi
+        phy = _phy()
+        no = phy.utils.ebnodb2no(ebno_db, num_bits_per_symbol=2, coderate=self.rate)
+        c = torch.zeros([batch_size, self.n_out], device=_ffi.device())
+        llr = self.source([batch_size, self.n], no)
+        msg = None
+        for _ in range(self.num_iter):
+            c_hat, msg = self.decoder(llr, msg_v2c=msg)
+        return c, c_hat
+
+
 class _Part1Uncoded:
     """``UncodedSystemAWGN`` of Sionna_tutorial_part1.ipynb cell 37: returns (bits, LLRs) - sim_ber(soft_estimates=True)."""
     soft = True
@@ -515,6 +551,15 @@ CURVES = [
             np.arange(0, 17, 2.0), bits_per_block=768, corr=4.0, group="cdl_time" if dom == "time" else "cdl", max_batch=1024,
             cite="ipynb:2375-2425")
       for i, (cp, dom) in enumerate(((20, "freq"), (20, "time"), (2, "freq"), (2, "time")))],
+    # --- Weighted_BP_Algorithm.ipynb cell 13 (BCH (63,45), untrained) and cell 26 (5G LDPC (400,800), prune_pcm=False, untrained):
+    #     ten one-iteration decoder calls chained through the decoder state; 2000 bit errors per point
+    Curve("Weighted_BP_Algorithm/c13/t0", "BCH(63,45) BP-10 tanh via state passing (generic HIP engine)", lambda: _WeightedBPUntrained(pcm_id=1),
+          np.arange(1, 7, 0.5), bits_per_block=63, work=63 * 40, group="state", cite="ipynb:364-380"),
+    Curve("Weighted_BP_Algorithm/c13/t0", "BCH(63,45) BP-10 with the WeightedBPCallback registered (device torch engine)",
+          lambda: _WeightedBPUntrained(pcm_id=1, callback=True), np.arange(1, 7, 0.5), bits_per_block=63, work=63 * 400, group="state_cb",
+          max_batch=20000, cite="ipynb:364-380"),
+    Curve("Weighted_BP_Algorithm/c26/t0", "5G LDPC (400,800) unpruned, BP-10 tanh via state passing", lambda: _WeightedBPUntrained(k=400, n=800),
+          np.arange(0, 4, 0.25), bits_per_block=400, work=800 * 40, group="state", cite="cell 26"),
     # --- Sionna_tutorial_part3.ipynb cells 40/41 (1x4 SIMO uplink CDL-C, 100 block errors per point)
     Curve("Sionna_tutorial_part3/c41/t0", "1x4 uplink CDL-C 10 m/s, LS-NN CSI, LMMSE, QPSK LDPC(912,1824)", lambda: _Part3Ofdm(False),
           np.linspace(-8, 3, 20), bits_per_block=912, group="cdl", max_batch=8192, cite="cell 41"),

@@ -32,8 +32,13 @@ KNOWN_MISS = {"MIMO_OFDM_Transmissions_over_CDL/c76/t3"}
 
 
 def _params():
-    return [pytest.param(c, id=c.key, marks=[pytest.mark.xfail(reason="ISI-limited floor differs from the saved notebook table", strict=False)]
-                         if c.key in KNOWN_MISS else []) for c in nc.CURVES]
+    seen = {}
+    ids = []
+    for c in nc.CURVES:
+        seen[c.key] = seen.get(c.key, 0) + 1
+        ids.append(c.key if seen[c.key] == 1 else f"{c.key}#{seen[c.key]}")
+    return [pytest.param(c, id=i, marks=[pytest.mark.xfail(reason="ISI-limited floor differs from the saved notebook table", strict=False)]
+                         if c.key in KNOWN_MISS else []) for c, i in zip(nc.CURVES, ids)]
 
 
 @pytest.mark.parametrize("curve", _params())

@@ -60,7 +60,7 @@ def main():
         res = nc.evaluate(c, ref, ours)
         res.update(name=c.name, cite=c.cite, seconds=time.perf_counter() - t0, ours=ours,
                    reference=[{k: r[k] for k in ("ber", "bler", "bit_errors", "num_bits", "block_errors", "num_blocks")} for r in ref])
-        doc["curves"][c.key] = res
+        doc["curves"][c.key if c.key not in doc["curves"] else c.key + "#" + c.group] = res
         n_all += 1
         n_ok += bool(res["ok"])
         cr = "  ".join(f"{k}: {v['delta_db']:+.3f} dB (tol {v['tol_db']:.3f})" for k, v in res["crossings"].items())
