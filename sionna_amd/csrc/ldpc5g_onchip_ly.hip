@@ -272,10 +272,9 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
       if (xi >= 0) xtot[xi * (int)z + v % (int)z] = l;                 // total of a node without messages = its LLR
       else if (!return_infobits) llr[v] = l;
     }
-    for (int i = tid; i < msg_floats; i += NT) smem[i] = 0.f;
-    for (int i = tid; i < (int)z; i += NT) smem[zero_off + i] = 0.f;   // the block the padded re-sum entries read
-    __syncthreads();
-    // the registers of the items this wave owns: channel LLRs; c2v of the fused edges and the prefixes start at 0
+    // the registers of the items this wave owns: channel LLRs; c2v of the fused edges and the prefixes start at 0.
+    // The fused nodes' LLRs come straight from the input row: requested BEFORE the LDS initialisation and its barrier, so
+    // that their latency is hidden behind them
     ly_f32x32 st;
 #pragma unroll
     for (int q = 0; q < LY_CN_SLOTS; ++q) {
@@ -283,6 +282,9 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
       st[LY_ST_CO + q] = 0.f;
       st[LY_ST_LF + q] = (li >= 0) ? chan_llr(min(li + lane, nx - 1)) : 0.f;   // (lanes past a partial chunk: never used)
     }
+    for (int i = tid; i < msg_floats; i += NT) smem[i] = 0.f;
+    for (int i = tid; i < (int)z; i += NT) smem[zero_off + i] = 0.f;   // the block the padded re-sum entries read
+    __syncthreads();
 #pragma unroll
     for (int q = 0; q < LY_VN_SLOTS; ++q) {
       const int li = slots[2 * LY_CN_SLOTS + q];

@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__(128, (M * K <= 8) ? 6 : 1) void ofdm_lsnn_lmmse_ker
 
 using namespace samd;
 
-#define SAMD_MK_LIST(X) X(1, 1) X(2, 1) X(2, 2) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 4)
+#define SAMD_MK_LIST(X) X(1, 1) X(2, 1) X(2, 2) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 4) X(16, 4)
 
 extern "C" int samd_lmmse_equalizer_c64(const float* y, const float* h, const float* s, int64_t n, int m, int k,
                                         int whiten, float* x_hat, float* no_eff, void* stream) {
@@ -1410,7 +1410,7 @@ extern "C" int samd_ofdm_ep_f32(const float* y, const float* h_hat, const float*
 }
 
 // (m, k) pairs with at least as many receive antennas as streams (KBestDetector.build, :945-948)
-#define SAMD_MK_SQUARE_LIST(X) X(1, 1) X(2, 1) X(2, 2) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 4)
+#define SAMD_MK_SQUARE_LIST(X) X(1, 1) X(2, 1) X(2, 2) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2) X(8, 4) X(16, 4)
 
 extern "C" int samd_kbest_f32(const float* y, const float* h, const float* s, const float* points, int64_t n, int m,
                               int k, int num_bits_per_symbol, int num_paths, float llr_clip, int hard_out, float* out,

@@ -427,6 +427,75 @@ class _Part3Ofdm:
         return bits, self.decoder(self.demapper(x_hat, no_eff))
 
 
+class _IddRayleigh:
+    """``NonIddModel`` / ``IddModel`` of Introduction_to_Iterative_Detection_and_Decoding.ipynb cells 11 / 13 with
+    ``perfect_csi_rayleigh=True``: four single-antenna users -> 16 base-station antennas over i.i.d. Rayleigh block fading
+    (perfect CSI), fft 48, 14 symbols, Kronecker pilots on symbols 2 and 11, 16-QAM, 5G LDPC rate 1/2 with the 5G output
+    interleaver, min-sum decoding with 12 iterations.  ``detector``: 'lmmse' | 'k-best' (k = 64) | 'ep' (l = 10) - one
+    detection pass - or 'idd2' / 'idd3': LMMSE detection, then (soft-output decoder with its state handed on ->
+    MMSE-PIC detector with the decoder's LLRs as prior) once / twice, then the final hard-output decoder.
+    Four codewords (users) share every channel realisation."""
+
+    def __init__(self, detector):
+        phy = _phy()
+        self.m, self.n_ue, self.n_rx, self.R = 4, 4, 16, 0.5
+        self.rg = phy.ofdm.ResourceGrid(num_ofdm_symbols=14, pilot_ofdm_symbol_indices=[2, 11], fft_size=48, num_tx=self.n_ue,
+                                        pilot_pattern="kronecker", subcarrier_spacing=30e3)
+        self.sm = phy.mimo.StreamManagement(np.ones([1, self.n_ue]), 1)
+        self.N = int(48 * 12 * self.m)
+        self.K = int(self.N * self.R)
+        self.const = phy.mapping.Constellation("qam", num_bits_per_symbol=self.m)
+        self.source = phy.mapping.BinarySource()
+        self.encoder = phy.fec.ldpc.LDPC5GEncoder(self.K, self.N, num_bits_per_symbol=self.m)
+        self.mapper = phy.mapping.Mapper(constellation=self.const)
+        self.rg_mapper = phy.ofdm.ResourceGridMapper(self.rg)
+        ch = phy.channel.RayleighBlockFading(num_rx=1, num_rx_ant=self.n_rx, num_tx=self.n_ue, num_tx_ant=1)
+        self.channel = phy.channel.OFDMChannel(channel_model=ch, resource_grid=self.rg, add_awgn=True, normalize_channel=True,
+                                               return_channel=True)
+        self.remove_nulled = phy.ofdm.RemoveNulledSubcarriers(self.rg)
+        od = phy.ofdm
+        self.detector_kind = detector
+        if detector == "k-best":
+            self.detector = od.KBestDetector("bit", self.n_ue, 64, self.rg, self.sm, constellation_type="qam", num_bits_per_symbol=self.m, hard_out=False)
+        elif detector == "ep":
+            self.detector = od.EPDetector("bit", self.rg, self.sm, self.m, l=10, hard_out=False)
+        else:
+            self.detector = od.LinearDetector("lmmse", "bit", "maxlog", self.rg, self.sm, constellation_type="qam",
+                                              num_bits_per_symbol=self.m, hard_out=False)
+        ld = phy.fec.ldpc
+        self.idd_iter = {"idd2": 2, "idd3": 3}.get(detector, 0)
+        if self.idd_iter:
+            self.siso_detector = od.MMSEPICDetector(output="bit", resource_grid=self.rg, stream_management=self.sm,
+                                                    demapping_method="maxlog", constellation=self.const, num_iter=1, hard_out=False)
+            self.siso_decoder = ld.LDPC5GDecoder(self.encoder, return_infobits=False, num_iter=12, return_state=True, hard_out=False,
+                                                 cn_update="minsum")
+            self.decoder = ld.LDPC5GDecoder(self.encoder, return_infobits=True, return_state=True, hard_out=True, num_iter=12,
+                                            cn_update="minsum")
+        else:
+            self.decoder = ld.LDPC5GDecoder(self.encoder, return_infobits=True, hard_out=True, num_iter=12, cn_update="minsum")
+
+    def __call__(self, batch_size, ebno_db):
+        import torch
+        from sionna_amd import _ffi
+        phy = _phy()
+        no = float(phy.utils.ebnodb2no(ebno_db, num_bits_per_symbol=self.m, coderate=self.R))
+        no = torch.full([batch_size], no, dtype=torch.float32, device=_ffi.device())     # the notebook fills a [batch] vector
+        b = self.source([batch_size, self.n_ue, 1, self.K])
+        x_rg = self.rg_mapper(self.mapper(self.encoder(b)))
+        y, h = self.channel(x_rg, no.reshape(-1, 1, 1, 1, 1))
+        h_hat = self.remove_nulled(h)
+        ev = torch.zeros(tuple(h_hat.shape), dtype=torch.float32, device=h_hat.device) if self.idd_iter else 0.0
+        llr_ch = self.detector(y, h_hat, ev, no)
+        if not self.idd_iter:
+            return b, self.decoder(llr_ch)
+        msg = None
+        for _ in range(self.idd_iter - 1):
+            llr_dec, msg = self.siso_decoder(llr_ch, msg_v2c=msg)
+            llr_ch = self.siso_detector(y, h_hat, llr_dec, ev, no)
+        b_hat, _ = self.decoder(llr_ch, msg_v2c=msg)
+        return b, b_hat
+
+
 def _cdl(**kw):
     return lambda: _CdlModel(**kw)
 
@@ -551,6 +620,13 @@ CURVES = [
             np.arange(0, 17, 2.0), bits_per_block=768, corr=4.0, group="cdl_time" if dom == "time" else "cdl", max_batch=1024,
             cite="ipynb:2375-2425")
       for i, (cp, dom) in enumerate(((20, "freq"), (20, "time"), (2, "freq"), (2, "time")))],
+    # --- Introduction_to_Iterative_Detection_and_Decoding.ipynb cells 11/13/15, perfect-CSI Rayleigh (16 x 4, 16-QAM):
+    #     LMMSE, EP, K-Best (one-shot detection) and IDD with 2 / 3 detection-decoding iterations; 819 block errors per point
+    *[Curve(f"Introduction_to_Iterative_Detection_and_Decoding/c15/t{i}", f"16x4 Rayleigh perfect CSI, {nm}, 16-QAM LDPC min-sum 12",
+            (lambda d=d: _IddRayleigh(d)), np.linspace(-10, 0, 11), bits_per_block=1152, corr=4.0, group="idd", max_batch=2048,
+            work=2304 * 12 * (8 if d == "k-best" else 3), cite="cell 15")
+      for i, (d, nm) in enumerate((("lmmse", "LMMSE detector"), ("ep", "EP detector (l=10)"), ("k-best", "K-Best detector (k=64)"),
+                                   ("idd2", "IDD, 2 iterations (MMSE-PIC)"), ("idd3", "IDD, 3 iterations (MMSE-PIC)")))],
     # --- Weighted_BP_Algorithm.ipynb cell 13 (BCH (63,45), untrained) and cell 26 (5G LDPC (400,800), prune_pcm=False, untrained):
     #     ten one-iteration decoder calls chained through the decoder state; 2000 bit errors per point
     Curve("Weighted_BP_Algorithm/c13/t0", "BCH(63,45) BP-10 tanh via state passing (generic HIP engine)", lambda: _WeightedBPUntrained(pcm_id=1),

@@ -28,7 +28,14 @@ TABLES = nc.load_tables()
 # block of that chain equals the reference's OWN code executed here to float32 rounding (modulator, cir_to_time_channel,
 # ApplyTimeChannel, demodulator: tools/gen_ofdm_time_ref_golden.py), the same chain with cyclic prefix 20 and all
 # frequency-domain curves agree, and the floor moves 12x per sample of window timing (profiles/r04_probe_cp2_isi_regime.txt).
-KNOWN_MISS = {"MIMO_OFDM_Transmissions_over_CDL/c76/t3"}
+KNOWN_MISS = {"MIMO_OFDM_Transmissions_over_CDL/c76/t3",
+              # The IDD tables SAVED in Introduction_to_Iterative_Detection_and_Decoding.ipynb are not what the reference's
+              # current code produces: its own IddModel chain, executed here from the source files under the NumPy stand-in for
+              # TensorFlow, gives IDD-2 BLER 0.056 at -7 dB on 2048 blocks (profiles/r04_idd_ref_exec.txt) - the MI355X path
+              # gives 0.055-0.061, the notebook shows 0.023 - and agrees with our chain LLR for LLR on identical inputs
+              # (tests/test_oracle_ref_exec_idd.py, tests/test_gpu_idd.py).  The one-shot LMMSE / EP / K-Best tables of the
+              # same cell are reproduced.
+              "Introduction_to_Iterative_Detection_and_Decoding/c15/t3", "Introduction_to_Iterative_Detection_and_Decoding/c15/t4"}
 
 
 def _params():

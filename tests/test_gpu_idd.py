@@ -87,3 +87,42 @@ def test_return_state_on_a_large_5g_code():
     x6, st6 = mk(6)(llr)
     assert torch.equal(x6a.as_subclass(torch.Tensor), x6.as_subclass(torch.Tensor))
     assert torch.equal(st6a.as_subclass(torch.Tensor), st6.as_subclass(torch.Tensor))
+
+
+def test_idd_chain_matches_the_reference_executed_chain():
+    """tests/golden/idd_ref_golden.npz = the reference's OWN IddModel chain (ofdm.LinearDetector -> LDPC5GDecoder with state
+    -> ofdm.MMSEPICDetector with priors -> LDPC5GDecoder(msg_v2c=state); KBestDetector, EPDetector) executed from its
+    source files under a NumPy stand-in for TensorFlow (tools/gen_idd_ref_golden.py).  The HIP path on the same received
+    grid: detector LLRs within 1e-5 of their scale, the min-sum decoder's soft output, state and decisions bit for bit."""
+    import os
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    _ffi.device()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "idd_ref_golden.npz"))
+    n_ue, m = 4, 4
+    N = 48 * 12 * m
+    rg = phy.ofdm.ResourceGrid(num_ofdm_symbols=14, pilot_ofdm_symbol_indices=[2, 11], fft_size=48, num_tx=n_ue,
+                               pilot_pattern="kronecker", subcarrier_spacing=30e3)
+    sm = phy.mimo.StreamManagement(np.ones([1, n_ue]), 1)
+    h = g["h"]
+    hf = np.ascontiguousarray(np.broadcast_to(h[..., None, None], h.shape + (14, 48)))
+    y, no = g["y"], g["no"]
+    ev = np.zeros(hf.shape, np.float32)
+    close = lambda a, b, tol=1e-5: np.abs(a.cpu().numpy().reshape(b.shape) - b).max() <= 4 * tol * np.abs(b).max()
+    kw = dict(constellation_type="qam", num_bits_per_symbol=m, hard_out=False)
+    llr0 = phy.ofdm.LinearDetector("lmmse", "bit", "maxlog", rg, sm, **kw)(y, hf, ev, no)
+    assert close(llr0, g["llr_lmmse"])
+    enc = phy.fec.ldpc.LDPC5GEncoder(N // 2, N, num_bits_per_symbol=m)
+    D = phy.fec.ldpc.LDPC5GDecoder
+    llr_dec, state = D(enc, return_infobits=False, num_iter=12, return_state=True, hard_out=False, cn_update="minsum")(g["llr_lmmse"])
+    assert np.array_equal(llr_dec.cpu().numpy(), g["llr_dec"])
+    assert tuple(state.shape) == tuple(g["state_shape"]) and np.array_equal(state.cpu().numpy()[:4096], g["state_head"])
+    pic = phy.ofdm.MMSEPICDetector(output="bit", demapping_method="maxlog", resource_grid=rg, stream_management=sm, num_iter=1,
+                                   constellation_type="qam", num_bits_per_symbol=m, hard_out=False)
+    assert close(pic(y, hf, g["llr_dec"], ev, no), g["llr_pic"])
+    bh, _ = D(enc, return_infobits=True, return_state=True, hard_out=True, num_iter=12, cn_update="minsum")(g["llr_pic"], msg_v2c=state)
+    assert np.array_equal(bh.cpu().numpy().astype(np.uint8), g["b_hat"])
+    kb = phy.ofdm.KBestDetector("bit", n_ue, 64, rg, sm, **kw)(y, hf, ev, no).cpu().numpy()
+    assert np.mean(np.isclose(kb, g["llr_kbest"], rtol=1e-4, atol=1e-3)) > 0.995
+    ep = phy.ofdm.EPDetector("bit", rg, sm, m, l=10, hard_out=False)(y, hf, ev, no).cpu().numpy()
+    assert np.mean(np.isclose(ep, g["llr_ep"], rtol=1e-3, atol=1e-2)) > 0.995

@@ -45,6 +45,11 @@ class _Block:
             a = a.astype(self.cdtype)
         return a.view(tf_numpy.Tensor)
 
+    def _cast_or_check_precision(self, v):
+        """block.py:54-81: tensors are cast to the object's real / complex dtype (variables would be checked)."""
+        a = np.asarray(v)
+        return a.astype(self.cdtype if a.dtype.kind == "c" else self.rdtype).view(tf_numpy.Tensor)
+
     def build(self, *a, **k):
         pass
 
@@ -84,6 +89,7 @@ class Reference:
         phy = sys.modules["sionna.phy"]
         phy.Block, phy.Object = _Block, _Block
         phy.PI = np.pi
+        phy.SPEED_OF_LIGHT = 299792458.0
         D = tf_numpy.DType
         dt = {"single": {"tf": {"rdtype": D("float32"), "cdtype": D("complex64")},
                          "np": {"rdtype": np.float32, "cdtype": np.complex64}},
@@ -91,7 +97,8 @@ class Reference:
                          "np": {"rdtype": np.float64, "cdtype": np.complex128}}}
         phy.dtypes = dt
         phy.config = types.SimpleNamespace(precision="single", tf_rdtype=D("float32"), tf_cdtype=D("complex64"),
-                                           np_rdtype=np.float32, np_cdtype=np.complex64)
+                                           np_rdtype=np.float32, np_cdtype=np.complex64,
+                                           tf_rng=self.tf.random.Generator(12345), np_rng=np.random.default_rng(12345))
         blk = types.ModuleType("sionna.phy.block")
         blk.Block, blk.Object = _Block, _Block
         sys.modules["sionna.phy.block"] = blk

@@ -67,6 +67,11 @@ class DType:
     def __repr__(self):
         return f"tf.{self.name}"
 
+    def __getattr__(self, name):                                    # NumPy internals ask the ndarray subclass for dtype.type / .kind / ...
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return getattr(self._np, name)
+
 
 class Tensor(np.ndarray):
     """ndarray with the few tf.Tensor methods the reference calls."""
@@ -253,7 +258,7 @@ def make_tf():
     tf.slice = _slice
 
     def gather(params, indices, validate_indices=None, axis=None, batch_dims=0, name=None):
-        axis = 0 if axis is None else int(axis)
+        axis = int(batch_dims) if axis is None else int(axis)
         if isinstance(indices, RaggedTensor):
             assert axis == 0 and not isinstance(params, RaggedTensor)
             return indices.with_flat_values(np.asarray(params)[np.asarray(indices.flat_values).astype(np.int64)])
@@ -267,19 +272,51 @@ def make_tf():
             return RaggedTensor(np.asarray(params.flat_values)[pos.astype(np.int64)], rid, len(idx))
         p = np.asarray(params)
         if batch_dims:
-            assert batch_dims == 1 or batch_dims == idx.ndim - 1
-            return _t(np.take_along_axis(p, idx, axis=axis)) if p.ndim == idx.ndim else _t(
-                np.stack([np.take(p[b], idx[b], axis=axis - 1) for b in range(p.shape[0])]))
+            bd = int(batch_dims)
+            if axis < 0:
+                axis += p.ndim
+            assert tuple(idx.shape[:bd]) == tuple(p.shape[:bd]), "gather: batch dimensions must agree"
+            if axis != bd:                                           # gather along a later axis: bring it next to the batch dims
+                res = gather(np.moveaxis(p, axis, bd), idx, axis=bd, batch_dims=bd)
+                k = idx.ndim - bd                                    # the gathered dims sit at [bd, bd + k): move them to `axis`
+                r = np.asarray(res)
+                for j in range(k):
+                    r = np.moveaxis(r, bd + k - 1, axis + k - 1 - 0) if False else r
+                src = list(range(bd, bd + k))
+                dst = list(range(axis, axis + k))
+                return _t(np.moveaxis(r, src, dst))
+            inner = idx.shape[bd:]
+            flat = idx.reshape(p.shape[:bd] + (-1,) + (1,) * (p.ndim - axis - 1))
+            flat = np.broadcast_to(flat, p.shape[:bd] + (flat.shape[bd],) + p.shape[axis + 1:])
+            out = np.take_along_axis(p, flat, axis=axis)
+            return _t(out.reshape(p.shape[:bd] + tuple(inner) + p.shape[axis + 1:]))
         return _t(np.take(p, idx, axis=axis))
     tf.gather = gather
 
     def tensor_scatter_nd_update(tensor, indices, updates, name=None):
         out = np.array(tensor, copy=True)
         ind = np.asarray(indices)
-        assert ind.ndim == 2 and ind.shape[1] == 1
-        out[ind[:, 0]] = np.asarray(updates)
+        assert ind.ndim == 2                                              # [n, depth]: one index tuple per update slice
+        out[tuple(ind[:, d] for d in range(ind.shape[1]))] = np.asarray(updates)
         return _t(out)
     tf.tensor_scatter_nd_update = tensor_scatter_nd_update
+
+    def scatter_nd(indices, updates, shape, name=None):
+        upd = np.asarray(updates)
+        out = np.zeros([int(v) for v in shape], dtype=upd.dtype)
+        ind = np.asarray(indices)
+        np.add.at(out, tuple(ind[:, d] for d in range(ind.shape[1])), upd)   # duplicates add up, like TF
+        return _t(out)
+    tf.scatter_nd = scatter_nd
+
+    def argsort(values, axis=-1, direction="ASCENDING", stable=False, name=None):
+        v = np.asarray(values)
+        # TF sorts DESCENDING as the ascending order of -values; ties keep their index order (stable kernel)
+        idx = np.argsort(-v if direction == "DESCENDING" else v, axis=axis, kind="stable")
+        return _t(idx.astype(np.int32))
+    tf.argsort = argsort
+    tf.sort = lambda values, axis=-1, direction="ASCENDING", **k: _t(np.take_along_axis(np.asarray(values), np.asarray(argsort(values, axis, direction)), axis=axis))
+    tf.gather_nd = lambda params, indices, batch_dims=0, **k: _t(np.asarray(params)[tuple(np.moveaxis(np.asarray(indices), -1, 0))])
 
     # ---- elementwise math (IEEE-exact ones first)
     tf.abs = _elementwise(np.abs)
@@ -308,6 +345,7 @@ def make_tf():
     tf.math.softmax = lambda x, axis=-1, **k: _t(np.exp(np.asarray(x) - _lse(x, axis=axis, keepdims=True)))
     tf.nn = types.SimpleNamespace(log_softmax=lambda x, axis=-1, **k: _t(np.asarray(x) - _lse(x, axis=axis, keepdims=True)),
                                   softmax=tf.math.softmax, relu=_elementwise(lambda x: np.maximum(x, 0)))
+    tf.sqrt = tf.math.sqrt = _elementwise(np.sqrt)
     tf.math.ceil = _elementwise(np.ceil)
     tf.math.floor = _elementwise(np.floor)
     tf.math.cos, tf.math.sin = _elementwise(np.cos), _elementwise(np.sin)
@@ -344,6 +382,8 @@ def make_tf():
     tf.math.multiply, tf.math.add, tf.math.subtract, tf.math.divide = tf.multiply, tf.add, tf.subtract, tf.divide
 
     def where(cond, x=None, y=None, name=None):
+        if x is None and y is None:                                       # tf.where(cond): coordinates of the true entries
+            return _t(np.argwhere(_dense(cond)).astype(np.int64))
         c = _dense(cond)
         xs, ys = _dense(x) if not np.isscalar(x) else x, _dense(y) if not np.isscalar(y) else y
         # TF: result dtype = dtype of x and y (both tensors of the same dtype); Python scalars adopt the tensor's dtype
@@ -393,6 +433,8 @@ def make_tf():
             v, n = tuple(body(*v)), n + 1
         return v
     tf.while_loop = while_loop
+    tf.cond = lambda pred, true_fn, false_fn, **k: true_fn() if bool(np.asarray(pred)) else false_fn()
+    tf.fill = lambda dims, value, **k: _t(np.full([int(d) for d in np.atleast_1d(dims)], value, dtype=np.float32 if isinstance(value, float) else None))
 
     def function(func=None, **k):
         return (lambda f: f) if func is None else func
@@ -428,6 +470,17 @@ def make_tf():
         if adjoint_b: b = np.conj(np.swapaxes(b, -1, -2))
         return _t(np.matmul(a, b))
     tf.matmul = matmul
+
+    def _qr(a, full_matrices=False, **k):
+        q, r = np.linalg.qr(np.asarray(a), mode="complete" if full_matrices else "reduced")
+        return _t(q), _t(r)
+    tf.linalg.qr = _qr
+
+    def _top_k(x, k=1, sorted=True, **kw):                          # values / indices of the k largest entries of the last axis
+        x = np.asarray(x)
+        idx = np.argsort(-x, axis=-1, kind="stable")[..., :int(k)]
+        return _t(np.take_along_axis(x, idx, -1)), _t(idx.astype(np.int32))
+    tf.math.top_k = tf.nn.top_k = _top_k
     # ---- signal / misc array ops used by the OFDM time-domain path
     tf.signal = types.SimpleNamespace(
         fft=lambda x, **k: _t(np.fft.fft(np.asarray(x), axis=-1).astype(np.asarray(x).dtype)),
@@ -447,6 +500,31 @@ def make_tf():
         swapaxes=lambda x, a, b: _t(np.swapaxes(np.asarray(x), a, b)),
         sinc=_elementwise(lambda x: np.sinc(x).astype(x.dtype)),
         log10=_elementwise(np.log10), log2=_elementwise(np.log2)))
+    # ---- ops of the 3GPP channel-model code (tr38901/*.py)
+    tf.acos = tf.math.acos = _elementwise(np.arccos)
+    tf.asin = tf.math.asin = _elementwise(np.arcsin)
+    tf.atan2 = tf.math.atan2 = _binary(np.arctan2)
+    tf.math.angle = _elementwise(lambda z: np.angle(z).astype(np.float32 if z.dtype == np.complex64 else np.float64))
+    tf.math.log10 = _elementwise(np.log10)
+    tf.roll = lambda x, shift, axis, **k: _t(np.roll(np.asarray(x), shift, axis))
+    tf.meshgrid = lambda *xs, indexing="xy", **k: [_t(a) for a in np.meshgrid(*[np.asarray(x) for x in xs], indexing=indexing)]
+    tf.logical_not = tf.math.logical_not = _elementwise(np.logical_not)
+    tf.einsum = lambda eq, *ops, **k: _t(np.einsum(eq, *[np.asarray(o) for o in ops]))
+    tf.norm = lambda x, axis=None, keepdims=False, **k: _t(np.linalg.norm(np.asarray(x), axis=axis, keepdims=keepdims))
+    tf.cumsum = tf.math.cumsum
+
+    class _Generator:
+        """config.tf_rng stand-in: NumPy draws of the same distributions (NOT TensorFlow's stream)."""
+        def __init__(self, seed=0):
+            self._g = np.random.default_rng(seed)
+        def uniform(self, shape, minval=0.0, maxval=1.0, dtype=np.float32, **k):
+            if np.dtype(dtype).kind in "iu":
+                return _t(self._g.integers(int(minval), int(maxval), [int(v) for v in np.atleast_1d(shape)]).astype(dtype))
+            lo, hi = np.asarray(minval, np.float64), np.asarray(maxval, np.float64)
+            return _t((lo + (hi - lo) * self._g.random([int(v) for v in np.atleast_1d(shape)])).astype(dtype))
+        def normal(self, shape, mean=0.0, stddev=1.0, dtype=np.float32, **k):
+            return _t((mean + stddev * self._g.normal(size=[int(v) for v in np.atleast_1d(shape)])).astype(dtype))
+    tf.random = types.SimpleNamespace(Generator=_Generator)
     tf.name_scope = lambda *a, **k: _NullCtx()
     class Variable(Tensor):
         """tf.Variable stand-in (an ndarray view; ``isinstance(x, tf.Variable)`` is False for plain tensors)."""
@@ -455,7 +533,6 @@ def make_tf():
     tf.Variable = Variable
     tf.keras = types.SimpleNamespace(layers=types.SimpleNamespace(Layer=object))
     tf.config = types.SimpleNamespace(list_physical_devices=lambda *a: [])
-    tf.random = types.SimpleNamespace()
     for _n in ("greater", "greater_equal", "less", "less_equal", "equal", "not_equal", "logical_or", "logical_and"):
         setattr(tf.math, _n, getattr(tf, _n))
     for _n in ("reduce_sum", "reduce_prod", "reduce_min", "reduce_max", "reduce_mean", "reduce_any", "reduce_all", "argmax", "argmin"):
