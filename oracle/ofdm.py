@@ -274,7 +274,7 @@ def nn_gather_ind(pp):
 
 def ls_estimate(rg, y, no, interpolation="nn"):
     """BaseChannelEstimator.call + LSChannelEstimator (channel_estimation.py:138-173, 257-285).
-    y [B,rx,ra,T,fft]; no scalar.  Returns h_hat [B,rx,ra,tx,s,T,Feff], err_var broadcastable."""
+    y [B,rx,ra,T,fft]; no scalar or per example.  Returns h_hat [B,rx,ra,tx,s,T,Feff], err_var broadcastable."""
     pp = rg.pilot_pattern
     y_eff = remove_nulled(rg, y)
     y_flat = y_eff.reshape(y_eff.shape[:-2] + (-1,))
@@ -284,8 +284,12 @@ def ls_estimate(rg, y, no, interpolation="nn"):
     pil = pp.pilots
     with np.errstate(divide="ignore", invalid="ignore"):
         h_ls = np.where(pil != 0, y_p / np.where(pil != 0, pil, 1), 0).astype(np.complex64)
-        ev = np.where(pil != 0, np.float32(no) / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(np.float32)
-    ev = ev[None, None, None]
+        # no: scalar or [B] / [B,rx] / [B,rx,ra], expanded at the end to the rank of h_ls (channel_estimation.py:270-276)
+        no_ = np.asarray(no, np.float32)
+        no_ = no_.reshape(no_.shape + (1,) * (h_ls.ndim - no_.ndim))
+        ev = np.where(pil != 0, no_ / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(np.float32)
+    if ev.ndim < h_ls.ndim:
+        ev = ev[None, None, None]
     if interpolation is None:
         return h_ls, ev
     g = nn_gather_ind(pp)                                               # [tx,s,T,F]

@@ -986,3 +986,59 @@ def test_tdl_spatial_correlation(phy):
     cov = (v.T @ v.conj()) / 20000
     cov = cov / np.real(np.trace(cov)) * (ra * ta)
     assert np.allclose(cov, r_full, atol=0.06)
+
+
+@pytest.mark.parametrize("name", ["c4", "cdl"])
+def test_receiver_front_end_matches_reference_execution(phy, name):
+    """The HIP blocks against outputs of the reference's OWN ResourceGridMapper / RemoveNulledSubcarriers /
+    LSChannelEstimator ("nn", "lin", "lin_time_avg") / LMMSE, ZF, MF equalizers / LinearDetector / MMSEPICDetector /
+    KBestDetector / EPDetector code with ESTIMATED channel state (tests/golden/ofdm_rx_ref_golden.npz,
+    tools/gen_ofdm_rx_ref_golden.py): guard carriers, DC null, error variance > 0, per-example noise variance.  Bars as
+    in tests/test_oracle_ref_exec_ofdm_rx.py (the oracle's twin of this test)."""
+    L = {"c4": dict(fft=76, guards=(3, 4), num_tx=2, spt=1, m=4, kbest=16), "cdl": dict(fft=72, guards=(5, 6), num_tx=1, spt=4, m=2, kbest=32)}[name]
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ofdm_rx_ref_golden.npz"))
+    g = {k.split("/", 1)[1]: gold[k] for k in gold.files if k.startswith(name + "/")}
+    rg = phy.ofdm.ResourceGrid(14, L["fft"], 15e3, num_tx=L["num_tx"], num_streams_per_tx=L["spt"], cyclic_prefix_length=6,
+                               num_guard_carriers=list(L["guards"]), dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    assert np.array_equal(rg.pilot_pattern.mask, g["mask"].astype(bool))
+    rg.pilot_pattern.pilots = g["pilots"]
+    sm = phy.mimo.StreamManagement(np.ones([1, L["num_tx"]]), L["spt"])
+    m = L["m"]
+
+    def close(a, b, tol=1e-5):
+        a = _np(a) if isinstance(a, torch.Tensor) else np.asarray(a)
+        a, b = np.broadcast_arrays(a, b) if a.ndim == b.ndim else (a.reshape(b.shape), b)
+        return np.abs(a - b).max() <= 4 * tol * np.abs(b).max()
+
+    def rel(a, b, floor):
+        a = _np(a).reshape(b.shape)
+        return np.abs(a - b) / np.maximum(np.abs(b), floor)
+
+    x = phy.mapping.Mapper("qam", m)(g["b"].astype(np.float32))
+    assert np.array_equal(_np(phy.ofdm.ResourceGridMapper(rg)(x)), g["x_rg"])
+    y, no = g["y"], g["no"]
+    assert np.array_equal(_np(phy.ofdm.RemoveNulledSubcarriers(rg)(y)), g["removed"])
+    for it in ("nn", "lin", "lin_time_avg"):
+        h, ev = phy.ofdm.LSChannelEstimator(rg, interpolation_type=it)(y, no)
+        assert close(h, g[f"h_hat_{it}"]) and close(ev, g[f"err_var_{it}"]), it
+    hh, ev = g["h_hat_lin"], g["err_var_lin"]
+    for kind, cls in (("lmmse", phy.ofdm.LMMSEEqualizer), ("mf", phy.ofdm.MFEqualizer)):
+        xh, ne = cls(rg, sm)(y, hh, ev, no)
+        assert close(xh, g[f"x_hat_{kind}"], 2e-5) and close(ne, g[f"no_eff_{kind}"], 2e-5), kind
+    xh, ne = phy.ofdm.ZFEqualizer(rg, sm)(y, hh, ev, no)                    # (conditioning: see the oracle's twin)
+    for a, b in ((xh, g["x_hat_zf"]), (ne, g["no_eff_zf"])):
+        r = rel(a, b, 1e-3 * np.abs(b).max())
+        assert r.max() < 4e-3 and np.quantile(r, 0.99) < 2e-4, (r.max(), np.quantile(r, 0.99))
+    kw = dict(constellation_type="qam", num_bits_per_symbol=m, hard_out=False)
+    for meth in ("app", "maxlog"):
+        assert close(phy.ofdm.LinearDetector("lmmse", "bit", meth, rg, sm, **kw)(y, hh, ev, no), g[f"llr_lmmse_{meth}"], 4e-5), meth
+    r = rel(phy.ofdm.LinearDetector("zf", "bit", "maxlog", rg, sm, **kw)(y, hh, ev, no), g["llr_zf_maxlog"], 1e-2 * np.abs(g["llr_zf_maxlog"]).max())
+    assert r.max() < 1e-2 and np.quantile(r, 0.99) < 4e-4, (r.max(), np.quantile(r, 0.99))
+    for meth in ("app", "maxlog"):
+        pic = phy.ofdm.MMSEPICDetector(output="bit", demapping_method=meth, resource_grid=rg, stream_management=sm, num_iter=2,
+                                       constellation_type="qam", num_bits_per_symbol=m, hard_out=False)
+        assert close(pic(y, hh, g["prior"], ev, no), g[f"llr_pic_{meth}"], 1e-4), meth
+    kb = _np(phy.ofdm.KBestDetector("bit", L["num_tx"] * L["spt"], L["kbest"], rg, sm, **kw)(y, hh, ev, no))
+    assert np.mean(np.isclose(kb.reshape(g["llr_kbest"].shape), g["llr_kbest"], rtol=1e-4, atol=1e-3)) > 0.99
+    r = rel(phy.ofdm.EPDetector("bit", rg, sm, m, l=6, hard_out=False)(y, hh, ev, no), g["llr_ep"], 1.0)
+    assert r.max() < 2e-2 and np.quantile(r, 0.5) < 1e-3, (r.max(), np.quantile(r, 0.5))

@@ -1,0 +1,109 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ofdm_rx_ref_golden.npz by EXECUTING the reference's own OFDM receiver front end under the NumPy
+stand-in for TensorFlow (tools/ref_exec): with ESTIMATED channel state (error variance > 0), guard carriers, a nulled DC
+carrier and several streams per transmitter - the regime tests/golden/idd_ref_golden.npz (perfect CSI) does not reach.
+
+    ofdm/resource_grid.py        ResourceGrid :16-497, ResourceGridMapper :500-601, RemoveNulledSubcarriers :700-750
+    ofdm/pilot_pattern.py        KroneckerPilotPattern
+    ofdm/channel_estimation.py   LSChannelEstimator :175-435 with NearestNeighborInterpolator :326-435 and
+                                 LinearInterpolator :437-733 ("nn", "lin", "lin_time_avg")
+    ofdm/equalization.py         LMMSEEqualizer / ZFEqualizer / MFEqualizer on OFDMEqualizer :18-249
+    ofdm/detection.py            LinearDetector ("app", "maxlog"), KBestDetector, EPDetector, MMSEPICDetector with priors
+
+Two links: "c4" = 2 single-stream transmitters -> 4 antennas, fft 76 (config C4's grid, here with guards 3 / 4 and DC
+null), per-example noise variance; "cdl" = 1 transmitter with 4 streams -> 4 antennas, fft 72, guards 5 / 6, DC null (the
+grid of MIMO_OFDM_Transmissions_over_CDL.ipynb).  The received grid is complex Gaussian noise plus a random channel applied
+to mapped symbols; pilots are QPSK from a NumPy generator (stored).  Run here (needs /root/reference); the fixture travels."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tests", "golden", "ofdm_rx_ref_golden.npz")
+
+LINKS = {   # name: (fft, guards, num_tx, streams per tx, rx antennas, batch, bits per symbol, K-Best list size)
+    "c4": dict(fft=76, guards=(3, 4), num_tx=2, spt=1, n_rx=4, batch=2, m=4, kbest=16),
+    "cdl": dict(fft=72, guards=(5, 6), num_tx=1, spt=4, n_rx=4, batch=1, m=2, kbest=32),
+}
+
+
+def load():
+    from tools.gen_idd_ref_golden import load as load_idd
+    from tools.ref_exec.loader import reference
+    mp, mimo, ofdm, od, _, _ = load_idd()
+    ref = reference()
+    sys.modules["sionna"].phy = sys.modules["sionna.phy"]
+    import types
+    chan = sys.modules["sionna.phy.channel"]
+    cu = ref.load("sionna.phy.channel.utils")
+    for k, v in vars(cu).items():
+        if not k.startswith("_"):
+            setattr(chan, k, v)
+    # channel_estimation.py imports the TDL power-delay profiles for tdl_time_cov_mat / tdl_freq_cov_mat (not used here)
+    t38 = types.ModuleType("sionna.phy.channel.tr38901")
+    t38.__path__ = [os.path.join(ref.root, "channel", "tr38901")] if hasattr(ref, "root") else []
+    t38.models = types.ModuleType("sionna.phy.channel.tr38901.models")
+    sys.modules.setdefault("sionna.phy.channel.tr38901", t38)
+    sys.modules.setdefault("sionna.phy.channel.tr38901.models", t38.models)
+    ce = ref.load("sionna.phy.ofdm.channel_estimation")
+    eq = ref.load("sionna.phy.ofdm.equalization")
+    return mp, mimo, ofdm, od, ce, eq
+
+
+def main():
+    mp, mimo, ofdm, od, ce, eq = load()
+    out = {}
+    for name, L in LINKS.items():
+        rng = np.random.default_rng({"c4": 41, "cdl": 42}[name])
+        B, T, S, R, F, m = L["batch"], L["num_tx"], L["spt"], L["n_rx"], L["fft"], L["m"]
+        rg = ofdm.ResourceGrid(num_ofdm_symbols=14, fft_size=F, subcarrier_spacing=15e3, num_tx=T, num_streams_per_tx=S,
+                               cyclic_prefix_length=6, num_guard_carriers=list(L["guards"]), dc_null=True,
+                               pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+        sm = mimo.StreamManagement(np.ones([1, T]), S)
+        const = mp.Constellation("qam", m)
+        nd = int(rg.num_data_symbols)
+        b = rng.integers(0, 2, (B, T, S, nd * m)).astype(np.float32)
+        x = np.asarray(mp.Mapper(constellation=const)(b))
+        x_rg = np.asarray(ofdm.ResourceGridMapper(rg)(x))
+        # a frequency- and time-selective channel: 3 taps per link, slow phase drift over the OFDM symbols
+        taps = (rng.normal(size=(B, 1, R, T, S, 3)) + 1j * rng.normal(size=(B, 1, R, T, S, 3))) / np.sqrt(6)
+        dly = np.array([0.0, 1.3, 3.1])
+        f = np.arange(F) - F // 2
+        hf = np.einsum("brmtsl,lf->brmtsf", taps, np.exp(-2j * np.pi * np.outer(dly, f) / F))
+        drift = np.exp(1j * 0.05 * np.arange(14))[None, None, None, None, None, :, None] * (1 + 0.02 * np.arange(14))[None, None, None, None, None, :, None]
+        h = (hf[..., None, :] * drift).astype(np.complex64)                        # [B, 1, R, T, S, 14, F]
+        no = (np.array([0.05, 0.2])[:B] if B > 1 else np.array([0.1])).astype(np.float32)
+        y = np.einsum("brmtsof,btsof->brmof", h, x_rg)
+        y = (y + np.sqrt(no / 2)[:, None, None, None, None] * (rng.normal(size=y.shape) + 1j * rng.normal(size=y.shape))).astype(np.complex64)
+        o = dict(pilots=np.asarray(rg.pilot_pattern._pilots).astype(np.complex64), mask=np.asarray(rg.pilot_pattern.mask).astype(np.uint8),
+                 b=b.astype(np.uint8), x_rg=x_rg, h=h, y=y, no=no,
+                 removed=np.asarray(ofdm.RemoveNulledSubcarriers(rg)(y)))
+        for it in ("nn", "lin", "lin_time_avg"):
+            hh, ev = ce.LSChannelEstimator(rg, interpolation_type=it)(y, no)
+            o[f"h_hat_{it}"], o[f"err_var_{it}"] = np.asarray(hh), np.asarray(ev)
+        hh, ev = o["h_hat_lin"], o["err_var_lin"]
+        for kind, cls in (("lmmse", eq.LMMSEEqualizer), ("zf", eq.ZFEqualizer), ("mf", eq.MFEqualizer)):
+            xh, ne = cls(rg, sm)(y, hh, ev, no)
+            o[f"x_hat_{kind}"], o[f"no_eff_{kind}"] = np.asarray(xh), np.asarray(ne)
+        kw = dict(constellation_type="qam", num_bits_per_symbol=m, hard_out=False)
+        for meth in ("app", "maxlog"):
+            o[f"llr_lmmse_{meth}"] = np.asarray(od.LinearDetector("lmmse", "bit", meth, rg, sm, **kw)(y, hh, ev, no))
+        o["llr_zf_maxlog"] = np.asarray(od.LinearDetector("zf", "bit", "maxlog", rg, sm, **kw)(y, hh, ev, no))
+        o["llr_kbest"] = np.asarray(od.KBestDetector("bit", T * S, L["kbest"], rg, sm, **kw)(y, hh, ev, no))
+        o["llr_ep"] = np.asarray(od.EPDetector("bit", rg, sm, m, l=6, hard_out=False)(y, hh, ev, no))
+        prior = (2.0 * rng.normal(size=(B, T, S, nd * m))).astype(np.float32)
+        o["prior"] = prior
+        for meth in ("app", "maxlog"):
+            o[f"llr_pic_{meth}"] = np.asarray(od.MMSEPICDetector(output="bit", resource_grid=rg, stream_management=sm, demapping_method=meth,
+                                                                   constellation=const, num_iter=2, hard_out=False)(y, hh, prior, ev, no))
+        for k, v in o.items():
+            out[f"{name}/{k}"] = v
+            print(name, k, v.shape, v.dtype)
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()
