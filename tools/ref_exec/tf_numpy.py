@@ -90,6 +90,10 @@ class Tensor(np.ndarray):
     def numpy(self):
         return np.asarray(self)
 
+    def __getitem__(self, key):                                  # x[i] of a vector is a 0-d TENSOR (has .numpy()), not a NumPy scalar
+        r = np.ndarray.__getitem__(self, key)
+        return r if isinstance(r, np.ndarray) else np.asarray(r).view(Tensor)
+
 
 def _t(x, dtype=None):
     if isinstance(x, RaggedTensor):
@@ -530,9 +534,15 @@ def make_tf():
         """tf.Variable stand-in (an ndarray view; ``isinstance(x, tf.Variable)`` is False for plain tensors)."""
         def __new__(cls, initial_value, *a, dtype=None, **k):
             return np.array(initial_value, dtype=dtype).view(cls)
+
+        def scatter_nd_add(self, indices, updates, **k):         # in place, like the TF variable method
+            np.add.at(np.asarray(self), tuple(np.asarray(indices).reshape(-1, np.asarray(indices).shape[-1]).T), np.asarray(updates))
+            return self
     tf.Variable = Variable
     tf.keras = types.SimpleNamespace(layers=types.SimpleNamespace(Layer=object))
-    tf.config = types.SimpleNamespace(list_physical_devices=lambda *a: [])
+    tf.config = types.SimpleNamespace(list_physical_devices=lambda *a: [], list_logical_devices=lambda *a: [])
+    tf.math.is_nan = lambda x, **k: _t(np.isnan(np.asarray(x)))
+    tf.math.is_inf = lambda x, **k: _t(np.isinf(np.asarray(x)))
     for _n in ("greater", "greater_equal", "less", "less_equal", "equal", "not_equal", "logical_or", "logical_and"):
         setattr(tf.math, _n, getattr(tf, _n))
     for _n in ("reduce_sum", "reduce_prod", "reduce_min", "reduce_max", "reduce_mean", "reduce_any", "reduce_all", "argmax", "argmin"):
