@@ -230,3 +230,31 @@ def test_c5_full_batch_properties(phy):
         u_hat = dec(2 * y / sigma ** 2)
         blers.append(float((u_hat != u).any(dim=1).float().mean()))
     assert blers[0] > blers[1] and blers[1] < 0.05
+
+
+REFX = np.load(os.path.join(GOLD, "polar5g_ref_golden.npz"))
+
+
+@pytest.mark.parametrize("i", range(len(REFX["cases"])))
+def test_polar5g_chain_matches_reference_execution(phy, i):
+    """The HIP encoder / decoders against the reference's OWN Polar5GEncoder / Polar5GDecoder (SC, the TensorFlow SCL-8 and
+    its NumPy twin, SCL-4, hybrid SCL-8, CRC status) executed under the NumPy stand-in for TensorFlow
+    (tests/golden/polar5g_ref_golden.npz, tools/gen_polar5g_ref_golden.py): codewords, decisions and CRC status bit for
+    bit, at noise levels where SC loses blocks that the list recovers.  Oracle twin: tests/test_oracle_ref_exec_polar.py."""
+    k, n, down, B = (int(v) for v in REFX["cases"][i])
+    ch = "downlink" if down else "uplink"
+    g = {key.split("/", 1)[1]: REFX[key] for key in REFX.files if key.startswith(f"{i}/")}
+    unpack = lambda a, w: np.unpackbits(a, axis=1)[:, :w].astype(np.float32)
+    enc = phy.fec.polar.Polar5GEncoder(k, n, channel_type=ch)
+    assert enc.n_polar == int(g["n_polar"]) and np.array_equal(np.asarray(enc.frozen_pos), g["frozen_pos"])
+    u = unpack(g["u"], k)
+    assert np.array_equal(_np(enc(u)), unpack(g["c"], n))
+    logits = g["logits"]
+    assert np.array_equal(_np(phy.fec.polar.Polar5GDecoder(enc, dec_type="SC")(logits)), unpack(g["u_hat_sc"], k))
+    for name, kw in (("scl8_tf", dict(dec_type="SCL", list_size=8)), ("scl4_tf", dict(dec_type="SCL", list_size=4)),
+                     ("hyb8", dict(dec_type="hybSCL", list_size=8))):
+        if f"u_hat_{name}" not in g:
+            continue
+        uh, st = phy.fec.polar.Polar5GDecoder(enc, return_crc_status=True, **kw)(logits)
+        assert np.array_equal(_np(uh), unpack(g[f"u_hat_{name}"], k)), name
+        assert np.array_equal(_np(st).astype(np.uint8).reshape(-1), g[f"crc_{name}"].reshape(-1)), name

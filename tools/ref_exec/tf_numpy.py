@@ -391,7 +391,9 @@ def make_tf():
         c = _dense(cond)
         xs, ys = _dense(x) if not np.isscalar(x) else x, _dense(y) if not np.isscalar(y) else y
         # TF: result dtype = dtype of x and y (both tensors of the same dtype); Python scalars adopt the tensor's dtype
-        dt = next((np.asarray(v).dtype for v in (xs, ys) if not np.isscalar(v)), np.float32)
+        dt = next((np.asarray(v).dtype for v in (xs, ys) if not np.isscalar(v)),
+                  np.bool_ if isinstance(xs, (bool, np.bool_)) and isinstance(ys, (bool, np.bool_)) else
+                  np.int32 if isinstance(xs, int) and isinstance(ys, int) else np.float32)
         return _t(np.where(c, np.asarray(xs, dtype=dt) if np.isscalar(xs) else xs, np.asarray(ys, dtype=dt) if np.isscalar(ys) else ys))
     tf.where = where
 
@@ -443,6 +445,13 @@ def make_tf():
     def function(func=None, **k):
         return (lambda f: f) if func is None else func
     tf.function = function
+
+    def py_function(func, inp, Tout, name=None):
+        r = func(*[_t(np.asarray(a)) for a in inp])
+        if isinstance(Tout, (list, tuple)):
+            return [_t(np.asarray(v).astype(t._np if isinstance(t, DType) else np.dtype(t))) for v, t in zip(r, Tout)]
+        return _t(np.asarray(r))
+    tf.py_function = py_function
     class _Debugging:
         @staticmethod
         def assert_equal(a, b, message=None, **k):
