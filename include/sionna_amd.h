@@ -41,12 +41,15 @@ extern "C" {
 #define SAMD_CN_BOXPLUS_PHI 1    /* cn_update_phi (default) decoding.py:1045-1166 */
 #define SAMD_CN_MINSUM 2         /* cn_update_minsum        decoding.py:911-953   */
 #define SAMD_CN_OFFSET_MINSUM 3  /* cn_update_offset_minsum decoding.py:755-909   */
-/* SAMD_CN_BOXPLUS_PHI evaluates phi = log(e^x+1) - log(e^x-1) on a DEFINED float32 exp / log (the Cephes / Eigen
- * algorithm TensorFlow-CPU's kernels are built on, one fixed sequence of IEEE operations: csrc/bp_math.h,
- * oracle/ldpc_bp.c) - results are bit-identical to the CPU oracle.  ..._PHI_FAST is the same rule on the GPU's
- * transcendental unit (v_exp_f32 / v_log_f32, ~1 ulp, unspecified last bits): ~1.5x faster node updates, soft outputs
- * within 1e-5 of the defined form on well-conditioned messages only (DESIGN.md "phi conditioning").  float32 engines
- * only (the float64 decoder has one form). */
+/* SAMD_CN_BOXPLUS_PHI evaluates phi = log(e^x+1) - log(e^x-1) on a DEFINED float32 exp / log (a Cephes-style range
+ * reduction + polynomial, one fixed sequence of IEEE operations: csrc/bp_math.h = oracle/ldpc_bp.c) - results are
+ * bit-identical to that specification, which is NOT claimed to be TensorFlow's / Eigen's bits: against the reference's own
+ * cn_update_phi executed on NumPy's float32 exp / log it agrees to 1e-5 (tests/test_oracle_ref_exec.py).  It is the
+ * reference's DEFAULT rule and ~1.7x slower here than ..._PHI_FAST, the same rule on the GPU's transcendental unit
+ * (v_exp_f32 / v_log_f32, ~1 ulp, unspecified last bits; soft outputs within 1e-5 of the defined form on
+ * well-conditioned messages only, DESIGN.md "phi conditioning").  ..._PHI_FAST exists on the float32 explicit-message, state-passing, layered and
+ * HBM-resident engines; the float64 decoder, the callback (torch) engine and the first on-chip boxplus engine
+ * (csrc/ldpc5g_onchip_bp.hip, codes the grouped engine does not take) run the defined form under either name. */
 #define SAMD_CN_BOXPLUS_PHI_FAST 4
 
 const char* samd_last_error(void);

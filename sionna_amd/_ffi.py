@@ -18,7 +18,9 @@ HEADER_PATH = os.path.join(_HERE, "..", "include", "sionna_amd.h")
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_WORKSPACE = 0, -1, -2, -3, -4
 # "boxplus-phi-fast": the same rule on the GPU's transcendental unit (SAMD_CN_BOXPLUS_PHI_FAST, include/sionna_amd.h) -
 # an addition to the reference's rule names; "boxplus-phi" evaluates phi on the defined float32 exp / log and is
-# bit-identical to the CPU oracle
+# bit-identical to the specification in oracle/ldpc_bp.c.  "fast" runs the DEFINED form on the float64 decoder, on the
+# callback (torch) engine of phy/fec/ldpc/custom.py and on the first on-chip boxplus engine (csrc/ldpc5g_onchip_bp.hip): which arithmetic "fast" means
+# depends on the engine, "boxplus-phi" means the same bits everywhere.
 CN_MODES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2, "min": 2, "offset-minsum": 3, "boxplus-phi-fast": 4}
 
 _lib = None

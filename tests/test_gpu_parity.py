@@ -805,3 +805,87 @@ def test_decoder_callbacks_and_custom_updates_on_device(phy):
     mi = EXITCallback(3)
     phy.fec.ldpc.LDPC5GDecoder(enc, num_iter=3, v2c_callbacks=[mi])(-4.0 - 2 * torch.randn(16, n, device="cuda"))
     assert np.all(np.isfinite(mi.mi))           # mi[0] = the initial messages (decoding.py:583-594)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The HIP decoders / encoder held DIRECTLY to outputs of the reference's own decoding.py / encoding.py executed under the
+# NumPy stand-in for TensorFlow (tests/golden/ldpc_bp_ref_golden.npz, tools/gen_ldpc_bp_golden.py) - not via the oracle.
+# The boxplus rules there ran on NumPy's float32 exp / log / tanh: an arithmetic INDEPENDENT of csrc/bp_math.h.
+# ---------------------------------------------------------------------------------------------------------------------
+_REFX = np.load(os.path.join(os.path.dirname(__file__), "golden", "ldpc_bp_ref_golden.npz"))
+
+
+def _refx_sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_generic_decoder_matches_reference_execution(phy, i):
+    """LDPCBPDecoder._bp_iter loops of the reference on the five example parity-check matrices: min-sum family soft outputs
+    and decoder state bit for bit (state by SHA-256), hard decisions and a resumed decode (msg_v2c) too; boxplus (tanh)
+    within 1e-5 (+1e-4 floor) on >= 99.9 % of the outputs, boxplus-phi the same for one iteration and >= 90 % / all signs /
+    maximum 0.5 after five (the reference side ran NumPy's exp / log: an arithmetic independent of csrc/bp_math.h)."""
+    g = _REFX
+    pcm, llr = _example_pcm(i), g[f"bp_ex{i}_llr"]
+    for rule in ("minsum", "offset-minsum", "boxplus", "boxplus-phi"):
+        for it in ((1, 5) if i != 4 else (5,)):
+            x, st = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update=rule, hard_out=False, num_iter=it, return_state=True)(llr)
+            ref = g[f"bp_ex{i}_{rule}_it{it}_x"]
+            if rule in ("minsum", "offset-minsum"):
+                assert np.array_equal(_np(x), ref), (rule, it)
+                assert np.array_equal(_refx_sha(_np(st)), g[f"bp_ex{i}_{rule}_it{it}_state_sha"]), (rule, it)
+            elif it == 1 or rule == "boxplus":
+                _close(_np(x), ref, f"{rule} it={it} vs reference execution")
+            else:
+                # five iterations of phi on two different exp / log: BP amplifies last-bit differences where
+                # phi(sum - phi_self) cancels (DESIGN.md "phi conditioning"); the defined form itself sits at 0.915 ... 1.0
+                # within the bar against the reference's NumPy-libm run on these matrices, maximum 0.22
+                got = _np(x)
+                assert np.mean(np.isclose(got, ref, rtol=1e-5, atol=1e-4)) >= 0.9 and np.max(np.abs(got - ref)) <= 0.5, (rule, it)
+                assert np.array_equal((got > 0)[np.abs(ref) > 1e-2], (ref > 0)[np.abs(ref) > 1e-2])
+    d = phy.fec.ldpc.LDPCBPDecoder(pcm, cn_update="minsum", hard_out=True, num_iter=3, return_state=True)
+    x1, st1 = d(llr)
+    x2, st2 = d(llr, msg_v2c=st1)
+    assert np.array_equal(_np(x1).astype(np.uint8), g[f"bp_ex{i}_minsum_hard3"])
+    assert np.array_equal(_np(x2).astype(np.uint8), g[f"bp_ex{i}_minsum_hard3_resumed"])
+    want = g[f"bp_ex{i}_minsum_resumed_state"]
+    assert np.array_equal(_np(st2) if i < 2 else _refx_sha(_np(st2)), want)
+
+
+@pytest.mark.parametrize("tag", ["c1", "bg2s", "bg2m", "bg1r"])
+def test_5g_chain_matches_reference_execution(phy, tag):
+    """LDPC5GEncoder -> LDPC5GDecoder of the reference (C1 = BG1 k=1024 n=2048 BP-10; BG2 small / with the output
+    interleaver; BG1 with rate matching): codewords bit for bit; min-sum family soft outputs (return_infobits=False),
+    decoder state and decisions bit for bit, flooding and layered; boxplus rules: decisions identical on the words the
+    reference decodes, all signs equal, soft outputs within 1e-5 (+1e-4) on >= 93 % for boxplus-phi (words that do not
+    converge amplify last bits; the reference side ran NumPy's exp / log) and >= 99 % for the tanh rule."""
+    g = _REFX
+    k, n, bg, z, m, iters = (int(v) for v in g[f"g5_{tag}_meta"])
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=(m or None), bg=f"bg{bg}")
+    assert enc.z == z
+    u, llr = g[f"g5_{tag}_u"], g[f"g5_{tag}_llr"]
+    assert np.array_equal(_np(enc(u.astype(np.float32))), g[f"g5_{tag}_c"])
+    D = phy.fec.ldpc.LDPC5GDecoder
+    for rule in ("minsum", "offset-minsum", "boxplus", "boxplus-phi"):
+        x, st = D(enc, cn_update=rule, hard_out=False, return_infobits=False, num_iter=iters, return_state=True)(llr)
+        uh = _np(D(enc, cn_update=rule, hard_out=True, return_infobits=True, num_iter=iters)(llr)).astype(np.uint8)
+        ref, uref = g[f"g5_{tag}_{rule}_x"], g[f"g5_{tag}_{rule}_uhat"]
+        if rule in ("minsum", "offset-minsum"):
+            assert np.array_equal(_np(x), ref), rule
+            assert np.array_equal(_refx_sha(_np(st)), g[f"g5_{tag}_{rule}_state_sha"]), rule
+            assert np.array_equal(uh, uref), rule
+        else:
+            # measured for the defined phi against this fixture (CPU, oracle/ldpc_bp.c): 95.7 ... 99.98 % within the bar,
+            # all signs equal, maximum 2.08 (one saturation step of phi on a word that does not converge)
+            conv = np.all(uref == u, axis=1)
+            got = _np(x)
+            assert conv.sum() >= 2 and np.array_equal(uh[conv], uref[conv]), rule
+            assert np.mean(np.isclose(got, ref, rtol=1e-5, atol=1e-4)) >= (0.93 if rule == "boxplus-phi" else 0.99), rule
+            assert np.max(np.abs(got - ref)) <= 2.5 and np.array_equal((got > 0)[np.abs(ref) > 1e-2], (ref > 0)[np.abs(ref) > 1e-2]), rule
+    if tag in ("c1", "bg2s"):
+        it = max(2, iters // 2)
+        x = D(enc, cn_update="minsum", hard_out=False, return_infobits=False, num_iter=it, cn_schedule="layered")(llr)
+        assert np.array_equal(_np(x), g[f"g5_{tag}_layered_minsum_x"])
+        x = D(enc, cn_update="boxplus-phi", hard_out=False, return_infobits=False, num_iter=it, cn_schedule="layered")(llr)
+        assert np.mean(np.isclose(_np(x), g[f"g5_{tag}_layered_phi_x"], rtol=1e-5, atol=1e-4)) >= 0.93
