@@ -22,14 +22,15 @@ MAX_WORK = 6e10               # bounds the deep points: the whole module runs in
 TABLES = nc.load_tables()
 
 
-# The one published curve this path does NOT reproduce (reported, not tuned away; DESIGN.md "Known parity discrepancy"):
-# CDL-C uplink, LS CSI, cyclic prefix 2 in the TIME domain - the ISI-limited regime of MIMO_OFDM_Transmissions_over_CDL.ipynb
-# cell 76.  Our error floor is 1.2e-2 where the notebook shows 5.9e-3 (the waterfall below 8 dB agrees).  Every deterministic
-# block of that chain equals the reference's OWN code executed here to float32 rounding (modulator, cir_to_time_channel,
-# ApplyTimeChannel, demodulator: tools/gen_ofdm_time_ref_golden.py), the same chain with cyclic prefix 20 and all
-# frequency-domain curves agree, and the floor moves 12x per sample of window timing (profiles/r04_probe_cp2_isi_regime.txt).
+# Published tables this path does not reproduce - reported as xfail, not tuned away, each with its cause established:
+# (1) MIMO_OFDM_Transmissions_over_CDL.ipynb cell 76, CDL-C uplink, LS CSI, cyclic prefix 2, TIME domain (the ISI-limited
+#     regime): the waterfall up to 6 dB agrees; the error floor is 1.2e-2 here against 5.9e-3 in the notebook - and
+#     anything between 4.7e-3 and 7.1e-2 on this same path depending on WHICH random QPSK pilot sequence the resource grid
+#     drew (the notebook's came from TensorFlow's generator and is not recoverable).  With the pilot sequence of the
+#     reference's own chain EXECUTED here, this path reproduces that chain's floor:
+#     test_cp2_floor_follows_the_pilot_sequence_and_matches_reference_execution below; DESIGN.md section 2.
 KNOWN_MISS = {"MIMO_OFDM_Transmissions_over_CDL/c76/t3",
-              # The IDD tables SAVED in Introduction_to_Iterative_Detection_and_Decoding.ipynb are not what the reference's
+              # (2) The IDD tables SAVED in Introduction_to_Iterative_Detection_and_Decoding.ipynb are not what the reference's
               # current code produces: its own IddModel chain, executed here from the source files under the NumPy stand-in for
               # TensorFlow, gives IDD-2 BLER 0.056 at -7 dB on 2048 blocks (profiles/r04_idd_ref_exec.txt) - the MI355X path
               # gives 0.055-0.061, the notebook shows 0.023 - and agrees with our chain LLR for LLR on identical inputs
@@ -44,7 +45,7 @@ def _params():
     for c in nc.CURVES:
         seen[c.key] = seen.get(c.key, 0) + 1
         ids.append(c.key if seen[c.key] == 1 else f"{c.key}#{seen[c.key]}")
-    return [pytest.param(c, id=i, marks=[pytest.mark.xfail(reason="ISI-limited floor differs from the saved notebook table", strict=False)]
+    return [pytest.param(c, id=i, marks=[pytest.mark.xfail(reason="saved notebook table not reproducible: pilot-sequence-dependent ISI floor (c76/t3), stale IDD tables (c15/t3, t4)", strict=False)]
                          if c.key in KNOWN_MISS else []) for c, i in zip(nc.CURVES, ids)]
 
 
@@ -61,3 +62,55 @@ def test_curve_overlaps_reference(curve):
     assert res["ok_crossings"], f"{curve.name}: Eb/N0 offset beyond 0.05 dB (+3 sigma MC): {detail}"
     if "ok_ber_crossings" in res:
         assert res["ok_ber_crossings"], f"{curve.name}: BER-curve offset beyond tolerance: {json.dumps(res['ber_crossings'], default=float)}"
+
+
+def test_cp2_floor_follows_the_pilot_sequence_and_matches_reference_execution():
+    """What the xfail of MIMO_OFDM_Transmissions_over_CDL/c76/t3 (cyclic prefix 2, time domain) comes down to.  The
+    Kronecker pilots are random QPSK symbols drawn ONCE when the resource grid is built; with a 2-sample prefix and the
+    strongest tap 6 samples behind the FFT window the LS estimates carry inter-symbol / inter-carrier interference from
+    the neighbouring pilots - a deterministic function of that ONE sequence.  Measured on this path at 16 dB
+    (profiles/r04_probe_cp2_pilots.txt): BLER 4.4e-4 with constant pilots, 4.7e-3 ... 7.1e-2 over eight random QPSK
+    sequences, 1.2e-2 with this build's default sequence; the notebook's 5.9e-3 is one more draw (TensorFlow's generator).
+    The comparable number is the reference's OWN chain executed here under the NumPy stand-in with a KNOWN pilot sequence
+    (tests/golden/cp2_ref_exec_mc.npz: 421 block errors in 51456 blocks at 16 dB over ten CPU-hours, reference CDL and
+    oracle CDL runs pooled): with THOSE pilots this path must give the same floor, and with other pilots a different one."""
+    import numpy as np
+    import torch
+    import sionna_amd.phy as phy
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cp2_ref_exec_mc.npz"))
+
+    def model(pilots):
+        m = nc._CdlModel("time", "C", False, 3.0, 2, [2, 11])
+        if pilots is not None:
+            m.rg.pilot_pattern.pilots = pilots
+            m.rg_mapper = phy.ofdm.ResourceGridMapper(m.rg)
+            m.ls_est = phy.ofdm.LSChannelEstimator(m.rg, interpolation_type="nn")
+            m.lmmse = phy.ofdm.LMMSEEqualizer(m.rg, m.sm)
+        return m
+
+    def bler(m, ebno, iters):
+        phy.config.seed = 2468
+        e = nb = 0
+        for _ in range(iters):
+            b, bh = m(1024, ebno)
+            bt, bht = (t.as_subclass(torch.Tensor).reshape(-1, t.shape[-1]) for t in (b, bh))
+            e += int((bt != bht).any(-1).sum())
+            nb += bt.shape[0]
+        return e, nb
+
+    at16 = g["ebno_db"] == 16.0
+    e_ref, n_ref = int(g["block_errors"][at16].sum()), int(g["blocks"][at16].sum())
+    e, n = bler(model(g["pilots"]), 16.0, 24)
+    p = (e + e_ref) / (n + n_ref)
+    z = (e / n - e_ref / n_ref) / np.sqrt(p * (1 - p) * (1 / n + 1 / n_ref))
+    assert abs(z) < 4.0, f"reference pilots: {e}/{n} = {e / n:.5f} here, {e_ref}/{n_ref} = {e_ref / n_ref:.5f} reference-executed (z = {z:.2f})"
+    at8 = g["ebno_db"] == 8.0
+    e8, n8 = bler(model(g["pilots"]), 8.0, 8)
+    e8r, n8r = int(g["block_errors"][at8].sum()), int(g["blocks"][at8].sum())
+    p8 = (e8 + e8r) / (n8 + n8r)
+    z8 = (e8 / n8 - e8r / n8r) / np.sqrt(p8 * (1 - p8) * (1 / n8 + 1 / n8r))
+    assert abs(z8) < 4.0, f"8 dB: {e8}/{n8} here, {e8r}/{n8r} reference-executed (z = {z8:.2f})"
+    own = np.asarray(model(None).rg.pilot_pattern._pilots)
+    e_c, n_c = bler(model(np.where(own != 0, (1 + 1j) / np.sqrt(2), 0).astype(np.complex64)), 16.0, 8)
+    e_d, n_d = bler(model(None), 16.0, 8)
+    assert e_c / n_c < 0.25 * e / n and e_d / n_d > 1.3 * e / n, (e_c / n_c, e / n, e_d / n_d)      # the floor follows the sequence
