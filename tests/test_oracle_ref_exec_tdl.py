@@ -50,20 +50,24 @@ def _stats(a):
     power = np.mean(np.abs(h[..., 0]) ** 2, axis=(0, 1, 2))
     num = np.sum(h * np.conj(h[..., :1]), axis=(0, 1, 2))
     v = h[..., 0].reshape(B, ra * ta, P)
-    return power, num / num[:, :1], np.einsum("bip,bjp->ij", v, np.conj(v)) / B
+    return power, num, np.einsum("bip,bjp->ij", v, np.conj(v)) / B
 
 
 @pytest.mark.parametrize("model,corr", [(m, False) for m in MODELS] + [("A", True)])
 def test_tdl_statistics_match_the_reference_executed_generator(model, corr):
     kw = dict(rx_corr_mat=_exp_corr(4, 0.7 + 0.2j), tx_corr_mat=_exp_corr(2, 0.5)) if corr else {}
     t, k = _tdl(model, **kw), f"{model}{'_corr' if corr else ''}_"
-    a, tau = o.tdl_cir(777, 0, NUM, T, FS, t.delays, t._mean_powers, t._min_doppler, t._max_doppler, 4, 2, 20,
-                       los_power=(t._los_power if t.los else None), los_aoa=t._los_angle_of_arrival)
-    if corr:                                                       # tdl.py:474-492 through the host class's square root
-        B = a.shape[0]
-        v = a[:, 0, :, 0].reshape(B, 8, -1)                         # rx-major antenna pairs
-        a = np.einsum("ij,bjx->bix", t._corr_sqrt, v).reshape(a[:, 0, :, 0].shape)[:, None, :, None]
-    power, rho, cov = _stats(a)
+    acc = None
+    for i in range(NUM // 250):                                    # (chunks: the oracle's [B,ra,ta,P,T,N] temporaries stay small)
+        a, tau = o.tdl_cir(777, 4 * i, 250, T, FS, t.delays, t._mean_powers, t._min_doppler, t._max_doppler, 4, 2, 20,
+                           los_power=(t._los_power if t.los else None), los_aoa=t._los_angle_of_arrival)
+        if corr:                                                   # tdl.py:474-492 through the host class's square root
+            v = a[:, 0, :, 0].reshape(250, 8, -1)                   # rx-major antenna pairs
+            a = np.einsum("ij,bjx->bix", t._corr_sqrt, v).reshape(a[:, 0, :, 0].shape)[:, None, :, None]
+        st = _stats(a)
+        acc = st if acc is None else tuple(x + y for x, y in zip(acc, st))
+    power, rho_num, cov = (x / (NUM // 250) for x in acc)
+    rho = rho_num / rho_num[:, :1]
     rp, rr, rc = G[k + "power"], G[k + "rho"], G[k + "cov"]
     # a tap's sample power over N x 8 antenna pairs: relative error ~ 1 / sqrt(8 N) for Rayleigh taps
     assert np.allclose(power, rp, rtol=0.04, atol=2e-4), np.max(np.abs(power - rp) / rp)
