@@ -46,7 +46,7 @@ def test_cdl_statistics_match_the_reference_executed_generator(model, direction)
     # cluster powers: a cluster's power is a sum over 20 rays and 32 antenna pairs of mostly coherent terms; its sample
     # mean over N realisations has a relative error of a few percent (LoS clusters less)
     assert np.allclose(power, rp, rtol=0.12, atol=0.02 * rp.max()), np.max(np.abs(power - rp) / rp)
-    assert abs(power.sum() / rp.sum() - 1) < 0.02
+    assert abs(power.sum() / rp.sum() - 1) < 0.035                # (2000 realisations here against 6000: ~1.5 % standard error)
     # spatial covariance: relative Frobenius distance; two independent estimates from 3000 / 6000 samples of the SAME
     # distribution differ by ~3-5 % (checked by splitting the reference samples), a wrong array geometry, polarisation
     # model or angle table moves it by tens of percent
