@@ -614,6 +614,9 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   for (size_t i = 0; i < units.size(); ++i) order[i] = (int)i;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return units[x].cost > units[y].cost; });
   std::vector<std::vector<long>> load(groups.size(), std::vector<long>(NW, 0));
+  // (the same objective per SIMD - waves w, w + 4, ... share one issue pipe - weighted by simd_beta percent; development knob)
+  const long simd_beta = opt_int("SAMD_LY_SIMD_BETA", split ? 0 : 10);
+  std::vector<std::array<long, 4>> sload_g(groups.size(), std::array<long, 4>{0, 0, 0, 0});
   std::vector<int> vn_slots(NW, 0);
   std::vector<std::vector<int>> vn_slot_llr(NW);
   for (int ui : order) {
@@ -624,8 +627,8 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       if (vn_slots[wv] + 1 + u.pair > LY_VN_SLOTS) continue;
       long inc = 0;
       for (auto& tj : touch[u.c]) {
-        const long cst = item_cost(u.c, tj.second, u.pair), l0 = load[tj.first][wv];
-        inc += (l0 + cst) * (l0 + cst) - l0 * l0;
+        const long cst = item_cost(u.c, tj.second, u.pair), l0 = load[tj.first][wv], s0 = sload_g[tj.first][wv & 3];
+        inc += (l0 + cst) * (l0 + cst) - l0 * l0 + simd_beta * ((s0 + cst) * (s0 + cst) - s0 * s0) / 100;
       }
       if (best < 0 || inc < best_inc) { best = wv; best_inc = inc; }
     }
@@ -636,7 +639,10 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
     if (xt_of_col[u.c] < 0) return 1;                                     // a unit's column keeps its total in LDS
     vn_slot_llr[best].push_back(xt_of_col[u.c] * z + u.q * 64);          // float index into the xtot blocks
     if (u.pair) vn_slot_llr[best].push_back(xt_of_col[u.c] * z + (u.q + 1) * 64);
-    for (auto& tj : touch[u.c]) load[tj.first][best] += item_cost(u.c, tj.second, u.pair);
+    for (auto& tj : touch[u.c]) {
+      load[tj.first][best] += item_cost(u.c, tj.second, u.pair);
+      sload_g[tj.first][best & 3] += item_cost(u.c, tj.second, u.pair);
+    }
   }
   std::vector<int32_t>& slot_tab = L.slot_tab;
   slot_tab.assign((size_t)NW * LY_SLOT_INTS, -1);
@@ -687,12 +693,28 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   std::stable_sort(vt.begin(), vt.end(), [](const VTask& x, const VTask& y) {
     return (x.hi - x.lo) != (y.hi - y.lo) ? (x.hi - x.lo) < (y.hi - y.lo) : x.cost > y.cost;
   });
+  // A step lasts as long as its busiest WAVE (a lone wave issues a dependent instruction every ~6.5 cycles) - or as its
+  // busiest SIMD: wave w runs on SIMD w % 4, which issues one wave64 operation per 4 cycles for all its waves together, so
+  // a re-sum placed beside a check-node item of the same SIMD slows that item down (profiles/r04b/layered_owed_*.txt).
+  // simd_alpha (percent; development knob, 0 = waves only) weighs the SIMD's summed load against the busiest wave's:
+  // 45 (+ simd_beta 10 in the ownership objective above) is worth +3.9 % at C2 for the whole-item lists (653 -> 678 k
+  // decodes/s, profiles/r04b/ly_simd_*.txt); the split lists of the boxplus rules lose 1 % with it and keep 0.
+  const long simd_alpha = opt_int("SAMD_LY_SIMD_ALPHA", split ? 0 : 45);
+  std::vector<std::array<long, 4>> simd(nsteps, std::array<long, 4>{0, 0, 0, 0});
+  for (int st = 0; st < nsteps; ++st)
+    for (int wv = 0; wv < NW; ++wv) simd[st][wv & 3] += sload[st][wv];
+  auto step_cost = [&](int st) {
+    long c = smax[st];
+    for (int q = 0; q < 4; ++q) c = std::max(c, simd_alpha * simd[st][q] / 100);
+    return c;
+  };
   for (auto& tk : vt) {
     const Unit& u = units[tk.unit];
     int best = -1;
     long best_inc = 0, best_load = 0;
     for (int st = tk.lo; st <= tk.hi; ++st) {
-      const long after = sload[st][u.wave] + tk.cost, inc = std::max(0L, after - smax[st]);
+      const long after = std::max(sload[st][u.wave] + tk.cost, simd_alpha * (simd[st][u.wave & 3] + tk.cost) / 100);
+      const long inc = std::max(0L, after - step_cost(st));
       if (best < 0 || inc < best_inc || (inc == best_inc && after < best_load)) { best = st; best_inc = inc; best_load = after; }
     }
     const int nl4 = (col_deg[u.c] - tk.j + 3) / 4 * 4;
@@ -701,6 +723,7 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
         LY_VN | (((nl4 / 4) | (u.pair << 4)) << 2) | ((tk.j == 0 ? 1 : 0) << 14) | (u.q << 16),
         xt_base + xt_of_col[u.c] * z * 4, 4 * (col_start[u.c] + 2 * tk.j), (LY_ST_P + u.slot) | ((LY_ST_P + ((u.slot + 1) & 7)) << 8)});
     sload[best][u.wave] += tk.cost;
+    simd[best][u.wave & 3] += tk.cost;
     smax[best] = std::max(smax[best], sload[best][u.wave]);
   }
   if (opt_set("SAMD_LY_DUMP")) {                             // development (tools/ly_dump.py): the schedule, estimated cycles
