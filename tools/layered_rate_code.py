@@ -4,6 +4,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sionna_amd.phy as phy
+from sionna_amd import _ffi   # switches reach the library through samd_debug_set_option (it never reads the environment after load)
 
 k, n = int(sys.argv[1]), int(sys.argv[2])
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16384
@@ -16,13 +17,13 @@ for cn in ("minsum", "boxplus-phi"):
     dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=10, cn_schedule="layered")
     for env in ("", "1"):
         if env:
-            os.environ["SAMD_NO_ONCHIP_LAYERED"] = env
+            _ffi.set_option("SAMD_NO_ONCHIP_LAYERED", env)
         else:
-            os.environ.pop("SAMD_NO_ONCHIP_LAYERED", None)
+            _ffi.set_option("SAMD_NO_ONCHIP_LAYERED", None)
         out = dec(llr); torch.cuda.synchronize()
         t0 = time.perf_counter(); reps = 2
         for _ in range(reps): dec(llr)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / reps
         print(f"k={k} n={n} Z={enc._z if hasattr(enc, '_z') else '?'} {cn:12s} {'HBM-resident' if env else 'on-chip     '}: {dt*1e3:8.2f} ms / {B} = {B/dt/1e3:8.1f} k decodes/s  BLER {float((out != u).any(dim=1).float().mean()):.4f}", flush=True)
-os.environ.pop("SAMD_NO_ONCHIP_LAYERED", None)
+_ffi.set_option("SAMD_NO_ONCHIP_LAYERED", None)

@@ -4,6 +4,7 @@ import itertools, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sionna_amd.phy as phy
+from sionna_amd import _ffi   # switches reach the library through samd_debug_set_option (it never reads the environment after load)
 
 k, n, m, B = 2816, 8448, 6, 16384
 phy.config.seed = 1
@@ -18,7 +19,7 @@ DEFAULT = (60, 300, 18, 250, 12)
 
 def measure(cfg, reps=3):
     for name, v in zip(KNOBS, cfg):
-        os.environ[name] = str(v)
+        _ffi.set_option(name, str(v))
     enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
     dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", cn_schedule="layered", num_iter=10)
     dec(llr); torch.cuda.synchronize()

@@ -4,6 +4,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sionna_amd.phy as phy
+from sionna_amd import _ffi   # switches reach the library through samd_debug_set_option (it never reads the environment after load)
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 k, n, m, B = 2816, 8448, 6, 32768
@@ -16,9 +17,9 @@ llr = phy.mapping.Demapper("app", "qam", m)(phy.channel.AWGN()(phy.mapping.Mappe
 
 def measure(seed, reps=6):
     if seed is None:
-        os.environ.pop("SAMD_MS_PERTURB", None)
+        _ffi.set_option("SAMD_MS_PERTURB", None)
     else:
-        os.environ["SAMD_MS_PERTURB"] = str(seed)
+        _ffi.set_option("SAMD_MS_PERTURB", str(seed))
     enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
     dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=20)
     dec(llr); torch.cuda.synchronize()

@@ -4,6 +4,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sionna_amd.phy as phy
+from sionna_amd import _ffi   # switches reach the library through samd_debug_set_option (it never reads the environment after load)
 
 phy.config.seed = 1
 for k, n, bg in ((2816, 8448, "bg1"), (2816, 5632, "bg1"), (1408, 4224, "bg1"), (4096, 6144, "bg1"), (1920, 5760, "bg2"), (768, 1536, "bg2"), (5632, 8448, "bg1")):
@@ -12,9 +13,9 @@ for k, n, bg in ((2816, 8448, "bg1"), (2816, 5632, "bg1"), (1408, 4224, "bg1"), 
     for env in ("0", None):
         for name in ("SAMD_MS_VN_REFINE", "SAMD_MS_CN_REFINE"):
             if env is None:
-                os.environ.pop(name, None)
+                _ffi.set_option(name, None)
             else:
-                os.environ[name] = env
+                _ffi.set_option(name, env)
         enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=2, bg=bg)
         u = phy.mapping.BinarySource()([B, k])
         no = phy.utils.ebnodb2no(2.0, 2, k / n)

@@ -12,6 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     import sionna_amd.phy as phy
+    from sionna_amd import _ffi   # switches reach the library through samd_debug_set_option (no environment reads after load)
     k, n, m, B = 2816, 8448, 6, 32768
     phy.config.seed = 1
     enc0 = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
@@ -28,13 +29,13 @@ def main():
     for a in sys.argv[1:]:
         if a.startswith("env="):
             kk, vv = a[4:].split(":")
-            os.environ[kk] = vv
+            _ffi.set_option(kk, vv)
     for cap in caps:
       if cap:
-        os.environ["SAMD_MS_CAP"] = cap
+        _ffi.set_option("SAMD_MS_CAP", cap)
         print("cap", cap)
       for cn, vn in grid:
-        os.environ["SAMD_MS_CN_OVH"], os.environ["SAMD_MS_VN_OVH"] = str(cn), str(vn)
+        _ffi.set_option("SAMD_MS_CN_OVH", cn); _ffi.set_option("SAMD_MS_VN_OVH", vn)
         enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
         dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=20)
         out = dec(llr)
