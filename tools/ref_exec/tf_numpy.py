@@ -192,6 +192,7 @@ def make_tf():
     tf.Tensor, tf.RaggedTensor = Tensor, RaggedTensor
     for name in ("float16", "float32", "float64", "int8", "int16", "int32", "int64", "uint8", "complex64", "complex128", "bool"):
         setattr(tf, name, DType(name))
+    tf.bfloat16 = type("BF16", (), {"__eq__": lambda self, o: False, "__hash__": lambda self: 0, "__repr__": lambda self: "tf.bfloat16"})()   # (no NumPy twin; only ever compared)
     tf.DType, tf.dtypes = DType, types.SimpleNamespace(DType=DType)
     tf.newaxis = None
 
@@ -352,6 +353,7 @@ def make_tf():
     tf.sqrt = tf.math.sqrt = _elementwise(np.sqrt)
     tf.math.ceil = _elementwise(np.ceil)
     tf.math.floor = _elementwise(np.floor)
+    tf.math.round = tf.round = _elementwise(np.round)                 # (both round half to even)
     tf.math.cos, tf.math.sin = _elementwise(np.cos), _elementwise(np.sin)
     tf.cos, tf.sin = tf.math.cos, tf.math.sin
     tf.math.mod = lambda a, b: _t(np.mod(np.asarray(a), b))
