@@ -15,7 +15,20 @@ against the reference's own golden vectors and embedded NumPy test formulas inst
 * demapper         -> ``test/unit/mapping/test_mapping.py:175-199`` (scipy logsumexp)
 * CRC / Polar      -> ``test/codes/crc/*.npy``, ``test/codes/polar/*.npy``
 
-Parity status: LMMSE, TDL, AWGN and end-to-end BER are "parity unpinned" by value in the
-reference (statistical / smoke tests only); for those the oracle
-restates the formulas and is checked by invariants.
+Since round 4 the oracle is ALSO pinned against the reference's own source files EXECUTED
+here under a NumPy stand-in for TensorFlow (``tools/ref_exec``; fixtures
+``tests/golden/*_ref_*``, tests ``tests/test_oracle_ref_exec*.py``,
+``tests/test_sim_ber_ref_exec.py``, ``tests/test_fec_utils_ref_exec.py``): BP node updates and
+whole decoders (min-sum family, VN update, state, layered: bit for bit), 5G LDPC / Polar
+encoders and Polar SC / SCL / hybrid decisions (bit for bit), mapper / demapper, MIMO
+equalisers, OFDM modulator / demodulator / time channel, LS estimators, OFDM detectors, the
+IDD chain, ``sim_ber`` (bit for bit), TDL / CDL generators (parameters exactly, realisations
+statistically), and against the BER / BLER tables the reference publishes in its notebooks
+(``tests/test_gpu_ber_reference.py``).
+
+Still "parity unpinned" by construction: the VALUES of random streams (bits, noise, channel
+draws, pilot symbols) - the reference takes them from TensorFlow's generators, this build from
+its own Philox specification (``oracle/utils.py``) - and TensorFlow's own last bits of exp / log
+in the boxplus rules (``oracle/ldpc_bp.c`` defines its arithmetic; 1e-5 against the reference's
+formulas on NumPy's exp / log).
 """

@@ -11,7 +11,9 @@ Sec. 7.7.1 as implemented by the reference:
 The reference draws the random ray coupling, the initial phases and the velocity vector from
 TensorFlow's RNG; this build defines its own counter-based streams instead ("parity unpinned" for
 the realisations; the deterministic part - tables, fields, array responses, Doppler, LoS / K-factor
-combination - is pinned by the physical checks of tests/test_oracle_cdl.py):
+combination - is pinned by the physical checks of tests/test_oracle_cdl.py, and the generator as a
+whole STATISTICALLY against the reference's own cdl.py / rays.py / channel_coefficients.py / antenna.py
+executed under tools/ref_exec: tests/test_oracle_ref_exec_cdl.py):
   (seed, call+0..2)  speed v_r, azimuth v_phi, zenith v_theta     one uniform per batch example
   (seed, call+3..6)  sort keys of the AoA, AoD, ZoA, ZoD shuffles  u32 per (b, cluster, ray)
   (seed, call+7)     initial phases Phi in (-pi, pi)               per (b, cluster, ray, 4)

@@ -18,9 +18,12 @@ TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  Restates (paths relative to
 * lmmse_equalizer / whiten_channel / lmmse_matrix / inv_cholesky
                                     mimo/equalization.py:11-233, mimo/utils.py:292-356, utils/linalg.py:8-32
 
-Parity status: the reference pins LMMSE / TDL only statistically ("parity unpinned" by value,
-SURVEY section 8c); this restatement is checked by invariants (whitening gives identity
-covariance, perfect-CSI noiseless recovery, PDP / unit energy of the TDL) in tests/.
+Parity status: the reference's own tests pin LMMSE / TDL only statistically (SURVEY section 8c);
+since round 4 this restatement is held to the reference's own code EXECUTED under tools/ref_exec:
+resource grid / LS estimators / equalisers / detectors (tests/test_oracle_ref_exec_ofdm_rx.py),
+modulator / demodulator / time channel (..._ofdm.py), the IDD chain (..._idd.py), the TDL generator's
+parameters exactly and its statistics (..._tdl.py) - plus the invariants in tests/ (whitening gives
+identity covariance, perfect-CSI noiseless recovery, PDP / unit energy of the TDL).
 Random draws use the build's Philox stream (oracle/utils.py) with the element layout documented
 in ``tdl_cir``; pilots of the Kronecker pattern are QPSK symbols drawn from that stream with the
 pattern's seed (the reference draws them from tf.random.Generator.from_seed(0)).

@@ -16,8 +16,11 @@ TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  Restates (paths relative to
 
 Pinned by the reference's golden vectors (tests/golden/{crc,polar}_golden.npz): CRC parity for
 all six polynomials, 5G encoder + rate matching (5 configurations x 100 words), SC and SCL(L=1)
-hard outputs (3 codes x 10 words).  List sizes > 1 are unpinned in the reference; tie-breaking of
-the path sort is fixed here to a stable sort (lowest position first).
+hard outputs (3 codes x 10 words).  The reference holds no vectors for list sizes > 1; those are pinned
+by EXECUTING its own decoders - the NumPy twin (tools/gen_polar_scl_golden.py, round 3) and the whole
+Polar5GEncoder / Polar5GDecoder chain with the TensorFlow list decoder under tools/ref_exec (round 4,
+tests/test_oracle_ref_exec_polar.py: SC / SCL-8 / SCL-4 / hybrid decisions and CRC status bit for bit).
+Tie-breaking of the path sort is fixed here to a stable sort (lowest position first).
 """
 import os
 
