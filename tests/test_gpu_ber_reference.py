@@ -112,5 +112,7 @@ def test_cp2_floor_follows_the_pilot_sequence_and_matches_reference_execution():
     assert abs(z8) < 4.0, f"8 dB: {e8}/{n8} here, {e8r}/{n8r} reference-executed (z = {z8:.2f})"
     own = np.asarray(model(None).rg.pilot_pattern._pilots)
     e_c, n_c = bler(model(np.where(own != 0, (1 + 1j) / np.sqrt(2), 0).astype(np.complex64)), 16.0, 8)
-    e_d, n_d = bler(model(None), 16.0, 8)
-    assert e_c / n_c < 0.25 * e / n and e_d / n_d > 1.3 * e / n, (e_c / n_c, e / n, e_d / n_d)      # the floor follows the sequence
+    rng = np.random.default_rng(101)                                  # another random QPSK sequence (3.3e-2 in the probe)
+    qp = ((1 - 2 * rng.integers(0, 2, own.shape)) + 1j * (1 - 2 * rng.integers(0, 2, own.shape))).astype(np.complex64) / np.sqrt(2)
+    e_d, n_d = bler(model(np.where(own != 0, qp, 0).astype(np.complex64)), 16.0, 8)
+    assert e_c / n_c < 0.25 * e / n and e_d / n_d > 2.0 * e / n, (e_c / n_c, e / n, e_d / n_d)      # the floor follows the sequence
