@@ -1,7 +1,8 @@
 """Flat-fading MIMO channel - mirrors of ``GenerateFlatFadingChannel``, ``ApplyFlatFadingChannel`` and
 ``FlatFadingChannel`` (reference src/sionna/phy/channel/flat_fading_channel.py:14-290): i.i.d. CN(0,1)
 channel matrices on the Philox stream and y = H x (+ AWGN) through ``samd_apply_ofdm_channel_c64``
-(one "resource element" per batch item).  Spatial correlation models have no HIP path."""
+(one "resource element" per batch item); spatial correlation models (spatial_correlation.py) through
+``samd_spatial_corr_c64``."""
 import torch
 
 from ... import _ffi
@@ -15,15 +16,25 @@ class GenerateFlatFadingChannel(Object):
 
     def __init__(self, num_tx_ant, num_rx_ant, spatial_corr=None, precision=None):
         super().__init__(precision=precision)
-        if spatial_corr is not None:
-            raise NotImplementedError("GenerateFlatFadingChannel: spatial correlation models have no HIP path")
         self._num_tx_ant, self._num_rx_ant = int(num_tx_ant), int(num_rx_ant)
+        self.spatial_corr = spatial_corr
 
-    spatial_corr = property(lambda self: None)
+    @property
+    def spatial_corr(self):
+        return self._spatial_corr
+
+    @spatial_corr.setter
+    def spatial_corr(self, value):
+        from .spatial_correlation import SpatialCorrelation
+        if value is not None and not isinstance(value, SpatialCorrelation):
+            raise TypeError("spatial_corr must be a SpatialCorrelation (KroneckerModel, PerColumnModel) or None")
+        self._spatial_corr = value
 
     def __call__(self, batch_size):
+        """flat_fading_channel.py:63-76: i.i.d. CN(0, 1) matrices, then the correlation model."""
         from ..utils.misc import complex_normal
-        return complex_normal([int(batch_size), self._num_rx_ant, self._num_tx_ant], 1.0, precision=self.precision)
+        h = complex_normal([int(batch_size), self._num_rx_ant, self._num_tx_ant], 1.0, precision=self.precision)
+        return h if self._spatial_corr is None else self._spatial_corr(h)
 
 
 class ApplyFlatFadingChannel(Block):
@@ -59,7 +70,7 @@ class FlatFadingChannel(Block):
         self._gen_chn = GenerateFlatFadingChannel(num_tx_ant, num_rx_ant, spatial_corr, precision=self.precision)
         self._app_chn = ApplyFlatFadingChannel(precision=self.precision)
 
-    spatial_corr = property(lambda self: None)
+    spatial_corr = property(lambda self: self._gen_chn.spatial_corr, lambda self, v: setattr(self._gen_chn, "spatial_corr", v))
     generate = property(lambda self: self._gen_chn)
     apply = property(lambda self: self._app_chn)
 

@@ -232,7 +232,7 @@ class _SimpleMimo:
     """``Model`` of Simple_MIMO_Simulation.ipynb cell 40 (uncorrelated): 4 tx x 16 rx i.i.d. Rayleigh flat fading with a
     fresh channel per symbol vector, 16-QAM, 5G LDPC (512, 1024) default decoder, ``lmmse_equalizer`` with S = no I."""
 
-    def __init__(self):
+    def __init__(self, kronecker=False):
         phy = _phy()
         self.n, self.k, self.m, self.ntx, self.nrx = 1024, 512, 4, 4, 16
         self.binary_source = phy.mapping.BinarySource()
@@ -240,7 +240,10 @@ class _SimpleMimo:
         self.mapper = phy.mapping.Mapper("qam", self.m)
         self.demapper = phy.mapping.Demapper("app", "qam", self.m)
         self.decoder = phy.fec.ldpc.LDPC5GDecoder(self.encoder, hard_out=True)
-        self.channel = phy.channel.FlatFadingChannel(self.ntx, self.nrx, add_awgn=True, return_channel=True)
+        # cell 44: KroneckerModel(exp_corr_mat(0.4, num_tx_ant), exp_corr_mat(0.7, num_rx_ant))
+        corr = (phy.channel.KroneckerModel(phy.channel.exp_corr_mat(0.4, self.ntx), phy.channel.exp_corr_mat(0.7, self.nrx))
+                if kronecker else None)
+        self.channel = phy.channel.FlatFadingChannel(self.ntx, self.nrx, spatial_corr=corr, add_awgn=True, return_channel=True)
 
     def __call__(self, batch_size, ebno_db):
         import torch
@@ -261,9 +264,12 @@ class _BicmLdpc:
     """``LDPC_QAM_AWGN`` of Bit_Interleaved_Coded_Modulation.ipynb cell 23 (k=600, n=1200, default 20 iterations)."""
 
     def __init__(self, m, demapping_method="app", cn_update="boxplus", use_allzero=False, use_scrambler=False,
-                 use_ldpc_output_interleaver=False, no_est_mismatch=1.0, k=600, n=1200):
+                 use_ldpc_output_interleaver=False, no_est_mismatch=1.0, k=600, n=1200, random_interleaver=False):
         phy = _phy()
         self.k, self.n, self.m = k, n, m
+        # cell 17 ("Baseline (with encoder)"): RandomInterleaver / Deinterleaver around mapper ... demapper
+        self.interleaver = phy.fec.interleaving.RandomInterleaver() if random_interleaver else None
+        self.deinterleaver = phy.fec.interleaving.Deinterleaver(self.interleaver) if random_interleaver else None
         self.use_allzero, self.use_scrambler, self.mismatch = use_allzero, use_scrambler, no_est_mismatch
         self.source = phy.mapping.BinarySource()
         self.constellation = phy.mapping.Constellation("qam", num_bits_per_symbol=m)
@@ -289,8 +295,12 @@ class _BicmLdpc:
             c = self.encoder(u)
         if self.use_scrambler:
             c = self.scrambler(c)
+        if self.interleaver is not None:
+            c = self.interleaver(c)
         y = self.channel(self.mapper(c), no)
         llr = self.demapper(y, no * self.mismatch)
+        if self.interleaver is not None:
+            llr = self.deinterleaver(llr)
         if self.use_scrambler:
             llr = self.descrambler(llr)
         return u, self.decoder(llr)
@@ -589,6 +599,8 @@ CURVES = [
     Curve(f"{EVO}/c18/t0", "Uncoded QPSK (2048 bit blocks)", _uncoded(2048), np.arange(-1, 1.8, 0.1), bits_per_block=2048, cite="cell 18", use_bits=True, work=2048),
     Curve(f"{EVO}/c18/t2", "5G LDPC BP-40 (2048,6156)", _ldpc(2048, 6156, 40), np.arange(-1, 1.8, 0.1), bits_per_block=2048, work=6156 * 40, cite="cell 18"),
     # --- Bit_Interleaved_Coded_Modulation.ipynb (k=600, n=1200; these cells stop on 1000..2000 BIT errors, so few block errors)
+    Curve(f"{BICM}/c19/t0", "BICM baseline with encoder + random interleaver, QPSK, boxplus-phi BP-20 (1000 bit errors per point)",
+          lambda: _BicmLdpc(2, cn_update="boxplus-phi", random_interleaver=True), np.arange(0, 5, 0.25), bits_per_block=600, cite="cells 17/19"),
     Curve(f"{BICM}/c26/t0", "BICM all-zero QPSK, boxplus BP-20", lambda: _BicmLdpc(2, use_allzero=True), np.arange(0, 5, 0.25), bits_per_block=600, cite="cell 26"),
     Curve(f"{BICM}/c31/t0", "BICM Gaussian-approximated LLRs, boxplus-phi BP-20", _BicmGa, np.arange(0, 5, 0.25), bits_per_block=600, cite="ipynb:916-932"),
     *[Curve(f"{BICM}/c{c}/t0", name, (lambda kw=kw: _BicmLdpc(4, **kw)), np.arange(*grid), bits_per_block=600, cite=f"cell {c}")
@@ -647,6 +659,9 @@ CURVES = [
     # --- Simple_MIMO_Simulation.ipynb cells 40/43 (100 block errors per point; 4 codewords per example but a fresh channel per symbol)
     Curve("Simple_MIMO_Simulation/c43/t0", "4x16 i.i.d. flat fading, lmmse_equalizer, 16-QAM LDPC(512,1024)", _SimpleMimo,
           np.arange(-2.5, 0.25, 0.25), bits_per_block=512, group="mimo", max_batch=2048, cite="ipynb:821-832"),
+    # --- same notebook, cell 44: Kronecker spatial correlation (exponential, 0.4 at the transmitter, 0.7 at the receiver; 200 block errors)
+    Curve("Simple_MIMO_Simulation/c44/t0", "4x16 flat fading with Kronecker correlation, lmmse_equalizer, 16-QAM LDPC(512,1024)",
+          lambda: _SimpleMimo(kronecker=True), np.arange(0, 2.6, 0.25), bits_per_block=512, group="mimo", max_batch=2048, cite="ipynb:866-880"),
 ]
 
 

@@ -894,8 +894,34 @@ def test_flat_fading_channel(phy):
     assert abs(nvar - 0.5) < 0.03
     h3 = phy.channel.GenerateFlatFadingChannel(2, 2)(7)
     assert tuple(phy.channel.ApplyFlatFadingChannel()(x[:7, :2], h3).shape) == (7, 2)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):
         phy.channel.FlatFadingChannel(2, 2, spatial_corr=object())
+
+
+def test_spatial_correlation_models_match_reference_execution(phy):
+    """KroneckerModel / PerColumnModel on the device (one samd_spatial_corr_c64 launch) against the reference's own models
+    executed under the NumPy stand-in (tests/golden/spatial_corr_ref_golden.npz), and through FlatFadingChannel: the sample
+    covariance of 40000 correlated 16 x 4 channels is R_rx (x) conj... of Simple_MIMO_Simulation.ipynb cell 44."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "spatial_corr_ref_golden.npz"))
+    ch = phy.channel
+    close = lambda a, b: np.abs(_np(a) - b).max() <= 1e-5 * max(1.0, np.abs(b).max())
+    assert close(ch.KroneckerModel(g["exp_04_4"], g["exp_07_16"])(g["h_16x4"]), g["kron_16x4"])
+    assert close(ch.KroneckerModel(None, g["exp_07_16"])(g["h_16x4"]), g["kron_rx_only"])
+    assert close(ch.KroneckerModel(g["exp_04_4"], None)(g["h_16x4"]), g["kron_tx_only"])
+    assert close(ch.KroneckerModel(g["r_tx3"], g["exp_c_5"])(g["h_5x3"]), g["kron_5x3"])
+    assert close(ch.PerColumnModel(g["r_cols"])(g["h_5x3"]), g["percol_5x3"])
+    phy.config.seed = 5
+    r_tx, r_rx = ch.exp_corr_mat(0.4, 4), ch.exp_corr_mat(0.7, 16)
+    fc = ch.FlatFadingChannel(4, 16, spatial_corr=ch.KroneckerModel(r_tx, r_rx), return_channel=True)
+    x = np.ones((40000, 4), np.complex64)
+    y, h = fc(x)
+    h = _np(h)
+    assert tuple(h.shape) == (40000, 16, 4) and np.allclose(_np(y), h.sum(-1), rtol=1e-4, atol=1e-4)
+    cov_rx = np.einsum("bik,bjk->ij", h, h.conj()) / (40000 * 4)                    # E[h h^H] / K = R_rx
+    cov_tx = np.einsum("bmi,bmj->ij", h.conj(), h) / (40000 * 16)                    # E[h^H h] / M = conj-free R_tx (real here)
+    assert np.abs(cov_rx - r_rx).max() < 0.02 and np.abs(cov_tx - r_tx).max() < 0.02
+    fc.spatial_corr = None
+    assert fc.spatial_corr is None and tuple(fc(x)[1].shape) == (40000, 16, 4)
 
 
 # ------------------------------------------------------------------ symbol output (SymbolDemapper, LinearDetector(output="symbol"))

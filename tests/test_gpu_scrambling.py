@@ -110,3 +110,34 @@ def test_row_column_interleaver(fec, shape, axis, depth):
         il.RowColumnInterleaver(depth, axis=5)(x)
     with pytest.raises(TypeError):
         il.RowColumnInterleaver(2.5)
+
+
+def test_random_interleaver(fec):
+    """RandomInterleaver (reference interleaving.py:198-497; tests test/unit/fec/test_interleaving.py): a permutation along
+    one axis, identical for all batch examples, undone by its Deinterleaver; explicit seeds pair up; keep_state=False
+    draws a fresh permutation per call."""
+    il = fec.interleaving
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(5, 3, 97)).astype(np.float32)
+    for axis in (-1, 1, 2):
+        i = il.RandomInterleaver(seed=11, axis=axis)
+        d = il.Deinterleaver(i)
+        y = _np(i(x))
+        assert y.shape == x.shape and not np.array_equal(y, x)
+        assert np.array_equal(np.sort(y, axis=axis), np.sort(x, axis=axis))          # a permutation along the axis ...
+        assert np.array_equal(_np(d(y)), x)                                           # ... undone by the deinterleaver
+        ref = np.moveaxis(np.moveaxis(x, axis, -1)[..., _np(i._perm(11, x.shape[axis])[0]).astype(int)], -1, axis)
+        assert np.array_equal(y, ref)                                                 # the same permutation for every example
+    a, b = il.RandomInterleaver(seed=1), il.RandomInterleaver(seed=2)
+    assert not np.array_equal(_np(a(x)), _np(b(x))) and np.array_equal(_np(a(x, seed=2)), _np(b(x)))
+    assert np.array_equal(_np(il.Deinterleaver(a)(_np(a(x, seed=77)), seed=77)), x)
+    assert np.array_equal(_np(a(x)), _np(a(x)))                                       # keep_state: the same permutation again
+    f = il.RandomInterleaver(seed=5, keep_state=False)
+    assert not np.array_equal(_np(f(x)), _np(f(x)))
+    assert np.array_equal(_np(il.RandomInterleaver(seed=5, inverse=True)(_np(il.RandomInterleaver(seed=5)(x)))), x)
+    s = il.RandomInterleaver(seed=4).find_s_min(4, 40)
+    assert 1 <= s <= 40
+    with pytest.raises(ValueError):
+        il.RandomInterleaver(axis=0)
+    with pytest.raises(NotImplementedError):
+        il.RandomInterleaver(keep_batch_constant=False)
