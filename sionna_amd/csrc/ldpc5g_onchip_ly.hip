@@ -597,9 +597,11 @@ int build_onchip_ly_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   const long ly_cn_slope = opt_int("SAMD_LY_CN_SLOPE", 60);
   const long ly_cn_ovh = opt_int("SAMD_LY_CN_OVH", 300);
   auto item_cost = [&](int c, int j, int pair) { return (pair ? 2 : 1) * ly_vn_slope * ((col_deg[c] - j + 3) / 4 * 4) + ly_vn_ovh; };
-  // (two-chunk lifting sizes: 8 is +0.9 % over 12 at C2, ly_grid_r03z.txt; with more chunks 12 stays - k=3000 n=6000,
-  // Z = 320, loses 2 % (boxplus-phi 7 %) with 8)
-  const int pair_max = (int)opt_int("SAMD_LY_PAIR_MAX", (chunks == 2 ? 8 : 12));
+  // (two-chunk lifting sizes with the split lists of the boxplus rules: 8 is +0.9 % over 12 at C2, ly_grid_r03z.txt; with
+  // more chunks 12 stays - k=3000 n=6000, Z = 320, loses 2 % (boxplus-phi 7 %) with 8.  Whole-item lists under the
+  // SIMD-aware schedule of round 4: 12 is +0.7 % over 8 at C2, profiles/r04b/ly_pair_max.txt - a pair halves the walker's
+  // share per chunk, and the steps are bound by the SIMD's instruction total, not by the longest wave)
+  const int pair_max = (int)opt_int("SAMD_LY_PAIR_MAX", (chunks == 2 && split ? 8 : 12));
   for (int c = 0; c < nbu; ++c) {
     if (xt_of_col[c] < 0) continue;
     for (int q = 0; q < chunks; ++q) {

@@ -13,8 +13,8 @@ no = phy.utils.ebnodb2no(4.5, m, k / n)
 u = phy.mapping.BinarySource()([B, k])
 llr = phy.mapping.Demapper("app", "qam", m)(phy.channel.AWGN()(phy.mapping.Mapper("qam", m)(enc0(u)), no), no)
 KNOBS = {"SAMD_LY_CN_SLOPE": [30, 60, 100], "SAMD_LY_CN_OVH": [150, 300, 600], "SAMD_LY_VN_SLOPE": [9, 18, 30],
-         "SAMD_LY_VN_OVH": [120, 250, 500], "SAMD_LY_PAIR_MAX": [8, 12]}
-DEFAULT = (60, 300, 18, 250, 12)
+         "SAMD_LY_VN_OVH": [120, 250, 500], "SAMD_LY_SIMD_ALPHA": [30, 45, 60]}
+DEFAULT = (60, 300, 18, 250, 45)
 
 
 def measure(cfg, reps=3):
