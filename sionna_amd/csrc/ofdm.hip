@@ -91,20 +91,11 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
     float ca_r[kMaxSin], ph_r[kMaxSin];
     const bool cached = N <= kMaxSin;
     if (cached) {
-      // consecutive sinusoids draw consecutive elements of a stream: one Philox block serves four of them (round 4; the
-      // kernel computed a block per element - the same values, four times the generator work)
-      const uint64_t th0 = (uint64_t)((b * P + p) * N), ph0 = (uint64_t)(i * N);
-      uint4 tb = philox_block(seed, call + 1, th0 >> 2), pb = philox_block(seed, call + 2, ph0 >> 2);
-      auto word = [](const uint4& r, uint64_t e) { return (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w; };
 #pragma unroll
       for (int n = 0; n < kMaxSin; ++n)
         if (n < N) {
-          const uint64_t te = th0 + (uint64_t)n, pe = ph0 + (uint64_t)n;
-          if (n > 0 && (te & 3) == 0) tb = philox_block(seed, call + 1, te >> 2);
-          if (n > 0 && (pe & 3) == 0) pb = philox_block(seed, call + 2, pe >> 2);
-          const float lo_t = -pi / (float)N, hi_t = pi / (float)N;
-          const float theta = lo_t + (hi_t - lo_t) * u01(word(tb, te));
-          ph_r[n] = -pi + (pi - -pi) * u01(word(pb, pe));
+          const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
+          ph_r[n] = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
           ca_r[n] = cosf((2.f * pi / (float)N) * (float)(n + 1) + theta);
         }
     }
