@@ -207,6 +207,13 @@ int samd_symbol_demap_f32(const float* y, const float* no, int64_t no_len, const
                           int64_t num_symbols, const float* prior, int64_t prior_len, int hard_out,
                           float* out, int32_t* out_idx, void* stream);
 
+/* SymbolLogits2LLRs.call  mapping.py:794-967: logits [rows, 2^m] on the constellation points (labels = point index, MSB
+ * first) -> out [rows, m] LLRs: reduce over the points whose bit i is 1 minus reduce over those whose bit is 0, reduce =
+ * logsumexp (method 0, "app") or max (method 1, "maxlog"); prior NULL or LLRs [m] / [rows, m] whose term
+ * sum_i log_sigmoid(+-prior_i) is added to every point's logit; hard_out: decisions llr > 0.  m in 1..8. */
+int samd_symbol_logits2llrs_f32(const float* logits, int m, int64_t rows, const float* prior, int64_t prior_len,
+                                int method, int hard_out, float* out, void* stream);
+
 /* Demapper.call with prior knowledge on the bits (mapping.py:664-691, 927-967): as samd_qam_demap_f32 with
  * the a-priori term sum_i log_sigmoid(+-prior_i) added to the exponent of every point.  prior DEVICE
  * float LLRs, [m] (shared by all symbols) or [num_symbols, m]. */

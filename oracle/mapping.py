@@ -116,3 +116,20 @@ def symbol_demapper(y, no, points, prior=None, hard_out=False):
         return np.argmax(e, axis=-1).astype(np.int32)
     mx = np.max(e, axis=-1, keepdims=True)
     return e - (mx + np.log(np.sum(np.exp(e - mx), axis=-1, keepdims=True)))
+
+
+def symbol_logits2llrs(logits, num_bits_per_symbol, method="app", prior=None, hard_out=False):
+    """SymbolLogits2LLRs.call (mapping.py:927-967) in float64: logits [..., 2^m] -> LLRs [..., m]."""
+    m = num_bits_per_symbol
+    z = np.asarray(logits, np.float64)
+    c0, c1 = _bit_sets(m)
+    labels = (np.arange(1 << m)[:, None] >> np.arange(m - 1, -1, -1)[None, :]) & 1           # [P, m], MSB first
+    if prior is not None:
+        pr = np.asarray(prior, np.float64)[..., None, :]                                       # [..., 1, m]
+        a = 2.0 * labels - 1.0
+        x = a * pr
+        ls = np.where(x < 0, x - np.log1p(np.exp(np.minimum(x, 0))), -np.log1p(np.exp(-np.maximum(x, 0))))
+        z = z + np.sum(ls, axis=-1)
+    red = (lambda v: _logsumexp(v, -2)) if method == "app" else (lambda v: np.max(v, axis=-2))
+    llr = red(z[..., c1]) - red(z[..., c0])
+    return (llr > 0).astype(np.float32) if hard_out else llr

@@ -53,7 +53,7 @@ int opt_generation() { return registry().generation.load(std::memory_order_acqui
 }  // namespace samd
 
 extern "C" const char* samd_last_error(void) { return samd::g_last_error.c_str(); }
-extern "C" int samd_version(void) { return 101; }
+extern "C" int samd_version(void) { return 102; }
 extern "C" int samd_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return SAMD_ERR_HIP;

@@ -301,6 +301,91 @@ extern "C" int samd_qam_demap_prior_f32(const float* y, const float* no, int64_t
   return launch_status();
 }
 
+// SymbolLogits2LLRs.call (mapping.py:927-967): LLR_i = reduce_{c: bit i = 1}(logit_c + prior term) - reduce_{c: bit i = 0}(...),
+// reduce = logsumexp ("app", with the set's own maximum subtracted like tf.reduce_logsumexp) or max ("maxlog").
+// One thread per row of 2^m logits; the per-(bit, value) maxima and sums are formed in two passes over the row.
+template <int M, bool MAXLOG>
+__global__ __launch_bounds__(256) void logits2llrs_kernel(const float* __restrict__ logits, const float* __restrict__ prior,
+                                                          int64_t prior_len, int64_t rows, int hard_out, float* __restrict__ out) {
+  constexpr int P = 1 << M;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < rows; s += (int64_t)gridDim.x * blockDim.x) {
+    const float* z = logits + s * P;
+    float ls[M][2];
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      const float p = prior ? prior[prior_len == M ? i : s * M + i] : 0.f;
+      ls[i][1] = prior ? (p < 0.f ? p - log1pf(expf(p)) : -log1pf(expf(-p))) : 0.f;
+      ls[i][0] = prior ? (-p < 0.f ? -p - log1pf(expf(-p)) : -log1pf(expf(p))) : 0.f;
+    }
+    auto expo = [&](int c) {
+      float e = z[c];
+      if (prior) {
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < M; ++i) ps += ls[i][(c >> (M - 1 - i)) & 1];
+        e = ps + e;
+      }
+      return e;
+    };
+    float mx[M][2];
+#pragma unroll
+    for (int i = 0; i < M; ++i) { mx[i][0] = -INFINITY; mx[i][1] = -INFINITY; }
+    for (int c = 0; c < P; ++c) {
+      const float e = expo(c);
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        if ((c >> (M - 1 - i)) & 1) mx[i][1] = fmaxf(mx[i][1], e); else mx[i][0] = fmaxf(mx[i][0], e);
+      }
+    }
+    float llr[M];
+    if constexpr (MAXLOG) {
+#pragma unroll
+      for (int i = 0; i < M; ++i) llr[i] = mx[i][1] - mx[i][0];
+    } else {
+      float sm[M][2];
+#pragma unroll
+      for (int i = 0; i < M; ++i) { sm[i][0] = 0.f; sm[i][1] = 0.f; }
+      for (int c = 0; c < P; ++c) {
+        const float e = expo(c);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+          if ((c >> (M - 1 - i)) & 1) sm[i][1] += exp_core_f32(e - mx[i][1]); else sm[i][0] += exp_core_f32(e - mx[i][0]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < M; ++i) llr[i] = (log_core_f32(sm[i][1]) + mx[i][1]) - (log_core_f32(sm[i][0]) + mx[i][0]);
+    }
+    float* o = out + s * M;
+#pragma unroll
+    for (int i = 0; i < M; ++i) o[i] = hard_out ? (llr[i] > 0.f ? 1.f : 0.f) : llr[i];
+  }
+}
+
+template <bool MAXLOG>
+static int launch_logits2llrs(int m, dim3 grid, hipStream_t st, const float* logits, const float* prior, int64_t prior_len,
+                              int64_t rows, int hard_out, float* out) {
+#define SAMD_L2L(MM) case MM: hipLaunchKernelGGL((logits2llrs_kernel<MM, MAXLOG>), grid, dim3(256), 0, st, logits, prior, prior_len, rows, hard_out, out); return SAMD_OK;
+  switch (m) {
+    SAMD_L2L(1) SAMD_L2L(2) SAMD_L2L(3) SAMD_L2L(4) SAMD_L2L(5) SAMD_L2L(6) SAMD_L2L(7) SAMD_L2L(8)
+    default: set_error("num_bits_per_symbol must be in 1..8"); return SAMD_ERR_UNSUPPORTED;
+  }
+#undef SAMD_L2L
+}
+
+extern "C" int samd_symbol_logits2llrs_f32(const float* logits, int m, int64_t rows, const float* prior, int64_t prior_len,
+                                           int method, int hard_out, float* out, void* stream) {
+  SAMD_REQUIRE(logits && out, "null argument");
+  SAMD_REQUIRE(m >= 1 && m <= 8, "num_bits_per_symbol must be in 1..8");
+  SAMD_REQUIRE(rows >= 0 && (method == 0 || method == 1), "bad argument");
+  SAMD_REQUIRE(!prior || prior_len == m || prior_len == rows * m, "prior must be [m] or [rows, m]");
+  if (rows == 0) return SAMD_OK;
+  const dim3 grid(grid_for(rows, 256));
+  const int rc = method == 1 ? launch_logits2llrs<true>(m, grid, (hipStream_t)stream, logits, prior, prior_len, rows, hard_out, out)
+                             : launch_logits2llrs<false>(m, grid, (hipStream_t)stream, logits, prior, prior_len, rows, hard_out, out);
+  if (rc != SAMD_OK) return rc;
+  return launch_status();
+}
+
 extern "C" int samd_symbol_demap_f32(const float* y, const float* no, int64_t no_len, const float* points, int m,
                                      int64_t num_symbols, const float* prior, int64_t prior_len, int hard_out, float* out,
                                      int32_t* out_idx, void* stream) {

@@ -14,7 +14,7 @@ class GenerateFlatFadingChannel(Object):
     """``GenerateFlatFadingChannel(num_tx_ant, num_rx_ant, spatial_corr=None)(batch_size)`` ->
     h [batch_size, num_rx_ant, num_tx_ant]."""
 
-    def __init__(self, num_tx_ant, num_rx_ant, spatial_corr=None, precision=None):
+    def __init__(self, num_tx_ant, num_rx_ant, spatial_corr=None, precision=None, **kwargs):
         super().__init__(precision=precision)
         self._num_tx_ant, self._num_rx_ant = int(num_tx_ant), int(num_rx_ant)
         self.spatial_corr = spatial_corr

@@ -15,7 +15,7 @@ class GenerateOFDMChannel(Object):
     """``GenerateOFDMChannel(channel_model, resource_grid, normalize_channel=False)(batch_size)`` ->
     h_freq [batch, num_rx, num_rx_ant, num_tx, num_tx_ant, num_ofdm_symbols, fft_size]."""
 
-    def __init__(self, channel_model, resource_grid, normalize_channel=False, precision=None):
+    def __init__(self, channel_model, resource_grid, normalize_channel=False, precision=None, **kwargs):
         super().__init__(precision=precision)
         self._cir_sampler = channel_model
         self._num_ofdm_symbols = resource_grid.num_ofdm_symbols
@@ -71,7 +71,7 @@ class RayleighBlockFading(Object):
     """i.i.d. CN(0,1) single-tap block fading: a [batch, num_rx, num_rx_ant, num_tx, num_tx_ant, 1,
     num_time_steps] (constant over time), tau = 0 (rayleigh_block_fading.py:62-110)."""
 
-    def __init__(self, num_rx, num_rx_ant, num_tx, num_tx_ant, precision=None):
+    def __init__(self, num_rx, num_rx_ant, num_tx, num_tx_ant, precision=None, **kwargs):
         super().__init__(precision=precision)
         self.num_rx, self.num_rx_ant, self.num_tx, self.num_tx_ant = num_rx, num_rx_ant, num_tx, num_tx_ant
 

@@ -42,7 +42,7 @@ class GenerateTimeChannel(Object):
     num_tx_ant, num_time_samples + l_max - l_min, l_max - l_min + 1]."""
 
     def __init__(self, channel_model, bandwidth, num_time_samples, l_min, l_max, normalize_channel=False,
-                 precision=None):
+                 precision=None, **kwargs):
         super().__init__(precision=precision)
         self._cir_sampler = channel_model
         self._l_min, self._l_max = int(l_min), int(l_max)

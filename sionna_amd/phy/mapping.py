@@ -4,7 +4,7 @@
 Constellation tables are built on the host with NumPy (init time); Mapper / Demapper /
 BinarySource call the HIP kernels in ``csrc/mapping.hip`` / ``csrc/channel.hip`` through
 the C-ABI.  Out of scope: LLRs2SymbolLogits,
-SymbolLogits2Moments, QAM2PAM, PAM sources, demapping with priors.
+SymbolLogits2Moments, QAM2PAM.
 """
 import numpy as np
 import torch
@@ -369,6 +369,40 @@ class SymbolDemapper(Block):
             _ffi.ptr(prior), 0 if prior is None else prior.numel(), int(hard), _ffi.ptr(out), _ffi.ptr(idx), _ffi.stream()),
             "SymbolDemapper")
         return idx if hard else out
+
+
+class SymbolLogits2LLRs(Block):
+    """``SymbolLogits2LLRs(method, num_bits_per_symbol, *, hard_out=False)(logits [..., n, 2^m], prior=None)`` ->
+    LLRs or hard decisions [..., n, m] (reference mapping.py:794-967): for every bit the reduction (logsumexp for "app",
+    max for "maxlog") over the points whose label has the bit set minus the one over the others; ``prior`` [m] or
+    [..., n, m] LLRs enter through log_sigmoid(+-prior_i).  One launch of ``samd_symbol_logits2llrs_f32``."""
+
+    def __init__(self, method, num_bits_per_symbol, *, hard_out=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        assert method in ("app", "maxlog"), "Unknown demapping method"
+        self._method, self._hard_out, self._num_bits_per_symbol = method, hard_out, int(num_bits_per_symbol)
+
+    num_bits_per_symbol = property(lambda self: self._num_bits_per_symbol)
+
+    def call(self, logits, prior=None):
+        self._require_single()
+        m = self._num_bits_per_symbol
+        z = _ffi.to_device(logits, torch.float32).contiguous()
+        assert z.shape[-1] == 1 << m, "the last dimension of logits must be 2**num_bits_per_symbol"
+        rows = z.numel() // (1 << m)
+        out = torch.empty(tuple(z.shape[:-1]) + (m,), dtype=torch.float32, device=z.device)
+        pr, plen = None, 0
+        if prior is not None:
+            pr = _ffi.to_device(prior, torch.float32)
+            if pr.dim() > 1 or rows == 1:
+                pr = torch.broadcast_to(pr, tuple(z.shape[:-1]) + (m,))
+            pr = pr.contiguous()
+            plen = pr.numel()
+            assert plen in (m, rows * m), "prior must be [num_bits_per_symbol] or broadcastable to [..., n, num_bits_per_symbol]"
+        _ffi.check(_ffi.lib().samd_symbol_logits2llrs_f32(_ffi.ptr(z), m, rows, _ffi.ptr(pr) if pr is not None else None, plen,
+                                                          1 if self._method == "maxlog" else 0, 1 if self._hard_out else 0,
+                                                          _ffi.ptr(out), _ffi.stream()), "SymbolLogits2LLRs")
+        return out
 
 
 class BinarySource(Block):

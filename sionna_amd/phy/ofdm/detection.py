@@ -103,11 +103,11 @@ class EPDetector(Block):
 
 class KBestDetector(Block):
     """``KBestDetector(output, num_streams, k, resource_grid, stream_management, constellation_type=None,
-    num_bits_per_symbol=None, constellation=None, hard_out=False, use_real_rep=False, list2llr="default")``
+    num_bits_per_symbol=None, constellation=None, hard_out=False, use_real_rep=False, list2llr=None)``
     ``(y, h_hat, err_var, no)`` -> [batch, num_tx, num_streams, num_data_symbols * num_bits_per_symbol]."""
 
     def __init__(self, output, num_streams, k, resource_grid, stream_management, constellation_type=None,
-                 num_bits_per_symbol=None, constellation=None, hard_out=False, use_real_rep=False, list2llr="default",
+                 num_bits_per_symbol=None, constellation=None, hard_out=False, use_real_rep=False, list2llr=None,
                  precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
         from ..mimo.detection import KBestDetector as _MimoKBest

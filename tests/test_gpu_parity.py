@@ -895,3 +895,21 @@ def test_5g_chain_matches_reference_execution(phy, tag):
         assert np.array_equal(_np(x), g[f"g5_{tag}_layered_minsum_x"])
         x = D(enc, cn_update="boxplus-phi", hard_out=False, return_infobits=False, num_iter=it, cn_schedule="layered")(llr)
         assert np.mean(np.isclose(_np(x), g[f"g5_{tag}_layered_phi_x"], rtol=1e-5, atol=1e-4)) >= 0.93
+
+
+@pytest.mark.parametrize("m", [1, 2, 4, 6])
+def test_symbol_logits2llrs_block(phy, m):
+    """phy.mapping.SymbolLogits2LLRs (samd_symbol_logits2llrs_f32) against the reference's own block executed under the
+    NumPy stand-in (tests/golden/phy_ref_golden.npz) and the float64 oracle: app / maxlog, priors per row and shared."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "phy_ref_golden.npz"))
+    z, pr, pv = g[f"l2l{m}_z"], g[f"l2l{m}_prior"], g[f"l2l{m}_prior_vec"]
+    for meth in ("app", "maxlog"):
+        blk = phy.mapping.SymbolLogits2LLRs(meth, m)
+        for key, prior in (("", None), ("_prior", pr), ("_prior_vec", pv)):
+            ref = g[f"l2l{m}_{meth}{key}"]
+            got = _np(blk(z) if prior is None else blk(z, prior))
+            assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (meth, key)
+            assert np.abs(got - omap.symbol_logits2llrs(z, m, meth, prior)).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+    hard = _np(phy.mapping.SymbolLogits2LLRs("app", m, hard_out=True)(z, pr))
+    assert np.array_equal(hard.astype(np.uint8), g[f"l2l{m}_hard"])
+    assert tuple(phy.mapping.SymbolLogits2LLRs("app", m)(np.zeros((0, 1 << m), np.float32)).shape) == (0, m)

@@ -117,3 +117,16 @@ def test_ebnodb2no_and_hard_decisions_bit_exact(g):
         got = outil.ebnodb2no(e, int(m), r)
         assert np.float32(got) == no or abs(np.float32(got) - no) <= np.spacing(no), (e, m, r, got, no)
     assert np.array_equal(outil.hard_decisions(g["hard_in"]), g["hard_out"])
+
+
+@pytest.mark.parametrize("m", [1, 2, 4, 6])
+def test_symbol_logits2llrs_matches_reference_execution(g, m):
+    """SymbolLogits2LLRs as a block (mapping.py:794-967): logits on the points -> LLRs, app / maxlog, no prior, a prior per
+    row, one prior vector for all rows, hard decisions."""
+    z, pr, pv = g[f"l2l{m}_z"], g[f"l2l{m}_prior"], g[f"l2l{m}_prior_vec"]
+    for meth in ("app", "maxlog"):
+        for key, prior in (("", None), ("_prior", pr), ("_prior_vec", pv)):
+            ref = g[f"l2l{m}_{meth}{key}"]
+            got = om.symbol_logits2llrs(z, m, meth, prior)
+            assert np.abs(got - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (meth, key)
+    assert np.array_equal(om.symbol_logits2llrs(z, m, "app", pr, hard_out=True).astype(np.uint8), g[f"l2l{m}_hard"])

@@ -91,6 +91,19 @@ def main():
     llr = np.array([-2.0, -0.0, 0.0, 1e-30, 3.0, -1e-30], np.float32)
     out["hard_in"], out["hard_out"] = llr, np.asarray(utils.hard_decisions(llr))
 
+    # SymbolLogits2LLRs as a block of its own (mapping.py:794-967): logits on the points, with / without bit priors
+    for m in (1, 2, 4, 6):
+        z = (3.0 * rng.normal(size=(3, 7, 1 << m))).astype(np.float32)
+        pr_row = (2.0 * rng.normal(size=(3, 7, m))).astype(np.float32)
+        pr_vec = (2.0 * rng.normal(size=(m,))).astype(np.float32)
+        out[f"l2l{m}_z"], out[f"l2l{m}_prior"], out[f"l2l{m}_prior_vec"] = z, pr_row, pr_vec
+        for meth in ("app", "maxlog"):
+            blk = mp.SymbolLogits2LLRs(meth, m)
+            out[f"l2l{m}_{meth}"] = np.asarray(blk(z))
+            out[f"l2l{m}_{meth}_prior"] = np.asarray(blk(z, pr_row))
+            out[f"l2l{m}_{meth}_prior_vec"] = np.asarray(blk(z, pr_vec))
+        out[f"l2l{m}_hard"] = np.asarray(mp.SymbolLogits2LLRs("app", m, hard_out=True)(z, pr_row)).astype(np.uint8)
+
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(out), "arrays")
 
