@@ -163,6 +163,17 @@ class KBestDetector(Block):
             raise NotImplementedError("KBestDetector: k <= 64 on the HIP path")
         self._llr_clip_val = 20.0
 
+    @property
+    def list2llr(self):
+        """The list-to-LLR function (mimo/detection.py:757-772).  ``None`` stands for the reference's default
+        ``List2LLRSimple(num_bits_per_symbol)`` with llr_clip_val 20, which is what the kernel computes."""
+        return None
+
+    @list2llr.setter
+    def list2llr(self, value):
+        if value is not None:
+            raise NotImplementedError("KBestDetector: custom list2llr callables have no HIP path (List2LLRSimple only)")
+
     def _kernel_params(self):
         pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex64), torch.complex64)
         return pts, self._constellation.num_bits_per_symbol, self._k, self._llr_clip_val, int(self._hard_out)

@@ -172,6 +172,33 @@ class LSChannelEstimator(Block):
         self._dev = None
         self._defer = bool(kwargs.get("defer", True))          # defer=False: always materialise h_hat (tests compare the two)
 
+    def estimate_at_pilot_locations(self, y_pilots, no):
+        """LS estimates at the pilot-carrying resource elements (channel_estimation.py:257-285): y_pilots
+        [batch, num_rx, num_rx_ant, num_tx, num_streams_per_tx, num_pilot_symbols] -> (h_ls = y_pilots / pilots with
+        divide_no_nan, err_var = no / |pilots|^2 broadcastable to it).  The scaling kernel of ``call`` with an identity gather."""
+        self._require_single()
+        pp = self._rg.pilot_pattern
+        yp = _ffi.to_device(y_pilots, torch.complex64).contiguous()
+        s, npil = pp.mask.shape[0] * pp.mask.shape[1], pp.num_pilot_symbols
+        assert yp.dim() == 6 and tuple(yp.shape[3:]) == (pp.mask.shape[0], pp.mask.shape[1], npil), \
+            "y_pilots must have shape [batch, num_rx, num_rx_ant, num_tx, num_streams_per_tx, num_pilot_symbols]"
+        pil = np.asarray(pp.pilots).reshape(s, -1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = np.where(pil != 0, 1 / np.where(pil != 0, pil, 1), 0).astype(np.complex64)
+            ev = np.where(pil != 0, 1 / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(np.float32)
+        src = np.arange(s * npil, dtype=np.int32).reshape(s, npil)
+        rows = yp.shape[0] * yp.shape[1] * yp.shape[2]
+        h_ls = torch.empty_like(yp)
+        if rows and npil:
+            _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(yp), _ffi.ptr(_ffi.to_device(src, torch.int32)),
+                                                           _ffi.ptr(_ffi.to_device(inv, torch.complex64)), rows, s, npil, s * npil,
+                                                           _ffi.ptr(h_ls), _ffi.stream()), "LSChannelEstimator.estimate_at_pilot_locations")
+        no = _ffi.to_device(no, torch.float32)
+        no = no.reshape(tuple(no.shape) + (1,) * (6 - no.dim()))
+        err_var = no * _ffi.to_device(ev, torch.float32).reshape(tuple(pp.mask.shape[:2]) + (npil,))
+        from ..block import wrap
+        return wrap(h_ls), wrap(err_var)
+
     def call(self, y, no):
         self._require_single()
         rg = self._rg

@@ -1068,3 +1068,21 @@ def test_receiver_front_end_matches_reference_execution(phy, name):
     assert np.mean(np.isclose(kb.reshape(g["llr_kbest"].shape), g["llr_kbest"], rtol=1e-4, atol=1e-3)) > 0.99
     r = rel(phy.ofdm.EPDetector("bit", rg, sm, m, l=6, hard_out=False)(y, hh, ev, no), g["llr_ep"], 1.0)
     assert r.max() < 6e-2 and np.quantile(r, 0.5) < 2e-3, (r.max(), np.quantile(r, 0.5))   # (measured 2.9e-2 / 4.4e-7 and 4.5e-3 / 3.7e-4)
+
+
+def test_estimate_at_pilot_locations(phy):
+    """LSChannelEstimator.estimate_at_pilot_locations (channel_estimation.py:257-285): y at the pilots / pilots with
+    divide_no_nan, err_var = no / |pilots|^2 - against the NumPy formula and consistent with the block's own call."""
+    rg, org = _grids(phy, num_tx=1, ns=4, fft=72)
+    pp = rg.pilot_pattern
+    rng = np.random.default_rng(3)
+    B = 3
+    yp = _cplx(rng, (B, 1, 4) + tuple(pp.mask.shape[:2]) + (pp.num_pilot_symbols,))
+    no = np.array([0.1, 0.2, 0.4], np.float32)
+    h, ev = phy.ofdm.LSChannelEstimator(rg).estimate_at_pilot_locations(yp, no)
+    pil = np.asarray(pp.pilots)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ref = np.where(pil != 0, yp / np.where(pil != 0, pil, 1), 0).astype(np.complex64)
+        ref_ev = np.where(pil != 0, no[:, None, None, None, None, None] / np.where(pil != 0, np.abs(pil) ** 2, 1), 0)
+    assert np.allclose(_np(h), ref, rtol=1e-6, atol=1e-7) and np.allclose(np.broadcast_to(_np(ev), ref_ev.shape), ref_ev, rtol=1e-6)
+    assert phy.mimo.KBestDetector("bit", 2, 4, "qam", 2).list2llr is None

@@ -83,10 +83,15 @@ def main():
         found = {}
         for node in tree.body:
             if isinstance(node, ast.ClassDef) and node.name in names:
-                entry = {"kind": "class"}
+                entry = {"kind": "class", "public": []}
                 for item in node.body:
                     if isinstance(item, ast.FunctionDef) and item.name in ("__init__", "call", "__call__"):
                         entry[item.name] = params(item)
+                    if isinstance(item, ast.FunctionDef) and not item.name.startswith("_") and item.name not in ("call", "build"):
+                        is_prop = any((isinstance(d, ast.Name) and d.id == "property") or (isinstance(d, ast.Attribute) and d.attr in ("setter", "getter"))
+                                      for d in item.decorator_list)
+                        if item.name not in [q[0] for q in entry["public"]]:
+                            entry["public"].append([item.name, "property" if is_prop else "method", None if is_prop else params(item)])
                 found[node.name] = entry
             elif isinstance(node, ast.FunctionDef) and node.name in names:
                 found[node.name] = {"kind": "function", "params": params(node)}
