@@ -70,9 +70,10 @@ class SpatialCorrelation(Object, ABC):
         assert mat.shape == (m * k, m * k), "correlation matrices do not fit the channel matrices"
         out = torch.empty_like(h)
         b = h.numel() // (m * k)
+        mat_d = _ffi.to_device(np.ascontiguousarray(mat), torch.complex64)          # (held until the launch is queued)
         if b:
-            _ffi.check(_ffi.lib().samd_spatial_corr_c64(_ffi.ptr(h), _ffi.ptr(_ffi.to_device(np.ascontiguousarray(mat), torch.complex64)), b, m, k, 1,
-                                                        _ffi.ptr(out), _ffi.stream()), "spatial correlation")
+            _ffi.check(_ffi.lib().samd_spatial_corr_c64(_ffi.ptr(h), _ffi.ptr(mat_d), b, m, k, 1, _ffi.ptr(out), _ffi.stream()),
+                       "spatial correlation")
         return wrap(out)
 
 

@@ -189,9 +189,9 @@ class LSChannelEstimator(Block):
         src = np.arange(s * npil, dtype=np.int32).reshape(s, npil)
         rows = yp.shape[0] * yp.shape[1] * yp.shape[2]
         h_ls = torch.empty_like(yp)
+        src_d, inv_d = _ffi.to_device(src, torch.int32), _ffi.to_device(inv, torch.complex64)   # (alive until the launch is queued)
         if rows and npil:
-            _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(yp), _ffi.ptr(_ffi.to_device(src, torch.int32)),
-                                                           _ffi.ptr(_ffi.to_device(inv, torch.complex64)), rows, s, npil, s * npil,
+            _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(yp), _ffi.ptr(src_d), _ffi.ptr(inv_d), rows, s, npil, s * npil,
                                                            _ffi.ptr(h_ls), _ffi.stream()), "LSChannelEstimator.estimate_at_pilot_locations")
         no = _ffi.to_device(no, torch.float32)
         no = no.reshape(tuple(no.shape) + (1,) * (6 - no.dim()))
