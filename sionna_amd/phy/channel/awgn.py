@@ -23,7 +23,8 @@ class AWGN(Block):
             w = torch.empty(x.shape, dtype=torch.complex64, device=x.device)
             one = torch.ones(1, dtype=torch.float32, device=x.device)
             rng = config.rng
-            _ffi.check(_ffi.lib().samd_awgn_c64(_ffi.ptr(torch.zeros_like(w)), _ffi.ptr(one), 1, rng.seed, rng.next_call(),
+            zero = torch.zeros_like(w)                     # (a named tensor: its storage must outlive the launch call)
+            _ffi.check(_ffi.lib().samd_awgn_c64(_ffi.ptr(zero), _ffi.ptr(one), 1, rng.seed, rng.next_call(),
                                                 w.numel(), _ffi.ptr(w), _ffi.stream()), "AWGN")
             return x + w.to(torch.complex128) * torch.sqrt(no)
         x = _ffi.to_device(x, torch.complex64)

@@ -53,7 +53,8 @@ class ApplyFlatFadingChannel(Block):
         x = torch.broadcast_to(x, (b, tx)).contiguous()
         y = torch.empty((b, rx), dtype=torch.complex64, device=x.device)
         if b:
-            _ffi.check(_ffi.lib().samd_apply_ofdm_channel_c64(_ffi.ptr(x), _ffi.ptr(h.contiguous()), b, rx, tx, 1, _ffi.ptr(y),
+            h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
+            _ffi.check(_ffi.lib().samd_apply_ofdm_channel_c64(_ffi.ptr(x), _ffi.ptr(h), b, rx, tx, 1, _ffi.ptr(y),
                                                               _ffi.stream()), "ApplyFlatFadingChannel")
         if no is not None:
             y = self._awgn(y, no)

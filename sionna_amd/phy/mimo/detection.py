@@ -81,7 +81,8 @@ class MMSEPICDetector(Block):
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
         prior = torch.broadcast_to(prior, lead + (k, nb)).contiguous()
         out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
-        _ffi.check(_ffi.lib().samd_mmse_pic_f32(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), _ffi.ptr(prior),
+        h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
+        _ffi.check(_ffi.lib().samd_mmse_pic_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(prior),
                                                 _ffi.ptr(pts), y.numel() // m, m, k, nb, maxlog, num_iter, hard,
                                                 _ffi.ptr(out), _ffi.stream()), "MMSEPICDetector")
         return wrap(out)
@@ -127,7 +128,8 @@ class EPDetector(Block):
         y = torch.broadcast_to(y, lead + (m,)).contiguous()
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
         out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
-        _ffi.check(_ffi.lib().samd_ep_f32(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), _ffi.ptr(pam), y.numel() // m, m, k,
+        h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
+        _ffi.check(_ffi.lib().samd_ep_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pam), y.numel() // m, m, k,
                                           nb, l, beta, es, prec, hard, _ffi.ptr(out), _ffi.stream()), "EPDetector")
         return wrap(out)
 
@@ -191,6 +193,7 @@ class KBestDetector(Block):
         y = torch.broadcast_to(y, lead + (m,)).contiguous()
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
         out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
-        _ffi.check(_ffi.lib().samd_kbest_f32(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), _ffi.ptr(pts), y.numel() // m, m,
+        h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
+        _ffi.check(_ffi.lib().samd_kbest_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pts), y.numel() // m, m,
                                              k, nb, kk, clip, hard, _ffi.ptr(out), _ffi.stream()), "KBestDetector")
         return wrap(out)

@@ -21,7 +21,8 @@ def _equalize(y, h, s, mode, precision, name):
     n = y.numel() // m
     x_hat = torch.empty(lead + (k,), dtype=torch.complex64, device=y.device)
     no_eff = torch.empty(lead + (k,), dtype=torch.float32, device=y.device)
-    _ffi.check(_ffi.lib().samd_lmmse_equalizer_c64(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), n, m, k, int(mode),
+    h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
+    _ffi.check(_ffi.lib().samd_lmmse_equalizer_c64(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), n, m, k, int(mode),
                                                   _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.stream()), name)
     return wrap(x_hat), wrap(no_eff)
 
@@ -38,7 +39,8 @@ def _equalize_f64(y, h, s, mode, name):
     n = y.numel() // m
     x_hat = torch.empty(lead + (k,), dtype=torch.complex128, device=y.device)
     no_eff = torch.empty(lead + (k,), dtype=torch.float64, device=y.device)
-    _ffi.check(_ffi.lib().samd_lmmse_equalizer_c128(_ffi.ptr(y), _ffi.ptr(h.contiguous()), _ffi.ptr(s), n, m, k, int(mode),
+    h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
+    _ffi.check(_ffi.lib().samd_lmmse_equalizer_c128(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), n, m, k, int(mode),
                                                    _ffi.ptr(x_hat), _ffi.ptr(no_eff), _ffi.stream()), name + "(double)")
     return wrap(x_hat), wrap(no_eff)
 
