@@ -551,6 +551,21 @@ int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops,
                               float* crc_status, void* workspace, size_t workspace_bytes,
                               void* stream);
 
+/* PolarBPDecoder.call  fec/polar/decoding.py:1587-1771 (and the decoder Polar5GDecoder(dec_type="BP")
+ * instantiates, :1896-1912): num_iter flooding iterations on the polar factor graph - per iteration a
+ * left-to-right sweep over the log2(n) butterfly stages (R messages) and a right-to-left sweep (L
+ * messages), boxplus log(1+exp(x+y)) - log(exp(x)+exp(y)) on inputs clipped to +-19.3 (:1587-1603) in
+ * float32 on the library's defined exp / log.  llr [batch,n] logits (n a power of two); prior DEVICE
+ * float[n]: the right-going messages entering column 0 (19.3 at frozen positions, 0 elsewhere, :1632-1636);
+ * info_pos DEVICE int32[k].  out [batch,k]: hard_out!=0 -> bits (1 where the final LLR <= 0), else soft
+ * logits (:1719-1723).  A codeword's messages ((2 log2(n) + 1) n floats) live in LDS for n <= 1024
+ * (samd_polar_bp_workspace_bytes() == 0, workspace may be NULL); longer codes keep them in the
+ * caller-owned device workspace. */
+size_t samd_polar_bp_workspace_bytes(int batch, int n);
+int samd_polar_bp_decode_f32(const float* llr, const float* prior, const int32_t* info_pos, int batch,
+                             int n, int k, int num_iter, int hard_out, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Error counting  utils/metrics.py:94-144 (count_errors, count_block_errors).
  * b, b_hat [num_blocks, block_len] float32; counters: DEVICE int64[2], ADDED to:

@@ -359,8 +359,9 @@ class SCLDecoder:
         return c_hat[:, self.info_pos], status
 
 
-def polar5g_decode(code, llr_logits, dec_type="SC", list_size=8):
-    """Polar5GDecoder.call (polar/decoding.py:1999-2086): logits [...,n_target] -> [...,k_target]."""
+def polar5g_decode(code, llr_logits, dec_type="SC", list_size=8, num_iter=20, bp_math="spec", keep_crc=False):
+    """Polar5GDecoder.call (polar/decoding.py:1999-2086): logits [...,n_target] -> [...,k_target].
+    dec_type "BP": PolarBPDecoder with hard decisions (decoding.py:1896-1912; oracle/polar_bp.py)."""
     llr = np.asarray(llr_logits, F)
     lead = llr.shape[:-1]
     llr = llr.reshape(-1, code.n_target)
@@ -378,8 +379,13 @@ def polar5g_decode(code, llr_logits, dec_type="SC", list_size=8):
     iil_inv = np.argsort(code.ind_input_int) if code.channel_type == "downlink" else None
     if dec_type == "SC":
         u_crc = sc_decode(dec_in, code.frozen_pos, npol)
+    elif dec_type == "BP":
+        from .polar_bp import bp_decode
+        u_crc = bp_decode(dec_in, code.frozen_pos, npol, num_iter, True, bp_math)
     else:
         u_crc, _ = SCLDecoder(code.frozen_pos, npol, list_size, code.crc_degree, ind_iil_inv=iil_inv).decode(dec_in)
     if iil_inv is not None:
         u_crc = u_crc[:, iil_inv]
+    if keep_crc:                                                       # the decisions with their CRC bits (status checks)
+        return u_crc
     return u_crc[:, :-code.k_crc].reshape(lead + (code.k_target,))

@@ -103,6 +103,8 @@ _SIGNATURES = {
     "samd_polar_scl_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "samd_polar_scl_decode_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i32, _vp, _vp,
                                          _vp, _sz, _vp]),
+    "samd_polar_bp_workspace_bytes": (_sz, [_i32, _i32]),
+    "samd_polar_bp_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "samd_count_errors_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "samd_ofdm_lsnn_lmmse_c64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                         _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

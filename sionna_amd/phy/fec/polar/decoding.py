@@ -1,13 +1,13 @@
-"""Polar decoders - mirror of ``sionna.phy.fec.polar.PolarSCDecoder`` / ``PolarSCLDecoder`` /
-``Polar5GDecoder`` (reference src/sionna/phy/fec/polar/decoding.py:15-263, 266-1437, 1774-2086).
+"""Polar decoders - mirror of ``sionna.phy.fec.polar.PolarSCDecoder`` / ``PolarSCLDecoder`` / ``PolarBPDecoder`` /
+``Polar5GDecoder`` (reference src/sionna/phy/fec/polar/decoding.py:15-263, 266-1437, 1440-1771, 1774-2086).
 
 The decoding tree of the reference's recursion (decoding.py:919-1005, with the fast-SCL
 rate-0 / repetition shortcuts of :525-599) is flattened ONCE on the host into a list of operations
 that ``samd_polar_scl_decode_f32`` interprets with one wave per codeword: the engine of
 csrc/polar_scl_reg.hip (SC and list sizes 1..32 at n >= 64: low tree stages in registers, whole sub-trees as
 one schedule record) or the generic engine of csrc/polar.hip (everything in LDS / L2 scratch).  The hybrid
-mode runs SC first and the list decoder on the words whose CRC fails, like the reference; BP decoding is
-outside the hot path."""
+mode runs SC first and the list decoder on the words whose CRC fails, like the reference.  ``PolarBPDecoder`` is
+``samd_polar_bp_decode_f32`` (csrc/polar_bp.hip): the whole iterative decode of a codeword in the LDS of one workgroup."""
 import numbers
 
 import numpy as np
@@ -245,6 +245,93 @@ class PolarSCLDecoder(_PolarListDecoderBase):
         return u_hat
 
 
+class PolarBPDecoder(Block):
+    """``PolarBPDecoder(frozen_pos, n, num_iter=20, hard_out=True)(llr_ch[..., n]) -> u_hat[..., k]``
+    (decoding.py:1440-1771): flooding belief propagation on the polar factor graph, boxplus evaluated literally on
+    inputs clipped to +-19.3 (:1587-1603); hard bits or soft logits of the k information positions.  One launch of
+    ``samd_polar_bp_decode_f32`` runs all iterations (the reference notes that unrolling its graph "can become time and
+    memory consuming" - here the messages of a codeword never leave LDS up to n = 1024)."""
+
+    def __init__(self, frozen_pos, n, num_iter=20, hard_out=True, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        if not isinstance(n, numbers.Number):
+            raise TypeError("n must be a number.")
+        n = int(n)
+        frozen_pos = np.asarray(frozen_pos)
+        if not np.issubdtype(frozen_pos.dtype, np.integer):
+            raise TypeError("frozen_pos contains non int.")
+        if len(frozen_pos) > n:
+            raise ValueError("Num. of elements in frozen_pos cannot be greater than n.")
+        if np.log2(n) != int(np.log2(n)):
+            raise ValueError("n must be a power of 2.")
+        if not isinstance(hard_out, bool):
+            raise TypeError("hard_out must be boolean.")
+        self._n = n
+        self._frozen_pos = frozen_pos
+        self._k = n - len(frozen_pos)
+        self._info_pos = np.setdiff1d(np.arange(n), frozen_pos)
+        if self._k != len(self._info_pos):
+            raise ArithmeticError("Internal error: invalid info_pos generated.")
+        if not isinstance(num_iter, int):
+            raise TypeError("num_iter must be integer.")
+        if num_iter <= 0:
+            raise ValueError("num_iter must be a positive value.")
+        self._num_iter = num_iter
+        self._llr_max = 19.3
+        self._hard_out = hard_out
+        self._n_stages = int(np.log2(n))
+        self._dev = None
+        self._ws = None
+
+    n = property(lambda self: self._n)
+    k = property(lambda self: self._k)
+    frozen_pos = property(lambda self: self._frozen_pos)
+    info_pos = property(lambda self: self._info_pos)
+    llr_max = property(lambda self: self._llr_max)
+    hard_out = property(lambda self: self._hard_out)
+
+    @property
+    def num_iter(self):
+        return self._num_iter
+
+    @num_iter.setter
+    def num_iter(self, num_iter):
+        if not isinstance(num_iter, int):
+            raise ValueError("num_iter must be int.")
+        if num_iter < 0:
+            raise ValueError("num_iter cannot be negative.")
+        self._num_iter = num_iter
+
+    def build(self, input_shape):
+        if input_shape[-1] != self._n:
+            raise ValueError("Invalid input shape")
+
+    def call(self, llr_ch):
+        self._require_single()
+        llr = _ffi.to_device(llr_ch, torch.float32)
+        if llr.shape[-1] != self._n:
+            raise ValueError("Invalid input shape")
+        if self._num_iter < 1:
+            raise ValueError("num_iter must be a positive value.")
+        if self._dev is None:
+            prior = np.zeros(self._n, np.float32)
+            prior[self._frozen_pos] = np.float32(self._llr_max)        # decoding.py:1632-1636
+            self._dev = (_ffi.to_device(prior, torch.float32),
+                         _ffi.to_device(np.ascontiguousarray(self._info_pos, np.int32), torch.int32))
+        prior, info = self._dev
+        llr2d = llr.reshape(-1, self._n)
+        b = llr2d.shape[0]
+        u_hat = torch.empty((b, self._k), dtype=torch.float32, device=llr.device)
+        if b > 0:
+            if self._ws is None:
+                self._ws = _ffi.Workspace()
+            ws, ws_bytes = self._ws.get(_ffi.lib().samd_polar_bp_workspace_bytes(b, self._n))
+            _ffi.check(_ffi.lib().samd_polar_bp_decode_f32(
+                _ffi.ptr(llr2d), _ffi.ptr(prior), _ffi.ptr(info), b, self._n, self._k, self._num_iter, int(self._hard_out),
+                _ffi.ptr(u_hat), _ffi.ptr(ws), ws_bytes, _ffi.stream()), "PolarBPDecoder")
+        return u_hat.reshape(tuple(llr.shape[:-1]) + (self._k,))
+
+
 class Polar5GDecoder(Block):
     """``Polar5GDecoder(enc_polar, dec_type="SC", list_size=8, num_iter=20, return_crc_status=False)``:
     rate recovery (channel de-interleaving, repetition combining / puncturing zeros / shortening
@@ -280,7 +367,13 @@ class Polar5GDecoder(Block):
                                               list_size=list_size, use_hybrid_sc=True, ind_iil_inv=self._ind_iil_inv,
                                               precision=precision)
         elif dec_type == "BP":
-            raise NotImplementedError("Polar5GDecoder: dec_type 'BP' is outside the MI355X hot path (SC / SCL / hybSCL)")
+            if not isinstance(num_iter, int):
+                raise TypeError("num_iter must be int.")
+            if num_iter <= 0:
+                raise ValueError("num_iter must be positive.")
+            self._num_iter = num_iter
+            self._polar_dec = PolarBPDecoder(enc_polar.frozen_pos, self._n_polar, num_iter=num_iter, hard_out=True,
+                                             precision=precision)
         else:
             raise ValueError("Unknown value for dec_type.")
         self._dec_crc = CRCDecoder(enc_polar.enc_crc, precision=precision) if return_crc_status else None

@@ -19,7 +19,7 @@ SURFACE = {      # reference file -> (import path in sionna.phy, names)
     "fec/ldpc/decoding.py": ("fec.ldpc", ["LDPCBPDecoder", "LDPC5GDecoder", "vn_update_sum", "cn_update_minsum", "cn_update_offset_minsum",
                                           "cn_update_phi", "cn_update_tanh"]),
     "fec/polar/encoding.py": ("fec.polar", ["PolarEncoder", "Polar5GEncoder"]),
-    "fec/polar/decoding.py": ("fec.polar", ["PolarSCDecoder", "PolarSCLDecoder", "Polar5GDecoder"]),
+    "fec/polar/decoding.py": ("fec.polar", ["PolarSCDecoder", "PolarSCLDecoder", "PolarBPDecoder", "Polar5GDecoder"]),
     "fec/polar/utils.py": ("fec.polar.utils", ["generate_5g_ranking", "generate_rm_code"]),
     "fec/crc.py": ("fec.crc", ["CRCEncoder", "CRCDecoder"]),
     "fec/scrambling.py": ("fec.scrambling", ["Scrambler", "TB5GScrambler", "Descrambler"]),

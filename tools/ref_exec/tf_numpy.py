@@ -256,6 +256,20 @@ def make_tf():
     tf.tile = lambda x, multiples, **k: _t(np.tile(np.asarray(x), [int(m) for m in multiples]))
     tf.broadcast_to = lambda x, shape, **k: _t(np.broadcast_to(np.asarray(x), [int(s) for s in shape]).copy())
 
+    class TensorArray:
+        """tf.TensorArray: write() returns the array (the reference rebinds it), read() the stored tensor (PolarBPDecoder)."""
+
+        def __init__(self, dtype, size=0, dynamic_size=False, clear_after_read=True, **k):
+            self._items = {}
+
+        def write(self, index, value):
+            self._items[int(np.asarray(index))] = _t(np.array(value, copy=True))
+            return self
+
+        def read(self, index):
+            return self._items[int(np.asarray(index))]
+    tf.TensorArray = TensorArray
+
     def _slice(x, begin, size, name=None):
         x = np.asarray(x)
         idx = tuple(slice(int(b), None if int(s) == -1 else int(b) + int(s)) for b, s in zip(begin, size))
