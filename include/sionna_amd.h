@@ -214,6 +214,24 @@ int samd_symbol_demap_f32(const float* y, const float* no, int64_t no_len, const
 int samd_symbol_logits2llrs_f32(const float* logits, int m, int64_t rows, const float* prior, int64_t prior_len,
                                 int method, int hard_out, float* out, void* stream);
 
+/* LLRs2SymbolLogits.call  mapping.py:969-1058: llrs [rows, m] -> out [rows, 2^m], logit of point c =
+ * sum_j log_sigmoid(+-llr_j) (+ where bit j of c's label - the binary representation of c, MSB first - is 1);
+ * hard_out: out_idx [rows] int32 = first maximum of the row (tf.argmax), out may be NULL.  m in 1..8. */
+int samd_llrs2symbol_logits_f32(const float* llrs, int m, int64_t rows, int hard_out, float* out,
+                                int32_t* out_idx, void* stream);
+
+/* SymbolLogits2Moments.call  mapping.py:1061-1138: logits [rows, 2^m], points DEVICE complex64[2^m] ->
+ * mean complex64 [rows] = sum_c softmax(logits)_c x_c, var float [rows] = sum_c softmax_c |x_c - mean|^2. */
+int samd_symbol_logits2moments_c64(const float* logits, const float* points, int m, int64_t rows,
+                                   float* mean, float* var, void* stream);
+
+/* PAM2QAM.__call__ on logits (hard_in_out=False)  mapping.py:1234-1314: pam1, pam2 [rows, 2^(nb/2)] logits of
+ * the real / imaginary PAM constellation -> out [rows, 2^nb]: the matrix pam1_i + pam2_j flattened and gathered
+ * with the table of interleaved labels, out[i P + j] = (pam1 (+) pam2)[t(i, j)] - the reference's expression,
+ * literally (see csrc/mapping.hip).  nb = num_bits_per_symbol of the QAM constellation, even, 2..10. */
+int samd_pam2qam_logits_f32(const float* pam1, const float* pam2, int num_bits_per_symbol, int64_t rows,
+                            float* out, void* stream);
+
 /* Demapper.call with prior knowledge on the bits (mapping.py:664-691, 927-967): as samd_qam_demap_f32 with
  * the a-priori term sum_i log_sigmoid(+-prior_i) added to the exponent of every point.  prior DEVICE
  * float LLRs, [m] (shared by all symbols) or [num_symbols, m]. */
@@ -333,8 +351,13 @@ int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const float* err_
 int samd_gf2_encode_f32(const float* u, const uint32_t* gm_cols, int64_t batch, int k, int n,
                         float* out, void* stream);
 
-/* EPDetector.call  mimo/detection.py:1229-1312, output="bit" (expectation propagation, l iterations,
- * damping beta): y [n,m], h [n,m,k], s [n,m,m] -> out [n,k,num_bits_per_symbol] max-log LLRs.
+/* EPDetector.call  mimo/detection.py:1229-1312 (expectation propagation, l iterations, damping beta):
+ * y [n,m], h [n,m,k], s [n,m,m] -> out [n,k,W].  hard_out selects the output of :1272-1312:
+ *   0  max-log LLRs, W = num_bits_per_symbol          (output="bit")
+ *   1  hard bits, W = num_bits_per_symbol              (output="bit", hard_out=True)
+ *   2  logits of the real and the imaginary PAM constellation, W = 2 * 2^(num_bits_per_symbol/2): [2][P]
+ *      (output="symbol": samd_pam2qam_logits_f32 forms the QAM logits from them)
+ *   3  QAM point index (as a float) of the two PAM argmax decisions, W = 1  (output="symbol", hard_out=True)
  * pam_points DEVICE float[2^(num_bits_per_symbol/2)]: unit-energy Gray PAM points / sqrt(2) in label
  * order; es = their variance; prec = numerical floor (1e-6 in single precision). */
 int samd_ep_f32(const float* y, const float* h, const float* s, const float* pam_points, int64_t n,
@@ -342,7 +365,7 @@ int samd_ep_f32(const float* y, const float* h, const float* s, const float* pam
                 int hard_out, float* out, void* stream);
 
 /* ofdm.EPDetector.call  ofdm/detection.py (OFDMDetector pre-processing + the detector above).
- * out [batch, num_streams_total, num_data * num_bits_per_symbol]. */
+ * out [batch, num_streams_total, num_data * W], W and hard_out as for samd_ep_f32. */
 int samd_ofdm_ep_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode,
                      const float* no, const float* pam_points, const int32_t* sc_ind,
                      const int32_t* desired, const int32_t* undesired, const int32_t* data_pos, int batch,

@@ -133,3 +133,68 @@ def symbol_logits2llrs(logits, num_bits_per_symbol, method="app", prior=None, ha
     red = (lambda v: _logsumexp(v, -2)) if method == "app" else (lambda v: np.max(v, axis=-2))
     llr = red(z[..., c1]) - red(z[..., c0])
     return (llr > 0).astype(np.float32) if hard_out else llr
+
+
+# ------------------------------------------------------------------ bit LLRs <-> point logits, moments, index tables
+def _labels(num_bits):
+    """[2^num_bits, num_bits]: binary representation of the index, MSB first (mapping.py:1031-1034, 1165-1170)."""
+    return (np.arange(1 << num_bits)[:, None] >> np.arange(num_bits - 1, -1, -1)[None, :]) & 1
+
+
+def llrs2symbol_logits(llrs, num_bits_per_symbol, hard_out=False):
+    """LLRs2SymbolLogits.call (mapping.py:1043-1058) in float64: llrs [..., m] -> logits [..., 2^m] = sum_j
+    log_sigmoid(a_cj llr_j), a = +-1 labels; hard_out: argmax (first maximum) as int32."""
+    a = 2.0 * _labels(num_bits_per_symbol) - 1.0
+    x = a * np.asarray(llrs, np.float64)[..., None, :]
+    ls = np.where(x < 0, x - np.log1p(np.exp(np.minimum(x, 0))), -np.log1p(np.exp(-np.maximum(x, 0))))
+    logits = np.sum(ls, axis=-1)
+    return np.argmax(logits, axis=-1).astype(np.int32) if hard_out else logits
+
+
+def symbol_logits2moments(logits, points):
+    """SymbolLogits2Moments.call (mapping.py:1125-1138) in float64 -> (mean complex [...], var [...])."""
+    z = np.asarray(logits, np.float64)
+    p = np.exp(z - z.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    pts = np.asarray(points, np.complex128)
+    mean = np.sum(p * pts, -1)
+    var = np.sum(p * np.abs(pts - mean[..., None]) ** 2, -1)
+    return mean, var
+
+
+def symbol_inds2bits(ind, num_bits_per_symbol):
+    """SymbolInds2Bits.call (mapping.py:1177-1178)."""
+    return _labels(num_bits_per_symbol)[np.asarray(ind)].astype(np.float32)
+
+
+def qam2pam(ind_qam, num_bits_per_symbol):
+    """QAM2PAM.__call__ (mapping.py:1212-1231): even label bits -> pam1 index, odd label bits -> pam2 index."""
+    lab = _labels(num_bits_per_symbol)
+    base = 1 << np.arange(num_bits_per_symbol // 2 - 1, -1, -1)
+    t1, t2 = np.sum(lab[:, 0::2] * base, -1), np.sum(lab[:, 1::2] * base, -1)
+    q = np.asarray(ind_qam)
+    return t1[q].astype(np.int32), t2[q].astype(np.int32)
+
+
+def pam2qam_table(num_bits_per_symbol):
+    """qam_ind[i, j] of PAM2QAM.__init__ (mapping.py:1278-1291): the QAM index whose label interleaves those of i and j."""
+    nbh = num_bits_per_symbol // 2
+    lab = _labels(nbh)
+    P = 1 << nbh
+    b = np.zeros([P, P, num_bits_per_symbol], np.int64)
+    b[:, :, 0::2] = lab[:, None, :]
+    b[:, :, 1::2] = lab[None, :, :]
+    return np.sum(b * (1 << np.arange(num_bits_per_symbol - 1, -1, -1)), -1)
+
+
+def pam2qam(pam1, pam2, num_bits_per_symbol, hard_in_out=True):
+    """PAM2QAM.__call__ (mapping.py:1293-1314).  Indices: table lookup.  Logits: the P x P matrix pam1_i + pam2_j flattened
+    and GATHERED with the flattened table - the reference's expression, literally (for 64-QAM and above the bit
+    permutation is not an involution, so this is not the scatter one might expect; parity follows the reference)."""
+    tab = pam2qam_table(num_bits_per_symbol)
+    if hard_in_out:
+        return tab[np.asarray(pam1), np.asarray(pam2)].astype(np.int32)
+    a, b = np.asarray(pam1), np.asarray(pam2)
+    mat = a[..., :, None] + b[..., None, :]
+    flat = mat.reshape(mat.shape[:-2] + (-1,))
+    return flat[..., tab.reshape(-1)]

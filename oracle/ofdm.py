@@ -381,11 +381,19 @@ def _bit_labels(nb):
     return ((p[:, None] >> (nb - 1 - np.arange(nb))[None, :]) & 1).astype(np.float64)       # [P, nb], MSB first
 
 
-def mmse_pic(y, h, s, prior, points, method="maxlog", num_iter=1, hard_out=False):
-    """MMSEPICDetector.call, output="bit" (mimo/detection.py:1496-1643) in float64.
-    y [...,M], h [...,M,K], s [...,M,M], prior [...,K,nb] -> extrinsic LLRs [...,K,nb]."""
+def mmse_pic(y, h, s, prior, points, method="maxlog", num_iter=1, hard_out=False, output="bit"):
+    """MMSEPICDetector.call (mimo/detection.py:1496-1643) in float64.
+    y [...,M], h [...,M,K], s [...,M,M], prior [...,K,nb] -> extrinsic LLRs [...,K,nb] (output="bit"); output="symbol":
+    prior = logits [...,K,2^nb] turned into LLRs by SymbolLogits2LLRs(method) (:1523-1524), result = LLRs2SymbolLogits of
+    the extrinsic LLRs, logits [...,K,2^nb] or with hard_out their argmax [...,K] (:1636-1637)."""
     y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
     points = np.asarray(points, np.complex128)
+    if output == "symbol":
+        from .mapping import symbol_logits2llrs, llrs2symbol_logits
+        nbs = int(np.log2(len(points)))
+        llr_e = mmse_pic(y, h, s, symbol_logits2llrs(prior, nbs, method), points, method, num_iter, False).astype(np.float64)
+        out = llrs2symbol_logits(llr_e, nbs, hard_out)
+        return out if hard_out else out.astype(np.float32)
     nb = prior.shape[-1]
     K = h.shape[-1]
     lab = _bit_labels(nb)
@@ -430,13 +438,17 @@ def mmse_pic(y, h, s, prior, points, method="maxlog", num_iter=1, hard_out=False
     return (llr_e > 0).astype(np.float32) if hard_out else llr_e.astype(np.float32)
 
 
-def ofdm_mmse_pic(rg, sm, y, h_hat, prior, err_var, no, points, method="maxlog", num_iter=1, hard_out=False):
-    """ofdm.MMSEPICDetector.call, output="bit" (ofdm/detection.py:448-560, 1062-1230).
-    prior [B,tx,streams,num_data*nb] -> LLRs of the same shape."""
+def ofdm_mmse_pic(rg, sm, y, h_hat, prior, err_var, no, points, method="maxlog", num_iter=1, hard_out=False, output="bit"):
+    """ofdm.MMSEPICDetector.call (ofdm/detection.py:448-560, 1062-1230).
+    output="bit": prior [B,tx,streams,num_data*nb] -> LLRs of the same shape; output="symbol": prior
+    [B,tx,streams,num_data,num_points] logits (zero off the data REs, :531-541) -> logits of the same shape or, with
+    hard_out, indices [B,tx,streams,num_data]."""
     nb = int(np.log2(len(points)))
     B = y.shape[0]
     y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
     T, F = rg.num_ofdm_symbols, rg.num_effective_subcarriers
+    if output == "symbol":
+        nb = len(points)                                   # the prior's last dimension: one logit per point
     pr = prior.reshape(B, sm.num_tx, rg.num_streams_per_tx, -1, nb)
     grid = np.zeros((B, sm.num_tx, rg.num_streams_per_tx, T * F, nb), np.float32)         # zero prior off the data REs
     di = data_ind(rg.pilot_pattern)
@@ -447,9 +459,9 @@ def ofdm_mmse_pic(rg, sm, y, h_hat, prior, err_var, no, points, method="maxlog",
     desired = np.asarray(sm.detection_desired_ind).reshape(sm.num_rx, sm.num_streams_per_rx) % grid.shape[1]
     pri = np.stack([grid[:, desired[r]] for r in range(sm.num_rx)], axis=1)               # [B,rx,K,T,F,nb]
     pri = np.transpose(pri, [0, 1, 3, 4, 2, 5])
-    llr = mmse_pic(y_dt, hd, s, pri, points, method, num_iter, hard_out)                  # [B,rx,T,F,K,nb]
+    llr = mmse_pic(y_dt, hd, s, pri, points, method, num_iter, hard_out, output=output)   # [B,rx,T,F,K,nb]
     out = _extract_data(rg, sm, llr, B)                                                   # [B,tx,s,ND,nb]
-    return out.reshape(out.shape[:3] + (-1,))
+    return out if output == "symbol" else out.reshape(out.shape[:3] + (-1,))
 
 
 # ------------------------------------------------------------------ time-domain variant
@@ -621,9 +633,10 @@ def _pam_points_over_sqrt2(nbh):
     return pts / np.sqrt(2.0)
 
 
-def ep_detector(y, h, s, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, prec=1e-6):
-    """EPDetector.call, output="bit" (mimo/detection.py:1166-1312) in float64.
-    y [...,M], h [...,M,K], s [...,M,M] -> max-log LLRs [...,K,num_bits_per_symbol]."""
+def ep_detector(y, h, s, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, prec=1e-6, output="bit"):
+    """EPDetector.call (mimo/detection.py:1166-1312) in float64.
+    y [...,M], h [...,M,K], s [...,M,M] -> max-log LLRs [...,K,num_bits_per_symbol] (output="bit"), or QAM logits
+    [...,K,2^num_bits_per_symbol] / QAM indices [...,K] through PAM2QAM (output="symbol", :1276-1295)."""
     nbh = num_bits_per_symbol // 2
     pts = _pam_points_over_sqrt2(nbh)
     es = np.var(pts)
@@ -655,22 +668,28 @@ def ep_detector(y, h, s, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, pr
         keep = lam_n < 0
         lam_n, gam_n = np.where(keep, lam, lam_n), np.where(keep, gam, gam_n)
         lam, gam = (1 - beta) * lam_n + beta * lam, (1 - beta) * gam_n + beta * gam
+    if output == "symbol":
+        from .mapping import pam2qam
+        if hard_out:
+            return pam2qam(np.argmax(logits[..., :K, :], -1), np.argmax(logits[..., K:, :], -1), num_bits_per_symbol, True)
+        return pam2qam(logits[..., :K, :], logits[..., K:, :], num_bits_per_symbol, False).astype(np.float32)
     lab = _bit_labels(nbh).T.astype(bool)                                          # [nbh, P]
     llr = np.stack([logits[..., lab[b]].max(-1) - logits[..., ~lab[b]].max(-1) for b in range(nbh)], -1)   # [..., 2K, nbh]
     llr = np.stack([llr[..., :K, :], llr[..., K:, :]], -1).reshape(llr.shape[:-2] + (K, 2 * nbh))
     return (llr > 0).astype(np.float32) if hard_out else llr.astype(np.float32)
 
 
-def ofdm_ep_detector(rg, sm, y, h_hat, err_var, no, num_bits_per_symbol, l=10, beta=0.9, hard_out=False):
-    """ofdm.EPDetector.call, output="bit" -> [B,tx,streams,num_data*num_bits_per_symbol]."""
+def ofdm_ep_detector(rg, sm, y, h_hat, err_var, no, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, output="bit"):
+    """ofdm.EPDetector.call -> [B,tx,streams,num_data*num_bits_per_symbol] (output="bit"), or the logits
+    [B,tx,streams,num_data,num_points] / indices [B,tx,streams,num_data] of output="symbol" (ofdm/detection.py:289-317)."""
     y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
-    llr = ep_detector(y_dt, hd, s, num_bits_per_symbol, l, beta, hard_out)
+    llr = ep_detector(y_dt, hd, s, num_bits_per_symbol, l, beta, hard_out, output=output)
     out = _extract_data(rg, sm, llr, y.shape[0])
-    return out.reshape(out.shape[:3] + (-1,))
+    return out if output == "symbol" else out.reshape(out.shape[:3] + (-1,))
 
 
 # ------------------------------------------------------------------ K-Best detector
-def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0):
+def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0, output="bit"):
     """KBestDetector.call (complex representation, mimo/detection.py:815-1037) + List2LLRSimple
     (mimo/utils.py:539-578) in float64: y [n,M], h [n,M,K], s [n,M,M] -> LLRs [n,K,nb]."""
     y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
@@ -701,6 +720,9 @@ def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0):
     inds = inds[:, :, ::-1]                                                                    # sorted-column order
     unsort = np.argsort(order, axis=-1, kind="stable")
     inds = np.take_along_axis(inds, unsort[:, None, :], axis=2)                                # original stream order
+    if output == "symbol":                                                                     # :1001-1019 (hard decisions only, :799-801)
+        assert hard_out, "Soft-symbols are not supported for this detector."
+        return inds[:, 0].astype(np.int32)
     bits = (inds[..., None] >> (nb - 1 - np.arange(nb))) & 1                                   # [n, paths, K, nb]
     if hard_out:
         return bits[:, 0].astype(np.float32)
@@ -711,14 +733,15 @@ def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0):
         return np.clip(l0 - l1, -llr_clip, llr_clip).astype(np.float32)
 
 
-def ofdm_kbest_detector(rg, sm, y, h_hat, err_var, no, points, k, hard_out=False):
-    """ofdm.KBestDetector.call, output="bit" -> [B,tx,streams,num_data*nb]."""
+def ofdm_kbest_detector(rg, sm, y, h_hat, err_var, no, points, k, hard_out=False, output="bit"):
+    """ofdm.KBestDetector.call -> [B,tx,streams,num_data*nb] (output="bit") or indices [B,tx,streams,num_data]
+    (output="symbol", hard decisions)."""
     y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
     shp = hd.shape[:-2]
     llr = kbest_detector(y_dt.reshape((-1,) + y_dt.shape[-1:]), hd.reshape((-1,) + hd.shape[-2:]),
-                         s.reshape((-1,) + s.shape[-2:]), points, k, hard_out)
-    out = _extract_data(rg, sm, llr.reshape(shp + llr.shape[-2:]), y.shape[0])
-    return out.reshape(out.shape[:3] + (-1,))
+                         s.reshape((-1,) + s.shape[-2:]), points, k, hard_out, output=output)
+    out = _extract_data(rg, sm, llr.reshape(shp + llr.shape[1:]), y.shape[0])
+    return out if output == "symbol" else out.reshape(out.shape[:3] + (-1,))
 
 
 # ------------------------------------------------------------------ ZF / MF equalisers

@@ -62,6 +62,9 @@ _SIGNATURES = {
     "samd_qam_demap_prior_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
     "samd_symbol_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
     "samd_symbol_logits2llrs_f32": (_i32, [_vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_llrs2symbol_logits_f32": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "samd_symbol_logits2moments_c64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "samd_pam2qam_logits_f32": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "samd_square_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
     "samd_binary_source_f32": (_i32, [_u64, _u64, _i64, _vp, _vp]),
     "samd_awgn_c64": (_i32, [_vp, _vp, _i64, _u64, _u64, _i64, _vp, _vp]),

@@ -386,6 +386,129 @@ extern "C" int samd_symbol_logits2llrs_f32(const float* logits, int m, int64_t r
   return launch_status();
 }
 
+// ------------------------------------------------------------------ bit LLRs <-> point logits, moments, PAM -> QAM
+// log_sigmoid in the form the demapper kernels above use for the a-priori terms
+__device__ __forceinline__ float log_sigmoid_f32(float p) { return p < 0.f ? p - log1pf(expf(p)) : -log1pf(expf(-p)); }
+
+// LLRs2SymbolLogits.call (mapping.py:1043-1058): logit of point c = sum_j log_sigmoid(+-llr_j), + where bit j of the label of
+// c (binary representation of c, MSB first) is 1.  A workgroup takes 64 rows: the 2 m log-sigmoids of a row are evaluated
+// once into LDS, then every lane forms outputs of the [64, 2^m] tile in storage order (coalesced stores; the output is
+// 2^m / m times the input, so the kernel is bound by its writes).  hard_out: the first maximum of the row (tf.argmax),
+// from the same sums.
+__global__ __launch_bounds__(256) void llrs2logits_kernel(const float* __restrict__ llrs, int m, int64_t rows, int hard_out,
+                                                          float* __restrict__ out, int32_t* __restrict__ out_idx) {
+  __shared__ float ls[64][8][2];
+  const int P = 1 << m;
+  for (int64_t row0 = (int64_t)blockIdx.x * 64; row0 < rows; row0 += (int64_t)gridDim.x * 64) {
+    const int nr = (int)(rows - row0 < 64 ? rows - row0 : 64);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nr * m; e += 256) {
+      const float l = llrs[row0 * m + e];
+      ls[e / m][e % m][1] = log_sigmoid_f32(l);
+      ls[e / m][e % m][0] = log_sigmoid_f32(-l);
+    }
+    __syncthreads();
+    if (!hard_out) {
+      for (int e = threadIdx.x; e < nr * P; e += 256) {
+        const int r = e >> m, c = e & (P - 1);
+        float acc = 0.f;
+        for (int j = 0; j < m; ++j) acc += ls[r][j][(c >> (m - 1 - j)) & 1];
+        out[row0 * P + e] = acc;
+      }
+    } else if ((int)threadIdx.x < nr) {
+      const int r = threadIdx.x;
+      float best = -INFINITY;
+      int bi = 0;
+      for (int c = 0; c < P; ++c) {
+        float acc = 0.f;
+        for (int j = 0; j < m; ++j) acc += ls[r][j][(c >> (m - 1 - j)) & 1];
+        if (acc > best) { best = acc; bi = c; }
+      }
+      out_idx[row0 + r] = bi;
+    }
+  }
+}
+
+// SymbolLogits2Moments.call (mapping.py:1125-1138): p = softmax(logits), mean = sum_c p_c x_c, var = sum_c p_c |x_c - mean|^2.
+// One thread per row of 2^m logits (three passes over a row that stays in L1 / L2, like logits2llrs_kernel); points in LDS.
+__global__ __launch_bounds__(256) void logits2moments_kernel(const float* __restrict__ logits, const float2* __restrict__ points,
+                                                             int P, int64_t rows, float2* __restrict__ mean,
+                                                             float* __restrict__ var) {
+  extern __shared__ float2 mom_pts[];
+  for (int c = threadIdx.x; c < P; c += 256) mom_pts[c] = points[c];
+  __syncthreads();
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < rows; s += (int64_t)gridDim.x * blockDim.x) {
+    const float* z = logits + s * P;
+    float mx = -INFINITY;
+    for (int c = 0; c < P; ++c) mx = fmaxf(mx, z[c]);
+    float den = 0.f;
+    for (int c = 0; c < P; ++c) den += expf(z[c] - mx);
+    float mr = 0.f, mi = 0.f;
+    for (int c = 0; c < P; ++c) {
+      const float pc = expf(z[c] - mx) / den;
+      mr += pc * mom_pts[c].x;
+      mi += pc * mom_pts[c].y;
+    }
+    float v = 0.f;
+    for (int c = 0; c < P; ++c) {
+      const float pc = expf(z[c] - mx) / den;
+      const float dr = mom_pts[c].x - mr, di = mom_pts[c].y - mi;
+      v += pc * (dr * dr + di * di);
+    }
+    mean[s] = make_float2(mr, mi);
+    var[s] = v;
+  }
+}
+
+// PAM2QAM.__call__ with hard_in_out=False (mapping.py:1304-1314), LITERALLY: the P x P matrix pam1_i + pam2_j is flattened
+// (index i P + j) and GATHERED with the table t(i, j) = QAM index whose label interleaves the labels of i and j:
+// out[i P + j] = pam1[t >> nbh] + pam2[t & (P - 1)].  (For 4- and 16-QAM this places pam1_i + pam2_j at QAM index t(i, j);
+// for 64-QAM and above the bit permutation is not its own inverse and the reference's output is this gather - kept.)
+__global__ __launch_bounds__(256) void pam2qam_logits_kernel(const float* __restrict__ pam1, const float* __restrict__ pam2,
+                                                             int nbh, int64_t rows, float* __restrict__ out) {
+  const int P = 1 << nbh, Q = P * P;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < rows * Q; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / Q;
+    const int c = (int)(e - r * Q), i = c >> nbh, j = c & (P - 1);
+    int t = 0;
+    for (int b = 0; b < nbh; ++b)
+      t |= (((i >> (nbh - 1 - b)) & 1) << (2 * nbh - 1 - 2 * b)) | (((j >> (nbh - 1 - b)) & 1) << (2 * nbh - 2 - 2 * b));
+    out[e] = pam1[r * P + (t >> nbh)] + pam2[r * P + (t & (P - 1))];
+  }
+}
+
+extern "C" int samd_llrs2symbol_logits_f32(const float* llrs, int m, int64_t rows, int hard_out, float* out, int32_t* out_idx,
+                                           void* stream) {
+  SAMD_REQUIRE(llrs && (hard_out ? out_idx != nullptr : out != nullptr), "null argument");
+  SAMD_REQUIRE(m >= 1 && m <= 8 && rows >= 0, "num_bits_per_symbol must be in 1..8");
+  if (rows == 0) return SAMD_OK;
+  hipLaunchKernelGGL(llrs2logits_kernel, dim3(grid_for((rows + 63) / 64 * 256, 256)), dim3(256), 0, (hipStream_t)stream, llrs, m,
+                     rows, hard_out, out, out_idx);
+  return launch_status();
+}
+
+extern "C" int samd_symbol_logits2moments_c64(const float* logits, const float* points, int m, int64_t rows, float* mean,
+                                              float* var, void* stream) {
+  SAMD_REQUIRE(logits && points && mean && var, "null argument");
+  SAMD_REQUIRE(m >= 1 && m <= 10 && rows >= 0, "num_bits_per_symbol must be in 1..10");
+  if (rows == 0) return SAMD_OK;
+  const int P = 1 << m;
+  hipLaunchKernelGGL(logits2moments_kernel, dim3(grid_for(rows, 256)), dim3(256), sizeof(float2) * P, (hipStream_t)stream, logits,
+                     (const float2*)points, P, rows, (float2*)mean, var);
+  return launch_status();
+}
+
+extern "C" int samd_pam2qam_logits_f32(const float* pam1, const float* pam2, int num_bits_per_symbol, int64_t rows, float* out,
+                                       void* stream) {
+  SAMD_REQUIRE(pam1 && pam2 && out, "null argument");
+  SAMD_REQUIRE(num_bits_per_symbol >= 2 && num_bits_per_symbol <= 10 && num_bits_per_symbol % 2 == 0 && rows >= 0,
+               "num_bits_per_symbol must be even, 2..10");
+  if (rows == 0) return SAMD_OK;
+  hipLaunchKernelGGL(pam2qam_logits_kernel, dim3(grid_for(rows << num_bits_per_symbol, 256)), dim3(256), 0, (hipStream_t)stream,
+                     pam1, pam2, num_bits_per_symbol / 2, rows, out);
+  return launch_status();
+}
+
 extern "C" int samd_symbol_demap_f32(const float* y, const float* no, int64_t no_len, const float* points, int m,
                                      int64_t num_symbols, const float* prior, int64_t prior_len, int hard_out, float* out,
                                      int32_t* out_idx, void* stream) {

@@ -736,8 +736,16 @@ struct EpParams {
   float beta, es, prec;   // damping, variance of the PAM points, numerical floor
 };
 
+// hard_out of EpParams selects what a detector call emits per stream (EPDetector.call :1272-1312):
+//   0 max-log LLRs [nb], 1 hard bits [nb] (output="bit"); 2 the logits of the two PAM constellations [2][P]
+//   (output="symbol", soft: the host's PAM2QAM forms the QAM logits), 3 the QAM index of the two PAM argmax decisions
+//   as a float (output="symbol", hard_out=True: tf.argmax = first maximum, PAM2QAM = interleaved bit labels)
+__device__ __forceinline__ int ep_out_width(const EpParams& q) {
+  return q.hard_out == 2 ? (2 << q.nbh) : q.hard_out == 3 ? 1 : 2 * q.nbh;
+}
+
 template <int M, int K>
-__device__ void ep_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&llr)[K][kMaxBits], const EpParams& q) {
+__device__ void ep_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&xo)[2 * K], float (&vo)[2 * K], const EpParams& q) {
   constexpr int N2 = 2 * K;
   const int P = 1 << q.nbh;
   cholesky<M>(s);                                             // whiten_channel
@@ -772,7 +780,7 @@ __device__ void ep_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&ll
     }
   }
   const float no = 0.5f;
-  float lam[N2], gam[N2], xo[N2], vo[N2];
+  float lam[N2], gam[N2];
 #pragma unroll
   for (int r = 0; r < N2; ++r) { lam[r] = 1.f / q.es; gam[r] = 0.f; xo[r] = 0.f; vo[r] = 1.f; }
   for (int it = 0; it < q.l; ++it) {
@@ -833,21 +841,56 @@ __device__ void ep_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&ll
       xo[r] = x_obs; vo[r] = v_obs;
     }
   }
-  // max-log LLRs of the PAM logits of the last iteration; bit order: I and Q bits interleaved
-  for (int k = 0; k < K; ++k)
+}
+
+// what stream k of a detector call emits (ep_out_width(q) floats at o), from the PAM logits of the last iteration
+// -(x_obs - point)^2 / (2 v_obs) of its real (r = k) and imaginary (r = K + k) dimension
+template <int K>
+__device__ void ep_emit(const float (&xo)[2 * K], const float (&vo)[2 * K], int k, const EpParams& q, float* __restrict__ o) {
+  const int P = 1 << q.nbh;
+  if (q.hard_out == 2) {
     for (int half = 0; half < 2; ++half) {
       const int r = half * K + k;
-      for (int b = 0; b < q.nbh; ++b) {
-        float m1 = -INFINITY, m0 = -INFINITY;
-        for (int p = 0; p < P; ++p) {
-          const float d = xo[r] - q.pam[p];
-          const float lg = -(d * d) / (2.f * vo[r]);
-          if ((p >> (q.nbh - 1 - b)) & 1) m1 = fmaxf(m1, lg); else m0 = fmaxf(m0, lg);
-        }
-        const float e = m1 - m0;
-        llr[k][2 * b + half] = q.hard_out ? (e > 0.f ? 1.f : 0.f) : e;
+      for (int p = 0; p < P; ++p) {
+        const float d = xo[r] - q.pam[p];
+        o[half * P + p] = -(d * d) / (2.f * vo[r]);
       }
     }
+    return;
+  }
+  if (q.hard_out == 3) {
+    int ind[2];
+    for (int half = 0; half < 2; ++half) {
+      const int r = half * K + k;
+      float best = -INFINITY;
+      int bi = 0;
+      for (int p = 0; p < P; ++p) {
+        const float d = xo[r] - q.pam[p];
+        const float lg = -(d * d) / (2.f * vo[r]);
+        if (lg > best) { best = lg; bi = p; }                 // strict: the first maximum, like tf.argmax
+      }
+      ind[half] = bi;
+    }
+    int qam = 0;                                               // PAM2QAM (mapping.py:1278-1291): bit labels interleaved
+    for (int b = 0; b < q.nbh; ++b)
+      qam |= (((ind[0] >> (q.nbh - 1 - b)) & 1) << (2 * q.nbh - 1 - 2 * b)) | (((ind[1] >> (q.nbh - 1 - b)) & 1) << (2 * q.nbh - 2 - 2 * b));
+    o[0] = (float)qam;
+    return;
+  }
+  // max-log LLRs; bit order: I and Q bits interleaved
+  for (int half = 0; half < 2; ++half) {
+    const int r = half * K + k;
+    for (int b = 0; b < q.nbh; ++b) {
+      float m1 = -INFINITY, m0 = -INFINITY;
+      for (int p = 0; p < P; ++p) {
+        const float d = xo[r] - q.pam[p];
+        const float lg = -(d * d) / (2.f * vo[r]);
+        if ((p >> (q.nbh - 1 - b)) & 1) m1 = fmaxf(m1, lg); else m0 = fmaxf(m0, lg);
+      }
+      const float e = m1 - m0;
+      o[2 * b + half] = q.hard_out ? (e > 0.f ? 1.f : 0.f) : e;
+    }
+  }
 }
 
 template <int M, int K>
@@ -857,7 +900,7 @@ __global__ __launch_bounds__(64) void ep_items_kernel(const float2* __restrict__
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   c32 yy[M], hh[M][K], ss[M][M];
-  float llr[K][kMaxBits];
+  float xo[2 * K], vo[2 * K];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     yy[m] = C(y[i * M + m].x, y[i * M + m].y);
@@ -866,10 +909,9 @@ __global__ __launch_bounds__(64) void ep_items_kernel(const float2* __restrict__
 #pragma unroll
     for (int j = 0; j < M; ++j) { const float2 v = s[(i * M + m) * M + j]; ss[m][j] = C(v.x, v.y); }
   }
-  ep_solve<M, K>(yy, hh, ss, llr, q);
-  const int nb = 2 * q.nbh;
-  for (int k = 0; k < K; ++k)
-    for (int b = 0; b < nb; ++b) out[(i * K + k) * nb + b] = llr[k][b];
+  ep_solve<M, K>(yy, hh, ss, xo, vo, q);
+  const int w = ep_out_width(q);
+  for (int k = 0; k < K; ++k) ep_emit<K>(xo, vo, k, q, out + (i * K + k) * w);
 }
 
 template <int M, int K>
@@ -881,14 +923,11 @@ __global__ __launch_bounds__(64) void ofdm_ep_kernel(OfdmEqArgs p, EpParams q, f
   int64_t b;
   c32 y[M], h[M][K], s[M][M];
   if (!load_re<M, K>(p, brx_i, re_i, y, h, s, dpos, b, rx)) return;
-  float llr[K][kMaxBits];
-  ep_solve<M, K>(y, h, s, llr, q);
-  const int nb = 2 * q.nbh;
+  float xo[2 * K], vo[2 * K];
+  ep_solve<M, K>(y, h, s, xo, vo, q);
+  const int w = ep_out_width(q);
   for (int k = 0; k < K; ++k)
-    if (dpos[k] >= 0) {
-      const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * nb;
-      for (int bb = 0; bb < nb; ++bb) out[o + bb] = llr[k][bb];
-    }
+    if (dpos[k] >= 0) ep_emit<K>(xo, vo, k, q, out + ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * w);
 }
 
 // ------------------------------------------------------------------ K-Best detector

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from .. import _ffi
-from .block import Block
+from .block import Block, Object
 from .config import config, dtypes, PhiloxGenerator
 
 
@@ -402,6 +402,137 @@ class SymbolLogits2LLRs(Block):
         _ffi.check(_ffi.lib().samd_symbol_logits2llrs_f32(_ffi.ptr(z), m, rows, _ffi.ptr(pr) if pr is not None else None, plen,
                                                           1 if self._method == "maxlog" else 0, 1 if self._hard_out else 0,
                                                           _ffi.ptr(out), _ffi.stream()), "SymbolLogits2LLRs")
+        return out
+
+
+class LLRs2SymbolLogits(Block):
+    """``LLRs2SymbolLogits(num_bits_per_symbol, hard_out=False)(llrs [..., n, m])`` -> logits (unnormalised
+    log-probabilities) of the 2^m constellation points, [..., n, 2^m], or with ``hard_out`` the index of the most likely
+    point, [..., n] int32 (reference mapping.py:969-1058): logit_c = sum_j log_sigmoid(l(c)_j llr_j) with the label of c =
+    binary representation of c, 0 replaced by -1.  One launch of ``samd_llrs2symbol_logits_f32``."""
+
+    def __init__(self, num_bits_per_symbol, hard_out=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._hard_out = hard_out
+        self._num_bits_per_symbol = int(num_bits_per_symbol)
+
+    num_bits_per_symbol = property(lambda self: self._num_bits_per_symbol)
+
+    def call(self, llrs):
+        self._require_single()
+        m = self._num_bits_per_symbol
+        x = _ffi.to_device(llrs, torch.float32).contiguous()
+        assert x.shape[-1] == m, "the last dimension of llrs must be num_bits_per_symbol"
+        rows = x.numel() // m
+        hard = bool(self._hard_out)
+        out = None if hard else torch.empty(tuple(x.shape[:-1]) + (1 << m,), dtype=torch.float32, device=x.device)
+        idx = torch.empty(tuple(x.shape[:-1]), dtype=torch.int32, device=x.device) if hard else None
+        _ffi.check(_ffi.lib().samd_llrs2symbol_logits_f32(_ffi.ptr(x), m, rows, int(hard), _ffi.ptr(out), _ffi.ptr(idx),
+                                                          _ffi.stream()), "LLRs2SymbolLogits")
+        return idx if hard else out
+
+
+class SymbolLogits2Moments(Block):
+    """``SymbolLogits2Moments(constellation_type=None, num_bits_per_symbol=None, constellation=None)``
+    ``(logits [..., n, num_points])`` -> (mean [..., n], var [..., n]) of the constellation under softmax(logits)
+    (reference mapping.py:1061-1138; the mean is real-valued float like the reference's ``tf.reduce_sum(p * points)``
+    when the constellation is real - here always returned as the block's complex dtype, the reference casts p to complex
+    too).  One launch of ``samd_symbol_logits2moments_c64``."""
+
+    def __init__(self, constellation_type=None, num_bits_per_symbol=None, constellation=None, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+
+    def call(self, logits):
+        self._require_single()
+        m = self._constellation.num_bits_per_symbol
+        z = _ffi.to_device(logits, torch.float32).contiguous()
+        assert z.shape[-1] == 1 << m, "the last dimension of logits must be the number of constellation points"
+        rows = z.numel() >> m
+        mean = torch.empty(tuple(z.shape[:-1]), dtype=torch.complex64, device=z.device)
+        var = torch.empty(tuple(z.shape[:-1]), dtype=torch.float32, device=z.device)
+        pts = self._constellation.device_points()
+        _ffi.check(_ffi.lib().samd_symbol_logits2moments_c64(_ffi.ptr(z), _ffi.ptr(pts), m, rows, _ffi.ptr(mean),
+                                                             _ffi.ptr(var), _ffi.stream()), "SymbolLogits2Moments")
+        return mean, var
+
+
+def _bit_labels(num_bits):
+    """[2^num_bits, num_bits]: binary representation of every index, MSB first (mapping.py:1165-1170)."""
+    idx = np.arange(1 << num_bits)
+    return ((idx[:, None] >> np.arange(num_bits - 1, -1, -1)[None, :]) & 1)
+
+
+class SymbolInds2Bits(Block):
+    """``SymbolInds2Bits(num_bits_per_symbol)(symbol_ind int [...])`` -> [..., num_bits_per_symbol] float: the binary
+    representation of the indices (reference mapping.py:1141-1178: a gather from the label table; index plumbing, no
+    arithmetic)."""
+
+    def __init__(self, num_bits_per_symbol, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        self._num_bits_per_symbol = int(num_bits_per_symbol)
+        self._labels = None
+
+    def call(self, symbol_ind):
+        ind = _ffi.to_device(symbol_ind, torch.int64)
+        if self._labels is None:
+            self._labels = _ffi.to_device(_bit_labels(self._num_bits_per_symbol).astype(np.float32), torch.float32).to(self.rdtype)
+        return self._labels.index_select(0, ind.reshape(-1)).reshape(tuple(ind.shape) + (self._num_bits_per_symbol,))
+
+
+class QAM2PAM(Object):
+    """``QAM2PAM(num_bits_per_symbol)(ind_qam int [...])`` -> (ind_pam1, ind_pam2) int32: the indices of the real and the
+    imaginary PAM component of QAM point indices - the even / odd bits of the label (reference mapping.py:1181-1231)."""
+
+    def __init__(self, num_bits_per_symbol, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        lab = _bit_labels(int(num_bits_per_symbol))
+        base = 1 << np.arange(int(num_bits_per_symbol) // 2 - 1, -1, -1)
+        self._tab = (np.sum(lab[:, 0::2] * base, -1).astype(np.int32), np.sum(lab[:, 1::2] * base, -1).astype(np.int32))
+        self._dev = None
+
+    def __call__(self, ind_qam):
+        ind = _ffi.to_device(ind_qam, torch.int64)
+        if self._dev is None:
+            self._dev = tuple(_ffi.to_device(t, torch.int32) for t in self._tab)
+        flat = ind.reshape(-1)
+        return tuple(t.index_select(0, flat).reshape(ind.shape) for t in self._dev)
+
+
+class PAM2QAM(Object):
+    """``PAM2QAM(num_bits_per_symbol, hard_in_out=True)(pam1, pam2)``: indices (int, [...]) or logits (float,
+    [..., 2^(num_bits_per_symbol/2)]) of the two PAM constellations -> indices / logits [..., 2^num_bits_per_symbol] of the
+    QAM constellation whose labels interleave theirs (reference mapping.py:1234-1314).  Indices are a table lookup; logits
+    are one launch of ``samd_pam2qam_logits_f32`` (the reference's flatten-and-gather, literally)."""
+
+    def __init__(self, num_bits_per_symbol, hard_in_out=True, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        nb = int(num_bits_per_symbol)
+        assert nb % 2 == 0, "num_bits_per_symbol must be even"
+        self._nb, self._hard_in_out = nb, hard_in_out
+        P = 1 << (nb // 2)
+        lab = _bit_labels(nb // 2)
+        b = np.zeros([P, P, nb], np.int64)
+        b[:, :, 0::2] = lab[:, None, :]
+        b[:, :, 1::2] = lab[None, :, :]
+        self._qam_ind = np.sum(b * (1 << np.arange(nb - 1, -1, -1)), -1).astype(np.int32)       # [P, P]
+        self._dev = None
+
+    def __call__(self, pam1, pam2):
+        P = 1 << (self._nb // 2)
+        if self._hard_in_out:
+            i1, i2 = _ffi.to_device(pam1, torch.int64), _ffi.to_device(pam2, torch.int64)
+            if self._dev is None:
+                self._dev = _ffi.to_device(self._qam_ind.reshape(-1), torch.int32)
+            return self._dev.index_select(0, (i1 * P + i2).reshape(-1)).reshape(i1.shape)
+        self._require_single()
+        a, b = _ffi.to_device(pam1, torch.float32).contiguous(), _ffi.to_device(pam2, torch.float32).contiguous()
+        assert a.shape == b.shape and a.shape[-1] == P, "logits must have 2**(num_bits_per_symbol/2) entries"
+        out = torch.empty(tuple(a.shape[:-1]) + (P * P,), dtype=torch.float32, device=a.device)
+        _ffi.check(_ffi.lib().samd_pam2qam_logits_f32(_ffi.ptr(a), _ffi.ptr(b), self._nb, a.numel() // P, _ffi.ptr(out),
+                                                      _ffi.stream()), "PAM2QAM")
         return out
 
 
