@@ -1,12 +1,13 @@
-"""``mimo.LinearDetector`` - equaliser followed by a demapper (reference
-src/sionna/phy/mimo/detection.py:24-143; only the LMMSE equaliser with bit output) - and
-``mimo.MMSEPICDetector`` (:1314-1643, bit output) on ``samd_mmse_pic_f32``."""
+"""``mimo.LinearDetector`` - equaliser followed by a demapper (reference src/sionna/phy/mimo/detection.py:24-143) -,
+``mimo.MMSEPICDetector`` (:1314-1643) on ``samd_mmse_pic_f32``, ``mimo.EPDetector`` (:1039-1312) on ``samd_ep_f32`` and
+``mimo.KBestDetector`` (:539-1037) on ``samd_kbest_f32``; bit and symbol output (logits / indices of the constellation
+points: the kernels' bit or PAM-logit outputs through ``SymbolLogits2LLRs`` / ``LLRs2SymbolLogits`` / ``PAM2QAM``)."""
 import numpy as np
 import torch
 
 from ... import _ffi
 from ..block import Block, wrap
-from ..mapping import Demapper, SymbolDemapper, Constellation
+from ..mapping import Demapper, SymbolDemapper, Constellation, SymbolLogits2LLRs, LLRs2SymbolLogits, PAM2QAM
 from .equalization import lmmse_equalizer, zf_equalizer, mf_equalizer
 
 
@@ -53,19 +54,23 @@ class MMSEPICDetector(Block):
         assert isinstance(num_iter, int), "num_iter must be an integer"
         assert output in ("bit", "symbol"), "Unknown output"
         assert demapping_method in ("app", "maxlog"), "Unknown demapping method"
-        if output != "bit":
-            raise NotImplementedError("MMSEPICDetector: only output='bit' has a HIP path")
         self._num_iter, self._output, self._demapping_method, self._hard_out = num_iter, output, demapping_method, hard_out
         self._constellation = Constellation.check_or_create(
             constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
             constellation=constellation, precision=precision)
+        if output == "symbol":
+            # priors arrive as logits on the points and leave as logits / indices (detection.py:1478-1486, 1523-1524, 1636-1637):
+            # the kernel works on bit LLRs in between
+            nb = self._constellation.num_bits_per_symbol
+            self._symbol_logits_2_llrs = SymbolLogits2LLRs(demapping_method, nb, precision=precision)
+            self._llr_2_symbol_logits_output = LLRs2SymbolLogits(nb, hard_out=hard_out, precision=precision)
 
     constellation = property(lambda self: self._constellation)
 
     def _kernel_params(self):
         pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex64), torch.complex64)
-        return pts, self._constellation.num_bits_per_symbol, int(self._demapping_method == "maxlog"), self._num_iter, \
-            int(bool(self._hard_out))
+        hard = int(bool(self._hard_out)) if self._output == "bit" else 0     # symbol output: soft extrinsic LLRs from the kernel
+        return pts, self._constellation.num_bits_per_symbol, int(self._demapping_method == "maxlog"), self._num_iter, hard
 
     def call(self, y, h, s, prior):
         self._require_single()
@@ -76,6 +81,9 @@ class MMSEPICDetector(Block):
         m, k = h.shape[-2], h.shape[-1]
         lead = tuple(h.shape[:-2])
         pts, nb, maxlog, num_iter, hard = self._kernel_params()
+        if self._output == "symbol":
+            assert tuple(prior.shape[-2:]) == (k, 1 << nb), "prior must have shape [..., num_streams, num_points]"
+            prior = self._symbol_logits_2_llrs(prior).as_subclass(torch.Tensor)
         assert tuple(prior.shape[-2:]) == (k, nb), "prior must have shape [..., num_streams, num_bits_per_symbol]"
         y = torch.broadcast_to(y, lead + (m,)).contiguous()
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
@@ -85,6 +93,8 @@ class MMSEPICDetector(Block):
         _ffi.check(_ffi.lib().samd_mmse_pic_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(prior),
                                                 _ffi.ptr(pts), y.numel() // m, m, k, nb, maxlog, num_iter, hard,
                                                 _ffi.ptr(out), _ffi.stream()), "MMSEPICDetector")
+        if self._output == "symbol":
+            return wrap(self._llr_2_symbol_logits_output(out))
         return wrap(out)
 
 
@@ -102,8 +112,6 @@ class EPDetector(Block):
     def __init__(self, output, num_bits_per_symbol, hard_out=False, l=10, beta=0.9, precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
         assert output in ("bit", "symbol"), "Unknown output"
-        if output != "bit":
-            raise NotImplementedError("EPDetector: only output='bit' has a HIP path")
         assert l >= 1, "l must be a positive integer"
         assert 0.0 <= beta <= 1.0, "beta must be in [0,1]"
         assert num_bits_per_symbol % 2 == 0, "EPDetector works on QAM constellations"
@@ -112,10 +120,29 @@ class EPDetector(Block):
         self._points = _pam_points_over_sqrt2(self._num_bits_per_symbol // 2)
         self._es = float(np.var(self._points))
         self._prec = 1e-6
+        if output == "symbol":
+            self._pam2qam = PAM2QAM(self._num_bits_per_symbol, hard_out, precision=precision)
 
     def _kernel_params(self):
+        """... and the output mode of ``samd_ep_f32``: 0 LLRs / 1 bits (output="bit"), 2 the logits of the two PAM
+        constellations / 3 the QAM index of their argmax decisions (output="symbol")."""
         pam = _ffi.to_device(self._points.astype(np.float32), torch.float32)
-        return pam, self._num_bits_per_symbol, self._l, self._beta, self._es, self._prec, int(bool(self._hard_out))
+        mode = int(bool(self._hard_out)) + (2 if self._output == "symbol" else 0)
+        return pam, self._num_bits_per_symbol, self._l, self._beta, self._es, self._prec, mode
+
+    def _out_width(self):
+        nb = self._num_bits_per_symbol
+        return nb if self._output == "bit" else (1 if self._hard_out else 2 << (nb // 2))
+
+    def _finish(self, out, lead_k):
+        """kernel output [*lead_k, W] -> what the block returns (detection.py:1272-1312)"""
+        if self._output == "bit":
+            return out.reshape(lead_k + (self._num_bits_per_symbol,))
+        if self._hard_out:
+            return out.reshape(lead_k).to(torch.int32)
+        P = 1 << (self._num_bits_per_symbol // 2)
+        z = out.reshape(lead_k + (2, P))
+        return self._pam2qam(z[..., 0, :].contiguous(), z[..., 1, :].contiguous())
 
     def call(self, y, h, s):
         self._require_single()
@@ -127,11 +154,11 @@ class EPDetector(Block):
         pam, nb, l, beta, es, prec, hard = self._kernel_params()
         y = torch.broadcast_to(y, lead + (m,)).contiguous()
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
-        out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
+        out = torch.empty(lead + (k, self._out_width()), dtype=torch.float32, device=y.device)
         h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
         _ffi.check(_ffi.lib().samd_ep_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pam), y.numel() // m, m, k,
                                           nb, l, beta, es, prec, hard, _ffi.ptr(out), _ffi.stream()), "EPDetector")
-        return wrap(out)
+        return wrap(self._finish(out, lead + (k,)))
 
 
 class KBestDetector(Block):
@@ -145,8 +172,9 @@ class KBestDetector(Block):
                  hard_out=False, use_real_rep=False, list2llr=None, precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
         assert output in ("bit", "symbol"), "Unknown output"
-        if output != "bit":
-            raise NotImplementedError("KBestDetector: only output='bit' has a HIP path")
+        if output == "symbol":
+            assert hard_out is True, "Soft-symbols are not supported for this detector."
+        self._output = output
         if use_real_rep:
             raise NotImplementedError("KBestDetector: the real-valued representation has no HIP path (use_real_rep=False)")
         if list2llr is not None:
@@ -180,6 +208,16 @@ class KBestDetector(Block):
         pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex64), torch.complex64)
         return pts, self._constellation.num_bits_per_symbol, self._k, self._llr_clip_val, int(self._hard_out)
 
+    def _finish(self, out, lead_k):
+        """kernel output [*lead_k, nb] (LLRs or the bits of the best path) -> what the block returns: for
+        output="symbol" the index of the best path's symbols (detection.py:1001-1019) - their bit labels read as a number"""
+        nb = self._constellation.num_bits_per_symbol
+        out = out.reshape(lead_k + (nb,))
+        if self._output == "bit":
+            return out
+        weights = (1 << torch.arange(nb - 1, -1, -1, device=out.device, dtype=torch.int32))
+        return (out.to(torch.int32) * weights).sum(-1, dtype=torch.int32)
+
     def call(self, y, h, s):
         self._require_single()
         y = _ffi.to_device(y, torch.complex64)
@@ -196,4 +234,4 @@ class KBestDetector(Block):
         h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
         _ffi.check(_ffi.lib().samd_kbest_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pts), y.numel() // m, m,
                                              k, nb, kk, clip, hard, _ffi.ptr(out), _ffi.stream()), "KBestDetector")
-        return wrap(out)
+        return wrap(self._finish(out, lead + (k,)))

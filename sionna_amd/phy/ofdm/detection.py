@@ -63,16 +63,25 @@ class MMSEPICDetector(Block):
     def call(self, y, h_hat, prior, err_var, no):
         self._require_single()
         rg = self._rg
-        pts, nb, maxlog, num_iter, hard = self._det._kernel_params()
+        det = self._det
+        pts, nb, maxlog, num_iter, hard = det._kernel_params()
         prior = _ffi.to_device(prior, torch.float32)
         keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
         b, nd = dims[0], rg.num_data_symbols
-        shape = (b, rg.num_tx, rg.num_streams_per_tx, nd * nb)
+        lead = (b, rg.num_tx, rg.num_streams_per_tx)
+        shape = lead + (nd * nb,)
+        if det._output == "symbol":
+            # logits on the points in, logits / indices out (ofdm/detection.py:531-560 around mimo/detection.py:1523-1524,
+            # 1636-1637); the fused kernel works on the bit LLRs in between
+            assert tuple(prior.shape) == lead + (nd, 1 << nb), "prior must have shape [batch, num_tx, num_streams, num_data_symbols, num_points]"
+            prior = det._symbol_logits_2_llrs(prior).as_subclass(torch.Tensor).reshape(shape)
         assert tuple(prior.shape) == shape, "prior must have shape [batch, num_tx, num_streams, num_data_symbols*num_bits_per_symbol]"
         prior = prior.contiguous()
         out = torch.zeros(shape, dtype=torch.float32, device=prior.device)
         _ffi.check(_ffi.lib().samd_ofdm_mmse_pic_f32(*head, _ffi.ptr(prior), _ffi.ptr(pts), *tabs, *dims, nb, maxlog, num_iter,
                                                      hard, _ffi.ptr(out), _ffi.stream()), "ofdm.MMSEPICDetector")
+        if det._output == "symbol":
+            return wrap(det._llr_2_symbol_logits_output(out.reshape(lead + (nd, nb))))
         return wrap(out)
 
 
@@ -94,10 +103,12 @@ class EPDetector(Block):
         rg = self._rg
         pam, nb, l, beta, es, prec, hard = self._det._kernel_params()
         keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
-        out = torch.zeros((dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols * nb), dtype=torch.float32,
-                          device=keep[0].device)
+        lead = (dims[0], rg.num_tx, rg.num_streams_per_tx)
+        out = torch.zeros(lead + (rg.num_data_symbols * self._det._out_width(),), dtype=torch.float32, device=keep[0].device)
         _ffi.check(_ffi.lib().samd_ofdm_ep_f32(*head, _ffi.ptr(pam), *tabs, *dims, nb, l, beta, es, prec, hard, _ffi.ptr(out),
                                                _ffi.stream()), "ofdm.EPDetector")
+        if self._det._output == "symbol":       # [batch, num_tx, num_streams, num_data_symbols(, num_points)] (:289-317)
+            return wrap(self._det._finish(out, lead + (rg.num_data_symbols,)))
         return wrap(out)
 
 
@@ -125,4 +136,6 @@ class KBestDetector(Block):
                           device=keep[0].device)
         _ffi.check(_ffi.lib().samd_ofdm_kbest_f32(*head, _ffi.ptr(pts), *tabs, *dims, nb, kk, clip, hard, _ffi.ptr(out),
                                                   _ffi.stream()), "ofdm.KBestDetector")
+        if self._det._output == "symbol":       # indices of the best path's symbols [batch, num_tx, num_streams, num_data_symbols]
+            return wrap(self._det._finish(out, (dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols)))
         return wrap(out)

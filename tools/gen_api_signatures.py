@@ -14,7 +14,7 @@ OUT = os.path.join(ROOT, "tests", "golden", "api_signatures.json")
 
 SURFACE = {      # reference file -> (import path in sionna.phy, names)
     "mapping.py": ("mapping", ["Constellation", "Mapper", "Demapper", "SymbolDemapper", "BinarySource", "QAMSource", "SymbolLogits2LLRs",
-                               "qam", "pam", "pam_gray"]),
+                               "LLRs2SymbolLogits", "SymbolLogits2Moments", "SymbolInds2Bits", "QAM2PAM", "PAM2QAM", "qam", "pam", "pam_gray"]),
     "fec/ldpc/encoding.py": ("fec.ldpc", ["LDPC5GEncoder"]),
     "fec/ldpc/decoding.py": ("fec.ldpc", ["LDPCBPDecoder", "LDPC5GDecoder", "vn_update_sum", "cn_update_minsum", "cn_update_offset_minsum",
                                           "cn_update_phi", "cn_update_tanh"]),
