@@ -590,6 +590,29 @@ int samd_polar_bp_decode_f32(const float* llr, const float* prior, const int32_t
                              size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Multi-GPU: the one collective of the path.  One process per GPU; the Monte-Carlo
+ * batches are independent, so the only exchange is the SUM of the int64 error counters
+ * {bit_errors, block_errors, num_bits, num_blocks} over the ranks - one RCCL allReduce of 32 bytes
+ * per iteration instead of the full-tensor gathers of the reference's tf.distribute path
+ * (utils/misc.py:546-547, 616-655).  Python hosts use torch.distributed (sim_ber(distribute=...));
+ * these entries give a C host the same collective.  RCCL is loaded on first use (dlopen).
+ *   samd_comm_unique_id      rank 0 fills SAMD_COMM_ID_BYTES host bytes and hands them to the other
+ *                            ranks out of band (file, socket, MPI, environment)
+ *   samd_comm_create         every rank, with the SAME id; binds the calling thread's current HIP
+ *                            device (call hipSetDevice(local_rank) first); collective: returns when
+ *                            all world_size ranks have called it
+ *   samd_comm_allreduce_sum_i64   counters DEVICE int64[count], in place, on `stream`
+ * ---------------------------------------------------------------------------------- */
+#define SAMD_COMM_ID_BYTES 128
+typedef struct samd_comm samd_comm_t;
+int samd_comm_unique_id(void* id_out);
+int samd_comm_create(const void* id, int rank, int world_size, samd_comm_t** out);
+int samd_comm_rank(const samd_comm_t* c);
+int samd_comm_world_size(const samd_comm_t* c);
+int samd_comm_allreduce_sum_i64(samd_comm_t* c, int64_t* counters, int64_t count, void* stream);
+void samd_comm_destroy(samd_comm_t* c);
+
+/* ------------------------------------------------------------------------------------
  * Error counting  utils/metrics.py:94-144 (count_errors, count_block_errors).
  * b, b_hat [num_blocks, block_len] float32; counters: DEVICE int64[2], ADDED to:
  * counters[0] += #(b != b_hat), counters[1] += #blocks with any mismatch.

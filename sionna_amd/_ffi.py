@@ -108,6 +108,12 @@ _SIGNATURES = {
                                          _vp, _sz, _vp]),
     "samd_polar_bp_workspace_bytes": (_sz, [_i32, _i32]),
     "samd_polar_bp_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "samd_comm_unique_id": (_i32, [_vp]),
+    "samd_comm_create": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
+    "samd_comm_rank": (_i32, [_vp]),
+    "samd_comm_world_size": (_i32, [_vp]),
+    "samd_comm_allreduce_sum_i64": (_i32, [_vp, _vp, _i64, _vp]),
+    "samd_comm_destroy": (None, [_vp]),
     "samd_count_errors_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "samd_ofdm_lsnn_lmmse_c64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                         _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -65,3 +65,29 @@ def test_bench_under_the_drivers_launcher_with_one_rank():
     assert out["collectives"] == {"backend": "nccl", "group_size": 1}
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
     assert out["bler"] < 1.0
+
+
+@pytest.mark.timeout(600)
+def test_c_abi_communicator_one_member():
+    """samd_comm_* (include/sionna_amd.h "Multi-GPU"): the C host's all-reduce of the int64 counters, here through ctypes
+    inside the torch process (the already-mapped librccl is reused): id, create, in-place sum on the current stream,
+    teardown.  (A torch-free C process does the same in tests/test_gpu_cabi_c.py.)"""
+    import ctypes as C
+    import torch
+    from sionna_amd import _ffi
+    dev = _ffi.device()
+    lib = _ffi.lib()
+    ident = (C.c_ubyte * 128)()
+    _ffi.check(lib.samd_comm_unique_id(ident), "samd_comm_unique_id")
+    assert any(ident)
+    comm = C.c_void_p()
+    _ffi.check(lib.samd_comm_create(ident, 0, 1, C.byref(comm)), "samd_comm_create")
+    assert comm.value and lib.samd_comm_rank(comm) == 0 and lib.samd_comm_world_size(comm) == 1
+    t = torch.tensor([3, 5, 7, 2 ** 40 + 11], dtype=torch.int64, device=dev)
+    for _ in range(2):
+        _ffi.check(lib.samd_comm_allreduce_sum_i64(comm, _ffi.ptr(t), 4, _ffi.stream()), "samd_comm_allreduce_sum_i64")
+    torch.cuda.synchronize()
+    assert t.tolist() == [3, 5, 7, 2 ** 40 + 11]
+    lib.samd_comm_destroy(comm)
+    with pytest.raises(ValueError):
+        _ffi.check(lib.samd_comm_create(ident, 1, 1, C.byref(comm)), "samd_comm_create")
