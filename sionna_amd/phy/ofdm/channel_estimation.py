@@ -136,11 +136,14 @@ class LSChannelEstimator(Block):
     def __init__(self, resource_grid, interpolation_type="nn", interpolator=None, precision=None, **kwargs):
         super().__init__(precision=precision, **kwargs)
         assert interpolation_type in ["nn", "lin", "lin_time_avg", None], "Unsupported `interpolation_type`"
-        if interpolator is not None and not isinstance(interpolator, (NearestNeighborInterpolator, LinearInterpolator)):
-            raise NotImplementedError("LSChannelEstimator: custom interpolators have no HIP path")
         self._rg = resource_grid
         self._lin = None
-        if isinstance(interpolator, LinearInterpolator):
+        if interpolator is not None and not isinstance(interpolator, (NearestNeighborInterpolator, LinearInterpolator)):
+            # any object with the interface of BaseChannelInterpolator (channel_estimation.py:287-321): called with the LS
+            # estimates and error variances at the pilots (device tensors), returns them for the whole grid (:160-167)
+            assert callable(interpolator), "interpolator must be callable: (h_hat, err_var) at the pilots -> whole grid"
+            self._lin, interpolation_type = interpolator, None
+        elif isinstance(interpolator, LinearInterpolator):
             self._lin, interpolation_type = interpolator, None
         elif isinstance(interpolator, NearestNeighborInterpolator):
             interpolation_type = "nn"
@@ -240,4 +243,5 @@ class LSChannelEstimator(Block):
         if self._lin is not None:
             err_var = torch.broadcast_to(err_var, tuple(err_var.shape[:3]) + self._out_shape)
             h_hat, err_var = self._lin(h_hat, err_var.contiguous())
+            h_hat, err_var = _ffi.to_device(h_hat, torch.complex64), _ffi.to_device(err_var, torch.float32)
         return h_hat, torch.clamp_min(err_var, 0.)

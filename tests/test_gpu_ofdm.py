@@ -668,6 +668,28 @@ def test_ls_estimator_linear_vs_oracle(phy, itype):
     assert np.array_equal(_np(h2), _np(h))
 
 
+def test_ls_estimator_custom_interpolator(phy):
+    """``interpolator=`` any object with BaseChannelInterpolator's call interface (channel_estimation.py:160-167, 287-321):
+    it receives the LS estimates / error variances at the pilots and returns them for the whole grid."""
+    rg, org = _grids(phy, num_tx=2, ns=2, fft=72, guards=(3, 4))
+    y = _cplx(np.random.default_rng(9), (4, 1, 4, 14, 72))
+    lin = phy.ofdm.LinearInterpolator(rg.pilot_pattern)
+    seen = {}
+
+    class Mine:                                                        # delegates, through NumPy on the way out
+        def __call__(self, h_hat, err_var):
+            seen["shapes"] = (tuple(h_hat.shape), tuple(err_var.shape))
+            h, ev = lin(h_hat, err_var)
+            return _np(h), _np(ev)
+
+    h, ev = phy.ofdm.LSChannelEstimator(rg, interpolator=Mine())(y, 0.05)
+    h_ref, ev_ref = phy.ofdm.LSChannelEstimator(rg, interpolation_type="lin")(y, 0.05)
+    npil = rg.pilot_pattern.num_pilot_symbols
+    assert seen["shapes"] == ((4, 1, 4, 2, 2, npil),) * 2
+    assert np.array_equal(_np(h), _np(h_ref)) and np.array_equal(_np(ev), np.broadcast_to(_np(ev_ref), ev.shape))
+    assert float(_np(ev).min()) >= 0.0
+
+
 def test_time_domain_chain_ls_lin_recovers_frequency_response(phy):
     """Reference test_channel_utils.py:83-135: static TDL channel through modulator -> ApplyTimeChannel ->
     demodulator; the noise-free LS estimate with linear interpolation equals the DFT of the taps."""
