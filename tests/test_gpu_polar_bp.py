@@ -112,3 +112,58 @@ def test_bp_decodes_and_validates(phy):
             phy.fec.polar.PolarBPDecoder(frozen, n, **bad)
     with pytest.raises(ValueError):
         phy.fec.polar.PolarBPDecoder(frozen[:10], 100)
+
+
+@pytest.mark.parametrize("k,n", [(1, 32), (10, 32), (32, 32), (100, 256), (123, 1024), (1024, 1024)])
+def test_bp_identity(phy, k, n):
+    """the reference's own test (test/unit/fec/test_polar_decoding.py:742-769): noiseless BPSK is recovered, k = n included,
+    and an input without batch dimension"""
+    frozen, _ = op.generate_5g_ranking(k, n)
+    frozen = np.asarray(frozen, int)
+    enc = phy.fec.polar.PolarEncoder(frozen, n)
+    dec = phy.fec.polar.PolarBPDecoder(frozen, n)
+    u = phy.mapping.BinarySource()([10, k])
+    assert np.array_equal(_np(dec(20. * (2. * enc(u) - 1.))), _np(u))
+    u1 = phy.mapping.BinarySource()([k])
+    out = dec(20. * (2. * enc(u1) - 1.))
+    assert out.shape == (k,) and np.array_equal(_np(out), _np(u1))
+
+
+@pytest.mark.parametrize("hard_out", [False, True])
+def test_bp_numerics_and_float64_twin(phy, hard_out):
+    """test_polar_decoding.py:819-842: 200 iterations on very large LLRs stay finite; :884-993: agreement with the
+    reference test's float64 NumPy decoder (in-place message arrays) at its own tolerance"""
+    k, n = 120, 256
+    frozen, _ = op.generate_5g_ranking(k, n)
+    rng = np.random.default_rng(5)
+    big = rng.normal(2000., np.sqrt(4000.), (100, n)).astype(np.float32)
+    out = _np(phy.fec.polar.PolarBPDecoder(frozen, n, hard_out=hard_out, num_iter=200)(big))
+    assert np.all(np.isfinite(out))
+    # float64 twin: the same schedule (the in-place arrays of the reference's test hold exactly the newest column values)
+    k, n = 64, 128
+    frozen, info = op.generate_5g_ranking(k, n)
+    llr = rng.normal(2 / 0.3, np.sqrt(4 / 0.3), (100, n)).astype(np.float32)
+    for it in (5, 10, 20, 40):
+        S = 7
+        L, R = np.zeros((100, S + 1, n)), np.zeros((100, S + 1, n))
+        L[:, S] = -1. * llr
+        R[:, 0, frozen] = 19.3
+
+        def bx(x, y):
+            x, y = np.clip(x, -19.3, 19.3), np.clip(y, -19.3, 19.3)
+            return np.log(1 + np.exp(x + y)) - np.log(np.exp(x) + np.exp(y))
+        for _ in range(it):
+            for s in range(S):
+                i1, i2 = obp.stage_indices(n, s)
+                l1, l2, r1, r2 = L[:, s + 1, i1], L[:, s + 1, i2], R[:, s, i1], R[:, s, i2]
+                R[:, s + 1, i1], R[:, s + 1, i2] = bx(r1, l2 + r2), bx(r1, l1) + r2
+            for s in range(S - 1, -1, -1):
+                i1, i2 = obp.stage_indices(n, s)
+                l1, l2, r1, r2 = L[:, s + 1, i1], L[:, s + 1, i2], R[:, s, i1], R[:, s, i2]
+                L[:, s, i1], L[:, s, i2] = bx(l1, l2 + r2), bx(r1, l1) + l2
+        soft_ref = L[:, 0, info]
+        got = _np(phy.fec.polar.PolarBPDecoder(frozen, n, hard_out=hard_out, num_iter=it)(llr))
+        if hard_out:
+            assert np.mean(got == 0.5 * (1 - np.sign(soft_ref))) > 0.9995
+        else:
+            assert np.allclose(-got, soft_ref, rtol=5e-2, atol=5e-3)
