@@ -447,6 +447,50 @@ def bench_c5(args, short=False):
     return out
 
 
+def bench_c5_bp(args, short=False):
+    """The C5 code under the OTHER iterative Polar decoder: PolarBPDecoder, 20 flooding iterations (reference
+    fec/polar/decoding.py:1440-1771), n = 1024, k_polar = 523, batch 32768 - one launch of samd_polar_bp_decode_f32 per step,
+    the factor graph of a codeword in the LDS of its workgroup.  Rate and kernel time only: no PMC counters exist for this
+    kernel yet (written after the round's GPU minutes were spent), so `roofline.achieved` is the static instruction estimate
+    of DESIGN section 4 over the measured time, marked as an estimate."""
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    _ffi.device()
+    phy.config.seed = 6
+    steps, warmup = (max(3, args.steps // 2), 1) if short else (args.steps, args.warmup)
+    B, k, n, m, it = (args.batch if args.batch != 65536 else 32768), 512, 1024, 2, 20
+    ebno = 3.0 if args.ebno_db == 4.5 else args.ebno_db
+    enc = phy.fec.polar.Polar5GEncoder(k, n)
+    dec = phy.fec.polar.Polar5GDecoder(enc, "BP", num_iter=it)
+    no = phy.utils.ebnodb2no(ebno, m, k / n)
+    u = phy.mapping.BinarySource()([B, k])
+    llr = phy.mapping.Demapper("app", "qam", m)(phy.channel.AWGN()(phy.mapping.Mapper("qam", m)(enc(u)), no), no)
+    torch.cuda.synchronize()
+    for _ in range(warmup):
+        dec(llr)
+    ev_t = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for e0, e1 in ev_t:
+        e0.record(); u_hat = dec(llr); e1.record()
+    torch.cuda.synchronize()
+    t_wall = time.perf_counter() - t0
+    ms = float(np.mean([a.elapsed_time(c) for a, c in ev_t]))
+    stages = 10
+    est_inst = it * (2 * stages - 2) * (n // 2) * 100 / 64                 # ~100 vector instructions per butterfly and lane
+    return {"metric": "codeword-decodes/sec (Polar5G n=1024 k=512, BP-20)", "value": round(B * steps / t_wall, 1),
+            "unit": "codewords/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(t_wall / steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C5 code, PolarBPDecoder 20 iterations through Polar5GDecoder(dec_type='BP'), QPSK AWGN, batch {B}",
+                       "batch": B, "ebno_db": ebno},
+            "bler": float((u_hat != u).any(dim=1).float().mean()),
+            "roofline": {"bound": "valu", "achieved": round(est_inst * B / (ms * 1e-3) / 1e9, 1), "peak": 1228.8,
+                         "unit": "G wave64-inst/s", "frac": round(est_inst * B / (ms * 1e-3) / 1e9 / 1228.8, 4), "traffic": None,
+                         "kernel": "polar_bp_kernel<false> (messages of a codeword in LDS, 512 lanes per codeword)",
+                         "ms_per_launch": round(ms, 3), "estimate": "static instruction count, not PMC",
+                         "compulsory_io_gbps": round((4 * n + 4 * k) * B / (ms * 1e-3) / 1e9, 2)}}
+
+
 # ------------------------------------------------------------------ C2 / C3: LDPC decode (headline)
 def cpu_baseline_c2(llr, k, n, m, cn_update, num_iter, dec, seconds, max_cw):
     from oracle import cbind, ldpc_bp as obp
@@ -676,7 +720,7 @@ def main():
         del llr, u
         torch.cuda.empty_cache()
         out["extra"] = {}
-        for name, fn in (("c4", bench_c4), ("c5", bench_c5)):
+        for name, fn in (("c4", bench_c4), ("c5", bench_c5), ("c5_bp", bench_c5_bp)):
             try:
                 out["extra"][name] = fn(args, short=True)
             except Exception as e:  # pylint: disable=broad-except  (a secondary workload must not lose the headline line)
