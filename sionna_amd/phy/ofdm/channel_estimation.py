@@ -241,7 +241,10 @@ class LSChannelEstimator(Block):
         fill_h(h_hat)
         err_var = no * ev.reshape(self._out_shape)
         if self._lin is not None:
-            err_var = torch.broadcast_to(err_var, tuple(err_var.shape[:3]) + self._out_shape)
+            # a foreign interpolator sees err_var broadcast to h_hat's shape like in the reference (channel_estimation.py:160-163);
+            # the built-in one keeps the leading [batch, num_rx, num_rx_ant] dims unexpanded (its kernel is linear in them)
+            lead = tuple(err_var.shape[:3]) if isinstance(self._lin, LinearInterpolator) else tuple(h_hat.shape[:3])
+            err_var = torch.broadcast_to(err_var, lead + self._out_shape)
             h_hat, err_var = self._lin(h_hat, err_var.contiguous())
             h_hat, err_var = _ffi.to_device(h_hat, torch.complex64), _ffi.to_device(err_var, torch.float32)
         return h_hat, torch.clamp_min(err_var, 0.)
