@@ -20,7 +20,9 @@ here under a NumPy stand-in for TensorFlow (``tools/ref_exec``; fixtures
 ``tests/golden/*_ref_*``, tests ``tests/test_oracle_ref_exec*.py``,
 ``tests/test_sim_ber_ref_exec.py``, ``tests/test_fec_utils_ref_exec.py``): BP node updates and
 whole decoders (min-sum family, VN update, state, layered: bit for bit), 5G LDPC / Polar
-encoders and Polar SC / SCL / hybrid decisions (bit for bit), mapper / demapper, MIMO
+encoders and Polar SC / SCL / hybrid decisions (bit for bit), the Polar BP decoder (``polar_bp.py``: soft outputs bit
+for bit on NumPy's exp / log, ``tests/test_oracle_ref_exec_polar_bp.py``), mapper / demapper, the symbol-domain blocks and
+the ``output="symbol"`` forms of the EP / K-Best / MMSE-PIC detectors (``tests/test_oracle_ref_exec_symbol.py``), MIMO
 equalisers, OFDM modulator / demodulator / time channel, LS estimators, OFDM detectors, the
 IDD chain, ``sim_ber`` (bit for bit), TDL / CDL generators (parameters exactly, realisations
 statistically), and against the BER / BLER tables the reference publishes in its notebooks
