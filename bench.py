@@ -478,17 +478,21 @@ def bench_c5_bp(args, short=False):
     ms = float(np.mean([a.elapsed_time(c) for a, c in ev_t]))
     stages = 10
     est_inst = it * (2 * stages - 2) * (n // 2) * 100 / 64                 # ~100 vector instructions per butterfly and lane
+    kname = "polar_bp_kernel<false> (messages of a codeword in LDS, 512 lanes per codeword)"
+    if load_counters("polar_bp"):                                           # PMC counters exist: the measured roofline
+        roof = onchip_roofline("polar_bp", kname, B, ms, {"compulsory_io_gbps": round((4 * n + 4 * k) * B / (ms * 1e-3) / 1e9, 2)})
+    else:
+        roof = {"bound": "valu", "achieved": round(est_inst * B / (ms * 1e-3) / 1e9, 1), "peak": 1228.8,
+                "unit": "G wave64-inst/s", "frac": round(est_inst * B / (ms * 1e-3) / 1e9 / 1228.8, 4), "traffic": None,
+                "kernel": kname, "ms_per_launch": round(ms, 3), "estimate": "static instruction count, not PMC",
+                "compulsory_io_gbps": round((4 * n + 4 * k) * B / (ms * 1e-3) / 1e9, 2)}
     return {"metric": "codeword-decodes/sec (Polar5G n=1024 k=512, BP-20)", "value": round(B * steps / t_wall, 1),
             "unit": "codewords/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(t_wall / steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"C5 code, PolarBPDecoder 20 iterations through Polar5GDecoder(dec_type='BP'), QPSK AWGN, batch {B}",
                        "batch": B, "ebno_db": ebno},
             "bler": float((u_hat != u).any(dim=1).float().mean()),
-            "roofline": {"bound": "valu", "achieved": round(est_inst * B / (ms * 1e-3) / 1e9, 1), "peak": 1228.8,
-                         "unit": "G wave64-inst/s", "frac": round(est_inst * B / (ms * 1e-3) / 1e9 / 1228.8, 4), "traffic": None,
-                         "kernel": "polar_bp_kernel<false> (messages of a codeword in LDS, 512 lanes per codeword)",
-                         "ms_per_launch": round(ms, 3), "estimate": "static instruction count, not PMC",
-                         "compulsory_io_gbps": round((4 * n + 4 * k) * B / (ms * 1e-3) / 1e9, 2)}}
+            "roofline": roof}
 
 
 # ------------------------------------------------------------------ C2 / C3: LDPC decode (headline)

@@ -742,8 +742,8 @@ def test_mimo_mmse_pic_vs_oracle(phy, m, k, nb, method):
     hard = _np(phy.mimo.MMSEPICDetector("bit", method, num_iter=2, constellation_type="qam", num_bits_per_symbol=nb,
                                         hard_out=True)(y, h, s, prior))
     assert set(np.unique(hard)) <= {0.0, 1.0}
-    with pytest.raises(NotImplementedError):
-        phy.mimo.MMSEPICDetector("symbol", method, constellation_type="qam", num_bits_per_symbol=nb)
+    # output="symbol" (logits on the points as priors and as result): tests/test_gpu_symbol.py
+    assert phy.mimo.MMSEPICDetector("symbol", method, constellation_type="qam", num_bits_per_symbol=nb)._output == "symbol"
 
 
 @pytest.mark.parametrize("num_tx,ns,assoc", [(1, 2, [[1]]), (2, 1, [[1, 1]]), (2, 2, [[1, 0], [0, 1]])])
@@ -798,8 +798,7 @@ def test_mimo_ep_detector_vs_oracle(phy, m, k, nb):
         lin = _np(phy.mimo.LinearDetector("lmmse", "bit", "maxlog", constellation_type="qam", num_bits_per_symbol=nb)(y, h, s))
         got = _np(phy.mimo.EPDetector("bit", nb)(y, h, s))
         assert np.mean((got > 0) != bits) < 0.7 * np.mean((lin > 0) != bits)
-    with pytest.raises(NotImplementedError):
-        phy.mimo.EPDetector("symbol", nb)
+    assert phy.mimo.EPDetector("symbol", nb)._output == "symbol"          # its outputs: tests/test_gpu_symbol.py
 
 
 def test_ofdm_ep_detector_vs_oracle(phy):

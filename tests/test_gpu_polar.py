@@ -211,8 +211,9 @@ def test_hybrid_scl(phy, k, n, ch, sigma):
     assert bler(u_l) <= bler(u_h) + 0.02 and bler(u_h) <= bler(u_s)
     with pytest.raises(ValueError):
         phy.fec.polar.PolarSCLDecoder(enc.frozen_pos, enc.n_polar, use_hybrid_sc=True)
-    with pytest.raises(NotImplementedError):
-        phy.fec.polar.Polar5GDecoder(enc, dec_type="BP")
+    assert phy.fec.polar.Polar5GDecoder(enc, dec_type="BP").dec_type == "BP"   # the BP decoder: tests/test_gpu_polar_bp.py
+    with pytest.raises(ValueError):
+        phy.fec.polar.Polar5GDecoder(enc, dec_type="ML")
 
 
 def test_c5_full_batch_properties(phy):

@@ -26,6 +26,7 @@ KERNELS = {   # key -> (substring of the kernel name, unit, source file)
     "ldpc5g_bp_fast": ("ldpc5g_decode_msg_kernel<2, true, 4, 0>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
     "ldpc5g_layered": ("ldpc5g_decode_ly_kernel", "decode", "sionna_amd/csrc/ldpc5g_onchip_ly.hip"),
     "polar_scl": ("polar_scl_reg_kernel", "decode", "sionna_amd/csrc/polar_scl_reg.hip"),
+    "polar_bp": ("polar_bp_kernel", "decode", "sionna_amd/csrc/polar_bp.hip"),
     "ofdm_lmmse": ("ofdm_lmmse_diag_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
 }
 
