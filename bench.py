@@ -80,7 +80,7 @@ def load_counters(kernel_key):
     if rec:
         rec = dict(rec)
         rec["stale"] = bool(rec.get("source") and _sha16(rec["source"]) != rec.get("source_sha16"))
-        rec["collected_on"] = allc.get("collected_on")
+        rec["collected_on"] = rec.get("collected_on") or allc.get("collected_on")     # (entries merged later carry their own)
         # static VALU mix x measured issue times (tools/valu_mix.py) and the ablation shares (tools/gpu_ablation.sh)
         rec["mix"] = _load_json("r03_valu_mix.json").get("kernels", {}).get(kernel_key)
         rec["ablation"] = _load_json("r03_ablation.json").get(kernel_key)

@@ -581,7 +581,7 @@ int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops,
  * float32 on the library's defined exp / log.  llr [batch,n] logits (n a power of two); prior DEVICE
  * float[n]: the right-going messages entering column 0 (19.3 at frozen positions, 0 elsewhere, :1632-1636);
  * info_pos DEVICE int32[k].  out [batch,k]: hard_out!=0 -> bits (1 where the final LLR <= 0), else soft
- * logits (:1719-1723).  A codeword's messages ((2 log2(n) + 1) n floats) live in LDS for n <= 1024
+ * logits (:1719-1723).  A codeword's messages ((2 log2(n) - 1) n floats) live in LDS for n <= 1024
  * (samd_polar_bp_workspace_bytes() == 0, workspace may be NULL); longer codes keep them in the
  * caller-owned device workspace. */
 size_t samd_polar_bp_workspace_bytes(int batch, int n);

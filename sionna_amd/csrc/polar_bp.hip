@@ -11,15 +11,16 @@
 // ever read again.
 //
 // MI355X design: the factor graph of a codeword is (log2 n + 1) columns of n left-going (L) and n right-going (R)
-// messages - 84 KB in float32 at n = 1024 - so a codeword's whole decoder state lives in the LDS of the workgroup that
-// decodes it and HBM sees the channel values once and the k decisions once (compulsory 4 n + 4 k bytes per codeword).
+// messages; the two columns that change - 76 KB in float32 at n = 1024 - live in the LDS of the workgroup that decodes
+// the codeword; HBM / L2 see the channel values once per iteration (4 n bytes, the only stage that reads them) and the k
+// decisions once (compulsory 4 n + 4 k bytes per codeword).
 //   * one butterfly (two boxplus evaluations) per lane and stage; both evaluations go through the packed-fp32 pipe
 //     together (v_pk_fma_f32 / v_pk_mul_f32: 5 packed exp / log calls per butterfly instead of 10 scalar ones);
 //   * short codes pack several codewords into a workgroup (256 lanes / (n/2) butterflies) so that every lane has work
 //     and the barriers between stages are shared;
 //   * the two stage updates whose results nothing reads - R of the last column, and L of column 0 in every iteration but
 //     the last - are skipped (same outputs, 2 of 2 log2(n) updates per iteration less);
-//   * n > 1024: the same kernel with its message columns in a caller-owned L2 / HBM workspace (no LDS for 188 KB).
+//   * n > 1024: the same kernel with its message columns in a caller-owned L2 / HBM workspace (no LDS for 172 KB).
 // Arithmetic: the literal form of _boxplus_tf (:1587-1603), log(1 + exp(x + y)) - log(exp(x) + exp(y)) on inputs clipped
 // to +-19.3, float32, on the DEFINED exp / log of bp_math.h (= oracle/ldpc_bp.c spec_expf / spec_logf): the CPU oracle
 // (oracle/polar_bp.py, math="spec") evaluates the same operations in the same order, so outputs are compared with
@@ -42,9 +43,44 @@ __device__ __forceinline__ f32x2 polar_boxplus2(float xa, float ya, float xb, fl
   return num - spec_log2_f32(spec_exp2_f32(x) + spec_exp2_f32(y));
 }
 
+// One stage update for the butterflies t, t + tpc, ... of a codeword.  Which of the two constant columns a stage reads is
+// a template parameter, not a selected pointer: the LDS columns keep their ds_read instructions (a pointer chosen at run
+// time between LDS and global memory turns every access into a flat load).
+//   R_PRIOR: the right-going inputs are the priors (stage 0);  L_CH: the left-going inputs are the channel (stage S-1,
+//   logits -> LLRs by lsgn = -1, decoding.py:1752)
+template <bool R_PRIOR>
+__device__ __forceinline__ void polar_bp_stage_lr(const float* Ls, const float* Rs, const float* __restrict__ prior, float* Ro,
+                                                  int s, int half, int t, int tpc) {
+  const int mask = (1 << s) - 1;
+  for (int r = t; r < half; r += tpc) {
+    const int i1 = 2 * r - (r & mask), i2 = i1 + (1 << s);
+    const float l1 = Ls[i1], l2 = Ls[i2];
+    const float r1 = R_PRIOR ? prior[i1] : Rs[i1], r2 = R_PRIOR ? prior[i2] : Rs[i2];
+    const f32x2 bp = polar_boxplus2(r1, l2 + r2, r1, l1);               // :1675-1676
+    Ro[i1] = bp.x;
+    Ro[i2] = bp.y + r2;
+  }
+}
+template <bool R_PRIOR, bool L_CH>
+__device__ __forceinline__ void polar_bp_stage_rl(const float* Ls, const float* __restrict__ ch, float lsgn, const float* Rs,
+                                                  const float* __restrict__ prior, float* Lo, int s, int half, int t, int tpc) {
+  const int mask = (1 << s) - 1;
+  for (int r = t; r < half; r += tpc) {
+    const int i1 = 2 * r - (r & mask), i2 = i1 + (1 << s);
+    const float l1 = L_CH ? lsgn * ch[i1] : Ls[i1], l2 = L_CH ? lsgn * ch[i2] : Ls[i2];
+    const float r1 = R_PRIOR ? prior[i1] : Rs[i1], r2 = R_PRIOR ? prior[i2] : Rs[i2];
+    const f32x2 bp = polar_boxplus2(l1, l2 + r2, r1, l1);               // :1706-1707
+    Lo[i1] = bp.x;
+    Lo[i2] = bp.y + l2;
+  }
+}
+
 // GLOBAL = false: message columns of the workgroup's codewords in dynamic LDS; true: in `ws` (one slab per codeword).
-// Column layout of one codeword (floats): L[0..S] (S + 1 columns of n; column S = channel LLRs), then R[0..S-1]
-// (column 0 = priors: llr_max at frozen positions, 0 elsewhere).
+// Column layout of one codeword (floats): L[0..S-1] (S columns of n), then R[1..S-1] (S - 1 columns).  The two columns
+// that never change are NOT stored: L column S is the channel (-llr, read from global memory by the one stage per
+// iteration that needs it) and R column 0 the priors (llr_max at frozen positions, 0 elsewhere: `prior`, shared by all
+// codewords) - 76 KB instead of 84 KB at n = 1024, so TWO workgroups fit the 160 KB of a CU (4 waves per SIMD instead
+// of 2: the barrier of one workgroup is hidden by the other; measured 1.14 M -> see DESIGN section 4).
 template <bool GLOBAL>
 __global__ __launch_bounds__(512) void polar_bp_kernel(const float* __restrict__ llr, const float* __restrict__ prior,
                                                        const int32_t* __restrict__ info_pos, int batch, int n, int S, int k,
@@ -57,46 +93,37 @@ __global__ __launch_bounds__(512) void polar_bp_kernel(const float* __restrict__
   const int w = (int)threadIdx.x / tpc, t = (int)threadIdx.x - w * tpc;
   const int64_t b = (int64_t)blockIdx.x * W + w;
   const bool live = b < batch;
-  const size_t slab = (size_t)(2 * S + 1) * n;
-  float* L = GLOBAL ? ws + (live ? b : 0) * slab : polar_bp_lds + (size_t)w * slab;
-  float* R = L + (size_t)(S + 1) * n;
+  const size_t slab = (size_t)(2 * S - 1) * n;
+  float* L = GLOBAL ? ws + (live ? b : 0) * slab : polar_bp_lds + (size_t)w * slab;     // columns 0 .. S-1
+  float* R = L + (size_t)(S - 1) * n;                                                    // column c (1 .. S-1) at R + c n
+  const float* ch = llr + (live ? b : 0) * (int64_t)n;
 
-  for (int i = t; i < n; i += tpc) {
-    L[(size_t)S * n + i] = live ? -1.f * llr[b * n + i] : 0.f;        // logits -> LLRs (:1752)
-    R[i] = prior[i];
+  for (int i = t; i < n; i += tpc)
     for (int c = 1; c < S; ++c) L[(size_t)c * n + i] = 0.f;            // "previous iteration" of the first sweep (:1655-1657)
-  }
   __syncthreads();
 
   for (int it = 0; it < num_iter; ++it) {
     // left to right (:1641-1683): R column s+1 from R column s and L column s+1; the last column's R is never read
     for (int s = 0; s + 1 < S; ++s) {
       const float* Ls = L + (size_t)(s + 1) * n;
-      const float* Rs = R + (size_t)s * n;
       float* Ro = R + (size_t)(s + 1) * n;
-      const int mask = (1 << s) - 1;
-      for (int r = t; r < half; r += tpc) {
-        const int i1 = 2 * r - (r & mask), i2 = i1 + (1 << s);
-        const float l1 = Ls[i1], l2 = Ls[i2], r1 = Rs[i1], r2 = Rs[i2];
-        const f32x2 bp = polar_boxplus2(r1, l2 + r2, r1, l1);
-        Ro[i1] = bp.x;
-        Ro[i2] = bp.y + r2;
-      }
+      if (s == 0) polar_bp_stage_lr<true>(Ls, Ls, prior, Ro, s, half, t, tpc);
+      else polar_bp_stage_lr<false>(Ls, R + (size_t)s * n, prior, Ro, s, half, t, tpc);
       __syncthreads();
     }
     // right to left (:1685-1713): L column s from L column s+1 and R column s; column 0 only feeds the decisions
     const int s_end = (it == num_iter - 1) ? 0 : 1;
+    const float lsgn = live ? -1.f : 0.f;
     for (int s = S - 1; s >= s_end; --s) {
-      const float* Ls = L + (size_t)(s + 1) * n;
-      const float* Rs = R + (size_t)s * n;
+      const float* Ls = L + (size_t)(s + 1 == S ? 0 : s + 1) * n;     // (column S is the channel: Ls unused then)
+      const float* Rs = R + (size_t)s * n;                              // (column 0 are the priors: Rs unused then)
       float* Lo = L + (size_t)s * n;
-      const int mask = (1 << s) - 1;
-      for (int r = t; r < half; r += tpc) {
-        const int i1 = 2 * r - (r & mask), i2 = i1 + (1 << s);
-        const float l1 = Ls[i1], l2 = Ls[i2], r1 = Rs[i1], r2 = Rs[i2];
-        const f32x2 bp = polar_boxplus2(l1, l2 + r2, r1, l1);
-        Lo[i1] = bp.x;
-        Lo[i2] = bp.y + l2;
+      if (s + 1 == S) {
+        if (s == 0) polar_bp_stage_rl<true, true>(Ls, ch, lsgn, Rs, prior, Lo, s, half, t, tpc);
+        else polar_bp_stage_rl<false, true>(Ls, ch, lsgn, Rs, prior, Lo, s, half, t, tpc);
+      } else {
+        if (s == 0) polar_bp_stage_rl<true, false>(Ls, ch, lsgn, Rs, prior, Lo, s, half, t, tpc);
+        else polar_bp_stage_rl<false, false>(Ls, ch, lsgn, Rs, prior, Lo, s, half, t, tpc);
       }
       __syncthreads();
     }
@@ -120,7 +147,7 @@ using namespace samd;
 
 extern "C" size_t samd_polar_bp_workspace_bytes(int batch, int n) {
   if (batch <= 0 || n < 2 || (n & (n - 1)) != 0) return 0;
-  const size_t slab = (size_t)(2 * polar_bp_stages(n) + 1) * n * sizeof(float);
+  const size_t slab = (size_t)(2 * polar_bp_stages(n) - 1) * n * sizeof(float);
   return slab <= (size_t)kPolarBpLdsMax ? 0 : (size_t)batch * slab + 256;
 }
 
@@ -131,7 +158,7 @@ extern "C" int samd_polar_bp_decode_f32(const float* llr, const float* prior, co
   SAMD_REQUIRE(n >= 2 && (n & (n - 1)) == 0 && n <= (1 << 20) && k >= 0 && k <= n, "n must be a power of two, 0 <= k <= n");
   SAMD_REQUIRE(num_iter >= 1, "num_iter must be positive");
   const int S = polar_bp_stages(n);
-  const size_t slab = (size_t)(2 * S + 1) * n * sizeof(float);
+  const size_t slab = (size_t)(2 * S - 1) * n * sizeof(float);
   const int half = n / 2;
   if (slab <= (size_t)kPolarBpLdsMax) {
     const int threads = half >= 512 ? 512 : 256;
