@@ -324,9 +324,20 @@ def make_tf():
         upd = np.asarray(updates)
         out = np.zeros([int(v) for v in shape], dtype=upd.dtype)
         ind = np.asarray(indices)
-        np.add.at(out, tuple(ind[:, d] for d in range(ind.shape[1])), upd)   # duplicates add up, like TF
+        depth = ind.shape[-1]                                             # indices [..., depth]: any number of leading dims
+        ind2 = ind.reshape(-1, depth)
+        np.add.at(out, tuple(ind2[:, d] for d in range(depth)), upd.reshape((ind2.shape[0],) + out.shape[depth:]))   # duplicates add up, like TF
         return _t(out)
     tf.scatter_nd = scatter_nd
+
+    def tensor_scatter_nd_add(tensor, indices, updates, name=None):
+        out = np.array(tensor, copy=True)
+        ind = np.asarray(indices)
+        depth = ind.shape[-1]
+        ind2 = ind.reshape(-1, depth)
+        np.add.at(out, tuple(ind2[:, d] for d in range(depth)), np.asarray(updates).reshape((ind2.shape[0],) + out.shape[depth:]))
+        return _t(out)
+    tf.tensor_scatter_nd_add = tensor_scatter_nd_add
 
     def argsort(values, axis=-1, direction="ASCENDING", stable=False, name=None):
         v = np.asarray(values)
@@ -479,7 +490,13 @@ def make_tf():
                 return lambda *a, **k: None
             raise AttributeError(name)
     tf.debugging = _Debugging()
+    def _lstsq(matrix, rhs, l2_regularizer=0.0, fast=True, name=None):
+        """tf.linalg.lstsq(fast=False): the minimum-norm least-squares solution through a complete orthogonal
+        decomposition - NumPy's pseudo-inverse (SVD) in the operands' precision."""
+        a, b = np.asarray(matrix), np.asarray(rhs)
+        return _t(np.matmul(np.linalg.pinv(a), b).astype(a.dtype))
     tf.linalg = types.SimpleNamespace(
+        lstsq=_lstsq,
         cholesky=lambda a: _t(np.linalg.cholesky(np.asarray(a))),
         matmul=lambda a, b, adjoint_a=False, adjoint_b=False, transpose_a=False, transpose_b=False, **k: tf.matmul(
             a, b, adjoint_a=adjoint_a, adjoint_b=adjoint_b, transpose_a=transpose_a, transpose_b=transpose_b),
