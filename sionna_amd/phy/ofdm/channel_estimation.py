@@ -248,3 +248,238 @@ class LSChannelEstimator(Block):
             h_hat, err_var = self._lin(h_hat, err_var.contiguous())
             h_hat, err_var = _ffi.to_device(h_hat, torch.complex64), _ffi.to_device(err_var, torch.float32)
         return h_hat, torch.clamp_min(err_var, 0.)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# LMMSE interpolation (reference channel_estimation.py:736-1853)
+#
+# Unlike the blocks above this is not a streaming pass over the grid but dense small-matrix algebra whose matrices depend
+# on the error variances handed in: per (example, receive antenna) and per group of grid rows with the same pilot
+# positions one Hermitian system "pilot covariance + diag(error variance)" is solved against the covariance columns, and
+# the resulting interpolation matrix is applied to the pilot estimates.  These are library-shaped operations (batched
+# LU solves and GEMMs: rocSOLVER / rocBLAS behind torch.linalg.solve / matmul on the device the estimates live on), so
+# there is no hand-written kernel here.  The covariance systems of the 38.901 models are ill-conditioned (1e4 and worse),
+# which single precision resolves poorly: the algebra runs in complex128 / float64 on the device and the results are cast
+# to the block's precision - the reference's float32 pseudo-inverse agrees with it to ~1e-4 of scale
+# (tests/test_lmmse_interpolator.py).
+def _c128(x, device=None):
+    t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    return t.to(device=device if device is not None else t.device, dtype=torch.complex128)
+
+
+def _rescale(h, err, hv, h_var):
+    """re-scaling after an intermediate step (channel_estimation.py:1129-1153, 1347-1363), complex arithmetic, divide_no_nan"""
+    den = hv + h_var - err
+    zero = den == 0
+    s = torch.where(zero, torch.zeros_like(den), 2. * h_var / torch.where(zero, torch.ones_like(den), den))
+    h = s * h
+    err = torch.real(s * (s - 1.) * hv + (1. - s) * h_var + s * err)
+    return h, torch.clamp_min(err, 0.)
+
+
+class _LMMSE1D:
+    """LMMSEInterpolator1D (channel_estimation.py:736-1155) on rows grouped by their pilot positions (the reference pads
+    every row to the largest pilot count and takes the minimum-norm least-squares solution, which is the same numbers
+    while pilot covariance + error variance is non-singular)."""
+
+    def __init__(self, pilot_mask, cov, last_step):
+        self._cov = np.asarray(cov, np.complex128)
+        self._last = last_step
+        ntx, ns, O, I = pilot_mask.shape
+        groups = {}
+        for tx in range(ntx):
+            for st in range(ns):
+                for o in range(O):
+                    groups.setdefault(tuple(np.flatnonzero(pilot_mask[tx, st, o] == 1)), []).append((tx * ns + st) * O + o)
+        self._groups = [(np.asarray(p, np.int64), np.asarray(r, np.int64)) for p, r in groups.items() if len(p)]
+        self._dev = {}
+
+    def _tables(self, device):
+        if device not in self._dev:
+            cov = torch.from_numpy(self._cov).to(device)
+            self._dev[device] = (cov, [(torch.from_numpy(p).to(device), torch.from_numpy(r).to(device)) for p, r in self._groups])
+        return self._dev[device]
+
+    def __call__(self, h, err):
+        """h complex128, err float64: [..., tx, st, O, I] -> the same shapes"""
+        cov, groups = self._tables(h.device)
+        shp = h.shape
+        R, I = shp[-4] * shp[-3] * shp[-2], shp[-1]
+        h2, e2 = h.reshape(shp[:-4] + (R, I)), err.reshape(shp[:-4] + (R, I))
+        h_var = torch.diagonal(cov)
+        out_h = torch.zeros_like(h2)
+        out_e = torch.clamp_min(torch.real(h_var), 0.).expand(e2.shape).clone()
+        out_hv = torch.zeros_like(h2)
+        for p, rows in groups:
+            hp = h2.index_select(-2, rows).index_select(-1, p)                 # [..., G, np]
+            ep = e2.index_select(-2, rows).index_select(-1, p)
+            cpp = cov.index_select(0, p).index_select(1, p)
+            b = cov.index_select(0, p)                                          # [np, I]
+            a = cpp + torch.diag_embed(ep).to(torch.complex128)
+            x = torch.linalg.solve(a, b.expand(a.shape[:-2] + b.shape))
+            ext = x.conj().transpose(-1, -2)                                    # [..., G, I, np]
+            hn = torch.matmul(ext, hp.unsqueeze(-1)).squeeze(-1)
+            en = torch.clamp_min(torch.real(h_var - torch.sum(ext * b.transpose(0, 1), dim=-1)), 0.)
+            hv = torch.sum(ext * torch.matmul(ext.conj(), cpp.transpose(0, 1)), dim=-1) \
+                + torch.sum(ext * ext.conj() * ep.unsqueeze(-2).to(torch.complex128), dim=-1)
+            out_h.index_copy_(-2, rows, hn)
+            out_e.index_copy_(-2, rows, en)
+            out_hv.index_copy_(-2, rows, hv)
+        if not self._last:
+            out_h, out_e = _rescale(out_h, out_e.to(torch.complex128), out_hv, h_var)
+        return out_h.reshape(shp), out_e.reshape(shp)
+
+
+class _SpatialFilter:
+    """SpatialChannelFilter (channel_estimation.py:1157-1365): LMMSE smoothing across the receive antennas of every
+    resource element; the antenna dimension is the last one of the inputs."""
+
+    def __init__(self, cov, last_step):
+        self._cov, self._last, self._dev = np.asarray(cov, np.complex128), last_step, {}
+
+    def __call__(self, h, err):
+        if h.device not in self._dev:
+            self._dev[h.device] = torch.from_numpy(self._cov).to(h.device)
+        cov = self._dev[h.device]
+        a = cov + torch.diag_embed(err).to(torch.complex128)
+        w = torch.linalg.solve(a, cov.expand(a.shape)).conj().transpose(-1, -2)           # (A^-1 C)^H (:1301-1306)
+        hn = torch.matmul(w, h.unsqueeze(-1)).squeeze(-1)
+        h_var = torch.diagonal(cov)
+        en = torch.clamp_min(torch.real(h_var - torch.sum(cov.transpose(0, 1) * w, dim=-1)), 0.)
+        if not self._last:
+            hv = torch.sum(w * torch.matmul(w.conj(), cov.transpose(0, 1)), dim=-1) \
+                + torch.sum(w * w.conj() * err.unsqueeze(-2).to(torch.complex128), dim=-1)
+            hn, en = _rescale(hn, en.to(torch.complex128), hv, h_var)
+        return hn, en
+
+
+class LMMSEInterpolator(Object):
+    """``LMMSEInterpolator(pilot_pattern, cov_mat_time, cov_mat_freq, cov_mat_space=None, order="t-f")(h_hat, err_var)``:
+    LMMSE interpolation of the channel estimates at the pilots [batch, num_rx, num_rx_ant, num_tx, num_streams_per_tx,
+    num_pilots] over the resource grid, dimension by dimension in the given ``order`` ("t" time, "f" frequency, optional
+    "s" smoothing across the receive antennas), with the re-scaling between steps; returns (h_hat, err_var)
+    [batch, num_rx, num_rx_ant, num_tx, num_streams_per_tx, num_ofdm_symbols, num_effective_subcarriers]
+    (reference channel_estimation.py:1367-1853).  Use as ``LSChannelEstimator(rg, interpolator=LMMSEInterpolator(...))``."""
+
+    def __init__(self, pilot_pattern, cov_mat_time, cov_mat_freq, cov_mat_space=None, order="t-f"):
+        super().__init__()
+        order = order.split("-")
+        assert 2 <= len(order) <= 3, "Invalid order for interpolation."
+        seen = set()
+        for o in order:
+            assert o in ("s", "f", "t"), f"Uknown dimension {o}"
+            assert o not in seen, {"s": "Spatial smoothing can be specified at most once",
+                                   "t": "Temporal interpolation can be specified once only",
+                                   "f": "Frequency interpolation can be specified once only"}[o]
+            seen.add(o)
+        if "s" in seen:
+            assert cov_mat_space is not None, "A spatial covariance matrix is required for spatial smoothing"
+        assert "f" in seen, "Frequency interpolation is required"
+        assert "t" in seen, "Time interpolation is required"
+        self._order = order
+        host = lambda c: None if c is None else np.asarray(c.detach().cpu() if isinstance(c, torch.Tensor) else c, np.complex128)
+        ct, cf, cs = host(cov_mat_time), host(cov_mat_freq), host(cov_mat_space)
+        mask, pilots = np.asarray(pilot_pattern.mask), np.asarray(pilot_pattern.pilots)
+        ntx, ns, T, F = mask.shape
+        # 0 data / unused, 1 pilot with energy, 2 zero-power pilot (_build_pilot_mask, :1704-1734)
+        pm = np.zeros([ntx, ns, T, F], int)
+        self._src, self._dst = [], []              # scatter of the inputs onto the grid (_build_inputs2rg_indices, :1736-1761)
+        for tx in range(ntx):
+            for st in range(ns):
+                pos = np.flatnonzero(mask[tx, st].reshape(-1))
+                live = np.abs(pilots[tx, st, :len(pos)]) > 0.0
+                pm[tx, st].reshape(-1)[pos] = np.where(live, 1, 2)
+                self._src.append((tx * ns + st) * pilots.shape[-1] + np.flatnonzero(live))
+                self._dst.append((tx * ns + st) * T * F + pos[live])
+        self._src, self._dst = np.concatenate(self._src), np.concatenate(self._dst)
+        self._grid = (ntx, ns, T, F)
+        self._num_pilots = pilots.shape[-1]
+        self._steps = []
+        for i, o in enumerate(order):
+            last = i == len(order) - 1
+            if o == "f":
+                step = _LMMSE1D(pm, cf, last)
+                pm = np.where(np.any(pm == 1, axis=-1, keepdims=True), 1, pm)
+            elif o == "t":
+                pmt = np.swapaxes(pm, -1, -2)
+                step = _LMMSE1D(pmt, ct, last)
+                pm = np.swapaxes(np.where(np.any(pmt == 1, axis=-1, keepdims=True), 1, pmt), -1, -2)
+            else:
+                step = _SpatialFilter(cs, last)
+            self._steps.append((o, step, (pm == 1).astype(np.float64)))
+        self._dev = {}
+
+    def _interpolate(self, h_hat, err_var):
+        """the algebra on whatever device the inputs live on (complex128 / float64 inside); h_hat
+        [B, rx, ra, tx, st, num_pilots], err_var broadcastable to it"""
+        dev = h_hat.device
+        ntx, ns, T, F = self._grid
+        if dev not in self._dev:
+            self._dev[dev] = (torch.from_numpy(self._src).to(dev), torch.from_numpy(self._dst).to(dev),
+                              [torch.from_numpy(m).to(dev) for _, _, m in self._steps])
+        src, dst, masks = self._dev[dev]
+        lead = tuple(h_hat.shape[:3])
+        assert tuple(h_hat.shape[3:]) == (ntx, ns, self._num_pilots), \
+            "h_hat must have shape [batch, num_rx, num_rx_ant, num_tx, num_streams_per_tx, num_pilots]"
+        hp = h_hat.to(torch.complex128).reshape(lead + (-1,))
+        ep = torch.broadcast_to(err_var, h_hat.shape).to(torch.float64).reshape(lead + (-1,))
+        h = torch.zeros(lead + (ntx * ns * T * F,), dtype=torch.complex128, device=dev).index_copy_(-1, dst, hp.index_select(-1, src))
+        e = torch.zeros(lead + (ntx * ns * T * F,), dtype=torch.float64, device=dev).index_copy_(-1, dst, ep.index_select(-1, src))
+        h, e = h.reshape(lead + (ntx, ns, T, F)), e.reshape(lead + (ntx, ns, T, F))
+        for (o, step, _), m in zip(self._steps, masks):
+            if o == "f":
+                h, e = step(h, e)
+            elif o == "t":
+                h, e = step(h.transpose(-1, -2).contiguous(), e.transpose(-1, -2).contiguous())
+                h, e = h.transpose(-1, -2), e.transpose(-1, -2)
+            else:
+                h, e = step(h.movedim(2, -1).contiguous(), e.movedim(2, -1).contiguous())
+                h, e = h.movedim(-1, 2), e.movedim(-1, 2)
+            e = e * m
+        return h.contiguous(), e.contiguous()
+
+    def __call__(self, h_hat, err_var):
+        h_hat = _ffi.to_device(h_hat, torch.complex64)
+        err_var = _ffi.to_device(err_var, torch.float32)
+        h, e = self._interpolate(h_hat, err_var)
+        return wrap(h.to(self.cdtype)), wrap(e.to(self.rdtype))
+
+
+def _tdl_pdp(model):
+    import json
+    import os
+    assert model in ("A", "B", "C", "D", "E"), "Invalid TDL model"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "channel", "tr38901", "tdl_models.json")
+    with open(path) as f:
+        p = json.load(f)[model]
+    return bool(p["los"]), np.asarray(p["delays"], float), np.power(10.0, np.asarray(p["powers"], float) / 10.0)
+
+
+def tdl_freq_cov_mat(model, subcarrier_spacing, fft_size, delay_spread, precision=None):
+    """Frequency covariance matrix of a TDL model, R[u, v] = sum_l P_l exp(-j 2 pi tau_l df (u - v)), [fft_size, fft_size]
+    (reference channel_estimation.py:1856-1953; host constant, like there)."""
+    from ..config import config, dtypes
+    los, delays, pw = _tdl_pdp(model)
+    delays = delays * delay_spread
+    if los:                                            # the specular and the first scattered tap share a delay (:1928-1931)
+        pw = np.concatenate([[pw[0] + pw[1]], pw[2:]])
+        delays = delays[1:]
+    pw = pw / pw.sum()
+    ph = np.exp(1j * (-2. * np.pi * subcarrier_spacing * np.arange(fft_size))[None, :] * delays[:, None])
+    cov = np.einsum("l,lu,lv->uv", pw, ph, np.conj(ph))
+    return wrap(torch.from_numpy(cov).to(dtypes[precision or config.precision]["torch"]["cdtype"]))
+
+
+def tdl_time_cov_mat(model, speed, carrier_frequency, ofdm_symbol_duration, num_ofdm_symbols, los_angle_of_arrival=np.pi / 4.,
+                     precision=None):
+    """Time covariance matrix of a TDL model: Jakes' J0(nu dt (u - v)) of the Doppler spread nu = 2 pi v / c f_c, plus the
+    specular term of the LoS models, [num_ofdm_symbols, num_ofdm_symbols] (reference channel_estimation.py:1956-2070)."""
+    from scipy.special import jv
+    from ..config import config, dtypes
+    los, _, pw = _tdl_pdp(model)
+    pw = pw / pw.sum()
+    nu = 2. * np.pi * speed / 299792458. * carrier_frequency
+    i = np.arange(num_ofdm_symbols)
+    e = nu * ofdm_symbol_duration * (i[:, None] - i[None, :])
+    cov = jv(0.0, e) * (pw[1:].sum() if los else pw.sum()) + (np.exp(1j * e * np.cos(los_angle_of_arrival)) * pw[0] if los else 0.)
+    return wrap(torch.from_numpy(np.asarray(cov, np.complex128)).to(dtypes[precision or config.precision]["torch"]["cdtype"]))

@@ -50,7 +50,8 @@ SURFACE = {      # reference file -> (import path in sionna.phy, names)
     "mimo/detection.py": ("mimo", ["LinearDetector", "KBestDetector", "EPDetector", "MMSEPICDetector"]),
     "ofdm/resource_grid.py": ("ofdm", ["ResourceGrid", "ResourceGridMapper", "ResourceGridDemapper", "RemoveNulledSubcarriers"]),
     "ofdm/pilot_pattern.py": ("ofdm", ["PilotPattern", "EmptyPilotPattern", "KroneckerPilotPattern"]),
-    "ofdm/channel_estimation.py": ("ofdm", ["LSChannelEstimator", "NearestNeighborInterpolator", "LinearInterpolator"]),
+    "ofdm/channel_estimation.py": ("ofdm", ["LSChannelEstimator", "NearestNeighborInterpolator", "LinearInterpolator", "LMMSEInterpolator",
+                                            "tdl_freq_cov_mat", "tdl_time_cov_mat"]),
     "ofdm/equalization.py": ("ofdm", ["OFDMEqualizer", "LMMSEEqualizer", "ZFEqualizer", "MFEqualizer"]),
     "ofdm/detection.py": ("ofdm", ["LinearDetector", "KBestDetector", "EPDetector", "MMSEPICDetector"]),
     "ofdm/modulator.py": ("ofdm", ["OFDMModulator"]),
