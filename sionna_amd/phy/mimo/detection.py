@@ -144,6 +144,36 @@ class EPDetector(Block):
         z = out.reshape(lead_k + (2, P))
         return self._pam2qam(z[..., 0, :].contiguous(), z[..., 1, :].contiguous())
 
+    # The steps of one EP iteration as the reference exposes them (mimo/detection.py:1166-1227), for code that drives the
+    # iteration itself (research variants of the detector): element-wise / small-matrix tensor algebra on whatever device the
+    # operands live on.  ``call`` does NOT go through them - the whole detector is one kernel (csrc/mimo.hip ep_solve).
+    def compute_sigma_mu(self, h_t_h, h_t_y, no, lam, gam):
+        """Equations (28) and (29)"""
+        sigma = torch.linalg.inv(h_t_h + no * torch.diag_embed(lam))
+        mu = torch.matmul(sigma, h_t_y + no * gam.unsqueeze(-1)).squeeze(-1)
+        return torch.diagonal(sigma * no, dim1=-2, dim2=-1), mu
+
+    def compute_v_x_obs(self, sigma, mu, lam, gam):
+        """Equations (31) and (32)"""
+        v_obs = torch.clamp_min(1 / (1 / sigma - lam), self._prec)
+        return v_obs, v_obs * (mu / sigma - gam)
+
+    def compute_v_x(self, v_obs, x_obs):
+        """Equation (33): mean and variance of the PAM symbols under the cavity distribution, and its logits"""
+        pts = torch.as_tensor(self._points, dtype=x_obs.dtype, device=x_obs.device)
+        logits = -torch.pow(x_obs.unsqueeze(-1) - pts, 2) / (2. * v_obs.unsqueeze(-1))
+        pmf = torch.softmax(logits, dim=-1)
+        x = torch.sum(pts * pmf, dim=-1, keepdim=True)
+        v = torch.clamp_min(torch.sum((pts - x) ** 2 * pmf, dim=-1), self._prec)
+        return v, x.squeeze(-1), logits
+
+    def update_lam_gam(self, v, v_obs, x, x_obs, lam, gam):
+        """Equations (35) - (38): new multipliers where they stay non-negative, damped by beta"""
+        lam_new, gam_new = 1 / v - 1 / v_obs, x / v - x_obs / v_obs
+        keep = lam_new < 0
+        lam_new, gam_new = torch.where(keep, lam, lam_new), torch.where(keep, gam, gam_new)
+        return (1 - self._beta) * lam_new + self._beta * lam, (1 - self._beta) * gam_new + self._beta * gam
+
     def call(self, y, h, s):
         self._require_single()
         y = _ffi.to_device(y, torch.complex64)

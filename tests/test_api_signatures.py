@@ -83,11 +83,7 @@ def test_signature_matches_reference(name):
 
 
 # public attributes the reference classes define that this build leaves out, each with its reason
-KNOWN_MISSING = {
-    # the steps of the EP iteration are public methods of the reference block; here the whole detector is one kernel
-    ("mimo.EPDetector", "compute_sigma_mu"): "inside csrc/mimo.hip", ("mimo.EPDetector", "compute_v_x_obs"): "inside csrc/mimo.hip",
-    ("mimo.EPDetector", "compute_v_x"): "inside csrc/mimo.hip", ("mimo.EPDetector", "update_lam_gam"): "inside csrc/mimo.hip",
-}
+KNOWN_MISSING = {}
 
 
 @pytest.mark.parametrize("name", sorted(k for k, v in SIG.items() if v["kind"] == "class" and v.get("public")))
