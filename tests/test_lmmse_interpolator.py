@@ -20,7 +20,7 @@ def _pattern(g):
     return types.SimpleNamespace(mask=g["mask"], pilots=g["pilots"])
 
 
-@pytest.mark.parametrize("gi", [0, 1])
+@pytest.mark.parametrize("gi", [0, 1, 2, 3])
 @pytest.mark.parametrize("order", ORDERS)
 def test_interpolator_matches_reference_execution_and_oracle(gi, order):
     from sionna_amd.phy.ofdm import LMMSEInterpolator

@@ -15,7 +15,7 @@ GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "lmmse_interp_r
 ORDERS = [str(o) for o in GOLD["orders"]]
 
 
-@pytest.mark.parametrize("gi", [0, 1])
+@pytest.mark.parametrize("gi", [0, 1, 2, 3])
 @pytest.mark.parametrize("order", ORDERS)
 def test_lmmse_interpolator_matches_reference_execution(gi, order):
     g = {k.split("/", 1)[1]: GOLD[k] for k in GOLD.files if k.startswith(f"g{gi}/")}

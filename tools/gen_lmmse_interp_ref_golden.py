@@ -13,7 +13,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 OUT = os.path.join(ROOT, "tests", "golden", "lmmse_interp_ref_golden.npz")
-GRIDS = [dict(fft=24, num_tx=2, spt=1, ra=4, B=3), dict(fft=16, num_tx=1, spt=2, ra=2, B=2)]
+GRIDS = [dict(fft=24, num_tx=2, spt=1, ra=4, B=3), dict(fft=16, num_tx=1, spt=2, ra=2, B=2),
+         # the pilot patterns of the reference's own test (test/unit/ofdm/test_ofdm_channel_estimation.py:829-883): one stream
+         # with two pilots and three with one on a single OFDM symbol (rows with different pilot counts, many zero-power
+         # slots), and a Kronecker pattern with a single pilot symbol
+         dict(fft=12, num_tx=4, spt=1, ra=2, B=2, sparse=True), dict(fft=16, num_tx=2, spt=1, ra=2, B=2, pilot_symbols=[3])]
 ORDERS = ["t-f", "f-t", "t-f-s", "s-f-t", "f-s-t"]
 
 
@@ -28,9 +32,17 @@ def main():
     out = {"orders": np.array(ORDERS)}
     for gi, G in enumerate(GRIDS):
         rng = np.random.default_rng(77 + gi)
-        rg = ofdm.ResourceGrid(num_ofdm_symbols=14, fft_size=G["fft"], subcarrier_spacing=30e3, num_tx=G["num_tx"],
-                               num_streams_per_tx=G["spt"], pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
-        pp = rg.pilot_pattern
+        if G.get("sparse"):
+            m = np.zeros([4, 1, 14, 12], bool)
+            m[..., 5, :] = True
+            p = np.zeros([4, 1, 12], np.complex64)
+            p[0, 0, [0, 11]], p[1, 0, 1], p[2, 0, 5], p[3, 0, 10] = 1, 1, 1, 1
+            pp = ofdm.PilotPattern(m, p)
+        else:
+            rg = ofdm.ResourceGrid(num_ofdm_symbols=14, fft_size=G["fft"], subcarrier_spacing=30e3, num_tx=G["num_tx"],
+                                   num_streams_per_tx=G["spt"], pilot_pattern="kronecker",
+                                   pilot_ofdm_symbol_indices=G.get("pilot_symbols", [2, 11]))
+            pp = rg.pilot_pattern
         pilots, mask = np.asarray(pp.pilots).astype(np.complex64), np.asarray(pp.mask).astype(np.uint8)
         F, T, ra, B = G["fft"], 14, G["ra"], G["B"]
         cf = np.asarray(ce.tdl_freq_cov_mat("A", 30e3, F, 300e-9)).astype(np.complex64)
