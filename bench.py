@@ -581,9 +581,12 @@ def main():
     ap.add_argument("--dry-dist", action="store_true",
                     help="launch / rendezvous / step / reduce logic only, on host tensors over gloo (no GPU, no kernels): "
                          "what tests/test_bench_dist.py runs through the real `--gpus N` self-launch")
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
-                    help="c2 = headline LDPC decode (default); c4 = OFDM 4x2 LMMSE pass; c5 = Polar SCL-8 (single GPU)")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5", "c5_bp"],
+                    help="c2 = headline LDPC decode (default); c4 = OFDM 4x2 LMMSE pass; c5 = Polar SCL-8; c5_bp = Polar BP-20 "
+                         "on the C5 code (single GPU)")
     args = ap.parse_args()
+    if args.workload == "c5_bp":
+        return print(json.dumps(bench_c5_bp(args)))
     if args.workload == "c4":
         return print(json.dumps(bench_c4(args)))
     if args.workload == "c5":
