@@ -184,6 +184,26 @@ int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
                            float offset, int hard_out, int return_infobits,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* Specialised decoders (csrc/ldpc5g_jit.cpp).  For codes whose schedule is static and whose messages fit in LDS (lifting
+ * size a multiple of 128, whole base rows / columns, k, n and the interleaver's row length multiples of 64 - BASELINE
+ * config C2), samd_ldpc5g_decode_f32 with SAMD_CN_MINSUM / SAMD_CN_OFFSET_MINSUM runs a kernel GENERATED for that one code:
+ * the per-wave work lists written out as straight-line source (block offsets, shifts and rate-matching offsets as
+ * constants), compiled once per process and code with hipRTC (libhiprtc.so, bound with dlopen) for gfx950.  Same
+ * reference path (decoding.py:1427-1536, 416-524, 681-953), same bits as the generic kernel.  Compilation happens at the
+ * first decode of at least 1024 codewords (development options SAMD_LDPC_JIT = 0 off / 1 default / 2 any batch,
+ * SAMD_LDPC_JIT_MIN_BATCH); whenever it is not possible the generic kernel runs.
+ *   ..._supported: 1 when the handle's code is in that class.
+ *   ..._prepare:   compile now; 1 ready, 0 not in the class / switched off, < 0 failed (samd_last_error = compiler log).
+ *   ..._source:    the generated translation unit (with_ops = 0: without the gfx950 operation definitions and the kernel
+ *                  entry - what tests/jit_emu runs on the CPU); returns its length, copies at most cap - 1 bytes.
+ *   ..._code:      the compiled code object (for llvm-objdump); returns its size, copies when cap suffices.
+ * ..._source works on a handle created under the development option SAMD_HOST_ONLY=1 (no device needed; such a handle
+ * builds tables and schedules only and refuses every launch). */
+int samd_ldpc5g_jit_supported(const samd_ldpc5g_t* h);
+int samd_ldpc5g_jit_prepare(const samd_ldpc5g_t* h, int return_infobits);
+long samd_ldpc5g_jit_source(const samd_ldpc5g_t* h, int return_infobits, int with_ops, char* buf, size_t cap);
+long samd_ldpc5g_jit_code(const samd_ldpc5g_t* h, int return_infobits, char* buf, size_t cap);
+
 /* ------------------------------------------------------------------------------------
  * Mapping.  points: DEVICE complex64[2^m] (interleaved re,im), label of point i = binary
  * representation of i, MSB first (mapping.py:486-514).

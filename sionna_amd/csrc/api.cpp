@@ -49,6 +49,7 @@ std::string opt_str(const char* key) {
   auto it = r.kv.find(key);
   return it == r.kv.end() ? std::string() : it->second;
 }
+bool host_only() { return opt_set("SAMD_HOST_ONLY"); }
 int opt_generation() { return registry().generation.load(std::memory_order_acquire); }
 }  // namespace samd
 

@@ -38,10 +38,15 @@ inline int launch_status() {
   return SAMD_OK;
 }
 
+// SAMD_HOST_ONLY (development option, read when a handle is built): tables and schedules are built, nothing is copied
+// to a device - for the tools and tests that inspect what the host generates (the specialised LDPC kernels' source) on
+// a machine without a GPU.  Such a handle refuses every launch.
+bool host_only();
+
 template <typename T>
 inline int upload(T** dst, const T* src, size_t n) {
   *dst = nullptr;
-  if (n == 0) return SAMD_OK;
+  if (n == 0 || host_only()) return SAMD_OK;
   SAMD_HIP_CHECK(hipMalloc((void**)dst, n * sizeof(T)));
   SAMD_HIP_CHECK(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
   return SAMD_OK;

@@ -1,0 +1,58 @@
+// Per-lane operations of the specialised 5G LDPC decoder as gfx950 code (source TEXT, compiled by hipRTC in front of
+// ldpc5g_jit_templates.h and the generated per-wave programs; csrc/ldpc5g_jit.cpp).  A "lane value" is an ordinary
+// float / unsigned here: one wavefront = 64 lifted copies of a base-graph node.
+typedef float F32;
+typedef unsigned U32;
+typedef __attribute__((address_space(3))) float jit_lds_f32;
+typedef float jit_f32x2 __attribute__((ext_vector_type(2)));
+#define JIT_DEV static __device__ __forceinline__
+#define JIT_INF __builtin_inff()
+#define JIT_BLOCK ((int)blockIdx.x)
+#define JIT_GRID ((int)gridDim.x)
+
+JIT_DEV U32 jit_lane4() { return 4u * (threadIdx.x & 63u); }
+JIT_DEV int jit_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// LDS is addressed by plain byte offsets: the kernel's only __shared__ object starts at offset 0 (checked at entry)
+JIT_DEV F32 lds_ld(U32 a, unsigned off) { return *(jit_lds_f32*)(unsigned long)(a + off); }
+JIT_DEV void lds_st(U32 a, unsigned off, F32 v) { *(jit_lds_f32*)(unsigned long)(a + off) = v; }
+JIT_DEV F32 g_ld(const float* row, U32 voff, unsigned coff) { return *(const float*)((const char*)row + (voff + coff)); }
+JIT_DEV void g_st(float* row, U32 voff, unsigned coff, F32 v) { *(float*)((char*)row + (voff + coff)) = v; }
+JIT_DEV F32 jit_bcast(float x) { return x; }
+JIT_DEV F32 f_med3(F32 a, F32 b, F32 c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+JIT_DEV F32 f_abs(F32 a) { return __builtin_fabsf(a); }
+JIT_DEV F32 f_neg(F32 a) { return -1.f * a; }
+JIT_DEV F32 f_clamp(F32 x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }   // tf.clip_by_value
+JIT_DEV F32 f_ge0_10(F32 x) { return (0.f >= x) ? 1.f : 0.f; }                                         // decoding.py:623-624
+JIT_DEV F32 f_sel_gt(F32 a, F32 b, F32 x, F32 y) { return a > b ? x : y; }
+JIT_DEV F32 f_sel_eq(F32 a, F32 b, F32 x, F32 y) { return a == b ? x : y; }
+JIT_DEV U32 f_bits(F32 a) { return __builtin_bit_cast(unsigned, a); }
+JIT_DEV F32 u_float(U32 a) { return __builtin_bit_cast(float, a); }
+JIT_DEV U32 u_min(U32 a, U32 b) { return a < b ? a : b; }
+// the value itself, opaque to the optimiser (no instruction beyond a register copy): what is derived from it is computed
+// where it is written instead of being hoisted out of the loops
+JIT_DEV U32 u_here(U32 a) {
+  asm volatile("" : "+v"(a));
+  return a;
+}
+// a ^ 256, computed where it is written (volatile: not hoisted out of the iteration loop into a long-lived register)
+JIT_DEV U32 u_xor256_here(U32 a) {
+  U32 r;
+  asm volatile("v_xor_b32_e32 %0, 0x100, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+JIT_DEV U32 u_xor3(U32 a, U32 b, U32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+JIT_DEV U32 u_xor_and(U32 m, U32 v, unsigned k) { return __builtin_amdgcn_bitop3_b32(m, v, k, 0x78); }   // m ^ (v & k)
+// two IEEE additions / subtractions in one issue slot (v_pk_add_f32)
+JIT_DEV void f_pk_add(F32& x0, F32& x1, F32 c0, F32 c1) {
+  jit_f32x2 x = {x0, x1};
+  x += jit_f32x2{c0, c1};
+  x0 = x.x; x1 = x.y;
+}
+JIT_DEV void f_pk_sub(F32& e0, F32& e1, F32 x0, F32 x1, F32 c0, F32 c1) {
+  const jit_f32x2 e = jit_f32x2{x0, x1} - jit_f32x2{c0, c1};
+  e0 = e.x; e1 = e.y;
+}
+// a phase exchanges LDS data only: wait for this wave's LDS operations, then the workgroup barrier
+JIT_DEV void jit_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <int P>
+JIT_DEV void jit_setprio() { __builtin_amdgcn_s_setprio(P); }

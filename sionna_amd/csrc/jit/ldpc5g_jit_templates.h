@@ -1,0 +1,161 @@
+// Node updates of the SPECIALISED 5G LDPC decoder (csrc/ldpc5g_jit.cpp), as source TEXT: this file is embedded in
+// libsionna_amd.so and compiled at run time (hipRTC, --offload-arch=gfx950) together with the per-wave programs the
+// library generates for ONE code (base graph, lifting size, rate matching).  It is written against a small set of
+// per-lane operations (F32 / U32 values, lds_ld / lds_st, f_med3, ...; gfx950 definitions: ldpc5g_jit_ops_gfx950.h) so
+// that tests/jit_emu can compile the SAME text with 64-wide CPU stand-ins and run the generated programs against the
+// C oracle without a GPU.  Uniform (per-wave) quantities are plain float / unsigned / int / bool.
+//
+// Arithmetic = csrc/ldpc5g_onchip_ms.inc (ms_cn_row with VAR 1, ms_vn_col), operation for operation: min-sum /
+// offset-min-sum of decoding.py:755-953 and vn_update_sum of decoding.py:681-732, hence the same bits as the oracle.
+// JIT_Z4 = 4 Z (bytes of one edge block); message layout as in ldpc5g_onchip_bp.hip: block (row, position in the row),
+// indexed by the CHECK node's lifted copy.
+// Value arrays are [edge][chunk]: the two chunks of an edge - the operands of one packed-fp32 operation - are neighbours
+// (with [chunk][edge] the optimiser forms overlapping vector accesses and leaves the arrays in scratch memory).
+
+#define JIT_NOOUT 0xFFFFFFFFu
+
+// value written to the output tensor for a VN total x (decoding.py:620-626): clip, then hard decision or the logit
+JIT_DEV F32 jit_outval(F32 x, float llr_max, int hard_out) {
+  const F32 xc = f_clamp(x, -llr_max, llr_max);
+  return hard_out ? f_ge0_10(xc) : f_neg(xc);
+}
+
+// channel LLR of one VN chunk (decoding.py:552-565): clip, logit -> LLR, "+ 0" so that no LLR is -0
+JIT_DEV F32 jit_chan(F32 raw, float llr_max) { return f_neg(f_clamp(raw, -llr_max, llr_max)) + 0.f; }
+
+// ((l4 + k) mod 4Z) + base for k in [0, 4Z): block position of the lane's VN in an edge block with that shift
+JIT_DEV U32 jit_vn_addr(U32 l4, unsigned k, unsigned base) {
+  const U32 t = l4 + k;
+  return u_min(t, t - (unsigned)JIT_Z4) + base;
+}
+
+// l4 + k as a value the compiler treats as computed HERE: the slots of a row are then this one register plus the offset
+// fields of the DS instructions.  (Written as plain l4 + k, every distinct slot address of every item is loop invariant
+// and is hoisted into a register of its own - hundreds of them, spilled to scratch.)
+JIT_DEV U32 jit_base(U32 l4, unsigned k) { return u_here(l4) + k; }
+
+// ---------------------------------------------------------------------------------------------- check node row
+// a0 = byte address of the lane's slot in the row's first block (chunk 0 of the item); NCH chunks of 64 lifted copies
+template <int D, int NCH>
+JIT_DEV void jit_cn_load(F32 (&v)[D][NCH], U32 a0) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) v[i][h] = lds_ld(a0, (unsigned)i * JIT_Z4 + 256u * h);
+}
+
+// FUSE: the row's last edge goes to a degree-1 VN of the same lane; its update happens here (lf = its channel LLR).
+// oc[h] = byte offset (constant part) of that VN's output element, JIT_NOOUT = not part of the output
+template <int D, int NCH, bool FUSE>
+JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, float offset, bool last,
+                           float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
+  F32 m1[NCH], m2[NCH];
+  U32 sx[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) { m1[h] = JIT_INF; m2[h] = JIT_INF; sx[h] = 0u; }
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const F32 av = f_abs(v[i][h]);
+      m2[h] = f_med3(m1[h], m2[h], av);              // second smallest, with multiplicity
+      m1[h] = f_med3(m1[h], av, 0.f);                // = min(m1, |v|) for non-negative values
+      if (i & 1) sx[h] = u_xor3(sx[h], f_bits(v[i - 1][h]), f_bits(v[i][h]));
+      else if (i == D - 1) sx[h] = sx[h] ^ f_bits(v[i][h]);
+    }
+  F32 a1[NCH], a2[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) {
+    // unique minimum <=> m2 > m1; (m2 - m1) + m1 is the reference's arithmetic (decoding.py:863)
+    const F32 min_e = f_sel_gt(m2[h], m1[h], (m2[h] - m1[h]) + m1[h], m1[h]);
+    a1[h] = f_med3(m1[h] - offset, 0.f, llr_max);
+    a2[h] = f_med3(min_e - offset, 0.f, llr_max);
+    sx[h] = sx[h] & 0x80000000u;                     // row sign into both candidates (their sign bits are 0)
+    a1[h] = u_float(f_bits(a1[h]) | sx[h]);
+    a2[h] = u_float(f_bits(a2[h]) | sx[h]);
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    F32 c2v[NCH];
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const F32 mag = f_sel_eq(f_abs(v[i][h]), m1[h], a2[h], a1[h]);
+      c2v[h] = u_float(u_xor_and(f_bits(mag), f_bits(v[i][h]), 0x80000000u));   // mag ^ (v & msb)
+      if (FUSE && i == D - 1) {
+        const F32 x = c2v[h] + lf[h];                // (0 + c2v) + llr
+        const unsigned oc = h ? oc1 : oc0;
+        if (oc != JIT_NOOUT) {
+          if (last) g_st(orow, u_here(ovoff), oc, jit_outval(x, llr_max, hard_out));
+        }
+        c2v[h] = f_med3(x - c2v[h], -llr_max, llr_max);   // the slot now holds the next v2c
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) lds_st(a0, (unsigned)i * JIT_Z4 + 256u * h, c2v[h]);
+  }
+}
+
+// v2c of iteration 0 for the fused degree-1 column of a row: its channel LLR
+template <int D, int NCH>
+JIT_DEV void jit_cn_init_fused(U32 a0, const F32 (&lf)[NCH]) {
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) lds_st(a0, (unsigned)(D - 1) * JIT_Z4 + 256u * h, lf[h]);
+}
+
+// ---------------------------------------------------------------------------------------------- variable node column
+// a[i][h] = byte address of the lane's slot in the block of the column's i-th edge (rows ascending), chunk h: registers
+// that live for the whole launch, or - second chunk at Z = 128 - the first chunk's position with bit 8 flipped,
+// ((t + 256) mod 512) = (t mod 512) ^ 256, computed per item (the generated code writes the array out)
+template <int D, int NCH>
+JIT_DEV void jit_vn_load(F32 (&c)[D][NCH], const U32 (&a)[D][NCH]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) c[i][h] = lds_ld(a[i][h], 0u);
+}
+
+template <int D, int NCH>
+JIT_DEV void jit_vn_init(const U32 (&a)[D][NCH], const F32 (&l)[NCH]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) lds_st(a[i][h], 0u, l[h]);
+}
+
+template <int D, int NCH>
+JIT_DEV void jit_vn_update(F32 (&c)[D][NCH], const U32 (&a)[D][NCH], const F32 (&l)[NCH], float llr_max, bool last,
+                           float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
+  F32 x[NCH];
+  if (NCH == 2) {
+    // both chunks of an edge in one packed-fp32 operation: two IEEE additions, the results of two scalar ones
+    F32 x0 = 0.f, x1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < D; ++i) f_pk_add(x0, x1, c[i][0], c[i][NCH - 1]);
+    f_pk_add(x0, x1, l[0], l[NCH - 1]);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      F32 e0, e1;
+      f_pk_sub(e0, e1, x0, x1, c[i][0], c[i][NCH - 1]);
+      lds_st(a[i][0], 0u, f_med3(e0, -llr_max, llr_max));
+      lds_st(a[i][NCH - 1], 0u, f_med3(e1, -llr_max, llr_max));
+    }
+    x[0] = x0; x[NCH - 1] = x1;
+  } else {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      x[h] = 0.f;
+#pragma unroll
+      for (int i = 0; i < D; ++i) x[h] = x[h] + c[i][h];
+      x[h] = x[h] + l[h];
+#pragma unroll
+      for (int i = 0; i < D; ++i) lds_st(a[i][h], 0u, f_med3(x[h] - c[i][h], -llr_max, llr_max));
+    }
+  }
+  if (last) {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      const unsigned oc = h ? oc1 : oc0;
+      if (oc != JIT_NOOUT) g_st(orow, u_here(ovoff), oc, jit_outval(x[h], llr_max, hard_out));
+    }
+  }
+}

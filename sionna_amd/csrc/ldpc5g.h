@@ -15,6 +15,7 @@ struct samd_ldpc5g_opt {
   bool enc_bytes = false, enc_persist = false, onchip_compressed = false, force_spill = false, no_spill = false;
   bool no_onchip_layered = false, bp_engine = false, onchip_v1 = false, ms_nogroup = false, ms_noz128 = false;
   int ms_var = 1, ms_ldsbar = 0, onchip_grid = 0, enc_dbg = 0, ms_dataflow = 0;
+  int jit = 1, jit_min_batch = 1024;     // specialised kernels (ldpc5g_jit.cpp): 0 off, 1 from jit_min_batch codewords, 2 always
   void capture() {
     using samd::opt_set; using samd::opt_int;
     enc_bytes = opt_set("SAMD_ENC_BYTES"); enc_persist = opt_set("SAMD_ENC_PERSIST");
@@ -25,14 +26,20 @@ struct samd_ldpc5g_opt {
     ms_var = (int)opt_int("SAMD_MS_VAR", 1) & 1; ms_ldsbar = (int)opt_int("SAMD_MS_LDSBAR", 0);
     onchip_grid = (int)opt_int("SAMD_ONCHIP_GRID", 0);
     ms_dataflow = (int)opt_int("SAMD_MS_DATAFLOW", 0);
+    jit = (int)opt_int("SAMD_LDPC_JIT", 1); jit_min_batch = (int)opt_int("SAMD_LDPC_JIT_MIN_BATCH", 1024);
 #ifdef SAMD_DEV
     enc_dbg = (int)opt_int("SAMD_ENC_DBG", 0);        // skips encoder phases: wrong results, development builds only
 #endif
   }
 };
 
+namespace samd { struct JitPlan; struct JitState; }
+
 struct samd_ldpc5g {
   samd_ldpc5g_opt opt;
+  int host_only = 0;           // built without a device (SAMD_HOST_ONLY): tables and schedules only, no launch
+  samd::JitPlan* jit_plan = nullptr;     // schedule of the specialised kernel (ldpc5g_jit.h); null: code outside its class
+  samd::JitState* jit_state = nullptr;   // compiled modules, created lazily (mutable behind a const handle)
   int bg = 0, z = 0, k = 0, n = 0, m_int = 0, nb_pruned = 0;
   int mb = 0, nb = 0, k_b = 0, k_ldpc = 0, n_ldpc = 0, n_vn = 0, n_cn = 0;
   int s_a = 0, s_b = 0;  // shifts of the core entries P_A, P_B (encoding.py:476-481)

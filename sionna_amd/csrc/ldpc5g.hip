@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "ldpc5g.h"
+#include "ldpc5g_jit.h"
 
 namespace samd {
 
@@ -376,6 +377,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   SAMD_REQUIRE(z >= 2 && z <= 384 && num_entries > 0, "bad lifting size");
   auto* h = new samd_ldpc5g();
   h->opt.capture();                                        // development switches: read once, here (options.h)
+  h->host_only = host_only() ? 1 : 0;
   h->bg = bg; h->z = z; h->k = k; h->n = n; h->m_int = num_bits_per_symbol; h->nb_pruned = nb_pruned;
   h->mb = bg == 1 ? 46 : 42; h->nb = bg == 1 ? 68 : 52; h->k_b = bg == 1 ? 22 : 10;
   h->k_ldpc = h->k_b * z; h->n_ldpc = h->nb * z;
@@ -450,6 +452,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   if (rc == SAMD_OK) rc = build_onchip_mss_tables(h, by_row);
   if (rc == SAMD_OK) rc = build_onchip_ly_tables(h, by_row);
   if (rc != SAMD_OK) { samd_ldpc5g_destroy(h); return rc; }
+  if (h->jit_plan) h->jit_state = new_jit_state();
   *out = h;
   return SAMD_OK;
 }
@@ -462,6 +465,7 @@ extern "C" void samd_ldpc5g_destroy(samd_ldpc5g_t* h) {
   free_onchip_bp_tables(h);
   free_onchip_mss_tables(h);
   free_onchip_ly_tables(h);
+  free_jit(h);
   delete h;
 }
 
@@ -568,6 +572,7 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
                                       int cn_mode, float llr_max, float offset, int hard_out, int return_infobits,
                                       void* workspace, size_t workspace_bytes, void* stream) {
   SAMD_REQUIRE(h && llr && out && batch > 0 && num_iter >= 0, "bad argument");
+  SAMD_REQUIRE(!h->host_only, "handle was built without a device (SAMD_HOST_ONLY)");
   if (cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || cn_mode == SAMD_CN_BOXPLUS_PHI_FAST) {   // one float per edge in LDS
     SAMD_REQUIRE(llr_max >= 0.f, "bad argument");
     if (use_spill_boxplus(h))                                             // ... the last rows' messages in L2

@@ -1,0 +1,54 @@
+// Specialised 5G LDPC decoders: the per-wave work lists of the explicit-message engine (ldpc5g_onchip_bp.hip builds
+// them, ldpc5g_decode_msg_kernel walks them with scalar code) turned into straight-line source for ONE code and
+// compiled at run time with hipRTC for gfx950 (ldpc5g_jit.cpp).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+struct samd_ldpc5g;
+
+namespace samd {
+
+struct JitItem {
+  int idx;    // base row (check-node item) or base column (variable-node item)
+  int q;      // first 64-lane chunk of lifted copies
+  int nch;    // chunks covered (1 or 2)
+  int prio;   // issue priority 0..3 (ldpc5g.h: item_priorities)
+};
+
+// Host-side description of the schedule (kept with the handle; nothing here lives on the device)
+struct JitPlan {
+  int z = 0, edges = 0, ncu = 0, nbu = 0;
+  std::vector<int32_t> row_off;                                     // [ncu] byte offset of the row's first edge block
+  std::vector<int> row_deg, fused_col;                              // [ncu]; fused degree-1 column or -1
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> col_edges;  // [nbu] (edge block byte offset, 4 shift), rows ascending
+  std::vector<char> col_fused;                                      // [nbu]
+  std::vector<std::vector<JitItem>> cn, vn;                         // [16 waves], in issue order
+};
+
+// development knobs of the generator (SAMD_JIT_* options, read when the source is generated)
+struct JitState;
+
+struct JitKnobs {
+  int pipe = 2;        // items whose loads are in flight (1: load - update - store per item)
+  int xor128 = 0;      // Z = 128: second chunk's block position recomputed in the loop (v_xor) instead of a register
+  int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
+  int prio = 1;        // s_setprio per item
+  int vnrev = 1;       // VN lists assigned to the waves in reverse order
+  void capture();
+};
+
+// true when the code is in the class the generator covers (see jit_eligible in ldpc5g_jit.cpp)
+bool jit_eligible(const samd_ldpc5g* h);
+// the whole translation unit handed to hipRTC.  with_ops = false: without the gfx950 operation definitions and the
+// __global__ entry (what tests/jit_emu compiles for the CPU)
+std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, bool with_ops, const JitKnobs& knobs);
+// SAMD_OK, SAMD_ERR_UNSUPPORTED (caller runs the generic kernel) or an error
+int launch_onchip_jit(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
+                      float llr_max, float offset, int hard_out, int return_infobits, void* stream);
+JitState* new_jit_state();
+void free_jit(samd_ldpc5g* h);
+
+}  // namespace samd

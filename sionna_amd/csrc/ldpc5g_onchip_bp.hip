@@ -19,6 +19,7 @@
 // (longest-processing-time first); every item is an instantiation for the row's exact degree / the
 // column's degree class, all table entries are wave-uniform scalars.
 #include "ldpc5g.h"
+#include "ldpc5g_jit.h"
 
 #include <cmath>
 #include "bp_math.h"
@@ -482,7 +483,9 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
   const bool df_shape = n_compact <= 64 && ncu <= 64;
   if (z % 128 == 0 && h->n_cn % z == 0 && h->n_vn % z == 0 && h->bp_waves == 16 && groups < 2) {
     bool ok = true;
-    struct It { int cost, key; int32_t x, y; int idx, pr; };
+    struct It { int cost, key; int32_t x, y; int idx, pr, q; };
+    JitPlan* plan = new JitPlan();
+    plan->cn.resize(h->bp_waves); plan->vn.resize(h->bp_waves);
     auto cost_in = [](const std::vector<std::pair<int, int32_t>>& items, int32_t id) {
       for (auto& it : items)
         if (it.second == id) return it.first;
@@ -501,7 +504,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
           if ((d >> 25) & 1) { ok = false; break; }
           const int idx = d & 0xFF, q = (d >> 8) & 0xFF, pr = (d >> 24) & 1;
           It it;
-          it.idx = idx; it.pr = pr;
+          it.idx = idx; it.pr = pr; it.q = q;
           it.cost = cost_in(phase ? vi2 : ci2, d) + 3;
           if (!phase) {
             const int f = fused_col[idx] >= 0;
@@ -563,6 +566,7 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
             rem -= it.cost;
             il.push_back(it.x | (prio << 24));
             il.push_back(it.y);
+            (phase ? plan->vn : plan->cn)[wv].push_back(JitItem{it.idx, it.q, it.pr ? 2 : 1, prio});
             const unsigned long long need = phase ? col_need[it.idx] : row_need[it.idx];
             dl.push_back((int32_t)(unsigned)(need & 0xFFFFFFFFull));
             dl.push_back((int32_t)(unsigned)(need >> 32));
@@ -577,6 +581,19 @@ int build_onchip_bp_tables(samd_ldpc5g* h, const std::vector<std::vector<std::pa
       if (il.size() / 2 >= 65536) ok = false;
     }
     h->ms_g_ok = ok && g_ptr.size() == (size_t)(2 * (nwv + 1)) ? 1 : 0;
+    if (h->ms_g_ok) {
+      // the same schedule as data for the source generator of the specialised kernel (ldpc5g_jit.cpp)
+      plan->z = z; plan->edges = edges; plan->ncu = ncu; plan->nbu = nbu;
+      plan->row_off.resize(ncu); plan->row_deg.resize(ncu); plan->fused_col.assign(fused_col.begin(), fused_col.begin() + ncu);
+      for (int r = 0; r < ncu; ++r) { plan->row_off[r] = row_off[r] & 0x3FFFF; plan->row_deg[r] = (int)by_row[r].size(); }
+      plan->col_edges.resize(nbu); plan->col_fused.assign(col_fused.begin(), col_fused.begin() + nbu);
+      for (int c = 0; c < nbu; ++c)
+        for (int i = 0; i < col_deg[c]; ++i)
+          plan->col_edges[c].push_back({col_ent2[col_start[c] + 2 * i], col_ent2[col_start[c] + 2 * i + 1]});
+      h->jit_plan = plan;
+    } else {
+      delete plan;
+    }
     g_cn.resize(g_cn.size() + 2, 0); g_vn.resize(g_vn.size() + 2, 0);
     i_cn.resize(i_cn.size() + 4, 0); i_vn.resize(i_vn.size() + 4, 0);
     d_cn.resize(d_cn.size() + 8, 0); d_vn.resize(d_vn.size() + 8, 0);

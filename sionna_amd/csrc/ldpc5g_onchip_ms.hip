@@ -23,6 +23,7 @@
 // the VALU operations directly (no scalar unpacking per edge).
 #define SAMD_MS_MAIN_TU
 #include "ldpc5g_onchip_ms.inc"
+#include "ldpc5g_jit.h"
 
 namespace samd {
 
@@ -46,6 +47,11 @@ int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int bat
     // kernels with the inlined tanh / atanh cost three minutes of compile time
     set_error("boxplus (tanh) runs on ldpc5g_decode_bp_kernel");
     return SAMD_ERR_UNSUPPORTED;
+  }
+  {
+    // the kernel generated for this code (ldpc5g_jit.cpp) when there is one; else the lists below
+    const int rc = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, st);
+    if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
   return launch_onchip_ms_mode<SAMD_CN_MINSUM>(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out,
                                                return_infobits, workspace, workspace_bytes, st);

@@ -1,0 +1,32 @@
+// TEST INFRASTRUCTURE: runs the per-wave programs libsionna_amd.so generated for one 5G LDPC code (JIT_EMU_SRC, written by
+// tests/test_jit_emu.py from samd_ldpc5g_jit_source) on the CPU - 16 host threads = the 16 waves of a workgroup, one
+// workgroup after the other.  See jit_emu_ops.h.
+#include "jit_emu_ops.h"
+#include JIT_EMU_SRC
+
+#include <thread>
+#include <vector>
+
+extern "C" int jit_emu_decode(const float* llr_in, float* out, int batch, int num_iter, float llr_max, float offset,
+                              int hard_out, int grid) {
+  std::vector<unsigned char> lds((size_t)JIT_LDS_FLOATS * 4);
+  for (int blk = 0; blk < grid; ++blk) {
+    memset(lds.data(), 0xFF, lds.size());                    // NaN pattern: a slot read before it was written shows up
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, 16);
+    std::vector<std::thread> th;
+    for (int w = 0; w < 16; ++w)
+      th.emplace_back([&, w]() {
+        jit_emu_ctx = JitEmuCtx{lds.data(), lds.size(), &bar, blk, grid};
+#define JIT_EMU_CASE(W) case W: jit_wave_##W(llr_in, out, batch, num_iter, llr_max, offset, hard_out); break;
+        switch (w) {
+          JIT_EMU_CASE(0) JIT_EMU_CASE(1) JIT_EMU_CASE(2) JIT_EMU_CASE(3) JIT_EMU_CASE(4) JIT_EMU_CASE(5) JIT_EMU_CASE(6)
+          JIT_EMU_CASE(7) JIT_EMU_CASE(8) JIT_EMU_CASE(9) JIT_EMU_CASE(10) JIT_EMU_CASE(11) JIT_EMU_CASE(12)
+          JIT_EMU_CASE(13) JIT_EMU_CASE(14) JIT_EMU_CASE(15)
+        }
+      });
+    for (auto& t : th) t.join();
+    pthread_barrier_destroy(&bar);
+  }
+  return 0;
+}

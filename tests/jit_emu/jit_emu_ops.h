@@ -1,0 +1,136 @@
+// TEST INFRASTRUCTURE (not part of the product): 64-wide CPU stand-ins for the per-lane operations of the specialised
+// 5G LDPC decoder, so that the source libsionna_amd.so GENERATES for a code (samd_ldpc5g_jit_source with with_ops = 0:
+// csrc/jit/ldpc5g_jit_templates.h + the per-wave programs) can be compiled with g++ and run against the C oracle on a
+// machine without a GPU (tests/test_jit_emu.py).  The gfx950 definitions of the same names are
+// sionna_amd/csrc/jit/ldpc5g_jit_ops_gfx950.h.  One "wave" = one host thread, LDS = one shared byte array, the workgroup
+// barrier = a pthread barrier; float arithmetic is IEEE single precision (compile with -ffp-contract=off).
+#pragma once
+#include <pthread.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+
+struct F32 {
+  float v[64];
+  F32() {}
+  F32(float x) { for (int i = 0; i < 64; ++i) v[i] = x; }
+};
+struct U32 {
+  unsigned v[64];
+  U32() {}
+  U32(unsigned x) { for (int i = 0; i < 64; ++i) v[i] = x; }
+};
+#define JIT_EMU_BIN(T, op)                                                       \
+  static inline T operator op(const T& a, const T& b) {                          \
+    T r;                                                                         \
+    for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] op b.v[i];                      \
+    return r;                                                                    \
+  }
+JIT_EMU_BIN(F32, +) JIT_EMU_BIN(F32, -) JIT_EMU_BIN(F32, *)
+JIT_EMU_BIN(U32, +) JIT_EMU_BIN(U32, -) JIT_EMU_BIN(U32, *) JIT_EMU_BIN(U32, ^) JIT_EMU_BIN(U32, &) JIT_EMU_BIN(U32, |)
+#undef JIT_EMU_BIN
+
+struct JitEmuCtx {
+  unsigned char* lds;
+  size_t lds_bytes;
+  pthread_barrier_t* bar;
+  int block, grid;
+};
+static thread_local JitEmuCtx jit_emu_ctx;
+
+#define JIT_DEV static inline
+#define JIT_INF std::numeric_limits<float>::infinity()
+#define JIT_BLOCK (jit_emu_ctx.block)
+#define JIT_GRID (jit_emu_ctx.grid)
+
+JIT_DEV U32 jit_lane4() {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = 4u * (unsigned)i;
+  return r;
+}
+JIT_DEV F32 lds_ld(const U32& a, unsigned off) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) {
+    const size_t p = (size_t)a.v[i] + off;
+    if (p + 4 > jit_emu_ctx.lds_bytes || (p & 3)) __builtin_trap();
+    memcpy(&r.v[i], jit_emu_ctx.lds + p, 4);
+  }
+  return r;
+}
+JIT_DEV void lds_st(const U32& a, unsigned off, const F32& x) {
+  for (int i = 0; i < 64; ++i) {
+    const size_t p = (size_t)a.v[i] + off;
+    if (p + 4 > jit_emu_ctx.lds_bytes || (p & 3)) __builtin_trap();
+    memcpy(jit_emu_ctx.lds + p, &x.v[i], 4);
+  }
+}
+JIT_DEV F32 g_ld(const float* row, const U32& voff, unsigned coff) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) memcpy(&r.v[i], (const char*)row + (voff.v[i] + coff), 4);
+  return r;
+}
+JIT_DEV void g_st(float* row, const U32& voff, unsigned coff, const F32& x) {
+  for (int i = 0; i < 64; ++i) memcpy((char*)row + (voff.v[i] + coff), &x.v[i], 4);
+}
+JIT_DEV F32 jit_bcast(float x) { return F32(x); }
+JIT_DEV float jit_emu_med3(float a, float b, float c) {      // v_med3_f32 on ordinary values: the middle operand itself
+  if (a <= b) return b <= c ? b : (a <= c ? c : a);
+  return a <= c ? a : (b <= c ? c : b);
+}
+JIT_DEV F32 f_med3(const F32& a, const F32& b, const F32& c) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = jit_emu_med3(a.v[i], b.v[i], c.v[i]);
+  return r;
+}
+JIT_DEV F32 f_abs(const F32& a) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = fabsf(a.v[i]);
+  return r;
+}
+JIT_DEV F32 f_neg(const F32& a) { return F32(-1.f) * a; }
+JIT_DEV F32 f_clamp(const F32& x, float lo, float hi) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = fminf(fmaxf(x.v[i], lo), hi);
+  return r;
+}
+JIT_DEV F32 f_ge0_10(const F32& x) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = (0.f >= x.v[i]) ? 1.f : 0.f;
+  return r;
+}
+JIT_DEV F32 f_sel_gt(const F32& a, const F32& b, const F32& x, const F32& y) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] > b.v[i] ? x.v[i] : y.v[i];
+  return r;
+}
+JIT_DEV F32 f_sel_eq(const F32& a, const F32& b, const F32& x, const F32& y) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] == b.v[i] ? x.v[i] : y.v[i];
+  return r;
+}
+JIT_DEV U32 f_bits(const F32& a) {
+  U32 r;
+  memcpy(r.v, a.v, sizeof(r.v));
+  return r;
+}
+JIT_DEV F32 u_float(const U32& a) {
+  F32 r;
+  memcpy(r.v, a.v, sizeof(r.v));
+  return r;
+}
+JIT_DEV U32 u_min(const U32& a, const U32& b) {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] < b.v[i] ? a.v[i] : b.v[i];
+  return r;
+}
+JIT_DEV U32 u_here(const U32& a) { return a; }
+JIT_DEV U32 u_xor256_here(const U32& a) { return a ^ U32(256u); }
+JIT_DEV U32 u_xor3(const U32& a, const U32& b, const U32& c) { return a ^ b ^ c; }
+JIT_DEV U32 u_xor_and(const U32& m, const U32& v, unsigned k) { return m ^ (v & U32(k)); }
+JIT_DEV void f_pk_add(F32& x0, F32& x1, const F32& c0, const F32& c1) { x0 = x0 + c0; x1 = x1 + c1; }
+JIT_DEV void f_pk_sub(F32& e0, F32& e1, const F32& x0, const F32& x1, const F32& c0, const F32& c1) { e0 = x0 - c0; e1 = x1 - c1; }
+JIT_DEV void jit_barrier() { pthread_barrier_wait(jit_emu_ctx.bar); }
+template <int P>
+JIT_DEV void jit_setprio() {}

@@ -1,0 +1,97 @@
+"""The specialised 5G LDPC decoder (csrc/ldpc5g_jit.cpp) held to the oracle WITHOUT a GPU.
+
+libsionna_amd.so generates, for one code, straight-line per-wave programs (block offsets, shifts, rate-matching offsets as
+constants) and compiles them with hipRTC for gfx950.  The generator is host code: here it runs on a handle built under
+SAMD_HOST_ONLY, the generated text (node updates csrc/jit/ldpc5g_jit_templates.h + per-wave programs) is compiled with g++
+against 64-wide CPU stand-ins of the per-lane operations (tests/jit_emu) and executed with 16 threads per workgroup - the
+schedule, every address and offset and the node arithmetic are what the GPU will run; only the operation definitions
+differ.  Soft outputs must be array_equal to oracle/ldpc_bp.c.  (`-m gpu` twin: tests/test_gpu_jit.py.)
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.ldpc5g import LDPC5GCode          # noqa: E402
+from oracle import ldpc_bp as obp, cbind      # noqa: E402
+from tools import jit_dump                    # noqa: E402
+
+EMU = os.path.join(ROOT, "tests", "jit_emu")
+
+
+def _build_emu(tmp_path, h, infobits, tag):
+    src = jit_dump.jit_source(h, infobits, 0)
+    inc = tmp_path / f"emu_src_{tag}.h"
+    inc.write_text(src)
+    so = tmp_path / f"emu_{tag}.so"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                           "-pthread", f"-DJIT_EMU_SRC=\"{inc}\"", "-I", EMU, "-o", str(so),
+                           os.path.join(EMU, "jit_emu_main.cpp")])
+    lib = C.CDLL(str(so))
+    lib.jit_emu_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int]
+    return lib, src
+
+
+def _noisy_llr(code, batch, seed, sigma=0.8):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 2, (batch, code.k)).astype(np.float32)
+    c = code.encode(u)
+    y = (2 * c - 1) + sigma * rng.normal(size=c.shape)
+    return (2 * y / sigma ** 2).astype(np.float32)
+
+
+def _reference(code, llr, cn, it, infobits, m, hard, offset=0.5):
+    odec = obp.LDPC5GDecoder(code, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=it)
+    xr = cbind.bp_decode(odec, odec.rate_recover(llr), num_iter=it, hard_out=0, offset=offset)
+    if infobits:
+        ref = xr[:, :code.k]
+    else:                                                        # decoding.py:1506-1531
+        x_nf = np.concatenate([xr[:, :code.k], xr[:, code.k_ldpc:]], axis=1)
+        ref = x_nf[:, 2 * code.z:2 * code.z + code.n]
+        if m is not None:
+            ref = ref[:, code.out_int]
+    return (ref >= 0).astype(np.float32) if hard else ref        # hard: 0 >= x_hat (internal sign) = returned logit >= 0
+
+
+# BASELINE config C2; the same code without interleaver; rate 1/2 at Z = 128 (pruned graph); Z = 256 at rate 2/3
+CODES = [(2816, 8448, "bg1", 6), (2816, 8448, "bg1", None), (2816, 5632, "bg1", 2), (5632, 8448, "bg1", None)]
+
+
+@pytest.mark.parametrize("k,n,bg,m", CODES)
+def test_generated_programs_match_oracle(tmp_path, k, n, bg, m):
+    from sionna_amd import _ffi
+    code = LDPC5GCode(k, n, m, bg)
+    h = jit_dump.host_only_handle(k, n, m, bg)
+    assert _ffi.lib().samd_ldpc5g_jit_supported(h) == 1
+    batch, grid = 5, 2                                           # workgroup 0 decodes 3 codewords in sequence, workgroup 1 two
+    llr = _noisy_llr(code, batch, k + n)
+    llr[0, :7] = 0
+    llr[1] = np.round(llr[1])                                    # exact ties
+    llr[2, ::5] *= 40                                            # clipping
+    for infobits in (1, 0):
+        lib, src = _build_emu(tmp_path, h, infobits, f"{k}_{n}_{m}_{infobits}")
+        assert "jit_wave_15" in src
+        for cn, it, hard in (("minsum", 1, 0), ("minsum", 6, 0), ("offset-minsum", 4, 0), ("minsum", 3, 1)):
+            out = np.full((batch, k if infobits else n), np.nan, np.float32)
+            x = np.ascontiguousarray(llr)
+            lib.jit_emu_decode(x.ctypes.data, out.ctypes.data, batch, it, 20.0, 0.5 if cn == "offset-minsum" else 0.0,
+                               hard, grid)
+            ref = _reference(code, llr, cn, it, bool(infobits), m, hard)
+            assert np.array_equal(out, ref), f"{cn} it={it} infobits={infobits} hard={hard}: " \
+                                             f"{np.mean(out != ref):.3e} differ, nan {np.isnan(out).sum()}"
+    _ffi.lib().samd_ldpc5g_destroy(h)
+
+
+def test_jit_class_boundaries():
+    """codes outside the class keep the generic kernel: odd lifting sizes, k / n / interleaver rows not multiples of 64"""
+    from sionna_amd import _ffi
+    for k, n, bg, m in ((1024, 2048, "bg1", None), (2816, 8436, "bg1", 6), (2800, 8448, "bg1", None), (768, 1536, None, 2)):
+        h = jit_dump.host_only_handle(k, n, m, bg)
+        assert _ffi.lib().samd_ldpc5g_jit_supported(h) == 0, (k, n, bg, m)
+        _ffi.lib().samd_ldpc5g_destroy(h)
