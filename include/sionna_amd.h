@@ -197,12 +197,14 @@ int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
  *   ..._source:    the generated translation unit (with_ops = 0: without the gfx950 operation definitions and the kernel
  *                  entry - what tests/jit_emu runs on the CPU); returns its length, copies at most cap - 1 bytes.
  *   ..._code:      the compiled code object (for llvm-objdump); returns its size, copies when cap suffices.
+ *   ..._launches:  how many decode calls of this handle ran on a specialised kernel so far.
  * ..._source works on a handle created under the development option SAMD_HOST_ONLY=1 (no device needed; such a handle
  * builds tables and schedules only and refuses every launch). */
 int samd_ldpc5g_jit_supported(const samd_ldpc5g_t* h);
 int samd_ldpc5g_jit_prepare(const samd_ldpc5g_t* h, int return_infobits);
 long samd_ldpc5g_jit_source(const samd_ldpc5g_t* h, int return_infobits, int with_ops, char* buf, size_t cap);
 long samd_ldpc5g_jit_code(const samd_ldpc5g_t* h, int return_infobits, char* buf, size_t cap);
+long samd_ldpc5g_jit_launches(const samd_ldpc5g_t* h);
 
 /* ------------------------------------------------------------------------------------
  * Mapping.  points: DEVICE complex64[2^m] (interleaved re,im), label of point i = binary

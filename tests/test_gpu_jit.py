@@ -1,0 +1,117 @@
+"""The specialised 5G LDPC decoder (csrc/ldpc5g_jit.cpp: per-wave straight-line programs generated for one code, compiled
+with hipRTC for gfx950) on the GPU: soft outputs array_equal to oracle/ldpc_bp.c and to the generic kernel, and the
+specialised kernel is the one that ran (samd_ldpc5g_jit_launches).  CPU twin of the generated source:
+tests/test_jit_emu.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.ldpc5g import LDPC5GCode
+from oracle import ldpc_bp as obp, cbind
+
+
+@pytest.fixture(scope="module")
+def phy():
+    import sionna_amd.phy as p
+    from sionna_amd import _ffi
+    _ffi.device()
+    return p
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _opt(key, value="1"):
+    from sionna_amd import _ffi
+    return _ffi.option(key, value)
+
+
+def _launches(enc, dec):
+    from sionna_amd import _ffi
+    return int(_ffi.lib().samd_ldpc5g_jit_launches(enc._handle(dec._nb_pruned_nodes)))
+
+
+def _noisy_llr(code, batch, seed, sigma=0.8):
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, 2, (batch, code.k)).astype(np.float32)
+    c = code.encode(u)
+    y = (2 * c - 1) + sigma * rng.normal(size=c.shape)
+    return (2 * y / sigma ** 2).astype(np.float32)
+
+
+def _reference(code, llr, cn, it, infobits, m):
+    odec = obp.LDPC5GDecoder(code, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=it)
+    xr = cbind.bp_decode(odec, odec.rate_recover(llr), num_iter=it, hard_out=0)
+    if infobits:
+        return xr[:, :code.k]
+    x_nf = np.concatenate([xr[:, :code.k], xr[:, code.k_ldpc:]], axis=1)          # decoding.py:1506-1531
+    ref = x_nf[:, 2 * code.z:2 * code.z + code.n]
+    return ref[:, code.out_int] if m is not None else ref
+
+
+CODES = [(2816, 8448, "bg1", 6), (2816, 8448, "bg1", None), (2816, 5632, "bg1", 2), (5632, 8448, "bg1", None)]
+
+
+@pytest.mark.parametrize("k,n,bg,m", CODES)
+@pytest.mark.parametrize("grid", [None, "2"])
+def test_specialised_kernel_bit_exact_vs_oracle(phy, k, n, bg, m, grid):
+    """small batches through the specialised kernel (SAMD_LDPC_JIT=2: any batch size); grid = 2 workgroups: each decodes
+    several codewords in sequence (the codeword loop with its prefetch of the next codeword's channel values)"""
+    code = LDPC5GCode(k, n, m, bg)
+    llr = _noisy_llr(code, 7, k + n)
+    llr[0, :7] = 0
+    llr[1] = np.round(llr[1])
+    llr[2, ::5] *= 40
+    import contextlib
+    with _opt("SAMD_LDPC_JIT", "2"), (_opt("SAMD_ONCHIP_GRID", grid) if grid else contextlib.nullcontext()):
+        enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+        for cn, it, infobits in (("minsum", 1, True), ("minsum", 6, False), ("offset-minsum", 5, True), ("minsum", 20, True)):
+            dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=it)
+            before = _launches(enc, dec)
+            got = _np(dec(llr))
+            assert _launches(enc, dec) == before + 1, "the specialised kernel did not run"
+            ref = _reference(code, llr, cn, it, infobits, m)
+            assert np.array_equal(got, ref), f"{cn} it={it} infobits={infobits}: {np.mean(got != ref):.3e} differ"
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=8)            # hard decisions
+        ref = _reference(code, llr, "minsum", 8, True, m)
+        assert np.array_equal(_np(dec(llr)), (0 >= -ref).astype(np.float32))
+
+
+def test_c2_at_scale_specialised_equals_generic_and_oracle(phy):
+    """BASELINE config C2 in the waterfall, 4096 codewords, 20 iterations: the default policy picks the specialised kernel
+    (batch >= 1024); its soft outputs equal the generic kernel's (SAMD_LDPC_JIT=0) and the oracle's on a sample"""
+    k, n, m, B = 2816, 8448, 6, 4096
+    phy.config.seed = 4243
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
+    no = phy.utils.ebnodb2no(4.0, m, k / n)
+    u = phy.mapping.BinarySource()([B, k])
+    llr = phy.mapping.Demapper("app", "qam", m)(phy.channel.AWGN()(phy.mapping.Mapper("qam", m)(enc(u)), no), no)
+    for cn in ("minsum", "offset-minsum"):
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=20, hard_out=False)
+        before = _launches(enc, dec)
+        got = _np(dec(llr))
+        assert _launches(enc, dec) == before + 1, "the specialised kernel did not run"
+        with _opt("SAMD_LDPC_JIT", "0"):
+            enc0 = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
+            dec0 = phy.fec.ldpc.LDPC5GDecoder(enc0, cn_update=cn, num_iter=20, hard_out=False)
+            gen = _np(dec0(llr))
+            assert _launches(enc0, dec0) == 0
+        assert np.array_equal(got, gen), f"{cn}: {np.mean(got != gen):.3e} of the soft outputs differ from the generic kernel"
+        code = LDPC5GCode(k, n, m, "bg1")
+        odec = obp.LDPC5GDecoder(code, cn_update=cn, num_iter=20, hard_out=False)
+        ref = cbind.bp_decode(odec, odec.rate_recover(_np(llr[:256])))[:, :k]
+        assert np.array_equal(got[:256], ref)
+    frac_err = np.mean(np.any((got > 0) != (_np(u) > 0), axis=1))
+    assert 0.0 < frac_err < 1.0
+
+
+def test_small_batches_keep_the_generic_kernel(phy):
+    """default policy: below SAMD_LDPC_JIT_MIN_BATCH codewords nothing is compiled"""
+    k, n, m = 2816, 8448, 6
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=3)
+    dec(torch.zeros((8, n), device="cuda"))
+    assert _launches(enc, dec) == 0
