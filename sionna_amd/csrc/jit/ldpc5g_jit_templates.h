@@ -13,6 +13,12 @@
 // (with [chunk][edge] the optimiser forms overlapping vector accesses and leaves the arrays in scratch memory).
 
 #define JIT_NOOUT 0xFFFFFFFFu
+// JIT_ABL (development builds of the library only - results are WRONG by construction; tools/gpu_jit_ablation.sh): bit 0 =
+// no check-node arithmetic (messages stored back as loaded), bit 1 = no variable-node arithmetic, bit 2 = no workgroup
+// barriers in the iteration loop.  What remains is timed unchanged: where an iteration's time goes.
+#ifndef JIT_ABL
+#define JIT_ABL 0
+#endif
 
 // value written to the output tensor for a VN total x (decoding.py:620-626): clip, then hard decision or the logit
 JIT_DEV F32 jit_outval(F32 x, float llr_max, int hard_out) {
@@ -32,7 +38,9 @@ JIT_DEV U32 jit_vn_addr(U32 l4, unsigned k, unsigned base) {
 // l4 + k as a value the compiler treats as computed HERE: the slots of a row are then this one register plus the offset
 // fields of the DS instructions.  (Written as plain l4 + k, every distinct slot address of every item is loop invariant
 // and is hoisted into a register of its own - hundreds of them, spilled to scratch.)
-JIT_DEV U32 jit_base(U32 l4, unsigned k) { return u_here(l4) + k; }
+// (... and the sum is opaque as well: left visible, k is folded into every slot offset, offsets beyond the 16 bits of the DS
+// offset field become one address addition per slot, and the two-slot forms ds_read2st64 / ds_write2st64 are lost.)
+JIT_DEV U32 jit_base(U32 l4, unsigned k) { return u_here(u_here(l4) + k); }
 
 // ---------------------------------------------------------------------------------------------- check node row
 // a0 = byte address of the lane's slot in the row's first block (chunk 0 of the item); NCH chunks of 64 lifted copies
@@ -49,6 +57,13 @@ JIT_DEV void jit_cn_load(F32 (&v)[D][NCH], U32 a0) {
 template <int D, int NCH, bool FUSE>
 JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, float offset, bool last,
                            float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
+  if (JIT_ABL & 1) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) lds_st(a0, (unsigned)i * JIT_Z4 + 256u * h, v[i][h]);
+    return;
+  }
   F32 m1[NCH], m2[NCH];
   U32 sx[NCH];
 #pragma unroll
@@ -126,6 +141,13 @@ template <int D, int NCH>
 JIT_DEV void jit_vn_update(F32 (&c)[D][NCH], const U32 (&a)[D][NCH], const F32 (&l)[NCH], float llr_max, bool last,
                            float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
   F32 x[NCH];
+  if (JIT_ABL & 2) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) lds_st(a[i][h], 0u, c[i][h]);
+    return;
+  }
   if (NCH == 2) {
     // both chunks of an edge in one packed-fp32 operation: two IEEE additions, the results of two scalar ones
     F32 x0 = 0.f, x1 = 0.f;

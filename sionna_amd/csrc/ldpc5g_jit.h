@@ -37,6 +37,10 @@ struct JitKnobs {
   int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
   int prio = 1;        // s_setprio per item
   int vnrev = 1;       // VN lists assigned to the waves in reverse order
+  int sched = 1;       // 1: items distributed by the specialised kernel's own costs; 0: the generic kernel's lists
+  int rotate = 1;      // a wave's item order rotated by its index on its SIMD
+  int cn_slope = 10, cn_ovh = 29, cn_fused = 6, vn_slope = 8, vn_ovh = 10, vn_pair_max = 12;   // cost model (instructions)
+  int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
 };
 

@@ -27,19 +27,30 @@ _PENDING = set()          # id() of every live deferred tensor (entries leave on
 # property getters / methods that only look at a tensor's metadata and therefore do not fill a deferred tensor
 _META_GET = {"shape", "dtype", "device", "is_cuda", "ndim", "requires_grad", "layout", "names", "is_sparse", "is_quantized",
              "is_meta", "grad_fn", "is_leaf", "itemsize", "nbytes", "is_cpu", "is_nested", "grad", "output_nr", "_version"}
+# ("type" only without arguments - t.type(dtype) converts the VALUES; not __repr__ / untyped_storage / is_set_to: they show or
+# hand out the storage.  data_ptr stays: the address identifies the tensor, _ffi.ptr fills before it passes one on.)
 _META_FN = {"dim", "size", "numel", "is_contiguous", "stride", "element_size", "ndimension", "is_floating_point", "is_complex",
-            "nelement", "get_device", "storage_offset", "is_pinned", "type", "__len__", "__hash__", "__repr__", "is_shared",
+            "nelement", "get_device", "storage_offset", "is_pinned", "__len__", "__hash__", "is_shared",
             "has_names", "is_same_size", "is_signed", "is_inference", "is_conj", "is_neg", "requires_grad_", "__class__",
-            "untyped_storage", "_is_view", "is_set_to", "data_ptr"}
+            "_is_view", "data_ptr"}
 
 
 class Pending:
     """How to fill a deferred tensor: ``fill(plain_tensor)`` launches the kernel(s) that write its storage; ``kind`` and
     the keyword attributes let a fusing consumer recognise the recipe."""
 
-    def __init__(self, kind, fill, **info):
+    def __init__(self, kind, fill, guard=(), **info):
         self.kind, self.fill = kind, fill
+        # inputs the recipe will read LATER: (tensor, its version counter now).  An in-place modification between the
+        # block's call and the first use of its deferred output would silently change that output - check_guard raises.
+        self.guard = [(g, g._version) for g in guard if isinstance(g, torch.Tensor)]
         self.__dict__.update(info)
+
+    def check_guard(self):
+        for g, ver in self.guard:
+            if g._version != ver:
+                raise RuntimeError("an input of a deferred block output was modified in place before that output was used "
+                                   "(e.g. a reused receive buffer): use the output first, or build the block with defer=False")
 
 
 def pending_of(t):
@@ -51,6 +62,7 @@ def materialize(t):
     """Fill a deferred tensor now (no-op for everything else); returns ``t``."""
     p = pending_of(t)
     if p is not None:
+        p.check_guard()
         del t.__dict__["_samd_pending"]
         _PENDING.discard(id(t))
         p.fill(torch.Tensor._make_subclass(torch.Tensor, t) if type(t) is not torch.Tensor else t)
@@ -87,7 +99,8 @@ class Tensor(torch.Tensor):
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         if _PENDING:                                   # some tensor somewhere is deferred: is one of the operands?
             name = getattr(func, "__name__", "")
-            meta = name in _META_FN or (name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", "") in _META_GET)
+            meta = name in _META_FN or (name == "__get__" and getattr(getattr(func, "__self__", None), "__name__", "") in _META_GET) \
+                or (name == "type" and len(args) <= 1 and not kwargs)
             if not meta:
                 _fill_all(args)
                 if kwargs:

@@ -234,8 +234,8 @@ class LSChannelEstimator(Block):
             else:
                 shape = tuple(torch.broadcast_shapes(tuple(no.shape), self._out_shape))
                 err_var = defer(torch.empty(shape, dtype=torch.float32, device=y.device),
-                                Pending("ls_err_var", lambda out: torch.clamp_min(no * ev.reshape(self._out_shape), 0., out=out)))
-            rec = Pending("ls_nn", fill_h, y=y, src=src, coef=inv, ev=ev, no=no3.reshape(-1) if no3.numel() == 1 else
+                                Pending("ls_err_var", lambda out: torch.clamp_min(no * ev.reshape(self._out_shape), 0., out=out), guard=(no,)))
+            rec = Pending("ls_nn", fill_h, guard=(y, no3), y=y, src=src, coef=inv, ev=ev, no=no3.reshape(-1) if no3.numel() == 1 else
                           torch.broadcast_to(no3, tuple(y.shape[:3])).contiguous().reshape(-1), rg=rg, err_var=err_var)
             return defer(h_hat, rec), err_var
         fill_h(h_hat)

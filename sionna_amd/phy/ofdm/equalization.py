@@ -150,6 +150,7 @@ class OFDMEqualizer(Block):
         if (pend is None or pend.kind != "ls_nn" or pend.rg is not self._rg or self._mode != MODE_LMMSE
                 or self.precision != "single" or not _same_tensor(err_var, pend.err_var)):
             return None
+        pend.check_guard()                                    # the recipe's inputs (y, no) unchanged since the estimator ran
         rg, sm = self._rg, self._sm
         sc_ind, desired, undesired, data_pos, n_und = self._tables()
         if n_und:

@@ -1,0 +1,37 @@
+
+
+# ------------------------------------------------------------------ deferred block outputs (phy/block.py; round-4 advisor findings)
+def test_deferred_tensor_fills_for_repr_and_type_conversion():
+    """repr() / print() and t.type(dtype) look at VALUES: a deferred tensor must be filled first; metadata access and
+    t.type() without arguments must not fill it"""
+    import torch
+    from sionna_amd.phy.block import Pending, defer, pending_of
+
+    def make():
+        calls = []
+        t = defer(torch.full((4,), -7.0), Pending("test", lambda out: (calls.append(1), out.fill_(3.0))))
+        return t, calls
+    t, calls = make()
+    assert t.shape == (4,) and t.dtype == torch.float32 and t.dim() == 1 and t.type() == "torch.FloatTensor"
+    assert not calls and pending_of(t) is not None
+    assert "3." in repr(t) and calls == [1] and pending_of(t) is None
+    t, calls = make()
+    assert torch.equal(t.type(torch.float64).as_subclass(torch.Tensor), torch.full((4,), 3.0, dtype=torch.float64)) and calls == [1]
+    t, calls = make()
+    assert float(t.untyped_storage().nbytes()) == 16 and calls == [1]
+
+
+def test_deferred_tensor_refuses_inputs_modified_in_place():
+    """the recipe reads its inputs when the output is first used: an in-place modification in between raises instead of
+    silently changing the output"""
+    import pytest
+    import torch
+    from sionna_amd.phy.block import Pending, defer, materialize
+    y = torch.ones(4)
+    t = defer(torch.empty(4), Pending("test", lambda out: out.copy_(2 * y), guard=(y,)))
+    y.add_(1.0)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        materialize(t)
+    y2 = torch.ones(4)
+    t2 = defer(torch.empty(4), Pending("test", lambda out: out.copy_(2 * y2), guard=(y2,)))
+    assert torch.equal(materialize(t2).as_subclass(torch.Tensor), torch.full((4,), 2.0))
