@@ -44,6 +44,7 @@ N_VN, N_CN, N_EDGES = 8704, 5888, 40448
 HBM_PEAK_GBPS = 8000.0
 NUM_SIMD, CLOCK_GHZ, NUM_CU = 1024, 2.4, 256
 VALU_PEAK_GINST = NUM_SIMD * CLOCK_GHZ / 2.0          # wave64 VALU instructions per ns -> G inst/s (2 cycles each)
+LDS_PIPE_PEAK_GCYC = NUM_CU * CLOCK_GHZ               # LDS-pipeline cycles per ns: one LDS per CU
 COUNTERS = os.path.join(ROOT, "profiles", "counters.json")
 
 
@@ -53,10 +54,14 @@ def b_msg(num_iter, k_out):
 
 
 # ------------------------------------------------------------------ counters (tools/pmc_counters.py)
-def _sha16(path):
+def _sha16(paths):
+    """hash over a kernel's own source list (counters.json `sources`; older entries name one `source`)"""
+    hsh = hashlib.sha256()
     try:
-        with open(os.path.join(ROOT, path), "rb") as f:
-            return hashlib.sha256(f.read()).hexdigest()[:16]
+        for path in ([paths] if isinstance(paths, str) else paths):
+            with open(os.path.join(ROOT, path), "rb") as f:
+                hsh.update(f.read())
+        return hsh.hexdigest()[:16]
     except OSError:
         return None
 
@@ -79,7 +84,8 @@ def load_counters(kernel_key):
         return None
     if rec:
         rec = dict(rec)
-        rec["stale"] = bool(rec.get("source") and _sha16(rec["source"]) != rec.get("source_sha16"))
+        srcs = rec.get("sources") or rec.get("source")
+        rec["stale"] = bool(srcs and _sha16(srcs) != rec.get("source_sha16"))
         rec["collected_on"] = rec.get("collected_on") or allc.get("collected_on")     # (entries merged later carry their own)
         # static VALU mix x measured issue times (tools/valu_mix.py) and the ablation shares (tools/gpu_ablation.sh)
         rec["mix"] = _load_json("r03_valu_mix.json").get("kernels", {}).get(kernel_key)
@@ -118,6 +124,18 @@ def onchip_roofline(kernel_key, kernel_name, units, ms, extra=None):
             out["valu_mix"] = {"ns_per_inst_est": ns, "class_counts": rec["mix"]["class_counts"],
                                "note": "static mix of the kernel x issue times measured by tools/ubench/valu_rate.hip "
                                        "(profiles/r03b/valu_rate_r03b.txt); peak under this mix = 1024 SIMDs / ns_per_inst"}
+        if rec.get("lds_pipe_cycles_per_unit"):
+            # The kernel generated for the code (csrc/ldpc5g_jit.cpp) is bound by the CU's LDS PIPELINE - every message
+            # crosses LDS four times per iteration (read + write in each phase) and a DS instruction occupies the pipeline
+            # for the cycles MI355X_MICROARCH.md (section LDS) gives: 2 per 32-lane read pass, 2 per source dword of a store.
+            # achieved = those cycles per decode (static: the code object's DS instruction mix, profiles/counters.json) x
+            # decodes per launch / the launch time measured here; peak = one LDS cycle per CU and clock.
+            gcyc = rec["lds_pipe_cycles_per_unit"] * units / (ms * 1e-3) / 1e9
+            out.update({"bound": "lds", "unit": "G LDS-pipeline cycles/s", "achieved": round(gcyc, 1), "peak": round(LDS_PIPE_PEAK_GCYC, 1),
+                        "frac": round(gcyc / LDS_PIPE_PEAK_GCYC, 4), "valu_frac": round(ginst / VALU_PEAK_GINST, 4),
+                        "valu_achieved_ginst": round(ginst, 1),
+                        "lds_pipe": {"cycles_per_decode": rec["lds_pipe_cycles_per_unit"], "static": rec.get("static")},
+                        "icache": rec.get("icache")})
     else:
         out["note"] = "profiles/counters.json has no entry for this kernel: run tools/gpu_pmc.sh + tools/pmc_counters.py"
     if extra:
@@ -519,7 +537,7 @@ def cpu_baseline_c2(llr, k, n, m, cn_update, num_iter, dec, seconds, max_cw):
             "hard_decision_agreement_with_gpu": agree}
 
 
-def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms):
+def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms, specialised=False):
     bytes_alg = b_msg(num_iter, k) * B
     equiv = {"algorithmic_bytes_per_decode": b_msg(num_iter, k), "gbps": round(bytes_alg / (dec_ms * 1e-3) / 1e9, 1),
              "frac_of_hbm_peak": round(bytes_alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -531,6 +549,10 @@ def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms):
         name = ("ldpc5g_decode_msg_kernel (on-chip min-sum, one float per edge in LDS, channel LLRs in an L2 workspace row, "
                 "grouped dispatch)" if minsum else
                 "ldpc5g_decode_msg_kernel<..., boxplus> (the same engine with bp_math's boxplus node update)")
+        if specialised:
+            key = "ldpc5g_jit"
+            name = ("samd_ldpc5g_jit (generated for this code and compiled with hipRTC at the first decode: one straight-line "
+                    "program per wave, messages in LDS, channel LLRs and block positions in registers; csrc/ldpc5g_jit.cpp)")
         return onchip_roofline(key, name, B, dec_ms, {"hbm_resident_equiv": equiv, **io})
     ach = bytes_alg / (dec_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
@@ -643,9 +665,17 @@ def main():
         t_wall, c = timed_steps(step, steps, warmup, world, dev, torch.cuda.synchronize, counters)
         return t_wall, float(np.mean([a.elapsed_time(b) for a, b in ev])), c
 
+    def specialised_ran(d):
+        """did this decoder's launches go to the kernel generated for the code (csrc/ldpc5g_jit.cpp)?"""
+        try:
+            return int(_ffi.lib().samd_ldpc5g_jit_launches(enc._handle(d._nb_pruned_nodes))) > 0
+        except Exception:                                # pylint: disable=broad-except
+            return False
+
     dec = make_dec(args.cn_update)
     t_wall, dec_ms, c = run(dec, args.steps, args.warmup)
     onchip = bool(dec._onchip_ok)
+    jit_ran = onchip and args.cn_update in ("minsum", "offset-minsum") and specialised_ran(dec)
     value = B * world * args.steps / t_wall
     out = {
         "metric": "codeword-decodes/sec (n=8448, BP iters=20)", "value": round(value, 1),
@@ -654,12 +684,27 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "C2: 5G LDPC BG1 k=2816 n=8448 (rate 1/3, Z=128), 64-QAM AWGN LLRs, flooding BP "
                                f"{args.num_iter} iterations, batch {B} per GPU",
-                   "cn_update": args.cn_update, "engine": "on-chip" if onchip else "generic-hbm",
+                   "cn_update": args.cn_update,
+                   "engine": ("on-chip, kernel specialised for the code (hipRTC)" if jit_ran else "on-chip") if onchip else "generic-hbm",
                    "batch_per_gpu": B, "ebno_db": args.ebno_db, "parallelism": f"dp{world}"},
         "ber": float(c[0] / max(c[2], 1)), "bler": float(c[1] / max(c[3], 1)),
         "input_generation_s": round(t_gen, 3),
-        "roofline": c2_roofline(args.cn_update, onchip, B, k, args.num_iter, dec_ms),
+        "roofline": c2_roofline(args.cn_update, onchip, B, k, args.num_iter, dec_ms, jit_ran),
     }
+
+    if jit_ran:
+        # the same decode on the GENERIC on-chip kernel (the lists walked by scalar code, ldpc5g_decode_msg_kernel) in the same
+        # run: what the specialisation buys, and that both produce the same decisions
+        with _ffi.option("SAMD_LDPC_JIT", "0"):
+            enc_g = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=BG)
+            dec_g = phy.fec.ldpc.LDPC5GDecoder(enc_g, cn_update=args.cn_update, num_iter=args.num_iter, hard_out=True, return_infobits=True)
+            steps_g = max(2, args.steps // 3)
+            tg, ms_g, _ = run(dec_g, steps_g, 1)
+            same = bool(torch.equal(dec_g(llr).as_subclass(torch.Tensor), dec(llr).as_subclass(torch.Tensor)))
+        out["generic_kernel"] = {"value": round(B * world * steps_g / tg, 1), "unit": "codewords/s", "steps": steps_g,
+                                 "ms_per_launch": round(ms_g, 3), "same_decisions_as_specialised": same,
+                                 "speedup_of_specialised": round((B * world * args.steps / t_wall) / (B * world * steps_g / tg), 3),
+                                 "roofline": c2_roofline(args.cn_update, True, B, k, args.num_iter, ms_g, False)}
 
     # whole chain source -> encoder -> mapper -> AWGN -> demapper -> decoder -> counters (SURVEY 8d "e2e")
     def chain_step():

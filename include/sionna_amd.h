@@ -189,7 +189,8 @@ int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
  * config C2), samd_ldpc5g_decode_f32 with SAMD_CN_MINSUM / SAMD_CN_OFFSET_MINSUM runs a kernel GENERATED for that one code:
  * the per-wave work lists written out as straight-line source (block offsets, shifts and rate-matching offsets as
  * constants), compiled once per process and code with hipRTC (libhiprtc.so, bound with dlopen) for gfx950.  Same
- * reference path (decoding.py:1427-1536, 416-524, 681-953), same bits as the generic kernel.  Compilation happens at the
+ * reference path (decoding.py:1427-1536, 416-524, 681-953), same bits as the generic kernel.  One kernel per (code,
+ * return_infobits, rule): cn_mode below is SAMD_CN_MINSUM or SAMD_CN_OFFSET_MINSUM.  Compilation happens at the
  * first decode of at least 1024 codewords (development options SAMD_LDPC_JIT = 0 off / 1 default / 2 any batch,
  * SAMD_LDPC_JIT_MIN_BATCH); whenever it is not possible the generic kernel runs.
  *   ..._supported: 1 when the handle's code is in that class.
@@ -201,9 +202,9 @@ int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
  * ..._source works on a handle created under the development option SAMD_HOST_ONLY=1 (no device needed; such a handle
  * builds tables and schedules only and refuses every launch). */
 int samd_ldpc5g_jit_supported(const samd_ldpc5g_t* h);
-int samd_ldpc5g_jit_prepare(const samd_ldpc5g_t* h, int return_infobits);
-long samd_ldpc5g_jit_source(const samd_ldpc5g_t* h, int return_infobits, int with_ops, char* buf, size_t cap);
-long samd_ldpc5g_jit_code(const samd_ldpc5g_t* h, int return_infobits, char* buf, size_t cap);
+int samd_ldpc5g_jit_prepare(const samd_ldpc5g_t* h, int return_infobits, int cn_mode);
+long samd_ldpc5g_jit_source(const samd_ldpc5g_t* h, int return_infobits, int cn_mode, int with_ops, char* buf, size_t cap);
+long samd_ldpc5g_jit_code(const samd_ldpc5g_t* h, int return_infobits, int cn_mode, char* buf, size_t cap);
 long samd_ldpc5g_jit_launches(const samd_ldpc5g_t* h);
 
 /* ------------------------------------------------------------------------------------

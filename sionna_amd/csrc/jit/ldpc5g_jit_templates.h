@@ -19,6 +19,7 @@
 #ifndef JIT_ABL
 #define JIT_ABL 0
 #endif
+// JIT_OFFSET0 = 1: the kernel is generated for plain min-sum (offset 0 exactly); 0: offset-min-sum with a run-time offset
 
 // value written to the output tensor for a VN total x (decoding.py:620-626): clip, then hard decision or the logit
 JIT_DEV F32 jit_outval(F32 x, float llr_max, int hard_out) {
@@ -67,24 +68,35 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
   F32 m1[NCH], m2[NCH];
   U32 sx[NCH];
 #pragma unroll
-  for (int h = 0; h < NCH; ++h) { m1[h] = JIT_INF; m2[h] = JIT_INF; sx[h] = 0u; }
+  for (int h = 0; h < NCH; ++h) { m1[h] = f_abs(v[0][h]); m2[h] = JIT_INF; sx[h] = 0u; }
 #pragma unroll
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      const F32 av = f_abs(v[i][h]);
-      m2[h] = f_med3(m1[h], m2[h], av);              // second smallest, with multiplicity
-      m1[h] = f_med3(m1[h], av, 0.f);                // = min(m1, |v|) for non-negative values
+      // the two smallest magnitudes, the second with multiplicity.  Edge 0: m1 = |v|, m2 = inf (no operation); edge 1:
+      // m2 = max, m1 = min; then m2 = med3(m1, m2, |v|), m1 = min(m1, |v|) - min / max of non-negative values as ONE
+      // v_med3 against 0 / inf (fminf / fmaxf would add a canonicalising v_max)
+      if (i >= 1) {
+        const F32 av = f_abs(v[i][h]);
+        m2[h] = (i == 1) ? f_med3(m1[h], av, JIT_INF) : f_med3(m1[h], m2[h], av);
+        m1[h] = f_med3(m1[h], av, 0.f);
+      }
       if (i & 1) sx[h] = u_xor3(sx[h], f_bits(v[i - 1][h]), f_bits(v[i][h]));
       else if (i == D - 1) sx[h] = sx[h] ^ f_bits(v[i][h]);
     }
   F32 a1[NCH], a2[NCH];
 #pragma unroll
   for (int h = 0; h < NCH; ++h) {
-    // unique minimum <=> m2 > m1; (m2 - m1) + m1 is the reference's arithmetic (decoding.py:863)
-    const F32 min_e = f_sel_gt(m2[h], m1[h], (m2[h] - m1[h]) + m1[h], m1[h]);
-    a1[h] = f_med3(m1[h] - offset, 0.f, llr_max);
-    a2[h] = f_med3(min_e - offset, 0.f, llr_max);
+    // decoding.py:863: min2 = (m2 - m1) + m1 for a unique minimum; a duplicated minimum has m2 == m1 and the same
+    // expression returns m1 (0 + m1), so no selection is needed
+    const F32 min_e = (m2[h] - m1[h]) + m1[h];
+    if (JIT_OFFSET0) {                               // plain min-sum: clip(m - 0, 0, llr_max) = min(m, llr_max), m >= 0
+      a1[h] = f_med3(m1[h], llr_max, 0.f);
+      a2[h] = f_med3(min_e, llr_max, 0.f);
+    } else {
+      a1[h] = f_med3(m1[h] - offset, 0.f, llr_max);
+      a2[h] = f_med3(min_e - offset, 0.f, llr_max);
+    }
     sx[h] = sx[h] & 0x80000000u;                     // row sign into both candidates (their sign bits are 0)
     a1[h] = u_float(f_bits(a1[h]) | sx[h]);
     a2[h] = u_float(f_bits(a2[h]) | sx[h]);

@@ -37,7 +37,10 @@ struct JitKnobs {
   int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
   int prio = 1;        // s_setprio per item
   int vnrev = 1;       // VN lists assigned to the waves in reverse order
-  int sched = 1;       // 1: items distributed by the specialised kernel's own costs; 0: the generic kernel's lists
+  int sched = 0;       // 0: the generic kernel's lists (tuned on hardware over rounds 2-3: cut items, SIMD-aware order);
+                       // 1: an own longest-processing-time assignment by instruction counts - measured 4-7 % slower
+                       // for every cost model tried (profiles/r05c_jit_sched_sweep.txt): an item's cost is its latency
+                       // chain, not its instruction count
   int rotate = 1;      // a wave's item order rotated by its index on its SIMD
   int cn_slope = 10, cn_ovh = 29, cn_fused = 6, vn_slope = 8, vn_ovh = 10, vn_pair_max = 12;   // cost model (instructions)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
@@ -48,7 +51,7 @@ struct JitKnobs {
 bool jit_eligible(const samd_ldpc5g* h);
 // the whole translation unit handed to hipRTC.  with_ops = false: without the gfx950 operation definitions and the
 // __global__ entry (what tests/jit_emu compiles for the CPU)
-std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, bool with_ops, const JitKnobs& knobs);
+std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, int offset0, bool with_ops, const JitKnobs& knobs);
 // SAMD_OK, SAMD_ERR_UNSUPPORTED (caller runs the generic kernel) or an error
 int launch_onchip_jit(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                       float llr_max, float offset, int hard_out, int return_infobits, void* stream);

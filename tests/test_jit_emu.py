@@ -25,8 +25,8 @@ from tools import jit_dump                    # noqa: E402
 EMU = os.path.join(ROOT, "tests", "jit_emu")
 
 
-def _build_emu(tmp_path, h, infobits, tag):
-    src = jit_dump.jit_source(h, infobits, 0)
+def _build_emu(tmp_path, h, infobits, tag, cn="minsum"):
+    src = jit_dump.jit_source(h, infobits, 0, cn)
     inc = tmp_path / f"emu_src_{tag}.h"
     inc.write_text(src)
     so = tmp_path / f"emu_{tag}.so"
@@ -75,9 +75,11 @@ def test_generated_programs_match_oracle(tmp_path, k, n, bg, m):
     llr[1] = np.round(llr[1])                                    # exact ties
     llr[2, ::5] *= 40                                            # clipping
     for infobits in (1, 0):
-        lib, src = _build_emu(tmp_path, h, infobits, f"{k}_{n}_{m}_{infobits}")
+      for rule, cases in (("minsum", (("minsum", 1, 0), ("minsum", 6, 0), ("minsum", 3, 1))),
+                          ("offset-minsum", (("offset-minsum", 4, 0), ("minsum", 2, 0)))):     # one kernel per rule (offset 0 = min-sum)
+        lib, src = _build_emu(tmp_path, h, infobits, f"{k}_{n}_{m}_{infobits}_{rule}", rule)
         assert "jit_wave_15" in src
-        for cn, it, hard in (("minsum", 1, 0), ("minsum", 6, 0), ("offset-minsum", 4, 0), ("minsum", 3, 1)):
+        for cn, it, hard in cases:
             out = np.full((batch, k if infobits else n), np.nan, np.float32)
             x = np.ascontiguousarray(llr)
             lib.jit_emu_decode(x.ctypes.data, out.ctypes.data, batch, it, 20.0, 0.5 if cn == "offset-minsum" else 0.0,

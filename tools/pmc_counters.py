@@ -17,10 +17,14 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {   # key -> (substring of the kernel name, unit, source file)
+KERNELS = {   # key -> (substring of the kernel name, unit, source file(s): the kernel's own translation unit list)
     # the explicit-message engine, by its last template argument: the check-node rule (2 min-sum, 1 boxplus-phi)
     # (round 3: the grouped-dispatch kernel <ZM = 2 (Z = 128), LLRG, rule, VAR>; rule 2 min-sum, 1 boxplus-phi on the
     # defined exp / log, 4 boxplus-phi on the hardware transcendentals)
+    # the kernel GENERATED for the code (csrc/ldpc5g_jit.cpp, compiled by hipRTC at run time): generator, node updates,
+    # operation definitions; the schedule it writes out comes from the table builder in ldpc5g_onchip_bp.hip
+    "ldpc5g_jit": ("samd_ldpc5g_jit", "decode", ["sionna_amd/csrc/ldpc5g_jit.cpp", "sionna_amd/csrc/jit/ldpc5g_jit_templates.h",
+                                                 "sionna_amd/csrc/jit/ldpc5g_jit_ops_gfx950.h", "sionna_amd/csrc/ldpc5g_onchip_bp.hip"]),
     "ldpc5g_ms": ("ldpc5g_decode_msg_kernel<2, true, 2, 1>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
     "ldpc5g_bp": ("ldpc5g_decode_msg_kernel<2, true, 1, 0>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
     "ldpc5g_bp_fast": ("ldpc5g_decode_msg_kernel<2, true, 4, 0>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
@@ -29,6 +33,39 @@ KERNELS = {   # key -> (substring of the kernel name, unit, source file)
     "polar_bp": ("polar_bp_kernel", "decode", "sionna_amd/csrc/polar_bp.hip"),
     "ofdm_lmmse": ("ofdm_lmmse_diag_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
 }
+
+
+def sources_sha16(srcs):
+    """one hash over the kernel's own sources (bench.py: counters are stale when any of THESE changed, not when a shared
+    file of another kernel did)"""
+    hsh = hashlib.sha256()
+    for s in srcs:
+        with open(os.path.join(ROOT, s), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()[:16]
+
+
+def jit_static(k=2816, n=8448, m=6, bg="bg1", num_iter=20):
+    """LDS-pipeline cycles and instruction counts per decode of the GENERATED kernel from its disassembly (no GPU needed:
+    tools/jit_dump.py builds the handle host-only and compiles with hipRTC) priced with the cycles per wave instruction of
+    MI355X_MICROARCH.md (section LDS)"""
+    sys.path.insert(0, ROOT)
+    import subprocess
+    import tempfile
+    from tools import jit_dump
+    h = jit_dump.host_only_handle(k, n, m, bg)
+    code = jit_dump.jit_code(h, 1, "minsum")
+    with tempfile.TemporaryDirectory() as td:
+        co = os.path.join(td, "code.co")
+        open(co, "wb").write(code)
+        asm = subprocess.check_output(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", co]).decode()
+    it = jit_dump.per_iteration_stats(asm)
+    per_it = {kk: it["cn_phase"][kk] + it["vn_phase"][kk] for kk in ("valu", "salu", "lds_insts", "lds_pipe_cycles")}
+    return {"per_iteration": per_it, "per_codeword": {kk: it["per_codeword"][kk] for kk in ("valu", "salu", "lds_insts", "lds_pipe_cycles")},
+            "lds_mix_cn": it["cn_phase"]["lds_mix"], "lds_mix_vn": it["vn_phase"]["lds_mix"], "num_iter": num_iter,
+            "lds_pipe_cycles_per_unit": num_iter * per_it["lds_pipe_cycles"] + it["per_codeword"]["lds_pipe_cycles"],
+            "note": "static: disassembly of the hipRTC code object x cycles per DS wave instruction (MI355X_MICROARCH.md, LDS table: "
+                    "reads 2 per 32-lane group pass, stores 2 per source dword incl. the address register)"}
 
 
 def per_kernel_means(root):
@@ -70,10 +107,10 @@ def main():
             for c, v in means[k].items():
                 m[c] = max(m[c], v)
         n = units[key]
-        with open(os.path.join(ROOT, src), "rb") as f:
-            sha = hashlib.sha256(f.read()).hexdigest()[:16]
+        srcs = src if isinstance(src, list) else [src]
+        sha = sources_sha16(srcs)
         rec = {"kernel": match[0].split("(")[0], "unit": unit, "units_per_launch": n, "from": f"profiles/{tag}_pmc/summary.txt",
-               "source": src, "source_sha16": sha,
+               "sources": srcs, "source_sha16": sha, "collected_on": collected,
                "valu_insts_per_unit": round(m["SQ_INSTS_VALU"] / n, 2), "salu_insts_per_unit": round(m["SQ_INSTS_SALU"] / n, 2),
                "lds_insts_per_unit": round(m["SQ_INSTS_LDS"] / n, 2), "lds_array_cycles_per_unit": round(m["SQ_LDS_IDX_ACTIVE"] / n, 2),
                "lds_bank_conflict_cycles_per_unit": round(m["SQ_LDS_BANK_CONFLICT"] / n, 3),
@@ -84,6 +121,15 @@ def main():
                "active_frac": round(m["SQ_ACTIVE_INST_ANY"] / max(m["SQ_WAVE_CYCLES"], 1), 4),
                "hbm_bytes_per_unit": round((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024 / n, 2),
                "fetch_size_kb_per_launch": m["FETCH_SIZE"], "write_size_kb_per_launch": m["WRITE_SIZE"]}
+        if key == "ldpc5g_jit":
+            try:
+                rec["static"] = jit_static()
+                rec["lds_pipe_cycles_per_unit"] = rec["static"]["lds_pipe_cycles_per_unit"]
+            except Exception as e:                             # pylint: disable=broad-except
+                print(f"static analysis of the generated kernel failed: {e}", file=sys.stderr)
+        for ck in ("SQC_ICACHE_REQ", "SQC_ICACHE_HITS", "SQC_ICACHE_MISSES", "SQC_ICACHE_MISSES_DUPLICATE"):
+            if ck in m:
+                rec.setdefault("icache", {})[ck.lower()] = m[ck]
         out["kernels"][key] = rec
     json.dump(out, sys.stdout, indent=1)
     print()
