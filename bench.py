@@ -180,6 +180,22 @@ def reduce_max(value, world, device):
     return float(t.item())
 
 
+def ranks_seen(world, rank, device):
+    """How many ranks took part in a collective of this run, and whether their Philox streams differ pairwise (the first
+    draw of every rank's generator, gathered): what the bench line reports as `rccl_ranks_seen` for N > 1."""
+    if not _grouped(world):
+        return 1, True
+    import torch.distributed as dist
+    from sionna_amd.phy.config import PhiloxGenerator
+    gen = PhiloxGenerator(20250923, rank=rank)
+    mine = torch.tensor([rank, gen.seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=device)
+    gathered = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(gathered, mine)
+    ranks = {int(g[0]) for g in gathered}
+    seeds = {int(g[1]) for g in gathered}
+    return len(ranks), len(seeds) == len(gathered)
+
+
 def self_launch_argv(n_gpus, argv=None, port=None):
     """Command line that runs this file as N ranks of ONE node (one process per GPU, RCCL over xGMI) - exactly the
     launch the driver uses for N > 1; `python bench.py --gpus N` from a plain shell re-executes itself as this."""
@@ -576,12 +592,14 @@ def dry_dist(args, world, rank):
     counters = torch.zeros(4, dtype=torch.int64)
     step = counted_step(lambda: (u + flips) % 2, u, counters, count_into, world)
     t_wall, c = timed_steps(step, args.steps, args.warmup, world, torch.device("cpu"), lambda: None, counters)
+    seen, distinct = ranks_seen(world, rank, torch.device("cpu"))
     if rank == 0:
         print(json.dumps({"metric": "dry-dist (control path only, no kernels)", "value": round(B * world * args.steps / t_wall, 1),
                           "unit": "codewords/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(t_wall / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                           "data": "synthetic", "config": {"workload": "dry-dist", "parallelism": f"dp{world}", "batch_per_gpu": B},
-                          "counters": [int(x) for x in c], "local_bits_per_rank": B * k * args.steps}))
+                          "counters": [int(x) for x in c], "local_bits_per_rank": B * k * args.steps,
+                          "ranks_seen": seen, "distinct_random_streams": distinct}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -779,7 +797,10 @@ def main():
                 out["extra"][name] = {"error": f"{type(e).__name__}: {e}"}
 
     if _grouped(world):
+        seen, distinct = ranks_seen(world, rank, dev)          # a collective of THIS run: who took part, are the streams distinct
         out["collectives"] = {"backend": dist.get_backend(), "group_size": dist.get_world_size()}
+        out["rccl_ranks_seen"] = seen
+        out["distinct_random_streams"] = distinct
     if rank == 0:
         print(json.dumps(out))
     if _grouped(world):

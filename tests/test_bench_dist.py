@@ -95,6 +95,24 @@ def test_bench_gpus_n_self_launches_its_ranks():
     assert rec["counters"][2] == 2 * rec["local_bits_per_rank"]      # counters = 2 x the single-rank ones
 
 
+@pytest.mark.timeout(600)
+def test_bench_gpus_8_self_launch_dry():
+    """the driver's 8-GPU shape end to end on the control path: `python bench.py --gpus 8` becomes eight ranks, rank 0
+    prints ONE line, the counters are eight times one rank's, all eight ranks are seen by a collective and their random
+    streams differ pairwise"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-dist", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=560, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["config"]["parallelism"] == "dp8"
+    assert rec["counters"][2] == 8 * rec["local_bits_per_rank"]
+    assert rec["ranks_seen"] == 8 and rec["distinct_random_streams"] is True
+
+
 def test_bench_self_launch_command_line():
     sys.path.insert(0, ROOT)
     import bench

@@ -1035,15 +1035,18 @@ def test_tdl_spatial_correlation(phy):
     assert np.allclose(cov, r_full, atol=0.06)
 
 
-@pytest.mark.parametrize("name", ["c4", "cdl"])
+@pytest.mark.parametrize("name", ["c4", "cdl", "c4b"])
 def test_receiver_front_end_matches_reference_execution(phy, name):
     """The HIP blocks against outputs of the reference's OWN ResourceGridMapper / RemoveNulledSubcarriers /
     LSChannelEstimator ("nn", "lin", "lin_time_avg") / LMMSE, ZF, MF equalizers / LinearDetector / MMSEPICDetector /
     KBestDetector / EPDetector code with ESTIMATED channel state (tests/golden/ofdm_rx_ref_golden.npz,
     tools/gen_ofdm_rx_ref_golden.py): guard carriers, DC null, error variance > 0, per-example noise variance.  Bars as
     in tests/test_oracle_ref_exec_ofdm_rx.py (the oracle's twin of this test)."""
-    L = {"c4": dict(fft=76, guards=(3, 4), num_tx=2, spt=1, m=4, kbest=16), "cdl": dict(fft=72, guards=(5, 6), num_tx=1, spt=4, m=2, kbest=32)}[name]
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ofdm_rx_ref_golden.npz"))
+    # "c4b": BASELINE config C4's grid itself (1 transmitter x 2 streams, guards [5, 6], 4 receive antennas, QPSK;
+    # tools/gen_ofdm_rx_ref_golden.py --baseline)
+    L = {"c4": dict(fft=76, guards=(3, 4), num_tx=2, spt=1, m=4, kbest=16), "cdl": dict(fft=72, guards=(5, 6), num_tx=1, spt=4, m=2, kbest=32),
+         "c4b": dict(fft=76, guards=(5, 6), num_tx=1, spt=2, m=2, kbest=16)}[name]
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ofdm_rx_ref_golden_c4.npz" if name == "c4b" else "ofdm_rx_ref_golden.npz"))
     g = {k.split("/", 1)[1]: gold[k] for k in gold.files if k.startswith(name + "/")}
     rg = phy.ofdm.ResourceGrid(14, L["fft"], 15e3, num_tx=L["num_tx"], num_streams_per_tx=L["spt"], cyclic_prefix_length=6,
                                num_guard_carriers=list(L["guards"]), dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
@@ -1068,6 +1071,15 @@ def test_receiver_front_end_matches_reference_execution(phy, name):
     for it in ("nn", "lin", "lin_time_avg"):
         h, ev = phy.ofdm.LSChannelEstimator(rg, interpolation_type=it)(y, no)
         assert close(h, g[f"h_hat_{it}"]) and close(ev, g[f"err_var_{it}"]), it
+    if name == "c4b":
+        # the bench's receiver on its own grid: LS (nearest neighbour, DEFERRED h_hat) -> LMMSE: the fused kernel
+        # (samd_ofdm_lsnn_lmmse_c64) and, through LinearDetector, the fused kernel with the app demapper
+        h_d, ev_d = phy.ofdm.LSChannelEstimator(rg)(y, no)
+        xh, ne = phy.ofdm.LMMSEEqualizer(rg, sm)(y, h_d, ev_d, no)
+        assert close(xh, g["x_hat_lmmse_nn"], 2e-5) and close(ne, g["no_eff_lmmse_nn"], 2e-5)
+        h_d, ev_d = phy.ofdm.LSChannelEstimator(rg)(y, no)
+        det = phy.ofdm.LinearDetector("lmmse", "bit", "app", rg, sm, constellation_type="qam", num_bits_per_symbol=m, hard_out=False)
+        assert close(det(y, h_d, ev_d, no), g["llr_lmmse_nn_app"], 4e-5)
     hh, ev = g["h_hat_lin"], g["err_var_lin"]
     for kind, cls in (("lmmse", phy.ofdm.LMMSEEqualizer), ("mf", phy.ofdm.MFEqualizer)):
         xh, ne = cls(rg, sm)(y, hh, ev, no)

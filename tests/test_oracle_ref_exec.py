@@ -17,13 +17,18 @@ from oracle import cbind, ldpc_bp as obp
 from oracle.ldpc5g import LDPC5GCode
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "ldpc_bp_ref_golden.npz")
+# tools/gen_ldpc_bp_golden.py --baseline: the BASELINE.json codes themselves (C2: BG1 k=2816 n=8448 with the 64-QAM
+# interleaver, 20 iterations; C4's code k=768 n=1536) through the executed reference
+GOLD_BASELINE = os.path.join(os.path.dirname(__file__), "golden", "ldpc_bp_ref_golden_baseline.npz")
 EX = os.path.join(os.path.dirname(__file__), "golden", "example_pcms.npz")
 RULES = ("minsum", "offset-minsum", "boxplus", "boxplus-phi")
 
 
 @pytest.fixture(scope="module")
 def g():
-    return np.load(GOLD)
+    merged = dict(np.load(GOLD))
+    merged.update(np.load(GOLD_BASELINE))
+    return merged
 
 
 def example_pcm(i):
@@ -127,7 +132,7 @@ def test_c_oracle_minsum_matches_reference_execution(g, i):
             assert np.array_equal(cbind.bp_decode(d, llr), g[f"bp_ex{i}_{rule}_it{it}_x"]), (rule, it)
 
 
-CASES_5G = ("c1", "bg2s", "bg2m", "bg1r")
+CASES_5G = ("c1", "bg2s", "bg2m", "bg1r", "c2", "c4")
 
 
 def _code(g, tag):
@@ -154,7 +159,7 @@ def test_5g_decoder_matches_reference_execution(g, tag, phi_as_numpy):
         assert np.array_equal(sha(st), g[f"g5_{tag}_{rule}_state_sha"]), rule
         d = obp.LDPC5GDecoder(code, rule, hard_out=True, return_infobits=True, num_iter=iters)
         assert np.array_equal(d.decode5g(llr).astype(np.uint8), g[f"g5_{tag}_{rule}_uhat"]), rule
-    if tag in ("c1", "bg2s"):
+    if tag in ("c1", "bg2s", "c2"):
         it = max(2, iters // 2)
         d = obp.LDPC5GDecoder(code, "minsum", hard_out=False, return_infobits=False, num_iter=it, cn_schedule="layered")
         assert np.array_equal(d.decode5g(llr), g[f"g5_{tag}_layered_minsum_x"])

@@ -13,17 +13,23 @@ import pytest
 from oracle import ofdm as o, mapping as om
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "ofdm_rx_ref_golden.npz")
-LINKS = {"c4": dict(fft=76, guards=(3, 4), num_tx=2, spt=1, m=4, kbest=16), "cdl": dict(fft=72, guards=(5, 6), num_tx=1, spt=4, m=2, kbest=32)}
+# "c4b" (tools/gen_ofdm_rx_ref_golden.py --baseline, fixture ofdm_rx_ref_golden_c4.npz): BASELINE config C4's grid ITSELF -
+# one transmitter with two streams, guards [5, 6], DC null, pilots at symbols 2 and 11, four receive antennas, QPSK
+GOLD_C4 = os.path.join(os.path.dirname(__file__), "golden", "ofdm_rx_ref_golden_c4.npz")
+LINKS = {"c4": dict(fft=76, guards=(3, 4), num_tx=2, spt=1, m=4, kbest=16), "cdl": dict(fft=72, guards=(5, 6), num_tx=1, spt=4, m=2, kbest=32),
+         "c4b": dict(fft=76, guards=(5, 6), num_tx=1, spt=2, m=2, kbest=16)}
 
 
 @pytest.fixture(scope="module")
 def gold():
-    return np.load(GOLD)
+    merged = dict(np.load(GOLD))
+    merged.update(np.load(GOLD_C4))
+    return merged
 
 
 def link(gold, name):
     L = LINKS[name]
-    g = {k.split("/", 1)[1]: gold[k] for k in gold.files if k.startswith(name + "/")}
+    g = {k.split("/", 1)[1]: gold[k] for k in gold if k.startswith(name + "/")}
     rg = o.ResourceGrid(14, L["fft"], 15e3, num_tx=L["num_tx"], num_streams_per_tx=L["spt"], cyclic_prefix_length=6,
                         num_guard_carriers=L["guards"], dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
     assert np.array_equal(rg.pilot_pattern.mask, g["mask"].astype(bool))
@@ -58,6 +64,10 @@ def test_equalizers_and_linear_detectors(gold, name):
     y, no, hh, ev = g["y"], g["no"], g["h_hat_lin"], g["err_var_lin"]
     xo, neo = o.ofdm_lmmse_equalize(rg, sm, y, hh, ev, no)
     assert close(xo, g["x_hat_lmmse"]) and close(neo, g["no_eff_lmmse"])
+    if name == "c4b":                                            # the bench's chain: LS (nearest neighbour) -> LMMSE -> app demapper
+        xn, nn = o.ofdm_lmmse_equalize(rg, sm, y, g["h_hat_nn"], g["err_var_nn"], no)
+        assert close(xn, g["x_hat_lmmse_nn"]) and close(nn, g["no_eff_lmmse_nn"])
+        assert close(om.demapper(xn.astype(np.complex64), nn.astype(np.float32), pts, "app"), g["llr_lmmse_nn_app"], 2e-5)
     for meth in ("app", "maxlog"):
         assert close(om.demapper(xo.astype(np.complex64), neo.astype(np.float32), pts, meth), g[f"llr_lmmse_{meth}"], 2e-5)
     x, ne = o.ofdm_linear_equalize(rg, sm, y, hh, ev, no, "mf")
