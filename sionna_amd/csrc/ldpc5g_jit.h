@@ -32,7 +32,7 @@ struct JitPlan {
 struct JitState;
 
 struct JitKnobs {
-  int pipe = 2;        // items whose loads are in flight (1: load - update - store per item)
+  int pipe = 1;        // items whose loads are in flight (1: load - update - store per item)
   int xor128 = 0;      // Z = 128: second chunk's block position recomputed in the loop (v_xor) instead of a register
   int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
   int prio = 1;        // s_setprio per item

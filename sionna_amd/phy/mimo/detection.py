@@ -18,12 +18,11 @@ class LinearDetector(Block):
         assert output in ("bit", "symbol"), "Unknown output"
         assert demapping_method in ("app", "maxlog"), "Unknown demapping method"
         self._output = output
-        if equalizer in ("lmmse", "zf", "mf"):
+        if isinstance(equalizer, str):                        # detection.py:101-111
+            assert equalizer in ("lmmse", "zf", "mf"), "Unknown equalizer."
             self._equalizer = {"lmmse": lmmse_equalizer, "zf": zf_equalizer, "mf": mf_equalizer}[equalizer]
-        elif callable(equalizer):
-            self._equalizer = equalizer
         else:
-            raise NotImplementedError(f"LinearDetector: equalizer '{equalizer}' is outside the hot path (lmmse only)")
+            self._equalizer = equalizer
         self._constellation = Constellation.check_or_create(
             constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
             constellation=constellation, precision=precision)

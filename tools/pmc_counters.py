@@ -91,6 +91,11 @@ def main():
         head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     except OSError:
         head = ""
+    if not head:                          # on the GPU box the snapshot has no .git: tools/gpu_*.sh callers leave the commit here
+        try:
+            head = " ".join(open(os.path.join(ROOT, "gpurun_in", "HEAD")).read().split())
+        except OSError:
+            head = ""
     collected = sys.argv[sys.argv.index("--collected-on") + 1] if "--collected-on" in sys.argv else head
     out = {"_comment": "per-unit PMC counters of the dominant kernels (tools/pmc_counters.py); bench.py multiplies them by the "
                        "units of a launch and divides by the launch time it measures", "tag": tag,
