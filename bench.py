@@ -345,6 +345,30 @@ def bench_c4(args, short=False):
         return a0.elapsed_time(a1) / reps_
     same_bits = bool(torch.equal(rx_separate(), rx_fused()))
     ms_sep, ms_fused = timed(rx_separate), timed(rx_fused)
+    # channel generation: the two kernels behind OFDMChannel, timed on their own
+    fs = 1.0 / rg.ofdm_symbol_duration
+    freqs = phy.channel.subcarrier_frequencies(rg.fft_size, rg.subcarrier_spacing)
+    a_t, tau_t = tdl(B, rg.num_ofdm_symbols, fs)
+    ms_tdl = timed(lambda: tdl(B, rg.num_ofdm_symbols, fs), 5)
+    ms_c2o = timed(lambda: phy.channel.cir_to_ofdm_channel(freqs, a_t, tau_t, normalize=True), 5)
+    c2o_out = B * 4 * 2 * rg.num_ofdm_symbols * rg.fft_size * 8              # h_freq [B, 1, 4, 1, 2, T, fft] complex64
+    c2o_in = int(a_t.numel()) * 8 + int(tau_t.numel()) * 4
+    rec_c2o, rec_tdl = load_counters("cir_to_ofdm"), load_counters("tdl_cir")
+    channel_kernels = {
+        "cir_to_ofdm": {"kernel": "cir_to_ofdm_reg_kernel<24, 24> (phase table + taps in LDS, results staged in registers, one store per value)",
+                        "ms_per_launch": round(ms_c2o, 4),
+                        "roofline": {"bound": "hbm", "achieved": round((c2o_in + c2o_out) / (ms_c2o * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                                     "unit": "GB/s", "frac": round((c2o_in + c2o_out) / (ms_c2o * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                                     "algorithmic_bytes": c2o_in + c2o_out,
+                                     "traffic": int(rec_c2o["hbm_bytes_per_unit"] * rec_c2o["units_per_launch"]) if rec_c2o else None,
+                                     "write_bytes_over_output": round(rec_c2o["write_size_kb_per_launch"] * 1024 / c2o_out, 3) if rec_c2o else None}},
+        "tdl_cir": {"kernel": "tdl_cir_kernel (sum of 20 sinusoids per tap, Philox draws in the kernel)", "ms_per_launch": round(ms_tdl, 4),
+                    "roofline": {"bound": "valu", "unit": "G wave64-inst/s", "peak": round(VALU_PEAK_GINST, 1),
+                                 "achieved": round(rec_tdl["valu_insts_per_unit"] * rec_tdl["units_per_launch"] / (ms_tdl * 1e-3) / 1e9, 1) if rec_tdl else None,
+                                 "frac": round(rec_tdl["valu_insts_per_unit"] * rec_tdl["units_per_launch"] / (ms_tdl * 1e-3) / 1e9 / VALU_PEAK_GINST, 4) if rec_tdl else None,
+                                 "traffic": int(rec_tdl["hbm_bytes_per_unit"] * rec_tdl["units_per_launch"]) if rec_tdl else None,
+                                 "output_bytes": int(a_t.numel()) * 8}}}
+    del a_t, tau_t
     n_data_re = B * rg.num_data_symbols
     ach = n_data_re * 120 / (ms * 1e-3) / 1e9
     t0 = time.perf_counter()
@@ -364,7 +388,7 @@ def bench_c4(args, short=False):
            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4),
                         "traffic": int(rec["hbm_bytes_per_unit"] * n_data_re) if rec else None,
-                        "kernel": "ofdm_lmmse_diag_kernel<4,2> (whole OFDMEqualizer.call in one launch)",
+                        "kernel": "ofdm_lmmse_diag_kernel<4,2,2> (whole OFDMEqualizer.call in one launch, two resource elements per lane)",
                         "algorithmic_bytes_per_re": 120, "ms_per_launch": round(ms, 4),
                         "ms_per_block_api_call": round(ms_call, 4), "host_overhead_ms": round(ms_call - ms, 4),
                         "note": "ms_per_launch = 20 back-to-back C-ABI launches between one pair of HIP events (queue "
@@ -372,12 +396,13 @@ def bench_c4(args, short=False):
            "receiver_front_end": {
                "stages": "LSChannelEstimator(nn) -> LMMSEEqualizer -> Demapper(app)", "ms_three_launches": round(ms_sep, 4),
                "ms_fused_one_launch": round(ms_fused, 4), "bit_identical": same_bits,
-               "kernel": "ofdm_lsnn_lmmse_kernel<4,2,1,app> (h_hat deferred, never written)",
+               "kernel": "ofdm_lsnn_lmmse_kernel<4,2,1,app,2> (h_hat deferred, never written; two resource elements per lane)",
                "algorithmic_GBps_at_120B_per_RE": round(n_data_re * 120 / (ms_fused * 1e-3) / 1e9, 1),
                "frac_of_hbm_peak_at_120B_per_RE": round(n_data_re * 120 / (ms_fused * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3),
                "note": "SURVEY 8(d)'s 120 B/RE assume h_hat (64 B/RE) is read from HBM; the fused kernel reads y (32 B/RE + "
                        "pilot rows from L2) and writes 16 B/RE of LLRs, so this fraction may exceed what an h_hat-reading "
                        "kernel can reach - it is reported for comparison with the separate-kernel figure above"},
+           "channel_kernels": channel_kernels,
            "end_to_end": {"codewords_per_s": round(2 * B / t_e2e, 1), "ms_per_batch": round(t_e2e * 1e3, 2)}}
     if not short:
         # time-domain variant of the same chain: OFDMModulator (rocFFT) -> TimeChannel -> OFDMDemodulator (rocFFT)

@@ -484,46 +484,69 @@ __device__ __forceinline__ bool load_re(const OfdmEqArgs& p, int brx_i, int re, 
 // only its M diagonal entries are formed (load as in load_re).
 // (occupancy bound: without it the scheduler hoists every load and spends 162 registers on <4, 2> - 3 waves per SIMD
 // for a kernel that streams 128 B per resource element; with it 68 registers and no spill)
-template <int M, int K>
-__global__ __launch_bounds__(128, (M * K <= 8) ? 6 : 1) void ofdm_lmmse_diag_kernel(OfdmEqArgs p) {
+// R (round 5): resource elements per lane - the SAME (t, f) of R consecutive (batch, receiver) pairs, so that a wave of
+// pilot-only resource elements still leaves as a whole.  One element per lane is a serial chain (loads -> 2 x 2 Cholesky ->
+// two triangular solves -> divisions) with nothing to issue while a load or a division is in flight (round-4 profile: 70 %
+// of the wave cycles parked, 0.49 of HBM peak); two independent chains in one basic block give the scheduler instruction-
+// level parallelism and twice the loads in flight per wave.  The arithmetic per element is unchanged (same bits).
+template <int M, int K, int R>
+__global__ __launch_bounds__(128, (M * K <= 8) ? (R == 1 ? 6 : 3) : 1) void ofdm_lmmse_diag_kernel(OfdmEqArgs p) {
   const int re_i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (re_i >= p.T * p.F) return;
-  const int brx_i = p.brx0 + (int)blockIdx.y;
+  const int brx_first = p.brx0 + (int)blockIdx.y * R;
   const int TF = p.T * p.F, re = re_i;
   const int t = (int)((unsigned)re / (unsigned)p.F), f = re - t * p.F;
-  const int rx = (int)((unsigned)brx_i % (unsigned)p.RX);
-  const int64_t b = (int64_t)((unsigned)brx_i / (unsigned)p.RX);
-  int dpos[K];
+  const int bin = p.sc_ind[f];
+  int dpos[R][K], sid[R][K];
+  int64_t bb[R];
+  bool live[R];
   bool any = false;
 #pragma unroll
-  for (int k = 0; k < K; ++k) { dpos[k] = p.data_pos[(int64_t)p.desired[rx * K + k] * TF + re]; any |= dpos[k] >= 0; }
-  if (!any) return;                                           // pilot-only resource element
-  const int64_t brx = b * p.RX + rx;
-  c32 y[M], h[M][K], xh[K];
-  float d[M], ne[K];
-  const int bin = p.sc_ind[f];
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const float2 v = p.y[((brx * M + m) * p.T + t) * p.FFT + bin];
-    y[m] = C(v.x, v.y);
+  for (int r = 0; r < R; ++r) {
+    const int brx_i = min(brx_first + r, p.B * p.RX - 1);     // (a last, odd pair repeats its element; not stored)
+    live[r] = brx_first + r < p.B * p.RX;
+    const int rx = (int)((unsigned)brx_i % (unsigned)p.RX);
+    bb[r] = (int64_t)((unsigned)brx_i / (unsigned)p.RX);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const float2 w = p.h_hat[((brx * M + m) * p.S + p.desired[rx * K + k]) * TF + re];
-      h[m][k] = C(w.x, w.y);
+      sid[r][k] = p.desired[rx * K + k];
+      dpos[r][k] = p.data_pos[(int64_t)sid[r][k] * TF + re];
+      any |= live[r] && dpos[r][k] >= 0;
     }
-    float dg = p.no[brx * M + m];                             // thermal noise + estimation error of ALL streams
-    if (p.ev_mode == 1) { for (int q = 0; q < p.S; ++q) dg += p.err_var[(int64_t)q * TF + re]; }
-    else if (p.ev_mode == 2) { for (int q = 0; q < p.S; ++q) dg += p.err_var[((brx * M + m) * p.S + q) * TF + re]; }
-    d[m] = dg;
   }
-  lmmse_solve_diag<M, K>(y, h, d, xh, ne);
+  if (!any) return;                                           // pilot-only resource element
+  c32 y[R][M], h[R][M][K], xh[R][K];
+  float d[R][M], ne[R][K];
 #pragma unroll
-  for (int k = 0; k < K; ++k)
-    if (dpos[k] >= 0) {
-      const int64_t o = (b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k];
-      p.x_hat[o] = make_float2(xh[k].re, xh[k].im);
-      p.no_eff[o] = ne[k];
+  for (int r = 0; r < R; ++r) {
+    const int brx_i = min(brx_first + r, p.B * p.RX - 1);
+    const int64_t brx = (int64_t)brx_i;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const float2 v = p.y[((brx * M + m) * p.T + t) * p.FFT + bin];
+      y[r][m] = C(v.x, v.y);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float2 w = p.h_hat[((brx * M + m) * p.S + sid[r][k]) * TF + re];
+        h[r][m][k] = C(w.x, w.y);
+      }
+      float dg = p.no[brx * M + m];                           // thermal noise + estimation error of ALL streams
+      if (p.ev_mode == 1) { for (int q = 0; q < p.S; ++q) dg += p.err_var[(int64_t)q * TF + re]; }
+      else if (p.ev_mode == 2) { for (int q = 0; q < p.S; ++q) dg += p.err_var[((brx * M + m) * p.S + q) * TF + re]; }
+      d[r][m] = dg;
     }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) lmmse_solve_diag<M, K>(y[r], h[r], d[r], xh[r], ne[r]);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (live[r] && dpos[r][k] >= 0) {
+        const int64_t o = (bb[r] * p.S + sid[r][k]) * p.ND + dpos[r][k];
+        p.x_hat[o] = make_float2(xh[r][k].re, xh[r][k].im);
+        p.no_eff[o] = ne[r][k];
+      }
 }
 
 template <int M, int K>
@@ -1169,8 +1192,9 @@ struct OfdmLsEqArgs {
   int hard_out;
 };
 
-template <int M, int K, int NB, bool MAXLOG>
-__global__ __launch_bounds__(128, (M * K <= 8) ? 6 : 1) void ofdm_lsnn_lmmse_kernel(OfdmLsEqArgs a) {
+// R: resource elements per lane = the same (t, f) of R consecutive (batch, receiver) pairs (see ofdm_lmmse_diag_kernel)
+template <int M, int K, int NB, bool MAXLOG, int R>
+__global__ __launch_bounds__(128, (M * K <= 8) ? (R == 1 ? 6 : 3) : 1) void ofdm_lsnn_lmmse_kernel(OfdmLsEqArgs a) {
   const OfdmEqArgs& p = a.e;
   [[maybe_unused]] __shared__ float lev[NB > 0 ? (1 << NB) : 1];
   if constexpr (NB > 0) {
@@ -1179,61 +1203,76 @@ __global__ __launch_bounds__(128, (M * K <= 8) ? 6 : 1) void ofdm_lsnn_lmmse_ker
   }
   const int re = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (re >= p.T * p.F) return;
-  const int brx_i = p.brx0 + (int)blockIdx.y;
+  const int brx_first = p.brx0 + (int)blockIdx.y * R;
   const int TF = p.T * p.F;
   const int t = (int)((unsigned)re / (unsigned)p.F), f = re - t * p.F;
-  const int rx = (int)((unsigned)brx_i % (unsigned)p.RX);
-  const int64_t b = (int64_t)((unsigned)brx_i / (unsigned)p.RX);
-  int dpos[K], sid[K];
+  int dpos[R][K], sid[R][K];
+  int64_t bb[R];
+  bool live[R];
   bool any = false;
 #pragma unroll
-  for (int k = 0; k < K; ++k) { sid[k] = p.desired[rx * K + k]; dpos[k] = p.data_pos[(int64_t)sid[k] * TF + re]; any |= dpos[k] >= 0; }
-  if (!any) return;                                           // pilot-only resource element
-  const int64_t brx = b * p.RX + rx;
-  c32 y[M], h[M][K], xh[K];
-  float d[M], ne[K];
-  const int bin = p.sc_ind[f];
-  int src[K];
-  float2 coef[K];
-#pragma unroll
-  for (int k = 0; k < K; ++k) { src[k] = a.ls_src[(int64_t)sid[k] * TF + re]; coef[k] = a.ls_coef[(int64_t)sid[k] * TF + re]; }
-  float evs = 0.f;                                            // (only for no_ls_len == 1: the same sum for every antenna)
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const int64_t row = (brx * M + m) * p.T * (int64_t)p.FFT;
-    const float2 v = p.y[row + (int64_t)t * p.FFT + bin];
-    y[m] = C(v.x, v.y);
+  for (int r = 0; r < R; ++r) {
+    const int brx_i = min(brx_first + r, p.B * p.RX - 1);     // (a last, odd pair repeats its element; not stored)
+    live[r] = brx_first + r < p.B * p.RX;
+    const int rx = (int)((unsigned)brx_i % (unsigned)p.RX);
+    bb[r] = (int64_t)((unsigned)brx_i / (unsigned)p.RX);
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const float2 yp = a.y_ls[row + src[k]];
-      h[m][k] = C(yp.x * coef[k].x - yp.y * coef[k].y, yp.x * coef[k].y + yp.y * coef[k].x);     // cmul(y, 1 / pilot)
+      sid[r][k] = p.desired[rx * K + k];
+      dpos[r][k] = p.data_pos[(int64_t)sid[r][k] * TF + re];
+      any |= live[r] && dpos[r][k] >= 0;
     }
-    const float nl = a.no_ls[a.no_ls_len == 1 ? 0 : brx * M + m];
-    float dg = p.no[brx * M + m];                             // thermal noise + estimation error of ALL streams, q ascending
-    for (int q = 0; q < p.S; ++q) dg += fmaxf(nl * a.ls_ev[(int64_t)q * TF + re], 0.f);
-    d[m] = dg;
   }
-  (void)evs;
-  lmmse_solve_diag<M, K>(y, h, d, xh, ne);
+  if (!any) return;                                           // pilot-only resource element
+  c32 y[R][M], h[R][M][K], xh[R][K];
+  float d[R][M], ne[R][K];
+  const int bin = p.sc_ind[f];
 #pragma unroll
-  for (int k = 0; k < K; ++k)
-    if (dpos[k] >= 0) {
-      const int64_t o = (b * p.S + sid[k]) * p.ND + dpos[k];
-      if constexpr (NB == 0) {
-        p.x_hat[o] = make_float2(xh[k].re, xh[k].im);
-        p.no_eff[o] = ne[k];
-      } else {
-        float llr[2 * NB];
-        square_qam_llr<NB, MAXLOG>(make_float2(xh[k].re, xh[k].im), ne[k], lev, llr);
-        float* op = a.llr + o * (2 * NB);
+  for (int r = 0; r < R; ++r) {
+    const int64_t brx = (int64_t)min(brx_first + r, p.B * p.RX - 1);
+    int src[K];
+    float2 coef[K];
 #pragma unroll
-        for (int i = 0; i < 2 * NB; i += 2) {
-          float2 v2 = make_float2(llr[i], llr[i + 1]);
-          if (a.hard_out) v2 = make_float2(v2.x > 0.f ? 1.f : 0.f, v2.y > 0.f ? 1.f : 0.f);
-          *reinterpret_cast<float2*>(op + i) = v2;
+    for (int k = 0; k < K; ++k) { src[k] = a.ls_src[(int64_t)sid[r][k] * TF + re]; coef[k] = a.ls_coef[(int64_t)sid[r][k] * TF + re]; }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int64_t row = (brx * M + m) * p.T * (int64_t)p.FFT;
+      const float2 v = p.y[row + (int64_t)t * p.FFT + bin];
+      y[r][m] = C(v.x, v.y);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float2 yp = a.y_ls[row + src[k]];
+        h[r][m][k] = C(yp.x * coef[k].x - yp.y * coef[k].y, yp.x * coef[k].y + yp.y * coef[k].x);     // cmul(y, 1 / pilot)
+      }
+      const float nl = a.no_ls[a.no_ls_len == 1 ? 0 : brx * M + m];
+      float dg = p.no[brx * M + m];                           // thermal noise + estimation error of ALL streams, q ascending
+      for (int q = 0; q < p.S; ++q) dg += fmaxf(nl * a.ls_ev[(int64_t)q * TF + re], 0.f);
+      d[r][m] = dg;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) lmmse_solve_diag<M, K>(y[r], h[r], d[r], xh[r], ne[r]);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (live[r] && dpos[r][k] >= 0) {
+        const int64_t o = (bb[r] * p.S + sid[r][k]) * p.ND + dpos[r][k];
+        if constexpr (NB == 0) {
+          p.x_hat[o] = make_float2(xh[r][k].re, xh[r][k].im);
+          p.no_eff[o] = ne[r][k];
+        } else {
+          float llr[2 * NB];
+          square_qam_llr<NB, MAXLOG>(make_float2(xh[r][k].re, xh[r][k].im), ne[r][k], lev, llr);
+          float* op = a.llr + o * (2 * NB);
+#pragma unroll
+          for (int i = 0; i < 2 * NB; i += 2) {
+            float2 v2 = make_float2(llr[i], llr[i + 1]);
+            if (a.hard_out) v2 = make_float2(v2.x > 0.f ? 1.f : 0.f, v2.y > 0.f ? 1.f : 0.f);
+            *reinterpret_cast<float2*>(op + i) = v2;
+          }
         }
       }
-    }
 }
 
 }  // namespace samd
@@ -1289,10 +1328,15 @@ extern "C" int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const flo
   const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 127) / 128, brx_total = batch * num_rx;
   static samd::CachedOpt lmmse_general_opt("SAMD_LMMSE_GENERAL");   // development: force the general-covariance kernel
   const bool diag = num_undesired == 0 && whiten == 1 && !lmmse_general_opt.is_set();   // diagonal covariance
+  static samd::CachedOpt lmmse_r1_opt("SAMD_LMMSE_R1");             // development: one resource element per lane (rounds 1-4)
 #define X(M, K)                                                                                            \
   if (num_rx_ant == M && streams_per_rx == K) {                                                            \
-    if (diag) for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 65535)                                                   \
-      hipLaunchKernelGGL((ofdm_lmmse_diag_kernel<M, K>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(128), 0,     \
+    if (diag && M * K <= 8 && brx_total >= 2 && !lmmse_r1_opt.is_set())                                   \
+      for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 2 * 65535)                                            \
+        hipLaunchKernelGGL((ofdm_lmmse_diag_kernel<M, K, 2>), dim3(tf_blocks, std::min((brx_total - p.brx0 + 1) / 2, 65535)), \
+                           dim3(128), 0, (hipStream_t)stream, p);                                          \
+    else if (diag) for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 65535)                                                   \
+      hipLaunchKernelGGL((ofdm_lmmse_diag_kernel<M, K, 1>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(128), 0,     \
                          (hipStream_t)stream, p); \
     else for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 65535)                                                   \
       hipLaunchKernelGGL((ofdm_lmmse_kernel<M, K>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(128), 0,     \
@@ -1322,10 +1366,17 @@ extern "C" int samd_ofdm_lsnn_lmmse_c64(const float* y, const float* y_ls, const
   if ((int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers == 0) return SAMD_OK;
   const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 127) / 128, brx_total = batch * num_rx;
   const int nb = num_bits_per_symbol / 2;
+  static samd::CachedOpt lsnn_r1_opt("SAMD_LMMSE_R1");              // development: one resource element per lane (round 4)
+  const bool two = brx_total >= 2 && !lsnn_r1_opt.is_set();
 #define LAUNCH(M, K, NB, ML)                                                                                         \
-  for (a.e.brx0 = 0; a.e.brx0 < brx_total; a.e.brx0 += 65535)                                                        \
-    hipLaunchKernelGGL((ofdm_lsnn_lmmse_kernel<M, K, NB, ML>), dim3(tf_blocks, std::min(brx_total - a.e.brx0, 65535)), \
-                       dim3(128), 0, (hipStream_t)stream, a);                                                         \
+  if (two && M * K <= 8)                                                                                             \
+    for (a.e.brx0 = 0; a.e.brx0 < brx_total; a.e.brx0 += 2 * 65535)                                                  \
+      hipLaunchKernelGGL((ofdm_lsnn_lmmse_kernel<M, K, NB, ML, 2>), dim3(tf_blocks, std::min((brx_total - a.e.brx0 + 1) / 2, 65535)), \
+                         dim3(128), 0, (hipStream_t)stream, a);                                                       \
+  else                                                                                                               \
+    for (a.e.brx0 = 0; a.e.brx0 < brx_total; a.e.brx0 += 65535)                                                      \
+      hipLaunchKernelGGL((ofdm_lsnn_lmmse_kernel<M, K, NB, ML, 1>), dim3(tf_blocks, std::min(brx_total - a.e.brx0, 65535)), \
+                         dim3(128), 0, (hipStream_t)stream, a);                                                       \
   return launch_status();
 #define X(M, K)                                                                                                      \
   if (num_rx_ant == M && streams_per_rx == K) {                                                                      \

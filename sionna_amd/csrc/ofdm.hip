@@ -12,6 +12,7 @@
 // materialises as rank-8 broadcast temporaries (3.4 GB for the TDL sinusoids, 12.8 GB for
 // the per-path frequency responses at config C4) stays in registers / LDS here.
 #include "common.h"
+#include "options.h"
 
 namespace samd {
 
@@ -249,6 +250,103 @@ __global__ __launch_bounds__(256) void cir_to_ofdm_kernel(const float2* __restri
   }
 }
 
+// Round 5: the same transform with the workgroup's results staged in REGISTERS (config C4: 8512 complex values = 68 KB per
+// (batch, rx, tx) link).  The kernel above writes H, re-reads it from L2 and writes it again scaled (WRITE_SIZE 1.99 x the
+// output, profiles/r04zz_pmc), spends ~100 vector instructions of index arithmetic (three integer divisions) per output
+// next to the 46 packed FMAs of a 23-path link, and walks the paths through 24 scalar branches per row (`p < P`).  Here:
+// taps and phases are padded with zeros to MAXP paths (no branch); a thread owns subcarrier f and every G-th row, its RPT
+// rows are an unrolled loop over a register array (independent FMA chains, (ra, ta, t) advanced by carries - no division
+// in the loops); the energy is reduced once and every value is stored ONCE, scaled.  Same products per output, summed in
+// ascending path order in two accumulators (real-tap and imaginary-tap contributions); held to 1e-4 of the float64 oracle
+// like the kernel above.
+template <int MAXP, int RPT>
+__global__ __launch_bounds__(512) void cir_to_ofdm_reg_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
+                                                              const float* __restrict__ freqs, int RX, int RA, int TX,
+                                                              int TA, int P, int T, int F, int normalize,
+                                                              float2* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float2 tab[];   // [MAXP][F] phases, taps [RA*TA][T][MAXP] (paths adjacent), red[blockDim]
+  float2* taps = tab + (size_t)MAXP * F;
+  float* red = reinterpret_cast<float*>(taps + (size_t)RA * TA * MAXP * T);
+  const int tx = blockIdx.x % TX;
+  const int rx = (blockIdx.x / TX) % RX;
+  const int b = blockIdx.x / (TX * RX);
+  const float* tb = tau + ((size_t)(b * RX + rx) * TX + tx) * P;
+  const int nt = blockDim.x, tid = threadIdx.x;
+  for (int i = tid; i < MAXP * F; i += nt) {
+    const int p = i / F, f = i - p * F;
+    float sn = 0.f, cs = 0.f;
+    if (p < P) sincosf(-2.f * 3.14159265358979323846f * freqs[f] * tb[p], &sn, &cs);
+    tab[i] = make_float2(cs, sn);
+  }
+  const int mt = MAXP * T;
+  for (int i = tid; i < RA * TA * mt; i += nt) {
+    const int lk = i / mt, q = i - lk * mt;                      // link (ra, ta), q = t * MAXP + p: a row's paths are adjacent
+    const int t = q / MAXP, p = q - t * MAXP;
+    const int ta = lk % TA, ra = lk / TA;
+    taps[i] = p < P ? a[((((size_t)(b * RX + rx) * RA + ra) * TX + tx) * TA + ta) * (size_t)(P * T) + (size_t)p * T + t] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  const int rows = RA * TA * T;
+  const int G = nt / F;                                           // row groups side by side (host: F <= blockDim)
+  const int g = tid / F, f = tid - g * F;
+  const bool act = g < G;
+  float2 ph[MAXP];
+#pragma unroll
+  for (int p = 0; p < MAXP; ++p) ph[p] = act ? tab[p * F + f] : make_float2(0.f, 0.f);
+  c2o_f32x2 acc[RPT];
+  float energy = 0.f;
+  {
+    int t = g % T, lk = g / T;                                    // row g = (link lk, symbol t); advanced by G with carries
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      c2o_f32x2 hv = {0.f, 0.f};
+      if (act && lk < RA * TA) {
+        const float2* ap = taps + (size_t)(lk * T + t) * MAXP;
+        // a e^{j phi} = (a.x c - a.y s, a.x s + a.y c) as two accumulators: u += a.x (c, s), v += a.y (s, c) - the swapped
+        // pair is an operand selection of the packed FMA, no negation per path - and h = (u.x - v.x, u.y + v.y) at the end
+        c2o_f32x2 u = {0.f, 0.f}, v = {0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+          const float2 av = ap[p];                                // the lanes of a group read one address: LDS broadcast
+          u = __builtin_elementwise_fma(c2o_f32x2{av.x, av.x}, c2o_f32x2{ph[p].x, ph[p].y}, u);
+          v = __builtin_elementwise_fma(c2o_f32x2{av.y, av.y}, c2o_f32x2{ph[p].y, ph[p].x}, v);
+        }
+        hv = c2o_f32x2{u.x - v.x, u.y + v.y};
+        energy += hv.x * hv.x + hv.y * hv.y;
+      }
+      acc[r] = hv;
+      t += G;
+      while (t >= T) { t -= T; ++lk; }
+    }
+  }
+  float inv = 1.f;
+  if (normalize) {
+    red[tid] = energy;
+    __syncthreads();
+    int o = 1;
+    while (o < nt) o <<= 1;
+    for (o >>= 1; o > 0; o >>= 1) {
+      if (tid < o && tid + o < nt) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    const float c = sqrtf(red[0] / (float)(rows * F));
+    inv = c > 0.f ? 1.f / c : 0.f;                               // divide_no_nan
+  }
+  float2* ob = out + ((size_t)(b * RX + rx) * RA) * TX * TA * (size_t)T * F;
+  {
+    int t = g % T, lk = g / T;
+    int ta = lk % TA, ra = lk / TA;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      if (act && ra < RA)
+        ob[(unsigned)((((ra * TX + tx) * TA + ta) * T + t) * F + f)] = normalize ? make_float2(acc[r].x * inv, acc[r].y * inv)
+                                                                              : make_float2(acc[r].x, acc[r].y);
+      t += G;
+      while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
+    }
+  }
+}
+
 // y[b,rx,ra,t,f] = sum_{tx,ta} h[b,rx,ra,tx,ta,t,f] * x[b,tx,ta,t,f]
 __global__ __launch_bounds__(256) void apply_ofdm_channel_kernel(const float2* __restrict__ x,
                                                                  const float2* __restrict__ h, int64_t total,
@@ -368,14 +466,41 @@ extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const floa
                                     int num_freqs, int normalize, float* h_freq, void* stream) {
   SAMD_REQUIRE(a && tau && frequencies && h_freq && batch > 0, "bad argument");
   SAMD_REQUIRE(num_paths >= 1 && num_freqs >= 1 && num_time_steps >= 1, "bad size");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(batch * num_rx * num_tx);
+  typedef void (*kern_t)(const float2*, const float*, const float*, int, int, int, int, int, int, int, int, float2*);
+  {
+    // results staged in registers (cir_to_ofdm_reg_kernel): block size = the multiple of 64 that fills its lanes best with
+    // G = blockDim / F row groups; every thread's ceil(rows / G) rows must fit the unrolled register array
+    static samd::CachedOpt opt_old("SAMD_C2O_TWO_PASS");       // development: the two-pass kernel of rounds 1-4
+    const int rows = num_rx_ant * num_tx_ant * num_time_steps;
+    int best_nt = 0, best_rpt = 0;
+    double best_u = 0.0;
+    for (int nt = 256; nt <= 512 && num_freqs <= 512; nt += 64) {
+      if (num_freqs > nt) continue;
+      const int gq = nt / num_freqs, rpt = (rows + gq - 1) / gq;
+      const double u = (double)(gq * num_freqs) / nt;
+      if (rpt <= 40 && u > best_u + 1e-9) { best_u = u; best_nt = nt; best_rpt = rpt; }
+    }
+    const int mp = num_paths <= 8 ? 8 : num_paths <= 16 ? 16 : num_paths <= 24 ? 24 : num_paths <= 32 ? 32 : 0;
+    const size_t lds_r = ((size_t)mp * num_freqs + (size_t)num_rx_ant * num_tx_ant * mp * num_time_steps) * sizeof(float2) + 512 * sizeof(float);
+    if (best_nt && mp && lds_r <= 64 * 1024 && !opt_old.is_set()) {
+#define SAMD_C2R_K(MP) {cir_to_ofdm_reg_kernel<MP, 8>, cir_to_ofdm_reg_kernel<MP, 16>, cir_to_ofdm_reg_kernel<MP, 24>, \
+                        cir_to_ofdm_reg_kernel<MP, 32>, cir_to_ofdm_reg_kernel<MP, 40>}
+      static const kern_t rk[4][5] = {SAMD_C2R_K(8), SAMD_C2R_K(16), SAMD_C2R_K(24), SAMD_C2R_K(32)};
+#undef SAMD_C2R_K
+      const kern_t kern = rk[mp / 8 - 1][(best_rpt + 7) / 8 - 1];
+      hipLaunchKernelGGL(kern, grid, dim3(best_nt), lds_r, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx,
+                         num_tx_ant, num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq);
+      return launch_status();
+    }
+  }
   const size_t tab_b = (size_t)num_paths * num_freqs * sizeof(float2) + 256 * sizeof(float);
   const size_t taps_b = (size_t)num_rx_ant * num_tx_ant * num_paths * num_time_steps * sizeof(float2);
   SAMD_REQUIRE(tab_b <= 160 * 1024, "phase table (num_paths x num_freqs) exceeds the LDS");
   const bool taps_lds = tab_b + taps_b <= 160 * 1024;      // else the taps are read from global memory (L1 broadcast)
   const size_t lds = tab_b + (taps_lds ? taps_b : 0);
-  const dim3 grid(batch * num_rx * num_tx), blk(256);
-  hipStream_t st = (hipStream_t)stream;
-  typedef void (*kern_t)(const float2*, const float*, const float*, int, int, int, int, int, int, int, int, float2*);
+  const dim3 blk(256);
 #define SAMD_C2O_K(MAXP) {cir_to_ofdm_kernel<MAXP, false>, cir_to_ofdm_kernel<MAXP, true>}
   static const kern_t kerns[6][2] = {SAMD_C2O_K(8), SAMD_C2O_K(16), SAMD_C2O_K(24), SAMD_C2O_K(32), SAMD_C2O_K(64), SAMD_C2O_K(0)};
 #undef SAMD_C2O_K

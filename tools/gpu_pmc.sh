@@ -20,5 +20,5 @@ run tcc1 FETCH_SIZE
 run tcc2 WRITE_SIZE
 cd $GRAFT_REPO_ROOT
 python tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
-python tools/pmc_counters.py $OUT --tag $TAG ldpc5g_jit=65536 ldpc5g_ms=65536 ldpc5g_bp=65536 ldpc5g_bp_fast=65536 ldpc5g_layered=65536 polar_scl=32768 polar_bp=32768 ofdm_lmmse=6291456 > $OUT/counters.json
+python tools/pmc_counters.py $OUT --tag $TAG ldpc5g_jit=65536 ldpc5g_ms=65536 ldpc5g_bp=65536 ldpc5g_bp_fast=65536 ldpc5g_layered=65536 polar_scl=32768 polar_bp=32768 ofdm_lmmse=6291456 ofdm_lsnn_lmmse=6291456 cir_to_ofdm=69730304 tdl_cir=21102592 > $OUT/counters.json
 head -c 1500 $OUT/counters.json

@@ -32,6 +32,9 @@ KERNELS = {   # key -> (substring of the kernel name, unit, source file(s): the 
     "polar_scl": ("polar_scl_reg_kernel", "decode", "sionna_amd/csrc/polar_scl_reg.hip"),
     "polar_bp": ("polar_bp_kernel", "decode", "sionna_amd/csrc/polar_bp.hip"),
     "ofdm_lmmse": ("ofdm_lmmse_diag_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
+    "ofdm_lsnn_lmmse": ("ofdm_lsnn_lmmse_kernel", "resource element", "sionna_amd/csrc/mimo.hip"),
+    "cir_to_ofdm": ("cir_to_ofdm", "channel coefficient", "sionna_amd/csrc/ofdm.hip"),
+    "tdl_cir": ("tdl_cir_kernel", "tap sample", "sionna_amd/csrc/ofdm.hip"),
 }
 
 
