@@ -388,7 +388,7 @@ def bench_c4(args, short=False):
            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBPS, 4),
                         "traffic": int(rec["hbm_bytes_per_unit"] * n_data_re) if rec else None,
-                        "kernel": "ofdm_lmmse_diag_kernel<4,2,2> (whole OFDMEqualizer.call in one launch, two resource elements per lane)",
+                        "kernel": "ofdm_lmmse_diag_kernel<4,2,1> (whole OFDMEqualizer.call in one launch)",
                         "algorithmic_bytes_per_re": 120, "ms_per_launch": round(ms, 4),
                         "ms_per_block_api_call": round(ms_call, 4), "host_overhead_ms": round(ms_call - ms, 4),
                         "note": "ms_per_launch = 20 back-to-back C-ABI launches between one pair of HIP events (queue "
@@ -396,7 +396,7 @@ def bench_c4(args, short=False):
            "receiver_front_end": {
                "stages": "LSChannelEstimator(nn) -> LMMSEEqualizer -> Demapper(app)", "ms_three_launches": round(ms_sep, 4),
                "ms_fused_one_launch": round(ms_fused, 4), "bit_identical": same_bits,
-               "kernel": "ofdm_lsnn_lmmse_kernel<4,2,1,app,2> (h_hat deferred, never written; two resource elements per lane)",
+               "kernel": "ofdm_lsnn_lmmse_kernel<4,2,1,app,1> (h_hat deferred, never written)",
                "algorithmic_GBps_at_120B_per_RE": round(n_data_re * 120 / (ms_fused * 1e-3) / 1e9, 1),
                "frac_of_hbm_peak_at_120B_per_RE": round(n_data_re * 120 / (ms_fused * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3),
                "note": "SURVEY 8(d)'s 120 B/RE assume h_hat (64 B/RE) is read from HBM; the fused kernel reads y (32 B/RE + "

@@ -29,7 +29,7 @@ def lib():
         _lib.oracle_ldpc_bp_decode_simd.restype = C.c_int
         _lib.oracle_ldpc_bp_decode_simd.argtypes = _lib.oracle_ldpc_bp_decode.argtypes
         _lib.oracle_num_threads.restype = C.c_int
-        for fn in (_lib.oracle_phi_f32, _lib.oracle_spec_exp_f32, _lib.oracle_spec_log_f32):
+        for fn in (_lib.oracle_phi_f32, _lib.oracle_spec_exp_f32, _lib.oracle_spec_log_f32, _lib.oracle_phi_exp_f32, _lib.oracle_phi_log_f32):
             fn.restype = None
             fn.argtypes = [C.c_void_p, C.c_void_p, C.c_long]
     return _lib
@@ -53,6 +53,16 @@ def spec_exp_f32(x):
 
 def spec_log_f32(x):
     return _elementwise(lib().oracle_spec_log_f32, x)
+
+
+def phi_exp_f32(x):
+    """exp of the boxplus-phi rule (round 5: magic-number rounding, exponent-field scaling; ldpc_bp.c phi_expf)"""
+    return _elementwise(lib().oracle_phi_exp_f32, x)
+
+
+def phi_log_f32(x):
+    """log of the boxplus-phi rule (round 5: table-driven, ldpc_bp.c phi_logf)"""
+    return _elementwise(lib().oracle_phi_log_f32, x)
 
 
 def bp_decode(dec, llr, num_iter=None, hard_out=None, offset=0.5, nthreads=0, simd=False):

@@ -136,21 +136,88 @@ __device__ __forceinline__ f32x2 phi_spec2_f32(float x0, float x1) {
 }
 __device__ __forceinline__ float phi_spec_f32(float x) { return phi_spec2_f32(x, x).x; }
 
-// phi of a rule: the defined arithmetic for SAMD_CN_BOXPLUS_PHI, the hardware transcendentals for ..._PHI_FAST
-template <int MODE>
-__device__ __forceinline__ f32x2 phi2_f32(float x0, float x1) {
-  if constexpr (MODE == SAMD_CN_BOXPLUS_PHI_FAST) return phi_fast2_f32(x0, x1);
-  else return phi_spec2_f32(x0, x1);
+// ---- round 5: a cheaper DEFINED phi (oracle/ldpc_bp.c: phi_expf / phi_logf, the same operations) ---------------------------
+// The literal form log(e^x + 1) - log(e^x - 1) stays; exp keeps the Cephes reduction and polynomial but rounds with the
+// magic-number addition and scales through the exponent field (14 instead of 17 issue slots per PAIR of values), log is
+// table-driven (Tang): p = mantissa in [1, 2), j = its top six bits, (1 / c_j, -ln(1 / c_j) - ln 2) from a 64-entry table,
+// r = fma(p, 1 / c_j, -1), ln p by three fma, exponent term by one more - 15 instead of 26 slots per pair and one 8-byte
+// table read per value.  The table (csrc/phi_tab.inc = oracle/phi_tab.inc, tools/gen_phi_tables.py) is read through `TAB`:
+// from global / constant memory by default (every engine, no set-up), from LDS where a kernel has staged it (PhiTabLds).
+// spec_exp2_f32 / spec_log2_f32 above remain the definition of the Polar BP decoder's boxplus.
+static __device__ const float2 kPhiTab[64] = {
+#include "phi_tab.inc"
+};
+struct PhiTabGlobal {
+  __device__ __forceinline__ float2 get(unsigned byte_off) const {
+    return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(kPhiTab) + byte_off);
+  }
+};
+typedef __attribute__((address_space(3))) f32x2 bp_lds_f32x2;
+struct PhiTabLds {                    // 512 bytes of LDS at byte offset `base`, filled by phi_tab_stage()
+  unsigned base;
+  __device__ __forceinline__ float2 get(unsigned byte_off) const {
+    const f32x2 v = *(bp_lds_f32x2*)(uintptr_t)(base + byte_off);
+    return make_float2(v.x, v.y);
+  }
+};
+__device__ __forceinline__ void phi_tab_stage(unsigned base, int tid) {          // call with tid = 0..63 (+ a barrier)
+  if (tid < 64) *(bp_lds_f32x2*)(uintptr_t)(base + 8u * (unsigned)tid) = f32x2{kPhiTab[tid].x, kPhiTab[tid].y};
 }
-template <int MODE>
-__device__ __forceinline__ float phi1_f32(float x) {
+__device__ __forceinline__ f32x2 phi_exp2_f32(f32x2 x) {
+  const f32x2 magic = {12582912.0f, 12582912.0f};
+  const f32x2 t = __builtin_elementwise_fma(x, f32x2{1.44269504088896341f, 1.44269504088896341f}, magic);
+  const f32x2 m = t - magic;
+  f32x2 r = __builtin_elementwise_fma(m, f32x2{-0.693359375f, -0.693359375f}, x);
+  r = __builtin_elementwise_fma(m, f32x2{2.12194440e-4f, 2.12194440e-4f}, r);
+  const f32x2 z = r * r;
+  f32x2 y = {1.9875691500E-4f, 1.9875691500E-4f};
+  y = __builtin_elementwise_fma(y, r, f32x2{1.3981999507E-3f, 1.3981999507E-3f});
+  y = __builtin_elementwise_fma(y, r, f32x2{8.3334519073E-3f, 8.3334519073E-3f});
+  y = __builtin_elementwise_fma(y, r, f32x2{4.1665795894E-2f, 4.1665795894E-2f});
+  y = __builtin_elementwise_fma(y, r, f32x2{1.6666665459E-1f, 1.6666665459E-1f});
+  y = __builtin_elementwise_fma(y, r, f32x2{5.0000001201E-1f, 5.0000001201E-1f});
+  y = __builtin_elementwise_fma(y, z, r);
+  y = y + f32x2{1.f, 1.f};
+  return f32x2{__uint_as_float(__float_as_uint(y.x) + (__float_as_uint(t.x) << 23)),
+               __uint_as_float(__float_as_uint(y.y) + (__float_as_uint(t.y) << 23))};
+}
+template <class TAB>
+__device__ __forceinline__ f32x2 phi_log2_f32(f32x2 x, const TAB& tab) {      // normal positive arguments
+  const unsigned b0 = __float_as_uint(x.x), b1 = __float_as_uint(x.y);
+  const f32x2 ef = {(float)__builtin_amdgcn_frexp_expf(x.x), (float)__builtin_amdgcn_frexp_expf(x.y)};   // e + 1
+  const float2 t0 = tab.get((b0 >> 14) & 0x1F8u), t1 = tab.get((b1 >> 14) & 0x1F8u);
+  const f32x2 p = {__uint_as_float((b0 & 0x007FFFFFu) | 0x3F800000u), __uint_as_float((b1 & 0x007FFFFFu) | 0x3F800000u)};
+  const f32x2 r = __builtin_elementwise_fma(p, f32x2{t0.x, t1.x}, f32x2{-1.f, -1.f});
+  f32x2 t = __builtin_elementwise_fma(r, f32x2{0.333333343f, 0.333333343f}, f32x2{-0.5f, -0.5f});
+  t = __builtin_elementwise_fma(t, r, f32x2{1.f, 1.f});
+  t = __builtin_elementwise_fma(t, r, f32x2{t0.y, t1.y});
+  return __builtin_elementwise_fma(ef, f32x2{0.69314718055994530942f, 0.69314718055994530942f}, t);
+}
+template <class TAB>
+__device__ __forceinline__ f32x2 phi_tab2_f32(float x0, float x1, const TAB& tab) {
+  const f32x2 x = {clampf(x0, 8.5e-8f, 16.635532f), clampf(x1, 8.5e-8f, 16.635532f)};
+  const f32x2 e = phi_exp2_f32(x), one = {1.f, 1.f};
+  f32x2 res = phi_log2_f32(e + one, tab) - phi_log2_f32(e - one, tab);
+  res.x = (x.x == 16.635532f) ? 0.f : res.x;
+  res.y = (x.y == 16.635532f) ? 0.f : res.y;
+  return res;
+}
+
+// phi of a rule: the defined arithmetic for SAMD_CN_BOXPLUS_PHI, the hardware transcendentals for ..._PHI_FAST
+template <int MODE, class TAB = PhiTabGlobal>
+__device__ __forceinline__ f32x2 phi2_f32(float x0, float x1, const TAB& tab = TAB()) {
+  if constexpr (MODE == SAMD_CN_BOXPLUS_PHI_FAST) return phi_fast2_f32(x0, x1);
+  else return phi_tab2_f32(x0, x1, tab);
+}
+template <int MODE, class TAB = PhiTabGlobal>
+__device__ __forceinline__ float phi1_f32(float x, const TAB& tab = TAB()) {
   if constexpr (MODE == SAMD_CN_BOXPLUS_PHI_FAST) return phi_fast_f32(x);
-  else return phi_spec_f32(x);
+  else return phi_tab2_f32(x, x, tab).x;
 }
 
 // ---- check-node update on one batch column; v[0..d) in CN edge order, in place.
-template <int MODE, int MAXD>
-__device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr_max, float offset) {
+template <int MODE, int MAXD, class TAB = PhiTabGlobal>
+__device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr_max, float offset, const TAB& tab = TAB()) {
   if constexpr (MODE == SAMD_CN_MINSUM || MODE == SAMD_CN_OFFSET_MINSUM) {
     float sgn[MAXD];
     float node_sign = 1.f, min1 = INFINITY;
@@ -195,25 +262,25 @@ __device__ __forceinline__ void cn_update_col(float (&v)[MAXD], int d, float llr
         sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
         sg[i + 1] = (v[i + 1] < 0.f) ? 0x80000000u : 0u;
         node ^= sg[i] ^ sg[i + 1];
-        const f32x2 p = phi2_f32<MODE>(fabsf(v[i]), fabsf(v[i + 1]));
+        const f32x2 p = phi2_f32<MODE>(fabsf(v[i]), fabsf(v[i + 1]), tab);
         v[i] = p.x; v[i + 1] = p.y;
         sum += p.x;
         sum += p.y;
       } else if (i < d) {
         sg[i] = (v[i] < 0.f) ? 0x80000000u : 0u;
         node ^= sg[i];
-        v[i] = phi1_f32<MODE>(fabsf(v[i]));
+        v[i] = phi1_f32<MODE>(fabsf(v[i]), tab);
         sum += v[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < MAXD; i += 2) {
       if (i + 1 < MAXD && i + 1 < d) {
-        const f32x2 q = phi2_f32<MODE>(-1.f * v[i] + sum, -1.f * v[i + 1] + sum);
+        const f32x2 q = phi2_f32<MODE>(-1.f * v[i] + sum, -1.f * v[i + 1] + sum, tab);
         v[i] = __uint_as_float(__float_as_uint(fminf(q.x, llr_max)) ^ (sg[i] ^ node));
         v[i + 1] = __uint_as_float(__float_as_uint(fminf(q.y, llr_max)) ^ (sg[i + 1] ^ node));
       } else if (i < d) {
-        const float q = phi1_f32<MODE>(-1.f * v[i] + sum);
+        const float q = phi1_f32<MODE>(-1.f * v[i] + sum, tab);
         v[i] = __uint_as_float(__float_as_uint(fminf(q, llr_max)) ^ (sg[i] ^ node));
       }
     }

@@ -484,11 +484,11 @@ __device__ __forceinline__ bool load_re(const OfdmEqArgs& p, int brx_i, int re, 
 // only its M diagonal entries are formed (load as in load_re).
 // (occupancy bound: without it the scheduler hoists every load and spends 162 registers on <4, 2> - 3 waves per SIMD
 // for a kernel that streams 128 B per resource element; with it 68 registers and no spill)
-// R (round 5): resource elements per lane - the SAME (t, f) of R consecutive (batch, receiver) pairs, so that a wave of
-// pilot-only resource elements still leaves as a whole.  One element per lane is a serial chain (loads -> 2 x 2 Cholesky ->
-// two triangular solves -> divisions) with nothing to issue while a load or a division is in flight (round-4 profile: 70 %
-// of the wave cycles parked, 0.49 of HBM peak); two independent chains in one basic block give the scheduler instruction-
-// level parallelism and twice the loads in flight per wave.  The arithmetic per element is unchanged (same bits).
+// R (round 5 experiment): resource elements per lane - the SAME (t, f) of R consecutive (batch, receiver) pairs, so that a
+// wave of pilot-only resource elements still leaves as a whole.  One element per lane is a serial chain (loads -> 2 x 2
+// Cholesky -> two triangular solves -> divisions); two independent chains in one basic block give the scheduler
+// instruction-level parallelism and twice the loads in flight per wave - at 104-118 registers instead of 68-78.  Same bits;
+// measured 17 % SLOWER (fewer resident waves), so R = 1 is what the launchers use unless SAMD_LMMSE_R2 is set.
 template <int M, int K, int R>
 __global__ __launch_bounds__(128, (M * K <= 8) ? (R == 1 ? 6 : 3) : 1) void ofdm_lmmse_diag_kernel(OfdmEqArgs p) {
   const int re_i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1328,10 +1328,14 @@ extern "C" int samd_ofdm_lmmse_c64(const float* y, const float* h_hat, const flo
   const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 127) / 128, brx_total = batch * num_rx;
   static samd::CachedOpt lmmse_general_opt("SAMD_LMMSE_GENERAL");   // development: force the general-covariance kernel
   const bool diag = num_undesired == 0 && whiten == 1 && !lmmse_general_opt.is_set();   // diagonal covariance
-  static samd::CachedOpt lmmse_r1_opt("SAMD_LMMSE_R1");             // development: one resource element per lane (rounds 1-4)
+  // two resource elements per lane (the round-4 verdict's proposal for instruction-level parallelism): measured SLOWER on
+  // MI355X - 216 us instead of 185 us per 6.29 M resource elements for <4, 2>, fused front end 360 instead of 336 us per call
+  // (profiles/r05e_c4_ab.txt): 104-118 registers = 4 waves per SIMD instead of 6, and the kernel lives on resident waves.
+  // Kept behind SAMD_LMMSE_R2 (development); one element per lane stays the product path.
+  static samd::CachedOpt lmmse_r2_opt("SAMD_LMMSE_R2");
 #define X(M, K)                                                                                            \
   if (num_rx_ant == M && streams_per_rx == K) {                                                            \
-    if (diag && M * K <= 8 && brx_total >= 2 && !lmmse_r1_opt.is_set())                                   \
+    if (diag && M * K <= 8 && brx_total >= 2 && lmmse_r2_opt.is_set())                                   \
       for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 2 * 65535)                                            \
         hipLaunchKernelGGL((ofdm_lmmse_diag_kernel<M, K, 2>), dim3(tf_blocks, std::min((brx_total - p.brx0 + 1) / 2, 65535)), \
                            dim3(128), 0, (hipStream_t)stream, p);                                          \
@@ -1366,8 +1370,8 @@ extern "C" int samd_ofdm_lsnn_lmmse_c64(const float* y, const float* y_ls, const
   if ((int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers == 0) return SAMD_OK;
   const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 127) / 128, brx_total = batch * num_rx;
   const int nb = num_bits_per_symbol / 2;
-  static samd::CachedOpt lsnn_r1_opt("SAMD_LMMSE_R1");              // development: one resource element per lane (round 4)
-  const bool two = brx_total >= 2 && !lsnn_r1_opt.is_set();
+  static samd::CachedOpt lsnn_r2_opt("SAMD_LMMSE_R2");              // development: two resource elements per lane (measured slower, see samd_ofdm_lmmse_c64)
+  const bool two = brx_total >= 2 && lsnn_r2_opt.is_set();
 #define LAUNCH(M, K, NB, ML)                                                                                         \
   if (two && M * K <= 8)                                                                                             \
     for (a.e.brx0 = 0; a.e.brx0 < brx_total; a.e.brx0 += 2 * 65535)                                                  \

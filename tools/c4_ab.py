@@ -1,6 +1,6 @@
 """A/B of the round-5 C4 kernels against their round-4 forms in ONE process (development options read at launch):
 cir_to_ofdm with results staged in registers vs the two-pass kernel (SAMD_C2O_TWO_PASS), the per-RE LMMSE equaliser and the
-fused LS-NN + LMMSE (+ demapper) front end with two resource elements per lane vs one (SAMD_LMMSE_R1).  LMMSE outputs must be
+fused LS-NN + LMMSE (+ demapper) front end with two resource elements per lane vs one (the experiment is behind SAMD_LMMSE_R2: it was slower).  LMMSE outputs must be
 bit-identical; the channel transform is compared at 1e-5 of its scale (different grouping of the normalisation sum)."""
 import json
 import os
@@ -58,16 +58,19 @@ def main():
 
     rows = []
     for name, fn, opt, exact in (("cir_to_ofdm", lambda: phy.channel.cir_to_ofdm_channel(freqs, a_t, tau_t, normalize=True), "SAMD_C2O_TWO_PASS", False),
-                                 ("lmmse_equalizer", lambda: eq(y, h_hat, ev, no)[0], "SAMD_LMMSE_R1", True),
-                                 ("fused_front_end", fused, "SAMD_LMMSE_R1", True)):
-        new = T(fn()).clone()
-        ms_new = timed(fn)
-        _ffi.set_option(opt, "1")
-        try:
-            old = T(fn()).clone()
-            ms_old = timed(fn)
-        finally:
-            _ffi.set_option(opt, None)
+                                 ("lmmse_equalizer", lambda: eq(y, h_hat, ev, no)[0], "!SAMD_LMMSE_R2", True),
+                                 ("fused_front_end", fused, "!SAMD_LMMSE_R2", True)):
+        # opt names the switch that selects the round-4 form; "!opt": the switch selects the round-5 experiment instead
+        def run_with(flag):
+            if flag:
+                _ffi.set_option(opt.lstrip("!"), "1")
+            try:
+                return T(fn()).clone(), timed(fn)
+            finally:
+                if flag:
+                    _ffi.set_option(opt.lstrip("!"), None)
+        new, ms_new = run_with(opt.startswith("!"))
+        old, ms_old = run_with(not opt.startswith("!"))
         if exact:
             same = bool(torch.equal(new, old))
         else:
