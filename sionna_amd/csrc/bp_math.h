@@ -160,6 +160,7 @@ struct PhiTabLds {                    // 512 bytes of LDS at byte offset `base`,
     return make_float2(v.x, v.y);
   }
 };
+constexpr unsigned kPhiNoLds = 0xFFFFFFFFu;
 __device__ __forceinline__ void phi_tab_stage(unsigned base, int tid) {          // call with tid = 0..63 (+ a barrier)
   if (tid < 64) *(bp_lds_f32x2*)(uintptr_t)(base + 8u * (unsigned)tid) = f32x2{kPhiTab[tid].x, kPhiTab[tid].y};
 }

@@ -114,6 +114,33 @@ def test_phi_spec_exp_log_accuracy_and_endpoints():
     assert np.allclose(cbind.phi_f32(xs), -np.log(np.tanh(xs.astype(np.float64) / 2)), rtol=2e-5, atol=1e-6)
 
 
+def test_phi_round5_exp_log_accuracy():
+    """The cheaper defined exp / log that phi evaluates since round 5 (oracle/ldpc_bp.c phi_expf / phi_logf = csrc/bp_math.h
+    phi_exp2_f32 / phi_log2_f32): exp within 1.1 ulp like the Cephes form (same reduction and polynomial); the table-driven
+    log within 1.2e-7 ABSOLUTE + 0.6 ulp (its error does not shrink with the result near ln 1 = 0 - phi only ever takes
+    differences of logarithms whose larger one is >= ln 2); and phi itself agrees with the Cephes-based phi of rounds 3-4
+    to 2e-6 relative over the clipped domain."""
+    rng = np.random.default_rng(1)
+    x = np.concatenate([np.exp(rng.uniform(np.log(8.5e-8), np.log(16.635532), 400000)), np.linspace(8.5e-8, 16.635532, 100001)]).astype(np.float32)
+    ulp = lambda v: np.spacing(np.abs(v).astype(np.float32)).astype(np.float64)
+    e = cbind.phi_exp_f32(x)
+    t = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(e - t) / ulp(t)) < 1.1
+    for a in (e + np.float32(1), e - np.float32(1)):
+        a = a[a > 0]
+        l, tl = cbind.phi_log_f32(a), np.log(a.astype(np.float64))
+        assert np.max(np.abs(l - tl) - 0.6 * ulp(tl)) < 1.2e-7
+    # against the literal form on float64: where phi is well conditioned
+    xs = np.linspace(0.05, 6, 4000).astype(np.float32)
+    assert np.allclose(cbind.phi_f32(xs), -np.log(np.tanh(xs.astype(np.float64) / 2)), rtol=2e-5, atol=1e-6)
+    # against the Cephes-based definition of rounds 3-4 (spec_exp / spec_log, still the Polar BP decoder's arithmetic)
+    xc = np.clip(x, np.float32(8.5e-8), np.float32(16.0))
+    ec = cbind.spec_exp_f32(xc)
+    old = cbind.spec_log_f32(ec + np.float32(1)) - cbind.spec_log_f32(ec - np.float32(1))
+    new = cbind.phi_f32(xc)
+    assert np.mean(new == old) > 0.85 and np.mean(np.abs(new - old) <= 1e-5 * np.abs(old) + 1e-7) > 0.99
+
+
 @pytest.mark.parametrize("k,n,m,bg,batch,iters,ebno", [(1024, 2048, 2, "bg1", 19, 10, 1.5), (2816, 8448, 6, "bg1", 9, 20, 4.5)])
 def test_simd_c_baseline_equals_scalar_c_oracle(k, n, m, bg, batch, iters, ebno):
     """bench.py's CPU baseline (8 codewords per vector, oracle_ldpc_bp_decode_simd) returns the scalar C oracle's soft
