@@ -20,6 +20,16 @@
 #define JIT_ABL 0
 #endif
 // JIT_OFFSET0 = 1: the kernel is generated for plain min-sum (offset 0 exactly); 0: offset-min-sum with a run-time offset
+// JIT_LAYOUT_B (Z = 128 only): the two 64-lane chunks of an edge block INTERLEAVED - lifted copy z of a check node at byte
+// 8 (z mod 64) + 4 (z div 64) of its 512-byte block - so that a pair item moves both of a lane's values with ONE 8-byte DS
+// instruction in each phase (ds_read_b64: 2 LDS-pipeline cycles per 512 bytes instead of 4; ds_write_b64: 6 instead of 8
+// for two ds_write_b32).  A variable-node lane reads the pair of slot (lane - shift) mod 64; its own two nodes (lane, lane + 64)
+// are that pair in this order or swapped - for the lanes below the shift - which costs two selections in and two out per
+// edge.  JIT_CH = byte distance between a lane's two chunk values (256 chunk-planar, 4 interleaved).
+#ifndef JIT_LAYOUT_B
+#define JIT_LAYOUT_B 0
+#endif
+#define JIT_CH (JIT_LAYOUT_B ? 4u : 256u)
 
 // value written to the output tensor for a VN total x (decoding.py:620-626): clip, then hard decision or the logit
 JIT_DEV F32 jit_outval(F32 x, float llr_max, int hard_out) {
@@ -43,14 +53,32 @@ JIT_DEV U32 jit_vn_addr(U32 l4, unsigned k, unsigned base) {
 // offset field become one address addition per slot, and the two-slot forms ds_read2st64 / ds_write2st64 are lost.)
 JIT_DEV U32 jit_base(U32 l4, unsigned k) { return u_here(u_here(l4) + k); }
 
+// interleaved layout, single-chunk variable-node item: byte position of check copy zc, given zc4 = 4 zc = (l4 + k) mod 512
+JIT_DEV U32 jit_vn_addr_b1(U32 l4, unsigned k, unsigned base) {
+  const U32 zc4 = (l4 + k) & 511u;
+  return u_shl(zc4 & 255u, 1) + u_shl(u_shr(zc4, 8), 2) + base;
+}
+
 // ---------------------------------------------------------------------------------------------- check node row
 // a0 = byte address of the lane's slot in the row's first block (chunk 0 of the item); NCH chunks of 64 lifted copies
 template <int D, int NCH>
 JIT_DEV void jit_cn_load(F32 (&v)[D][NCH], U32 a0) {
 #pragma unroll
-  for (int i = 0; i < D; ++i)
+  for (int i = 0; i < D; ++i) {
+    if (JIT_LAYOUT_B && NCH == 2) lds_ld2(a0, (unsigned)i * JIT_Z4, v[i][0], v[i][NCH - 1]);
+    else {
 #pragma unroll
-    for (int h = 0; h < NCH; ++h) v[i][h] = lds_ld(a0, (unsigned)i * JIT_Z4 + 256u * h);
+      for (int h = 0; h < NCH; ++h) v[i][h] = lds_ld(a0, (unsigned)i * JIT_Z4 + JIT_CH * h);
+    }
+  }
+}
+template <int NCH>
+JIT_DEV void jit_cn_store(U32 a0, unsigned off, const F32 (&c)[NCH]) {
+  if (JIT_LAYOUT_B && NCH == 2) lds_st2(a0, off, c[0], c[NCH - 1]);
+  else {
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) lds_st(a0, off + JIT_CH * h, c[h]);
+  }
 }
 
 // FUSE: the row's last edge goes to a degree-1 VN of the same lane; its update happens here (lf = its channel LLR).
@@ -60,9 +88,7 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
                            float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
   if (JIT_ABL & 1) {
 #pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-      for (int h = 0; h < NCH; ++h) lds_st(a0, (unsigned)i * JIT_Z4 + 256u * h, v[i][h]);
+    for (int i = 0; i < D; ++i) jit_cn_store<NCH>(a0, (unsigned)i * JIT_Z4, v[i]);
     return;
   }
   F32 m1[NCH], m2[NCH];
@@ -117,16 +143,14 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
         c2v[h] = f_med3(x - c2v[h], -llr_max, llr_max);   // the slot now holds the next v2c
       }
     }
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) lds_st(a0, (unsigned)i * JIT_Z4 + 256u * h, c2v[h]);
+    jit_cn_store<NCH>(a0, (unsigned)i * JIT_Z4, c2v);
   }
 }
 
 // v2c of iteration 0 for the fused degree-1 column of a row: its channel LLR
 template <int D, int NCH>
 JIT_DEV void jit_cn_init_fused(U32 a0, const F32 (&lf)[NCH]) {
-#pragma unroll
-  for (int h = 0; h < NCH; ++h) lds_st(a0, (unsigned)(D - 1) * JIT_Z4 + 256u * h, lf[h]);
+  jit_cn_store<NCH>(a0, (unsigned)(D - 1) * JIT_Z4, lf);
 }
 
 // ---------------------------------------------------------------------------------------------- variable node column
@@ -147,6 +171,49 @@ JIT_DEV void jit_vn_init(const U32 (&a)[D][NCH], const F32 (&l)[NCH]) {
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int h = 0; h < NCH; ++h) lds_st(a[i][h], 0u, l[h]);
+}
+
+// ---- interleaved layout, pair items: a[i] = byte address of slot (lane - shift_i) mod 64 in the block of edge i, sw[i] = the
+// lanes whose node `lane` (chunk 0) sits in the HIGH half of that slot (then node lane + 64 sits in the low half)
+template <int D>
+JIT_DEV void jit_vnb_load(F32 (&c)[D][2], const U32 (&a)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) lds_ld2(a[i], 0u, c[i][0], c[i][1]);
+}
+template <int D>
+JIT_DEV void jit_vnb_init(const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) lds_st2(a[i], 0u, f_sel(sw[i], l[1], l[0]), f_sel(sw[i], l[0], l[1]));
+}
+template <int D>
+JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2], float llr_max, bool last,
+                            float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
+  if (JIT_ABL & 2) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) lds_st2(a[i], 0u, c[i][0], c[i][1]);
+    return;
+  }
+  F32 x0 = 0.f, x1 = 0.f;
+  F32 v0[D], v1[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {                          // slot order -> node order
+    v0[i] = f_sel(sw[i], c[i][1], c[i][0]);
+    v1[i] = f_sel(sw[i], c[i][0], c[i][1]);
+    f_pk_add(x0, x1, v0[i], v1[i]);
+  }
+  f_pk_add(x0, x1, l[0], l[1]);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    F32 e0, e1;
+    f_pk_sub(e0, e1, x0, x1, v0[i], v1[i]);
+    e0 = f_med3(e0, -llr_max, llr_max);
+    e1 = f_med3(e1, -llr_max, llr_max);
+    lds_st2(a[i], 0u, f_sel(sw[i], e1, e0), f_sel(sw[i], e0, e1));     // node order -> slot order
+  }
+  if (last) {
+    if (oc0 != JIT_NOOUT) g_st(orow, u_here(ovoff), oc0, jit_outval(x0, llr_max, hard_out));
+    if (oc1 != JIT_NOOUT) g_st(orow, u_here(ovoff), oc1, jit_outval(x1, llr_max, hard_out));
+  }
 }
 
 template <int D, int NCH>

@@ -34,6 +34,7 @@ struct JitState;
 struct JitKnobs {
   int pipe = 1;        // items whose loads are in flight (1: load - update - store per item)
   int xor128 = 0;      // Z = 128: second chunk's block position recomputed in the loop (v_xor) instead of a register
+  int layout = 0;      // 1 (Z = 128): the two chunks of an edge block interleaved (8-byte DS instructions in both phases)
   int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
   int prio = 1;        // s_setprio per item
   int vnrev = 1;       // VN lists assigned to the waves in reverse order

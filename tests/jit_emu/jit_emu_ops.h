@@ -66,6 +66,43 @@ JIT_DEV void lds_st(const U32& a, unsigned off, const F32& x) {
     memcpy(jit_emu_ctx.lds + p, &x.v[i], 4);
   }
 }
+JIT_DEV void lds_ld2(const U32& a, unsigned off, F32& x0, F32& x1) {
+  for (int i = 0; i < 64; ++i) {
+    const size_t p = (size_t)a.v[i] + off;
+    if (p + 8 > jit_emu_ctx.lds_bytes || (p & 7)) __builtin_trap();
+    memcpy(&x0.v[i], jit_emu_ctx.lds + p, 4);
+    memcpy(&x1.v[i], jit_emu_ctx.lds + p + 4, 4);
+  }
+}
+JIT_DEV void lds_st2(const U32& a, unsigned off, const F32& x0, const F32& x1) {
+  for (int i = 0; i < 64; ++i) {
+    const size_t p = (size_t)a.v[i] + off;
+    if (p + 8 > jit_emu_ctx.lds_bytes || (p & 7)) __builtin_trap();
+    memcpy(jit_emu_ctx.lds + p, &x0.v[i], 4);
+    memcpy(jit_emu_ctx.lds + p + 4, &x1.v[i], 4);
+  }
+}
+struct M64 { bool v[64]; };
+JIT_DEV M64 u_testbit(const U32& x, unsigned mask) {
+  M64 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = (x.v[i] & mask) != 0u;
+  return r;
+}
+JIT_DEV F32 f_sel(const M64& m, const F32& a, const F32& b) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i];
+  return r;
+}
+JIT_DEV U32 u_shl(const U32& a, int n) {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] << n;
+  return r;
+}
+JIT_DEV U32 u_shr(const U32& a, int n) {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] >> n;
+  return r;
+}
 JIT_DEV F32 g_ld(const float* row, const U32& voff, unsigned coff) {
   F32 r;
   for (int i = 0; i < 64; ++i) memcpy(&r.v[i], (const char*)row + (voff.v[i] + coff), 4);

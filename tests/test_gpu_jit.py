@@ -80,6 +80,31 @@ def test_specialised_kernel_bit_exact_vs_oracle(phy, k, n, bg, m, grid):
         assert np.array_equal(_np(dec(llr)), (0 >= -ref).astype(np.float32))
 
 
+@pytest.mark.parametrize("opts", [{"SAMD_JIT_LAYOUT": "1"}, {"SAMD_JIT_LAYOUT": "1", "SAMD_JIT_PIPE": "2", "SAMD_JIT_PREFETCH": "0"},
+                                  {"SAMD_JIT_SCHED": "1", "SAMD_JIT_PIPE": "2", "SAMD_JIT_XOR128": "1"}])
+def test_generator_variants_bit_exact(phy, opts):
+    """the generator's other forms of the C2 kernel (interleaved message layout with 8-byte DS instructions, own schedule,
+    pipelined loads, xor positions): the same soft outputs as the oracle"""
+    import contextlib
+    k, n, m, bg = 2816, 8448, 6, "bg1"
+    code = LDPC5GCode(k, n, m, bg)
+    llr = _noisy_llr(code, 9, 99)
+    llr[0, :9] = 0
+    llr[1] = np.round(llr[1])
+    with contextlib.ExitStack() as st:
+        st.enter_context(_opt("SAMD_LDPC_JIT", "2"))
+        st.enter_context(_opt("SAMD_ONCHIP_GRID", "2"))
+        for kk, vv in opts.items():
+            st.enter_context(_opt(kk, vv))
+        enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+        for cn, it, infobits in (("minsum", 7, True), ("offset-minsum", 4, False)):
+            dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=it)
+            before = _launches(enc, dec)
+            got = _np(dec(llr))
+            assert _launches(enc, dec) == before + 1
+            assert np.array_equal(got, _reference(code, llr, cn, it, infobits, m)), (cn, opts)
+
+
 def test_c2_at_scale_specialised_equals_generic_and_oracle(phy):
     """BASELINE config C2 in the waterfall, 4096 codewords, 20 iterations: the default policy picks the specialised kernel
     (batch >= 1024); its soft outputs equal the generic kernel's (SAMD_LDPC_JIT=0) and the oracle's on a sample"""

@@ -63,12 +63,31 @@ def _reference(code, llr, cn, it, infobits, m, hard, offset=0.5):
 CODES = [(2816, 8448, "bg1", 6), (2816, 8448, "bg1", None), (2816, 5632, "bg1", 2), (5632, 8448, "bg1", None)]
 
 
+# generator options exercised besides the defaults: the interleaved message layout (8-byte DS instructions, Z = 128), an own
+# LPT schedule with pipelined loads and the second chunk's positions by xor
+VARIANTS = [{}, {"SAMD_JIT_LAYOUT": "1"}, {"SAMD_JIT_SCHED": "1", "SAMD_JIT_PIPE": "2", "SAMD_JIT_XOR128": "1", "SAMD_JIT_PREFETCH": "0"}]
+
+
 @pytest.mark.parametrize("k,n,bg,m", CODES)
-def test_generated_programs_match_oracle(tmp_path, k, n, bg, m):
+@pytest.mark.parametrize("variant", range(len(VARIANTS)))
+def test_generated_programs_match_oracle(tmp_path, k, n, bg, m, variant):
     from sionna_amd import _ffi
+    if variant and (k, n) != (2816, 8448):
+        pytest.skip("generator variants are exercised on the C2 code")
     code = LDPC5GCode(k, n, m, bg)
     h = jit_dump.host_only_handle(k, n, m, bg)
     assert _ffi.lib().samd_ldpc5g_jit_supported(h) == 1
+    for kk, vv in VARIANTS[variant].items():
+        _ffi.set_option(kk, vv)
+    try:
+        _run_generated(tmp_path, code, h, k, n, m)
+    finally:
+        for kk in VARIANTS[variant]:
+            _ffi.set_option(kk, None)
+    _ffi.lib().samd_ldpc5g_destroy(h)
+
+
+def _run_generated(tmp_path, code, h, k, n, m):
     batch, grid = 5, 2                                           # workgroup 0 decodes 3 codewords in sequence, workgroup 1 two
     llr = _noisy_llr(code, batch, k + n)
     llr[0, :7] = 0
@@ -87,7 +106,6 @@ def test_generated_programs_match_oracle(tmp_path, k, n, bg, m):
             ref = _reference(code, llr, cn, it, bool(infobits), m, hard)
             assert np.array_equal(out, ref), f"{cn} it={it} infobits={infobits} hard={hard}: " \
                                              f"{np.mean(out != ref):.3e} differ, nan {np.isnan(out).sum()}"
-    _ffi.lib().samd_ldpc5g_destroy(h)
 
 
 def test_jit_class_boundaries():

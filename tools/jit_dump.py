@@ -87,7 +87,7 @@ def isa_stats(asm):
 # cycles, stores = the VGPR -> LDS transfer at 2 cycles per source dword incl. the address register)
 LDS_CYCLES = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read2_b32": 4, "ds_read2st64_b32": 4, "ds_read_b128": 4, "ds_read2_b64": 8,
               "ds_write_b32": 4, "ds_write_b64": 6, "ds_write2_b32": 6, "ds_write2st64_b32": 6, "ds_write_b128": 13,
-              "ds_write2_b64": 13, "ds_write_addtid_b32": 2, "ds_read_addtid_b32": 2}
+              "ds_write2_b64": 13, "ds_write_addtid_b32": 2, "ds_read_addtid_b32": 2, "ds_read2st64_b64": 8, "ds_write2st64_b64": 13}
 
 
 def per_iteration_stats(asm):
