@@ -34,16 +34,16 @@ struct JitState;
 struct JitKnobs {
   int pipe = 1;        // items whose loads are in flight (1: load - update - store per item)
   int xor128 = 0;      // Z = 128: second chunk's block position recomputed in the loop (v_xor) instead of a register
-  int layout = 0;      // 1 (Z = 128): the two chunks of an edge block interleaved (8-byte DS instructions in both phases)
+  int layout = 1;      // 1 (Z = 128 only): the two chunks of an edge block interleaved (8-byte DS instructions in both phases)
   int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
   int prio = 1;        // s_setprio per item
   int vnrev = 1;       // VN lists assigned to the waves in reverse order
-  int sched = 0;       // 0: the generic kernel's lists (tuned on hardware over rounds 2-3: cut items, SIMD-aware order);
+  int sched = -1;      // -1: by layout (interleaved 1, planar 0).  0: the generic kernel's lists (tuned on hardware over rounds 2-3: cut items, SIMD-aware order);
                        // 1: an own longest-processing-time assignment by instruction counts - measured 4-7 % slower
                        // for every cost model tried (profiles/r05c_jit_sched_sweep.txt): an item's cost is its latency
                        // chain, not its instruction count
   int rotate = 1;      // a wave's item order rotated by its index on its SIMD
-  int cn_slope = 10, cn_ovh = 29, cn_fused = 6, vn_slope = 8, vn_ovh = 10, vn_pair_max = 12;   // cost model (instructions)
+  int cn_slope = 10, cn_ovh = -1, cn_fused = 6, vn_slope = 8, vn_ovh = 10, vn_pair_max = -1;   // cost model (-1: by layout)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
 };

@@ -7,8 +7,8 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.txt 2>&1; tail -4 $OUT/pytest_gpu.txt
-timeout 300 python tools/jit_ab.py --out $OUT/jit_ab.json generic:SAMD_LDPC_JIT=0 jit_default: pipe1:SAMD_JIT_PIPE=1 noprefetch:SAMD_JIT_PREFETCH=0 \
-   sched1:SAMD_JIT_SCHED=1 > $OUT/jit_ab.txt 2>&1; cat $OUT/jit_ab.txt
+timeout 300 python tools/jit_ab.py --out $OUT/jit_ab.json generic:SAMD_LDPC_JIT=0 jit_default: planar_layout:SAMD_JIT_LAYOUT=0 noprefetch:SAMD_JIT_PREFETCH=0 \
+   cn_ovh80:SAMD_JIT_CN_OVH=80 pair12:SAMD_JIT_VN_PAIR_MAX=12 > $OUT/jit_ab.txt 2>&1; cat $OUT/jit_ab.txt
 timeout 300 python tools/jit_ab.py --cn offset-minsum --out $OUT/jit_ab_offset.json generic:SAMD_LDPC_JIT=0 jit_default: > $OUT/jit_ab_offset.txt 2>&1; cat $OUT/jit_ab_offset.txt
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py > $OUT/bench_traced.json 2> $OUT/trace.log
