@@ -66,6 +66,24 @@ JIT_DEV void f_pk_sub(F32& e0, F32& e1, F32 x0, F32 x1, F32 c0, F32 c1) {
   const jit_f32x2 e = jit_f32x2{x0, x1} - jit_f32x2{c0, c1};
   e0 = e.x; e1 = e.y;
 }
+// packed fused multiply-adds (v_pk_fma_f32): (d0, d1) = (a0, a1) * (b0, b1) + (c0, c1); scalar operands are broadcast
+JIT_DEV void f_pk_fma(F32& d0, F32& d1, F32 a0, F32 a1, F32 b0, F32 b1, F32 c0, F32 c1) {
+  const jit_f32x2 d = __builtin_elementwise_fma(jit_f32x2{a0, a1}, jit_f32x2{b0, b1}, jit_f32x2{c0, c1});
+  d0 = d.x; d1 = d.y;
+}
+JIT_DEV void f_pk_fma(F32& d0, F32& d1, F32 a0, F32 a1, float b, F32 c0, F32 c1) { f_pk_fma(d0, d1, a0, a1, b, b, c0, c1); }
+JIT_DEV void f_pk_mul(F32& d0, F32& d1, F32 a0, F32 a1, F32 b0, F32 b1) {
+  const jit_f32x2 d = jit_f32x2{a0, a1} * jit_f32x2{b0, b1};
+  d0 = d.x; d1 = d.y;
+}
+JIT_DEV void f_pk_addc(F32& d0, F32& d1, F32 a0, F32 a1, float c) {
+  const jit_f32x2 d = jit_f32x2{a0, a1} + jit_f32x2{c, c};
+  d0 = d.x; d1 = d.y;
+}
+JIT_DEV F32 f_frexp_exp(F32 x) { return (float)__builtin_amdgcn_frexp_expf(x); }      // exponent e + 1 of a normal x, as a float
+JIT_DEV F32 f_min(F32 a, float b) { return __builtin_fminf(a, b); }
+JIT_DEV U32 u_and_or(U32 a, unsigned m, unsigned o) { return (a & m) | o; }
+JIT_DEV U32 u_msb_if_neg(F32 v) { return (v < 0.f) ? 0x80000000u : 0u; }
 // a phase exchanges LDS data only: wait for this wave's LDS operations, then the workgroup barrier
 JIT_DEV void jit_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int P>

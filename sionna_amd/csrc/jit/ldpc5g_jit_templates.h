@@ -147,6 +147,100 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
   }
 }
 
+// ---------------------------------------------------------------------------------------------- boxplus-phi check node row
+// JIT_RULE_PHI = 1: the kernel is generated for cn_update_phi (decoding.py:1045-1166) on the DEFINED exp / log of round 5
+// (csrc/bp_math.h phi_exp2_f32 / phi_log2_f32 = oracle/ldpc_bp.c phi_expf / phi_logf, operation for operation).  Packed
+// operations pair the two CHUNKS of an edge (the generic engines pair two edges of one chunk - the arithmetic per value is
+// the same, so are the bits).  The 64-entry table of the logarithm sits in LDS at JIT_PHI_TAB (8 bytes per entry).
+#ifndef JIT_RULE_PHI
+#define JIT_RULE_PHI 0
+#endif
+#if JIT_RULE_PHI
+JIT_DEV void jit_phi_exp2(F32& e0, F32& e1, F32 x0, F32 x1) {
+  F32 t0, t1, m0, m1, r0, r1, z0, z1, y0, y1;
+  f_pk_fma(t0, t1, x0, x1, 1.44269504088896341f, 12582912.0f, 12582912.0f);
+  f_pk_addc(m0, m1, t0, t1, -12582912.0f);
+  f_pk_fma(r0, r1, m0, m1, -0.693359375f, x0, x1);
+  f_pk_fma(r0, r1, m0, m1, 2.12194440e-4f, r0, r1);
+  f_pk_mul(z0, z1, r0, r1, r0, r1);
+  y0 = 1.9875691500E-4f; y1 = 1.9875691500E-4f;
+  f_pk_fma(y0, y1, y0, y1, r0, r1, 1.3981999507E-3f, 1.3981999507E-3f);
+  f_pk_fma(y0, y1, y0, y1, r0, r1, 8.3334519073E-3f, 8.3334519073E-3f);
+  f_pk_fma(y0, y1, y0, y1, r0, r1, 4.1665795894E-2f, 4.1665795894E-2f);
+  f_pk_fma(y0, y1, y0, y1, r0, r1, 1.6666665459E-1f, 1.6666665459E-1f);
+  f_pk_fma(y0, y1, y0, y1, r0, r1, 5.0000001201E-1f, 5.0000001201E-1f);
+  f_pk_fma(y0, y1, y0, y1, z0, z1, r0, r1);
+  f_pk_addc(y0, y1, y0, y1, 1.0f);
+  e0 = u_float(f_bits(y0) + u_shl(f_bits(t0), 23));          // 2^m through the exponent field, m = low bits of t
+  e1 = u_float(f_bits(y1) + u_shl(f_bits(t1), 23));
+}
+JIT_DEV void jit_phi_log2(F32& l0, F32& l1, F32 x0, F32 x1) {      // normal positive arguments
+  const U32 b0 = f_bits(x0), b1 = f_bits(x1);
+  const F32 ef0 = f_frexp_exp(x0), ef1 = f_frexp_exp(x1);          // e + 1 as a float
+  F32 i0, c0, i1, c1, r0, r1, t0, t1;
+  lds_ld2(u_and_or(u_shr(b0, 14), 0x1F8u, JIT_PHI_TAB), 0u, i0, c0);
+  lds_ld2(u_and_or(u_shr(b1, 14), 0x1F8u, JIT_PHI_TAB), 0u, i1, c1);
+  const F32 p0 = u_float(u_and_or(b0, 0x007FFFFFu, 0x3F800000u)), p1 = u_float(u_and_or(b1, 0x007FFFFFu, 0x3F800000u));
+  f_pk_fma(r0, r1, p0, p1, i0, i1, -1.0f, -1.0f);
+  f_pk_fma(t0, t1, r0, r1, 0.333333343f, -0.5f, -0.5f);
+  f_pk_fma(t0, t1, t0, t1, r0, r1, 1.0f, 1.0f);
+  f_pk_fma(t0, t1, t0, t1, r0, r1, c0, c1);
+  f_pk_fma(l0, l1, ef0, ef1, 0.69314718055994530942f, t0, t1);
+}
+JIT_DEV void jit_phi2(F32& y0, F32& y1, F32 x0, F32 x1) {
+  F32 e0, e1, a0, a1, b0, b1, p0, p1, q0, q1;
+  x0 = f_clamp(x0, 8.5e-8f, 16.635532f);
+  x1 = f_clamp(x1, 8.5e-8f, 16.635532f);
+  jit_phi_exp2(e0, e1, x0, x1);
+  f_pk_addc(a0, a1, e0, e1, 1.0f);
+  f_pk_addc(b0, b1, e0, e1, -1.0f);
+  jit_phi_log2(p0, p1, a0, a1);
+  jit_phi_log2(q0, q1, b0, b1);
+  f_pk_sub(y0, y1, p0, p1, q0, q1);
+  y0 = f_sel_eq(x0, 16.635532f, 0.f, y0);
+  y1 = f_sel_eq(x1, 16.635532f, 0.f, y1);
+}
+// the check-node update of bp_math.h's cn_update_col (boxplus-phi branch) on the two chunks of a row side by side
+template <int D, int NCH, bool FUSE>
+JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, bool last, float* orow, U32 ovoff,
+                               unsigned oc0, unsigned oc1, int hard_out) {
+  U32 sg[D][NCH], node[NCH];
+  F32 sum[NCH];
+#pragma unroll
+  for (int h = 0; h < NCH; ++h) { node[h] = 0u; sum[h] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    F32 p[2];
+    jit_phi2(p[0], p[1], f_abs(v[i][0]), f_abs(v[i][NCH - 1]));
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      sg[i][h] = u_msb_if_neg(v[i][h]);                      // sign_nz(v) = -1 <=> v < 0 (a -0 counts as +)
+      node[h] = node[h] ^ sg[i][h];
+      v[i][h] = p[h];
+      sum[h] = sum[h] + p[h];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    F32 q[2], c2v[NCH];
+    jit_phi2(q[0], q[1], f_neg(v[i][0]) + sum[0], f_neg(v[i][NCH - 1]) + sum[NCH - 1]);
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) {
+      c2v[h] = u_float(f_bits(f_min(q[h], llr_max)) ^ (sg[i][h] ^ node[h]));
+      if (FUSE && i == D - 1) {
+        const F32 x = c2v[h] + lf[h];
+        const unsigned oc = h ? oc1 : oc0;
+        if (oc != JIT_NOOUT) {
+          if (last) g_st(orow, u_here(ovoff), oc, jit_outval(x, llr_max, hard_out));
+        }
+        c2v[h] = f_med3(x - c2v[h], -llr_max, llr_max);
+      }
+    }
+    jit_cn_store<NCH>(a0, (unsigned)i * JIT_Z4, c2v);
+  }
+}
+#endif
+
 // v2c of iteration 0 for the fused degree-1 column of a row: its channel LLR
 template <int D, int NCH>
 JIT_DEV void jit_cn_init_fused(U32 a0, const F32 (&lf)[NCH]) {

@@ -168,6 +168,38 @@ JIT_DEV U32 u_xor3(const U32& a, const U32& b, const U32& c) { return a ^ b ^ c;
 JIT_DEV U32 u_xor_and(const U32& m, const U32& v, unsigned k) { return m ^ (v & U32(k)); }
 JIT_DEV void f_pk_add(F32& x0, F32& x1, const F32& c0, const F32& c1) { x0 = x0 + c0; x1 = x1 + c1; }
 JIT_DEV void f_pk_sub(F32& e0, F32& e1, const F32& x0, const F32& x1, const F32& c0, const F32& c1) { e0 = x0 - c0; e1 = x1 - c1; }
+JIT_DEV void f_pk_fma(F32& d0, F32& d1, const F32& a0, const F32& a1, const F32& b0, const F32& b1, const F32& c0, const F32& c1) {
+  F32 r0, r1;
+  for (int i = 0; i < 64; ++i) { r0.v[i] = fmaf(a0.v[i], b0.v[i], c0.v[i]); r1.v[i] = fmaf(a1.v[i], b1.v[i], c1.v[i]); }
+  d0 = r0; d1 = r1;
+}
+JIT_DEV void f_pk_fma(F32& d0, F32& d1, const F32& a0, const F32& a1, float b, const F32& c0, const F32& c1) {
+  f_pk_fma(d0, d1, a0, a1, F32(b), F32(b), c0, c1);
+}
+JIT_DEV void f_pk_mul(F32& d0, F32& d1, const F32& a0, const F32& a1, const F32& b0, const F32& b1) {
+  const F32 r0 = a0 * b0, r1 = a1 * b1;
+  d0 = r0; d1 = r1;
+}
+JIT_DEV void f_pk_addc(F32& d0, F32& d1, const F32& a0, const F32& a1, float c) {
+  const F32 r0 = a0 + F32(c), r1 = a1 + F32(c);
+  d0 = r0; d1 = r1;
+}
+JIT_DEV F32 f_frexp_exp(const F32& x) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) { unsigned b; memcpy(&b, &x.v[i], 4); r.v[i] = (float)((int)((b >> 23) & 0xffu) - 126); }
+  return r;
+}
+JIT_DEV F32 f_min(const F32& a, float b) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = fminf(a.v[i], b);
+  return r;
+}
+JIT_DEV U32 u_and_or(const U32& a, unsigned m, unsigned o) { return (a & U32(m)) | U32(o); }
+JIT_DEV U32 u_msb_if_neg(const F32& v) {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = (v.v[i] < 0.f) ? 0x80000000u : 0u;
+  return r;
+}
 JIT_DEV void jit_barrier() { pthread_barrier_wait(jit_emu_ctx.bar); }
 template <int P>
 JIT_DEV void jit_setprio() {}
