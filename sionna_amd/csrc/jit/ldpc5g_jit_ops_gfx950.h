@@ -80,6 +80,8 @@ JIT_DEV void f_pk_addc(F32& d0, F32& d1, F32 a0, F32 a1, float c) {
   const jit_f32x2 d = jit_f32x2{a0, a1} + jit_f32x2{c, c};
   d0 = d.x; d1 = d.y;
 }
+#define JIT_TABLE __device__ const
+JIT_DEV void jit_tab_lane(F32& a, F32& b, const float (*tab)[2]) { a = tab[threadIdx.x & 63u][0]; b = tab[threadIdx.x & 63u][1]; }
 JIT_DEV F32 f_frexp_exp(F32 x) { return (float)__builtin_amdgcn_frexp_expf(x); }      // exponent e + 1 of a normal x, as a float
 JIT_DEV F32 f_min(F32 a, float b) { return __builtin_fminf(a, b); }
 JIT_DEV U32 u_and_or(U32 a, unsigned m, unsigned o) { return (a & m) | o; }

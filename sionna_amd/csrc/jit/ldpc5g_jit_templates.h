@@ -156,6 +156,9 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
 #define JIT_RULE_PHI 0
 #endif
 #if JIT_RULE_PHI
+static JIT_TABLE float jit_phi_tab[64][2] = {
+JIT_PHI_TAB_ROWS
+};
 JIT_DEV void jit_phi_exp2(F32& e0, F32& e1, F32 x0, F32 x1) {
   F32 t0, t1, m0, m1, r0, r1, z0, z1, y0, y1;
   f_pk_fma(t0, t1, x0, x1, 1.44269504088896341f, 12582912.0f, 12582912.0f);
@@ -200,7 +203,14 @@ JIT_DEV void jit_phi2(F32& y0, F32& y1, F32 x0, F32 x1) {
   y0 = f_sel_eq(x0, 16.635532f, 0.f, y0);
   y1 = f_sel_eq(x1, 16.635532f, 0.f, y1);
 }
-// the check-node update of bp_math.h's cn_update_col (boxplus-phi branch) on the two chunks of a row side by side
+// the table of the logarithm into LDS (wave 0, once per launch; the first workgroup barrier orders it before its first use)
+JIT_DEV void jit_phi_stage(U32 l4) {
+  F32 a, b;
+  jit_tab_lane(a, b, jit_phi_tab);
+  lds_st2(l4 + l4, JIT_PHI_TAB, a, b);
+}
+// the check-node update of bp_math.h's cn_update_col (boxplus-phi branch).  NCH = 2: the two chunks of an edge share every
+// packed operation; NCH = 1 (rows of high degree, one chunk per item: registers): two EDGES share them.
 template <int D, int NCH, bool FUSE>
 JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, bool last, float* orow, U32 ovoff,
                                unsigned oc0, unsigned oc1, int hard_out) {
@@ -209,24 +219,50 @@ JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], f
 #pragma unroll
   for (int h = 0; h < NCH; ++h) { node[h] = 0u; sum[h] = 0.f; }
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    F32 p[2];
-    jit_phi2(p[0], p[1], f_abs(v[i][0]), f_abs(v[i][NCH - 1]));
+  for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
       sg[i][h] = u_msb_if_neg(v[i][h]);                      // sign_nz(v) = -1 <=> v < 0 (a -0 counts as +)
       node[h] = node[h] ^ sg[i][h];
-      v[i][h] = p[h];
-      sum[h] = sum[h] + p[h];
+    }
+  if (NCH == 2) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      F32 p0, p1;
+      jit_phi2(p0, p1, f_abs(v[i][0]), f_abs(v[i][NCH - 1]));
+      v[i][0] = p0; v[i][NCH - 1] = p1;
+      sum[0] = sum[0] + p0; sum[NCH - 1] = sum[NCH - 1] + p1;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; i += 2) {
+      const int i2 = (i + 1 < D) ? i + 1 : i;
+      F32 p0, p1;
+      jit_phi2(p0, p1, f_abs(v[i][0]), f_abs(v[i2][0]));
+      v[i][0] = p0;
+      sum[0] = sum[0] + p0;
+      if (i + 1 < D) { v[i2][0] = p1; sum[0] = sum[0] + p1; }
+    }
+  }
+  F32 q[D][NCH];
+  if (NCH == 2) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) jit_phi2(q[i][0], q[i][NCH - 1], f_neg(v[i][0]) + sum[0], f_neg(v[i][NCH - 1]) + sum[NCH - 1]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < D; i += 2) {
+      const int i2 = (i + 1 < D) ? i + 1 : i;
+      F32 q1;
+      jit_phi2(q[i][0], q1, f_neg(v[i][0]) + sum[0], f_neg(v[i2][0]) + sum[0]);
+      if (i + 1 < D) q[i2][0] = q1;
     }
   }
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    F32 q[2], c2v[NCH];
-    jit_phi2(q[0], q[1], f_neg(v[i][0]) + sum[0], f_neg(v[i][NCH - 1]) + sum[NCH - 1]);
+    F32 c2v[NCH];
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      c2v[h] = u_float(f_bits(f_min(q[h], llr_max)) ^ (sg[i][h] ^ node[h]));
+      c2v[h] = u_float(f_bits(f_min(q[i][h], llr_max)) ^ (sg[i][h] ^ node[h]));
       if (FUSE && i == D - 1) {
         const F32 x = c2v[h] + lf[h];
         const unsigned oc = h ? oc1 : oc0;

@@ -44,6 +44,7 @@ struct JitKnobs {
                        // chain, not its instruction count
   int rotate = 1;      // a wave's item order rotated by its index on its SIMD
   int cn_slope = 10, cn_ovh = -1, cn_fused = 6, vn_slope = 8, vn_ovh = 10, vn_pair_max = -1;   // cost model (-1: by layout)
+  int cn_pair_max = 32;   // rows of higher degree are two single-chunk items
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
 };
@@ -52,7 +53,8 @@ struct JitKnobs {
 bool jit_eligible(const samd_ldpc5g* h);
 // the whole translation unit handed to hipRTC.  with_ops = false: without the gfx950 operation definitions and the
 // __global__ entry (what tests/jit_emu compiles for the CPU)
-std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, int offset0, bool with_ops, const JitKnobs& knobs);
+// rule: 0 offset-min-sum, 1 min-sum, 2 boxplus-phi on the defined exp / log
+std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, int rule, bool with_ops, const JitKnobs& knobs);
 // SAMD_OK, SAMD_ERR_UNSUPPORTED (caller runs the generic kernel) or an error
 int launch_onchip_jit(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                       float llr_max, float offset, int hard_out, int return_infobits, void* stream);

@@ -36,6 +36,11 @@ int launch_onchip_ms_phi_fast(const samd_ldpc5g* h, const float* llr, float* out
 int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace,
                      size_t workspace_bytes, hipStream_t st) {
+  if (cn_mode == SAMD_CN_BOXPLUS_PHI) {
+    // the kernel generated for this code (ldpc5g_jit.cpp) when there is one - the same defined phi, the same bits
+    const int rcj = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, st);
+    if (rcj != SAMD_ERR_UNSUPPORTED) return rcj;
+  }
   if (cn_mode == SAMD_CN_BOXPLUS_PHI)
     return launch_onchip_ms_phi(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, workspace,
                                 workspace_bytes, st);

@@ -184,6 +184,10 @@ JIT_DEV void f_pk_addc(F32& d0, F32& d1, const F32& a0, const F32& a1, float c) 
   const F32 r0 = a0 + F32(c), r1 = a1 + F32(c);
   d0 = r0; d1 = r1;
 }
+#define JIT_TABLE const
+JIT_DEV void jit_tab_lane(F32& a, F32& b, const float (*tab)[2]) {
+  for (int i = 0; i < 64; ++i) { a.v[i] = tab[i][0]; b.v[i] = tab[i][1]; }
+}
 JIT_DEV F32 f_frexp_exp(const F32& x) {
   F32 r;
   for (int i = 0; i < 64; ++i) { unsigned b; memcpy(&b, &x.v[i], 4); r.v[i] = (float)((int)((b >> 23) & 0xffu) - 126); }

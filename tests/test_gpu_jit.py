@@ -105,6 +105,26 @@ def test_generator_variants_bit_exact(phy, opts):
             assert np.array_equal(got, _reference(code, llr, cn, it, infobits, m)), (cn, opts)
 
 
+def test_boxplus_phi_on_the_generated_kernel_bit_exact(phy):
+    """the defined phi of round 5 inside a generated kernel (SAMD_LDPC_JIT_PHI=1; off by default - measured slower than the
+    generic explicit-message kernel): soft outputs array_equal to the oracle, both output forms"""
+    import contextlib
+    k, n, m, bg = 2816, 8448, 6, "bg1"
+    code = LDPC5GCode(k, n, m, bg)
+    llr = _noisy_llr(code, 6, 7, sigma=0.7)
+    llr[0, :9] = 0
+    with contextlib.ExitStack() as st:
+        for kk, vv in (("SAMD_LDPC_JIT", "2"), ("SAMD_LDPC_JIT_PHI", "1"), ("SAMD_ONCHIP_GRID", "2")):
+            st.enter_context(_opt(kk, vv))
+        enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+        for it, infobits in ((1, True), (6, False)):
+            dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="boxplus-phi", hard_out=False, return_infobits=infobits, num_iter=it)
+            before = _launches(enc, dec)
+            got = _np(dec(llr))
+            assert _launches(enc, dec) == before + 1, "the generated kernel did not run"
+            assert np.array_equal(got, _reference(code, llr, "boxplus-phi", it, infobits, m)), (it, infobits)
+
+
 def test_c2_at_scale_specialised_equals_generic_and_oracle(phy):
     """BASELINE config C2 in the waterfall, 4096 codewords, 20 iterations: the default policy picks the specialised kernel
     (batch >= 1024); its soft outputs equal the generic kernel's (SAMD_LDPC_JIT=0) and the oracle's on a sample"""

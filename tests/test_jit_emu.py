@@ -95,7 +95,8 @@ def _run_generated(tmp_path, code, h, k, n, m):
     llr[2, ::5] *= 40                                            # clipping
     for infobits in (1, 0):
       for rule, cases in (("minsum", (("minsum", 1, 0), ("minsum", 6, 0), ("minsum", 3, 1))),
-                          ("offset-minsum", (("offset-minsum", 4, 0), ("minsum", 2, 0)))):     # one kernel per rule (offset 0 = min-sum)
+                          ("offset-minsum", (("offset-minsum", 4, 0), ("minsum", 2, 0))),      # one kernel per rule (offset 0 = min-sum)
+                          ("boxplus-phi", (("boxplus-phi", 1, 0), ("boxplus-phi", 5, 0), ("boxplus-phi", 3, 1)))):
         lib, src = _build_emu(tmp_path, h, infobits, f"{k}_{n}_{m}_{infobits}_{rule}", rule)
         assert "jit_wave_15" in src
         for cn, it, hard in cases:

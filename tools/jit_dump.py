@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--m", type=int, default=6)
     ap.add_argument("--bg", default="bg1")
     ap.add_argument("--infobits", type=int, default=1)
-    ap.add_argument("--cn", default="minsum", choices=["minsum", "offset-minsum"])
+    ap.add_argument("--cn", default="minsum", choices=["minsum", "offset-minsum", "boxplus-phi"])
     ap.add_argument("--out", default="/tmp/jit")
     ap.add_argument("--opt", action="append", default=[], help="SAMD_JIT_*=value (repeatable)")
     a = ap.parse_args()
