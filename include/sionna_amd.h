@@ -295,7 +295,7 @@ int samd_rg_map_c64(const float* x, const float* pilots, const int32_t* data_pos
                     int num_data, int num_pilots, float* out, void* stream);
 
 /* Generic index gather out[b,g,j] = in[b, src_group[g], idx[g,j]] on float32 (floats_per_elem
- * = 1) or complex64 (= 2) elements.  Implements RemoveNulledSubcarriers.call
+ * = 1), complex64 / float64 (= 2) or complex128 (= 4) elements.  Implements RemoveNulledSubcarriers.call
  * (ofdm/resource_grid.py:551-552) and ResourceGridDemapper.call (:466-520). */
 int samd_gather3(const float* in, const int32_t* src_group, const int32_t* idx, int batch,
                  int groups_in, int n_in, int groups_out, int n_out, int floats_per_elem,
@@ -421,6 +421,9 @@ int samd_ofdm_kbest_f32(const float* y, const float* h_hat, const float* err_var
  * seq DEVICE float32 0/1 [period]; period = numel of the trailing dims the sequence spans. */
 int samd_scramble_f32(const float* x, const float* seq, int64_t total, int64_t period, int binary,
                       float* out, void* stream);
+/* the same on float64 values (precision = "double"); the bit sequence stays float32 */
+int samd_scramble_f64(const double* x, const float* seq, int64_t total, int64_t period, int binary,
+                      double* out, void* stream);
 
 /* generate_prng_seq nr/utils.py:14-78 (TS 38.211 5.2.1 length-31 Gold sequence, N_c = 1600):
  * out DEVICE float32 0/1 [length].  Init-time helper (host recurrence + one upload). */
@@ -550,6 +553,34 @@ int samd_ldpc5g_extract_codeword_f64(const samd_ldpc5g_t* h, const double* x_hat
 int samd_qam_demap_f64(const double* y, const double* no, int64_t no_len, const double* points,
                        int m, int64_t num_symbols, const double* prior, int64_t prior_len,
                        int method, int hard_out, double* out, void* stream);
+
+/* complex128 / float64 variants of the OFDM link blocks of config C4 (csrc/f64_ofdm.hip, csrc/ofdm_time.hip): the same
+ * layouts, index tables and Philox stream positions as the complex64 entries above (samd_awgn_c64, samd_rg_map_c64,
+ * samd_tdl_cir_c64, samd_cir_to_ofdm_c64, samd_apply_ofdm_channel_c64, samd_ls_gather_scale_c64, samd_ofdm_modulate_c64,
+ * samd_ofdm_demodulate_c64), every real argument double.  Random draws: the float32 stream's 24-bit uniforms (exact in
+ * double), Box-Muller / affine maps evaluated in double - specification oracle/f64_ofdm.py.  samd_awgn_c128: x nullable
+ * (= 0: complex_normal, utils/misc.py:19-54, with no = var).  samd_gather3 moves complex128 elements with
+ * floats_per_elem = 4. */
+int samd_awgn_c128(const double* x, const double* no, int64_t no_len, uint64_t seed, uint64_t call, int64_t n,
+                   double* y, void* stream);
+int samd_rg_map_c128(const double* x, const double* pilots, const int32_t* data_pos, const int32_t* pilot_pos,
+                     int batch, int num_streams, int num_re, int num_data, int num_pilots, double* out, void* stream);
+int samd_tdl_cir_c128(uint64_t seed, uint64_t call, int batch, int num_rx_ant, int num_tx_ant, int num_paths,
+                      int num_time_steps, int num_sinusoids, double sampling_frequency, const double* mean_powers,
+                      double min_doppler, double max_doppler, int los, double los_power, double los_aoa, double* a,
+                      void* stream);
+int samd_cir_to_ofdm_c128(const double* a, const double* tau, const double* frequencies, int batch, int num_rx,
+                          int num_rx_ant, int num_tx, int num_tx_ant, int num_paths, int num_time_steps,
+                          int num_freqs, int normalize, double* h_freq, void* stream);
+int samd_apply_ofdm_channel_c128(const double* x, const double* h_freq, int batch, int num_rx_x_ant,
+                                 int num_tx_x_ant, int num_re, double* y, void* stream);
+int samd_ls_gather_scale_c128(const double* y, const int32_t* src, const double* coef, int rows, int num_streams,
+                              int n_out, int n_in, double* out, void* stream);
+int samd_ofdm_modulate_c128(const double* x, int rows, int num_ofdm_symbols, int fft_size, const int32_t* cp_len,
+                            const int32_t* sym_off, int max_cp, int out_len, double* work, double* out, void* stream);
+int samd_ofdm_demodulate_c128(const double* y, int rows, int in_len, int num_ofdm_symbols, int fft_size,
+                              const int32_t* cp_len, const int32_t* sym_off, int l_min, double* work, double* out,
+                              void* stream);
 
 /* lmmse_equalizer / zf_equalizer / mf_equalizer in complex128 (precision = "double", reference block.py:25-52;
  * mimo/equalization.py:101-470): y [n, M], h [n, M, K], s [n, M, M] complex128 -> x_hat [n, K] complex128, no_eff

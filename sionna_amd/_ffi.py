@@ -25,7 +25,7 @@ CN_MODES = {"boxplus": 0, "boxplus-phi": 1, "minsum": 2, "min": 2, "offset-minsu
 
 _lib = None
 
-_vp, _i32, _i64, _u64, _f32, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+_vp, _i32, _i64, _u64, _f32, _sz, _f64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_size_t, C.c_double
 _SIGNATURES = {
     "samd_last_error": (C.c_char_p, []),
     "samd_version": (_i32, []),
@@ -46,6 +46,15 @@ _SIGNATURES = {
     "samd_ldpc5g_extract_codeword_f64": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "samd_lmmse_equalizer_c128": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "samd_qam_demap_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_scramble_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
+    "samd_awgn_c128": (_i32, [_vp, _vp, _i64, _u64, _u64, _i64, _vp, _vp]),
+    "samd_rg_map_c128": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_tdl_cir_c128": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _i32, _f64, _vp, _f64, _f64, _i32, _f64, _f64, _vp, _vp]),
+    "samd_cir_to_ofdm_c128": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_apply_ofdm_channel_c128": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_ls_gather_scale_c128": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_ofdm_modulate_c128": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "samd_ofdm_demodulate_c128": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "samd_ldpc5g_create": (_i32, [_i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.POINTER(_vp)]),
     "samd_ldpc5g_destroy": (None, [_vp]),
     "samd_ldpc5g_encode_f32": (_i32, [_vp, _vp, _vp, _i32, _vp]),

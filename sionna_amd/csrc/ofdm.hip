@@ -427,10 +427,14 @@ extern "C" int samd_rg_map_c64(const float* x, const float* pilots, const int32_
 extern "C" int samd_gather3(const float* in, const int32_t* src_group, const int32_t* idx, int batch, int groups_in,
                             int n_in, int groups_out, int n_out, int floats_per_elem, float* out, void* stream) {
   SAMD_REQUIRE(in && src_group && idx && out, "null argument");
-  SAMD_REQUIRE(floats_per_elem == 1 || floats_per_elem == 2, "element must be float32 or complex64");
+  SAMD_REQUIRE(floats_per_elem == 1 || floats_per_elem == 2 || floats_per_elem == 4,
+               "element must be float32 (1), complex64 / float64 (2) or complex128 (4 floats)");
   const int64_t total = (int64_t)batch * groups_out * n_out;
   if (total == 0) return SAMD_OK;
-  if (floats_per_elem == 2)
+  if (floats_per_elem == 4)
+    hipLaunchKernelGGL(gather3_kernel<4>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, src_group,
+                       idx, total, groups_in, n_in, groups_out, n_out, out);
+  else if (floats_per_elem == 2)
     hipLaunchKernelGGL(gather3_kernel<2>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in, src_group,
                        idx, total, groups_in, n_in, groups_out, n_out, out);
   else

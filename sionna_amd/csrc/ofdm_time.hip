@@ -91,8 +91,8 @@ bool load_rocfft_locked() {
   return true;
 }
 
-// Batched in-place 1-D complex64 transform of `batch` contiguous rows of length n.
-int fft_inplace(float* data, int n, int batch, bool inverse, hipStream_t stream) {
+// Batched in-place 1-D complex64 (dbl: complex128) transform of `batch` contiguous rows of length n.
+int fft_inplace(void* data, int n, int batch, bool inverse, hipStream_t stream, bool dbl = false) {
   std::lock_guard<std::mutex> lock(g_fft_mutex);
   if (!load_rocfft_locked()) {
     set_error(g_fft.err);
@@ -100,14 +100,14 @@ int fft_inplace(float* data, int n, int batch, bool inverse, hipStream_t stream)
   }
   int dev = 0;
   SAMD_HIP_CHECK(hipGetDevice(&dev));
-  const auto key = std::make_tuple(dev, n, batch, inverse ? 1 : 0);
+  const auto key = std::make_tuple(dev, n, batch, (inverse ? 1 : 0) | (dbl ? 2 : 0));
   auto it = g_plans.find(key);
   if (it == g_plans.end()) {
     FftPlan p;
     const size_t len = (size_t)n;
     if (g_fft.plan_create(&p.plan, rocfft_placement_inplace,
                           inverse ? rocfft_transform_type_complex_inverse : rocfft_transform_type_complex_forward,
-                          rocfft_precision_single, 1, &len, (size_t)batch, nullptr) != rocfft_status_success) {
+                          dbl ? rocfft_precision_double : rocfft_precision_single, 1, &len, (size_t)batch, nullptr) != rocfft_status_success) {
       set_error("rocfft_plan_create failed");
       return SAMD_ERR_HIP;
     }
@@ -139,7 +139,11 @@ int fft_inplace(float* data, int n, int batch, bool inverse, hipStream_t stream)
 // ---------------------------------------------------------------- kernels
 // work[r, s, k] = x[r, s, (k + n/2 [ceil for ifftshift]) mod n]: ifftshift moves the DC
 // subcarrier (index n//2) to bin 0 (modulator.py:100).
-__global__ void ifftshift_kernel(const float2* __restrict__ x, long long total, int n, float2* __restrict__ work) {
+__device__ __forceinline__ void sincos_r(float x, float* s, float* c) { sincosf(x, s, c); }
+__device__ __forceinline__ void sincos_r(double x, double* s, double* c) { sincos(x, s, c); }
+
+template <typename R2, typename R>
+__global__ void ifftshift_kernel(const R2* __restrict__ x, long long total, int n, R2* __restrict__ work) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int k = (int)(i % n);
@@ -150,9 +154,10 @@ __global__ void ifftshift_kernel(const float2* __restrict__ x, long long total, 
 
 // out[r, off[s] + t] = work[r, s, (t - cp[s]) mod n] / sqrt(n), t in [0, n + cp[s])
 // (modulator.py:103-124 with ifft = sqrt(n) * IDFT_normalised, signal/utils.py:246-262).
-__global__ void add_cp_kernel(const float2* __restrict__ work, const int32_t* __restrict__ cp,
-                              const int32_t* __restrict__ off, int nsym, int n, int out_len, float scale,
-                              int ntb, float2* __restrict__ out) {
+template <typename R2, typename R>
+__global__ void add_cp_kernel(const R2* __restrict__ work, const int32_t* __restrict__ cp,
+                              const int32_t* __restrict__ off, int nsym, int n, int out_len, R scale,
+                              int ntb, R2* __restrict__ out) {
   const int s = (blockIdx.x / ntb) % nsym;
   const long long r = blockIdx.x / ntb / nsym;
   const int t = (blockIdx.x % ntb) * blockDim.x + threadIdx.x;
@@ -160,14 +165,15 @@ __global__ void add_cp_kernel(const float2* __restrict__ work, const int32_t* __
   if (t >= n + c) return;
   int src = t - c;
   if (src < 0) src += n;
-  const float2 v = work[(r * nsym + s) * n + src];
-  out[r * out_len + off[s] + t] = make_float2(v.x * scale, v.y * scale);
+  const R2 v = work[(r * nsym + s) * n + src];
+  out[r * out_len + off[s] + t] = R2{v.x * scale, v.y * scale};
 }
 
 // work[r, s, t] = y[r, off[s] + cp[s] + t]  (demodulator.py:184-195)
-__global__ void remove_cp_kernel(const float2* __restrict__ y, const int32_t* __restrict__ cp,
+template <typename R2, typename R>
+__global__ void remove_cp_kernel(const R2* __restrict__ y, const int32_t* __restrict__ cp,
                                  const int32_t* __restrict__ off, int nsym, int n, int in_len,
-                                 int ntb, float2* __restrict__ work) {
+                                 int ntb, R2* __restrict__ work) {
   const int s = (blockIdx.x / ntb) % nsym;
   const long long r = blockIdx.x / ntb / nsym;
   const int t = (blockIdx.x % ntb) * blockDim.x + threadIdx.x;
@@ -177,20 +183,21 @@ __global__ void remove_cp_kernel(const float2* __restrict__ y, const int32_t* __
 
 // out[r, s, k'] = work[r, s, k] * exp(j * phase_step * k) / sqrt(n), k = (k' - n//2) mod n
 // i.e. fftshift after the phase compensation (demodulator.py:197-203).
-__global__ void demod_post_kernel(const float2* __restrict__ work, long long total, int n, float phase_step, float scale,
-                                  float2* __restrict__ out) {
+template <typename R2, typename R>
+__global__ void demod_post_kernel(const R2* __restrict__ work, long long total, int n, R phase_step, R scale,
+                                  R2* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int kp = (int)(i % n);
   const long long row = i / n;
   int k = kp - n / 2;  // np.fft.fftshift: out[k'] = in[(k' - n//2) % n]
   if (k < 0) k += n;
-  const float2 v = work[row * n + k];
-  float sn, cs;
-  sincosf(phase_step * (float)k, &sn, &cs);
-  const float re = (v.x * cs - v.y * sn) * scale;
-  const float im = (v.x * sn + v.y * cs) * scale;
-  out[i] = make_float2(re, im);
+  const R2 v = work[row * n + k];
+  R sn, cs;
+  sincos_r(phase_step * (R)k, &sn, &cs);
+  const R re = (v.x * cs - v.y * sn) * scale;
+  const R im = (v.x * sn + v.y * cs) * scale;
+  out[i] = R2{re, im};
 }
 
 __device__ __forceinline__ float sincf(float x) {
@@ -340,12 +347,12 @@ extern "C" int samd_ofdm_modulate_c64(const float* x, int rows, int num_ofdm_sym
   if (rows == 0) return SAMD_OK;
   hipStream_t st = (hipStream_t)stream;
   const long long total = (long long)rows * num_ofdm_symbols * fft_size;
-  ifftshift_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const float2*)x, total, fft_size, (float2*)work);
+  ifftshift_kernel<float2, float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const float2*)x, total, fft_size, (float2*)work);
   if (int rc = launch_status()) return rc;
   if (int rc = fft_inplace(work, fft_size, rows * num_ofdm_symbols, true, st)) return rc;
   const int ntb = (fft_size + max_cp + 255) / 256;
   SAMD_REQUIRE((long long)ntb * num_ofdm_symbols * rows < (1ll << 31), "grid too large");
-  add_cp_kernel<<<(unsigned)((long long)ntb * num_ofdm_symbols * rows), 256, 0, st>>>(
+  add_cp_kernel<float2, float><<<(unsigned)((long long)ntb * num_ofdm_symbols * rows), 256, 0, st>>>(
       (const float2*)work, cp_len, sym_off, num_ofdm_symbols, fft_size, out_len, 1.0f / sqrtf((float)fft_size), ntb,
       (float2*)out);
   return launch_status();
@@ -360,15 +367,53 @@ extern "C" int samd_ofdm_demodulate_c64(const float* y, int rows, int in_len, in
   hipStream_t st = (hipStream_t)stream;
   const int ntb = (fft_size + 255) / 256;
   SAMD_REQUIRE((long long)ntb * num_ofdm_symbols * rows < (1ll << 31), "grid too large");
-  remove_cp_kernel<<<(unsigned)((long long)ntb * num_ofdm_symbols * rows), 256, 0, st>>>(
+  remove_cp_kernel<float2, float><<<(unsigned)((long long)ntb * num_ofdm_symbols * rows), 256, 0, st>>>(
       (const float2*)y, cp_len, sym_off, num_ofdm_symbols, fft_size, in_len, ntb, (float2*)work);
   if (int rc = launch_status()) return rc;
   if (int rc = fft_inplace(work, fft_size, rows * num_ofdm_symbols, false, st)) return rc;
   const long long total = (long long)rows * num_ofdm_symbols * fft_size;
   // demodulator.py:143-146: -2 * PI * l_min / fft_size * range(fft_size), float32 left to right
   const float phase_step = (-2.0f * 3.14159265358979323846f * (float)l_min) / (float)fft_size;
-  demod_post_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const float2*)work, total, fft_size, phase_step,
+  demod_post_kernel<float2, float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const float2*)work, total, fft_size, phase_step,
                                                                      1.0f / sqrtf((float)fft_size), (float2*)out);
+  return launch_status();
+}
+
+// precision = "double" (reference block.py:25-52): the same passes on complex128 with a double-precision rocFFT plan
+extern "C" int samd_ofdm_modulate_c128(const double* x, int rows, int num_ofdm_symbols, int fft_size, const int32_t* cp_len,
+                                       const int32_t* sym_off, int max_cp, int out_len, double* work, double* out, void* stream) {
+  SAMD_REQUIRE(x && cp_len && sym_off && work && out, "null argument");
+  SAMD_REQUIRE(rows >= 0 && num_ofdm_symbols > 0 && fft_size > 0 && max_cp >= 0 && max_cp <= fft_size, "bad shape");
+  if (rows == 0) return SAMD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const long long total = (long long)rows * num_ofdm_symbols * fft_size;
+  ifftshift_kernel<double2, double><<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const double2*)x, total, fft_size, (double2*)work);
+  if (int rc = launch_status()) return rc;
+  if (int rc = fft_inplace(work, fft_size, rows * num_ofdm_symbols, true, st, true)) return rc;
+  const int ntb = (fft_size + max_cp + 255) / 256;
+  SAMD_REQUIRE((long long)ntb * num_ofdm_symbols * rows < (1ll << 31), "grid too large");
+  add_cp_kernel<double2, double><<<(unsigned)((long long)ntb * num_ofdm_symbols * rows), 256, 0, st>>>(
+      (const double2*)work, cp_len, sym_off, num_ofdm_symbols, fft_size, out_len, 1.0 / sqrt((double)fft_size), ntb, (double2*)out);
+  return launch_status();
+}
+
+extern "C" int samd_ofdm_demodulate_c128(const double* y, int rows, int in_len, int num_ofdm_symbols, int fft_size,
+                                         const int32_t* cp_len, const int32_t* sym_off, int l_min, double* work, double* out,
+                                         void* stream) {
+  SAMD_REQUIRE(y && cp_len && sym_off && work && out, "null argument");
+  SAMD_REQUIRE(rows >= 0 && num_ofdm_symbols > 0 && fft_size > 0 && l_min <= 0, "bad shape");
+  if (rows == 0) return SAMD_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntb = (fft_size + 255) / 256;
+  SAMD_REQUIRE((long long)ntb * num_ofdm_symbols * rows < (1ll << 31), "grid too large");
+  remove_cp_kernel<double2, double><<<(unsigned)((long long)ntb * num_ofdm_symbols * rows), 256, 0, st>>>(
+      (const double2*)y, cp_len, sym_off, num_ofdm_symbols, fft_size, in_len, ntb, (double2*)work);
+  if (int rc = launch_status()) return rc;
+  if (int rc = fft_inplace(work, fft_size, rows * num_ofdm_symbols, false, st, true)) return rc;
+  const long long total = (long long)rows * num_ofdm_symbols * fft_size;
+  const double phase_step = (-2.0 * 3.14159265358979323846 * (double)l_min) / (double)fft_size;
+  demod_post_kernel<double2, double><<<(unsigned)((total + 255) / 256), 256, 0, st>>>((const double2*)work, total, fft_size, phase_step,
+                                                                                     1.0 / sqrt((double)fft_size), (double2*)out);
   return launch_status();
 }
 

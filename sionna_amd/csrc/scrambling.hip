@@ -11,13 +11,15 @@
 namespace samd {
 namespace {
 
-__global__ void scramble_kernel(const float* __restrict__ x, const float* __restrict__ seq, long long total,
-                                long long period, int binary, float* __restrict__ out) {
+template <typename R>
+__global__ void scramble_kernel(const R* __restrict__ x, const float* __restrict__ seq, long long total,
+                                long long period, int binary, R* __restrict__ out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
-  const float s = seq[i % period];
+  const R s = (R)seq[i % period];
   // binary: |x - s| (scrambling.py:252-254); soft values: x * (-2 s + 1) (:255-257)
-  out[i] = binary ? fabsf(x[i] - s) : x[i] * (-2.f * s + 1.f);
+  const R d = x[i] - s;
+  out[i] = binary ? (d < (R)0 ? -d : d) : x[i] * ((R)-2 * s + (R)1);
 }
 
 }  // namespace
@@ -31,7 +33,18 @@ extern "C" int samd_scramble_f32(const float* x, const float* seq, int64_t total
   SAMD_REQUIRE(total >= 0 && period > 0, "bad size");
   if (total == 0) return SAMD_OK;
   SAMD_REQUIRE((total + 255) / 256 < (1ll << 31), "grid too large");
-  scramble_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, seq, total, period, binary, out);
+  scramble_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, seq, total, period, binary, out);
+  return launch_status();
+}
+
+// precision = "double" (reference block.py:25-52): float64 values, the same float32 bit sequence
+extern "C" int samd_scramble_f64(const double* x, const float* seq, int64_t total, int64_t period, int binary,
+                                 double* out, void* stream) {
+  SAMD_REQUIRE(x && seq && out, "null argument");
+  SAMD_REQUIRE(total >= 0 && period > 0, "bad size");
+  if (total == 0) return SAMD_OK;
+  SAMD_REQUIRE((total + 255) / 256 < (1ll << 31), "grid too large");
+  scramble_kernel<double><<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, seq, total, period, binary, out);
   return launch_status();
 }
 

@@ -136,6 +136,13 @@ class Object(ABC):
     def rdtype(self):
         return dtypes[self.precision]["torch"]["rdtype"]
 
+    _np_cdtype = property(lambda self: dtypes[self.precision]["np"]["cdtype"])
+    _np_rdtype = property(lambda self: dtypes[self.precision]["np"]["rdtype"])
+
+    def _bits(self, t):
+        """Output of a bit-domain block (bits are exact in either precision: the kernels carry them as float32)."""
+        return t if self._precision == "single" else t.to(self.rdtype)
+
     def _require_single(self):
         """The HIP kernels compute in float32 (BASELINE north-star dtype)."""
         if self._precision != "single":

@@ -37,14 +37,13 @@ class ApplyOFDMChannel(Block):
         self._awgn = AWGN(precision=self.precision)
 
     def call(self, x, h_freq, no=None):
-        self._require_single()
-        x = _ffi.to_device(x, torch.complex64)
-        h = _ffi.to_device(h_freq, torch.complex64)
+        x = _ffi.to_device(x, self.cdtype)
+        h = _ffi.to_device(h_freq, self.cdtype)
         b, rx, ra, tx, ta, t, f = h.shape
         assert tuple(x.shape) == (b, tx, ta, t, f), "x must have shape [batch, num_tx, num_tx_ant, num_ofdm_symbols, fft_size]"
-        y = torch.empty((b, rx, ra, t, f), dtype=torch.complex64, device=x.device)
-        _ffi.check(_ffi.lib().samd_apply_ofdm_channel_c64(_ffi.ptr(x), _ffi.ptr(h), b, rx * ra, tx * ta, t * f,
-                                                          _ffi.ptr(y), _ffi.stream()), "ApplyOFDMChannel")
+        y = torch.empty((b, rx, ra, t, f), dtype=self.cdtype, device=x.device)
+        fn = _ffi.lib().samd_apply_ofdm_channel_c128 if self.precision == "double" else _ffi.lib().samd_apply_ofdm_channel_c64
+        _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(h), b, rx * ra, tx * ta, t * f, _ffi.ptr(y), _ffi.stream()), "ApplyOFDMChannel")
         if no is not None:
             y = self._awgn(y, no)
         return y
@@ -76,11 +75,9 @@ class RayleighBlockFading(Object):
         self.num_rx, self.num_rx_ant, self.num_tx, self.num_tx_ant = num_rx, num_rx_ant, num_tx, num_tx_ant
 
     def __call__(self, batch_size, num_time_steps, sampling_frequency=None):
-        if self.precision != "single":
-            raise NotImplementedError("RayleighBlockFading: precision='single' only")
         from ..utils.misc import complex_normal
         shape = [int(batch_size), self.num_rx, self.num_rx_ant, self.num_tx, self.num_tx_ant, 1, 1]
-        h = complex_normal(shape, 1.0).as_subclass(torch.Tensor)
+        h = complex_normal(shape, 1.0, precision=self.precision).as_subclass(torch.Tensor)
         h = h.expand(*shape[:-1], int(num_time_steps)).contiguous()
-        tau = torch.zeros((int(batch_size), self.num_rx, self.num_tx, 1), dtype=torch.float32, device=h.device)
+        tau = torch.zeros((int(batch_size), self.num_rx, self.num_tx, 1), dtype=self.rdtype, device=h.device)
         return wrap(h), wrap(tau)

@@ -51,15 +51,14 @@ class CRCEncoder(Block):
         self._n = self._k + self._crc_length
 
     def call(self, bits, /):
-        self._require_single()
-        bits = _ffi.to_device(bits, torch.float32)
+        bits = _ffi.to_device(bits, torch.float32)          # bits are exact in either precision (block.py::_bits)
         if bits.shape[-1] != self._k:
             self.build(bits.shape)
         k = bits.shape[-1]
         out = torch.empty(tuple(bits.shape[:-1]) + (k + self._crc_length,), dtype=torch.float32, device=bits.device)
         _ffi.check(_ffi.lib().samd_crc_f32(_ffi.ptr(bits), bits.numel() // k, k, self._mask, self._crc_length, 0,
                                            _ffi.ptr(out), _ffi.stream()), "CRCEncoder")
-        return out
+        return self._bits(out)
 
 
 class CRCDecoder(Block):
@@ -75,11 +74,10 @@ class CRCDecoder(Block):
     encoder = property(lambda self: self._encoder)
 
     def call(self, x_crc, /):
-        self._require_single()
         x = _ffi.to_device(x_crc, torch.float32)
         n = x.shape[-1]
         enc = self._encoder
         valid = torch.empty(tuple(x.shape[:-1]) + (1,), dtype=torch.float32, device=x.device)
         _ffi.check(_ffi.lib().samd_crc_f32(_ffi.ptr(x), x.numel() // n, n, enc._mask, enc.crc_length, 1,
                                            _ffi.ptr(valid), _ffi.stream()), "CRCDecoder")
-        return x[..., :n - enc.crc_length], valid > 0.5
+        return self._bits(x[..., :n - enc.crc_length]), valid > 0.5

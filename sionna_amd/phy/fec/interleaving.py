@@ -55,8 +55,7 @@ class RowColumnInterleaver(Block):
         return self._dev[inverse]
 
     def call(self, x, /, *, inverse=None, **kwargs):
-        self._require_single()
-        x = _ffi.to_device(x, torch.float32)
+        x = _ffi.to_device(x, self.rdtype)
         if self._perm_seq is None or x.shape[self._axis] != self._perm_seq.shape[0]:
             self.build(tuple(x.shape))
         inverse = self._inverse if inverse is None else bool(inverse)
@@ -66,7 +65,7 @@ class RowColumnInterleaver(Block):
         rows = xm.numel() // n if n else 0
         out = torch.empty_like(xm)
         if rows:
-            _ffi.check(_ffi.lib().samd_gather3(_ffi.ptr(xm), _ffi.ptr(zero), _ffi.ptr(perm), rows, 1, n, 1, n, 1,
+            _ffi.check(_ffi.lib().samd_gather3(_ffi.ptr(xm), _ffi.ptr(zero), _ffi.ptr(perm), rows, 1, n, 1, n, xm.element_size() // 4,
                                                _ffi.ptr(out), _ffi.stream()), "RowColumnInterleaver")
         return wrap(torch.movedim(out, -1, self._axis).contiguous())
 
@@ -139,8 +138,7 @@ class RandomInterleaver(Block):
         return int(s_min)
 
     def call(self, x, /, *, seed=None, inverse=None, **kwargs):
-        self._require_single()
-        x = _ffi.to_device(x, torch.float32)
+        x = _ffi.to_device(x, self.rdtype)
         if self._axis >= x.dim() or self._axis < -x.dim():
             raise ValueError("Axis does not match input shape")
         if seed is None:
@@ -156,7 +154,7 @@ class RandomInterleaver(Block):
         rows = xm.numel() // n if n else 0
         out = torch.empty_like(xm)
         if rows:
-            _ffi.check(_ffi.lib().samd_gather3(_ffi.ptr(xm), _ffi.ptr(zero), _ffi.ptr(inv if inverse else perm), rows, 1, n, 1, n, 1,
+            _ffi.check(_ffi.lib().samd_gather3(_ffi.ptr(xm), _ffi.ptr(zero), _ffi.ptr(inv if inverse else perm), rows, 1, n, 1, n, xm.element_size() // 4,
                                                _ffi.ptr(out), _ffi.stream()), "RandomInterleaver")
         return wrap(torch.movedim(out, -1, self._axis).contiguous())
 

@@ -43,8 +43,7 @@ class LinearEncoder(Block):
             raise ValueError(f"Last dimension must be of size k={self._k}.")
 
     def call(self, bits, /):
-        self._require_single()
-        u = _ffi.to_device(bits, torch.float32)
+        u = _ffi.to_device(bits, torch.float32)              # bits are exact in either precision (block.py::_bits)
         if u.shape[-1] != self._k:
             raise ValueError(f"Last dimension must be of size k={self._k}.")
         if self._dev is None:
@@ -54,7 +53,7 @@ class LinearEncoder(Block):
         out = torch.empty((u2.shape[0], self._n), dtype=torch.float32, device=u.device)
         _ffi.check(_ffi.lib().samd_gf2_encode_f32(_ffi.ptr(u2), _ffi.ptr(self._dev), u2.shape[0], self._k, self._n,
                                                   _ffi.ptr(out), _ffi.stream()), "LinearEncoder")
-        return wrap(out.reshape(lead + (self._n,)))
+        return wrap(self._bits(out.reshape(lead + (self._n,))))
 
 
 class AllZeroEncoder(Block):

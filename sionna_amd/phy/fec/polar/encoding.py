@@ -72,12 +72,11 @@ class PolarEncoder(Block):
             raise ValueError("Last input dimension must be of length k.")
 
     def call(self, bits):
-        self._require_single()
-        bits = _ffi.to_device(bits, torch.float32)
+        bits = _ffi.to_device(bits, torch.float32)          # bits are exact in either precision (block.py::_bits)
         if bits.shape[-1] != self._k:
             raise ValueError("Last input dimension must be of length k.")
         out = self._encode_2d(bits.reshape(-1, self._k))
-        return out.reshape(tuple(bits.shape[:-1]) + (out.shape[-1],))
+        return self._bits(out.reshape(tuple(bits.shape[:-1]) + (out.shape[-1],)))
 
 
 def _subblock_pattern(k):
@@ -130,7 +129,7 @@ class Polar5GEncoder(PolarEncoder):
         self._channel_type, self._k_target, self._n_target, self._verbose = channel_type, k, n, verbose
         crc_degree, n_polar, frozen_pos, idx_rm, idx_input = self._init_rate_match(k, n)
         self._ind_rate_matching, self._ind_input_int = idx_rm, idx_input
-        self._enc_crc = CRCEncoder(crc_degree, precision=precision)
+        self._enc_crc = CRCEncoder(crc_degree, precision="single")       # inner stage: bits as float32 (exact)
         super().__init__(frozen_pos, n_polar, precision=precision, **kwargs)
         self._out_idx = np.asarray(idx_rm, np.int32)
         self._dev_iil = None
@@ -232,7 +231,6 @@ class Polar5GEncoder(PolarEncoder):
             raise ValueError("Invalid input shape.")
 
     def call(self, bits):
-        self._require_single()
         bits = _ffi.to_device(bits, torch.float32)
         if bits.shape[-1] != self._k_target:
             raise ValueError("Invalid input shape.")
@@ -242,4 +240,4 @@ class Polar5GEncoder(PolarEncoder):
                 self._dev_iil = torch.from_numpy(np.asarray(self._ind_input_int, np.int64)).to(u_crc.device)
             u_crc = u_crc.index_select(1, self._dev_iil).contiguous()
         c = self._encode_2d(u_crc)
-        return c.reshape(tuple(bits.shape[:-1]) + (self._n_target,))
+        return self._bits(c.reshape(tuple(bits.shape[:-1]) + (self._n_target,)))

@@ -15,13 +15,14 @@ from ..config import config
 _CALL = 1337          # the reference seeds with (1337, seed), scrambling.py:124
 
 
-def _apply(x, seq, period, binary):
-    x = _ffi.to_device(x, torch.float32)
+def _apply(x, seq, period, binary, rdtype=torch.float32):
+    x = _ffi.to_device(x, rdtype)
     out = torch.empty_like(x)
     if x.numel() == 0:
         return wrap(out)
-    _ffi.check(_ffi.lib().samd_scramble_f32(_ffi.ptr(x), _ffi.ptr(seq), x.numel(), int(period), int(bool(binary)),
-                                            _ffi.ptr(out), _ffi.stream()), "scramble")
+    fn = _ffi.lib().samd_scramble_f64 if rdtype == torch.float64 else _ffi.lib().samd_scramble_f32
+    _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(seq), x.numel(), int(period), int(bool(binary)), _ffi.ptr(out), _ffi.stream()),
+               "scramble")
     return wrap(out)
 
 
@@ -32,6 +33,7 @@ def _check_binary_flag(binary):
 
 
 class Scrambler(Block):
+    _io_rdtype = None          # set by a Descrambler of another precision around its call
     """``Scrambler(seed=None, keep_batch_constant=False, binary=True, sequence=None,
     keep_state=True)(x, seed=None, binary=None)``."""
 
@@ -73,9 +75,8 @@ class Scrambler(Block):
         return seq, n
 
     def call(self, x, seed=None, binary=None):
-        self._require_single()
         binary = self._binary if binary is None else _check_binary_flag(binary)
-        x = _ffi.to_device(x, torch.float32)
+        x = _ffi.to_device(x, self._io_rdtype or self.rdtype)
         if seed is not None:
             s = int(seed)
         elif self._keep_state:
@@ -90,9 +91,9 @@ class Scrambler(Block):
                 raise ValueError("sequence has more dimensions than the input")
             seq = np.broadcast_to(seq, tuple(x.shape)[x.dim() - seq.ndim:]) if seq.ndim else seq.reshape(1)
             seq_d = _ffi.to_device(np.ascontiguousarray(seq, np.float32).reshape(-1), torch.float32)
-            return _apply(x, seq_d, seq_d.numel(), binary)
+            return _apply(x, seq_d, seq_d.numel(), binary, self._io_rdtype or self.rdtype)
         seq_d, period = self._random_sequence(x.shape, s)
-        return _apply(x, seq_d, period, binary)
+        return _apply(x, seq_d, period, binary, self._io_rdtype or self.rdtype)
 
 
 class TB5GScrambler(Block):
@@ -138,6 +139,7 @@ class TB5GScrambler(Block):
         self._sequence = None
 
     keep_state = property(lambda self: True)
+    _io_rdtype = None
 
     def _build_sequence(self, n):
         seq = torch.empty((len(self._c_init), n), dtype=torch.float32, device=_ffi.device())
@@ -146,15 +148,14 @@ class TB5GScrambler(Block):
         self._sequence, self._seq_len = seq, n
 
     def call(self, x, /, *, binary=None):
-        self._require_single()
         binary = self._binary if binary is None else _check_binary_flag(binary)
-        x = _ffi.to_device(x, torch.float32)
+        x = _ffi.to_device(x, self._io_rdtype or self.rdtype)
         if self._multi_stream:
             assert x.dim() >= 2 and x.shape[-2] == len(self._c_init), \
                 "Dimension of axis=-2 must be equal to len(n_rnti)."
         if self._seq_len != x.shape[-1]:
             self._build_sequence(int(x.shape[-1]))
-        return _apply(x, self._sequence, self._sequence.numel(), binary)
+        return _apply(x, self._sequence, self._sequence.numel(), binary, self._io_rdtype or self.rdtype)
 
 
 class Descrambler(Block):
@@ -173,7 +174,12 @@ class Descrambler(Block):
     scrambler = property(lambda self: self._scrambler)
 
     def call(self, x, /, *, seed=None):
-        if isinstance(self._scrambler, Scrambler):
-            s = seed if seed is not None else self._scrambler.seed
-            return self._scrambler(x, seed=s, binary=self._binary)
-        return self._scrambler(x, binary=self._binary)
+        scr = self._scrambler
+        scr._io_rdtype = self.rdtype               # the descrambler's own precision (scrambling.py:573-583 casts to it)
+        try:
+            if isinstance(scr, Scrambler):
+                s = seed if seed is not None else scr.seed
+                return scr(x, seed=s, binary=self._binary)
+            return scr(x, binary=self._binary)
+        finally:
+            scr._io_rdtype = None

@@ -288,7 +288,6 @@ class GaussianPriorSource(Block):
     J-function): N(-mu, sigma^2) with sigma^2 = 4/no, mu = sigma^2/2."""
 
     def call(self, output_shape, no=None, mi=None):
-        self._require_single()
         if no is None:
             if mi is None:
                 raise ValueError("Either no or mi must be provided.")
@@ -300,5 +299,5 @@ class GaussianPriorSource(Block):
             sigma_llr = float(np.sqrt(4 / no))
             mu_llr = sigma_llr ** 2 / 2
         from ..utils.misc import complex_normal
-        w = complex_normal(list(output_shape), 2.0 * sigma_llr ** 2).as_subclass(torch.Tensor)   # real part ~ N(0, sigma^2)
+        w = complex_normal(list(output_shape), 2.0 * sigma_llr ** 2, precision=self.precision).as_subclass(torch.Tensor)   # real part ~ N(0, sigma^2)
         return wrap((w.real - mu_llr).contiguous())

@@ -39,9 +39,8 @@ class TBDecoder(Block):
         assert input_shapes[-1] == self.n, f"Invalid input shape. Expected input length is {self.n}."
 
     def call(self, inputs):
-        self._require_single()
         enc = self._tb_encoder
-        llr = _ffi.to_device(inputs, torch.float32)
+        llr = _ffi.to_device(inputs, self.rdtype)
         assert llr.shape[-1] == self.n, f"Invalid input shape. Expected input length is {self.n}."
         shape = tuple(llr.shape)
         llr = llr.reshape(-1, enc.num_tx, enc.n)
@@ -61,7 +60,7 @@ class TBDecoder(Block):
         llr_int = torch.empty_like(llr)
         if llr.shape[0]:
             _ffi.check(_ffi.lib().samd_gather3(_ffi.ptr(llr), _ffi.ptr(zero), _ffi.ptr(perm), llr.shape[0], 1, n_full, 1,
-                                               n_full, 1, _ffi.ptr(llr_int), _ffi.stream()), "TBDecoder deinterleaver")
+                                               n_full, llr.element_size() // 4, _ffi.ptr(llr_int), _ffi.stream()), "TBDecoder deinterleaver")
         llr_cb = llr_int.reshape(-1, enc.num_tx, self._num_cbs, enc.ldpc_encoder.n)
         u_hat_cb = self._decoder(llr_cb)
         if self._cb_crc_decoder is not None:

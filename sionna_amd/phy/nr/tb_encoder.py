@@ -64,14 +64,15 @@ class TBEncoder(Block):
             print(f"Note: actual tb_size={self._tb_size} is slightly different than requested "
                   f"target_tb_size={self._target_tb_size} due to quantization. Internal zero padding will be applied.")
         self._coderate = self._tb_size / self._num_coded_bits
-        self._tb_crc_encoder = CRCEncoder("CRC16" if self._tb_crc_length == 16 else "CRC24A", precision=precision)
-        self._cb_crc_encoder = CRCEncoder("CRC24B", precision=precision) if self._cb_crc_length == 24 else None
+        # the stages work on bits carried as float32 (exact); with precision="double" the block's output is cast (block.py::_bits)
+        self._tb_crc_encoder = CRCEncoder("CRC16" if self._tb_crc_length == 16 else "CRC24A", precision="single")
+        self._cb_crc_encoder = CRCEncoder("CRC24B", precision="single") if self._cb_crc_length == 24 else None
         # lists -> one stream per entry on axis -2 (tb_encoder.py:232-240)
         self._scrambler = TB5GScrambler(n_rnti=self._n_rnti, n_id=self._n_id, binary=True, channel_type=channel_type,
-                                        codeword_index=codeword_index, precision=precision) if use_scrambler else None
+                                        codeword_index=codeword_index, precision="single") if use_scrambler else None
         lmin, lmax = int(np.min(self._cw_lengths)), int(np.max(self._cw_lengths))
         # num_bits_per_symbol=1 deactivates the encoder's own interleaver (tb_encoder.py:243-246)
-        self._encoder = LDPC5GEncoder(self._cb_size, lmax, num_bits_per_symbol=1, precision=precision)
+        self._encoder = LDPC5GEncoder(self._cb_size, lmax, num_bits_per_symbol=1, precision="single")
         perm_short, _ = self._encoder.generate_out_int(lmin, self._num_bits_per_symbol)
         perm_long, _ = self._encoder.generate_out_int(lmax, self._num_bits_per_symbol)
         perm, punc, pos = [], [], 0
@@ -107,7 +108,6 @@ class TBEncoder(Block):
         assert input_shapes[-1] == self.k, f"Invalid input shape. Expected TB length is {self.k}."
 
     def call(self, inputs):
-        self._require_single()
         u = _ffi.to_device(inputs, torch.float32)
         assert u.shape[-1] == self.k, f"Invalid input shape. Expected TB length is {self.k}."
         shape = tuple(u.shape)
@@ -133,4 +133,4 @@ class TBEncoder(Block):
         c = out.reshape(-1, self._num_tx, self.n)
         if self._scrambler is not None:
             c = self._scrambler(c)
-        return wrap(c.reshape(shape[:-1] + (self.n,)))
+        return wrap(self._bits(c.reshape(shape[:-1] + (self.n,))))

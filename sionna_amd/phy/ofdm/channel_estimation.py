@@ -158,8 +158,8 @@ class LSChannelEstimator(Block):
         pilot_re = np.stack([np.flatnonzero(m[a]) for a in range(s)])         # [S, num_pilots] effective grid
         pil = np.asarray(pp.pilots).reshape(s, -1)
         with np.errstate(divide="ignore", invalid="ignore"):
-            inv = np.where(pil != 0, 1 / np.where(pil != 0, pil, 1), 0).astype(np.complex64)      # divide_no_nan
-            ev = np.where(pil != 0, 1 / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(np.float32)
+            inv = np.where(pil != 0, 1 / np.where(pil != 0, pil, 1), 0).astype(self._np_cdtype)      # divide_no_nan
+            ev = np.where(pil != 0, 1 / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(self._np_rdtype)
         if interpolation_type == "nn":
             g = NearestNeighborInterpolator(pp).gather_ind.reshape(s, -1)     # [S, T*F] pilot number
             pilot_re = np.take_along_axis(pilot_re, g, axis=1)
@@ -179,53 +179,54 @@ class LSChannelEstimator(Block):
         """LS estimates at the pilot-carrying resource elements (channel_estimation.py:257-285): y_pilots
         [batch, num_rx, num_rx_ant, num_tx, num_streams_per_tx, num_pilot_symbols] -> (h_ls = y_pilots / pilots with
         divide_no_nan, err_var = no / |pilots|^2 broadcastable to it).  The scaling kernel of ``call`` with an identity gather."""
-        self._require_single()
         pp = self._rg.pilot_pattern
-        yp = _ffi.to_device(y_pilots, torch.complex64).contiguous()
+        yp = _ffi.to_device(y_pilots, self.cdtype).contiguous()
         s, npil = pp.mask.shape[0] * pp.mask.shape[1], pp.num_pilot_symbols
         assert yp.dim() == 6 and tuple(yp.shape[3:]) == (pp.mask.shape[0], pp.mask.shape[1], npil), \
             "y_pilots must have shape [batch, num_rx, num_rx_ant, num_tx, num_streams_per_tx, num_pilot_symbols]"
         pil = np.asarray(pp.pilots).reshape(s, -1)
         with np.errstate(divide="ignore", invalid="ignore"):
-            inv = np.where(pil != 0, 1 / np.where(pil != 0, pil, 1), 0).astype(np.complex64)
-            ev = np.where(pil != 0, 1 / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(np.float32)
+            inv = np.where(pil != 0, 1 / np.where(pil != 0, pil, 1), 0).astype(self._np_cdtype)
+            ev = np.where(pil != 0, 1 / np.where(pil != 0, np.abs(pil) ** 2, 1), 0).astype(self._np_rdtype)
         src = np.arange(s * npil, dtype=np.int32).reshape(s, npil)
         rows = yp.shape[0] * yp.shape[1] * yp.shape[2]
         h_ls = torch.empty_like(yp)
-        src_d, inv_d = _ffi.to_device(src, torch.int32), _ffi.to_device(inv, torch.complex64)   # (alive until the launch is queued)
+        src_d, inv_d = _ffi.to_device(src, torch.int32), _ffi.to_device(inv, self.cdtype)   # (alive until the launch is queued)
         if rows and npil:
-            _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(yp), _ffi.ptr(src_d), _ffi.ptr(inv_d), rows, s, npil, s * npil,
-                                                           _ffi.ptr(h_ls), _ffi.stream()), "LSChannelEstimator.estimate_at_pilot_locations")
-        no = _ffi.to_device(no, torch.float32)
+            _ffi.check(self._ls_fn()(_ffi.ptr(yp), _ffi.ptr(src_d), _ffi.ptr(inv_d), rows, s, npil, s * npil,
+                                     _ffi.ptr(h_ls), _ffi.stream()), "LSChannelEstimator.estimate_at_pilot_locations")
+        no = _ffi.to_device(no, self.rdtype)
         no = no.reshape(tuple(no.shape) + (1,) * (6 - no.dim()))
-        err_var = no * _ffi.to_device(ev, torch.float32).reshape(tuple(pp.mask.shape[:2]) + (npil,))
+        err_var = no * _ffi.to_device(ev, self.rdtype).reshape(tuple(pp.mask.shape[:2]) + (npil,))
         from ..block import wrap
         return wrap(h_ls), wrap(err_var)
 
+    def _ls_fn(self):
+        return _ffi.lib().samd_ls_gather_scale_c128 if self.precision == "double" else _ffi.lib().samd_ls_gather_scale_c64
+
     def call(self, y, no):
-        self._require_single()
         rg = self._rg
-        y = _ffi.to_device(y, torch.complex64)
+        dbl = self.precision == "double"      # float64: csrc/f64_ofdm.hip, h_hat always materialised (the fused kernels are float32)
+        y = _ffi.to_device(y, self.cdtype)
         assert y.dim() == 5 and y.shape[-2:] == (rg.num_ofdm_symbols, rg.fft_size), \
             "y must have shape [batch, num_rx, num_rx_ant, num_ofdm_symbols, fft_size]"
         if self._dev is None:
-            self._dev = (_ffi.to_device(self._src, torch.int32), _ffi.to_device(self._inv, torch.complex64),
-                         _ffi.to_device(self._ev, torch.float32))
+            self._dev = (_ffi.to_device(self._src, torch.int32), _ffi.to_device(self._inv, self.cdtype),
+                         _ffi.to_device(self._ev, self.rdtype))
         src, inv, ev = self._dev
         s, n_out = src.shape
         rows = y.shape[0] * y.shape[1] * y.shape[2]
-        h_hat = torch.empty(tuple(y.shape[:3]) + self._out_shape, dtype=torch.complex64, device=y.device)
+        h_hat = torch.empty(tuple(y.shape[:3]) + self._out_shape, dtype=self.cdtype, device=y.device)
 
         def fill_h(out):
-            _ffi.check(_ffi.lib().samd_ls_gather_scale_c64(_ffi.ptr(y), _ffi.ptr(src), _ffi.ptr(inv), rows, s, n_out,
-                                                           rg.num_ofdm_symbols * rg.fft_size, _ffi.ptr(out),
-                                                           _ffi.stream()), "LSChannelEstimator")
+            _ffi.check(self._ls_fn()(_ffi.ptr(y), _ffi.ptr(src), _ffi.ptr(inv), rows, s, n_out,
+                                     rg.num_ofdm_symbols * rg.fft_size, _ffi.ptr(out), _ffi.stream()), "LSChannelEstimator")
         # err_var = no / |pilot|^2, broadcastable to h_hat (channel_estimation.py:276-283); `no` has the
         # first n <= 3 dims of [batch, num_rx, num_rx_ant] - a handful of elements, plain broadcasting
-        no = _ffi.to_device(no, torch.float32)
+        no = _ffi.to_device(no, self.rdtype)
         no3 = no.reshape(tuple(no.shape) + (1,) * (3 - no.dim()))
         no = no3.reshape(tuple(no3.shape) + (1,) * len(self._out_shape))
-        if self._interpolation_type == "nn" and self._defer:
+        if self._interpolation_type == "nn" and self._defer and not dbl:
             # nearest-neighbour interpolation: h_hat is a gather of the LS estimates at the pilots.  It is returned DEFERRED
             # (block.py): the fused LS + LMMSE (+ demapper) kernel of LMMSEEqualizer / LinearDetector works from the
             # recipe and never materialises it; any other use fills it with the gather kernel first.
@@ -241,12 +242,15 @@ class LSChannelEstimator(Block):
         fill_h(h_hat)
         err_var = no * ev.reshape(self._out_shape)
         if self._lin is not None:
+            if dbl and isinstance(self._lin, LinearInterpolator):
+                raise NotImplementedError("LSChannelEstimator: the linear interpolator kernel is precision='single' only "
+                                          "(interpolation_type='nn' and LMMSEInterpolator run in double)")
             # a foreign interpolator sees err_var broadcast to h_hat's shape like in the reference (channel_estimation.py:160-163);
             # the built-in one keeps the leading [batch, num_rx, num_rx_ant] dims unexpanded (its kernel is linear in them)
             lead = tuple(err_var.shape[:3]) if isinstance(self._lin, LinearInterpolator) else tuple(h_hat.shape[:3])
             err_var = torch.broadcast_to(err_var, lead + self._out_shape)
             h_hat, err_var = self._lin(h_hat, err_var.contiguous())
-            h_hat, err_var = _ffi.to_device(h_hat, torch.complex64), _ffi.to_device(err_var, torch.float32)
+            h_hat, err_var = _ffi.to_device(h_hat, self.cdtype), _ffi.to_device(err_var, self.rdtype)
         return h_hat, torch.clamp_min(err_var, 0.)
 
 

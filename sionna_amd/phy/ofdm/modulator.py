@@ -1,6 +1,6 @@
 """``OFDMModulator`` / ``OFDMDemodulator`` - mirrors of reference src/sionna/phy/ofdm/
 modulator.py:13-124 and demodulator.py:14-203.  The transform is rocFFT's, reached through
-``samd_ofdm_modulate_c64`` / ``samd_ofdm_demodulate_c64``."""
+``samd_ofdm_modulate_c64`` / ``samd_ofdm_demodulate_c64`` (``_c128`` with ``precision="double"``)."""
 import numpy as np
 import torch
 
@@ -49,8 +49,7 @@ class OFDMModulator(Block):
         self._cyclic_prefix_length = v.astype(np.int32)
 
     def call(self, inputs):
-        self._require_single()
-        x = _ffi.to_device(inputs, torch.complex64)
+        x = _ffi.to_device(inputs, self.cdtype)
         nsym, n = int(x.shape[-2]), int(x.shape[-1])
         key = (nsym, n)
         if key not in self._tables:
@@ -60,11 +59,11 @@ class OFDMModulator(Block):
         cp, off, max_cp, out_len = self._tables[key]
         lead = tuple(x.shape[:-2])
         rows = int(np.prod(lead)) if lead else 1
-        work = torch.empty((rows, nsym, n), dtype=torch.complex64, device=x.device)
-        out = torch.empty(lead + (out_len,), dtype=torch.complex64, device=x.device)
-        _ffi.check(_ffi.lib().samd_ofdm_modulate_c64(_ffi.ptr(x), rows, nsym, n, _ffi.ptr(cp), _ffi.ptr(off), max_cp,
-                                                     out_len, _ffi.ptr(work), _ffi.ptr(out), _ffi.stream()),
-                   "OFDMModulator")
+        work = torch.empty((rows, nsym, n), dtype=self.cdtype, device=x.device)
+        out = torch.empty(lead + (out_len,), dtype=self.cdtype, device=x.device)
+        fn = _ffi.lib().samd_ofdm_modulate_c128 if self.precision == "double" else _ffi.lib().samd_ofdm_modulate_c64
+        _ffi.check(fn(_ffi.ptr(x), rows, nsym, n, _ffi.ptr(cp), _ffi.ptr(off), max_cp,
+                      out_len, _ffi.ptr(work), _ffi.ptr(out), _ffi.stream()), "OFDMModulator")
         return wrap(out)
 
 
@@ -90,8 +89,7 @@ class OFDMDemodulator(Block):
     cyclic_prefix_length = property(lambda self: self._cyclic_prefix_length)
 
     def call(self, inputs):
-        self._require_single()
-        y = _ffi.to_device(inputs, torch.complex64)
+        y = _ffi.to_device(inputs, self.cdtype)
         in_len, n = int(y.shape[-1]), self._fft_size
         if in_len not in self._tables:
             cp0 = self._cyclic_prefix_length
@@ -105,9 +103,9 @@ class OFDMDemodulator(Block):
         cp, off, nsym = self._tables[in_len]
         lead = tuple(y.shape[:-1])
         rows = int(np.prod(lead)) if lead else 1
-        work = torch.empty((rows, nsym, n), dtype=torch.complex64, device=y.device)
-        out = torch.empty(lead + (nsym, n), dtype=torch.complex64, device=y.device)
-        _ffi.check(_ffi.lib().samd_ofdm_demodulate_c64(_ffi.ptr(y), rows, in_len, nsym, n, _ffi.ptr(cp), _ffi.ptr(off),
-                                                       self._l_min, _ffi.ptr(work), _ffi.ptr(out), _ffi.stream()),
-                   "OFDMDemodulator")
+        work = torch.empty((rows, nsym, n), dtype=self.cdtype, device=y.device)
+        out = torch.empty(lead + (nsym, n), dtype=self.cdtype, device=y.device)
+        fn = _ffi.lib().samd_ofdm_demodulate_c128 if self.precision == "double" else _ffi.lib().samd_ofdm_demodulate_c64
+        _ffi.check(fn(_ffi.ptr(y), rows, in_len, nsym, n, _ffi.ptr(cp), _ffi.ptr(off), self._l_min, _ffi.ptr(work),
+                      _ffi.ptr(out), _ffi.stream()), "OFDMDemodulator")
         return wrap(out)

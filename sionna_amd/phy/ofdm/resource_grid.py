@@ -148,22 +148,21 @@ class ResourceGridMapper(Block):
         self._tables = None
 
     def call(self, inputs):
-        self._require_single()
         rg = self._resource_grid
         if self._tables is None:
             dp, pp = rg._positions()
-            pil = rg.pilot_pattern.pilots.reshape(dp.shape[0], -1).astype(np.complex64)
-            self._tables = (_dev_i32(dp), _dev_i32(pp), _ffi.to_device(pil, torch.complex64))
+            pil = np.asarray(rg.pilot_pattern.pilots).reshape(dp.shape[0], -1)
+            self._tables = (_dev_i32(dp), _dev_i32(pp), _ffi.to_device(pil, self.cdtype))
         dp, pp, pil = self._tables
-        x = _ffi.to_device(inputs, torch.complex64)
+        x = _ffi.to_device(inputs, self.cdtype)
         b = x.shape[0]
         s, nd, npil = dp.shape[0], rg.num_data_symbols, pil.shape[1]
         assert tuple(x.shape[1:]) == (rg.num_tx, rg.num_streams_per_tx, nd), "unexpected input shape"
         out = torch.empty((b, rg.num_tx, rg.num_streams_per_tx, rg.num_ofdm_symbols, rg.fft_size),
-                          dtype=torch.complex64, device=x.device)
-        _ffi.check(_ffi.lib().samd_rg_map_c64(_ffi.ptr(x), _ffi.ptr(pil) if npil else None, _ffi.ptr(dp), _ffi.ptr(pp),
-                                              b, s, dp.shape[1], nd, npil, _ffi.ptr(out), _ffi.stream()),
-                   "ResourceGridMapper")
+                          dtype=self.cdtype, device=x.device)
+        fn = _ffi.lib().samd_rg_map_c128 if self.precision == "double" else _ffi.lib().samd_rg_map_c64
+        _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(pil) if npil else None, _ffi.ptr(dp), _ffi.ptr(pp), b, s, dp.shape[1], nd, npil,
+                      _ffi.ptr(out), _ffi.stream()), "ResourceGridMapper")
         return out
 
 
@@ -177,10 +176,10 @@ class RemoveNulledSubcarriers(Block):
         self._dev = None
 
     def call(self, inputs):
-        self._require_single()
         x = inputs
         cplx = x.dtype.is_complex
-        x = _ffi.to_device(x, torch.complex64 if cplx else torch.float32)
+        x = _ffi.to_device(x, self.cdtype if cplx else self.rdtype)
+        el = (2 if cplx else 1) * (2 if self.precision == "double" else 1)       # floats per element
         assert x.shape[-1] == self._fft_size
         if self._dev is None:
             self._dev = (_dev_i32(self._sc_ind.reshape(1, -1)), _dev_i32(np.zeros(1)))
@@ -188,7 +187,7 @@ class RemoveNulledSubcarriers(Block):
         rows = x.numel() // self._fft_size
         out = torch.empty(tuple(x.shape[:-1]) + (len(self._sc_ind),), dtype=x.dtype, device=x.device)
         _ffi.check(_ffi.lib().samd_gather3(_ffi.ptr(x), _ffi.ptr(grp), _ffi.ptr(idx), rows, 1, self._fft_size, 1,
-                                           len(self._sc_ind), 2 if cplx else 1, _ffi.ptr(out), _ffi.stream()),
+                                           len(self._sc_ind), el, _ffi.ptr(out), _ffi.stream()),
                    "RemoveNulledSubcarriers")
         return out
 
@@ -203,10 +202,10 @@ class ResourceGridDemapper(Block):
         self._dev = None
 
     def call(self, y):  # pylint: disable=arguments-renamed
-        self._require_single()
         rg, sm = self._rg, self._sm
         cplx = y.dtype.is_complex
-        y = _ffi.to_device(y, torch.complex64 if cplx else torch.float32)
+        y = _ffi.to_device(y, self.cdtype if cplx else self.rdtype)
+        el = (2 if cplx else 1) * (2 if self.precision == "double" else 1)       # floats per element
         extra = y.dim() == 6
         if extra:   # [b, rx, s, T, fft, D] -> treat D as part of the batch
             d = y.shape[-1]
@@ -223,7 +222,7 @@ class ResourceGridDemapper(Block):
         g_out, n_out = idx.shape
         out = torch.empty((b, sm.num_tx, sm.num_streams_per_tx, n_out), dtype=y.dtype, device=y.device)
         _ffi.check(_ffi.lib().samd_gather3(_ffi.ptr(y), _ffi.ptr(grp), _ffi.ptr(idx), b, g_in, n_in, g_out, n_out,
-                                           2 if cplx else 1, _ffi.ptr(out), _ffi.stream()), "ResourceGridDemapper")
+                                           el, _ffi.ptr(out), _ffi.stream()), "ResourceGridDemapper")
         if extra:
             out = out.reshape((-1, d) + tuple(out.shape[1:])).permute(0, 2, 3, 4, 1).contiguous()
         return out

@@ -48,9 +48,15 @@ def hard_decisions(llr):
 
 def complex_normal(shape, var=1.0, precision=None):
     """CN(0, var) samples on the device Philox stream (misc.py:19-54)."""
-    if precision not in (None, "single") or (precision is None and config.precision != "single"):
-        raise NotImplementedError("complex_normal: the MI355X kernels implement precision='single' only")
     shape = tuple(int(s) for s in shape)
+    if (config.precision if precision is None else precision) == "double":
+        # the float32 stream's uniforms, Box-Muller evaluated in double (oracle/f64_ofdm.py::complex_normal)
+        x = torch.empty(shape, dtype=torch.complex128, device=_ffi.device())
+        no = torch.tensor([float(var)], dtype=torch.float64, device=x.device)
+        rng = config.rng
+        _ffi.check(_ffi.lib().samd_awgn_c128(None, _ffi.ptr(no), 1, rng.seed, rng.next_call(), x.numel(), _ffi.ptr(x),
+                                             _ffi.stream()), "complex_normal")
+        return x
     x = torch.zeros(shape, dtype=torch.complex64, device=_ffi.device())
     no = torch.tensor([float(var)], dtype=torch.float32, device=x.device)
     rng = config.rng

@@ -176,3 +176,182 @@ def test_ofdm_lmmse_equalizer_double_vs_oracle(phy):
     assert np.allclose(_np(x), xr, rtol=2e-6, atol=2e-6) and np.allclose(_np(ne), nr, rtol=2e-6, atol=2e-6)
     xs, ns = phy.ofdm.LMMSEEqualizer(rg, sm)(y.astype(np.complex64), h.astype(np.complex64), ev.astype(np.float32), no.astype(np.float32))
     assert np.allclose(_np(xs), _np(x), rtol=2e-3, atol=2e-4) and np.allclose(_np(ns), _np(ne), rtol=2e-3, atol=2e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# precision="double" for the OFDM link blocks of config C4 (csrc/f64_ofdm.hip, csrc/ofdm_time.hip) against the float64
+# restatement oracle/f64_ofdm.py on the same inputs and the same Philox stream positions: rtol/atol 1e-9 (float64
+# arithmetic; sums of <= 100 terms of magnitude <= 10).
+from oracle import f64_ofdm as o64, ofdm as o32
+
+
+def _c128(rng, shape, scale=1.0):
+    return (rng.normal(size=shape) + 1j * rng.normal(size=shape)) * scale
+
+
+def _close9(got, ref):
+    got, ref = np.asarray(got), np.asarray(ref)
+    assert got.shape == ref.shape and got.dtype == ref.dtype, (got.shape, ref.shape, got.dtype, ref.dtype)
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-9), float(np.max(np.abs(got - ref)))
+    return True
+
+
+def _grids64(phy, **kw):
+    base = dict(num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6], dc_null=True,
+                pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    base.update(kw)
+    rg = phy.ofdm.ResourceGrid(14, 76, 15e3, precision="double", **base)
+    org = o32.ResourceGrid(14, 76, 15e3, **base)
+    assert rg.pilot_pattern.pilots.dtype == np.complex128
+    org.pilot_pattern.pilots = np.asarray(rg.pilot_pattern.pilots)             # the oracle sees the block's own pilots
+    return rg, org
+
+
+def test_complex_normal_awgn_double(phy):
+    phy.config.seed = 5
+    w = phy.utils.complex_normal([3, 1001], 2.5, precision="double")
+    assert w.dtype == torch.complex128
+    _close9(_np(w).reshape(-1), o64.complex_normal(5, 0, 3003, 2.5))
+    # the float32 stream's realisation to float32 rounding
+    phy.config.seed = 5
+    w32 = _np(phy.utils.complex_normal([3, 1001], 2.5))
+    assert np.allclose(w32, _np(w), rtol=0, atol=2e-6)
+    rng = np.random.default_rng(0)
+    x = _c128(rng, (4, 7, 33))
+    for no in (np.float64(0.3), rng.uniform(0.1, 2.0, size=(4, 1, 1)), rng.uniform(0.1, 2.0, size=(4, 7, 33))):
+        phy.config.seed = 9
+        y = phy.channel.AWGN(precision="double")(x, no)
+        assert y.dtype == torch.complex128
+        _close9(_np(y), o64.awgn(x, no, 9, 0))
+
+
+def test_resource_grid_blocks_double(phy):
+    rg, org = _grids64(phy, num_tx=2, num_guard_carriers=[3, 4])
+    sm = phy.mimo.StreamManagement([[1, 0], [0, 1]], 2)
+    rng = np.random.default_rng(1)
+    x = _c128(rng, (5, 2, 2, rg.num_data_symbols))
+    grid = phy.ofdm.ResourceGridMapper(rg, precision="double")(x)
+    assert grid.dtype == torch.complex128 and np.array_equal(_np(grid), o64.rg_map(org, x))
+    eff = phy.ofdm.RemoveNulledSubcarriers(rg, precision="double")(grid)
+    assert eff.dtype == torch.complex128 and np.array_equal(_np(eff), o32.remove_nulled(org, _np(grid)))
+    back = phy.ofdm.ResourceGridDemapper(rg, sm, precision="double")(grid)
+    assert back.dtype == torch.complex128 and np.array_equal(_np(back), x)
+    real = torch.from_numpy(rng.normal(size=(5, 2, 2, 14, 76))).cuda()
+    assert np.array_equal(_np(phy.ofdm.RemoveNulledSubcarriers(rg, precision="double")(real)), o32.remove_nulled(org, _np(real)))
+
+
+@pytest.mark.parametrize("model", ["A", "D"])
+def test_tdl_ofdm_channel_double(phy, model):
+    phy.config.seed = 11
+    tdl = phy.channel.tr38901.TDL(model, 300e-9, 2.6e9, min_speed=3., max_speed=30., num_rx_ant=4, num_tx_ant=2, precision="double")
+    fs = 1 / 71.4e-6
+    a, tau = tdl(16, 14, fs)
+    assert a.dtype == torch.complex128 and tau.dtype == torch.float64
+    ref_a, ref_tau = o64.tdl_cir(11, 0, 16, 14, fs, tdl.delays, tdl._mean_powers, tdl._min_doppler, tdl._max_doppler, 4, 2, 20,
+                                 los_power=tdl._los_power if tdl.los else None)
+    _close9(_np(a), ref_a)
+    _close9(_np(tau), ref_tau)
+    # the float32 block draws the same realisation
+    phy.config.seed = 11
+    a32, _ = phy.channel.tr38901.TDL(model, 300e-9, 2.6e9, min_speed=3., max_speed=30., num_rx_ant=4, num_tx_ant=2)(16, 14, fs)
+    assert np.allclose(_np(a32), ref_a, rtol=1e-3, atol=2e-4)
+    fr = phy.channel.subcarrier_frequencies(76, 15e3, precision="double")
+    assert fr.dtype == np.float64
+    for norm in (False, True):
+        h = phy.channel.cir_to_ofdm_channel(fr, a, tau, normalize=norm)
+        assert h.dtype == torch.complex128
+        _close9(_np(h), o64.cir_to_ofdm_channel(fr, ref_a, ref_tau, normalize=norm))
+    rng = np.random.default_rng(2)
+    x = _c128(rng, (16, 1, 2, 14, 76))
+    y = phy.channel.ApplyOFDMChannel(precision="double")(x, h)
+    _close9(_np(y), o64.apply_ofdm_channel(x, _np(h)))
+
+
+def test_ofdm_channel_block_and_rayleigh_double(phy):
+    rg, org = _grids64(phy)
+    phy.config.seed = 21
+    tdl = phy.channel.tr38901.TDL("B", 100e-9, 3.5e9, min_speed=5., num_rx_ant=4, num_tx_ant=2, precision="double")
+    ch = phy.channel.OFDMChannel(tdl, rg, normalize_channel=True, return_channel=True, precision="double")
+    rng = np.random.default_rng(3)
+    x = _c128(rng, (8, 1, 2, 14, 76))
+    y, h = ch(x, 0.05)
+    assert y.dtype == torch.complex128 and h.dtype == torch.complex128
+    ref_a, ref_tau = o64.tdl_cir(21, 0, 8, 14, 1 / rg.ofdm_symbol_duration, tdl.delays, tdl._mean_powers, tdl._min_doppler,
+                                 tdl._max_doppler, 4, 2, 20)
+    ref_h = o64.cir_to_ofdm_channel(o64.subcarrier_frequencies(76, 15e3), ref_a, ref_tau, normalize=True)
+    _close9(_np(h), ref_h)
+    _close9(_np(y), o64.awgn(o64.apply_ofdm_channel(x, ref_h), 0.05, 21, 4))       # TDL consumes calls 0..3
+    phy.config.seed = 4
+    a, tau = phy.channel.RayleighBlockFading(1, 4, 1, 2, precision="double")(6, 14)
+    assert a.dtype == torch.complex128 and tau.dtype == torch.float64 and a.shape == (6, 1, 4, 1, 2, 1, 14)
+    _close9(_np(a)[..., 0].reshape(-1), o64.complex_normal(4, 0, 48, 1.0))
+
+
+def test_ls_estimator_double(phy):
+    rg, org = _grids64(phy, num_tx=2, num_guard_carriers=[3, 4])
+    rng = np.random.default_rng(4)
+    y = _c128(rng, (3, 2, 4, 14, 76))
+    for no in (0.1, rng.uniform(0.05, 0.5, size=(3,)), rng.uniform(0.05, 0.5, size=(3, 2, 4))):
+        est = phy.ofdm.LSChannelEstimator(rg, interpolation_type="nn", precision="double")
+        h, ev = est(y, no)
+        rh, rev = o64.ls_estimate(org, y, no)
+        assert h.dtype == torch.complex128 and ev.dtype == torch.float64
+        _close9(_np(h), rh)
+        _close9(np.broadcast_to(_np(ev), rev.shape), rev)
+    est = phy.ofdm.LSChannelEstimator(rg, interpolation_type=None, precision="double")
+    h, ev = est(y, 0.1)
+    rh, rev = o64.ls_estimate(org, y, 0.1, interpolation=None)
+    _close9(_np(h), rh)
+    _close9(np.broadcast_to(_np(ev), rh.shape), np.broadcast_to(rev, rh.shape))
+    with pytest.raises(NotImplementedError):
+        phy.ofdm.LSChannelEstimator(rg, interpolation_type="lin", precision="double")(y, 0.1)
+
+
+@pytest.mark.parametrize("fft,cp", [(76, 6), (64, [5] + [4] * 6), (128, 0)])
+def test_ofdm_modulator_demodulator_double(phy, fft, cp):
+    rng = np.random.default_rng(5)
+    nsym = 14 if np.ndim(cp) == 0 else len(cp)
+    x = _c128(rng, (3, 2, nsym, fft))
+    t = phy.ofdm.OFDMModulator(cp, precision="double")(x)
+    assert t.dtype == torch.complex128
+    _close9(_np(t), o64.ofdm_modulate(x, cp))
+    for l_min in (0, -3):
+        back = phy.ofdm.OFDMDemodulator(fft, l_min, cp, precision="double")(t)
+        assert back.dtype == torch.complex128
+        _close9(_np(back), o64.ofdm_demodulate(_np(t), fft, l_min, cp, nsym))
+        if l_min == 0:
+            _close9(_np(back), x)
+
+
+def test_bit_domain_blocks_double(phy):
+    """CRC, Polar / linear encoders, scramblers, interleavers, transport-block chain with precision="double": bits are exact
+    in either precision (the kernels carry them as float32); soft values go through float64 kernels (sign flips, gathers)."""
+    rng = np.random.default_rng(6)
+    u = rng.integers(0, 2, (7, 100)).astype(np.float64)
+    for cls, args in ((phy.fec.crc.CRCEncoder, ("CRC24A",)), (phy.fec.polar.Polar5GEncoder, (100, 256)),):
+        d, s = cls(*args, precision="double"), cls(*args)
+        out = d(u)
+        assert out.dtype == torch.float64 and np.array_equal(_np(out), _np(s(u.astype(np.float32))).astype(np.float64))
+    enc = phy.fec.crc.CRCEncoder("CRC16", precision="double")
+    x, ok = phy.fec.crc.CRCDecoder(enc, precision="double")(enc(u))
+    assert x.dtype == torch.float64 and np.array_equal(_np(x), u) and bool(ok.all())
+    llr = rng.normal(size=(7, 96)) * 4
+    scr = phy.fec.scrambling.Scrambler(seed=3, binary=False, precision="double")
+    y = scr(llr)
+    s32 = _np(phy.fec.scrambling.Scrambler(seed=3, binary=False)(np.ones((7, 96), np.float32))).astype(np.float64)
+    assert y.dtype == torch.float64 and np.array_equal(_np(y), llr * s32)
+    assert np.array_equal(_np(phy.fec.scrambling.Descrambler(scr, binary=False)(y)), llr)
+    for il in (phy.fec.interleaving.RowColumnInterleaver(8, precision="double"),
+               phy.fec.interleaving.RandomInterleaver(seed=2, precision="double")):
+        z = il(llr)
+        assert z.dtype == torch.float64 and np.array_equal(np.sort(_np(z), -1), np.sort(llr, -1))
+        assert np.array_equal(_np(phy.fec.interleaving.Deinterleaver(il)(z)), llr)
+    # transport block: encode in double, decode double LLRs
+    tb = phy.nr.TBEncoder(target_tb_size=1000, num_coded_bits=2400, target_coderate=1000 / 2400, num_bits_per_symbol=4,
+                          n_rnti=5, n_id=7, precision="double")
+    bits = rng.integers(0, 2, (3, tb.k)).astype(np.float64)
+    c = tb(bits)
+    assert c.dtype == torch.float64
+    dec = phy.nr.TBDecoder(tb, num_bp_iter=10, cn_update="minsum", precision="double")
+    u_hat, crc_ok = dec((2 * _np(c) - 1) * 6.0 + rng.normal(size=c.shape) * 0.5)
+    assert u_hat.dtype == torch.float64 and np.array_equal(_np(u_hat), bits) and bool(crc_ok.all())

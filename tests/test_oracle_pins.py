@@ -152,3 +152,35 @@ def test_simd_c_baseline_equals_scalar_c_oracle(k, n, m, bg, batch, iters, ebno)
         llr_full = dec.rate_recover(llr)
         assert np.array_equal(cbind.bp_decode(dec, llr_full, simd=True), cbind.bp_decode(dec, llr_full)), cn
         assert np.array_equal(cbind.bp_decode(dec, llr_full, simd=True, hard_out=True), cbind.bp_decode(dec, llr_full, hard_out=True))
+
+
+def test_f64_ofdm_oracle_is_the_float32_oracle_in_double():
+    """oracle/f64_ofdm.py (specification of precision="double" for the OFDM link blocks) draws the same Philox realisation as
+    the float32 oracle - which is pinned to the executed reference - and evaluates the same formulas: both agree to float32
+    rounding on the same inputs."""
+    from oracle import f64_ofdm as o64, ofdm as o32, utils as outil
+    w64, w32 = o64.complex_normal(3, 1, 999, 1.7), outil.complex_normal(3, 1, 999, 1.7)
+    assert w64.dtype == np.complex128 and np.allclose(w64, w32, rtol=0, atol=2e-6)
+    a64, t64 = o64.tdl_cir(7, 0, 4, 14, 14e3, [0, 3e-8, 2e-7], [0.5, 0.3, 0.2], 10.0, 200.0, 2, 2, 20, los_power=0.4)
+    a32, t32 = o32.tdl_cir(7, 0, 4, 14, 14e3, [0, 3e-8, 2e-7], [0.5, 0.3, 0.2], 10.0, 200.0, 2, 2, 20, los_power=0.4)
+    assert np.allclose(a64, a32, rtol=1e-3, atol=2e-4) and np.allclose(t64, t32)
+    fr = o64.subcarrier_frequencies(76, 15e3)
+    assert np.array_equal(fr.astype(np.float32), o32.subcarrier_frequencies(76, 15e3))
+    for norm in (False, True):
+        h64 = o64.cir_to_ofdm_channel(fr, a64, t64, norm)
+        assert np.allclose(h64, o32.cir_to_ofdm_channel(fr.astype(np.float32), a32, t32, norm), rtol=1e-3, atol=1e-3)
+    rng = np.random.default_rng(0)
+    x = (rng.normal(size=(4, 1, 2, 14, 76)) + 1j * rng.normal(size=(4, 1, 2, 14, 76)))
+    assert np.allclose(o64.apply_ofdm_channel(x, h64), o32.apply_ofdm_channel(x.astype(np.complex64), h64.astype(np.complex64)), rtol=1e-4, atol=1e-4)
+    xt = o64.ofdm_modulate(x, 6)
+    assert np.allclose(xt, o32.ofdm_modulate(x.astype(np.complex64), 6), rtol=1e-5, atol=1e-5)
+    assert np.allclose(o64.ofdm_demodulate(xt, 76, -2, 6), o32.ofdm_demodulate(xt.astype(np.complex64), 76, -2, 6), rtol=1e-4, atol=1e-4)
+    assert np.allclose(o64.ofdm_demodulate(xt, 76, 0, 6), x, rtol=1e-12, atol=1e-12)
+    rg = o32.ResourceGrid(14, 76, 15e3, num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[5, 6],
+                          dc_null=True, pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    d = (rng.normal(size=(3, 1, 2, rg.num_data_symbols)) + 1j * rng.normal(size=(3, 1, 2, rg.num_data_symbols)))
+    assert np.allclose(o64.rg_map(rg, d), o32.rg_map(rg, d.astype(np.complex64)), rtol=1e-6, atol=1e-6)
+    y = (rng.normal(size=(3, 1, 4, 14, 76)) + 1j * rng.normal(size=(3, 1, 4, 14, 76)))
+    h64, e64 = o64.ls_estimate(rg, y, 0.2)
+    h32, e32 = o32.ls_estimate(rg, y.astype(np.complex64), 0.2)
+    assert np.allclose(h64, h32, rtol=1e-5, atol=1e-5) and np.allclose(e64, e32, rtol=1e-5, atol=1e-6)
