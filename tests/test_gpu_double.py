@@ -203,7 +203,13 @@ def _grids64(phy, **kw):
     rg = phy.ofdm.ResourceGrid(14, 76, 15e3, precision="double", **base)
     org = o32.ResourceGrid(14, 76, 15e3, **base)
     assert rg.pilot_pattern.pilots.dtype == np.complex128
-    org.pilot_pattern.pilots = np.asarray(rg.pilot_pattern.pilots)             # the oracle sees the block's own pilots
+    opp = org.pilot_pattern
+
+    class _Pilots64:                                                            # the oracle sees the block's own (float64) pilots
+        mask, num_pilot_symbols, num_data_symbols = opp.mask, opp.num_pilot_symbols, opp.num_data_symbols
+        pilots = np.asarray(rg.pilot_pattern.pilots)
+    assert np.allclose(_Pilots64.pilots, opp.pilots, rtol=1e-6, atol=1e-7)
+    org.pilot_pattern = _Pilots64
     return rg, org
 
 
@@ -215,7 +221,7 @@ def test_complex_normal_awgn_double(phy):
     # the float32 stream's realisation to float32 rounding
     phy.config.seed = 5
     w32 = _np(phy.utils.complex_normal([3, 1001], 2.5))
-    assert np.allclose(w32, _np(w), rtol=0, atol=2e-6)
+    assert np.allclose(w32, _np(w), rtol=0, atol=2e-5)
     rng = np.random.default_rng(0)
     x = _c128(rng, (4, 7, 33))
     for no in (np.float64(0.3), rng.uniform(0.1, 2.0, size=(4, 1, 1)), rng.uniform(0.1, 2.0, size=(4, 7, 33))):
