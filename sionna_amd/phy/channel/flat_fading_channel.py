@@ -46,16 +46,15 @@ class ApplyFlatFadingChannel(Block):
         self._awgn = AWGN(precision=self.precision)
 
     def call(self, x, h, no=None):
-        self._require_single()
-        x = _ffi.to_device(x, torch.complex64)
-        h = _ffi.to_device(h, torch.complex64)
+        x = _ffi.to_device(x, self.cdtype)
+        h = _ffi.to_device(h, self.cdtype)
         b, rx, tx = h.shape
         x = torch.broadcast_to(x, (b, tx)).contiguous()
-        y = torch.empty((b, rx), dtype=torch.complex64, device=x.device)
+        y = torch.empty((b, rx), dtype=self.cdtype, device=x.device)
         if b:
             h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
-            _ffi.check(_ffi.lib().samd_apply_ofdm_channel_c64(_ffi.ptr(x), _ffi.ptr(h), b, rx, tx, 1, _ffi.ptr(y),
-                                                              _ffi.stream()), "ApplyFlatFadingChannel")
+            fn = _ffi.lib().samd_apply_ofdm_channel_c128 if self.precision == "double" else _ffi.lib().samd_apply_ofdm_channel_c64
+            _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(h), b, rx, tx, 1, _ffi.ptr(y), _ffi.stream()), "ApplyFlatFadingChannel")
         if no is not None:
             y = self._awgn(y, no)
         return wrap(y)

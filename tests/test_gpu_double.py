@@ -361,3 +361,14 @@ def test_bit_domain_blocks_double(phy):
     dec = phy.nr.TBDecoder(tb, num_bp_iter=10, cn_update="minsum", precision="double")
     u_hat, crc_ok = dec((2 * _np(c) - 1) * 6.0 + rng.normal(size=c.shape) * 0.5)
     assert u_hat.dtype == torch.float64 and np.array_equal(_np(u_hat), bits) and bool(crc_ok.all())
+
+
+def test_flat_fading_channel_double(phy):
+    phy.config.seed = 8
+    ch = phy.channel.FlatFadingChannel(3, 5, return_channel=True, precision="double")
+    rng = np.random.default_rng(7)
+    x = _c128(rng, (40, 3))
+    y, h = ch(x, 0.2)
+    assert y.dtype == torch.complex128 and h.dtype == torch.complex128
+    _close9(_np(h).reshape(-1), o64.complex_normal(8, 0, 40 * 5 * 3, 1.0))
+    _close9(_np(y), o64.awgn(np.einsum("brt,bt->br", _np(h), x), 0.2, 8, 1))
