@@ -627,6 +627,15 @@ int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops,
                               int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat,
                               float* crc_status, void* workspace, size_t workspace_bytes,
                               void* stream);
+/* precision = "double" (reference block.py:25-52): the same decoder on float64 LLRs with the arithmetic of the reference's own
+ * float64 NumPy twin (decoding.py:1113-1149: literal log(1 + e^x) and log(1 + e^(x+y)) - log(e^x + e^y), libm) - oracle/polar_scl.c
+ * precision 1.  Always the generic engine: the schedule must use stage-1 SUBTREE records only (what
+ * samd_polar_scl_register_stages() = -1 asks for).  u_hat / crc_status double. */
+size_t samd_polar_scl_workspace_bytes_f64(int batch, int n, int list_size);
+int samd_polar_scl_decode_f64(const double* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
+                              const int32_t* iil_inv, int batch, int n, int k, int list_size, int sc_mode,
+                              uint32_t crc_poly, int crc_len, double* u_hat, double* crc_status,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* PolarBPDecoder.call  fec/polar/decoding.py:1587-1771 (and the decoder Polar5GDecoder(dec_type="BP")
  * instantiates, :1896-1912): num_iter flooding iterations on the polar factor graph - per iteration a

@@ -53,13 +53,14 @@ def scl_list_decode(logits, frozen_pos, n, list_size, use_fast_scl=True, precisi
     return uhat, pm
 
 
-def sc_decode(llr_logits, frozen_pos, n):
-    """PolarSCDecoder.call in the float32 specification arithmetic: logits [B,n] -> u_hat at the info positions."""
-    logits = np.ascontiguousarray(llr_logits, F).reshape(-1, n)
+def sc_decode(llr_logits, frozen_pos, n, precision="f32"):
+    """PolarSCDecoder.call in the float32 specification arithmetic (precision "f64": float64 with the literal boxplus of the
+    reference's NumPy twin): logits [B,n] -> u_hat at the info positions."""
+    logits = np.ascontiguousarray(llr_logits, F if precision == "f32" else np.float64).reshape(-1, n)
     frozen = np.zeros(n, np.int32)
     frozen[np.asarray(frozen_pos, int)] = 1
     out = np.empty((logits.shape[0], n), np.uint8)
-    fn = lib().oracle_polar_sc_decode
+    fn = lib().oracle_polar_sc_decode if precision == "f32" else lib().oracle_polar_sc_decode_f64
     fn.restype, fn.argtypes = C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     assert fn(n, frozen.ctypes.data, logits.ctypes.data, logits.shape[0], out.ctypes.data) == 0
     return out[:, np.setdiff1d(np.arange(n), np.asarray(frozen_pos, int))].astype(F)

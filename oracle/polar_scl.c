@@ -157,6 +157,43 @@ int oracle_polar_sc_decode(int n, const int32_t* frozen, const float* logits, in
   return 0;
 }
 
+/* the same decoder in float64 with the literal boxplus of the reference's NumPy twin (precision 1 above): the specification of
+ * PolarSCDecoder(precision="double") */
+static void sc_rec_f64(const int32_t* frozen, int lo, int m, const double* l, uint8_t* u, uint8_t* x) {
+  if (m > 1) {
+    int nf = 0;
+    for (int i = 0; i < m; ++i) nf += frozen[lo + i];
+    if (nf == m) {
+      memset(u + lo, 0, m);
+      memset(x + lo, 0, m);
+      return;
+    }
+    const int h = m / 2;
+    double buf[512];
+    for (int i = 0; i < h; ++i) buf[i] = cn_op_f64(l[i], l[h + i]);
+    sc_rec_f64(frozen, lo, h, buf, u, x);
+    for (int i = 0; i < h; ++i) buf[i] = (1.0 - 2.0 * (double)x[lo + i]) * l[i] + l[h + i];
+    sc_rec_f64(frozen, lo + h, h, buf, u, x);
+    for (int i = 0; i < h; ++i) x[lo + i] ^= x[lo + h + i];
+  } else if (frozen[lo]) {
+    u[lo] = x[lo] = 0;
+  } else {
+    u[lo] = x[lo] = l[0] > 0.0 ? 0 : 1;
+  }
+}
+
+int oracle_polar_sc_decode_f64(int n, const int32_t* frozen, const double* logits, int batch, uint8_t* u_hat) {
+  if (n < 2 || n > 1024 || (n & (n - 1)) || batch < 0) return -1;
+#pragma omp parallel for schedule(static)
+  for (int b = 0; b < batch; ++b) {
+    double l[1024];
+    uint8_t x[1024];
+    for (int i = 0; i < n; ++i) l[i] = -1.0 * logits[(size_t)b * n + i];
+    sc_rec_f64(frozen, 0, n, l, u_hat + (size_t)b * n, x);
+  }
+  return 0;
+}
+
 int oracle_polar_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

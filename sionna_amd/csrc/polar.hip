@@ -121,14 +121,14 @@ __global__ __launch_bounds__(256) void polar_encode_kernel(const float* __restri
 // the decided bits and the path bookkeeping (~4 KB at n = 1024, L = 8); the top G stages, touched by
 // 2^(G+1) ops per decode, and the channel LLRs live in L2: 32 instead of 2 codewords per CU
 // (measured on MI355X, n=1024 k=512 L=8: 137k -> 642k decodes/s).
-template <int NT>
-__global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+template <int NT, typename R = float>
+__global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgsT<R> p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n = p.n, L = p.L, tid = threadIdx.x;
   const int words = (n + 31) / 32;
-  float* llr = smem;                                      // [L][n/2^G] stage s < m-G at [2^s, 2^(s+1))
+  R* llr = reinterpret_cast<R*>(smem);                                      // [L][n/2^G] stage s < m-G at [2^s, 2^(s+1))
   const int hn = n >> p.gstages;
-  auto stage = [&](int slot, int s) -> float* {           // the 2^s LLRs of stage s held by `slot`
+  auto stage = [&](int slot, int s) -> R* {           // the 2^s LLRs of stage s held by `slot`
     if (s >= p.m - p.gstages) return p.gscratch + ((size_t)blockIdx.x * L + slot) * (n - hn) + ((1 << s) - hn);
     return llr + (size_t)slot * hn + (1 << s);
   };
@@ -140,15 +140,15 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
     return beta + (size_t)slot * hn + (1 << s);
   };
   uint32_t* bits = reinterpret_cast<uint32_t*>(beta + (size_t)L * hn);            // [L][words] decided u bits
-  float* pm = reinterpret_cast<float*>(bits + (size_t)L * words);                 // [L]   by position
-  float* cand = pm + L;                                   // [2L] candidate metrics
-  float* blk = cand + 2 * L;                              // [2L] block metrics (rate-0 / rep)
+  R* pm = reinterpret_cast<R*>((reinterpret_cast<uintptr_t>(bits + (size_t)L * words) + sizeof(R) - 1) & ~(uintptr_t)(sizeof(R) - 1));   // [L] by position
+  R* cand = pm + L;                                   // [2L] candidate metrics
+  R* blk = cand + 2 * L;                              // [2L] block metrics (rate-0 / rep)
   int* order = reinterpret_cast<int*>(blk + 2 * L);       // [L]   position -> slot
   int* new_order = order + L;                             // [L]
   int* clone_src = new_order + L;                         // [L]   for new position: slot to copy from (-1: none)
   int* new_bit = clone_src + L;                           // [L]
-  float* new_pm = reinterpret_cast<float*>(new_bit + L);  // [L]
-  float* red = new_pm + L;                                // [256] reduction scratch
+  R* new_pm = reinterpret_cast<R*>(new_bit + L);  // [L]
+  R* red = new_pm + L;                                // [256] reduction scratch
   // Lazy path copies.  All live paths execute the same op in lockstep and every op rewrites one whole
   // (array, stage) region of every path, so a path always writes into its OWN slot and records that in
   // its pointer table; a clone only inherits the tables (3 x 16 small ints) instead of the parent's n
@@ -161,10 +161,10 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
   // the schedule is read with scalar loads one op ahead (wave-uniform index): no LDS copy
 
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
-    const float* llr_ch = p.llr_in + (size_t)b * n;       // logits: negated where they are read (LLR = -logit)
+    const R* llr_ch = p.llr_in + (size_t)b * n;       // logits: negated where they are read (LLR = -logit)
     for (int i = tid; i < L * words; i += NT) bits[i] = 0u;
     for (int i = tid; i < L * 16; i += NT) { lp[i] = (unsigned char)(i >> 4); bl[i] = lp[i]; br[i] = lp[i]; }
-    if (tid < L) { pm[tid] = tid == 0 ? 0.f : kPolarLlrMax; order[tid] = tid; }         // decoding.py:1029-1033
+    if (tid < L) { pm[tid] = tid == 0 ? (R)0 : (R)kPolarLlrMax; order[tid] = tid; }         // decoding.py:1029-1033
     __syncthreads();
 
     int next_rec = p.ops[0];
@@ -200,12 +200,12 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         for (int w = tid; w < L * half; w += NT) {
           const int pos = w >> (s - 1), j = w & (half - 1);     // half = 2^(s-1): no integer division
           const int slot = order[pos];
-          const float* in = (s == p.m) ? llr_ch : stage(lp[slot * 16 + s], s);
-          const float sg = (s == p.m) ? -1.f : 1.f;
-          const float x = sg * in[j], y = sg * in[j + half];
-          float r;
+          const R* in = (s == p.m) ? llr_ch : stage(lp[slot * 16 + s], s);
+          const R sg = (s == p.m) ? (R)-1 : (R)1;
+          const R x = sg * in[j], y = sg * in[j + half];
+          R r;
           if (op == OP_F) r = cn_op(x, y);
-          else r = (1.f - 2.f * (float)(bstage(bl[slot * 16 + s - 1], s - 1)[j] & 1)) * x + y;  // vn_op :707-714
+          else r = ((R)1 - (R)2 * (R)(bstage(bl[slot * 16 + s - 1], s - 1)[j] & 1)) * x + y;  // vn_op :707-714
           stage(slot, s - 1)[j] = r;
         }
         if (tid < L) lp[order[tid] * 16 + s - 1] = (unsigned char)order[tid];
@@ -233,31 +233,33 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         // block metrics of every live path: m0 = sum softplus(-l), m1 = sum softplus(+l)
         if (sz == 1) {
           if (tid < L) {                                      // one lane per path
-            const float* in = (s == p.m) ? llr_ch : stage(lp[order[tid] * 16 + s], s);
-            const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[0], -kPolarLlrMax, kPolarLlrMax);
-            const float tl = scl_T(fabsf(l));                 // shared by softplus(-l) and softplus(l)
-            blk[tid] = fmaxf(-l, 0.f) + tl;
-            if (info) blk[L + tid] = fmaxf(l, 0.f) + tl;
+            const R* in = (s == p.m) ? llr_ch : stage(lp[order[tid] * 16 + s], s);
+            const R l = clamp_llr(((s == p.m) ? (R)-1 : (R)1) * in[0]);
+            R s0, s1;
+            softplus_pair(l, s0, s1);
+            blk[tid] = s0;
+            if (info) blk[L + tid] = s1;
           }
         } else {
           for (int pos = 0; pos < L; ++pos) {
-            const float* in = (s == p.m) ? llr_ch : stage(lp[order[pos] * 16 + s], s);
+            const R* in = (s == p.m) ? llr_ch : stage(lp[order[pos] * 16 + s], s);
             // defined summation order (oracle/polar_scl.c block_sum_f32): lane l accumulates terms l, l+64, l+128, ...
             // in ascending order, then the halving tree over the 64 lanes (xor butterfly: both operands of every
             // addition are the same two numbers on both lanes, so all lanes hold lane 0's tree)
-            float m0 = 0.f, m1 = 0.f;
+            R m0 = (R)0, m1 = (R)0;
             for (int j = tid; j < sz; j += NT) {
-              const float l = clampf(((s == p.m) ? -1.f : 1.f) * in[j], -kPolarLlrMax, kPolarLlrMax);
-              const float tl = scl_T(fabsf(l));
-              m0 += fmaxf(-l, 0.f) + tl;
-              m1 += fmaxf(l, 0.f) + tl;
+              const R l = clamp_llr(((s == p.m) ? (R)-1 : (R)1) * in[j]);
+              R s0, s1;
+              softplus_pair(l, s0, s1);
+              m0 += s0;
+              m1 += s1;
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { m0 += __shfl_xor(m0, o, 64); m1 += __shfl_xor(m1, o, 64); }
             if constexpr (NT > 64) {                          // fixed-order combination of the waves
               if ((tid & 63) == 0) { red[tid >> 6] = m0; red[8 + (tid >> 6)] = m1; }
               __syncthreads();
-              m0 = 0.f; m1 = 0.f;
+              m0 = (R)0; m1 = (R)0;
               for (int w = 0; w < NT / 64; ++w) { m0 += red[w]; m1 += red[8 + w]; }
               __syncthreads();
             }
@@ -281,8 +283,8 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
         if (p.sc_mode) {
           // PolarSCDecoder leaf: u = 0.5 (1 - sign(l)), exact zero -> 1 (decoding.py:208-212)
           if (tid == 0) {
-            const float l = ((s == p.m) ? -1.f : 1.f) * ((s == p.m) ? llr_ch : stage(lp[order[0] * 16 + s], s))[0];
-            new_order[0] = order[0]; clone_src[0] = -1; new_bit[0] = (l <= 0.f) ? 1 : 0; new_pm[0] = 0.f;
+            const R l = ((s == p.m) ? (R)-1 : (R)1) * ((s == p.m) ? llr_ch : stage(lp[order[0] * 16 + s], s))[0];
+            new_order[0] = order[0]; clone_src[0] = -1; new_bit[0] = (l <= (R)0) ? 1 : 0; new_pm[0] = (R)0;
           }
         } else {
           int* rnk = reinterpret_cast<int*>(red);                                  // [2L] candidate ranks
@@ -292,14 +294,14 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           // every candidate gets g = 64 / 2L lanes, each counting a slice of the comparisons (xor-shuffle sum)
           if (NT == 64 && 2 * L <= 64 && (64 % (2 * L)) == 0) {
             const int g = 64 / (2 * L), c = tid / g, q = tid - c * g, per = (2 * L + g - 1) / g;
-            const float me = cand[c];
+            const R me = cand[c];
             int rank = 0;
             for (int d = q * per; d < min((q + 1) * per, 2 * L); ++d) rank += (cand[d] < me || (cand[d] == me && d < c)) ? 1 : 0;
             for (int o = 1; o < g; o <<= 1) rank += __shfl_xor(rank, o, 64);
             if (q == 0) rnk[c] = rank;
           } else if (tid < 2 * L) {
             int rank = 0;
-            const float me = cand[tid];
+            const R me = cand[tid];
             for (int d = 0; d < 2 * L; ++d) rank += (cand[d] < me || (cand[d] == me && d < tid)) ? 1 : 0;
             rnk[tid] = rank;
           }
@@ -399,7 +401,7 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
     // ---- final selection (decoding.py:1396-1419): CRC over the info bits of every path, penalty, first min
     if (tid < L) {
       const uint32_t* bw = bits + (size_t)order[tid] * words;
-      float pen = 0.f;
+      R pen = (R)0;
       if (p.crc_len > 0) {
         uint32_t reg = 0;
         for (int i = 0; i < p.k; ++i) {
@@ -407,8 +409,8 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
           const int pos = p.info_pos[src];
           reg = crc_step(reg, (bw[pos >> 5] >> (pos & 31)) & 1u, p.crc_poly, p.crc_len);
         }
-        blk[tid] = reg == 0 ? 1.f : 0.f;
-        pen = reg == 0 ? 0.f : kPolarLlrMax * (float)p.k;
+        blk[tid] = reg == 0 ? (R)1 : (R)0;
+        pen = reg == 0 ? (R)0 : (R)kPolarLlrMax * (R)p.k;
       }
       cand[tid] = pm[tid] + pen;
     }
@@ -422,18 +424,18 @@ __global__ __launch_bounds__(NT) void polar_scl_kernel(SclArgs p) {
     const uint32_t* bw = bits + (size_t)order[best] * words;
     for (int i = tid; i < p.k; i += NT) {
       const int pos = p.info_pos[i];
-      p.u_hat[(size_t)b * p.k + i] = (float)((bw[pos >> 5] >> (pos & 31)) & 1u);
+      p.u_hat[(size_t)b * p.k + i] = (R)((bw[pos >> 5] >> (pos & 31)) & 1u);
     }
-    if (tid == 0 && p.crc_status) p.crc_status[b] = p.crc_len > 0 ? blk[best] : 1.f;
+    if (tid == 0 && p.crc_status) p.crc_status[b] = p.crc_len > 0 ? blk[best] : (R)1;
     __syncthreads();
   }
 }
 
-static size_t scl_lds_bytes(int n, int L, int num_ops) {
+static size_t scl_lds_bytes(int n, int L, int num_ops, size_t real = sizeof(float)) {
   const size_t words = (n + 31) / 32;
   (void)num_ops;
-  return (size_t)L * (n >> scl_gstages(n)) * 5 + (size_t)L * words * 4 + (size_t)L * 4 * 5 +
-         (size_t)L * 4 * 5 + 256 * 4 + 3 * (size_t)L * 16 + 64;
+  return (size_t)L * (n >> scl_gstages(n)) * (real + 1) + (size_t)L * words * 4 + (size_t)L * real * 5 +
+         (size_t)L * (4 * 4 + real) + 256 * real + 3 * (size_t)L * 16 + 64;
 }
 
 // resident workgroups (= codewords in flight): as many as the list state of the engine that runs lets a CU hold
@@ -527,5 +529,43 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   if (reg_engine) return scl_reg_launch(p, grid, (hipStream_t)stream);
   // one wave per codeword: the block sums of rate-0 / repetition nodes are defined on 64 lanes (scl_math.h)
   hipLaunchKernelGGL(polar_scl_kernel<64>, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
+  return launch_status();
+}
+
+// ---- precision = "double" (reference block.py:25-52): the generic engine on float64 (definitions: polar_scl.h)
+extern "C" size_t samd_polar_scl_workspace_bytes_f64(int batch, int n, int list_size) {
+  if (batch <= 0 || n < 8 || list_size < 1) return 0;
+  const int grid = scl_grid(batch, n, list_size, false);
+  return (size_t)grid * list_size * (size_t)n * (sizeof(double) + 1) + 512;
+}
+
+extern "C" int samd_polar_scl_decode_f64(const double* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
+                                         const int32_t* iil_inv, int batch, int n, int k, int list_size, int sc_mode,
+                                         uint32_t crc_poly, int crc_len, double* u_hat, double* crc_status, void* workspace,
+                                         size_t workspace_bytes, void* stream) {
+  SAMD_REQUIRE(llr && ops && info_pos && u_hat && batch > 0, "bad argument");
+  if (!workspace || workspace_bytes < samd_polar_scl_workspace_bytes_f64(batch, n, list_size)) {
+    set_error("workspace too small");
+    return SAMD_ERR_WORKSPACE;
+  }
+  SAMD_REQUIRE(n >= 8 && (n & (n - 1)) == 0 && k >= 0 && k <= n, "n must be a power of two >= 8, 0 <= k <= n");
+  SAMD_REQUIRE(list_size >= 1 && list_size <= 32 && (list_size & (list_size - 1)) == 0, "list_size must be a power of two <= 32");
+  SAMD_REQUIRE(num_ops > 0 && n <= 1024, "schedule missing or n > 1024");
+  const size_t lds = scl_lds_bytes(n, list_size, num_ops, sizeof(double));
+  if (lds > 160 * 1024) {
+    set_error("list state does not fit in LDS (reduce list_size or n)");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  auto kern = polar_scl_kernel<64, double>;
+  SAMD_SET_MAX_LDS(kern, 160 * 1024);
+  int m = 0;
+  while ((1 << m) < n) ++m;
+  // resident workgroups: the float32 engine's count (its LDS footprint is the smaller one; the hardware places as many as fit)
+  const int grid = scl_grid(batch, n, list_size, false);
+  double* gs = reinterpret_cast<double*>(align_up((size_t)workspace, 256));
+  unsigned char* gb = reinterpret_cast<unsigned char*>(gs + (size_t)grid * list_size * n);
+  SclArgsT<double> p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, nullptr, scl_gstages(n, false), batch, n, m, k,
+                     list_size, sc_mode, crc_len, crc_poly};
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, (hipStream_t)stream, p);
   return launch_status();
 }

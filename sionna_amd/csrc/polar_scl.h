@@ -32,15 +32,16 @@ __device__ __forceinline__ float cn_op(float x, float y) {  // polar/decoding.py
   return softplus(x + y) - lse;
 }
 
-struct SclArgs {
-  const float* llr_in;     // [B, n] logits
-  float* u_hat;            // [B, k] bits at the information positions of the selected path
-  float* crc_status;       // nullable [B]
+template <typename R>
+struct SclArgsT {          // R = float (both engines) or double (precision = "double": generic engine only)
+  const R* llr_in;         // [B, n] logits
+  R* u_hat;                // [B, k] bits at the information positions of the selected path
+  R* crc_status;           // nullable [B]
   const int32_t* ops;      // [num_ops] packed: op | stage<<3 | side<<7 | (a2+2048)<<8
   int num_ops;
   const int32_t* info_pos; // [k]
   const int32_t* iil_inv;  // nullable [k] inverse input interleaver applied before the CRC check
-  float* gscratch;         // [grid][L][n - n/2^G] the G top LLR stages of every slot: touched by a handful
+  R* gscratch;             // [grid][L][n - n/2^G] the G top LLR stages of every slot: touched by a handful
                            // of ops per decode, kept in L2 instead of LDS so that more codewords fit on a CU
   unsigned char* gbeta;    // [grid][L][n - n/2^G] partial sums of the same top stages
   const uint32_t* crc_tab; // nullable [k]: remainder contributed by bit i of the CRC-checked sequence (register engine)
@@ -48,6 +49,30 @@ struct SclArgs {
   int batch, n, m, k, L, sc_mode, crc_len;
   uint32_t crc_poly;
 };
+using SclArgs = SclArgsT<float>;
+
+// precision = "double" (reference block.py:25-52): the arithmetic of the reference's own float64 NumPy twin
+// (decoding.py:1113-1149: literal log(1 + e^x), log(1 + e^(x+y)) - log(e^x + e^y) on inputs clipped to +-30, libm exp / log) -
+// oracle/polar_scl.c precision 1, which is pinned by fixtures generated from that twin (tests/golden/polar_scl_np_golden.npz)
+__device__ __forceinline__ double cn_op(double x, double y) {
+  x = fmax(fmin(x, (double)kPolarLlrMax), -(double)kPolarLlrMax);
+  y = fmax(fmin(y, (double)kPolarLlrMax), -(double)kPolarLlrMax);
+  double o = log(1.0 + exp(x + y));
+  o -= log(exp(x) + exp(y));
+  return o;
+}
+// (softplus(-l), softplus(+l)) of a clipped LLR: the metric increments of deciding 0 / 1
+__device__ __forceinline__ void softplus_pair(float l, float& m0, float& m1) {
+  const float tl = scl_T(fabsf(l));                 // shared by softplus(-l) and softplus(l)
+  m0 = fmaxf(-l, 0.f) + tl;
+  m1 = fmaxf(l, 0.f) + tl;
+}
+__device__ __forceinline__ void softplus_pair(double l, double& m0, double& m1) {
+  m0 = log(1.0 + exp(-l));
+  m1 = log(1.0 + exp(l));
+}
+__device__ __forceinline__ float clamp_llr(float x) { return clampf(x, -kPolarLlrMax, kPolarLlrMax); }
+__device__ __forceinline__ double clamp_llr(double x) { return fmax(fmin(x, (double)kPolarLlrMax), -(double)kPolarLlrMax); }
 
 
 inline int scl_gstages(int n, bool reg_engine = false) {

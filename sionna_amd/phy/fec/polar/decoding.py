@@ -134,20 +134,24 @@ class _PolarListDecoderBase(Block):
             i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
             # the engine that will run says which stages it keeps in registers: it decodes a whole node one stage above
             # them (f / g from memory around two register-stage subtrees) without further schedule dispatch
-            r = _ffi.lib().samd_polar_scl_register_stages(self._n, self._list_size, self._sc_mode)
+            # (precision="double": always the generic engine, csrc/polar.hip polar_scl_kernel<64, double>)
+            r = -1 if self.precision == "double" else _ffi.lib().samd_polar_scl_register_stages(self._n, self._list_size, self._sc_mode)
             ops = self._ops if r < 1 else build_schedule(self._frozen_ind, self._use_fast, use_rep=not self._sc_mode,
                                                          subtree_stage=r + 1)
             self._dev = (i32(pack_schedule(ops)), i32(self._info_pos),
                          i32(self._ind_iil_inv) if self._ind_iil_inv is not None else None)
         ops, info, iil = self._dev
         b = llr.shape[0]
-        u_hat = torch.empty((b, self._k), dtype=torch.float32, device=llr.device)
-        status = torch.empty((b,), dtype=torch.float32, device=llr.device) if want_status else None
+        dbl = self.precision == "double"
+        lib = _ffi.lib()
+        u_hat = torch.empty((b, self._k), dtype=self.rdtype, device=llr.device)
+        status = torch.empty((b,), dtype=self.rdtype, device=llr.device) if want_status else None
         if b > 0:
             if getattr(self, "_ws", None) is None:
                 self._ws = _ffi.Workspace()
-            ws, ws_bytes = self._ws.get(_ffi.lib().samd_polar_scl_workspace_bytes(b, self._n, self._list_size))
-            _ffi.check(_ffi.lib().samd_polar_scl_decode_f32(
+            ws, ws_bytes = self._ws.get((lib.samd_polar_scl_workspace_bytes_f64 if dbl else lib.samd_polar_scl_workspace_bytes)(
+                b, self._n, self._list_size))
+            _ffi.check((lib.samd_polar_scl_decode_f64 if dbl else lib.samd_polar_scl_decode_f32)(
                 _ffi.ptr(llr), _ffi.ptr(ops), ops.numel(), _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size,
                 self._sc_mode, self._crc_mask, self._crc_len, _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.ptr(ws), ws_bytes,
                 _ffi.stream()), type(self).__name__)
@@ -166,8 +170,7 @@ class PolarSCDecoder(_PolarListDecoderBase):
         self._setup(frozen_pos, n, 1, 1, None, True, None)     # rate-0 shortcut = use_fast_sc (:186-190)
 
     def call(self, llr_ch, /):
-        self._require_single()
-        llr = _ffi.to_device(llr_ch, torch.float32)
+        llr = _ffi.to_device(llr_ch, self.rdtype)
         if llr.shape[-1] != self._n:
             raise ValueError("Invalid input shape.")
         u_hat, _ = self._decode_2d(llr.reshape(-1, self._n))
@@ -217,8 +220,7 @@ class PolarSCLDecoder(_PolarListDecoderBase):
     k_crc = property(lambda self: self._k_crc)
 
     def call(self, llr_ch):
-        self._require_single()
-        llr = _ffi.to_device(llr_ch, torch.float32)
+        llr = _ffi.to_device(llr_ch, self.rdtype)
         if llr.shape[-1] != self._n:
             raise ValueError("Invalid input shape.")
         llr2d = llr.reshape(-1, self._n)
@@ -231,7 +233,7 @@ class PolarSCLDecoder(_PolarListDecoderBase):
             if self._return_crc_status:
                 chk = u_hat if self._ind_iil_inv is None else \
                     u_hat[:, _ffi.to_device(np.asarray(self._ind_iil_inv, np.int64), torch.int64)]
-                status = self._crc_decoder(chk.contiguous())[1].reshape(-1).to(torch.float32)
+                status = self._crc_decoder(chk.contiguous())[1].reshape(-1).to(self.rdtype)
             if redo.numel() > 0:
                 u_scl, st = self._decode_2d(llr2d.index_select(0, redo).contiguous(), self._return_crc_status)
                 u_hat.index_copy_(0, redo, u_scl)
@@ -414,8 +416,9 @@ class Polar5GDecoder(Block):
             raise ValueError("Invalid input shape.")
 
     def call(self, llr_ch):
-        self._require_single()
-        llr = _ffi.to_device(llr_ch, torch.float32)
+        if self.precision == "double" and self._dec_type == "BP":
+            raise NotImplementedError("Polar5GDecoder: dec_type='BP' is implemented for precision='single' only")
+        llr = _ffi.to_device(llr_ch, self.rdtype)
         if llr.shape[-1] != self._n_target:
             raise ValueError("Invalid input shape.")
         lead = tuple(llr.shape[:-1])
@@ -428,10 +431,10 @@ class Polar5GDecoder(Block):
                          torch.from_numpy(self._src_b >= 0).to(dev), bool((self._src_b >= 0).any()))
         ia, ma, sa, ib, mb, has_b = self._dev
         # index plumbing of the rate recovery (gathers only; decoding.py:2018-2052)
-        dec_in = torch.where(ma, x.index_select(1, ia), torch.zeros((), device=x.device))
-        dec_in = torch.where(sa, torch.full((), -self._llr_max, device=x.device), dec_in)
+        dec_in = torch.where(ma, x.index_select(1, ia), torch.zeros((), dtype=x.dtype, device=x.device))
+        dec_in = torch.where(sa, torch.full((), -self._llr_max, dtype=x.dtype, device=x.device), dec_in)
         if has_b:
-            dec_in = dec_in + torch.where(mb, x.index_select(1, ib), torch.zeros((), device=x.device))
+            dec_in = dec_in + torch.where(mb, x.index_select(1, ib), torch.zeros((), dtype=x.dtype, device=x.device))
         u_crc = self._polar_dec(dec_in.contiguous()).as_subclass(torch.Tensor)
         if self._iil:
             u_crc = u_crc.index_select(1, torch.from_numpy(self._ind_iil_inv.astype(np.int64)).to(u_crc.device))

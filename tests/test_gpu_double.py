@@ -372,3 +372,71 @@ def test_flat_fading_channel_double(phy):
     assert y.dtype == torch.complex128 and h.dtype == torch.complex128
     _close9(_np(h).reshape(-1), o64.complex_normal(8, 0, 40 * 5 * 3, 1.0))
     _close9(_np(y), o64.awgn(np.einsum("brt,bt->br", _np(h), x), 0.2, 8, 1))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Polar SC / SC-list decoders with precision="double": polar_scl_kernel<64, double> (csrc/polar.hip) against the float64
+# instantiation of the C oracle = the arithmetic of the reference's own NumPy twin (oracle/polar_scl.c precision 1, pinned
+# by tests/golden/polar_scl_np_golden.npz).  The inputs are float32-representable so that both sides see the same numbers.
+from oracle import polar as opol, polar_c as pc
+
+
+@pytest.mark.parametrize("n,k,L,crc,fast", [(128, 64, 8, None, True), (128, 64, 4, "CRC11", True), (256, 100, 8, "CRC11", False),
+                                            (1024, 512, 8, "CRC11", True), (64, 20, 2, None, True), (512, 300, 16, "CRC24C", True),
+                                            (32, 16, 32, None, True)])
+def test_scl_double_vs_float64_oracle(phy, n, k, L, crc, fast):
+    frozen, info = phy.fec.polar.generate_5g_ranking(k, n)
+    rng = np.random.default_rng(n + k + L)
+    B = 48 if n >= 512 else 160
+    kc = opol.CRC_POLYS[crc][0] if crc else 0
+    u = rng.integers(0, 2, (B, k - kc)).astype(np.float32)
+    uc = opol.crc_encode(u, crc) if crc else u
+    c = opol.polar_encode(uc, info, n)
+    for sigma in (0.75, 0.95):
+        y = (2 * c - 1) + sigma * rng.normal(size=c.shape)
+        logits = (2 * y / sigma ** 2).astype(np.float32).astype(np.float64)
+        dec = phy.fec.polar.PolarSCLDecoder(frozen, n, list_size=L, crc_degree=crc, use_fast_scl=fast,
+                                            return_crc_status=crc is not None, precision="double")
+        out = dec(logits)
+        got, status = (out if crc else (out, None))
+        assert got.dtype == torch.float64
+        ref, ref_status = pc.SCLDecoder(frozen, n, L, crc, fast, precision="f64").decode(logits)
+        assert np.array_equal(_np(got), ref.astype(np.float64)), f"{(~np.all(_np(got) == ref, axis=1)).sum()} of {B} codewords differ"
+        if crc:
+            assert np.array_equal(_np(status), ref_status.astype(bool))
+        single = phy.fec.polar.PolarSCLDecoder(frozen, n, list_size=L, crc_degree=crc, use_fast_scl=fast)(logits.astype(np.float32))
+        assert np.mean(np.all(_np(single).astype(np.float64) == _np(got), axis=1)) >= 0.9      # same decoder, other rounding
+
+
+@pytest.mark.parametrize("n,k", [(128, 37), (256, 128), (1024, 700), (32, 20)])
+def test_sc_double_vs_float64_oracle(phy, n, k):
+    frozen, info = phy.fec.polar.generate_5g_ranking(k, n)
+    rng = np.random.default_rng(n + k)
+    u = rng.integers(0, 2, (100, k)).astype(np.float32)
+    c = opol.polar_encode(u, info, n)
+    y = (2 * c - 1) + 0.8 * rng.normal(size=c.shape)
+    logits = (2 * y / 0.64).astype(np.float32).astype(np.float64)
+    got = phy.fec.polar.PolarSCDecoder(frozen, n, precision="double")(logits)
+    assert got.dtype == torch.float64
+    assert np.array_equal(_np(got), pc.sc_decode(logits, frozen, n, precision="f64").astype(np.float64))
+
+
+@pytest.mark.parametrize("k,n,ch,dec_type", [(64, 128, "uplink", "SCL"), (30, 70, "uplink", "SC"), (40, 200, "downlink", "SCL"),
+                                             (100, 300, "uplink", "hybSCL")])
+def test_polar5g_decoder_double(phy, k, n, ch, dec_type):
+    """Polar5GEncoder / Polar5GDecoder with precision="double": same decisions as the float32 chain on the same (float32-
+    representable) LLRs wherever no near-tie is involved, and error free at high SNR."""
+    enc = phy.fec.polar.Polar5GEncoder(k, n, channel_type=ch, precision="double")
+    dec = phy.fec.polar.Polar5GDecoder(enc, dec_type, list_size=8, return_crc_status=True, precision="double")
+    rng = np.random.default_rng(k + n)
+    u = rng.integers(0, 2, (64, k)).astype(np.float64)
+    c = enc(u)
+    assert c.dtype == torch.float64
+    llr = ((2 * _np(c) - 1) * 4.0 + rng.normal(size=(64, n)) * 1.2).astype(np.float32).astype(np.float64)
+    u_hat, ok = dec(llr)
+    assert u_hat.dtype == torch.float64 and ok.dtype == torch.bool
+    enc32 = phy.fec.polar.Polar5GEncoder(k, n, channel_type=ch)
+    u32, ok32 = phy.fec.polar.Polar5GDecoder(enc32, dec_type, list_size=8, return_crc_status=True)(llr.astype(np.float32))
+    assert np.mean(np.all(_np(u32).astype(np.float64) == _np(u_hat), axis=1)) >= 0.95
+    good = _np(ok)
+    assert good.mean() > 0.9 and np.array_equal(_np(u_hat)[good], u[good])
