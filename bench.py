@@ -355,7 +355,7 @@ def bench_c4(args, short=False):
     c2o_in = int(a_t.numel()) * 8 + int(tau_t.numel()) * 4
     rec_c2o, rec_tdl = load_counters("cir_to_ofdm"), load_counters("tdl_cir")
     channel_kernels = {
-        "cir_to_ofdm": {"kernel": "cir_to_ofdm_reg_kernel<24, 24> (phase table + taps in LDS, results staged in registers, one store per value)",
+        "cir_to_ofdm": {"kernel": "cir_to_ofdm_pass_kernel<24, 24, 4> (phase table + taps in LDS, paths in passes of 4 with the next row's taps requested ahead, results staged in registers, one store per value)",
                         "ms_per_launch": round(ms_c2o, 4),
                         "roofline": {"bound": "hbm", "achieved": round((c2o_in + c2o_out) / (ms_c2o * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
                                      "unit": "GB/s", "frac": round((c2o_in + c2o_out) / (ms_c2o * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

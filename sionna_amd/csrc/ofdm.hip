@@ -347,6 +347,179 @@ __global__ __launch_bounds__(512) void cir_to_ofdm_reg_kernel(const float2* __re
   }
 }
 
+// The same kernel with the paths walked in passes of PW: only PW phases (and the PW taps of a row, and with PF those of the
+// next row, requested a row ahead) are live beside the RPT staged results, so the kernel needs 80-94 instead of 164 vector
+// registers and three to four workgroups instead of two (at 384 threads) share a CU.  History on the C4 shapes (8192 links
+// of 4 x 2 antennas, 23 paths, 14 x 76 grid; tools/c2o_ab.py, profiles/r05o*): all phases in registers 688 us -> passes of 8
+// 450 us -> every batch of staging loads issued back to back before its first use, passes of 4 with look-ahead 330-357 us
+// (a plain fill of the 558 MB output: 88 us).  Where the rest goes (ablation build, profiles/r05o8_c2o_ab.txt; kernel-only
+// times through the C-ABI): the FMA loop 165 us (92 us at the packed-FMA issue rate: the LDS broadcast reads and the waits
+// behind them), the stores 47, the taps gather 37, sincosf 15 - and ~80 us that no part owns: a workgroup is one link, its
+// life is a chain of dependent round trips (tau -> sincos -> LDS -> barrier -> FMA -> store), and a CU holds three of them.
+// The vector pipe was 60 % busy with 3.4 k instructions per wave of which 1.15 k are the packed FMAs in the first pass
+// version (profiles/r05p): predication of the rows beyond the link, 64-bit address arithmetic, integer divisions in the
+// staging loops, two accumulators per row and pass.  Here: the tap array is padded with zero rows to RPT * G rows (no
+// predicate in the FMA loop), a result is ONE accumulator updated by two packed FMAs per path (h += a.x (c, s) + a.y (-s, c)),
+// the staging loops decompose indices with multiply-high, the energy is reduced with wave shuffles.  Sum over the paths in
+// ascending order, pass by pass (the same chain for every PW: the variants are bit-identical to each other); held to 1e-4 of
+// the float64 oracle like the kernels above.
+template <int MAXP, int RPT, int PW, bool PF>
+__global__ __launch_bounds__(512) void cir_to_ofdm_pass_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
+                                                               const float* __restrict__ freqs, int RX, int RA, int TX,
+                                                               int TA, int P, int T, int F, int normalize,
+                                                               float2* __restrict__ out) {
+  static_assert(MAXP % PW == 0, "pass width must divide the padded path count");
+  extern __shared__ __attribute__((aligned(16))) float2 tab[];   // [MAXP][F] phases, taps [RPT * G][MAXP] (zero rows behind the link), red[8]
+  const int nt = blockDim.x, tid = threadIdx.x;
+  const int G = nt / F;                                           // row groups side by side (host: F <= blockDim)
+  const int rows = RA * TA * T, rows_pad = RPT * G;
+  float2* taps = tab + (size_t)MAXP * F;
+  float* red = reinterpret_cast<float*>(taps + (size_t)rows_pad * MAXP);
+  const int tx = blockIdx.x % TX;
+  const int rx = (blockIdx.x / TX) % RX;
+  const int b = blockIdx.x / (TX * RX);
+  const float* tb = tau + ((size_t)(b * RX + rx) * TX + tx) * P;
+  const int g0 = tid / F, f = tid - g0 * F;
+  const bool act = g0 < G;
+  const int g = act ? g0 : 0;                                     // the spare lanes of the block shadow group 0 and store nothing
+  // Staging.  A workgroup of this kernel lives ~100 k cycles of which the FMA loop is ~5 k per wave: what it waits for are the
+  // dependent global round trips of the staging loops.  So every batch of loads is issued back to back into registers
+  // (KB independent requests per thread) before the first of them is used: one round trip per batch instead of one per element.
+  constexpr int KB = 8;
+  auto magic = [](unsigned d) { return d > 1 ? 0xFFFFFFFFu / d + 1u : 0u; };        // n / d = umulhi(n, magic(d)) for n, d < 2^13
+  auto divu = [](unsigned n, unsigned d, unsigned m) { return d > 1 ? __umulhi(n, m) : n; };
+  {
+    const float wf = -2.f * 3.14159265358979323846f * freqs[f];
+    for (int pb = g0; pb < MAXP; pb += KB * G) {                  // phases: thread (g, f) fills the rows p = g, g + G, ...
+      float tv[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const int p = pb + k * G;
+        tv[k] = (act && p < P) ? tb[p] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const int p = pb + k * G;
+        if (act && p < MAXP) {
+          float sn = 0.f, cs = 0.f;
+          if (p < P) sincosf(wf * tv[k], &sn, &cs);
+          tab[p * F + f] = make_float2(cs, sn);
+        }
+      }
+    }
+  }
+  {
+    // taps: source order (ra | ta, p, t) with t fastest - consecutive lanes on consecutive addresses - transposed into [row][p]
+    const unsigned pt = (unsigned)(P * T), lpt = (unsigned)TA * pt, total = (unsigned)RA * lpt;
+    const unsigned m_lpt = magic(lpt), m_pt = magic(pt), m_t = magic((unsigned)T);
+    const float2* src = a + (((size_t)(b * RX + rx) * RA) * TX + tx) * (size_t)lpt;
+    const size_t ra_stride = (size_t)TX * lpt;
+    for (unsigned i0 = (unsigned)tid; i0 < total; i0 += (unsigned)(KB * nt)) {
+      float2 v[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const unsigned i = i0 + (unsigned)(k * nt);
+        if (i < total) {
+          const unsigned ra = divu(i, lpt, m_lpt);
+          v[k] = src[ra * ra_stride + (i - ra * lpt)];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k) {
+        const unsigned i = i0 + (unsigned)(k * nt);
+        if (i < total) {
+          const unsigned lk = divu(i, pt, m_pt), q = i - lk * pt;
+          const unsigned pp = divu(q, (unsigned)T, m_t), t = q - pp * (unsigned)T;
+          taps[(lk * (unsigned)T + t) * MAXP + pp] = v[k];
+        }
+      }
+    }
+    const int zp = MAXP - P;                                      // zero columns of the real rows, zero rows behind them
+    for (int i = tid; i < rows * zp; i += nt) {
+      const int row = i / zp;
+      taps[(unsigned)(row * MAXP + P + (i - row * zp))] = make_float2(0.f, 0.f);
+    }
+    for (int i = rows * MAXP + tid; i < rows_pad * MAXP; i += nt) taps[i] = make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  c2o_f32x2 acc[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) acc[r] = c2o_f32x2{0.f, 0.f};
+  const unsigned rstride = (unsigned)(G * MAXP);
+#pragma unroll 1
+  for (int p0 = 0; p0 < MAXP; p0 += PW) {
+    float2 ph[PW];
+#pragma unroll
+    for (int p = 0; p < PW; ++p) ph[p] = tab[(p0 + p) * F + f];
+    unsigned ai = (unsigned)(g * MAXP + p0);
+    asm volatile("" : "+v"(ai));          // (the RPT tap addresses of a thread are re-derived per pass, not kept in RPT registers)
+    if constexpr (PF) {
+      float2 cur[PW], nxt[PW];                                    // the taps of row r + 1 are requested before row r is summed
+#pragma unroll
+      for (int p = 0; p < PW; ++p) cur[p] = taps[ai + p];         // the lanes of a group read one address: LDS broadcast
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        ai += rstride;
+        if (r + 1 < RPT) {
+#pragma unroll
+          for (int p = 0; p < PW; ++p) nxt[p] = taps[ai + p];
+        }
+        c2o_f32x2 h = acc[r];
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+          h = __builtin_elementwise_fma(c2o_f32x2{cur[p].x, cur[p].x}, c2o_f32x2{ph[p].x, ph[p].y}, h);
+          h = __builtin_elementwise_fma(c2o_f32x2{cur[p].y, cur[p].y}, c2o_f32x2{-ph[p].y, ph[p].x}, h);
+        }
+        acc[r] = h;
+#pragma unroll
+        for (int p = 0; p < PW; ++p) cur[p] = nxt[p];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {                             // taps read where they are used: fewest registers, most waves
+        const float2* ap = taps + ai;
+        c2o_f32x2 h = acc[r];
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+          const float2 av = ap[p];
+          h = __builtin_elementwise_fma(c2o_f32x2{av.x, av.x}, c2o_f32x2{ph[p].x, ph[p].y}, h);
+          h = __builtin_elementwise_fma(c2o_f32x2{av.y, av.y}, c2o_f32x2{-ph[p].y, ph[p].x}, h);
+        }
+        acc[r] = h;
+        ai += rstride;
+      }
+    }
+  }
+  float inv = 1.f;
+  if (normalize) {
+    float energy = 0.f;
+    if (act) {
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) energy += acc[r].x * acc[r].x + acc[r].y * acc[r].y;  // rows behind the link are zero
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) energy += __shfl_xor(energy, o, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = energy;
+    __syncthreads();
+    float e = 0.f;
+    for (int w = 0; w < (nt + 63) / 64; ++w) e += red[w];
+    const float c = sqrtf(e / (float)(rows * F));
+    inv = c > 0.f ? 1.f / c : 0.f;                               // divide_no_nan
+  }
+  float2* ob = out + ((size_t)(b * RX + rx) * RA) * TX * TA * (size_t)T * F;
+  {
+    int t = g % T, lk = g / T;
+    int ta = lk % TA, ra = lk / TA;
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      if (act && ra < RA)
+        ob[(unsigned)((((ra * TX + tx) * TA + ta) * T + t) * F + f)] = make_float2(acc[r].x * inv, acc[r].y * inv);
+      t += G;
+      while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
+    }
+  }
+}
+
 // y[b,rx,ra,t,f] = sum_{tx,ta} h[b,rx,ra,tx,ta,t,f] * x[b,tx,ta,t,f]
 __global__ __launch_bounds__(256) void apply_ofdm_channel_kernel(const float2* __restrict__ x,
                                                                  const float2* __restrict__ h, int64_t total,
@@ -493,9 +666,22 @@ extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const floa
                         cir_to_ofdm_reg_kernel<MP, 32>, cir_to_ofdm_reg_kernel<MP, 40>}
       static const kern_t rk[4][5] = {SAMD_C2R_K(8), SAMD_C2R_K(16), SAMD_C2R_K(24), SAMD_C2R_K(32)};
 #undef SAMD_C2R_K
-      const kern_t kern = rk[mp / 8 - 1][(best_rpt + 7) / 8 - 1];
-      hipLaunchKernelGGL(kern, grid, dim3(best_nt), lds_r, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx,
-                         num_tx_ant, num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq);
+      // paths in passes of 4 with the next row's taps requested a row ahead (cir_to_ofdm_pass_kernel: 94 registers, 5 waves per
+      // SIMD); development: SAMD_C2O_PASS = 0 keeps all phases in registers (the kernel of profiles/r05k, 164 registers), 2 =
+      // passes of 2 (80 registers), 8 = passes of 8 without the look-ahead (94 registers) - profiles/r05o
+      static samd::CachedOpt opt_pass("SAMD_C2O_PASS");
+      const long pw = opt_pass.get(4);
+#define SAMD_C2P_K(MP, PW, PF) {cir_to_ofdm_pass_kernel<MP, 8, PW, PF>, cir_to_ofdm_pass_kernel<MP, 16, PW, PF>, cir_to_ofdm_pass_kernel<MP, 24, PW, PF>, \
+                                cir_to_ofdm_pass_kernel<MP, 32, PW, PF>, cir_to_ofdm_pass_kernel<MP, 40, PW, PF>}
+      static const kern_t pk4[4][5] = {SAMD_C2P_K(8, 4, true), SAMD_C2P_K(16, 4, true), SAMD_C2P_K(24, 4, true), SAMD_C2P_K(32, 4, true)};
+      static const kern_t pk2[4][5] = {SAMD_C2P_K(8, 2, true), SAMD_C2P_K(16, 2, true), SAMD_C2P_K(24, 2, true), SAMD_C2P_K(32, 2, true)};
+      static const kern_t pk8n[4][5] = {SAMD_C2P_K(8, 8, false), SAMD_C2P_K(16, 8, false), SAMD_C2P_K(24, 8, false), SAMD_C2P_K(32, 8, false)};
+#undef SAMD_C2P_K
+      const size_t lds_p = ((size_t)mp * num_freqs + (size_t)(((best_rpt + 7) / 8) * 8) * (best_nt / num_freqs) * mp) * sizeof(float2) + 64;
+      const bool pass = (pw == 8 || pw == 4 || pw == 2) && lds_p <= 64 * 1024 && (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant < 8192;
+      const kern_t kern = !pass ? rk[mp / 8 - 1][(best_rpt + 7) / 8 - 1] : (pw == 8 ? pk8n : pw == 4 ? pk4 : pk2)[mp / 8 - 1][(best_rpt + 7) / 8 - 1];
+      hipLaunchKernelGGL(kern, grid, dim3(best_nt), pass ? lds_p : lds_r, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant,
+                         num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq);
       return launch_status();
     }
   }
