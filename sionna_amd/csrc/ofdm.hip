@@ -65,6 +65,18 @@ __device__ __forceinline__ float uni(uint64_t seed, uint64_t call, uint64_t i, f
   return lo + (hi - lo) * u01(w);
 }
 
+// consecutive elements of one stream: the Philox block of four words is computed once per four elements, not once per element
+struct UniStream {
+  uint64_t seed, call, blk = ~0ull;
+  uint4 r;
+  __device__ __forceinline__ UniStream(uint64_t s, uint64_t c) : seed(s), call(c) { r = make_uint4(0u, 0u, 0u, 0u); }
+  __device__ __forceinline__ float operator()(uint64_t i, float lo, float hi) {
+    if ((i >> 2) != blk) { blk = i >> 2; r = philox_block(seed, call, blk); }
+    const uint32_t w = (i & 3) == 0 ? r.x : (i & 3) == 1 ? r.y : (i & 3) == 2 ? r.z : r.w;
+    return lo + (hi - lo) * u01(w);
+  }
+};
+
 __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t call, int B, int RA, int TA, int P,
                                                       int T, int N, float sampling_frequency,
                                                       const float* __restrict__ mean_powers, float min_doppler,
@@ -92,11 +104,12 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
     float ca_r[kMaxSin], ph_r[kMaxSin];
     const bool cached = N <= kMaxSin;
     if (cached) {
+      UniStream u_theta(seed, call + 1), u_phi(seed, call + 2);
 #pragma unroll
       for (int n = 0; n < kMaxSin; ++n)
         if (n < N) {
-          const float theta = uni(seed, call + 1, (uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
-          ph_r[n] = uni(seed, call + 2, (uint64_t)(i * N + n), -pi, pi);
+          const float theta = u_theta((uint64_t)((b * P + p) * N + n), -pi / (float)N, pi / (float)N);
+          ph_r[n] = u_phi((uint64_t)(i * N + n), -pi, pi);
           ca_r[n] = cosf((2.f * pi / (float)N) * (float)(n + 1) + theta);
         }
     }
