@@ -414,6 +414,23 @@ int samd_ofdm_kbest_f32(const float* y, const float* h_hat, const float* err_var
                         int num_data, int num_bits_per_symbol, int num_paths, float llr_clip,
                         int hard_out, float* out, void* stream);
 
+/* MaximumLikelihoodDetector.call  mimo/detection.py:145-537 on n independent problems: whitening with the Cholesky factor of s,
+ * then the exponent -||y~ - H~ x||^2 (+ prior logits of the symbols of x) of every candidate vector x in points^k (stream 0 =
+ * most significant digit, _build_vecs :414-470), reduced per (stream, point) with logsumexp (maxlog = 0, "app") or max.
+ * y [n,m], h [n,m,k], s [n,m,m] complex64; prior nullable [n,k,2^num_bits_per_symbol] logits; points DEVICE complex64
+ * [2^num_bits_per_symbol] -> logits [n,k,2^num_bits_per_symbol].  Bit LLRs / hard decisions: samd_symbol_logits2llrs_f32 on the
+ * result (what the reference block does, :531-536).  UNSUPPORTED beyond 65536 candidate vectors or k * 2^nb > 200. */
+int samd_ml_detect_f32(const float* y, const float* h, const float* s, const float* prior, const float* points,
+                       int64_t n, int m, int k, int num_bits_per_symbol, int maxlog, float* logits, void* stream);
+/* ofdm.MaximumLikelihoodDetector(.WithPrior).call  ofdm/detection.py:524-738 (on OFDMDetector / OFDMDetectorWithPrior :21-510):
+ * the arguments of samd_ofdm_kbest_f32; prior (nullable) and logits [batch, num_streams_total, num_data, 2^num_bits_per_symbol]. */
+int samd_ofdm_ml_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode, const float* no,
+                     const float* prior, const float* points, const int32_t* sc_ind, const int32_t* desired,
+                     const int32_t* undesired, const int32_t* data_pos, int batch, int num_rx, int num_rx_ant,
+                     int num_streams_total, int streams_per_rx, int num_undesired, int num_ofdm_symbols,
+                     int num_eff_subcarriers, int fft_size, int num_data, int num_bits_per_symbol, int maxlog,
+                     float* logits, void* stream);
+
 /* ---- scrambling --------------------------------------------------- */
 
 /* Scrambler.call fec/scrambling.py:186-261 / TB5GScrambler.call :442-468:

@@ -744,6 +744,70 @@ def ofdm_kbest_detector(rg, sm, y, h_hat, err_var, no, points, k, hard_out=False
     return out if output == "symbol" else out.reshape(out.shape[:3] + (-1,))
 
 
+# ------------------------------------------------------------------ maximum-likelihood detector
+def ml_detector(y, h, s, points, method="app", prior=None, output="bit", hard_out=False):
+    """MaximumLikelihoodDetector.call (mimo/detection.py:145-537) in float64: y [n,M], h [n,M,K], s [n,M,M]; prior = LLRs
+    [n,K,nb] (output "bit") or logits [n,K,P] ("symbol").  Candidate vectors as _build_vecs (:414-470): stream 0 is the slowest
+    index.  -> LLRs / hard bits [n,K,nb], or logits [n,K,P] / indices [n,K]."""
+    y, h, s = np.asarray(y, np.complex128), np.asarray(h, np.complex128), np.asarray(s, np.complex128)
+    points = np.asarray(points, np.complex128)
+    n, M, K = h.shape
+    P = len(points)
+    nb = int(np.log2(P))
+    lab = _bit_labels(nb)                                                        # [P, nb], 0/1
+    if prior is not None:
+        prior = np.asarray(prior, np.float64)
+        if output == "bit":                                                     # LLRs2SymbolLogits (mapping.py:969-1058)
+            prior = np.sum(_log_sigmoid((2. * lab[None, None] - 1.) * prior[:, :, None, :]), -1)
+    li = np.linalg.inv(np.linalg.cholesky(s))                                   # whiten_channel (mimo/utils.py:292-356)
+    yw = np.einsum("nij,nj->ni", li, y)
+    hw = li @ h
+    idx = np.stack(np.meshgrid(*[np.arange(P)] * K, indexing="ij"), -1).reshape(-1, K)          # [num_vecs, K]
+    vecs = points[idx]                                                                           # [num_vecs, K]
+    diff = yw[:, None, :] - np.einsum("nmk,vk->nvm", hw, vecs)
+    expo = -np.sum(np.abs(diff) ** 2, -1)                                                        # [n, num_vecs]
+    if prior is not None:
+        expo = expo + np.sum(prior[:, np.arange(K)[None, :], idx], -1)
+    logits = np.empty((n, K, P))
+    for k in range(K):
+        for p_ in range(P):
+            e = expo[:, idx[:, k] == p_]
+            mx = e.max(-1)
+            logits[:, k, p_] = mx if method == "maxlog" else mx + np.log(np.sum(np.exp(e - mx[:, None]), -1))
+    if output == "symbol":
+        return np.argmax(logits, -1).astype(np.int32) if hard_out else logits
+    red = (lambda a: a.max(-1)) if method == "maxlog" else (lambda a: a.max(-1) + np.log(np.sum(np.exp(a - a.max(-1, keepdims=True)), -1)))
+    llr = np.stack([red(logits[..., lab[:, b] == 1]) - red(logits[..., lab[:, b] == 0]) for b in range(nb)], -1)   # :927-967
+    return (llr > 0).astype(np.float64) if hard_out else llr
+
+
+def ofdm_ml_detector(rg, sm, y, h_hat, err_var, no, points, method="app", prior=None, output="bit", hard_out=False):
+    """ofdm.MaximumLikelihoodDetector(.WithPrior).call (ofdm/detection.py:524-738): prior / result in the block's layouts
+    ([B,tx,streams,num_data*nb] for "bit", [B,tx,streams,num_data,P] for "symbol")."""
+    y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
+    shp = hd.shape[:-2]                                                          # [B,rx,T,F]
+    K, P = hd.shape[-1], len(points)
+    nb = int(np.log2(P))
+    pr = None
+    if prior is not None:
+        # [B,tx,streams,num_data,(nb|P)] -> per RE of the receivers' streams [B,rx,T,F,K,(nb|P)]: zero prior on REs without data
+        last = nb if output == "bit" else P
+        pri = np.asarray(prior, np.float64).reshape(prior.shape[:3] + (rg.num_data_symbols, last))
+        full = np.zeros((y.shape[0], rg.num_tx * rg.num_streams_per_tx, rg.num_ofdm_symbols * rg.num_effective_subcarriers, last))
+        di = data_ind(rg.pilot_pattern).reshape(rg.num_tx * rg.num_streams_per_tx, -1)
+        flat = pri.reshape(y.shape[0], rg.num_tx * rg.num_streams_per_tx, rg.num_data_symbols, last)
+        for st in range(full.shape[1]):
+            full[:, st, di[st]] = flat[:, st]
+        full = full.reshape(y.shape[0], -1, rg.num_ofdm_symbols, rg.num_effective_subcarriers, last)
+        sel = np.asarray(sm.detection_desired_ind).reshape(sm.num_rx, sm.num_streams_per_rx)
+        pr = np.stack([full[:, sel[r]] for r in range(sm.num_rx)], 1)           # [B,rx,K,T,F,last]
+        pr = np.transpose(pr, [0, 1, 3, 4, 2, 5]).reshape(-1, K, last)
+    out = ml_detector(y_dt.reshape((-1,) + y_dt.shape[-1:]), hd.reshape((-1,) + hd.shape[-2:]), s.reshape((-1,) + s.shape[-2:]),
+                      points, method, pr, output, hard_out)
+    out = _extract_data(rg, sm, out.reshape(shp + out.shape[1:]), y.shape[0])
+    return out.reshape(out.shape[:3] + (-1,)) if output == "bit" else out
+
+
 # ------------------------------------------------------------------ ZF / MF equalisers
 def zf_equalizer(y, h, s):
     """mimo/equalization.py:235-298 (complex128)."""

@@ -112,6 +112,9 @@ _SIGNATURES = {
     "samd_ofdm_ep_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                 _i32, _i32, _i32, _i32, _i32, _f32, _f32, _f32, _i32, _vp, _vp]),
     "samd_kbest_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "samd_ml_detect_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_ofdm_ml_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_ofdm_kbest_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "samd_crc_f32": (_i32, [_vp, _i64, _i32, C.c_uint32, _i32, _i32, _vp, _vp]),

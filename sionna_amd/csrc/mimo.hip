@@ -1170,6 +1170,136 @@ __global__ __launch_bounds__(64) void ofdm_mmse_pic_kernel(OfdmEqArgs p, const f
     }
 }
 
+// ---- MaximumLikelihoodDetector.call (mimo/detection.py:145-537): whiten with the Cholesky factor of S, then for every
+// candidate vector x of the P^K (P = 2^nb points, K streams; stream 0 the most significant digit as in _build_vecs :414-470)
+// the exponent -||y~ - H~ x||^2 (+ the prior logits of its symbols), reduced per (stream, point) with logsumexp ("app") or max
+// ("maxlog") -> logits [K][P].  One lane per problem; its K * P running (max, scaled sum) pairs - an online logsumexp - and the
+// prior live in LDS with the lane as the fastest index (conflict-free), the candidates are enumerated in registers.  Bit LLRs /
+// hard decisions are the host block's second launch of samd_symbol_logits2llrs_f32, as in the reference (:531-536).
+struct MlParams {
+  const float2* points;   // [2^nb]
+  int nb, maxlog, has_prior;
+};
+
+template <int M, int K>
+__device__ void ml_logits(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float* __restrict__ acc, const float* __restrict__ prior,
+                          const MlParams& q) {
+  const int P = 1 << q.nb, lane = threadIdx.x;
+  cholesky<M>(s);                                             // whiten_channel: y~ = L^-1 y, H~ = L^-1 H
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    c32 v = y[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v = v - s[i][k] * y[k];
+    y[i] = scale(v, 1.f / s[i][i].re);
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      c32 w = h[i][c];
+#pragma unroll
+      for (int k = 0; k < i; ++k) w = w - s[i][k] * h[k][c];
+      h[i][c] = scale(w, 1.f / s[i][i].re);
+    }
+  }
+  for (int a = 0; a < K * P; ++a) { acc[(2 * a) * 64 + lane] = -INFINITY; acc[(2 * a + 1) * 64 + lane] = 0.f; }
+  int nv = 1;
+  for (int k = 0; k < K; ++k) nv *= P;
+  for (int v = 0; v < nv; ++v) {
+    int idx[K];
+    c32 x[K];
+    int r = v;
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+      idx[k] = r & (P - 1);
+      r >>= q.nb;
+      const float2 pt = q.points[idx[k]];
+      x[k] = C(pt.x, pt.y);
+    }
+    float e = 0.f;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      c32 d = y[m];
+#pragma unroll
+      for (int k = 0; k < K; ++k) d = d - h[m][k] * x[k];
+      e -= d.re * d.re + d.im * d.im;
+    }
+    if (q.has_prior) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) e += prior[(k * P + idx[k]) * 64 + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float* a = acc + (size_t)(2 * (k * P + idx[k])) * 64 + lane;
+      const float mx = a[0];
+      if (q.maxlog) {
+        a[0] = fmaxf(mx, e);
+      } else if (e > mx) {                                     // online logsumexp: sum is relative to the running maximum
+        a[64] = a[64] * expf(mx - e) + 1.f;                     // (first visit: 0 * exp(-inf) + 1)
+        a[0] = e;
+      } else {
+        a[64] += expf(e - mx);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ float ml_logit(const float* __restrict__ acc, int a, int maxlog) {
+  const float mx = acc[(2 * a) * 64 + threadIdx.x];
+  return maxlog ? mx : mx + logf(acc[(2 * a + 1) * 64 + threadIdx.x]);
+}
+
+// y [n,M], h [n,M,K], s [n,M,M], prior nullable [n,K,P] -> logits [n,K,P]
+template <int M, int K>
+__global__ __launch_bounds__(64) void ml_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                      const float2* __restrict__ s, const float* __restrict__ prior, int64_t n,
+                                                      MlParams q, float* __restrict__ out) {
+  extern __shared__ float ml_lds[];                           // acc [K*P][2][64], prior [K*P][64]
+  const int P = 1 << q.nb;
+  float* acc = ml_lds;
+  float* pr = ml_lds + (size_t)2 * K * P * 64;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  c32 yy[M], hh[M][K], ss[M][M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    yy[m] = C(y[i * M + m].x, y[i * M + m].y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float2 v = h[(i * M + m) * K + k]; hh[m][k] = C(v.x, v.y); }
+#pragma unroll
+    for (int j = 0; j < M; ++j) { const float2 v = s[(i * M + m) * M + j]; ss[m][j] = C(v.x, v.y); }
+  }
+  if (q.has_prior)
+    for (int a = 0; a < K * P; ++a) pr[a * 64 + threadIdx.x] = prior[i * K * P + a];
+  ml_logits<M, K>(yy, hh, ss, acc, pr, q);
+  for (int a = 0; a < K * P; ++a) out[i * K * P + a] = ml_logit(acc, a, q.maxlog);
+}
+
+// fused OFDM form (ofdm/detection.py:524-738 on OFDMDetector / OFDMDetectorWithPrior): prior / out [B, S, ND, P]
+template <int M, int K>
+__global__ __launch_bounds__(64) void ofdm_ml_kernel(OfdmEqArgs p, const float* __restrict__ prior, MlParams q, float* __restrict__ out) {
+  extern __shared__ float ml_lds[];
+  const int P = 1 << q.nb;
+  float* acc = ml_lds;
+  float* pr = ml_lds + (size_t)2 * K * P * 64;
+  const int re_i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (re_i >= p.T * p.F) return;
+  const int brx_i = p.brx0 + (int)blockIdx.y;
+  int dpos[K], rx;
+  int64_t b;
+  c32 y[M], h[M][K], s[M][M];
+  if (!load_re<M, K>(p, brx_i, re_i, y, h, s, dpos, b, rx)) return;
+  if (q.has_prior)
+    for (int k = 0; k < K; ++k) {
+      const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + (dpos[k] >= 0 ? dpos[k] : 0)) * P;
+      for (int c = 0; c < P; ++c) pr[(k * P + c) * 64 + threadIdx.x] = dpos[k] >= 0 ? prior[o + c] : 0.f;
+    }
+  ml_logits<M, K>(y, h, s, acc, pr, q);
+  for (int k = 0; k < K; ++k)
+    if (dpos[k] >= 0) {
+      const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * P;
+      for (int c = 0; c < P; ++c) out[o + c] = ml_logit(acc, k * P + c, q.maxlog);
+    }
+}
+
 // ---- LSChannelEstimator(interpolation_type="nn") + LMMSEEqualizer (+ Demapper) in ONE pass over the received grid.
 // With nearest-neighbour interpolation h_hat holds, at every resource element, a copy of the LS estimate of the nearest
 // pilot: 8 M K bytes per RE that the estimator writes and the equaliser reads back (64 of config C4's 120 B per RE).  This
@@ -1556,5 +1686,72 @@ extern "C" int samd_ofdm_kbest_f32(const float* y, const float* h_hat, const flo
   SAMD_MK_SQUARE_LIST(X)
 #undef X
   set_error("ofdm_kbest: unsupported (num_rx_ant, streams_per_rx) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+// ---- MaximumLikelihoodDetector (mimo/detection.py:145-537; ofdm/detection.py:524-738)
+static int ml_check(int num_bits_per_symbol, int k, size_t* lds) {
+  if (num_bits_per_symbol < 1 || num_bits_per_symbol > 8 || k < 1) return SAMD_ERR_INVALID;
+  const int64_t P = 1ll << num_bits_per_symbol;
+  int64_t nv = 1;
+  for (int i = 0; i < k; ++i) { nv *= P; if (nv > 65536) break; }
+  *lds = (size_t)3 * k * P * 64 * sizeof(float);
+  if (nv > 65536 || *lds > 150 * 1024) {
+    set_error("ml detector: num_points^num_streams <= 65536 and num_streams * num_points <= 200 on the HIP path");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  return SAMD_OK;
+}
+
+extern "C" int samd_ml_detect_f32(const float* y, const float* h, const float* s, const float* prior, const float* points,
+                                  int64_t n, int m, int k, int num_bits_per_symbol, int maxlog, float* logits, void* stream) {
+  SAMD_REQUIRE(y && h && s && points && logits && n >= 0, "bad argument");
+  size_t lds = 0;
+  if (int rc = ml_check(num_bits_per_symbol, k, &lds)) { if (rc == SAMD_ERR_INVALID) set_error("bad detector parameters"); return rc; }
+  if (n == 0) return SAMD_OK;
+  const MlParams q{(const float2*)points, num_bits_per_symbol, maxlog ? 1 : 0, prior ? 1 : 0};
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define X(M, K)                                                                                                 \
+  if (m == M && k == K) {                                                                                       \
+    if (lds > 64 * 1024) SAMD_SET_MAX_LDS((ml_items_kernel<M, K>), 160 * 1024);                                 \
+    hipLaunchKernelGGL((ml_items_kernel<M, K>), grid, dim3(64), lds, (hipStream_t)stream, (const float2*)y,    \
+                       (const float2*)h, (const float2*)s, prior, n, q, logits);                                \
+    return launch_status();                                                                                     \
+  }
+  SAMD_MK_SQUARE_LIST(X)
+#undef X
+  set_error("ml detector: unsupported (num_rx_ant, num_streams) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_ofdm_ml_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode, const float* no,
+                                const float* prior, const float* points, const int32_t* sc_ind, const int32_t* desired,
+                                const int32_t* undesired, const int32_t* data_pos, int batch, int num_rx, int num_rx_ant,
+                                int num_streams_total, int streams_per_rx, int num_undesired, int num_ofdm_symbols,
+                                int num_eff_subcarriers, int fft_size, int num_data, int num_bits_per_symbol, int maxlog,
+                                float* logits, void* stream) {
+  SAMD_REQUIRE(y && h_hat && no && points && sc_ind && desired && data_pos && logits, "null argument");
+  SAMD_REQUIRE(ev_mode >= 0 && ev_mode <= 2 && (ev_mode == 0 || err_var), "bad err_var mode");
+  SAMD_REQUIRE(num_undesired == 0 || undesired, "undesired stream table missing");
+  size_t lds = 0;
+  if (int rc = ml_check(num_bits_per_symbol, streams_per_rx, &lds)) { if (rc == SAMD_ERR_INVALID) set_error("bad detector parameters"); return rc; }
+  OfdmEqArgs p{(const float2*)y, (const float2*)h_hat, err_var, no, sc_ind, desired, undesired, data_pos, nullptr,
+               nullptr, batch, num_rx, num_streams_total, num_ofdm_symbols, num_eff_subcarriers, fft_size,
+               num_undesired, num_data, ev_mode, 1};
+  const MlParams q{(const float2*)points, num_bits_per_symbol, maxlog ? 1 : 0, prior ? 1 : 0};
+  const int64_t total = (int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers;
+  if (total == 0) return SAMD_OK;
+  const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 63) / 64, brx_total = batch * num_rx;
+#define X(M, K)                                                                                          \
+  if (num_rx_ant == M && streams_per_rx == K) {                                                          \
+    if (lds > 64 * 1024) SAMD_SET_MAX_LDS((ofdm_ml_kernel<M, K>), 160 * 1024);                           \
+    for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 65535)                                                \
+      hipLaunchKernelGGL((ofdm_ml_kernel<M, K>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(64), lds, \
+                         (hipStream_t)stream, p, prior, q, logits);                                      \
+    return launch_status();                                                                              \
+  }
+  SAMD_MK_SQUARE_LIST(X)
+#undef X
+  set_error("ofdm_ml: unsupported (num_rx_ant, streams_per_rx) combination");
   return SAMD_ERR_UNSUPPORTED;
 }

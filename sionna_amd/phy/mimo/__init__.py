@@ -2,4 +2,4 @@
 for the hot path: StreamManagement, lmmse_equalizer, LinearDetector("lmmse"))."""
 from .stream_management import StreamManagement
 from .equalization import lmmse_equalizer, zf_equalizer, mf_equalizer
-from .detection import LinearDetector, MMSEPICDetector, EPDetector, KBestDetector
+from .detection import LinearDetector, MMSEPICDetector, EPDetector, KBestDetector, MaximumLikelihoodDetector

@@ -264,3 +264,74 @@ class KBestDetector(Block):
         _ffi.check(_ffi.lib().samd_kbest_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pts), y.numel() // m, m,
                                              k, nb, kk, clip, hard, _ffi.ptr(out), _ffi.stream()), "KBestDetector")
         return wrap(self._finish(out, lead + (k,)))
+
+
+class MaximumLikelihoodDetector(Block):
+    """``MaximumLikelihoodDetector(output, demapping_method, num_streams, constellation_type=None, num_bits_per_symbol=None,
+    constellation=None, hard_out=False)(y, h, s, prior=None)`` - exhaustive maximum-likelihood detection (reference
+    mimo/detection.py:145-537): the channel is whitened with ``s``, the exponents ``-||y~ - H~ x||^2`` (+ prior) of ALL
+    ``num_points ** num_streams`` candidate vectors are reduced per stream and constellation point with logsumexp ("app") or max
+    ("maxlog") - one launch of ``samd_ml_detect_f32`` - and, for ``output="bit"``, turned into LLRs / hard bits by
+    :class:`~sionna_amd.phy.mapping.SymbolLogits2LLRs` like in the reference (:531-536).
+
+    y [..., M], h [..., M, num_streams], s [..., M, M]; prior: LLRs [..., num_streams, num_bits_per_symbol] ("bit") or logits
+    [..., num_streams, num_points] ("symbol") -> LLRs / bits [..., num_streams, num_bits_per_symbol], or logits
+    [..., num_streams, num_points] / symbol indices [..., num_streams] int32."""
+
+    def __init__(self, output, demapping_method, num_streams, constellation_type=None, num_bits_per_symbol=None,
+                 constellation=None, hard_out=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        assert output in ("bit", "symbol"), "Unknown output"
+        assert demapping_method in ("app", "maxlog"), "Unknown demapping method"
+        self._output, self._demapping_method, self._hard_out = output, demapping_method, bool(hard_out)
+        self._num_streams = int(num_streams)
+        self._constellation = Constellation.check_or_create(
+            constellation_type=constellation_type, num_bits_per_symbol=num_bits_per_symbol,
+            constellation=constellation, precision=precision)
+        nb = self._constellation.num_bits_per_symbol
+        if (1 << nb) ** self._num_streams > 65536 or self._num_streams * (1 << nb) > 200:
+            raise NotImplementedError("MaximumLikelihoodDetector: num_points ** num_streams <= 65536 and "
+                                      "num_streams * num_points <= 200 on the HIP path")
+        if output == "bit":
+            from ..mapping import SymbolLogits2LLRs, LLRs2SymbolLogits
+            self._logits2llr = SymbolLogits2LLRs(demapping_method, nb, hard_out=hard_out, precision=precision)
+            self._llrs2logits = LLRs2SymbolLogits(nb, hard_out=False, precision=precision)
+
+    constellation = property(lambda self: self._constellation)
+
+    def _kernel_params(self):
+        pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex64), torch.complex64)
+        return pts, self._constellation.num_bits_per_symbol, int(self._demapping_method == "maxlog")
+
+    def _finish(self, logits):
+        """logits [..., num_streams, num_points] -> the block's output (mimo/detection.py:529-537)"""
+        if self._output == "bit":
+            return self._logits2llr(logits)
+        if self._hard_out:
+            return torch.argmax(logits.as_subclass(torch.Tensor), dim=-1).to(torch.int32)
+        return logits
+
+    def call(self, y, h, s, prior=None):
+        self._require_single()
+        y = _ffi.to_device(y, torch.complex64)
+        h = _ffi.to_device(h, torch.complex64)
+        s = _ffi.to_device(s, torch.complex64)
+        m, k = h.shape[-2], h.shape[-1]
+        assert k == self._num_streams, "h must have num_streams columns"
+        lead = tuple(h.shape[:-2])
+        pts, nb, maxlog = self._kernel_params()
+        npts = 1 << nb
+        y = torch.broadcast_to(y, lead + (m,)).contiguous()
+        s = torch.broadcast_to(s, lead + (m, m)).contiguous()
+        h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
+        pr = None
+        if prior is not None:
+            pr = _ffi.to_device(prior, torch.float32)
+            if self._output == "bit":           # LLRs on the bits -> logits on the points (:475-479)
+                pr = self._llrs2logits(pr).as_subclass(torch.Tensor)
+            pr = torch.broadcast_to(pr, lead + (k, npts)).contiguous()
+        logits = torch.empty(lead + (k, npts), dtype=torch.float32, device=y.device)
+        _ffi.check(_ffi.lib().samd_ml_detect_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pr) if pr is not None else None,
+                                                 _ffi.ptr(pts), y.numel() // m, m, k, nb, maxlog, _ffi.ptr(logits), _ffi.stream()),
+                   "MaximumLikelihoodDetector")
+        return wrap(self._finish(logits))

@@ -5,5 +5,6 @@ from .resource_grid import ResourceGrid, ResourceGridMapper, ResourceGridDemappe
 from .channel_estimation import (LSChannelEstimator, NearestNeighborInterpolator, LinearInterpolator, LMMSEInterpolator,
                                  tdl_freq_cov_mat, tdl_time_cov_mat)
 from .equalization import OFDMEqualizer, LMMSEEqualizer, ZFEqualizer, MFEqualizer
-from .detection import LinearDetector, MMSEPICDetector, EPDetector, KBestDetector
+from .detection import LinearDetector, MMSEPICDetector, EPDetector, KBestDetector, MaximumLikelihoodDetector, \
+    MaximumLikelihoodDetectorWithPrior
 from .modulator import OFDMModulator, OFDMDemodulator

@@ -139,3 +139,60 @@ class KBestDetector(Block):
         if self._det._output == "symbol":       # indices of the best path's symbols [batch, num_tx, num_streams, num_data_symbols]
             return wrap(self._det._finish(out, (dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols)))
         return wrap(out)
+
+
+class MaximumLikelihoodDetector(Block):
+    """``MaximumLikelihoodDetector(output, demapping_method, resource_grid, stream_management, constellation_type=None,
+    num_bits_per_symbol=None, constellation=None, hard_out=False)(y, h_hat, err_var, no)`` (reference ofdm/detection.py:524-625 on
+    OFDMDetector :21-317): exhaustive ML detection of every data-carrying resource element in one fused launch
+    (``samd_ofdm_ml_f32``; covariance of noise + estimation error + undesired streams as for the other OFDM detectors), then
+    ``SymbolLogits2LLRs`` for ``output="bit"``.  -> [batch, num_tx, num_streams, num_data_symbols * num_bits_per_symbol] (LLRs /
+    bits), or [batch, num_tx, num_streams, num_data_symbols, num_points] logits / [..., num_data_symbols] int32 indices."""
+
+    _with_prior = False
+
+    def __init__(self, output, demapping_method, resource_grid, stream_management, constellation_type=None,
+                 num_bits_per_symbol=None, constellation=None, hard_out=False, precision=None, **kwargs):
+        super().__init__(precision=precision, **kwargs)
+        from ..mimo.detection import MaximumLikelihoodDetector as _MimoML
+        self._det = _MimoML(output, demapping_method, stream_management.num_streams_per_rx, constellation_type, num_bits_per_symbol,
+                            constellation, hard_out, precision=precision)
+        self._pre = OFDMEqualizer("lmmse", resource_grid, stream_management, precision=precision)
+        self._rg = resource_grid
+
+    def _run(self, y, h_hat, prior, err_var, no):
+        self._require_single()
+        rg, det = self._rg, self._det
+        pts, nb, maxlog = det._kernel_params()
+        npts = 1 << nb
+        keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
+        lead = (dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols)
+        pr = None
+        if prior is not None:
+            pr = _ffi.to_device(prior, torch.float32)
+            if det._output == "bit":            # [batch, num_tx, num_streams, num_data_symbols * nb] LLRs -> logits on the points
+                assert tuple(pr.shape) == lead[:3] + (lead[3] * nb,), "prior must have shape [batch, num_tx, num_streams, num_data_symbols*num_bits_per_symbol]"
+                pr = det._llrs2logits(pr.reshape(lead + (nb,))).as_subclass(torch.Tensor)
+            assert tuple(pr.shape) == lead + (npts,), "prior must have shape [batch, num_tx, num_streams, num_data_symbols, num_points]"
+            pr = pr.contiguous()
+        logits = torch.zeros(lead + (npts,), dtype=torch.float32, device=keep[0].device)
+        _ffi.check(_ffi.lib().samd_ofdm_ml_f32(*head, _ffi.ptr(pr) if pr is not None else None, _ffi.ptr(pts), *tabs, *dims, nb, maxlog,
+                                               _ffi.ptr(logits), _ffi.stream()), "ofdm.MaximumLikelihoodDetector")
+        out = det._finish(logits)
+        if det._output == "bit":                # [batch, num_tx, num_streams, num_data_symbols * nb] (ofdm/detection.py:289-317)
+            out = out.as_subclass(torch.Tensor).reshape(lead[:3] + (lead[3] * nb,))
+        return wrap(out)
+
+    def call(self, y, h_hat, err_var, no):
+        return self._run(y, h_hat, None, err_var, no)
+
+
+class MaximumLikelihoodDetectorWithPrior(MaximumLikelihoodDetector):
+    """``MaximumLikelihoodDetectorWithPrior(...)(y, h_hat, prior, err_var, no)`` (reference ofdm/detection.py:627-738 on
+    OFDMDetectorWithPrior :320-510): ``prior`` = LLRs [batch, num_tx, num_streams, num_data_symbols * num_bits_per_symbol]
+    (``output="bit"``) or logits [batch, num_tx, num_streams, num_data_symbols, num_points] (``"symbol"``)."""
+
+    _with_prior = True
+
+    def call(self, y, h_hat, prior, err_var, no):  # pylint: disable=arguments-differ
+        return self._run(y, h_hat, prior, err_var, no)
