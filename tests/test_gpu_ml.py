@@ -1,0 +1,137 @@
+"""GPU parity of the maximum-likelihood detectors (csrc/mimo.hip ml_items_kernel / ofdm_ml_kernel behind
+phy.mimo.MaximumLikelihoodDetector and phy.ofdm.MaximumLikelihoodDetector(.WithPrior)) against the reference's own detector
+EXECUTED under the NumPy stand-in for TensorFlow (tests/golden/ml_ref_golden.npz, tools/gen_ml_ref_golden.py) and against the
+float64 oracle (oracle/ofdm.py::ml_detector, pinned to the same fixture by tests/test_oracle_ref_exec_ml.py).  Float32 exponents
+of magnitude up to ~7e2: soft values within 2e-3 absolute + 2e-4 relative (the tolerance the fixture needs against float64)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ofdm as o, mapping as omap
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ml_ref_golden.npz"))
+CASES = ast.literal_eval(str(G["cases"]))
+
+
+@pytest.fixture(scope="module")
+def phy():
+    import sionna_amd.phy as p
+    from sionna_amd import _ffi
+    _ffi.device()
+    return p
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _cplx(rng, shape, scale=1.0):
+    return ((rng.normal(size=shape) + 1j * rng.normal(size=shape)) * scale / np.sqrt(2)).astype(np.complex64)
+
+
+def _check(got, ref, soft_ref, output, hard):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if not hard:
+        assert np.allclose(got, ref, rtol=2e-4, atol=2e-3), float(np.max(np.abs(got - ref)))
+        return
+    if output == "bit":
+        sure = np.abs(soft_ref) > 1e-2
+    else:
+        top2 = np.sort(soft_ref, -1)[..., -2:]
+        sure = (top2[..., 1] - top2[..., 0]) > 1e-2
+    assert sure.mean() > 0.95 and np.array_equal(got[sure], ref[sure])
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_ml_detector_matches_reference_execution(phy, ci):
+    M, K, nb, output, method, hard, with_prior = CASES[ci]
+    y, h, s, ref = G[f"c{ci}_y"], G[f"c{ci}_h"], G[f"c{ci}_s"], G[f"c{ci}_out"]
+    prior = G[f"c{ci}_prior"] if with_prior else None
+    det = phy.mimo.MaximumLikelihoodDetector(output, method, K, "qam", nb, hard_out=hard)
+    got = _np(det(y, h, s, prior) if with_prior else det(y, h, s))
+    if output == "symbol" and hard:
+        assert got.dtype == np.int32
+    soft = o.ml_detector(y, h, s, G[f"c{ci}_points"], method, prior, output, False)
+    _check(got, ref, soft, output, hard)
+
+
+@pytest.mark.parametrize("m,k,nb,method", [(4, 2, 2, "app"), (4, 2, 4, "maxlog"), (8, 4, 2, "app"), (2, 2, 4, "app"), (1, 1, 6, "maxlog"),
+                                           (16, 4, 2, "maxlog"), (4, 1, 4, "app")])
+def test_ml_detector_vs_oracle(phy, m, k, nb, method):
+    rng = np.random.default_rng(m * 7 + k + nb)
+    n = 300
+    pts = omap.qam(nb)
+    h = _cplx(rng, (n, m, k))
+    x = pts[rng.integers(0, 1 << nb, (n, k))]
+    a = _cplx(rng, (n, m, m), 0.3)
+    s = (a @ np.conj(np.swapaxes(a, -1, -2)) + 0.1 * np.eye(m)).astype(np.complex64)
+    y = (np.einsum("nmk,nk->nm", h, x) + _cplx(rng, (n, m), 0.3)).astype(np.complex64)
+    prior_llr = (rng.normal(size=(n, k, nb)) * 2).astype(np.float32)
+    for output, prior in (("bit", None), ("bit", prior_llr), ("symbol", None), ("symbol", (rng.normal(size=(n, k, 1 << nb))).astype(np.float32))):
+        det = phy.mimo.MaximumLikelihoodDetector(output, method, k, "qam", nb)
+        got = _np(det(y, h, s, prior) if prior is not None else det(y, h, s))
+        ref = o.ml_detector(y, h, s, pts, method, prior, output, False)
+        _check(got, ref, ref, output, False)
+    # leading dimensions and broadcasting of y / s like the other detectors
+    det = phy.mimo.MaximumLikelihoodDetector("bit", method, k, "qam", nb, hard_out=True)
+    got = _np(det(y.reshape(3, 100, m), h.reshape(3, 100, m, k), s.reshape(3, 100, m, m)))
+    soft = o.ml_detector(y, h, s, pts, method, None, "bit", False).reshape(3, 100, k, nb)
+    _check(got, (soft > 0).astype(np.float32), soft, "bit", True)
+
+
+def test_ml_detector_limits(phy):
+    with pytest.raises(NotImplementedError):
+        phy.mimo.MaximumLikelihoodDetector("bit", "app", 4, "qam", 6)              # 64^4 candidate vectors
+
+
+def _grids(phy, **kw):
+    base = dict(num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[3, 4], dc_null=True,
+                pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
+    base.update(kw)
+    return phy.ofdm.ResourceGrid(14, 72, 15e3, **base), o.ResourceGrid(14, 72, 15e3, **base)
+
+
+@pytest.mark.parametrize("output,method,hard", [("bit", "app", False), ("bit", "maxlog", True), ("symbol", "app", False), ("symbol", "maxlog", True)])
+def test_ofdm_ml_detector_vs_oracle(phy, output, method, hard):
+    rg, org = _grids(phy)
+    sm, osm = phy.mimo.StreamManagement(np.array([[1]]), 2), o.StreamManagement(np.array([[1]]), 2)
+    rng = np.random.default_rng(8)
+    B, nb = 3, 2
+    pts = omap.qam(nb)
+    y = _cplx(rng, (B, 1, 4, 14, 72))
+    h_hat = _cplx(rng, (B, 1, 4, 1, 2, 14, rg.num_effective_subcarriers))
+    ev = rng.uniform(0.0, 0.05, size=(1, 1, 1, 1, 2, 14, rg.num_effective_subcarriers)).astype(np.float32)
+    det = phy.ofdm.MaximumLikelihoodDetector(output, method, rg, sm, constellation_type="qam", num_bits_per_symbol=nb, hard_out=hard)
+    got = _np(det(y, h_hat, ev, 0.4))
+    ref = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.4, pts, method, None, output, hard)
+    soft = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.4, pts, method, None, output, False)
+    _check(got, ref.astype(got.dtype) if hard else ref, soft, output, hard)
+    # with prior
+    nd = rg.num_data_symbols
+    prior = (rng.normal(size=(B, 1, 2, nd * nb)) * 2).astype(np.float32) if output == "bit" else rng.normal(size=(B, 1, 2, nd, 1 << nb)).astype(np.float32)
+    detp = phy.ofdm.MaximumLikelihoodDetectorWithPrior(output, method, rg, sm, constellation_type="qam", num_bits_per_symbol=nb, hard_out=hard)
+    got = _np(detp(y, h_hat, prior, ev, 0.4))
+    ref = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.4, pts, method, prior, output, hard)
+    soft = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.4, pts, method, prior, output, False)
+    _check(got, ref.astype(got.dtype) if hard else ref, soft, output, hard)
+
+
+def test_ofdm_ml_two_receivers_with_interference(phy):
+    """two receivers, one stream each, the other transmitter's stream is interference (undesired stream in the covariance)"""
+    rg, org = _grids(phy, num_tx=2, num_streams_per_tx=1)
+    assoc = np.array([[1, 0], [0, 1]])
+    sm, osm = phy.mimo.StreamManagement(assoc, 1), o.StreamManagement(assoc, 1)
+    rng = np.random.default_rng(9)
+    B, nb = 2, 4
+    pts = omap.qam(nb)
+    y = _cplx(rng, (B, 2, 4, 14, 72))
+    h_hat = _cplx(rng, (B, 2, 4, 2, 1, 14, rg.num_effective_subcarriers))
+    det = phy.ofdm.MaximumLikelihoodDetector("bit", "app", rg, sm, constellation_type="qam", num_bits_per_symbol=nb)
+    got = _np(det(y, h_hat, 0.0, 0.3))
+    ref = o.ofdm_ml_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.3, pts, "app")
+    _check(got, ref, ref, "bit", False)

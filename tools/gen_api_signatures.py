@@ -47,13 +47,14 @@ SURFACE = {      # reference file -> (import path in sionna.phy, names)
     "channel/tr38901/antenna.py": ("channel.tr38901", ["Antenna", "AntennaArray", "PanelArray"]),
     "mimo/stream_management.py": ("mimo", ["StreamManagement"]),
     "mimo/equalization.py": ("mimo", ["lmmse_equalizer", "zf_equalizer", "mf_equalizer"]),
-    "mimo/detection.py": ("mimo", ["LinearDetector", "KBestDetector", "EPDetector", "MMSEPICDetector"]),
+    "mimo/detection.py": ("mimo", ["LinearDetector", "KBestDetector", "EPDetector", "MMSEPICDetector", "MaximumLikelihoodDetector"]),
     "ofdm/resource_grid.py": ("ofdm", ["ResourceGrid", "ResourceGridMapper", "ResourceGridDemapper", "RemoveNulledSubcarriers"]),
     "ofdm/pilot_pattern.py": ("ofdm", ["PilotPattern", "EmptyPilotPattern", "KroneckerPilotPattern"]),
     "ofdm/channel_estimation.py": ("ofdm", ["LSChannelEstimator", "NearestNeighborInterpolator", "LinearInterpolator", "LMMSEInterpolator",
                                             "tdl_freq_cov_mat", "tdl_time_cov_mat"]),
     "ofdm/equalization.py": ("ofdm", ["OFDMEqualizer", "LMMSEEqualizer", "ZFEqualizer", "MFEqualizer"]),
-    "ofdm/detection.py": ("ofdm", ["LinearDetector", "KBestDetector", "EPDetector", "MMSEPICDetector"]),
+    "ofdm/detection.py": ("ofdm", ["LinearDetector", "KBestDetector", "EPDetector", "MMSEPICDetector", "MaximumLikelihoodDetector",
+                                    "MaximumLikelihoodDetectorWithPrior"]),
     "ofdm/modulator.py": ("ofdm", ["OFDMModulator"]),
     "ofdm/demodulator.py": ("ofdm", ["OFDMDemodulator"]),
     "utils/misc.py": ("utils", ["ebnodb2no", "hard_decisions", "sim_ber", "complex_normal"]),
