@@ -414,6 +414,20 @@ int samd_ofdm_kbest_f32(const float* y, const float* h_hat, const float* err_var
                         int num_data, int num_bits_per_symbol, int num_paths, float llr_clip,
                         int hard_out, float* out, void* stream);
 
+/* KBestDetector(use_real_rep=True)  mimo/detection.py:705-727, 815-823, 1011-1030: the same tree search on the real-valued
+ * equivalent of the channel (complex2real_channel, mimo/utils.py:13-190) - 2k real streams over the PAM levels of one axis,
+ * distances halved for the LLRs (List2LLRSimple, mimo/utils.py:544-547).  Arguments of samd_kbest_f32 / samd_ofdm_kbest_f32
+ * with pam_points DEVICE complex64 [2^(num_bits_per_symbol/2)] = the levels as (p, 0); num_bits_per_symbol even (square QAM);
+ * out [n, k, num_bits_per_symbol] (resp. [batch, num_streams_total, num_data * num_bits_per_symbol]) in the QAM's bit order. */
+int samd_kbest_real_f32(const float* y, const float* h, const float* s, const float* pam_points, int64_t n, int m, int k,
+                        int num_bits_per_symbol, int num_paths, float llr_clip, int hard_out, float* out, void* stream);
+int samd_ofdm_kbest_real_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode, const float* no,
+                             const float* pam_points, const int32_t* sc_ind, const int32_t* desired,
+                             const int32_t* undesired, const int32_t* data_pos, int batch, int num_rx, int num_rx_ant,
+                             int num_streams_total, int streams_per_rx, int num_undesired, int num_ofdm_symbols,
+                             int num_eff_subcarriers, int fft_size, int num_data, int num_bits_per_symbol,
+                             int num_paths, float llr_clip, int hard_out, float* out, void* stream);
+
 /* MaximumLikelihoodDetector.call  mimo/detection.py:145-537 on n independent problems: whitening with the Cholesky factor of s,
  * then the exponent -||y~ - H~ x||^2 (+ prior logits of the symbols of x) of every candidate vector x in points^k (stream 0 =
  * most significant digit, _build_vecs :414-470), reduced per (stream, point) with logsumexp (maxlog = 0, "app") or max.

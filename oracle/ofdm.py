@@ -689,7 +689,34 @@ def ofdm_ep_detector(rg, sm, y, h_hat, err_var, no, num_bits_per_symbol, l=10, b
 
 
 # ------------------------------------------------------------------ K-Best detector
-def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0, output="bit"):
+def pam_levels_real_rep(nbh):
+    """the PAM constellation of the real-valued K-Best (mimo/detection.py:719-724): Gray-labelled, unnormalised levels of
+    mapping.pam_gray divided by std * sqrt(2)"""
+    from . import mapping as omap
+    lab = _bit_labels(nbh)
+    pts = np.array([omap.pam_gray(lab[i]) for i in range(1 << nbh)], np.float64)
+    return pts / (np.std(pts) * np.sqrt(2))
+
+
+def kbest_detector_real(y, h, s, num_bits_per_symbol, k, hard_out=False, llr_clip=20.0, output="bit"):
+    """KBestDetector(use_real_rep=True).call (mimo/detection.py:705-727, 815-823, 1011-1030): complex2real_channel
+    (mimo/utils.py:13-190), the tree search over the PAM levels with 2K real streams, distances halved in List2LLRSimple
+    (mimo/utils.py:544-547), LLRs / bits of the in-phase and quadrature streams interleaved into the QAM's bit order."""
+    y, h, s = np.asarray(y, np.complex128), np.asarray(h, np.complex128), np.asarray(s, np.complex128)
+    K = h.shape[-1]
+    yr = np.concatenate([y.real, y.imag], -1)
+    hr = np.concatenate([np.concatenate([h.real, -h.imag], -1), np.concatenate([h.imag, h.real], -1)], -2)
+    sr = 0.5 * np.concatenate([np.concatenate([s.real, -s.imag], -1), np.concatenate([s.imag, s.real], -1)], -2)
+    nbh = num_bits_per_symbol // 2
+    out = kbest_detector(yr, hr, sr, pam_levels_real_rep(nbh), k, hard_out, llr_clip, "bit", dist_scale=0.5)     # [n, 2K, nbh]
+    out = np.stack([out[:, :K], out[:, K:]], -1).reshape(out.shape[0], K, 2 * nbh)
+    if output == "symbol":
+        assert hard_out, "Soft-symbols are not supported for this detector."
+        return np.sum(out.astype(np.int64) << (2 * nbh - 1 - np.arange(2 * nbh)), -1).astype(np.int32)
+    return out
+
+
+def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0, output="bit", dist_scale=1.0):
     """KBestDetector.call (complex representation, mimo/detection.py:815-1037) + List2LLRSimple
     (mimo/utils.py:539-578) in float64: y [n,M], h [n,M,K], s [n,M,M] -> LLRs [n,K,nb]."""
     y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
@@ -726,20 +753,24 @@ def kbest_detector(y, h, s, points, k, hard_out=False, llr_clip=20.0, output="bi
     bits = (inds[..., None] >> (nb - 1 - np.arange(nb))) & 1                                   # [n, paths, K, nb]
     if hard_out:
         return bits[:, 0].astype(np.float32)
-    dd = dists[:, :, None, None]
+    dd = dist_scale * dists[:, :, None, None]
     l0 = np.min(np.where(bits == 0, dd, np.inf), axis=1)
     l1 = np.min(np.where(bits == 1, dd, np.inf), axis=1)
     with np.errstate(invalid="ignore"):
         return np.clip(l0 - l1, -llr_clip, llr_clip).astype(np.float32)
 
 
-def ofdm_kbest_detector(rg, sm, y, h_hat, err_var, no, points, k, hard_out=False, output="bit"):
+def ofdm_kbest_detector(rg, sm, y, h_hat, err_var, no, points, k, hard_out=False, output="bit", use_real_rep=False):
     """ofdm.KBestDetector.call -> [B,tx,streams,num_data*nb] (output="bit") or indices [B,tx,streams,num_data]
     (output="symbol", hard decisions)."""
     y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
     shp = hd.shape[:-2]
-    llr = kbest_detector(y_dt.reshape((-1,) + y_dt.shape[-1:]), hd.reshape((-1,) + hd.shape[-2:]),
-                         s.reshape((-1,) + s.shape[-2:]), points, k, hard_out, output=output)
+    if use_real_rep:
+        llr = kbest_detector_real(y_dt.reshape((-1,) + y_dt.shape[-1:]), hd.reshape((-1,) + hd.shape[-2:]),
+                                  s.reshape((-1,) + s.shape[-2:]), int(np.log2(len(points))), k, hard_out, output=output)
+    else:
+        llr = kbest_detector(y_dt.reshape((-1,) + y_dt.shape[-1:]), hd.reshape((-1,) + hd.shape[-2:]),
+                             s.reshape((-1,) + s.shape[-2:]), points, k, hard_out, output=output)
     out = _extract_data(rg, sm, llr.reshape(shp + llr.shape[1:]), y.shape[0])
     return out if output == "symbol" else out.reshape(out.shape[:3] + (-1,))
 

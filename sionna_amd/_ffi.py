@@ -117,6 +117,9 @@ _SIGNATURES = {
                                 _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_ofdm_kbest_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "samd_kbest_real_f32": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "samd_ofdm_kbest_real_f32": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                   _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "samd_crc_f32": (_i32, [_vp, _i64, _i32, C.c_uint32, _i32, _i32, _vp, _vp]),
     "samd_polar_encode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_polar_scl_register_stages": (_i32, [_i32, _i32, _i32]),

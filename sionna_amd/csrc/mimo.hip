@@ -964,6 +964,7 @@ struct KBestParams {
   const float2* points;   // [2^nb]
   int nb, k, hard_out;
   float clip;
+  float dist_scale = 1.f;   // real-valued representation: List2LLRSimple halves the distances (mimo/utils.py:544-547)
 };
 
 template <int M, int K>
@@ -1077,7 +1078,7 @@ __device__ void kbest_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (
       for (int pth = 0; pth < np_old; ++pth) {
         if ((sym[cur][pth][t] >> (q.nb - 1 - b)) & 1) l1 = fminf(l1, dist[cur][pth]); else l0 = fminf(l0, dist[cur][pth]);
       }
-      llr[k][b] = clampf(l0 - l1, -q.clip, q.clip);
+      llr[k][b] = clampf(q.dist_scale * l0 - q.dist_scale * l1, -q.clip, q.clip);
     }
   }
 }
@@ -1118,6 +1119,74 @@ __global__ __launch_bounds__(64) void ofdm_kbest_kernel(OfdmEqArgs p, KBestParam
     if (dpos[k] >= 0) {
       const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * q.nb;
       for (int bb = 0; bb < q.nb; ++bb) out[o + bb] = llr[k][bb];
+    }
+}
+
+// ---- KBestDetector(use_real_rep=True) (mimo/detection.py:705-727, 815-823, 1011-1030): the real-valued equivalent of the channel
+// (complex2real_channel, mimo/utils.py:13-190: y_r = [Re y; Im y], H_r = [[Re H, -Im H], [Im H, Re H]], S_r = 1/2 [[Re S, -Im S],
+// [Im S, Re S]]) is searched over the PAM levels of one axis - 2K real streams of nb/2 bits - by the SAME tree search, instantiated
+// at (2M, 2K) on numbers whose imaginary parts are zero; distances halved for the LLRs; the LLRs (or bits) of stream k are the
+// interleaved ones of real streams k (in-phase: even bits) and K + k (quadrature: odd bits).  q.points = the PAM levels as (p, 0),
+// q.nb = nb / 2.  out [.., K, nb].
+template <int M, int K>
+__device__ void kbest_real_solve(const c32 (&y)[M], const c32 (&h)[M][K], const c32 (&s)[M][M], float (&out)[K][kMaxBits], const KBestParams& q) {
+  c32 yr[2 * M], hr[2 * M][2 * K], sr[2 * M][2 * M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    yr[i] = C(y[i].re, 0.f); yr[M + i] = C(y[i].im, 0.f);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      hr[i][k] = C(h[i][k].re, 0.f); hr[i][K + k] = C(-h[i][k].im, 0.f);
+      hr[M + i][k] = C(h[i][k].im, 0.f); hr[M + i][K + k] = C(h[i][k].re, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      sr[i][j] = C(0.5f * s[i][j].re, 0.f); sr[i][M + j] = C(-0.5f * s[i][j].im, 0.f);
+      sr[M + i][j] = C(0.5f * s[i][j].im, 0.f); sr[M + i][M + j] = C(0.5f * s[i][j].re, 0.f);
+    }
+  }
+  float lr[2 * K][kMaxBits];
+  kbest_solve<2 * M, 2 * K>(yr, hr, sr, lr, q);
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < q.nb; ++b) { out[k][2 * b] = lr[k][b]; out[k][2 * b + 1] = lr[K + k][b]; }
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(64) void kbest_real_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
+                                                              const float2* __restrict__ s, int64_t n, KBestParams q,
+                                                              float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  c32 yy[M], hh[M][K], ss[M][M];
+  float llr[K][kMaxBits];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    yy[m] = C(y[i * M + m].x, y[i * M + m].y);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { const float2 v = h[(i * M + m) * K + k]; hh[m][k] = C(v.x, v.y); }
+#pragma unroll
+    for (int j = 0; j < M; ++j) { const float2 v = s[(i * M + m) * M + j]; ss[m][j] = C(v.x, v.y); }
+  }
+  kbest_real_solve<M, K>(yy, hh, ss, llr, q);
+  for (int k = 0; k < K; ++k)
+    for (int b = 0; b < 2 * q.nb; ++b) out[(i * K + k) * 2 * q.nb + b] = llr[k][b];
+}
+
+template <int M, int K>
+__global__ __launch_bounds__(64) void ofdm_kbest_real_kernel(OfdmEqArgs p, KBestParams q, float* __restrict__ out) {
+  const int re_i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (re_i >= p.T * p.F) return;
+  const int brx_i = p.brx0 + (int)blockIdx.y;
+  int dpos[K], rx;
+  int64_t b;
+  c32 y[M], h[M][K], s[M][M];
+  if (!load_re<M, K>(p, brx_i, re_i, y, h, s, dpos, b, rx)) return;
+  float llr[K][kMaxBits];
+  kbest_real_solve<M, K>(y, h, s, llr, q);
+  for (int k = 0; k < K; ++k)
+    if (dpos[k] >= 0) {
+      const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * 2 * q.nb;
+      for (int bb = 0; bb < 2 * q.nb; ++bb) out[o + bb] = llr[k][bb];
     }
 }
 
@@ -1753,5 +1822,60 @@ extern "C" int samd_ofdm_ml_f32(const float* y, const float* h_hat, const float*
   SAMD_MK_SQUARE_LIST(X)
 #undef X
   set_error("ofdm_ml: unsupported (num_rx_ant, streams_per_rx) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+// ---- KBestDetector(use_real_rep=True): the arguments of samd_kbest_f32 / samd_ofdm_kbest_f32 with `points` = the 2^(nb/2) PAM
+// levels of one axis as complex numbers (p, 0) and num_bits_per_symbol = the QAM's (even)
+#define SAMD_MK_REAL_LIST(X) X(1, 1) X(2, 1) X(2, 2) X(4, 1) X(4, 2) X(4, 4) X(8, 1) X(8, 2)
+
+extern "C" int samd_kbest_real_f32(const float* y, const float* h, const float* s, const float* pam_points, int64_t n, int m, int k,
+                                   int num_bits_per_symbol, int num_paths, float llr_clip, int hard_out, float* out, void* stream) {
+  SAMD_REQUIRE(y && h && s && pam_points && out && n >= 0, "bad argument");
+  SAMD_REQUIRE(num_bits_per_symbol >= 2 && num_bits_per_symbol % 2 == 0 && num_bits_per_symbol <= 2 * kMaxBits && 2 * (num_bits_per_symbol / 2) <= kMaxBits &&
+                   num_paths >= 1 && num_paths <= kMaxPaths, "bad detector parameters (square QAM, num_paths <= 64)");
+  if (n == 0) return SAMD_OK;
+  const KBestParams q{(const float2*)pam_points, num_bits_per_symbol / 2, num_paths, hard_out, llr_clip, 0.5f};
+  const dim3 grid((unsigned)((n + 63) / 64));
+#define X(M, K)                                                                                                      \
+  if (m == M && k == K) {                                                                                            \
+    hipLaunchKernelGGL((kbest_real_items_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, (const float2*)y,   \
+                       (const float2*)h, (const float2*)s, n, q, out);                                               \
+    return launch_status();                                                                                          \
+  }
+  SAMD_MK_REAL_LIST(X)
+#undef X
+  set_error("kbest (real representation): unsupported (num_rx_ant, num_streams) combination");
+  return SAMD_ERR_UNSUPPORTED;
+}
+
+extern "C" int samd_ofdm_kbest_real_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode, const float* no,
+                                        const float* pam_points, const int32_t* sc_ind, const int32_t* desired,
+                                        const int32_t* undesired, const int32_t* data_pos, int batch, int num_rx, int num_rx_ant,
+                                        int num_streams_total, int streams_per_rx, int num_undesired, int num_ofdm_symbols,
+                                        int num_eff_subcarriers, int fft_size, int num_data, int num_bits_per_symbol,
+                                        int num_paths, float llr_clip, int hard_out, float* out, void* stream) {
+  SAMD_REQUIRE(y && h_hat && no && pam_points && sc_ind && desired && data_pos && out, "null argument");
+  SAMD_REQUIRE(ev_mode >= 0 && ev_mode <= 2 && (ev_mode == 0 || err_var), "bad err_var mode");
+  SAMD_REQUIRE(num_undesired == 0 || undesired, "undesired stream table missing");
+  SAMD_REQUIRE(num_bits_per_symbol >= 2 && num_bits_per_symbol % 2 == 0 && num_bits_per_symbol <= kMaxBits && num_paths >= 1 &&
+                   num_paths <= kMaxPaths, "bad detector parameters (square QAM, num_paths <= 64)");
+  OfdmEqArgs p{(const float2*)y, (const float2*)h_hat, err_var, no, sc_ind, desired, undesired, data_pos, nullptr,
+               nullptr, batch, num_rx, num_streams_total, num_ofdm_symbols, num_eff_subcarriers, fft_size,
+               num_undesired, num_data, ev_mode, 1};
+  const KBestParams q{(const float2*)pam_points, num_bits_per_symbol / 2, num_paths, hard_out, llr_clip, 0.5f};
+  const int64_t total = (int64_t)batch * num_rx * num_ofdm_symbols * num_eff_subcarriers;
+  if (total == 0) return SAMD_OK;
+  const int tf_blocks = (num_ofdm_symbols * num_eff_subcarriers + 63) / 64, brx_total = batch * num_rx;
+#define X(M, K)                                                                                          \
+  if (num_rx_ant == M && streams_per_rx == K) {                                                          \
+    for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 65535)                                                \
+      hipLaunchKernelGGL((ofdm_kbest_real_kernel<M, K>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(64), 0, \
+                         (hipStream_t)stream, p, q, out);                                                \
+    return launch_status();                                                                              \
+  }
+  SAMD_MK_REAL_LIST(X)
+#undef X
+  set_error("ofdm_kbest (real representation): unsupported (num_rx_ant, streams_per_rx) combination");
   return SAMD_ERR_UNSUPPORTED;
 }

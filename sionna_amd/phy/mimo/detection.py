@@ -194,7 +194,8 @@ class KBestDetector(Block):
     """``KBestDetector(output, num_streams, k, constellation_type=None, num_bits_per_symbol=None,
     constellation=None, hard_out=False, use_real_rep=False, list2llr=None)(y, h, s)``: breadth-first
     tree search keeping the k best partial paths (mimo/detection.py:539-1037) with the default
-    ``List2LLRSimple`` (mimo/utils.py:420-578); complex representation, bit output:
+    ``List2LLRSimple`` (mimo/utils.py:420-578); complex representation or (``use_real_rep=True``, QAM) the real-valued
+    equivalent of the channel with twice the streams over the PAM levels (``samd_kbest_real_f32``):
     y [...,M], h [...,M,K], s [...,M,M] -> [...,K,num_bits_per_symbol] (LLRs clipped to +-20, or bits)."""
 
     def __init__(self, output, num_streams, k, constellation_type=None, num_bits_per_symbol=None, constellation=None,
@@ -204,8 +205,7 @@ class KBestDetector(Block):
         if output == "symbol":
             assert hard_out is True, "Soft-symbols are not supported for this detector."
         self._output = output
-        if use_real_rep:
-            raise NotImplementedError("KBestDetector: the real-valued representation has no HIP path (use_real_rep=False)")
+        self._use_real_rep = bool(use_real_rep)
         if list2llr is not None:
             raise NotImplementedError("KBestDetector: custom list2llr callables have no HIP path (List2LLRSimple only)")
         self._constellation = Constellation.check_or_create(
@@ -213,7 +213,17 @@ class KBestDetector(Block):
             constellation=constellation, precision=precision)
         self._num_streams, self._hard_out = int(num_streams), bool(hard_out)
         num_symbols = 2 ** self._constellation.num_bits_per_symbol
-        self._k = int(min(k, num_symbols ** self._num_streams))
+        depth = self._num_streams
+        if self._use_real_rep:
+            # the real-valued equivalent of the channel: 2 num_streams real streams over the PAM levels of one axis
+            # (mimo/detection.py:705-727): QAM only
+            ct = constellation_type if constellation_type is not None else getattr(constellation, "_constellation_type", None)
+            assert ct == "qam", "Only QAM can be used for the real-valued representation"
+            nbh = self._constellation.num_bits_per_symbol // 2
+            pam = np.asarray(Constellation("pam", nbh, normalize=False, precision=precision).points)
+            self._pam_points = (pam / (np.std(pam) * np.sqrt(2))).astype(np.complex64)
+            num_symbols, depth = 2 ** nbh, 2 * self._num_streams
+        self._k = int(min(k, num_symbols ** depth))
         if self._k < k:
             import warnings
             warnings.warn(f"KBestDetector: The provided value of k={k} is larger than the possible maximum number of "
@@ -234,7 +244,8 @@ class KBestDetector(Block):
             raise NotImplementedError("KBestDetector: custom list2llr callables have no HIP path (List2LLRSimple only)")
 
     def _kernel_params(self):
-        pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex64), torch.complex64)
+        pts = self._pam_points if self._use_real_rep else np.asarray(self._constellation.points, np.complex64)
+        pts = _ffi.to_device(pts, torch.complex64)
         return pts, self._constellation.num_bits_per_symbol, self._k, self._llr_clip_val, int(self._hard_out)
 
     def _finish(self, out, lead_k):
@@ -261,8 +272,9 @@ class KBestDetector(Block):
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
         out = torch.empty(lead + (k, nb), dtype=torch.float32, device=y.device)
         h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
-        _ffi.check(_ffi.lib().samd_kbest_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pts), y.numel() // m, m,
-                                             k, nb, kk, clip, hard, _ffi.ptr(out), _ffi.stream()), "KBestDetector")
+        fn = _ffi.lib().samd_kbest_real_f32 if self._use_real_rep else _ffi.lib().samd_kbest_f32
+        _ffi.check(fn(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pts), y.numel() // m, m, k, nb, kk, clip, hard,
+                      _ffi.ptr(out), _ffi.stream()), "KBestDetector")
         return wrap(self._finish(out, lead + (k,)))
 
 

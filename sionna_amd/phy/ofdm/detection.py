@@ -134,8 +134,8 @@ class KBestDetector(Block):
         keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
         out = torch.zeros((dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols * nb), dtype=torch.float32,
                           device=keep[0].device)
-        _ffi.check(_ffi.lib().samd_ofdm_kbest_f32(*head, _ffi.ptr(pts), *tabs, *dims, nb, kk, clip, hard, _ffi.ptr(out),
-                                                  _ffi.stream()), "ofdm.KBestDetector")
+        fn = _ffi.lib().samd_ofdm_kbest_real_f32 if self._det._use_real_rep else _ffi.lib().samd_ofdm_kbest_f32
+        _ffi.check(fn(*head, _ffi.ptr(pts), *tabs, *dims, nb, kk, clip, hard, _ffi.ptr(out), _ffi.stream()), "ofdm.KBestDetector")
         if self._det._output == "symbol":       # indices of the best path's symbols [batch, num_tx, num_streams, num_data_symbols]
             return wrap(self._det._finish(out, (dims[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols)))
         return wrap(out)

@@ -135,3 +135,64 @@ def test_ofdm_ml_two_receivers_with_interference(phy):
     got = _np(det(y, h_hat, 0.0, 0.3))
     ref = o.ofdm_ml_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.3, pts, "app")
     _check(got, ref, ref, "bit", False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# KBestDetector(use_real_rep=True): samd_kbest_real_f32 / samd_ofdm_kbest_real_f32 against the reference's detector executed
+# (the same fixture file) and the float64 oracle (oracle/ofdm.py::kbest_detector_real)
+KB = ast.literal_eval(str(G["kbest_real_cases"]))
+
+
+@pytest.mark.parametrize("ci", range(len(KB)))
+def test_kbest_real_rep_matches_reference_execution(phy, ci):
+    M, K, nb, kk, output, hard = KB[ci]
+    y, h, s, ref = G[f"k{ci}_y"], G[f"k{ci}_h"], G[f"k{ci}_s"], G[f"k{ci}_out"]
+    det = phy.mimo.KBestDetector(output, K, kk, "qam", nb, hard_out=hard, use_real_rep=True)
+    got = _np(det(y, h, s))
+    assert got.shape == ref.shape
+    if hard:
+        assert np.mean(got == ref) > 0.97
+    else:
+        assert np.mean(np.isclose(got, ref, rtol=1e-3, atol=5e-3)) > 0.97      # a different k-th path at a float32 near-tie moves single LLRs
+
+
+@pytest.mark.parametrize("m,k,nb,paths", [(4, 2, 4, 16), (2, 2, 2, 16), (4, 4, 2, 32), (8, 2, 6, 24), (2, 1, 4, 4), (1, 1, 2, 4), (4, 1, 6, 8)])
+def test_kbest_real_rep_vs_oracle(phy, m, k, nb, paths):
+    rng = np.random.default_rng(m * 5 + k + nb)
+    n = 300
+    pts = omap.qam(nb)
+    h = _cplx(rng, (n, m, k))
+    x = pts[rng.integers(0, 1 << nb, (n, k))]
+    a = _cplx(rng, (n, m, m), 0.3)
+    s = (a @ np.conj(np.swapaxes(a, -1, -2)) + 0.1 * np.eye(m)).astype(np.complex64)
+    y = (np.einsum("nmk,nk->nm", h, x) + _cplx(rng, (n, m), 0.3)).astype(np.complex64)
+    got = _np(phy.mimo.KBestDetector("bit", k, paths, "qam", nb, use_real_rep=True)(y, h, s))
+    ref = o.kbest_detector_real(y, h, s, nb, paths)
+    ok = np.all(np.isclose(got, ref, rtol=1e-3, atol=2e-3), axis=(1, 2))
+    assert ok.mean() > 0.97, (1 - ok.mean(), np.max(np.abs(got - ref)))
+    hard = _np(phy.mimo.KBestDetector("bit", k, paths, "qam", nb, hard_out=True, use_real_rep=True)(y, h, s))
+    assert np.mean(np.all(hard == o.kbest_detector_real(y, h, s, nb, paths, hard_out=True), axis=(1, 2))) > 0.99
+    sym = _np(phy.mimo.KBestDetector("symbol", k, paths, "qam", nb, hard_out=True, use_real_rep=True)(y, h, s))
+    assert sym.dtype == np.int32 and np.mean(sym == o.kbest_detector_real(y, h, s, nb, paths, hard_out=True, output="symbol")) > 0.99
+    # both representations search the same lattice: with every path kept the hard decisions coincide (mimo/detection.py:546-549)
+    if (1 << nb) ** k <= 64:
+        full = (1 << nb) ** k
+        a_ = _np(phy.mimo.KBestDetector("bit", k, full, "qam", nb, hard_out=True, use_real_rep=True)(y, h, s))
+        b_ = _np(phy.mimo.KBestDetector("bit", k, full, "qam", nb, hard_out=True)(y, h, s))
+        assert np.mean(np.all(a_ == b_, axis=(1, 2))) > 0.99
+    with pytest.raises(AssertionError):
+        phy.mimo.KBestDetector("bit", k, paths, "pam", 2, use_real_rep=True)
+
+
+def test_ofdm_kbest_real_rep_vs_oracle(phy):
+    rg, org = _grids(phy)
+    sm, osm = phy.mimo.StreamManagement(np.array([[1]]), 2), o.StreamManagement(np.array([[1]]), 2)
+    rng = np.random.default_rng(11)
+    B, nb = 3, 4
+    pts = omap.qam(nb)
+    y = _cplx(rng, (B, 1, 4, 14, 72))
+    h_hat = _cplx(rng, (B, 1, 4, 1, 2, 14, rg.num_effective_subcarriers))
+    got = _np(phy.ofdm.KBestDetector("bit", 2, 16, rg, sm, constellation_type="qam", num_bits_per_symbol=nb, use_real_rep=True)(y, h_hat, 0.0, 0.4))
+    ref = o.ofdm_kbest_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.4, pts, 16, use_real_rep=True)
+    assert got.shape == ref.shape
+    assert np.mean(np.isclose(got, ref, rtol=1e-3, atol=2e-3)) > 0.99

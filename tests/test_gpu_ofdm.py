@@ -842,8 +842,8 @@ def test_mimo_kbest_vs_oracle(phy, m, k, nb, paths):
     if (m, k, nb, paths) == (2, 2, 2, 16):       # full enumeration == max-log ML: more bits right than the linear detector
         lin = _np(phy.mimo.LinearDetector("lmmse", "bit", "maxlog", constellation_type="qam", num_bits_per_symbol=nb)(y, h, s))
         assert np.mean((got > 0) != bits) <= np.mean((lin > 0) != bits)
-    with pytest.raises(NotImplementedError):
-        phy.mimo.KBestDetector("bit", k, paths, constellation_type="qam", num_bits_per_symbol=nb, use_real_rep=True)
+    with pytest.raises(NotImplementedError):                                   # custom list-to-LLR callables: no HIP path
+        phy.mimo.KBestDetector("bit", k, paths, constellation_type="qam", num_bits_per_symbol=nb, list2llr=lambda *a: None)
 
 
 def test_ofdm_kbest_vs_oracle(phy):

@@ -33,3 +33,21 @@ def test_ml_oracle_matches_reference_execution(ci):
         top2 = np.sort(soft, -1)[..., -2:]
         sure = (top2[..., 1] - top2[..., 0]) > 1e-2
         assert np.array_equal(got[sure], ref[sure]) and sure.mean() > 0.95
+
+
+KB = ast.literal_eval(str(G["kbest_real_cases"]))
+
+
+@pytest.mark.parametrize("ci", range(len(KB)))
+def test_kbest_real_rep_oracle_matches_reference_execution(ci):
+    """oracle/ofdm.py::kbest_detector_real against the reference's KBestDetector(use_real_rep=True) executed: LLRs (clipped to
+    +-20) within 5e-3 where the candidate lists agree - the float32 reference and the float64 oracle may keep a different k-th
+    path at a near-tie, which moves single LLRs: at least 97 % of the entries must agree."""
+    M, K, nb, kk, output, hard = KB[ci]
+    y, h, s, ref = G[f"k{ci}_y"], G[f"k{ci}_h"], G[f"k{ci}_s"], G[f"k{ci}_out"]
+    got = o.kbest_detector_real(y, h, s, nb, kk, hard, output=output)
+    assert got.shape == ref.shape
+    if hard:
+        assert np.mean(got == ref) > 0.97
+    else:
+        assert np.mean(np.isclose(got, ref, rtol=1e-3, atol=5e-3)) > 0.97, float(np.mean(np.isclose(got, ref, rtol=1e-3, atol=5e-3)))
