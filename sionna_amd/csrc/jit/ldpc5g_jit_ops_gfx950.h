@@ -27,6 +27,20 @@ JIT_DEV void lds_st2(U32 a, unsigned off, F32 x0, F32 x1) { *(jit_lds_f32x2*)(un
 typedef bool M64;                                                      // one bit per lane (an SGPR pair)
 JIT_DEV M64 u_testbit(U32 x, unsigned mask) { return (x & mask) != 0u; }
 JIT_DEV F32 f_sel(M64 m, F32 a, F32 b) { return m ? a : b; }
+// f_eq / f_sel_m: a comparison whose lane mask is consumed several instructions later.  Written as volatile assembly so that the
+// order of the generated text is the order of the instructions: the compiler's scheduler moves a v_cmp next to the v_cndmask that
+// reads its mask (shortest scalar live range) and then has to pad the two wait states gfx950 wants between them with s_nop.
+typedef unsigned long long M64S;
+JIT_DEV M64S f_eq_abs(F32 a, F32 b) {                        // |a| == b
+  M64S m;
+  asm volatile("v_cmp_eq_f32_e64 %0, |%1|, %2" : "=s"(m) : "v"(a), "v"(b));
+  return m;
+}
+JIT_DEV F32 f_sel_m(M64S m, F32 a, F32 b) {                 // m ? a : b
+  F32 r;
+  asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
 JIT_DEV U32 u_shl(U32 a, int n) { return a << n; }
 JIT_DEV U32 u_shr(U32 a, int n) { return a >> n; }
 JIT_DEV F32 g_ld(const float* row, U32 voff, unsigned coff) { return *(const float*)((const char*)row + (voff + coff)); }

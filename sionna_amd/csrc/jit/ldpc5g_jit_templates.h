@@ -83,6 +83,9 @@ JIT_DEV void jit_cn_store(U32 a0, unsigned off, const F32 (&c)[NCH]) {
 
 // FUSE: the row's last edge goes to a degree-1 VN of the same lane; its update happens here (lf = its channel LLR).
 // oc[h] = byte offset (constant part) of that VN's output element, JIT_NOOUT = not part of the output
+#ifndef JIT_CMP_AHEAD
+#define JIT_CMP_AHEAD 0
+#endif
 template <int D, int NCH, bool FUSE>
 JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, float offset, bool last,
                            float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
@@ -127,12 +130,32 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
     a1[h] = u_float(f_bits(a1[h]) | sx[h]);
     a2[h] = u_float(f_bits(a2[h]) | sx[h]);
   }
+#if JIT_CMP_AHEAD
+  // the comparisons of JIT_CMP_AHEAD edges are issued before the first selection that reads one of them: a v_cmp writes its lane
+  // mask to a scalar register pair and gfx950 wants wait states before a v_cndmask reads it - back to back, the compiler fills
+  // them with s_nop (587 of them per iteration in the check-node programs of C2, one per 7 vector instructions)
+  M64S eq[D][NCH];
+#pragma unroll
+  for (int i = 0; i < (D < JIT_CMP_AHEAD ? D : JIT_CMP_AHEAD); ++i)
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) eq[i][h] = f_eq_abs(v[i][h], m1[h]);
+#endif
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     F32 c2v[NCH];
+#if JIT_CMP_AHEAD
+    if (i + JIT_CMP_AHEAD < D) {
+#pragma unroll
+      for (int h = 0; h < NCH; ++h) eq[i + JIT_CMP_AHEAD][h] = f_eq_abs(v[i + JIT_CMP_AHEAD][h], m1[h]);
+    }
+#endif
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
+#if JIT_CMP_AHEAD
+      const F32 mag = f_sel_m(eq[i][h], a2[h], a1[h]);
+#else
       const F32 mag = f_sel_eq(f_abs(v[i][h]), m1[h], a2[h], a1[h]);
+#endif
       c2v[h] = u_float(u_xor_and(f_bits(mag), f_bits(v[i][h]), 0x80000000u));   // mag ^ (v & msb)
       if (FUSE && i == D - 1) {
         const F32 x = c2v[h] + lf[h];                // (0 + c2v) + llr

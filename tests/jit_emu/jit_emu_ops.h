@@ -93,6 +93,13 @@ JIT_DEV F32 f_sel(const M64& m, const F32& a, const F32& b) {
   for (int i = 0; i < 64; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i];
   return r;
 }
+typedef M64 M64S;
+JIT_DEV M64S f_eq_abs(const F32& a, const F32& b) {
+  M64 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = fabsf(a.v[i]) == b.v[i];
+  return r;
+}
+JIT_DEV F32 f_sel_m(const M64S& m, const F32& a, const F32& b) { return f_sel(m, a, b); }
 JIT_DEV U32 u_shl(const U32& a, int n) {
   U32 r;
   for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] << n;

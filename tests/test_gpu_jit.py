@@ -81,7 +81,7 @@ def test_specialised_kernel_bit_exact_vs_oracle(phy, k, n, bg, m, grid):
 
 
 @pytest.mark.parametrize("opts", [{"SAMD_JIT_LAYOUT": "1"}, {"SAMD_JIT_LAYOUT": "1", "SAMD_JIT_PIPE": "2", "SAMD_JIT_PREFETCH": "0"},
-                                  {"SAMD_JIT_SCHED": "1", "SAMD_JIT_PIPE": "2", "SAMD_JIT_XOR128": "1"}])
+                                  {"SAMD_JIT_SCHED": "1", "SAMD_JIT_PIPE": "2", "SAMD_JIT_XOR128": "1"}, {"SAMD_JIT_CMP_AHEAD": "2"}])
 def test_generator_variants_bit_exact(phy, opts):
     """the generator's other forms of the C2 kernel (interleaved message layout with 8-byte DS instructions, own schedule,
     pipelined loads, xor positions): the same soft outputs as the oracle"""
