@@ -45,6 +45,7 @@ struct JitKnobs {
   int rotate = 1;      // a wave's item order rotated by its index on its SIMD
   int cn_slope = 10, cn_ovh = -1, cn_fused = 6, vn_slope = 8, vn_ovh = 10, vn_pair_max = -1;   // cost model (-1: by layout)
   int cn_pair_max = 32;   // rows of higher degree are two single-chunk items
+  int waves = 0;          // own schedule (sched = 1): waves per workgroup, 0 = the generic kernel's 16
   int cmp_ahead = 0;      // min-sum check node: comparisons issued this many edges ahead of the selections that read them
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
