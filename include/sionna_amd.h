@@ -613,6 +613,21 @@ int samd_ofdm_demodulate_c128(const double* y, int rows, int in_len, int num_ofd
                               const int32_t* cp_len, const int32_t* sym_off, int l_min, double* work, double* out,
                               void* stream);
 
+/* float64 variants of the symbol-domain mapping entries (csrc/f64_mapping.hip): the argument layouts of samd_symbol_demap_f32,
+ * samd_symbol_logits2llrs_f32, samd_llrs2symbol_logits_f32, samd_symbol_logits2moments_c64, samd_pam2qam_logits_f32 with every
+ * real argument double (complex128 symbols / points / means). */
+int samd_symbol_demap_f64(const double* y, const double* no, int64_t no_len, const double* points, int m,
+                          int64_t num_symbols, const double* prior, int64_t prior_len, int hard_out, double* out,
+                          int32_t* out_idx, void* stream);
+int samd_symbol_logits2llrs_f64(const double* logits, int m, int64_t rows, const double* prior, int64_t prior_len,
+                                int method, int hard_out, double* out, void* stream);
+int samd_llrs2symbol_logits_f64(const double* llrs, int m, int64_t rows, int hard_out, double* out, int32_t* out_idx,
+                                void* stream);
+int samd_symbol_logits2moments_c128(const double* logits, const double* points, int m, int64_t rows, double* mean,
+                                    double* var, void* stream);
+int samd_pam2qam_logits_f64(const double* pam1, const double* pam2, int num_bits_per_symbol, int64_t rows, double* out,
+                            void* stream);
+
 /* lmmse_equalizer / zf_equalizer / mf_equalizer in complex128 (precision = "double", reference block.py:25-52;
  * mimo/equalization.py:101-470): y [n, M], h [n, M, K], s [n, M, M] complex128 -> x_hat [n, K] complex128, no_eff
  * [n, K] float64; mode 0 LMMSE without whitening, 1 LMMSE, 2 ZF, 3 MF; K <= 8, K <= M <= 16.  OFDMEqualizer.call with

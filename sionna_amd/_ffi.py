@@ -46,6 +46,11 @@ _SIGNATURES = {
     "samd_ldpc5g_extract_codeword_f64": (_i32, [_vp, _vp, _vp, _i32, _vp]),
     "samd_lmmse_equalizer_c128": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "samd_qam_demap_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_symbol_demap_f64": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _vp, _i64, _i32, _vp, _vp, _vp]),
+    "samd_symbol_logits2llrs_f64": (_i32, [_vp, _i32, _i64, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_llrs2symbol_logits_f64": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
+    "samd_symbol_logits2moments_c128": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
+    "samd_pam2qam_logits_f64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "samd_scramble_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "samd_awgn_c128": (_i32, [_vp, _vp, _i64, _u64, _u64, _i64, _vp, _vp]),
     "samd_rg_map_c128": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -351,21 +351,23 @@ class SymbolDemapper(Block):
     constellation = property(lambda self: self._constellation)
 
     def call(self, y, no, prior=None):
-        self._require_single()
+        dbl = self.precision == "double"       # float64: csrc/f64_mapping.hip
         m = self._constellation.num_bits_per_symbol
         npts = 1 << m
-        y = _ffi.to_device(y, torch.complex64)
-        no = _ffi.to_device(no, torch.float32)
+        y = _ffi.to_device(y, self.cdtype)
+        no = _ffi.to_device(no, self.rdtype)
         no = no.reshape(1) if no.numel() == 1 else torch.broadcast_to(no, y.shape).contiguous()
         if prior is not None:
-            prior = _ffi.to_device(prior, torch.float32)
+            prior = _ffi.to_device(prior, self.rdtype)
             prior = prior.contiguous() if prior.dim() == 1 else torch.broadcast_to(prior, tuple(y.shape) + (npts,)).contiguous()
             assert prior.shape[-1] == npts, "prior must have num_points entries"
         hard = bool(self._hard_out)
-        out = None if hard else torch.empty(tuple(y.shape) + (npts,), dtype=torch.float32, device=y.device)
+        out = None if hard else torch.empty(tuple(y.shape) + (npts,), dtype=self.rdtype, device=y.device)
         idx = torch.empty(tuple(y.shape), dtype=torch.int32, device=y.device) if hard else None
-        _ffi.check(_ffi.lib().samd_symbol_demap_f32(
-            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(self._constellation.device_points(raw=True)), m, y.numel(),
+        pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex128), torch.complex128) if dbl \
+            else self._constellation.device_points(raw=True)
+        _ffi.check((_ffi.lib().samd_symbol_demap_f64 if dbl else _ffi.lib().samd_symbol_demap_f32)(
+            _ffi.ptr(y), _ffi.ptr(no), no.numel(), _ffi.ptr(pts), m, y.numel(),
             _ffi.ptr(prior), 0 if prior is None else prior.numel(), int(hard), _ffi.ptr(out), _ffi.ptr(idx), _ffi.stream()),
             "SymbolDemapper")
         return idx if hard else out
@@ -385,21 +387,21 @@ class SymbolLogits2LLRs(Block):
     num_bits_per_symbol = property(lambda self: self._num_bits_per_symbol)
 
     def call(self, logits, prior=None):
-        self._require_single()
+        dbl = self.precision == "double"
         m = self._num_bits_per_symbol
-        z = _ffi.to_device(logits, torch.float32).contiguous()
+        z = _ffi.to_device(logits, self.rdtype).contiguous()
         assert z.shape[-1] == 1 << m, "the last dimension of logits must be 2**num_bits_per_symbol"
         rows = z.numel() // (1 << m)
-        out = torch.empty(tuple(z.shape[:-1]) + (m,), dtype=torch.float32, device=z.device)
+        out = torch.empty(tuple(z.shape[:-1]) + (m,), dtype=self.rdtype, device=z.device)
         pr, plen = None, 0
         if prior is not None:
-            pr = _ffi.to_device(prior, torch.float32)
+            pr = _ffi.to_device(prior, self.rdtype)
             if pr.dim() > 1 or rows == 1:
                 pr = torch.broadcast_to(pr, tuple(z.shape[:-1]) + (m,))
             pr = pr.contiguous()
             plen = pr.numel()
             assert plen in (m, rows * m), "prior must be [num_bits_per_symbol] or broadcastable to [..., n, num_bits_per_symbol]"
-        _ffi.check(_ffi.lib().samd_symbol_logits2llrs_f32(_ffi.ptr(z), m, rows, _ffi.ptr(pr) if pr is not None else None, plen,
+        _ffi.check((_ffi.lib().samd_symbol_logits2llrs_f64 if dbl else _ffi.lib().samd_symbol_logits2llrs_f32)(_ffi.ptr(z), m, rows, _ffi.ptr(pr) if pr is not None else None, plen,
                                                           1 if self._method == "maxlog" else 0, 1 if self._hard_out else 0,
                                                           _ffi.ptr(out), _ffi.stream()), "SymbolLogits2LLRs")
         return out
@@ -419,15 +421,15 @@ class LLRs2SymbolLogits(Block):
     num_bits_per_symbol = property(lambda self: self._num_bits_per_symbol)
 
     def call(self, llrs):
-        self._require_single()
+        dbl = self.precision == "double"
         m = self._num_bits_per_symbol
-        x = _ffi.to_device(llrs, torch.float32).contiguous()
+        x = _ffi.to_device(llrs, self.rdtype).contiguous()
         assert x.shape[-1] == m, "the last dimension of llrs must be num_bits_per_symbol"
         rows = x.numel() // m
         hard = bool(self._hard_out)
-        out = None if hard else torch.empty(tuple(x.shape[:-1]) + (1 << m,), dtype=torch.float32, device=x.device)
+        out = None if hard else torch.empty(tuple(x.shape[:-1]) + (1 << m,), dtype=self.rdtype, device=x.device)
         idx = torch.empty(tuple(x.shape[:-1]), dtype=torch.int32, device=x.device) if hard else None
-        _ffi.check(_ffi.lib().samd_llrs2symbol_logits_f32(_ffi.ptr(x), m, rows, int(hard), _ffi.ptr(out), _ffi.ptr(idx),
+        _ffi.check((_ffi.lib().samd_llrs2symbol_logits_f64 if dbl else _ffi.lib().samd_llrs2symbol_logits_f32)(_ffi.ptr(x), m, rows, int(hard), _ffi.ptr(out), _ffi.ptr(idx),
                                                           _ffi.stream()), "LLRs2SymbolLogits")
         return idx if hard else out
 
@@ -446,15 +448,16 @@ class SymbolLogits2Moments(Block):
             constellation=constellation, precision=precision)
 
     def call(self, logits):
-        self._require_single()
+        dbl = self.precision == "double"
         m = self._constellation.num_bits_per_symbol
-        z = _ffi.to_device(logits, torch.float32).contiguous()
+        z = _ffi.to_device(logits, self.rdtype).contiguous()
         assert z.shape[-1] == 1 << m, "the last dimension of logits must be the number of constellation points"
         rows = z.numel() >> m
-        mean = torch.empty(tuple(z.shape[:-1]), dtype=torch.complex64, device=z.device)
-        var = torch.empty(tuple(z.shape[:-1]), dtype=torch.float32, device=z.device)
-        pts = self._constellation.device_points()
-        _ffi.check(_ffi.lib().samd_symbol_logits2moments_c64(_ffi.ptr(z), _ffi.ptr(pts), m, rows, _ffi.ptr(mean),
+        mean = torch.empty(tuple(z.shape[:-1]), dtype=self.cdtype, device=z.device)
+        var = torch.empty(tuple(z.shape[:-1]), dtype=self.rdtype, device=z.device)
+        pts = _ffi.to_device(np.asarray(self._constellation.points, np.complex128), torch.complex128) if dbl \
+            else self._constellation.device_points()
+        _ffi.check((_ffi.lib().samd_symbol_logits2moments_c128 if dbl else _ffi.lib().samd_symbol_logits2moments_c64)(_ffi.ptr(z), _ffi.ptr(pts), m, rows, _ffi.ptr(mean),
                                                              _ffi.ptr(var), _ffi.stream()), "SymbolLogits2Moments")
         return mean, var
 
@@ -527,12 +530,13 @@ class PAM2QAM(Object):
             if self._dev is None:
                 self._dev = _ffi.to_device(self._qam_ind.reshape(-1), torch.int32)
             return self._dev.index_select(0, (i1 * P + i2).reshape(-1)).reshape(i1.shape)
-        self._require_single()
-        a, b = _ffi.to_device(pam1, torch.float32).contiguous(), _ffi.to_device(pam2, torch.float32).contiguous()
+        dbl = self.precision == "double"
+        rdt = torch.float64 if dbl else torch.float32
+        a, b = _ffi.to_device(pam1, rdt).contiguous(), _ffi.to_device(pam2, rdt).contiguous()
         assert a.shape == b.shape and a.shape[-1] == P, "logits must have 2**(num_bits_per_symbol/2) entries"
-        out = torch.empty(tuple(a.shape[:-1]) + (P * P,), dtype=torch.float32, device=a.device)
-        _ffi.check(_ffi.lib().samd_pam2qam_logits_f32(_ffi.ptr(a), _ffi.ptr(b), self._nb, a.numel() // P, _ffi.ptr(out),
-                                                      _ffi.stream()), "PAM2QAM")
+        out = torch.empty(tuple(a.shape[:-1]) + (P * P,), dtype=rdt, device=a.device)
+        _ffi.check((_ffi.lib().samd_pam2qam_logits_f64 if dbl else _ffi.lib().samd_pam2qam_logits_f32)(
+            _ffi.ptr(a), _ffi.ptr(b), self._nb, a.numel() // P, _ffi.ptr(out), _ffi.stream()), "PAM2QAM")
         return out
 
 

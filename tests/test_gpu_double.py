@@ -440,3 +440,43 @@ def test_polar5g_decoder_double(phy, k, n, ch, dec_type):
     assert np.mean(np.all(_np(u32).astype(np.float64) == _np(u_hat), axis=1)) >= 0.95
     good = _np(ok)
     assert good.mean() > 0.9 and np.array_equal(_np(u_hat)[good], u[good])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# symbol-domain mapping blocks with precision="double" (csrc/f64_mapping.hip) against oracle/mapping.py (float64): 1e-9
+@pytest.mark.parametrize("m", [2, 4, 6])
+def test_symbol_blocks_double(phy, m):
+    rng = np.random.default_rng(m)
+    pts = omap.qam(m, dtype=np.complex128)
+    n = 257
+    y = _c128(rng, (3, n), 0.7)
+    for no in (np.float64(0.3), rng.uniform(0.1, 1.0, size=(3, n))):
+        for prior in (None, rng.normal(size=(1 << m,)), rng.normal(size=(3, n, 1 << m))):
+            d = phy.mapping.SymbolDemapper("qam", m, precision="double")
+            got = d(y, no, prior) if prior is not None else d(y, no)
+            assert got.dtype == torch.float64
+            _close9(_np(got), omap.symbol_demapper(y, no, pts, prior))
+            dh = phy.mapping.SymbolDemapper("qam", m, hard_out=True, precision="double")
+            hard = dh(y, no, prior) if prior is not None else dh(y, no)
+            assert np.array_equal(_np(hard), omap.symbol_demapper(y, no, pts, prior, hard_out=True))
+    logits = rng.normal(size=(5, 33, 1 << m)) * 3
+    for method in ("app", "maxlog"):
+        for prior in (None, rng.normal(size=(m,)), rng.normal(size=(5, 33, m))):
+            blk = phy.mapping.SymbolLogits2LLRs(method, m, precision="double")
+            got = blk(logits, prior) if prior is not None else blk(logits)
+            assert got.dtype == torch.float64
+            _close9(_np(got), omap.symbol_logits2llrs(logits, m, method, prior))
+    llrs = rng.normal(size=(7, 19, m)) * 4
+    got = phy.mapping.LLRs2SymbolLogits(m, precision="double")(llrs)
+    assert got.dtype == torch.float64
+    _close9(_np(got), omap.llrs2symbol_logits(llrs, m))
+    assert np.array_equal(_np(phy.mapping.LLRs2SymbolLogits(m, hard_out=True, precision="double")(llrs)), omap.llrs2symbol_logits(llrs, m, True))
+    mean, var = phy.mapping.SymbolLogits2Moments("qam", m, precision="double")(logits)
+    rm, rv = omap.symbol_logits2moments(logits, pts)
+    assert mean.dtype == torch.complex128 and var.dtype == torch.float64
+    _close9(_np(mean), rm)
+    _close9(_np(var), rv)
+    P = 1 << (m // 2)
+    p1, p2 = rng.normal(size=(4, 9, P)), rng.normal(size=(4, 9, P))
+    got = phy.mapping.PAM2QAM(m, hard_in_out=False, precision="double")(p1, p2)
+    assert got.dtype == torch.float64 and np.array_equal(_np(got), omap.pam2qam(p1, p2, m, hard_in_out=False))
