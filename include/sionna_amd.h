@@ -613,6 +613,16 @@ int samd_ofdm_demodulate_c128(const double* y, int rows, int in_len, int num_ofd
                               const int32_t* cp_len, const int32_t* sym_off, int l_min, double* work, double* out,
                               void* stream);
 
+/* samd_spatial_corr_c64 on complex128 coefficients (precision = "double") */
+int samd_spatial_corr_c128(const double* a, const double* mat, int batch, int num_rx_ant, int num_tx_ant, int64_t inner,
+                           double* out, void* stream);
+
+/* samd_lin_interp_c64 on complex128 estimates (precision = "double"); index and position tables as for the complex64 entry */
+int samd_lin_interp_c128(const double* hp, const int32_t* fi0, const int32_t* fi1, const float* fx0,
+                         const float* fx1, const int32_t* t0, const int32_t* t1, const float* npil,
+                         int rows, int num_streams, int num_pilots, int num_ofdm_symbols,
+                         int num_subcarriers, int time_avg, double* out, void* stream);
+
 /* float64 variants of the symbol-domain mapping entries (csrc/f64_mapping.hip): the argument layouts of samd_symbol_demap_f32,
  * samd_symbol_logits2llrs_f32, samd_llrs2symbol_logits_f32, samd_symbol_logits2moments_c64, samd_pam2qam_logits_f32 with every
  * real argument double (complex128 symbols / points / means). */

@@ -122,6 +122,16 @@ def ls_estimate(rg, y, no, interpolation="nn"):
     return h_ls[:, :, :, tx, s, g], np.maximum(ev[:, :, :, tx, s, g], 0)
 
 
+def ls_estimate_lin(rg, y, no, time_avg=False):
+    """LSChannelEstimator(interpolation_type="lin" / "lin_time_avg") (ofdm/channel_estimation.py:138-173, 437-733): the float64
+    interior of oracle/ofdm.py::LinearInterpolator without its casts to single precision"""
+    h_p, ev_p = ls_estimate(rg, y, no, interpolation=None)
+    li = o32.LinearInterpolator(rg.pilot_pattern, time_avg)
+    h = li._interp(h_p)
+    ev = np.real(li._interp(np.broadcast_to(ev_p, h_p.shape).astype(np.complex128)))
+    return h, np.maximum(ev, 0)
+
+
 def ofdm_modulate(x, cyclic_prefix_length):
     """ofdm/modulator.py:97-124"""
     n = x.shape[-1]

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "samd_tdl_cir_c64": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _f32, _f32, _i32, _f32,
                                 _f32, _vp, _vp]),
     "samd_spatial_corr_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "samd_spatial_corr_c128": (_i32, [_vp, _vp, _i32, _i32, _i32, _i64, _vp, _vp]),
     "samd_cdl_workspace_bytes": (_sz, [_i32, _i32]),
     "samd_cdl_cir_c64": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _f32, _f32, _f32, _f32, _vp, _sz, _vp, _vp]),
@@ -107,6 +108,7 @@ _SIGNATURES = {
                                     _vp, _vp, _vp]),
     "samd_apply_time_channel_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_lin_interp_c64": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_lin_interp_c128": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_lmmse_equalizer_c64": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "samd_ofdm_lmmse_c64": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                    _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -570,22 +570,23 @@ __global__ __launch_bounds__(256) void ls_gather_scale_kernel(const float2* __re
 // correlation matrix, out[i] = sum_j mat[i][j] a[j] (Kronecker case: mat = sqrt(R_rx) (x) conj(sqrt(R_tx)), built on the
 // host).  a / out [B, 1, RA, 1, TA, inner] with inner = num_paths * num_time_steps; one lane per output element,
 // consecutive lanes are consecutive inner positions (coalesced); ascending-j accumulation.
-__global__ __launch_bounds__(256) void spatial_corr_kernel(const float2* __restrict__ a, const float2* __restrict__ mat, int batch,
-                                                           int ra, int ta, int64_t inner, float2* __restrict__ out) {
+template <typename R2, typename R>
+__global__ __launch_bounds__(256) void spatial_corr_kernel(const R2* __restrict__ a, const R2* __restrict__ mat, int batch,
+                                                           int ra, int ta, int64_t inner, R2* __restrict__ out) {
   const int n = ra * ta;
   const int64_t total = (int64_t)batch * n * inner;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t q = idx % inner;
     const int i = (int)((idx / inner) % n);
     const int64_t b = idx / (inner * n);
-    const float2* src = a + b * n * inner + q;
-    float re = 0.f, im = 0.f;
+    const R2* src = a + b * n * inner + q;
+    R re = (R)0, im = (R)0;
     for (int j = 0; j < n; ++j) {
-      const float2 m = mat[i * n + j], v = src[(int64_t)j * inner];
+      const R2 m = mat[i * n + j], v = src[(int64_t)j * inner];
       re += m.x * v.x - m.y * v.y;
       im += m.x * v.y + m.y * v.x;
     }
-    out[idx] = make_float2(re, im);
+    out[idx] = R2{re, im};
   }
 }
 
@@ -646,8 +647,19 @@ extern "C" int samd_spatial_corr_c64(const float* a, const float* mat, int batch
   SAMD_REQUIRE(a && mat && out && a != out, "bad argument (out must not alias a)");
   SAMD_REQUIRE(batch > 0 && num_rx_ant > 0 && num_tx_ant > 0 && inner > 0, "bad size");
   const int64_t total = (int64_t)batch * num_rx_ant * num_tx_ant * inner;
-  hipLaunchKernelGGL(spatial_corr_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)a,
+  hipLaunchKernelGGL((spatial_corr_kernel<float2, float>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)a,
                      (const float2*)mat, batch, num_rx_ant, num_tx_ant, inner, (float2*)out);
+  return launch_status();
+}
+
+// precision = "double" (reference block.py:25-52)
+extern "C" int samd_spatial_corr_c128(const double* a, const double* mat, int batch, int num_rx_ant, int num_tx_ant, int64_t inner,
+                                      double* out, void* stream) {
+  SAMD_REQUIRE(a && mat && out && a != out, "bad argument (out must not alias a)");
+  SAMD_REQUIRE(batch > 0 && num_rx_ant > 0 && num_tx_ant > 0 && inner > 0, "bad size");
+  const int64_t total = (int64_t)batch * num_rx_ant * num_tx_ant * inner;
+  hipLaunchKernelGGL((spatial_corr_kernel<double2, double>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const double2*)a, (const double2*)mat, batch, num_rx_ant, num_tx_ant, inner, (double2*)out);
   return launch_status();
 }
 
@@ -729,48 +741,50 @@ extern "C" int samd_apply_ofdm_channel_c64(const float* x, const float* h_freq, 
 // estimates at the pilots.  hp [rows, S, P]; fi0/fi1 [S,T,F] = 1 + pilot number of the left/right
 // support (0: the zero pad of symbols without pilots), fx0/fx1 their subcarrier positions;
 // t0/t1 [S,T] the supporting OFDM symbols.  divide_no_nan: a zero span gives slope 0.
-__device__ __forceinline__ float2 lin_freq(const float2* __restrict__ hp_rs, const int32_t* __restrict__ fi0,
+template <typename R2, typename R>
+__device__ __forceinline__ R2 lin_freq(const R2* __restrict__ hp_rs, const int32_t* __restrict__ fi0,
                                            const int32_t* __restrict__ fi1, const float* __restrict__ fx0,
                                            const float* __restrict__ fx1, int idx, int f) {
   const int i0 = fi0[idx], i1 = fi1[idx];
-  const float2 y0 = i0 > 0 ? hp_rs[i0 - 1] : make_float2(0.f, 0.f);
-  const float2 y1 = i1 > 0 ? hp_rs[i1 - 1] : make_float2(0.f, 0.f);
-  const float x0 = fx0[idx], dx = fx1[idx] - x0;
-  float2 slope = make_float2(0.f, 0.f);
-  if (dx != 0.f) slope = make_float2((y1.x - y0.x) / dx, (y1.y - y0.y) / dx);
-  const float w = (float)f - x0;
-  return make_float2(w * slope.x + y0.x, w * slope.y + y0.y);
+  const R2 y0 = i0 > 0 ? hp_rs[i0 - 1] : R2{(R)0, (R)0};
+  const R2 y1 = i1 > 0 ? hp_rs[i1 - 1] : R2{(R)0, (R)0};
+  const R x0 = (R)fx0[idx], dx = (R)fx1[idx] - x0;
+  R2 slope = R2{(R)0, (R)0};
+  if (dx != (R)0) slope = R2{(y1.x - y0.x) / dx, (y1.y - y0.y) / dx};
+  const R w = (R)f - x0;
+  return R2{w * slope.x + y0.x, w * slope.y + y0.y};
 }
 
-__global__ void lin_interp_kernel(const float2* __restrict__ hp, const int32_t* __restrict__ fi0,
+template <typename R2, typename R>
+__global__ void lin_interp_kernel(const R2* __restrict__ hp, const int32_t* __restrict__ fi0,
                                   const int32_t* __restrict__ fi1, const float* __restrict__ fx0,
                                   const float* __restrict__ fx1, const int32_t* __restrict__ t0,
                                   const int32_t* __restrict__ t1, const float* __restrict__ npil, long long total, int S,
-                                  int P, int T, int F, int time_avg, float2* __restrict__ out) {
+                                  int P, int T, int F, int time_avg, R2* __restrict__ out) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
   const int f = (int)(i % F);
   const int t = (int)((i / F) % T);
   const int s = (int)((i / ((long long)F * T)) % S);
   const long long r = i / ((long long)F * T * S);
-  const float2* hp_rs = hp + (r * S + s) * P;
+  const R2* hp_rs = hp + (r * S + s) * P;
   const int base = s * T * F;
-  float2 res;
+  R2 res;
   if (time_avg) {
-    float2 acc = make_float2(0.f, 0.f);
+    R2 acc = R2{(R)0, (R)0};
     for (int tt = 0; tt < T; ++tt) {
-      const float2 v = lin_freq(hp_rs, fi0, fi1, fx0, fx1, base + tt * F + f, f);
+      const R2 v = lin_freq<R2, R>(hp_rs, fi0, fi1, fx0, fx1, base + tt * F + f, f);
       acc.x += v.x; acc.y += v.y;
     }
-    res = make_float2(acc.x / npil[s], acc.y / npil[s]);
+    res = R2{acc.x / (R)npil[s], acc.y / (R)npil[s]};
   } else {
     const int a = t0[s * T + t], b = t1[s * T + t];
-    const float2 y0 = lin_freq(hp_rs, fi0, fi1, fx0, fx1, base + a * F + f, f);
-    const float2 y1 = lin_freq(hp_rs, fi0, fi1, fx0, fx1, base + b * F + f, f);
-    const float dx = (float)(b - a);
-    float2 slope = make_float2(0.f, 0.f);
-    if (dx != 0.f) slope = make_float2((y1.x - y0.x) / dx, (y1.y - y0.y) / dx);
-    const float w = (float)(t - a);
-    res = make_float2(w * slope.x + y0.x, w * slope.y + y0.y);
+    const R2 y0 = lin_freq<R2, R>(hp_rs, fi0, fi1, fx0, fx1, base + a * F + f, f);
+    const R2 y1 = lin_freq<R2, R>(hp_rs, fi0, fi1, fx0, fx1, base + b * F + f, f);
+    const R dx = (R)(b - a);
+    R2 slope = R2{(R)0, (R)0};
+    if (dx != (R)0) slope = R2{(y1.x - y0.x) / dx, (y1.y - y0.y) / dx};
+    const R w = (R)(t - a);
+    res = R2{w * slope.x + y0.x, w * slope.y + y0.y};
   }
   out[i] = res;
   }
@@ -783,9 +797,23 @@ extern "C" int samd_lin_interp_c64(const float* hp, const int32_t* fi0, const in
   SAMD_REQUIRE(hp && fi0 && fi1 && fx0 && fx1 && t0 && t1 && npil && out, "null argument");
   const long long total = (long long)rows * num_streams * num_ofdm_symbols * num_subcarriers;
   if (total == 0) return SAMD_OK;
-  hipLaunchKernelGGL(lin_interp_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)hp,
+  hipLaunchKernelGGL((lin_interp_kernel<float2, float>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, (const float2*)hp,
                      fi0, fi1, fx0, fx1, t0, t1, npil, total, num_streams, num_pilots, num_ofdm_symbols, num_subcarriers,
                      time_avg, (float2*)out);
+  return launch_status();
+}
+
+// precision = "double" (reference block.py:25-52): complex128 estimates, the same index / position tables (positions are small
+// integers, exact in float32)
+extern "C" int samd_lin_interp_c128(const double* hp, const int32_t* fi0, const int32_t* fi1, const float* fx0, const float* fx1,
+                                    const int32_t* t0, const int32_t* t1, const float* npil, int rows, int num_streams, int num_pilots,
+                                    int num_ofdm_symbols, int num_subcarriers, int time_avg, double* out, void* stream) {
+  SAMD_REQUIRE(hp && fi0 && fi1 && fx0 && fx1 && t0 && t1 && npil && out, "null argument");
+  const long long total = (long long)rows * num_streams * num_ofdm_symbols * num_subcarriers;
+  if (total == 0) return SAMD_OK;
+  hipLaunchKernelGGL((lin_interp_kernel<double2, double>), dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const double2*)hp, fi0, fi1, fx0, fx1, t0, t1, npil, total, num_streams, num_pilots, num_ofdm_symbols,
+                     num_subcarriers, time_avg, (double2*)out);
   return launch_status();
 }
 

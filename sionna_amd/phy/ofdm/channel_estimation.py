@@ -103,7 +103,9 @@ class LinearInterpolator(Object):
         self._num_pilots = pil.shape[-1]
 
     def _interpolate(self, x):
-        x = _ffi.to_device(x, torch.complex64)
+        dbl = str(getattr(x, "dtype", "")).endswith("complex128")          # the precision follows the estimates handed in
+        cdt = torch.complex128 if dbl else torch.complex64
+        x = _ffi.to_device(x, cdt)
         s, t_, f_ = self._tables[0].shape
         assert x.shape[-1] == self._num_pilots and x.shape[-3] * x.shape[-2] == s, \
             "inputs must have shape [..., num_tx, num_streams_per_tx, num_pilots]"
@@ -113,17 +115,17 @@ class LinearInterpolator(Object):
                               for a in (fi0, fi1, fx0, fx1, t0, t1, npil))
         lead = tuple(x.shape[:-3])
         rows = int(np.prod(lead)) if lead else 1
-        out = torch.empty(lead + self._mask_shape, dtype=torch.complex64, device=x.device)
+        out = torch.empty(lead + self._mask_shape, dtype=cdt, device=x.device)
         d = self._dev
-        _ffi.check(_ffi.lib().samd_lin_interp_c64(_ffi.ptr(x), _ffi.ptr(d[0]), _ffi.ptr(d[1]), _ffi.ptr(d[2]), _ffi.ptr(d[3]),
-                                                  _ffi.ptr(d[4]), _ffi.ptr(d[5]), _ffi.ptr(d[6]), rows, s, self._num_pilots,
-                                                  t_, f_, int(self._time_avg), _ffi.ptr(out), _ffi.stream()),
+        fn = _ffi.lib().samd_lin_interp_c128 if dbl else _ffi.lib().samd_lin_interp_c64
+        _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(d[0]), _ffi.ptr(d[1]), _ffi.ptr(d[2]), _ffi.ptr(d[3]), _ffi.ptr(d[4]), _ffi.ptr(d[5]),
+                      _ffi.ptr(d[6]), rows, s, self._num_pilots, t_, f_, int(self._time_avg), _ffi.ptr(out), _ffi.stream()),
                    "LinearInterpolator")
         return out
 
     def __call__(self, h_hat, err_var):
         h = self._interpolate(h_hat)
-        ev = _ffi.to_device(err_var, torch.float32)
+        ev = _ffi.to_device(err_var, torch.float64 if str(getattr(err_var, "dtype", "")).endswith("float64") else torch.float32)
         ev = self._interpolate(torch.complex(ev, torch.zeros_like(ev))).real      # :726-730
         return wrap(h), wrap(ev.contiguous())
 
@@ -242,9 +244,6 @@ class LSChannelEstimator(Block):
         fill_h(h_hat)
         err_var = no * ev.reshape(self._out_shape)
         if self._lin is not None:
-            if dbl and isinstance(self._lin, LinearInterpolator):
-                raise NotImplementedError("LSChannelEstimator: the linear interpolator kernel is precision='single' only "
-                                          "(interpolation_type='nn' and LMMSEInterpolator run in double)")
             # a foreign interpolator sees err_var broadcast to h_hat's shape like in the reference (channel_estimation.py:160-163);
             # the built-in one keeps the leading [batch, num_rx, num_rx_ant] dims unexpanded (its kernel is linear in them)
             lead = tuple(err_var.shape[:3]) if isinstance(self._lin, LinearInterpolator) else tuple(h_hat.shape[:3])

@@ -309,8 +309,12 @@ def test_ls_estimator_double(phy):
     rh, rev = o64.ls_estimate(org, y, 0.1, interpolation=None)
     _close9(_np(h), rh)
     _close9(np.broadcast_to(_np(ev), rh.shape), np.broadcast_to(rev, rh.shape))
-    with pytest.raises(NotImplementedError):
-        phy.ofdm.LSChannelEstimator(rg, interpolation_type="lin", precision="double")(y, 0.1)
+    for kind, tavg in (("lin", False), ("lin_time_avg", True)):
+        h, ev = phy.ofdm.LSChannelEstimator(rg, interpolation_type=kind, precision="double")(y, 0.1)
+        rh, rev = o64.ls_estimate_lin(org, y, 0.1, tavg)
+        assert h.dtype == torch.complex128 and ev.dtype == torch.float64
+        _close9(_np(h), rh)
+        _close9(np.broadcast_to(_np(ev), rev.shape), rev)
 
 
 @pytest.mark.parametrize("fft,cp", [(76, 6), (64, [5] + [4] * 6), (128, 0)])
@@ -480,3 +484,24 @@ def test_symbol_blocks_double(phy, m):
     p1, p2 = rng.normal(size=(4, 9, P)), rng.normal(size=(4, 9, P))
     got = phy.mapping.PAM2QAM(m, hard_in_out=False, precision="double")(p1, p2)
     assert got.dtype == torch.float64 and np.array_equal(_np(got), omap.pam2qam(p1, p2, m, hard_in_out=False))
+
+
+def test_tdl_spatial_correlation_double(phy):
+    """TDL with rx / tx correlation matrices in double (samd_spatial_corr_c128): H <- sqrt(R_rx) H sqrt(R_tx)^H applied to the
+    float64 taps of the same stream position (tdl.py:474-492)."""
+    rx = np.asarray(phy.channel.exp_corr_mat(0.6 + 0.2j, 4), np.complex128)
+    tx = np.asarray(phy.channel.exp_corr_mat(0.3, 2), np.complex128)
+    kw = dict(min_speed=3., max_speed=30., num_rx_ant=4, num_tx_ant=2, precision="double")
+    phy.config.seed = 13
+    a, _ = phy.channel.tr38901.TDL("A", 300e-9, 2.6e9, rx_corr_mat=rx, tx_corr_mat=tx, **kw)(8, 14, 14e3)
+    phy.config.seed = 13
+    a0, _ = phy.channel.tr38901.TDL("A", 300e-9, 2.6e9, **kw)(8, 14, 14e3)
+    assert a.dtype == torch.complex128
+
+    def msqrt(r):
+        r = np.asarray(r, np.complex128)
+        w, v = np.linalg.eigh((r + r.conj().T) / 2)
+        return (v * np.sqrt(np.clip(w, 0, None))) @ v.conj().T
+    h0 = _np(a0)[:, 0, :, 0]                                                # [B, ra, ta, P, T]
+    ref = np.einsum("ij,bjkpt,lk->bilpt", msqrt(rx), h0, msqrt(tx).conj())
+    _close9(_np(a)[:, 0, :, 0], ref)
