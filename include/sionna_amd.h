@@ -613,6 +613,14 @@ int samd_ofdm_demodulate_c128(const double* y, int rows, int in_len, int num_ofd
                               const int32_t* cp_len, const int32_t* sym_off, int l_min, double* work, double* out,
                               void* stream);
 
+/* cir_to_time_channel / ApplyTimeChannel in complex128 (precision = "double"; csrc/f64_time.hip): the layouts of
+ * samd_cir_to_time_c64 / samd_apply_time_channel_c64 without the deferred normalisation factor (h_time is normalised in place) */
+int samd_cir_to_time_c128(double bandwidth, const double* a, const double* tau, int l_min, int l_max, int batch,
+                          int num_rx, int num_rx_ant, int num_tx, int num_tx_ant, int num_paths, int num_time_steps,
+                          int normalize, double* h_time, void* stream);
+int samd_apply_time_channel_c128(const double* x, const double* h_time, int batch, int num_rx, int num_rx_ant,
+                                 int num_tx, int num_tx_ant, int num_time_samples, int l_tot, double* y, void* stream);
+
 /* samd_spatial_corr_c64 on complex128 coefficients (precision = "double") */
 int samd_spatial_corr_c128(const double* a, const double* mat, int batch, int num_rx_ant, int num_tx_ant, int64_t inner,
                            double* out, void* stream);

@@ -153,3 +153,27 @@ def ofdm_demodulate(y, fft_size, l_min, cyclic_prefix_length, num_ofdm_symbols=N
     xf = np.fft.fft(np.asarray(rows, np.complex128), axis=-1) / np.sqrt(n)
     xf = xf * np.exp(1j * ((-2 * PI * l_min) / n * np.arange(n, dtype=np.float64)))
     return np.fft.fftshift(xf, axes=-1)
+
+
+def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False):
+    """channel/utils.py:256-349: a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P] -> h [B,rx,ra,tx,ta,T,L]"""
+    lags = np.arange(l_min, l_max + 1, dtype=np.float64)
+    g = np.sinc(lags - np.asarray(tau, np.float64)[..., None] * float(bandwidth))                 # [B,rx,tx,P,L]
+    h = np.einsum("brxtypn,brtpl->brxtynl", np.asarray(a, np.complex128), g)
+    if normalize:
+        c = np.mean(np.sum(np.abs(h) ** 2, axis=-1), axis=(2, 4, 5), keepdims=True)[..., None]
+        h = np.where(c > 0, h / np.sqrt(np.where(c > 0, c, 1)), 0)
+    return h
+
+
+def apply_time_channel(x, h_time):
+    """channel/apply_time_channel.py:95-175: x [B,tx,ta,Tn], h [B,rx,ra,tx,ta,Tn+L-1,L] -> y [B,rx,ra,Tn+L-1]"""
+    x, h = np.asarray(x, np.complex128), np.asarray(h_time, np.complex128)
+    tn, l_tot = x.shape[-1], h.shape[-1]
+    tout = tn + l_tot - 1
+    y = np.zeros(h.shape[:3] + (tout,), np.complex128)
+    for l in range(l_tot):
+        xs = np.zeros(x.shape[:-1] + (tout,), np.complex128)
+        xs[..., l:l + tn] = x                                                                     # x[t - l]
+        y += np.sum(h[..., l] * xs[:, None, None], axis=(3, 4))
+    return y

@@ -20,13 +20,19 @@ def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False, _defer
     l = l_min..l_max (utils.py:256-349).  ``_defer_norm`` (internal, TimeChannel): return (h un-normalised,
     scale [b,rx,tx]) so that the normalisation is applied to the received signal instead of in a second
     pass over h."""
-    a = _ffi.to_device(a, torch.complex64)
-    tau = _ffi.to_device(tau, torch.float32)
+    dbl = str(getattr(a, "dtype", "")).endswith("complex128")          # the precision follows the coefficients (utils.py:309)
+    a = _ffi.to_device(a, torch.complex128 if dbl else torch.complex64)
+    tau = _ffi.to_device(tau, torch.float64 if dbl else torch.float32)
     if tau.dim() != 4:
         raise NotImplementedError("cir_to_time_channel: per-antenna delays (rank-6 tau) are outside the hot path")
     b, rx, ra, tx, ta, p, t = a.shape
     assert tuple(tau.shape) == (b, rx, tx, p), "tau must have shape [batch, num_rx, num_tx, num_paths]"
     l_min, l_max = int(l_min), int(l_max)
+    if dbl:                                                            # float64 kernels (csrc/f64_time.hip): normalised in place
+        h = torch.empty((b, rx, ra, tx, ta, t, l_max - l_min + 1), dtype=torch.complex128, device=a.device)
+        _ffi.check(_ffi.lib().samd_cir_to_time_c128(float(bandwidth), _ffi.ptr(a), _ffi.ptr(tau), l_min, l_max, b, rx, ra, tx, ta, p, t,
+                                                    int(bool(normalize)), _ffi.ptr(h), _ffi.stream()), "cir_to_time_channel")
+        return (wrap(h), None) if _defer_norm else wrap(h)
     h = torch.empty((b, rx, ra, tx, ta, t, l_max - l_min + 1), dtype=torch.complex64, device=a.device)
     scale = torch.empty((b, rx, tx), dtype=torch.float32, device=a.device) if (_defer_norm and normalize) else None
     _ffi.check(_ffi.lib().samd_cir_to_time_c64(float(bandwidth), _ffi.ptr(a), _ffi.ptr(tau), l_min, l_max, b, rx, ra,
@@ -66,16 +72,21 @@ class ApplyTimeChannel(Block):
         self._awgn = AWGN(precision=self.precision)
 
     def call(self, x, h_time, no=None, _link_scale=None):
-        self._require_single()
-        x = _ffi.to_device(x, torch.complex64)
-        h = _ffi.to_device(h_time, torch.complex64)
+        dbl = self.precision == "double"
+        x = _ffi.to_device(x, self.cdtype)
+        h = _ffi.to_device(h_time, self.cdtype)
         b, rx, ra, tx, ta, tout, l = h.shape
         tn = self._num_time_samples
         assert l == self._l_tot and tout == tn + l - 1, "h_time must have num_time_samples + l_tot - 1 time steps"
         assert tuple(x.shape) == (b, tx, ta, tn), "x must have shape [batch, num_tx, num_tx_ant, num_time_samples]"
-        y = torch.empty((b, rx, ra, tout), dtype=torch.complex64, device=x.device)
-        _ffi.check(_ffi.lib().samd_apply_time_channel_c64(_ffi.ptr(x), _ffi.ptr(h), _ffi.ptr(_link_scale), b, rx, ra, tx,
-                                                          ta, tn, l, _ffi.ptr(y), _ffi.stream()), "ApplyTimeChannel")
+        y = torch.empty((b, rx, ra, tout), dtype=self.cdtype, device=x.device)
+        if dbl:
+            assert _link_scale is None
+            _ffi.check(_ffi.lib().samd_apply_time_channel_c128(_ffi.ptr(x), _ffi.ptr(h), b, rx, ra, tx, ta, tn, l, _ffi.ptr(y),
+                                                               _ffi.stream()), "ApplyTimeChannel")
+        else:
+            _ffi.check(_ffi.lib().samd_apply_time_channel_c64(_ffi.ptr(x), _ffi.ptr(h), _ffi.ptr(_link_scale), b, rx, ra, tx,
+                                                              ta, tn, l, _ffi.ptr(y), _ffi.stream()), "ApplyTimeChannel")
         if no is not None:
             y = self._awgn(y, no)
         return wrap(y)

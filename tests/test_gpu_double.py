@@ -505,3 +505,31 @@ def test_tdl_spatial_correlation_double(phy):
     h0 = _np(a0)[:, 0, :, 0]                                                # [B, ra, ta, P, T]
     ref = np.einsum("ij,bjkpt,lk->bilpt", msqrt(rx), h0, msqrt(tx).conj())
     _close9(_np(a)[:, 0, :, 0], ref)
+
+
+def test_time_channel_double(phy):
+    """cir_to_time_channel / ApplyTimeChannel / TimeChannel in double (csrc/f64_time.hip) against oracle/f64_ofdm.py"""
+    rng = np.random.default_rng(12)
+    B, rx, ra, tx, ta, P, tn, l_min, l_max = 3, 1, 2, 2, 2, 5, 40, -3, 7
+    L = l_max - l_min + 1
+    a = _c128(rng, (B, rx, ra, tx, ta, P, tn + L - 1), 0.5)
+    tau = rng.uniform(0, 3e-7, size=(B, rx, tx, P))
+    W = 15.36e6
+    for norm in (False, True):
+        h = phy.channel.cir_to_time_channel(W, a, tau, l_min, l_max, normalize=norm)
+        assert h.dtype == torch.complex128
+        _close9(_np(h), o64.cir_to_time_channel(W, a, tau, l_min, l_max, norm))
+    x = _c128(rng, (B, tx, ta, tn))
+    y = phy.channel.ApplyTimeChannel(tn, L, precision="double")(x, h)
+    assert y.dtype == torch.complex128
+    _close9(_np(y), o64.apply_time_channel(x, _np(h)))
+    # the block on a TDL model, with and without the channel handed out: the same received signal
+    phy.config.seed = 31
+    tdl = phy.channel.tr38901.TDL("C", 100e-9, 3.5e9, min_speed=3., num_rx_ant=2, num_tx_ant=2, precision="double")
+    ch = phy.channel.TimeChannel(tdl, W, tn, l_min=l_min, l_max=l_max, normalize_channel=True, return_channel=True, precision="double")
+    xb = _c128(rng, (4, 1, 2, tn))
+    yb, hb = ch(xb)
+    _close9(_np(yb), o64.apply_time_channel(xb, _np(hb)))
+    phy.config.seed = 31
+    y2 = phy.channel.TimeChannel(tdl, W, tn, l_min=l_min, l_max=l_max, normalize_channel=True, precision="double")(xb)
+    _close9(_np(y2), _np(yb))
