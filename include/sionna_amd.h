@@ -715,6 +715,12 @@ size_t samd_polar_bp_workspace_bytes(int batch, int n);
 int samd_polar_bp_decode_f32(const float* llr, const float* prior, const int32_t* info_pos, int batch,
                              int n, int k, int num_iter, int hard_out, float* out, void* workspace,
                              size_t workspace_bytes, void* stream);
+/* the same decoder on float64 (precision = "double"): libm exp / log in the literal boxplus; message columns that exceed the
+ * LDS in double (n >= 1024) go to the workspace */
+size_t samd_polar_bp_workspace_bytes_f64(int batch, int n);
+int samd_polar_bp_decode_f64(const double* llr, const double* prior, const int32_t* info_pos, int batch, int n,
+                             int k, int num_iter, int hard_out, double* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-GPU: the one collective of the path.  One process per GPU; the Monte-Carlo

@@ -28,6 +28,8 @@ LLR_MAX = F(19.3)          # decoding.py:1527
 
 
 def _exp_log(math):
+    if math == "f64":                                # precision = "double": float64, NumPy's (libm) exp / log
+        return np.exp, np.log
     if math == "numpy":
         return (lambda v: np.exp(v, dtype=F)), (lambda v: np.log(v, dtype=F))
     if math == "spec":
@@ -38,8 +40,9 @@ def _exp_log(math):
 def boxplus(x, y, math="spec"):
     """_boxplus_tf (decoding.py:1587-1603), element-wise, float32."""
     exp, log = _exp_log(math)
-    x = np.clip(np.asarray(x, F), -LLR_MAX, LLR_MAX)
-    y = np.clip(np.asarray(y, F), -LLR_MAX, LLR_MAX)
+    F = np.float64 if math == "f64" else np.float32
+    x = np.clip(np.asarray(x, F), -F(LLR_MAX), F(LLR_MAX))
+    y = np.clip(np.asarray(y, F), -F(LLR_MAX), F(LLR_MAX))
     out = log(F(1.) + exp(x + y))
     return out - log(exp(x) + exp(y))
 
@@ -54,6 +57,7 @@ def stage_indices(n, s):
 def bp_decode(llr_logits, frozen_pos, n, num_iter=20, hard_out=True, math="spec", return_all=False):
     """PolarBPDecoder.call (decoding.py:1735-1771): logits [..., n] -> [..., k] (hard bits as float32, or soft logits).
     return_all: also the final L column 0 for every position (internal LLR sign), for diagnostics."""
+    F = np.float64 if math == "f64" else np.float32
     llr = np.asarray(llr_logits, F)
     lead = llr.shape[:-1]
     ch = (F(-1.) * llr.reshape(-1, n)).astype(F)                       # :1752 logits -> LLRs
@@ -64,7 +68,7 @@ def bp_decode(llr_logits, frozen_pos, n, num_iter=20, hard_out=True, math="spec"
     L = np.zeros((S + 1, B, n), F)                                       # column S = channel
     R = np.zeros((S + 1, B, n), F)                                       # column 0 = priors (:1632-1636)
     L[S] = ch
-    R[0][:, frozen_pos] = LLR_MAX
+    R[0][:, frozen_pos] = F(LLR_MAX)
     idx = [stage_indices(n, s) for s in range(S)]
     for _ in range(int(num_iter)):
         for s in range(S):                                               # left to right (:1641-1683)

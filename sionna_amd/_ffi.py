@@ -140,6 +140,8 @@ _SIGNATURES = {
     "samd_polar_scl_workspace_bytes_f64": (_sz, [_i32, _i32, _i32]),
     "samd_polar_bp_workspace_bytes": (_sz, [_i32, _i32]),
     "samd_polar_bp_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "samd_polar_bp_decode_f64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "samd_polar_bp_workspace_bytes_f64": (_sz, [_i32, _i32]),
     "samd_comm_unique_id": (_i32, [_vp]),
     "samd_comm_create": (_i32, [_vp, _i32, _i32, C.POINTER(_vp)]),
     "samd_comm_rank": (_i32, [_vp]),

@@ -309,26 +309,27 @@ class PolarBPDecoder(Block):
             raise ValueError("Invalid input shape")
 
     def call(self, llr_ch):
-        self._require_single()
-        llr = _ffi.to_device(llr_ch, torch.float32)
+        dbl = self.precision == "double"        # float64: polar_bp_kernel<.., double> on libm exp / log
+        llr = _ffi.to_device(llr_ch, self.rdtype)
         if llr.shape[-1] != self._n:
             raise ValueError("Invalid input shape")
         if self._num_iter < 1:
             raise ValueError("num_iter must be a positive value.")
         if self._dev is None:
-            prior = np.zeros(self._n, np.float32)
-            prior[self._frozen_pos] = np.float32(self._llr_max)        # decoding.py:1632-1636
-            self._dev = (_ffi.to_device(prior, torch.float32),
+            prior = np.zeros(self._n, np.float64 if dbl else np.float32)
+            prior[self._frozen_pos] = np.float32(self._llr_max)        # decoding.py:1632-1636 (19.3 as a float32, cast)
+            self._dev = (_ffi.to_device(prior, self.rdtype),
                          _ffi.to_device(np.ascontiguousarray(self._info_pos, np.int32), torch.int32))
         prior, info = self._dev
         llr2d = llr.reshape(-1, self._n)
         b = llr2d.shape[0]
-        u_hat = torch.empty((b, self._k), dtype=torch.float32, device=llr.device)
+        u_hat = torch.empty((b, self._k), dtype=self.rdtype, device=llr.device)
         if b > 0:
             if self._ws is None:
                 self._ws = _ffi.Workspace()
-            ws, ws_bytes = self._ws.get(_ffi.lib().samd_polar_bp_workspace_bytes(b, self._n))
-            _ffi.check(_ffi.lib().samd_polar_bp_decode_f32(
+            lib = _ffi.lib()
+            ws, ws_bytes = self._ws.get((lib.samd_polar_bp_workspace_bytes_f64 if dbl else lib.samd_polar_bp_workspace_bytes)(b, self._n))
+            _ffi.check((lib.samd_polar_bp_decode_f64 if dbl else lib.samd_polar_bp_decode_f32)(
                 _ffi.ptr(llr2d), _ffi.ptr(prior), _ffi.ptr(info), b, self._n, self._k, self._num_iter, int(self._hard_out),
                 _ffi.ptr(u_hat), _ffi.ptr(ws), ws_bytes, _ffi.stream()), "PolarBPDecoder")
         return u_hat.reshape(tuple(llr.shape[:-1]) + (self._k,))
@@ -416,8 +417,6 @@ class Polar5GDecoder(Block):
             raise ValueError("Invalid input shape.")
 
     def call(self, llr_ch):
-        if self.precision == "double" and self._dec_type == "BP":
-            raise NotImplementedError("Polar5GDecoder: dec_type='BP' is implemented for precision='single' only")
         llr = _ffi.to_device(llr_ch, self.rdtype)
         if llr.shape[-1] != self._n_target:
             raise ValueError("Invalid input shape.")

@@ -533,3 +533,23 @@ def test_time_channel_double(phy):
     phy.config.seed = 31
     y2 = phy.channel.TimeChannel(tdl, W, tn, l_min=l_min, l_max=l_max, normalize_channel=True, precision="double")(xb)
     _close9(_np(y2), _np(yb))
+
+
+@pytest.mark.parametrize("n,k", [(64, 32), (256, 128), (1024, 512)])
+def test_polar_bp_double_vs_oracle(phy, n, k):
+    """PolarBPDecoder with precision="double" (polar_bp_kernel<.., double>; n = 1024 runs with its message columns in the
+    workspace) against oracle/polar_bp.py in float64: soft outputs within 1e-9, hard decisions equal."""
+    from oracle import polar_bp as opb
+    frozen, info = phy.fec.polar.generate_5g_ranking(k, n)
+    rng = np.random.default_rng(n)
+    u = rng.integers(0, 2, (20, k)).astype(np.float32)
+    c = opol.polar_encode(u, info, n)
+    llr = (2 * c - 1) * 2.0 + rng.normal(size=c.shape)
+    for it in (1, 5):
+        soft = phy.fec.polar.PolarBPDecoder(frozen, n, num_iter=it, hard_out=False, precision="double")(llr)
+        assert soft.dtype == torch.float64
+        ref = opb.bp_decode(llr, frozen, n, num_iter=it, hard_out=False, math="f64")
+        assert np.allclose(_np(soft), ref, rtol=1e-9, atol=1e-9), float(np.max(np.abs(_np(soft) - ref)))
+    hard = phy.fec.polar.PolarBPDecoder(frozen, n, num_iter=5, precision="double")(llr)
+    sure = np.abs(ref) > 1e-6
+    assert np.array_equal(_np(hard)[sure], opb.bp_decode(llr, frozen, n, num_iter=5, math="f64")[sure])
