@@ -332,6 +332,15 @@ int samd_cdl_cir_c64(uint64_t seed, uint64_t call, int batch, int num_clusters, 
                      const float* amp, const float* los, float xpr_scale, float two_pi_over_lambda,
                      float min_speed, float max_speed, void* workspace, size_t workspace_bytes,
                      float* a, void* stream);
+/* the same on float64 tables (precision = "double"): every float argument double, a [..] complex128; the random part uses the
+ * float32 stream's 24-bit uniforms (exact in double), so a double run sees the float32 run's realisation */
+int samd_cdl_cir_c128(uint64_t seed, uint64_t call, int batch, int num_clusters, int num_rx_ant,
+                      int num_tx_ant, int num_time_steps, double sampling_frequency, const double* f_rx,
+                      const double* f_tx, const double* a_rx, const double* a_tx, const double* r_rx,
+                      const int32_t* pol_rx, const int32_t* pol_tx, const int32_t* order,
+                      const double* amp, const double* los, double xpr_scale, double two_pi_over_lambda,
+                      double min_speed, double max_speed, void* workspace, size_t workspace_bytes,
+                      double* a, void* stream);
 
 /* cir_to_ofdm_channel  channel/utils.py:180-253.  a [B,rx,ra,tx,ta,P,T], tau [B,rx,tx,P],
  * frequencies DEVICE float[F] -> h_freq [B,rx,ra,tx,ta,T,F]; normalize: unit mean energy over

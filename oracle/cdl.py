@@ -194,12 +194,17 @@ class CDL:
         self.xpr = 10 ** (p["xpr"] / 10)
         self.order = np.argsort(delays, kind="stable")                 # channel_coefficients.py:905-913
 
-    def draw(self, seed, call, batch):
-        """The random quantities of one call (stream layout: module docstring)."""
+    def draw(self, seed, call, batch, precision="single"):
+        """The random quantities of one call (stream layout: module docstring).  precision="double": the same 24-bit uniforms
+        mapped to their intervals in float64 (oracle/f64_ofdm.py::_u) instead of float32."""
         N, M = self.num_clusters, NUM_RAYS
-        v_r = _u(seed, call, batch, self.min_speed, self.max_speed)
-        v_phi = _u(seed, call + 1, batch, 0.0, 2 * PI)
-        v_theta = _u(seed, call + 2, batch, 0.0, PI)
+        if precision == "double":
+            from .f64_ofdm import _u as _ud
+        else:
+            _ud = _u
+        v_r = _ud(seed, call, batch, self.min_speed, self.max_speed)
+        v_phi = _ud(seed, call + 1, batch, 0.0, 2 * PI)
+        v_theta = _ud(seed, call + 2, batch, 0.0, PI)
         vel = np.stack([v_r * np.cos(v_phi) * np.sin(v_theta), v_r * np.sin(v_phi) * np.sin(v_theta), v_r * np.cos(v_theta)],
                        axis=-1).astype(np.float64)
         perms = []
@@ -207,7 +212,7 @@ class CDL:
             nb = (batch * N * M + 3) // 4
             keys = np.stack(outil.philox_block(seed, call + 3 + i, nb), axis=1).reshape(-1)[:batch * N * M]
             perms.append(np.argsort(keys.reshape(batch, N, M), axis=-1, kind="stable"))
-        phases = _u(seed, call + 7, batch * N * M * 4, -PI, PI).reshape(batch, N, M, 4).astype(np.float64)
+        phases = _ud(seed, call + 7, batch * N * M * 4, -PI, PI).reshape(batch, N, M, 4).astype(np.float64)
         return vel, dict(aoa=perms[0], aod=perms[1], zoa=perms[2], zod=perms[3]), phases
 
     def _link(self, aoa, aod, zoa, zod, pm, vel, t):
@@ -225,10 +230,11 @@ class CDL:
         dop = np.exp(1j * w[..., None] * t)                                                       # [..., R, T]
         return np.einsum("...rus,...ru,...rs,...rt->...ust", field, a_rx, a_tx, dop)
 
-    def __call__(self, seed, call, batch, num_time_steps, sampling_frequency):
-        """-> a [B,1,U,1,S,N,T] complex64, tau [B,1,1,N] float32 (cdl.py:258-333)."""
+    def __call__(self, seed, call, batch, num_time_steps, sampling_frequency, precision="single"):
+        """-> a [B,1,U,1,S,N,T] complex64, tau [B,1,1,N] float32 (cdl.py:258-333); precision="double": complex128 / float64
+        without the final casts and with the draws mapped in float64."""
         N = self.num_clusters
-        vel, perm, phi = self.draw(seed, call, batch)
+        vel, perm, phi = self.draw(seed, call, batch, precision)
         t = np.arange(num_time_steps) / sampling_frequency
         ang = {k: np.take_along_axis(np.broadcast_to(self.rays[k], (batch, N, NUM_RAYS)), perm[k], axis=-1) for k in perm}
         k = np.sqrt(1 / self.xpr)
@@ -247,4 +253,6 @@ class CDL:
             h[:, 0] += h_los * np.sqrt(kf / (kf + 1))
         a = np.transpose(h, [0, 2, 3, 1, 4])[:, None, :, None]                                     # [B,1,U,1,S,N,T]
         tau = np.broadcast_to(delays[None, None, None, :], (batch, 1, 1, N))
+        if precision == "double":
+            return np.ascontiguousarray(a), np.ascontiguousarray(tau, dtype=np.float64)
         return a.astype(np.complex64), tau.astype(np.float32)

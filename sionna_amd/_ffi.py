@@ -98,6 +98,8 @@ _SIGNATURES = {
     "samd_cdl_workspace_bytes": (_sz, [_i32, _i32]),
     "samd_cdl_cir_c64": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _f32, _f32, _f32, _f32, _vp, _sz, _vp, _vp]),
+    "samd_cdl_cir_c128": (_i32, [_u64, _u64, _i32, _i32, _i32, _i32, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _f64, _f64, _f64, _f64, _vp, _sz, _vp, _vp]),
     "samd_cir_to_ofdm_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_apply_ofdm_channel_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_ls_gather_scale_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),

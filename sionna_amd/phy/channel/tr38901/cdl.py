@@ -150,9 +150,9 @@ class CDL(Object):
                 amp = amp * np.sqrt(1 / (kf + 1))
                 c2f = lambda z: np.stack([z.real, z.imag], -1).reshape(-1)
                 los = np.concatenate([lf_rx.reshape(-1), lf_tx.reshape(-1), c2f(la_rx.reshape(-1)), c2f(la_tx.reshape(-1)),
-                                      lr_rx.reshape(-1), [np.sqrt(kf / (kf + 1))]]).astype(np.float32)
-            f32 = lambda x: _ffi.to_device(np.ascontiguousarray(x, np.float32), torch.float32)
-            c64 = lambda x: _ffi.to_device(np.ascontiguousarray(x, np.complex64), torch.complex64)
+                                      lr_rx.reshape(-1), [np.sqrt(kf / (kf + 1))]])
+            f32 = lambda x: _ffi.to_device(np.ascontiguousarray(x, self._np_rdtype), self.rdtype)
+            c64 = lambda x: _ffi.to_device(np.ascontiguousarray(x, self._np_cdtype), self.cdtype)
             i32 = lambda x: _ffi.to_device(np.ascontiguousarray(x, np.int32), torch.int32)
             self._dev = (f32(f_rx), f32(f_tx), c64(a_rx), c64(a_tx), f32(r_rx), i32(self._rx_array.pol_index()),
                          i32(self._tx_array.pol_index()), i32(self._order), f32(amp), f32(los) if los is not None else None,
@@ -160,8 +160,6 @@ class CDL(Object):
         return self._dev
 
     def __call__(self, batch_size, num_time_steps, sampling_frequency):
-        if self.precision != "single":
-            raise NotImplementedError("CDL: the MI355X kernels implement precision='single' only")
         f_rx, f_tx, a_rx, a_tx, r_rx, pol_rx, pol_tx, order, amp, los, xpr_scale, k0 = self._tables()
         b, n, t = int(batch_size), self._num_clusters, int(num_time_steps)
         u, s = self._rx_array.num_ant, self._tx_array.num_ant
@@ -169,13 +167,13 @@ class CDL(Object):
         call = rng.next_call()
         for _ in range(7):                                      # the kernel consumes calls call .. call+7
             rng.next_call()
-        a = torch.empty((b, 1, u, 1, s, n, t), dtype=torch.complex64, device=_ffi.device())
+        a = torch.empty((b, 1, u, 1, s, n, t), dtype=self.cdtype, device=_ffi.device())
         ws, ws_bytes = self._ws.get(_ffi.lib().samd_cdl_workspace_bytes(b, n))
-        _ffi.check(_ffi.lib().samd_cdl_cir_c64(rng.seed, call, b, n, u, s, t, float(sampling_frequency), _ffi.ptr(f_rx),
+        _ffi.check((_ffi.lib().samd_cdl_cir_c128 if self.precision == "double" else _ffi.lib().samd_cdl_cir_c64)(rng.seed, call, b, n, u, s, t, float(sampling_frequency), _ffi.ptr(f_rx),
                                                _ffi.ptr(f_tx), _ffi.ptr(a_rx), _ffi.ptr(a_tx), _ffi.ptr(r_rx), _ffi.ptr(pol_rx),
                                                _ffi.ptr(pol_tx), _ffi.ptr(order), _ffi.ptr(amp), _ffi.ptr(los), xpr_scale, k0,
                                                self._min_speed, self._max_speed, _ffi.ptr(ws), ws_bytes, _ffi.ptr(a),
                                                _ffi.stream()), "CDL")
-        tau = torch.from_numpy((self._delays_norm * self._delay_spread)[self._order].astype(np.float32)).to(a.device)
+        tau = torch.from_numpy((self._delays_norm * self._delay_spread)[self._order].astype(self._np_rdtype)).to(a.device)
         tau = tau.reshape(1, 1, 1, n).expand(b, 1, 1, n).contiguous()
         return wrap(a), wrap(tau)

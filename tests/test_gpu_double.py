@@ -553,3 +553,31 @@ def test_polar_bp_double_vs_oracle(phy, n, k):
     hard = phy.fec.polar.PolarBPDecoder(frozen, n, num_iter=5, precision="double")(llr)
     sure = np.abs(ref) > 1e-6
     assert np.array_equal(_np(hard)[sure], opb.bp_decode(llr, frozen, n, num_iter=5, math="f64")[sure])
+
+
+@pytest.mark.parametrize("model,direction,kind", [("A", "uplink", "mimo"), ("D", "downlink", "panel"), ("C", "downlink", "siso")])
+def test_cdl_double(phy, model, direction, kind):
+    """CDL with precision="double" (cdl_cir_kernel<double, double2> on float64 tables) against oracle/cdl.py in double on the same
+    Philox stream: 1e-8 of the tap scale (the host tables go through the antenna-pattern arithmetic of both sides in float64)."""
+    from oracle import cdl as oc
+    FC = 3.5e9
+    t38 = phy.channel.tr38901
+
+    def arrays(mod, **kw):
+        if kind == "siso":
+            return mod.Antenna("single", "V", "omni", FC, **kw), mod.Antenna("single", "V", "omni", FC, **kw)
+        if kind == "mimo":
+            return mod.Antenna("dual", "cross", "omni", FC, **kw), mod.AntennaArray(2, 2, "dual", "cross", "38.901", FC, **kw)
+        return mod.AntennaArray(1, 2, "single", "H", "38.901", FC, **kw), mod.PanelArray(1, 2, "dual", "VH", "38.901", FC, num_rows=1, num_cols=2, **kw)
+    ut, bs = arrays(t38)
+    out, obs = arrays(oc)
+    kw = dict(min_speed=3.0, max_speed=30.0)
+    cdl = t38.CDL(model, 300e-9, FC, ut, bs, direction, precision="double", **kw)
+    ref = oc.CDL(model, 300e-9, FC, out, obs, direction, **kw)
+    phy.config.seed = 42
+    a, tau = cdl(9, 14, 15e3 * 14)
+    a_ref, tau_ref = ref(42, 0, 9, 14, 15e3 * 14, precision="double")
+    assert a.dtype == torch.complex128 and tau.dtype == torch.float64 and tuple(a.shape) == a_ref.shape
+    scale = np.sqrt(np.mean(np.abs(a_ref) ** 2))
+    assert np.allclose(_np(a), a_ref, rtol=1e-8, atol=1e-8 * scale), np.max(np.abs(_np(a) - a_ref)) / scale
+    assert np.allclose(_np(tau), tau_ref, rtol=1e-12, atol=0)
