@@ -4,4 +4,4 @@ TAG=${1:-r05t}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_double.py tests/test_gpu_polar_bp.py -q > $OUT/pytest_ml.txt 2>&1; tail -40 $OUT/pytest_ml.txt
+timeout 900 python -m pytest tests/test_gpu_double.py tests/test_gpu_cdl.py -q > $OUT/pytest_ml.txt 2>&1; tail -40 $OUT/pytest_ml.txt
