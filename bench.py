@@ -703,8 +703,14 @@ def main():
     counters = torch.zeros(4, dtype=torch.int64, device=dev)
 
     def run(dec, steps, warmup):
+        # untimed preparation, independent of --warmup: the first decode of a handle generates and compiles its kernel (hipRTC,
+        # ~4 s of host time during which the GPU idles and drops its clocks); two more decodes bring the clocks back.  With
+        # --warmup 1 and this missing, the timed steps measured the clock ramp (20.4 instead of 16.1 ms per step, profiles/r05smoke)
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         step = counted_step(lambda: dec(llr), u, counters, phy.utils.metrics.count_errors_into, world, ev)
+        for _ in range(3):
+            step(None)                      # (the counters are zeroed again before the timed region)
+        torch.cuda.synchronize()
         t_wall, c = timed_steps(step, steps, warmup, world, dev, torch.cuda.synchronize, counters)
         return t_wall, float(np.mean([a.elapsed_time(b) for a, b in ev])), c
 
