@@ -30,7 +30,7 @@ def _build_emu(tmp_path, h, infobits, tag, cn="minsum"):
     inc = tmp_path / f"emu_src_{tag}.h"
     inc.write_text(src)
     so = tmp_path / f"emu_{tag}.so"
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas",
+    subprocess.check_call(["g++", "-O0", "-std=c++17", "-shared", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas",
                            "-pthread", f"-DJIT_EMU_SRC=\"{inc}\"", "-I", EMU, "-o", str(so),
                            os.path.join(EMU, "jit_emu_main.cpp")])
     lib = C.CDLL(str(so))
