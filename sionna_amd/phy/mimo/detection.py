@@ -33,7 +33,7 @@ class LinearDetector(Block):
             self._demapper = SymbolDemapper(constellation=self._constellation, hard_out=hard_out, precision=precision)
 
     def call(self, y, h, s):
-        x_hat, no_eff = self._equalizer(y, h, s)
+        x_hat, no_eff = self._equalizer(y, h, s, precision=self.precision)   # detection.py:134
         z = self._demapper(x_hat, no_eff)                     # bit: [..., K*m]; symbol: [..., K, num_points] or [..., K]
         if self._output == "symbol":
             return z

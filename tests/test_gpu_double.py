@@ -581,3 +581,36 @@ def test_cdl_double(phy, model, direction, kind):
     scale = np.sqrt(np.mean(np.abs(a_ref) ** 2))
     assert np.allclose(_np(a), a_ref, rtol=1e-8, atol=1e-8 * scale), np.max(np.abs(_np(a) - a_ref)) / scale
     assert np.allclose(_np(tau), tau_ref, rtol=1e-12, atol=0)
+
+
+def test_linear_detectors_double(phy):
+    """mimo.LinearDetector and ofdm.LinearDetector with precision="double": the complex128 equaliser followed by the float64
+    demapper / symbol demapper - against the float64 oracle (LLRs 1e-7: the chain squares the conditioning of the LMMSE solve)."""
+    rng = np.random.default_rng(21)
+    n, m, k, nb = 200, 4, 2, 4
+    pts = omap.qam(nb, dtype=np.complex128)
+    h = _c128(rng, (n, m, k), 0.7)
+    x = pts[rng.integers(0, 1 << nb, (n, k))]
+    s = np.tile(0.05 * np.eye(m), (n, 1, 1)).astype(np.complex128)
+    y = np.einsum("nmk,nk->nm", h, x) + _c128(rng, (n, m), 0.15)
+    det = phy.mimo.LinearDetector("lmmse", "bit", "app", constellation_type="qam", num_bits_per_symbol=nb, precision="double")
+    llr = det(y, h, s)
+    assert llr.dtype == torch.float64 and tuple(llr.shape) == (n, k, nb)
+    xr, ner = o32.lmmse_equalizer(y, h, s)
+    ref = omap.demapper(xr.astype(np.complex128), ner.astype(np.float64), pts, "app").reshape(n, k, nb)
+    assert np.allclose(_np(llr), ref, rtol=1e-7, atol=1e-7), float(np.max(np.abs(_np(llr) - ref)))
+    sym = phy.mimo.LinearDetector("lmmse", "symbol", "app", constellation_type="qam", num_bits_per_symbol=nb, hard_out=True,
+                                  precision="double")(y, h, s)
+    assert np.mean(_np(sym) == np.argmin(np.abs(xr[..., None] - pts), -1)) > 0.99
+    rg, org = _grids64(phy)
+    sm, osm = phy.mimo.StreamManagement(np.array([[1]]), 2), o32.StreamManagement(np.array([[1]]), 2)
+    yg = _c128(rng, (3, 1, 4, 14, 76))
+    hg = _c128(rng, (3, 1, 4, 1, 2, 14, rg.num_effective_subcarriers))
+    d2 = phy.ofdm.LinearDetector("lmmse", "bit", "maxlog", rg, sm, constellation_type="qam", num_bits_per_symbol=nb, precision="double")
+    out = d2(yg, hg, 0.0, 0.25)
+    assert out.dtype == torch.float64 and tuple(out.shape) == (3, 1, 2, rg.num_data_symbols * nb)
+    y_dt, hd, s_ = o32._ofdm_preprocess(org, osm, yg, hg, np.zeros(1), 0.25)         # ofdm_lmmse_equalize without its float32 cast
+    xh, ne = o32.lmmse_equalizer(y_dt, hd, s_)
+    xh, ne = o32._extract_data(org, osm, xh, 3), o32._extract_data(org, osm, ne, 3)
+    ref2 = omap.demapper(xh, ne, pts, "maxlog").reshape(out.shape)
+    assert np.allclose(_np(out), ref2, rtol=1e-7, atol=1e-7), float(np.max(np.abs(_np(out) - ref2)))
