@@ -62,18 +62,18 @@ class SpatialCorrelation(Object, ABC):
         return NotImplemented
 
     def _apply(self, h, mat):
-        """h [..., M, K] complex64 on the device -> mat [M K, M K] applied to the rx-major vector of every matrix."""
-        if self.precision != "single":
-            raise NotImplementedError("spatial correlation: the MI355X kernel implements precision='single' only")
-        h = _ffi.to_device(h, torch.complex64).contiguous()
+        """h [..., M, K] on the device (complex64, complex128 with precision="double") -> mat [M K, M K] applied to the
+        rx-major vector of every matrix."""
+        dbl = self.precision == "double"
+        h = _ffi.to_device(h, self.cdtype).contiguous()
         m, k = int(h.shape[-2]), int(h.shape[-1])
         assert mat.shape == (m * k, m * k), "correlation matrices do not fit the channel matrices"
         out = torch.empty_like(h)
         b = h.numel() // (m * k)
-        mat_d = _ffi.to_device(np.ascontiguousarray(mat), torch.complex64)          # (held until the launch is queued)
+        mat_d = _ffi.to_device(np.ascontiguousarray(mat), self.cdtype)               # (held until the launch is queued)
         if b:
-            _ffi.check(_ffi.lib().samd_spatial_corr_c64(_ffi.ptr(h), _ffi.ptr(mat_d), b, m, k, 1, _ffi.ptr(out), _ffi.stream()),
-                       "spatial correlation")
+            fn = _ffi.lib().samd_spatial_corr_c128 if dbl else _ffi.lib().samd_spatial_corr_c64
+            _ffi.check(fn(_ffi.ptr(h), _ffi.ptr(mat_d), b, m, k, 1, _ffi.ptr(out), _ffi.stream()), "spatial correlation")
         return wrap(out)
 
 
@@ -103,7 +103,7 @@ class KroneckerModel(SpatialCorrelation):
             return h
         l_rx = np.eye(m) if self._l_r_rx is None else self._l_r_rx
         l_tx = np.eye(k) if self._l_r_tx is None else self._l_r_tx
-        return self._apply(h, np.kron(l_rx, np.conj(l_tx)).astype(np.complex64))
+        return self._apply(h, np.kron(l_rx, np.conj(l_tx)).astype(self._np_cdtype))
 
 
 class PerColumnModel(SpatialCorrelation):
@@ -136,4 +136,4 @@ class PerColumnModel(SpatialCorrelation):
         mat = np.zeros((m, k, m, k), np.complex128)
         for kk in range(k):
             mat[:, kk, :, kk] = self._l_rx[kk]
-        return self._apply(h, mat.reshape(m * k, m * k).astype(np.complex64))
+        return self._apply(h, mat.reshape(m * k, m * k).astype(self._np_cdtype))

@@ -442,8 +442,8 @@ class LMMSEInterpolator(Object):
         return h.contiguous(), e.contiguous()
 
     def __call__(self, h_hat, err_var):
-        h_hat = _ffi.to_device(h_hat, torch.complex64)
-        err_var = _ffi.to_device(err_var, torch.float32)
+        h_hat = _ffi.to_device(h_hat, self.cdtype)              # config.precision (the block takes no precision argument)
+        err_var = _ffi.to_device(err_var, self.rdtype)
         h, e = self._interpolate(h_hat, err_var)
         return wrap(h.to(self.cdtype)), wrap(e.to(self.rdtype))
 

@@ -376,6 +376,22 @@ def test_flat_fading_channel_double(phy):
     assert y.dtype == torch.complex128 and h.dtype == torch.complex128
     _close9(_np(h).reshape(-1), o64.complex_normal(8, 0, 40 * 5 * 3, 1.0))
     _close9(_np(y), o64.awgn(np.einsum("brt,bt->br", _np(h), x), 0.2, 8, 1))
+    # spatial correlation in double: L_rx h L_tx^H with the Cholesky factors (channel/spatial_correlation.py:41-122, 125-200)
+    r_rx = phy.channel.exp_corr_mat(0.6 + 0.3j, 5, precision="double")
+    r_tx = phy.channel.exp_corr_mat(0.4, 3, precision="double")
+    hw = _c128(rng, (40, 5, 3))
+    l_rx, l_tx = np.linalg.cholesky(np.asarray(r_rx)), np.linalg.cholesky(np.asarray(r_tx))
+    hk = phy.channel.KroneckerModel(r_tx, r_rx, precision="double")(hw)
+    assert hk.dtype == torch.complex128
+    _close9(_np(hk), l_rx @ hw @ np.conj(l_tx.T))
+    rk = np.stack([np.asarray(phy.channel.exp_corr_mat(a, 5, precision="double")) for a in (0.1, 0.5j, 0.8)])
+    hp = phy.channel.PerColumnModel(rk, precision="double")(hw)
+    _close9(_np(hp), np.stack([np.linalg.cholesky(rk[kk]) @ hw[:, :, kk].T for kk in range(3)], -1).transpose(1, 0, 2))
+    phy.config.seed = 8
+    ch2 = phy.channel.FlatFadingChannel(3, 5, spatial_corr=phy.channel.KroneckerModel(r_tx, r_rx, precision="double"),
+                                        return_channel=True, precision="double")
+    _, h2 = ch2(x, 0.2)
+    _close9(_np(h2), l_rx @ _np(h) @ np.conj(l_tx.T))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
