@@ -755,6 +755,28 @@ int samd_comm_allreduce_sum_i64(samd_comm_t* c, int64_t* counters, int64_t count
 void samd_comm_destroy(samd_comm_t* c);
 
 /* ------------------------------------------------------------------------------------
+ * The per-item linear-algebra helpers of the MIMO blocks as calls of their own (csrc/mimo_linalg.hip): n independent
+ * problems, interleaved complex, row-major matrices, 1 <= M, K <= 16; _c64 = complex64, _c128 = complex128
+ * (precision = "double").  The receiver kernels carry the same algebra fused; these are for host code that calls the
+ * helpers directly.
+ *   samd_inv_cholesky    utils/linalg.py:8-32      a [n,M,M] Hermitian positive definite = L L^H -> out [n,M,M] = L^-1
+ *   samd_matrix_pinv     utils/linalg.py:35-66     a [n,M,K] of full column rank (K <= M) -> out [n,K,M] = (A^H A)^-1 A^H
+ *   samd_whiten_channel  mimo/utils.py:292-356     y [n,M], h [n,M,K], s [n,M,M] = L L^H -> yw = L^-1 y, hw = L^-1 h
+ *   samd_lmmse_matrix    mimo/equalization.py:11-99  h [n,M,K], s [n,M,M] or NULL -> g [n,K,M] = H^H (H H^H + S)^-1,
+ *                        with s == NULL (white unit-variance noise) (H^H H + I)^-1 H^H
+ * ---------------------------------------------------------------------------------- */
+int samd_inv_cholesky_c64(const float* a, int64_t n, int m, float* out, void* stream);
+int samd_inv_cholesky_c128(const double* a, int64_t n, int m, double* out, void* stream);
+int samd_matrix_pinv_c64(const float* a, int64_t n, int m, int k, float* out, void* stream);
+int samd_matrix_pinv_c128(const double* a, int64_t n, int m, int k, double* out, void* stream);
+int samd_whiten_channel_c64(const float* y, const float* h, const float* s, int64_t n, int m, int k, float* yw, float* hw,
+                            void* stream);
+int samd_whiten_channel_c128(const double* y, const double* h, const double* s, int64_t n, int m, int k, double* yw,
+                             double* hw, void* stream);
+int samd_lmmse_matrix_c64(const float* h, const float* s, int64_t n, int m, int k, float* g, void* stream);
+int samd_lmmse_matrix_c128(const double* h, const double* s, int64_t n, int m, int k, double* g, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Error counting  utils/metrics.py:94-144 (count_errors, count_block_errors).
  * b, b_hat [num_blocks, block_len] float32; counters: DEVICE int64[2], ADDED to:
  * counters[0] += #(b != b_hat), counters[1] += #blocks with any mismatch.

@@ -51,6 +51,14 @@ _SIGNATURES = {
     "samd_llrs2symbol_logits_f64": (_i32, [_vp, _i32, _i64, _i32, _vp, _vp, _vp]),
     "samd_symbol_logits2moments_c128": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "samd_pam2qam_logits_f64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "samd_inv_cholesky_c64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "samd_inv_cholesky_c128": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "samd_matrix_pinv_c64": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_matrix_pinv_c128": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_whiten_channel_c64": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "samd_whiten_channel_c128": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "samd_lmmse_matrix_c64": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "samd_lmmse_matrix_c128": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "samd_cir_to_time_c128": (_i32, [_f64, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_apply_time_channel_c128": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_scramble_f64": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),

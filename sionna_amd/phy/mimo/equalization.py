@@ -45,6 +45,23 @@ def _equalize_f64(y, h, s, mode, name):
     return wrap(x_hat), wrap(no_eff)
 
 
+def lmmse_matrix(h, s=None, precision=None):
+    """h [...,M,K] (and the noise covariance s [...,M,M]; None: white, unit variance) -> the LMMSE equalisation matrices
+    G = H^H (H H^H + S)^-1, [...,K,M] (equalization.py:11-99; csrc/mimo_linalg.hip, 1 <= M, K <= 16)."""
+    from ..config import config
+    dbl = (precision or config.precision) == "double"
+    cdt = torch.complex128 if dbl else torch.complex64
+    h = _ffi.to_device(h, cdt).contiguous()
+    m, k = int(h.shape[-2]), int(h.shape[-1])
+    lead = tuple(h.shape[:-2])
+    if s is not None:
+        s = torch.broadcast_to(_ffi.to_device(s, cdt), lead + (m, m)).contiguous()
+    g = torch.empty(lead + (k, m), dtype=cdt, device=h.device)
+    fn = _ffi.lib().samd_lmmse_matrix_c128 if dbl else _ffi.lib().samd_lmmse_matrix_c64
+    _ffi.check(fn(_ffi.ptr(h), _ffi.ptr(s), h.numel() // (m * k), m, k, _ffi.ptr(g), _ffi.stream()), "lmmse_matrix")
+    return wrap(g)
+
+
 def lmmse_equalizer(y, h, s, whiten_interference=True, precision=None):
     """y [...,M], h [...,M,K], s [...,M,M] -> (x_hat [...,K] complex, no_eff [...,K] float)."""
     return _equalize(y, h, s, int(bool(whiten_interference)), precision, "lmmse_equalizer")

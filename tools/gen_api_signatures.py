@@ -46,7 +46,10 @@ SURFACE = {      # reference file -> (import path in sionna.phy, names)
     "channel/tr38901/cdl.py": ("channel.tr38901", ["CDL"]),
     "channel/tr38901/antenna.py": ("channel.tr38901", ["Antenna", "AntennaArray", "PanelArray"]),
     "mimo/stream_management.py": ("mimo", ["StreamManagement"]),
-    "mimo/equalization.py": ("mimo", ["lmmse_equalizer", "zf_equalizer", "mf_equalizer"]),
+    "mimo/equalization.py": ("mimo", ["lmmse_matrix", "lmmse_equalizer", "zf_equalizer", "mf_equalizer"]),
+    "mimo/utils.py": ("mimo", ["whiten_channel", "complex2real_vector", "real2complex_vector", "complex2real_matrix", "real2complex_matrix",
+                               "complex2real_covariance", "real2complex_covariance", "complex2real_channel", "real2complex_channel"]),
+    "utils/linalg.py": ("utils", ["inv_cholesky", "matrix_pinv"]),
     "mimo/detection.py": ("mimo", ["LinearDetector", "KBestDetector", "EPDetector", "MMSEPICDetector", "MaximumLikelihoodDetector"]),
     "ofdm/resource_grid.py": ("ofdm", ["ResourceGrid", "ResourceGridMapper", "ResourceGridDemapper", "RemoveNulledSubcarriers"]),
     "ofdm/pilot_pattern.py": ("ofdm", ["PilotPattern", "EmptyPilotPattern", "KroneckerPilotPattern"]),
