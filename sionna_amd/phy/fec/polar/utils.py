@@ -59,3 +59,45 @@ def generate_rm_code(r, m):
     if k != sum(comb(m, i) for i in range(r + 1)):
         raise ValueError("Error: resulting k is inconsistent.")
     return idx[frozen], idx[~frozen], n, k, 1 << (m - r)
+
+
+def generate_polar_transform_mat(n_lift):
+    """The Polar transformation matrix: the ``n_lift``-fold Kronecker power of [[1, 0], [1, 1]], [2^n_lift, 2^n_lift] of 0 / 1
+    (reference polar/utils.py:114-146).  Entry (i, j) is 1 iff the set bits of j are a subset of those of i."""
+    if int(n_lift) != n_lift:
+        raise ValueError("n_lift must be integer.")
+    if n_lift < 0:
+        raise ValueError("n_lift must be positive.")
+    if n_lift >= 20:
+        raise ValueError("Warning: the resulting code length is large (=2^n_lift).")
+    idx = np.arange(1 << max(int(n_lift), 1))
+    return ((idx[:, None] & idx[None, :]) == idx[None, :]).astype(float)
+
+
+def generate_dense_polar(frozen_pos, n, verbose=True):
+    """Dense parity-check and generator matrices of the Polar code with the given frozen positions (Lemma 1 of [Goala_LP]; reference
+    polar/utils.py:217-290): gm = the information rows of the transformation matrix [k, n], pcm = its frozen columns
+    transposed [n-k, n]; the all-zero syndrome pcm gm^T is verified.  (Usable with LinearEncoder and LDPCBPDecoder; the
+    graph is dense, PolarBPDecoder is the iterative decoder to use.)"""
+    import numbers
+    if not isinstance(n, numbers.Number):
+        raise TypeError("n must be a number.")
+    n = int(n)
+    frozen_pos = np.asarray(frozen_pos)
+    if not np.issubdtype(frozen_pos.dtype, np.integer):
+        raise TypeError("frozen_pos must consist of ints.")
+    if len(frozen_pos) > n:
+        raise ValueError("Number of elements in frozen_pos cannot be greater than n.")
+    if n < 1 or n & (n - 1):
+        raise ValueError("n must be a power of 2.")
+    info_pos = np.setdiff1d(np.arange(n), frozen_pos)
+    if n - len(frozen_pos) != len(info_pos):
+        raise ArithmeticError("Internal error: invalid info_pos generated.")
+    g = generate_polar_transform_mat(n.bit_length() - 1)
+    gm, pcm = g[info_pos, :], np.transpose(g[:, frozen_pos])
+    if verbose:
+        print("Shape of the generator matrix: ", gm.shape)
+        print("Shape of the parity-check matrix: ", pcm.shape)
+    if np.any((pcm.astype(np.int64) @ gm.astype(np.int64).T) & 1):
+        raise ArithmeticError("Non-zero syndrome for H*G'.")
+    return pcm, gm

@@ -69,3 +69,16 @@ def test_gaussian_prior_source(phy):
         assert abs(u.llr2mi(-llr) - mi) < 0.02 or abs(u.llr2mi(llr) - mi) < 0.02
     with pytest.raises(ValueError):
         src([2, 2])
+
+
+def test_linear_encoder_on_dense_polar_matrices(phy):
+    """LinearEncoder(gm) with gm from generate_dense_polar is the Polar encoder (reference test_linear_encoding.py:115-143), and the
+    dense parity-check matrix checks its codewords"""
+    from sionna_amd.phy.fec.polar import generate_dense_polar, generate_5g_ranking
+    for k, n in ((32, 64), (100, 256), (300, 512)):
+        f, _ = generate_5g_ranking(k, n)
+        pcm, gm = generate_dense_polar(f, n, verbose=False)
+        u = phy.mapping.BinarySource()([50, k])
+        c = _np(phy.fec.linear.LinearEncoder(gm)(u))
+        assert np.array_equal(c, _np(phy.fec.polar.PolarEncoder(f, n)(u)))
+        assert not np.any((c.astype(int) @ pcm.astype(int).T) % 2)

@@ -62,3 +62,33 @@ def test_ranking_and_e2e():
         llr = (2 * y / 0.25).astype(np.float32)
         assert np.array_equal(op.polar5g_decode(code, llr, "SCL", 4), u)
         assert np.mean(op.polar5g_decode(code, llr, "SC") != u) < 0.05
+
+
+def test_polar_transform_matrix_and_dense_polar():
+    """generate_polar_transform_mat / generate_dense_polar (reference polar/utils.py:114-146, 217-290) in the terms of the
+    reference's own tests (test/unit/fec/test_polar_utils.py:56-100, test_polar_encoding.py:130-150): shapes, the all-zero
+    syndrome, and u gm = the Polar encoder's codeword."""
+    from sionna_amd.phy.fec.polar.utils import generate_polar_transform_mat, generate_dense_polar, generate_5g_ranking
+    g1 = np.array([[1, 0], [1, 1]])
+    g = g1
+    for n_lift in range(1, 8):
+        assert np.array_equal(generate_polar_transform_mat(n_lift), g)
+        g = np.kron(g, g1)
+    assert generate_polar_transform_mat(0).shape == (2, 2)                 # the reference's own quirk (the loop runs n_lift-1 times)
+    for bad in (1.5, -1, 20):
+        with pytest.raises(ValueError):
+            generate_polar_transform_mat(bad)
+    rng = np.random.default_rng(5)
+    for n in (32, 64, 128, 256, 512, 1024):
+        for r in (0.1, 0.5, 0.9):
+            k = int(n * r)
+            frozen, info = generate_5g_ranking(k, n)
+            pcm, gm = generate_dense_polar(frozen, n, verbose=False)
+            assert pcm.shape == (n - k, n) and gm.shape == (k, n)
+            assert not np.any((pcm.astype(int) @ gm.astype(int).T) % 2)
+            u = rng.integers(0, 2, (20, k))
+            assert np.array_equal((u @ gm.astype(int)) % 2, op.polar_encode(u.astype(np.float32), info, n).astype(int))
+    with pytest.raises(ValueError):
+        generate_dense_polar(np.arange(3), 48, verbose=False)
+    with pytest.raises(TypeError):
+        generate_dense_polar(np.array([0.0, 1.0]), 8, verbose=False)

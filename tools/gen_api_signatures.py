@@ -20,7 +20,7 @@ SURFACE = {      # reference file -> (import path in sionna.phy, names)
                                           "cn_update_phi", "cn_update_tanh"]),
     "fec/polar/encoding.py": ("fec.polar", ["PolarEncoder", "Polar5GEncoder"]),
     "fec/polar/decoding.py": ("fec.polar", ["PolarSCDecoder", "PolarSCLDecoder", "PolarBPDecoder", "Polar5GDecoder"]),
-    "fec/polar/utils.py": ("fec.polar.utils", ["generate_5g_ranking", "generate_rm_code"]),
+    "fec/polar/utils.py": ("fec.polar.utils", ["generate_5g_ranking", "generate_rm_code", "generate_polar_transform_mat", "generate_dense_polar"]),
     "fec/crc.py": ("fec.crc", ["CRCEncoder", "CRCDecoder"]),
     "fec/scrambling.py": ("fec.scrambling", ["Scrambler", "TB5GScrambler", "Descrambler"]),
     "fec/interleaving.py": ("fec.interleaving", ["RowColumnInterleaver", "RandomInterleaver", "Deinterleaver"]),
