@@ -1391,9 +1391,15 @@ struct OfdmLsEqArgs {
   int hard_out;
 };
 
+// waves per SIMD the front end is compiled for (M K <= 8): 6 (80 registers) where the demapper fits; the max-log forms need
+// 84-100 and 256-QAM 100-117 registers - compiled for 6 waves they spill 8-43 of them.  Measured on the C4 shapes
+// (profiles/r05_lsnn_occ_ab.txt, block calls): 256-QAM app 810 -> 535 us, max-log 554 -> 430 us; 64-QAM max-log 437 -> 369 us;
+// 16-QAM max-log 389 -> 345 us; the forms that fit are the same code.  Same bits.
+constexpr int lsnn_waves(int nb, bool maxlog) { return nb >= 4 ? 4 : (maxlog && nb >= 1 ? 5 : 6); }
+
 // R: resource elements per lane = the same (t, f) of R consecutive (batch, receiver) pairs (see ofdm_lmmse_diag_kernel)
 template <int M, int K, int NB, bool MAXLOG, int R>
-__global__ __launch_bounds__(128, (M * K <= 8) ? (R == 1 ? 6 : 3) : 1) void ofdm_lsnn_lmmse_kernel(OfdmLsEqArgs a) {
+__global__ __launch_bounds__(128, (M * K <= 8) ? (R == 1 ? lsnn_waves(NB, MAXLOG) : 3) : 1) void ofdm_lsnn_lmmse_kernel(OfdmLsEqArgs a) {
   const OfdmEqArgs& p = a.e;
   [[maybe_unused]] __shared__ float lev[NB > 0 ? (1 << NB) : 1];
   if constexpr (NB > 0) {
