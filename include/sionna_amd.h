@@ -662,6 +662,13 @@ int samd_pam2qam_logits_f64(const double* pam1, const double* pam2, int num_bits
 int samd_lmmse_equalizer_c128(const double* y, const double* h, const double* s, int64_t n, int m, int k, int mode,
                               double* x_hat, double* no_eff, void* stream);
 
+/* MaximumLikelihoodDetector.call in float64 (precision = "double"; mimo/detection.py:463-537): y [n, M], h [n, M, K], s [n, M, M]
+ * complex128, prior DEVICE float64 [n, K, 2^nb] logits on the points or NULL, points DEVICE complex128 [2^nb] -> out [n, K, 2^nb]
+ * logits; maxlog 0 = "app".  K <= 8, M <= 16, (2^nb)^K <= 65536, K 2^nb <= 200.  The OFDM blocks build the per-resource-element
+ * inputs on the device (as for samd_lmmse_equalizer_c128) and call this. */
+int samd_ml_detect_f64(const double* y, const double* h, const double* s, const double* prior, const double* points, int64_t n,
+                       int m, int k, int num_bits_per_symbol, int maxlog, double* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * CRC and Polar codes (config C5 of the north star).
  * ---------------------------------------------------------------------------------- */

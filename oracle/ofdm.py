@@ -830,7 +830,10 @@ def ofdm_ml_detector(rg, sm, y, h_hat, err_var, no, points, method="app", prior=
         for st in range(full.shape[1]):
             full[:, st, di[st]] = flat[:, st]
         full = full.reshape(y.shape[0], -1, rg.num_ofdm_symbols, rg.num_effective_subcarriers, last)
-        sel = np.asarray(sm.detection_desired_ind).reshape(sm.num_rx, sm.num_streams_per_rx)
+        # stream (tx-major) detected at position k of receiver r: the inverse of stream_ind (ofdm/detection.py:289-317).  The reference
+        # itself tiles the priors of ALL streams over the receivers (:497-498) and is only defined for one receiver detecting every
+        # stream, where the two coincide.
+        sel = np.argsort(np.asarray(sm.stream_ind)).reshape(sm.num_rx, sm.num_streams_per_rx)
         pr = np.stack([full[:, sel[r]] for r in range(sm.num_rx)], 1)           # [B,rx,K,T,F,last]
         pr = np.transpose(pr, [0, 1, 3, 4, 2, 5]).reshape(-1, K, last)
     out = ml_detector(y_dt.reshape((-1,) + y_dt.shape[-1:]), hd.reshape((-1,) + hd.shape[-2:]), s.reshape((-1,) + s.shape[-2:]),

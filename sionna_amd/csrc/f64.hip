@@ -406,6 +406,90 @@ __global__ __launch_bounds__(64) void equalize_items_f64_kernel(const double2* _
 }  // namespace
 }  // namespace samd
 
+// precision = "double" of MaximumLikelihoodDetector.call (reference mimo/detection.py:463-537): the channel whitened with the
+// Cholesky factor of s, the exponents -||y~ - H~ x||^2 (+ prior) of ALL P^K candidate vectors reduced per stream and point by
+// an online logsumexp ("app") or a maximum ("maxlog").  One lane per problem, run-time M <= 16, K <= 8 (arrays in scratch,
+// like the equaliser above); the K P (max, scaled sum) pairs and the prior of a lane live in LDS, lane-fastest, 32 lanes per
+// workgroup so that K P = 200 points fit.  Held to oracle/ofdm.py::ml_detector (complex128) at 1e-9.
+namespace samd {
+namespace {
+__global__ __launch_bounds__(32) void ml_items_f64_kernel(const double2* __restrict__ y, const double2* __restrict__ h,
+                                                         const double2* __restrict__ s, const double* __restrict__ prior,
+                                                         const double2* __restrict__ points, int64_t n, int M, int K, int nb,
+                                                         int maxlog, double* __restrict__ out) {
+  extern __shared__ double ml64_lds[];                       // acc [K P][2][32], prior [K P][32]
+  const int P = 1 << nb, lane = threadIdx.x;
+  double* acc = ml64_lds;
+  double* pr = ml64_lds + (size_t)2 * K * P * 32;
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= n) return;
+  c64 Y[kEqM], H[kEqM * kEqK], S[kEqM * kEqM];
+  for (int i = 0; i < M; ++i) { const double2 v = y[it * M + i]; Y[i] = C64(v.x, v.y); }
+  for (int i = 0; i < M * K; ++i) { const double2 v = h[it * M * K + i]; H[i] = C64(v.x, v.y); }
+  for (int i = 0; i < M * M; ++i) { const double2 v = s[it * M * M + i]; S[i] = C64(v.x, v.y); }
+  chol64(S, M, M);
+  fwd64(S, M, M, Y, 1, 1);
+  fwd64(S, M, M, H, K, K);
+  for (int a = 0; a < K * P; ++a) {
+    acc[(2 * a) * 32 + lane] = -INFINITY;
+    acc[(2 * a + 1) * 32 + lane] = 0.0;
+    if (prior) pr[a * 32 + lane] = prior[it * K * P + a];
+  }
+  int64_t nv = 1;
+  for (int k = 0; k < K; ++k) nv *= P;
+  for (int64_t v = 0; v < nv; ++v) {
+    int idx[kEqK];
+    c64 x[kEqK];
+    int64_t r = v;
+    for (int k = K - 1; k >= 0; --k) {                        // stream 0 is the slowest digit (detection.py:398-411)
+      idx[k] = (int)(r & (P - 1));
+      r >>= nb;
+      x[k] = C64(points[idx[k]].x, points[idx[k]].y);
+    }
+    double e = 0.0;
+    for (int m = 0; m < M; ++m) {
+      c64 d = Y[m];
+      for (int k = 0; k < K; ++k) d = d - H[m * K + k] * x[k];
+      e -= d.re * d.re + d.im * d.im;
+    }
+    if (prior)
+      for (int k = 0; k < K; ++k) e += pr[(k * P + idx[k]) * 32 + lane];
+    for (int k = 0; k < K; ++k) {
+      double* a = acc + (size_t)(2 * (k * P + idx[k])) * 32 + lane;
+      const double mx = a[0];
+      if (maxlog) {
+        a[0] = fmax(mx, e);
+      } else if (e > mx) {
+        a[32] = a[32] * exp(mx - e) + 1.0;
+        a[0] = e;
+      } else {
+        a[32] += exp(e - mx);
+      }
+    }
+  }
+  for (int a = 0; a < K * P; ++a) {
+    const double mx = acc[(2 * a) * 32 + lane];
+    out[it * K * P + a] = maxlog ? mx : mx + log(acc[(2 * a + 1) * 32 + lane]);
+  }
+}
+}  // namespace
+}  // namespace samd
+
+extern "C" int samd_ml_detect_f64(const double* y, const double* h, const double* s, const double* prior, const double* points,
+                                  int64_t n, int m, int k, int num_bits_per_symbol, int maxlog, double* out, void* stream) {
+  SAMD_REQUIRE(y && h && s && points && out && n >= 0, "null argument");
+  SAMD_REQUIRE(m >= 1 && m <= samd::kEqM && k >= 1 && k <= samd::kEqK, "float64 ML detector: 1 <= K <= 8, 1 <= M <= 16");
+  SAMD_REQUIRE(num_bits_per_symbol >= 1 && num_bits_per_symbol <= 8, "num_bits_per_symbol must be in 1..8");
+  const int64_t P = (int64_t)1 << num_bits_per_symbol;
+  SAMD_REQUIRE(k * num_bits_per_symbol <= 16 && k * P <= 200, "num_points ** num_streams <= 65536 and num_streams * num_points <= 200");
+  if (n == 0) return SAMD_OK;
+  const size_t lds = (size_t)3 * k * P * 32 * sizeof(double);
+  SAMD_SET_MAX_LDS(samd::ml_items_f64_kernel, 160 * 1024);
+  hipLaunchKernelGGL(samd::ml_items_f64_kernel, dim3((unsigned)((n + 31) / 32)), dim3(32), lds, (hipStream_t)stream, (const double2*)y,
+                     (const double2*)h, (const double2*)s, prior, (const double2*)points, n, m, k, num_bits_per_symbol, maxlog, out);
+  return samd::launch_status();
+}
+
 extern "C" int samd_lmmse_equalizer_c128(const double* y, const double* h, const double* s, int64_t n, int m, int k, int mode,
                                          double* x_hat, double* no_eff, void* stream) {
   SAMD_REQUIRE(y && h && s && x_hat && no_eff && n >= 0, "null argument");

@@ -323,27 +323,34 @@ class MaximumLikelihoodDetector(Block):
             return torch.argmax(logits.as_subclass(torch.Tensor), dim=-1).to(torch.int32)
         return logits
 
+    def _logits(self, y, h, s, pr):
+        """device tensors y [..., M], h [..., M, K], s [..., M, M] (contiguous, the block's complex dtype), pr logits on the points
+        [..., K, num_points] or None -> logits [..., K, num_points]: one launch of samd_ml_detect_f32 / _f64"""
+        m, k = h.shape[-2], h.shape[-1]
+        dbl = self.precision == "double"
+        nb = self._constellation.num_bits_per_symbol
+        pts = _ffi.to_device(np.asarray(self._constellation.points, self._np_cdtype), self.cdtype)
+        logits = torch.empty(tuple(h.shape[:-2]) + (k, 1 << nb), dtype=self.rdtype, device=y.device)
+        fn = _ffi.lib().samd_ml_detect_f64 if dbl else _ffi.lib().samd_ml_detect_f32
+        _ffi.check(fn(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pr) if pr is not None else None, _ffi.ptr(pts), y.numel() // m, m, k,
+                      nb, int(self._demapping_method == "maxlog"), _ffi.ptr(logits), _ffi.stream()), "MaximumLikelihoodDetector")
+        return logits
+
     def call(self, y, h, s, prior=None):
-        self._require_single()
-        y = _ffi.to_device(y, torch.complex64)
-        h = _ffi.to_device(h, torch.complex64)
-        s = _ffi.to_device(s, torch.complex64)
+        y = _ffi.to_device(y, self.cdtype)
+        h = _ffi.to_device(h, self.cdtype)
+        s = _ffi.to_device(s, self.cdtype)
         m, k = h.shape[-2], h.shape[-1]
         assert k == self._num_streams, "h must have num_streams columns"
         lead = tuple(h.shape[:-2])
-        pts, nb, maxlog = self._kernel_params()
-        npts = 1 << nb
+        npts = 1 << self._constellation.num_bits_per_symbol
         y = torch.broadcast_to(y, lead + (m,)).contiguous()
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
         h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
         pr = None
         if prior is not None:
-            pr = _ffi.to_device(prior, torch.float32)
+            pr = _ffi.to_device(prior, self.rdtype)
             if self._output == "bit":           # LLRs on the bits -> logits on the points (:475-479)
                 pr = self._llrs2logits(pr).as_subclass(torch.Tensor)
             pr = torch.broadcast_to(pr, lead + (k, npts)).contiguous()
-        logits = torch.empty(lead + (k, npts), dtype=torch.float32, device=y.device)
-        _ffi.check(_ffi.lib().samd_ml_detect_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pr) if pr is not None else None,
-                                                 _ffi.ptr(pts), y.numel() // m, m, k, nb, maxlog, _ffi.ptr(logits), _ffi.stream()),
-                   "MaximumLikelihoodDetector")
-        return wrap(self._finish(logits))
+        return wrap(self._finish(self._logits(y, h, s, pr)))

@@ -160,8 +160,29 @@ class MaximumLikelihoodDetector(Block):
         self._pre = OFDMEqualizer("lmmse", resource_grid, stream_management, precision=precision)
         self._rg = resource_grid
 
+    def _run_double(self, y, h_hat, prior, err_var, no):
+        """precision="double": the reference's own decomposition (ofdm/detection.py:229-317, 454-510) - per-RE inputs built on the
+        device, the float64 detector kernel on every resource element, the data symbols of the streams gathered"""
+        rg, det = self._rg, self._det
+        nb = det._constellation.num_bits_per_symbol
+        y_dt, hd, s, extract, scatter = self._pre._double_inputs(y, h_hat, err_var, no)
+        lead = (y_dt.shape[0], rg.num_tx, rg.num_streams_per_tx, rg.num_data_symbols)
+        pr = None
+        if prior is not None:
+            pr = _ffi.to_device(prior, torch.float64)
+            if det._output == "bit":
+                assert tuple(pr.shape) == lead[:3] + (lead[3] * nb,), "prior must have shape [batch, num_tx, num_streams, num_data_symbols*num_bits_per_symbol]"
+                pr = det._llrs2logits(pr.reshape(lead + (nb,))).as_subclass(torch.Tensor)
+            assert tuple(pr.shape) == lead + (1 << nb,), "prior must have shape [batch, num_tx, num_streams, num_data_symbols, num_points]"
+            pr = scatter(pr)                                                       # [B,rx,T,F,K,num_points], zeros off the data
+        out = det._finish(extract(det._logits(y_dt, hd, s, pr)))
+        if det._output == "bit":
+            out = out.as_subclass(torch.Tensor).reshape(lead[:3] + (lead[3] * nb,))
+        return wrap(out)
+
     def _run(self, y, h_hat, prior, err_var, no):
-        self._require_single()
+        if self.precision == "double":
+            return self._run_double(y, h_hat, prior, err_var, no)
         rg, det = self._rg, self._det
         pts, nb, maxlog = det._kernel_params()
         npts = 1 << nb

@@ -95,11 +95,11 @@ class OFDMEqualizer(Block):
         dims = (b, rx, m, s, sm.num_streams_per_rx, n_und, t, f, rg.fft_size, rg.num_data_symbols)
         return keep, head, tabs, dims
 
-    def _call_double(self, y, h_hat, err_var, no):
-        """precision="double": the steps of the reference's call (ofdm/equalization.py:107-275) as device tensor
-        operations in complex128 around the complex128 equaliser kernel (the single-precision path fuses them into
-        one launch; this one exists for analysis runs)."""
-        from ..mimo.equalization import _equalize_f64
+    def _double_inputs(self, y, h_hat, err_var, no):
+        """precision="double": the pre-processing of the reference's OFDM receivers (ofdm/equalization.py:107-230 =
+        ofdm/detection.py:229-287) as device tensor operations in complex128 -> (y_dt [B,rx,T,F,M], hd [B,rx,T,F,M,K],
+        s [B,rx,T,F,M,M], extract, scatter): ``extract`` takes per-RE results [B,rx,T,F,K,...] to the data symbols of the
+        streams [B,tx,s,num_data,...] (:232-275), ``scatter`` is its inverse with zeros at the other resource elements."""
         rg, sm = self._rg, self._sm
         dev = _ffi.device()
         y = _ffi.to_device(y, torch.complex128)
@@ -126,18 +126,42 @@ class OFDMEqualizer(Block):
         if ind_u.numel() > 0:
             hu = h_dt.index_select(0, ind_u).reshape((sm.num_rx, -1) + tuple(h_dt.shape[1:])).permute(2, 0, 4, 5, 3, 1)
             s = s + hu @ hu.conj().transpose(-1, -2)
-        x_hat, no_eff = _equalize_f64(y_dt.contiguous(), hd.contiguous(), s.contiguous(), int(self._mode), type(self).__name__)
+        stream_ind = torch.as_tensor(np.asarray(sm.stream_ind), dtype=torch.int64, device=dev)
+        di = torch.as_tensor(np.asarray(rg._data_ind_eff()), dtype=torch.int64, device=dev)       # [tx*s, num_data]
+        di = di.reshape(rg.num_tx, rg.num_streams_per_tx, -1)
 
-        def extract(z):                                                            # [B,rx,T,F,K] -> [B,tx,s,num_data]
-            z = z.as_subclass(torch.Tensor).permute(1, 4, 2, 3, 0)                 # [rx,K,T,F,B]
-            z = z.reshape((-1,) + tuple(z.shape[2:]))
-            z = z.index_select(0, torch.as_tensor(np.asarray(sm.stream_ind), dtype=torch.int64, device=dev))
-            z = z.reshape((rg.num_tx, rg.num_streams_per_tx, -1, z.shape[-1]))     # [tx,s,T*F,B]
-            di = torch.as_tensor(np.asarray(rg._data_ind_eff()), dtype=torch.int64, device=dev)   # [tx*s, num_data]
-            di = di.reshape(rg.num_tx, rg.num_streams_per_tx, -1)
-            z = torch.gather(z, 2, di[..., None].expand(-1, -1, -1, z.shape[-1]))  # [tx,s,ND,B]
-            return z.permute(3, 0, 1, 2).contiguous()
+        def extract(z):                                                            # [B,rx,T,F,K,...] -> [B,tx,s,num_data,...]
+            z = z.as_subclass(torch.Tensor)
+            tail = tuple(z.shape[5:])
+            z = z.reshape(tuple(z.shape[:5]) + (-1,)).permute(1, 4, 2, 3, 0, 5)    # [rx,K,T,F,B,E]
+            z = z.reshape((-1,) + tuple(z.shape[2:])).index_select(0, stream_ind)  # streams in transmitter order
+            z = z.reshape((rg.num_tx, rg.num_streams_per_tx, -1) + tuple(z.shape[-2:]))             # [tx,s,T*F,B,E]
+            z = torch.gather(z, 2, di[..., None, None].expand(-1, -1, -1, z.shape[-2], z.shape[-1]))
+            return z.permute(3, 0, 1, 2, 4).reshape((z.shape[3], rg.num_tx, rg.num_streams_per_tx, -1) + tail).contiguous()
+
+        def scatter(z):                                                            # [B,tx,s,num_data,...] -> [B,rx,T,F,K,...]
+            z = z.as_subclass(torch.Tensor)
+            tail = tuple(z.shape[4:])
+            b = z.shape[0]
+            z = z.reshape(tuple(z.shape[:4]) + (-1,)).permute(1, 2, 3, 0, 4)       # [tx,s,ND,B,E]
+            t_, f_ = y_dt.shape[2], y_dt.shape[3]
+            full = torch.zeros((rg.num_tx, rg.num_streams_per_tx, t_ * f_) + tuple(z.shape[-2:]), dtype=z.dtype, device=dev)
+            full.scatter_(2, di[..., None, None].expand(-1, -1, -1, z.shape[-2], z.shape[-1]), z)
+            full = full.reshape((-1, t_, f_) + tuple(z.shape[-2:]))                # [tx*s,T,F,B,E]
+            inv = torch.empty_like(stream_ind)
+            inv[stream_ind] = torch.arange(stream_ind.numel(), device=dev)
+            full = full.index_select(0, inv).reshape((sm.num_rx, sm.num_streams_per_rx, t_, f_) + tuple(z.shape[-2:]))
+            return full.permute(4, 0, 2, 3, 1, 5).reshape((b, sm.num_rx, t_, f_, sm.num_streams_per_rx) + tail).contiguous()
+
+        return y_dt.contiguous(), hd.contiguous(), s.contiguous(), extract, scatter
+
+    def _call_double(self, y, h_hat, err_var, no):
+        """precision="double": ``_double_inputs`` around the complex128 equaliser kernel (the single-precision path fuses
+        all of it into one launch; this one exists for analysis runs)."""
+        from ..mimo.equalization import _equalize_f64
         from ..block import wrap
+        y_dt, hd, s, extract, _ = self._double_inputs(y, h_hat, err_var, no)
+        x_hat, no_eff = _equalize_f64(y_dt, hd, s, int(self._mode), type(self).__name__)
         return wrap(extract(x_hat)), wrap(extract(no_eff))
 
     def _fused_lsnn(self, y, h_hat, err_var, no, demap=None):

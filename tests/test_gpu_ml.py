@@ -93,7 +93,8 @@ def _grids(phy, **kw):
     base = dict(num_tx=1, num_streams_per_tx=2, cyclic_prefix_length=6, num_guard_carriers=[3, 4], dc_null=True,
                 pilot_pattern="kronecker", pilot_ofdm_symbol_indices=[2, 11])
     base.update(kw)
-    return phy.ofdm.ResourceGrid(14, 72, 15e3, **base), o.ResourceGrid(14, 72, 15e3, **base)
+    obase = {k_: v for k_, v in base.items() if k_ != "precision"}                # (the oracle's grid is index bookkeeping only)
+    return phy.ofdm.ResourceGrid(14, 72, 15e3, **base), o.ResourceGrid(14, 72, 15e3, **obase)
 
 
 @pytest.mark.parametrize("output,method,hard", [("bit", "app", False), ("bit", "maxlog", True), ("symbol", "app", False), ("symbol", "maxlog", True)])
@@ -135,6 +136,11 @@ def test_ofdm_ml_two_receivers_with_interference(phy):
     got = _np(det(y, h_hat, 0.0, 0.3))
     ref = o.ofdm_ml_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.3, pts, "app")
     _check(got, ref, ref, "bit", False)
+    # with prior: every receiver's stream takes the prior of the stream it detects
+    prior = rng.normal(size=(B, 2, 1, rg.num_data_symbols * nb)).astype(np.float32)
+    detp = phy.ofdm.MaximumLikelihoodDetectorWithPrior("bit", "app", rg, sm, constellation_type="qam", num_bits_per_symbol=nb)
+    refp = o.ofdm_ml_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.3, pts, "app", prior)
+    _check(_np(detp(y, h_hat, prior, 0.0, 0.3)), refp, refp, "bit", False)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -196,3 +202,97 @@ def test_ofdm_kbest_real_rep_vs_oracle(phy):
     ref = o.ofdm_kbest_detector(org, osm, y, h_hat, np.zeros(1, np.float32), 0.4, pts, 16, use_real_rep=True)
     assert got.shape == ref.shape
     assert np.mean(np.isclose(got, ref, rtol=1e-3, atol=2e-3)) > 0.99
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# precision="double" (the reference's own ML tests run in double: test/unit/mimo/test_mimo_ml_det.py:371-407): samd_ml_detect_f64
+# (csrc/f64.hip) against the float64 oracle at 1e-9, and against the reference-executed fixture
+def _c128(rng, shape, scale=1.0):
+    return (rng.normal(size=shape) + 1j * rng.normal(size=shape)) * scale / np.sqrt(2)
+
+
+def _check64(got, ref, soft_ref, output, hard):
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    if not hard:
+        assert got.dtype == np.float64
+        assert np.allclose(got, ref, rtol=1e-9, atol=1e-9), float(np.max(np.abs(got - ref)))
+        return
+    if output == "bit":
+        sure = np.abs(soft_ref) > 1e-9
+    else:
+        top2 = np.sort(soft_ref, -1)[..., -2:]
+        sure = (top2[..., 1] - top2[..., 0]) > 1e-9
+    assert sure.mean() > 0.99 and np.array_equal(got[sure], ref[sure])
+
+
+@pytest.mark.parametrize("m,k,nb,method", [(4, 2, 2, "app"), (4, 2, 4, "maxlog"), (8, 4, 2, "app"), (2, 2, 4, "app"), (1, 1, 6, "maxlog"),
+                                           (16, 4, 2, "maxlog"), (4, 1, 4, "app"), (3, 3, 1, "app")])
+def test_ml_detector_double_vs_oracle(phy, m, k, nb, method):
+    rng = np.random.default_rng(m * 11 + k + nb)
+    n = 150
+    pts = omap.qam(nb, dtype=np.complex128) if nb > 1 else np.array([1.0, -1.0], np.complex128)      # BPSK = 1-bit PAM (mapping.py:15-42)
+    ctype = "qam" if nb > 1 else "pam"
+    h = _c128(rng, (n, m, k))
+    x = pts[rng.integers(0, 1 << nb, (n, k))]
+    a = _c128(rng, (n, m, m), 0.3)
+    s = a @ np.conj(np.swapaxes(a, -1, -2)) + 0.1 * np.eye(m)
+    y = np.einsum("nmk,nk->nm", h, x) + _c128(rng, (n, m), 0.3)
+    prior_llr = rng.normal(size=(n, k, nb)) * 2
+    for output, prior in (("bit", None), ("bit", prior_llr), ("symbol", None), ("symbol", rng.normal(size=(n, k, 1 << nb)))):
+        for hard in (False, True):
+            det = phy.mimo.MaximumLikelihoodDetector(output, method, k, ctype, nb, hard_out=hard, precision="double")
+            got = _np(det(y, h, s, prior) if prior is not None else det(y, h, s))
+            ref = o.ml_detector(y, h, s, pts, method, prior, output, hard)
+            soft = o.ml_detector(y, h, s, pts, method, prior, output, False)
+            _check64(got, ref.astype(got.dtype) if hard else ref, soft, output, hard)
+
+
+@pytest.mark.parametrize("ci", range(len(CASES)))
+def test_ml_detector_double_matches_reference_execution(phy, ci):
+    """the fixture holds float32 executions of the reference: the double kernel agrees to float32 accuracy"""
+    M, K, nb, output, method, hard, with_prior = CASES[ci]
+    y, h, s, ref = G[f"c{ci}_y"], G[f"c{ci}_h"], G[f"c{ci}_s"], G[f"c{ci}_out"]
+    prior = G[f"c{ci}_prior"] if with_prior else None
+    det = phy.mimo.MaximumLikelihoodDetector(output, method, K, "qam", nb, hard_out=hard, precision="double")
+    got = _np(det(y, h, s, prior) if with_prior else det(y, h, s))
+    soft = o.ml_detector(y, h, s, G[f"c{ci}_points"], method, prior, output, False)
+    _check(got, ref, soft, output, hard)
+
+
+@pytest.mark.parametrize("output,method,hard", [("bit", "app", False), ("bit", "maxlog", True), ("symbol", "app", False), ("symbol", "maxlog", True)])
+def test_ofdm_ml_detector_double_vs_oracle(phy, output, method, hard):
+    rg, org = _grids(phy, precision="double")
+    sm, osm = phy.mimo.StreamManagement(np.array([[1]]), 2), o.StreamManagement(np.array([[1]]), 2)
+    rng = np.random.default_rng(18)
+    B, nb = 2, 2
+    pts = omap.qam(nb, dtype=np.complex128)
+    y = _c128(rng, (B, 1, 4, 14, 72))
+    h_hat = _c128(rng, (B, 1, 4, 1, 2, 14, rg.num_effective_subcarriers))
+    ev = rng.uniform(0.0, 0.05, size=(1, 1, 1, 1, 2, 14, rg.num_effective_subcarriers))
+    kw = dict(constellation_type="qam", num_bits_per_symbol=nb, hard_out=hard, precision="double")
+    got = _np(phy.ofdm.MaximumLikelihoodDetector(output, method, rg, sm, **kw)(y, h_hat, ev, 0.25))
+    ref = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.25, pts, method, None, output, hard)
+    soft = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.25, pts, method, None, output, False)
+    _check64(got, ref.astype(got.dtype) if hard else ref, soft, output, hard)
+    nd = rg.num_data_symbols
+    prior = rng.normal(size=(B, 1, 2, nd * nb)) * 2 if output == "bit" else rng.normal(size=(B, 1, 2, nd, 1 << nb))
+    got = _np(phy.ofdm.MaximumLikelihoodDetectorWithPrior(output, method, rg, sm, **kw)(y, h_hat, prior, ev, 0.25))
+    ref = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.25, pts, method, prior, output, hard)
+    soft = o.ofdm_ml_detector(org, osm, y, h_hat, ev, 0.25, pts, method, prior, output, False)
+    _check64(got, ref.astype(got.dtype) if hard else ref, soft, output, hard)
+
+
+def test_ofdm_ml_double_two_receivers_with_interference(phy):
+    rg, org = _grids(phy, num_tx=2, num_streams_per_tx=1, precision="double")
+    assoc = np.array([[1, 0], [0, 1]])
+    sm, osm = phy.mimo.StreamManagement(assoc, 1), o.StreamManagement(assoc, 1)
+    rng = np.random.default_rng(19)
+    B, nb = 2, 4
+    pts = omap.qam(nb, dtype=np.complex128)
+    y = _c128(rng, (B, 2, 4, 14, 72))
+    h_hat = _c128(rng, (B, 2, 4, 2, 1, 14, rg.num_effective_subcarriers))
+    det = phy.ofdm.MaximumLikelihoodDetectorWithPrior("bit", "app", rg, sm, constellation_type="qam", num_bits_per_symbol=nb, precision="double")
+    prior = rng.normal(size=(B, 2, 1, rg.num_data_symbols * nb))
+    got = _np(det(y, h_hat, prior, 0.0, 0.25))
+    ref = o.ofdm_ml_detector(org, osm, y, h_hat, np.zeros(1), 0.25, pts, "app", prior)
+    _check64(got, ref, ref, "bit", False)
