@@ -669,6 +669,13 @@ int samd_lmmse_equalizer_c128(const double* y, const double* h, const double* s,
 int samd_ml_detect_f64(const double* y, const double* h, const double* s, const double* prior, const double* points, int64_t n,
                        int m, int k, int num_bits_per_symbol, int maxlog, double* out, void* stream);
 
+/* EPDetector.call in float64 (precision = "double"; mimo/detection.py:1166-1312): arguments and output modes of samd_ep_f32
+ * (hard_out 0 max-log LLRs [n, K, nb] / 1 hard bits, 2 the logits of the two PAM constellations [n, K, 2, 2^(nb/2)], 3 the QAM
+ * index of their argmax decisions [n, K]) on complex128 / float64 buffers; pam DEVICE float64 [2^(nb/2)]; K <= 8, M <= 16. */
+int samd_ep_f64(const double* y, const double* h, const double* s, const double* pam, int64_t n, int m, int k,
+                int num_bits_per_symbol, int num_iter, double beta, double es, double prec, int hard_out, double* out,
+                void* stream);
+
 /* ------------------------------------------------------------------------------------
  * CRC and Polar codes (config C5 of the north star).
  * ---------------------------------------------------------------------------------- */

@@ -633,7 +633,7 @@ def _pam_points_over_sqrt2(nbh):
     return pts / np.sqrt(2.0)
 
 
-def ep_detector(y, h, s, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, prec=1e-6, output="bit"):
+def ep_detector(y, h, s, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, prec=1e-6, output="bit", out_dtype=np.float32):
     """EPDetector.call (mimo/detection.py:1166-1312) in float64.
     y [...,M], h [...,M,K], s [...,M,M] -> max-log LLRs [...,K,num_bits_per_symbol] (output="bit"), or QAM logits
     [...,K,2^num_bits_per_symbol] / QAM indices [...,K] through PAM2QAM (output="symbol", :1276-1295)."""
@@ -672,18 +672,19 @@ def ep_detector(y, h, s, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, pr
         from .mapping import pam2qam
         if hard_out:
             return pam2qam(np.argmax(logits[..., :K, :], -1), np.argmax(logits[..., K:, :], -1), num_bits_per_symbol, True)
-        return pam2qam(logits[..., :K, :], logits[..., K:, :], num_bits_per_symbol, False).astype(np.float32)
+        return pam2qam(logits[..., :K, :], logits[..., K:, :], num_bits_per_symbol, False).astype(out_dtype)
     lab = _bit_labels(nbh).T.astype(bool)                                          # [nbh, P]
     llr = np.stack([logits[..., lab[b]].max(-1) - logits[..., ~lab[b]].max(-1) for b in range(nbh)], -1)   # [..., 2K, nbh]
     llr = np.stack([llr[..., :K, :], llr[..., K:, :]], -1).reshape(llr.shape[:-2] + (K, 2 * nbh))
-    return (llr > 0).astype(np.float32) if hard_out else llr.astype(np.float32)
+    return (llr > 0).astype(out_dtype) if hard_out else llr.astype(out_dtype)
 
 
-def ofdm_ep_detector(rg, sm, y, h_hat, err_var, no, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, output="bit"):
+def ofdm_ep_detector(rg, sm, y, h_hat, err_var, no, num_bits_per_symbol, l=10, beta=0.9, hard_out=False, output="bit", prec=1e-6,
+                     out_dtype=np.float32):
     """ofdm.EPDetector.call -> [B,tx,streams,num_data*num_bits_per_symbol] (output="bit"), or the logits
     [B,tx,streams,num_data,num_points] / indices [B,tx,streams,num_data] of output="symbol" (ofdm/detection.py:289-317)."""
     y_dt, hd, s = _ofdm_preprocess(rg, sm, y, h_hat, err_var, no)
-    llr = ep_detector(y_dt, hd, s, num_bits_per_symbol, l, beta, hard_out, output=output)
+    llr = ep_detector(y_dt, hd, s, num_bits_per_symbol, l, beta, hard_out, prec, output=output, out_dtype=out_dtype)
     out = _extract_data(rg, sm, llr, y.shape[0])
     return out if output == "symbol" else out.reshape(out.shape[:3] + (-1,))
 

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "samd_symbol_logits2moments_c128": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp, _vp]),
     "samd_pam2qam_logits_f64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "samd_ml_detect_f64": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_ep_f64": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f64, _f64, _f64, _i32, _vp, _vp]),
     "samd_inv_cholesky_c64": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "samd_inv_cholesky_c128": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "samd_matrix_pinv_c64": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),

@@ -490,6 +490,147 @@ extern "C" int samd_ml_detect_f64(const double* y, const double* h, const double
   return samd::launch_status();
 }
 
+// precision = "double" of EPDetector.call (reference mimo/detection.py:1166-1312): whitening, the real-valued equivalent of the
+// channel, l iterations of expectation propagation on the 2K real dimensions (equations (28)-(38) of [EP2014] as the reference
+// writes them; the 2K x 2K inverse by Gauss-Jordan with partial pivoting) and the output stage of the float32 kernel (csrc/mimo.hip
+// ep_emit): mode 0 max-log LLRs [nb] / 1 hard bits, 2 the logits of the two PAM constellations [2][P], 3 the QAM index of their
+// argmax decisions.  One lane per problem, run-time M <= 16, K <= 8, arrays in scratch.  Held to oracle/ofdm.py::ep_detector.
+namespace samd {
+namespace {
+constexpr int kEpN = 2 * kEqK;
+
+__global__ __launch_bounds__(64) void ep_items_f64_kernel(const double2* __restrict__ y, const double2* __restrict__ h,
+                                                         const double2* __restrict__ s, const double* __restrict__ pam, int64_t n, int M,
+                                                         int K, int nbh, int iters, double beta, double es, double prec, int mode,
+                                                         double* __restrict__ out) {
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= n) return;
+  const int P = 1 << nbh, N2 = 2 * K;
+  c64 Y[kEqM], H[kEqM * kEqK], S[kEqM * kEqM];
+  for (int i = 0; i < M; ++i) { const double2 v = y[it * M + i]; Y[i] = C64(v.x, v.y); }
+  for (int i = 0; i < M * K; ++i) { const double2 v = h[it * M * K + i]; H[i] = C64(v.x, v.y); }
+  for (int i = 0; i < M * M; ++i) { const double2 v = s[it * M * M + i]; S[i] = C64(v.x, v.y); }
+  chol64(S, M, M);
+  fwd64(S, M, M, Y, 1, 1);
+  fwd64(S, M, M, H, K, K);
+  double hth[kEpN * kEpN], hty[kEpN];                         // H_r^T H_r, H_r^T y_r from the complex Gramian / matched filter
+  for (int k = 0; k < K; ++k) {
+    c64 mf = C64(0.0, 0.0);
+    for (int m = 0; m < M; ++m) mf = mf + mulcj(Y[m], H[m * K + k]);
+    hty[k] = mf.re; hty[K + k] = mf.im;
+    for (int j = 0; j < K; ++j) {
+      c64 g = C64(0.0, 0.0);
+      for (int m = 0; m < M; ++m) g = g + mulcj(H[m * K + j], H[m * K + k]);   // conj(h[m][k]) h[m][j]
+      hth[k * N2 + j] = g.re; hth[k * N2 + K + j] = -g.im; hth[(K + k) * N2 + j] = g.im; hth[(K + k) * N2 + K + j] = g.re;
+    }
+  }
+  const double no = 0.5;
+  double lam[kEpN], gam[kEpN], xo[kEpN], vo[kEpN];
+  for (int r = 0; r < N2; ++r) { lam[r] = 1.0 / es; gam[r] = 0.0; xo[r] = 0.0; vo[r] = 1.0; }
+  for (int itn = 0; itn < iters; ++itn) {
+    double a[kEpN * kEpN], ai[kEpN * kEpN];
+    for (int r = 0; r < N2; ++r)
+      for (int c = 0; c < N2; ++c) { a[r * N2 + c] = hth[r * N2 + c] + (r == c ? no * lam[r] : 0.0); ai[r * N2 + c] = r == c ? 1.0 : 0.0; }
+    for (int c = 0; c < N2; ++c) {
+      int piv = c;
+      double best = fabs(a[c * N2 + c]);
+      for (int r = c + 1; r < N2; ++r)
+        if (fabs(a[r * N2 + c]) > best) { best = fabs(a[r * N2 + c]); piv = r; }
+      if (piv != c)
+        for (int j = 0; j < N2; ++j) {
+          double t = a[c * N2 + j]; a[c * N2 + j] = a[piv * N2 + j]; a[piv * N2 + j] = t;
+          t = ai[c * N2 + j]; ai[c * N2 + j] = ai[piv * N2 + j]; ai[piv * N2 + j] = t;
+        }
+      const double inv = 1.0 / a[c * N2 + c];
+      for (int j = 0; j < N2; ++j) { a[c * N2 + j] *= inv; ai[c * N2 + j] *= inv; }
+      for (int r = 0; r < N2; ++r)
+        if (r != c) {
+          const double f = a[r * N2 + c];
+          for (int j = 0; j < N2; ++j) { a[r * N2 + j] -= f * a[c * N2 + j]; ai[r * N2 + j] -= f * ai[c * N2 + j]; }
+        }
+    }
+    double mu_all[kEpN];
+    for (int r = 0; r < N2; ++r) {                             // (29) with the multipliers of the previous iteration
+      double mu = 0.0;
+      for (int c = 0; c < N2; ++c) mu += ai[r * N2 + c] * (hty[c] + no * gam[c]);
+      mu_all[r] = mu;
+    }
+    for (int r = 0; r < N2; ++r) {
+      const double mu = mu_all[r], sigma = no * ai[r * N2 + r];                          // (28)
+      const double v_obs = fmax(1.0 / (1.0 / sigma - lam[r]), prec);                     // (31)
+      const double x_obs = v_obs * (mu / sigma - gam[r]);                                // (32)
+      double mx = -INFINITY;
+      for (int p = 0; p < P; ++p) { const double d = x_obs - pam[p]; mx = fmax(mx, -(d * d) / (2.0 * v_obs)); }
+      double den = 0.0, x = 0.0;
+      for (int p = 0; p < P; ++p) {
+        const double d = x_obs - pam[p], e = exp(-(d * d) / (2.0 * v_obs) - mx);
+        den += e; x += e * pam[p];
+      }
+      x /= den;
+      double v = 0.0;
+      for (int p = 0; p < P; ++p) {
+        const double d = x_obs - pam[p], dd = pam[p] - x;
+        v += dd * dd * (exp(-(d * d) / (2.0 * v_obs) - mx) / den);
+      }
+      v = fmax(v, prec);                                                                 // (33)
+      const double ln = 1.0 / v - 1.0 / v_obs, gn = x / v - x_obs / v_obs;               // (35), (36)
+      const double l_new = ln < 0.0 ? lam[r] : ln, g_new = ln < 0.0 ? gam[r] : gn;
+      lam[r] = (1.0 - beta) * l_new + beta * lam[r];                                     // (37), (38)
+      gam[r] = (1.0 - beta) * g_new + beta * gam[r];
+      xo[r] = x_obs; vo[r] = v_obs;
+    }
+  }
+  const int w = mode == 2 ? 2 * P : mode == 3 ? 1 : 2 * nbh;
+  for (int k = 0; k < K; ++k) {
+    double* o = out + (it * K + k) * w;
+    if (mode == 2) {
+      for (int half = 0; half < 2; ++half)
+        for (int p = 0; p < P; ++p) { const double d = xo[half * K + k] - pam[p]; o[half * P + p] = -(d * d) / (2.0 * vo[half * K + k]); }
+    } else if (mode == 3) {
+      int ind[2];
+      for (int half = 0; half < 2; ++half) {
+        double best = -INFINITY;
+        int bi = 0;
+        for (int p = 0; p < P; ++p) {
+          const double d = xo[half * K + k] - pam[p], lg = -(d * d) / (2.0 * vo[half * K + k]);
+          if (lg > best) { best = lg; bi = p; }
+        }
+        ind[half] = bi;
+      }
+      int qam = 0;
+      for (int b = 0; b < nbh; ++b)
+        qam |= (((ind[0] >> (nbh - 1 - b)) & 1) << (2 * nbh - 1 - 2 * b)) | (((ind[1] >> (nbh - 1 - b)) & 1) << (2 * nbh - 2 - 2 * b));
+      o[0] = (double)qam;
+    } else {
+      for (int half = 0; half < 2; ++half)
+        for (int b = 0; b < nbh; ++b) {
+          double m1 = -INFINITY, m0 = -INFINITY;
+          for (int p = 0; p < P; ++p) {
+            const double d = xo[half * K + k] - pam[p], lg = -(d * d) / (2.0 * vo[half * K + k]);
+            if ((p >> (nbh - 1 - b)) & 1) m1 = fmax(m1, lg); else m0 = fmax(m0, lg);
+          }
+          const double e = m1 - m0;
+          o[2 * b + half] = mode == 1 ? (e > 0.0 ? 1.0 : 0.0) : e;
+        }
+    }
+  }
+}
+}  // namespace
+}  // namespace samd
+
+extern "C" int samd_ep_f64(const double* y, const double* h, const double* s, const double* pam, int64_t n, int m, int k,
+                           int num_bits_per_symbol, int num_iter, double beta, double es, double prec, int hard_out, double* out,
+                           void* stream) {
+  SAMD_REQUIRE(y && h && s && pam && out && n >= 0, "null argument");
+  SAMD_REQUIRE(m >= 1 && m <= samd::kEqM && k >= 1 && k <= samd::kEqK, "float64 EP detector: 1 <= K <= 8, 1 <= M <= 16");
+  SAMD_REQUIRE(num_bits_per_symbol >= 2 && num_bits_per_symbol <= 10 && num_bits_per_symbol % 2 == 0, "QAM with 2..10 bits per symbol");
+  SAMD_REQUIRE(num_iter >= 1 && hard_out >= 0 && hard_out <= 3, "bad detector parameters");
+  if (n == 0) return SAMD_OK;
+  hipLaunchKernelGGL(samd::ep_items_f64_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, (const double2*)y,
+                     (const double2*)h, (const double2*)s, pam, n, m, k, num_bits_per_symbol / 2, num_iter, beta, es, prec, hard_out, out);
+  return samd::launch_status();
+}
+
 extern "C" int samd_lmmse_equalizer_c128(const double* y, const double* h, const double* s, int64_t n, int m, int k, int mode,
                                          double* x_hat, double* no_eff, void* stream) {
   SAMD_REQUIRE(y && h && s && x_hat && no_eff && n >= 0, "null argument");

@@ -97,10 +97,11 @@ class MMSEPICDetector(Block):
         return wrap(out)
 
 
-def _pam_points_over_sqrt2(nbh):
-    """Constellation("pam", nbh)() / sqrt(2): the real dimensions of the unit-energy QAM constellation."""
+def _pam_points_over_sqrt2(nbh, precision=None):
+    """Constellation("pam", nbh, precision=precision)() / sqrt(2): the real dimensions of the unit-energy QAM constellation,
+    formed in the block's precision (detection.py:1155-1161)."""
     from ..mapping import pam
-    return np.asarray(pam(nbh), np.complex128).real / np.sqrt(2.0)
+    return np.asarray(pam(nbh, precision=precision), np.complex128).real / np.sqrt(2.0)
 
 
 class EPDetector(Block):
@@ -116,16 +117,16 @@ class EPDetector(Block):
         assert num_bits_per_symbol % 2 == 0, "EPDetector works on QAM constellations"
         self._output, self._hard_out, self._l, self._beta = output, hard_out, int(l), float(beta)
         self._num_bits_per_symbol = int(num_bits_per_symbol)
-        self._points = _pam_points_over_sqrt2(self._num_bits_per_symbol // 2)
+        self._points = _pam_points_over_sqrt2(self._num_bits_per_symbol // 2, self.precision)
         self._es = float(np.var(self._points))
-        self._prec = 1e-6
+        self._prec = 1e-6 if self.precision == "single" else 1e-12           # detection.py:1129-1132
         if output == "symbol":
             self._pam2qam = PAM2QAM(self._num_bits_per_symbol, hard_out, precision=precision)
 
     def _kernel_params(self):
         """... and the output mode of ``samd_ep_f32``: 0 LLRs / 1 bits (output="bit"), 2 the logits of the two PAM
         constellations / 3 the QAM index of their argmax decisions (output="symbol")."""
-        pam = _ffi.to_device(self._points.astype(np.float32), torch.float32)
+        pam = _ffi.to_device(self._points.astype(self._np_rdtype), self.rdtype)
         mode = int(bool(self._hard_out)) + (2 if self._output == "symbol" else 0)
         return pam, self._num_bits_per_symbol, self._l, self._beta, self._es, self._prec, mode
 
@@ -173,21 +174,27 @@ class EPDetector(Block):
         lam_new, gam_new = torch.where(keep, lam, lam_new), torch.where(keep, gam, gam_new)
         return (1 - self._beta) * lam_new + self._beta * lam, (1 - self._beta) * gam_new + self._beta * gam
 
+    def _solve(self, y, h, s):
+        """contiguous device tensors y [..., M], h [..., M, K], s [..., M, M] in the block's complex dtype -> the kernel's
+        output [..., K, W] (one launch of samd_ep_f32 / samd_ep_f64)"""
+        m, k = h.shape[-2], h.shape[-1]
+        pam, nb, l, beta, es, prec, hard = self._kernel_params()
+        out = torch.empty(tuple(h.shape[:-2]) + (k, self._out_width()), dtype=self.rdtype, device=y.device)
+        fn = _ffi.lib().samd_ep_f64 if self.precision == "double" else _ffi.lib().samd_ep_f32
+        _ffi.check(fn(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pam), y.numel() // m, m, k, nb, l, beta, es, prec, hard,
+                      _ffi.ptr(out), _ffi.stream()), "EPDetector")
+        return out
+
     def call(self, y, h, s):
-        self._require_single()
-        y = _ffi.to_device(y, torch.complex64)
-        h = _ffi.to_device(h, torch.complex64)
-        s = _ffi.to_device(s, torch.complex64)
+        y = _ffi.to_device(y, self.cdtype)
+        h = _ffi.to_device(h, self.cdtype)
+        s = _ffi.to_device(s, self.cdtype)
         m, k = h.shape[-2], h.shape[-1]
         lead = tuple(h.shape[:-2])
-        pam, nb, l, beta, es, prec, hard = self._kernel_params()
         y = torch.broadcast_to(y, lead + (m,)).contiguous()
         s = torch.broadcast_to(s, lead + (m, m)).contiguous()
-        out = torch.empty(lead + (k, self._out_width()), dtype=torch.float32, device=y.device)
         h = h.contiguous()                      # (a named tensor: its storage must outlive the launch call)
-        _ffi.check(_ffi.lib().samd_ep_f32(_ffi.ptr(y), _ffi.ptr(h), _ffi.ptr(s), _ffi.ptr(pam), y.numel() // m, m, k,
-                                          nb, l, beta, es, prec, hard, _ffi.ptr(out), _ffi.stream()), "EPDetector")
-        return wrap(self._finish(out, lead + (k,)))
+        return wrap(self._finish(self._solve(y, h, s), lead + (k,)))
 
 
 class KBestDetector(Block):

@@ -99,8 +99,13 @@ class EPDetector(Block):
         self._rg = resource_grid
 
     def call(self, y, h_hat, err_var, no):
-        self._require_single()
         rg = self._rg
+        if self.precision == "double":          # the reference's decomposition around the float64 kernel (ofdm/detection.py:229-317)
+            y_dt, hd, s, extract, _ = self._pre._double_inputs(y, h_hat, err_var, no)
+            out = extract(self._det._solve(y_dt, hd, s))                       # [batch, num_tx, num_streams, num_data, W]
+            if self._det._output == "symbol":
+                return wrap(self._det._finish(out, tuple(out.shape[:4])))
+            return wrap(out.reshape(tuple(out.shape[:3]) + (-1,)))
         pam, nb, l, beta, es, prec, hard = self._det._kernel_params()
         keep, head, tabs, dims = self._pre._prepare(y, h_hat, err_var, no)
         lead = (dims[0], rg.num_tx, rg.num_streams_per_tx)

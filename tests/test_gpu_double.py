@@ -630,3 +630,67 @@ def test_linear_detectors_double(phy):
     xh, ne = o32._extract_data(org, osm, xh, 3), o32._extract_data(org, osm, ne, 3)
     ref2 = omap.demapper(xh, ne, pts, "maxlog").reshape(out.shape)
     assert np.allclose(_np(out), ref2, rtol=1e-7, atol=1e-7), float(np.max(np.abs(_np(out) - ref2)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# EPDetector with precision="double" (the reference's own EP test runs single and double: test/unit/mimo/test_ep_det.py:127):
+# samd_ep_f64 (csrc/f64.hip) against the float64 oracle with the double-precision floor 1e-12 (detection.py:1129-1132).  The
+# first iteration is held to 1e-9.  For l > 1 the bar is 2e-3 (1 + |LLR|) on more than 99 % of the LLRs and the same signs wherever
+# the oracle's LLR is not ~0: a dimension whose decision has become certain gets a multiplier lam ~ 1 / 1e-12, the matrix
+# H^T H + no diag(lam) is then conditioned like 1e12 and Gauss-Jordan (here) and LAPACK (oracle) need not agree beyond ~1e-4
+# relative.  (How much of the bar is needed was not re-measured after the PAM points moved to the block's precision.)
+@pytest.mark.parametrize("m,k,nb", [(4, 2, 4), (4, 4, 2), (8, 4, 4), (2, 2, 6), (16, 8, 2), (1, 1, 4)])
+def test_ep_detector_double_vs_oracle(phy, m, k, nb):
+    rng = np.random.default_rng(m + 3 * k + nb)
+    n = 200
+    pts = omap.qam(nb, dtype=np.complex128)
+    x = pts[rng.integers(0, 1 << nb, (n, k))]
+    h = _c128(rng, (n, m, k), 0.7)
+    a = _c128(rng, (n, m, m), 0.07)
+    s = a @ np.conj(np.swapaxes(a, -1, -2)) + 0.1 * np.eye(m)
+    y = np.einsum("nmk,nk->nm", h, x) + _c128(rng, (n, m), 0.22)
+    for l, beta in ((1, 0.9), (10, 0.9), (5, 0.5)):
+        got = _np(phy.mimo.EPDetector("bit", nb, l=l, beta=beta, precision="double")(y, h, s))
+        ref = o32.ep_detector(y, h, s, nb, l=l, beta=beta, prec=1e-12, out_dtype=np.float64)
+        assert got.dtype == np.float64 and got.shape == ref.shape == (n, k, nb)
+        if l == 1:
+            assert np.allclose(got, ref, rtol=1e-9, atol=1e-9), float(np.max(np.abs(got - ref)))
+            continue
+        ok = np.abs(got - ref) <= 2e-3 * (1 + np.abs(ref))
+        assert ok.mean() > 0.99, (ok.mean(), float(np.max(np.abs(got - ref))))
+        sure = np.abs(ref) > 1e-2
+        assert np.mean((got[sure] > 0) == (ref[sure] > 0)) > 0.999
+    hard = _np(phy.mimo.EPDetector("bit", nb, hard_out=True, precision="double")(y, h, s))
+    soft = o32.ep_detector(y, h, s, nb, prec=1e-12, out_dtype=np.float64)
+    sure = np.abs(soft) > 1e-2
+    assert hard.dtype == np.float64 and np.mean(hard[sure] == (soft[sure] > 0)) > 0.999
+    sym = _np(phy.mimo.EPDetector("symbol", nb, precision="double")(y, h, s))
+    ref_sym = o32.ep_detector(y, h, s, nb, prec=1e-12, output="symbol", out_dtype=np.float64)
+    assert sym.dtype == np.float64 and sym.shape == ref_sym.shape == (n, k, 1 << nb)
+    okq = np.abs(sym - ref_sym) <= 2e-3 * (1 + np.abs(ref_sym))
+    assert okq.mean() > 0.99
+    ind = _np(phy.mimo.EPDetector("symbol", nb, hard_out=True, precision="double")(y, h, s))
+    ref_ind = o32.ep_detector(y, h, s, nb, prec=1e-12, output="symbol", hard_out=True)
+    assert ind.dtype == np.int32 and np.mean(ind == ref_ind) > 0.99
+
+
+def test_ofdm_ep_detector_double_vs_oracle(phy):
+    rg, org = _grids64(phy, num_tx=2, num_streams_per_tx=2)
+    assoc = np.array([[1, 0], [0, 1]])
+    sm, osm = phy.mimo.StreamManagement(assoc, 2), o32.StreamManagement(assoc, 2)
+    rng = np.random.default_rng(31)
+    B, nb = 2, 4
+    y = _c128(rng, (B, 2, 4, 14, 76))
+    h_hat = _c128(rng, (B, 2, 4, 2, 2, 14, rg.num_effective_subcarriers))
+    ev = rng.uniform(0.0, 0.05, (1, 1, 1, 2, 2, 14, rg.num_effective_subcarriers))
+    got = _np(phy.ofdm.EPDetector("bit", rg, sm, nb, l=6, precision="double")(y, h_hat, ev, 0.25))
+    ref = o32.ofdm_ep_detector(org, osm, y, h_hat, ev, 0.25, nb, l=6, prec=1e-12, out_dtype=np.float64)
+    assert got.dtype == np.float64 and got.shape == ref.shape
+    ok = np.abs(got - ref) <= 2e-3 * (1 + np.abs(ref))
+    assert ok.mean() > 0.99, (ok.mean(), float(np.max(np.abs(got - ref))))
+    one = _np(phy.ofdm.EPDetector("bit", rg, sm, nb, l=1, precision="double")(y, h_hat, ev, 0.25))
+    ref1 = o32.ofdm_ep_detector(org, osm, y, h_hat, ev, 0.25, nb, l=1, prec=1e-12, out_dtype=np.float64)
+    assert np.allclose(one, ref1, rtol=1e-9, atol=1e-9), float(np.max(np.abs(one - ref1)))
+    ind = _np(phy.ofdm.EPDetector("symbol", rg, sm, nb, l=6, hard_out=True, precision="double")(y, h_hat, ev, 0.25))
+    ref_ind = o32.ofdm_ep_detector(org, osm, y, h_hat, ev, 0.25, nb, l=6, hard_out=True, output="symbol", prec=1e-12)
+    assert ind.dtype == np.int32 and ind.shape == ref_ind.shape and np.mean(ind == ref_ind) > 0.99
