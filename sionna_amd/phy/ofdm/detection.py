@@ -2,13 +2,12 @@
 (-> ``OFDMDetector.call`` :289-317 -> ``mimo.LinearDetector``): fused LMMSE equaliser followed by
 the LLR demapper with the per-symbol effective noise variance - and ``ofdm.MMSEPICDetector``
 (:1062-1230 on ``OFDMDetectorWithPrior`` :320-560, bit output) in one fused launch."""
-import numpy as np
 import torch
 
 from ... import _ffi
 from ..block import Block, wrap
 from ..mapping import Demapper, SymbolDemapper, Constellation
-from .equalization import LMMSEEqualizer, OFDMEqualizer
+from .equalization import OFDMEqualizer
 
 
 class LinearDetector(Block):

@@ -9,7 +9,6 @@ max-log 554 -> 430 us, 64-QAM max-log 437 -> 369 us, 16-QAM max-log 389 -> 345 u
 import os
 import sys
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
