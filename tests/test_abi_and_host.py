@@ -165,3 +165,34 @@ def test_library_never_calls_getenv_and_option_registry_works():
     import pytest
     with pytest.raises(ValueError):
         _ffi.set_option("HOME", "x")
+
+
+def test_integration_stubs_match_the_abi():
+    """every ``lib.samd_*(...)`` call written out in INTEGRATION.md names an exported entry point and passes as many arguments as
+    include/sionna_amd.h declares (stubs that splat a prepared argument list with ``*`` are checked by name only)"""
+    import os
+    import re
+    with open(os.path.join(os.path.dirname(__file__), "..", "INTEGRATION.md")) as f:
+        src = f.read()
+    seen = 0
+    for m in re.finditer(r"lib\.(samd_\w+)\(", src):
+        name, i, depth = m.group(1), m.end(), 1
+        j = i
+        while depth and j < len(src):
+            depth += (src[j] == "(") - (src[j] == ")")
+            j += 1
+        parts, d, cur = [], 0, ""
+        for c in src[i:j - 1]:
+            d += (c in "([") - (c in ")]")
+            if c == "," and d == 0:
+                parts.append(cur)
+                cur = ""
+            else:
+                cur += c
+        if cur.strip():
+            parts.append(cur)
+        assert name in _ffi._SIGNATURES, f"INTEGRATION.md calls {name}, which include/sionna_amd.h does not declare"
+        if not any(p.strip().startswith("*") for p in parts):
+            assert len(parts) == len(_ffi._SIGNATURES[name][1]), f"INTEGRATION.md: {name} is written with {len(parts)} arguments, the ABI has {len(_ffi._SIGNATURES[name][1])}"
+        seen += 1
+    assert seen >= 15
