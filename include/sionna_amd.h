@@ -365,7 +365,7 @@ int samd_mmse_pic_f32(const float* y, const float* h, const float* s, const floa
                       const float* points, int64_t n, int m, int k, int num_bits_per_symbol,
                       int maxlog, int num_iter, int hard_out, float* out, void* stream);
 
-/* ofdm.MMSEPICDetector.call  ofdm/detection.py:1062-1230 (OFDMDetectorWithPrior :320-560): the
+/* ofdm.MMSEPICDetector.call  ofdm/detection.py:1062-1173 (OFDMDetectorWithPrior :320-560): the
  * pre-processing of samd_ofdm_lmmse_c64 + the detector above in one launch.  prior / out
  * [batch, num_streams_total, num_data * num_bits_per_symbol]. */
 int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const float* err_var, int ev_mode,
@@ -377,7 +377,7 @@ int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const float* err_
                            int num_bits_per_symbol, int maxlog, int num_iter, int hard_out, float* out,
                            void* stream);
 
-/* LinearEncoder.call  fec/linear/encoding.py:143-168: c = (u G) mod 2 for a binary generator
+/* LinearEncoder.call  fec/linear/encoding.py:122-140: c = (u G) mod 2 for a binary generator
  * matrix.  gm_cols DEVICE uint32 [n][ceil(k/32)]: bit (i & 31) of word (i >> 5) of row j = G[i][j]
  * (the columns of G, packed).  u [batch,k] float 0/1 -> out [batch,n] float 0/1. */
 int samd_gf2_encode_f32(const float* u, const uint32_t* gm_cols, int64_t batch, int k, int n,
@@ -499,7 +499,7 @@ int samd_cir_to_time_c64(float bandwidth, const float* a, const float* tau, int 
                          int num_paths, int num_time_steps, int normalize, float* h_time,
                          float* norm_scale, void* stream);
 
-/* ApplyTimeChannel.call (noise-free part)  channel/apply_time_channel.py:95-175.
+/* ApplyTimeChannel.call (noise-free part)  channel/apply_time_channel.py:85-137.
  * x [B,tx,ta,num_time_samples], h_time [B,rx,ra,tx,ta,num_time_samples+l_tot-1,l_tot] ->
  * y [B,rx,ra,num_time_samples+l_tot-1].  link_scale: nullable [B,rx,tx] factor per link. */
 int samd_apply_time_channel_c64(const float* x, const float* h_time, const float* link_scale, int batch,
@@ -656,7 +656,7 @@ int samd_pam2qam_logits_f64(const double* pam1, const double* pam2, int num_bits
                             void* stream);
 
 /* lmmse_equalizer / zf_equalizer / mf_equalizer in complex128 (precision = "double", reference block.py:25-52;
- * mimo/equalization.py:101-470): y [n, M], h [n, M, K], s [n, M, M] complex128 -> x_hat [n, K] complex128, no_eff
+ * mimo/equalization.py:101-463): y [n, M], h [n, M, K], s [n, M, M] complex128 -> x_hat [n, K] complex128, no_eff
  * [n, K] float64; mode 0 LMMSE without whitening, 1 LMMSE, 2 ZF, 3 MF; K <= 8, K <= M <= 16.  OFDMEqualizer.call with
  * precision="double" builds the per-resource-element inputs on the device and calls this. */
 int samd_lmmse_equalizer_c128(const double* y, const double* h, const double* s, int64_t n, int m, int k, int mode,
@@ -774,7 +774,7 @@ void samd_comm_destroy(samd_comm_t* c);
  * (precision = "double").  The receiver kernels carry the same algebra fused; these are for host code that calls the
  * helpers directly.
  *   samd_inv_cholesky    utils/linalg.py:8-32      a [n,M,M] Hermitian positive definite = L L^H -> out [n,M,M] = L^-1
- *   samd_matrix_pinv     utils/linalg.py:35-66     a [n,M,K] of full column rank (K <= M) -> out [n,K,M] = (A^H A)^-1 A^H
+ *   samd_matrix_pinv     utils/linalg.py:35-59     a [n,M,K] of full column rank (K <= M) -> out [n,K,M] = (A^H A)^-1 A^H
  *   samd_whiten_channel  mimo/utils.py:292-356     y [n,M], h [n,M,K], s [n,M,M] = L L^H -> yw = L^-1 y, hw = L^-1 h
  *   samd_lmmse_matrix    mimo/equalization.py:11-99  h [n,M,K], s [n,M,M] or NULL -> g [n,K,M] = H^H (H H^H + S)^-1,
  *                        with s == NULL (white unit-variance noise) (H^H H + I)^-1 H^H

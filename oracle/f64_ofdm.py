@@ -167,7 +167,7 @@ def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False):
 
 
 def apply_time_channel(x, h_time):
-    """channel/apply_time_channel.py:95-175: x [B,tx,ta,Tn], h [B,rx,ra,tx,ta,Tn+L-1,L] -> y [B,rx,ra,Tn+L-1]"""
+    """channel/apply_time_channel.py:85-137: x [B,tx,ta,Tn], h [B,rx,ra,tx,ta,Tn+L-1,L] -> y [B,rx,ra,Tn+L-1]"""
     x, h = np.asarray(x, np.complex128), np.asarray(h_time, np.complex128)
     tn, l_tot = x.shape[-1], h.shape[-1]
     tout = tn + l_tot - 1

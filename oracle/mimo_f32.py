@@ -8,7 +8,7 @@ TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  Restates (paths relative to /
 * lmmse_matrix             mimo/equalization.py:11-99    (G = (H^H H + I)^-1 H^H through a Cholesky solve)
 * inv_cholesky / matrix_pinv   utils/linalg.py:8-58
 * zf_equalizer             mimo/equalization.py:235-298
-* mf_equalizer             mimo/equalization.py:300-470
+* mf_equalizer             mimo/equalization.py:300-463
 * OFDMEqualizer.call       ofdm/equalization.py:109-275  (covariance S = H_u H_u^H + diag(no) + diag(sum err_var))
 
 Why a second oracle next to ``oracle/ofdm.py``'s complex128 one: the reference evaluates these formulas in

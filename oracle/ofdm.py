@@ -513,7 +513,7 @@ def cir_to_time_channel(bandwidth, a, tau, l_min, l_max, normalize=False):
 
 
 def apply_time_channel(x, h_time):
-    """channel/apply_time_channel.py:95-175 without noise: x [B,tx,ta,Tn],
+    """channel/apply_time_channel.py:85-137 without noise: x [B,tx,ta,Tn],
     h_time [B,rx,ra,tx,ta,Tn+L-1,L] -> y [B,rx,ra,Tn+L-1]."""
     B, rx, ra, tx, ta, Tout, L = h_time.shape
     Tn = x.shape[-1]
@@ -854,7 +854,7 @@ def zf_equalizer(y, h, s):
 
 
 def mf_equalizer(y, h, s):
-    """mimo/equalization.py:300-470 (complex128)."""
+    """mimo/equalization.py:300-463 (complex128)."""
     y, h, s = y.astype(np.complex128), h.astype(np.complex128), s.astype(np.complex128)
     hh = np.conj(np.swapaxes(h, -1, -2))
     d = 1 / np.diagonal(hh @ h, axis1=-2, axis2=-1)

@@ -1,6 +1,6 @@
 // precision = "double" (reference src/sionna/phy/block.py:25-52) for the time-domain channel: float64 variants of
 //   cir_to_time_channel    channel/utils.py:256-349
-//   ApplyTimeChannel.call  channel/apply_time_channel.py:95-175
+//   ApplyTimeChannel.call  channel/apply_time_channel.py:85-137
 // Layouts of samd_cir_to_time_c64 / samd_apply_time_channel_c64 (csrc/ofdm_time.hip).  One output per lane, ascending path / tap
 // order; the normalisation is a second pass (the deferred-scale form of the float32 kernels is a throughput feature).  Held to
 // oracle/f64_ofdm.py at 1e-9; the tuned kernels are the float32 ones.

@@ -1,5 +1,5 @@
 // Generic binary linear block encoder.
-//   LinearEncoder.call   /root/reference/src/sionna/phy/fec/linear/encoding.py:143-168
+//   LinearEncoder.call   /root/reference/src/sionna/phy/fec/linear/encoding.py:122-140
 //                        (c = (u G) mod 2 as a float matmul + int_mod_2)
 // GF(2) formulation: the information word is packed into 32-bit words once per codeword (ballot)
 // and every codeword bit is the parity of popcount(u & g_col) over k/32 words - bit exact, no

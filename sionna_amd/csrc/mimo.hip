@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(64) void mmse_pic_items_kernel(const float2* __rest
     for (int b = 0; b < q.nb; ++b) out[(i * K + k) * q.nb + b] = llr[k][b];
 }
 
-// ---- fused OFDM MMSE-PIC detector (ofdm/detection.py:1062-1230 + OFDMDetectorWithPrior :320-560):
+// ---- fused OFDM MMSE-PIC detector (ofdm/detection.py:1062-1173 + OFDMDetectorWithPrior :320-560):
 // prior / out [B, S, ND * nb]; REs without data for a stream enter with a zero prior.
 template <int M, int K>
 __global__ __launch_bounds__(64) void ofdm_mmse_pic_kernel(OfdmEqArgs p, const float* __restrict__ prior, PicParams q,

@@ -1,6 +1,6 @@
 // The small per-item linear algebra the reference's MIMO blocks are written in, as entry points of their own:
 //   inv_cholesky    utils/linalg.py:8-32      A = L L^H            -> L^-1
-//   matrix_pinv     utils/linalg.py:35-66     A [M,K]              -> (A^H A)^-1 A^H
+//   matrix_pinv     utils/linalg.py:35-59     A [M,K]              -> (A^H A)^-1 A^H
 //   whiten_channel  mimo/utils.py:292-356     y, H, S = L L^H      -> L^-1 y, L^-1 H
 //   lmmse_matrix    mimo/equalization.py:11-99  H (and S)          -> H^H (H H^H + S)^-1, or (H^H H + I)^-1 H^H without S
 // The receiver kernels (csrc/mimo.hip, csrc/f64.hip) carry this algebra fused and unrolled for their sizes; these entries

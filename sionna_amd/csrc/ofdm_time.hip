@@ -5,7 +5,7 @@
 //   OFDMDemodulator.call    /root/reference/src/sionna/phy/ofdm/demodulator.py:143-203
 //   fft / ifft              /root/reference/src/sionna/phy/signal/utils.py:150-262
 //   cir_to_time_channel     /root/reference/src/sionna/phy/channel/utils.py:256-349
-//   ApplyTimeChannel.call   /root/reference/src/sionna/phy/channel/apply_time_channel.py:95-175
+//   ApplyTimeChannel.call   /root/reference/src/sionna/phy/channel/apply_time_channel.py:85-137
 //
 // The batched 1-D transforms are rocFFT's (north_star: "OFDM FFT goes to rocFFT"); the
 // library is bound lazily with dlopen so that libsionna_amd.so itself carries no link-time
@@ -292,7 +292,7 @@ __global__ void __launch_bounds__(256) cir_to_time_kernel(const float2* __restri
 }
 
 // y[b, rxa, t] = sum_{txa} sum_l h[b, rxa, txa, t, l] x[b, txa, t - l], 0 <= t - l < Tn
-// (apply_time_channel.py:155-166); rxa = rx * RA + ra, txa = tx * TA + ta.
+// (apply_time_channel.py:121-132); rxa = rx * RA + ra, txa = tx * TA + ta.
 __global__ void __launch_bounds__(256) apply_time_kernel(const float2* __restrict__ x, const float2* __restrict__ h,
                                                          const float* __restrict__ link_scale, int num_rx, int RA,
                                                          int num_tx, int TA, int Tn, int L, int ntb,

@@ -1,5 +1,5 @@
 """Flat-fading MIMO channel - mirrors of ``GenerateFlatFadingChannel``, ``ApplyFlatFadingChannel`` and
-``FlatFadingChannel`` (reference src/sionna/phy/channel/flat_fading_channel.py:14-290): i.i.d. CN(0,1)
+``FlatFadingChannel`` (reference src/sionna/phy/channel/flat_fading_channel.py:14-246): i.i.d. CN(0,1)
 channel matrices on the Philox stream and y = H x (+ AWGN) through ``samd_apply_ofdm_channel_c64``
 (one "resource element" per batch item); spatial correlation models (spatial_correlation.py) through
 ``samd_spatial_corr_c64``."""

@@ -1,5 +1,5 @@
 """Spatial correlation models of the flat-fading channel - mirrors of ``SpatialCorrelation``, ``KroneckerModel`` and
-``PerColumnModel`` (reference src/sionna/phy/channel/spatial_correlation.py:13-200) and of ``exp_corr_mat`` /
+``PerColumnModel`` (reference src/sionna/phy/channel/spatial_correlation.py:13-195) and of ``exp_corr_mat`` /
 ``one_ring_corr_mat`` (channel/utils.py:1490-1652).
 
 The Cholesky factors are taken on the host when the matrices are set (they are [M, M] / [K, K]); applying a model to
@@ -108,7 +108,7 @@ class KroneckerModel(SpatialCorrelation):
 
 class PerColumnModel(SpatialCorrelation):
     """``PerColumnModel(r_rx)(h)``: column k of h is correlated with its own matrix, h[:, k] <- L_rx[k] h[:, k]
-    (spatial_correlation.py:125-200).  r_rx [K, M, M]."""
+    (spatial_correlation.py:125-195).  r_rx [K, M, M]."""
 
     def __init__(self, r_rx, precision=None):
         super().__init__(precision=precision)

@@ -1,7 +1,7 @@
 """Time-domain channel: ``cir_to_time_channel``, ``time_lag_discrete_time_channel``,
 ``GenerateTimeChannel``, ``ApplyTimeChannel``, ``TimeChannel`` - mirrors of reference
 src/sionna/phy/channel/utils.py:121-178 and :256-349, generate_time_channel.py:9-100,
-apply_time_channel.py:14-175, time_channel.py:13-165."""
+apply_time_channel.py:14-137, time_channel.py:13-163."""
 import numpy as np
 import torch
 

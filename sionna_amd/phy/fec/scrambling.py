@@ -175,7 +175,7 @@ class Descrambler(Block):
 
     def call(self, x, /, *, seed=None):
         scr = self._scrambler
-        scr._io_rdtype = self.rdtype               # the descrambler's own precision (scrambling.py:573-583 casts to it)
+        scr._io_rdtype = self.rdtype               # the descrambler's own precision (scrambling.py:573-579 casts to it)
         try:
             if isinstance(scr, Scrambler):
                 s = seed if seed is not None else scr.seed

@@ -128,7 +128,7 @@ def test_chain_in_double_precision(phy):
 def test_equalizers_double_vs_complex128_oracle(phy, m, k):
     """lmmse_equalizer (with / without whitening), zf_equalizer, mf_equalizer with precision="double" (the last
     precision="single"-only blocks of the hot path in round 2): complex128 kernel against the NumPy complex128
-    restatement of mimo/equalization.py:101-470 at 1e-9."""
+    restatement of mimo/equalization.py:101-463 at 1e-9."""
     from oracle import ofdm as oo
     rng = np.random.default_rng(m * 10 + k)
     n = 257

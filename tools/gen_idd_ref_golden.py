@@ -4,7 +4,7 @@ the NumPy stand-in for TensorFlow (tools/ref_exec): the ``IddModel`` of
 tutorials/phy/Introduction_to_Iterative_Detection_and_Decoding.ipynb (cells 9-13) with perfect-CSI Rayleigh fading -
 ``ofdm.LinearDetector("lmmse", "bit", "maxlog")`` (ofdm/detection.py:740-847 on OFDMDetector :21-317 and
 mimo/detection.py:24-143) -> ``LDPC5GDecoder(return_infobits=False, return_state=True)`` (soft output + decoder state) ->
-``ofdm.MMSEPICDetector`` with the decoder's LLRs as prior (ofdm/detection.py:1062-1230 on OFDMDetectorWithPrior :320-510,
+``ofdm.MMSEPICDetector`` with the decoder's LLRs as prior (ofdm/detection.py:1062-1173 on OFDMDetectorWithPrior :320-510,
 mimo/detection.py:1314-1643) -> ``LDPC5GDecoder(..., msg_v2c=state)`` -, plus ``KBestDetector`` / ``EPDetector`` outputs on
 the same received grid.  ResourceGrid / KroneckerPilotPattern / StreamManagement / ResourceGridMapper are the reference's
 too (pilot symbols from a NumPy generator instead of TF's - perfect CSI, they do not enter).  16 receive antennas, 4

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates tests/golden/linalg_ref_golden.npz by EXECUTING the reference's own ``inv_cholesky`` / ``matrix_pinv``
-(/root/reference/src/sionna/phy/utils/linalg.py:8-66), ``whiten_channel`` and the complex <-> real-valued representation
+(/root/reference/src/sionna/phy/utils/linalg.py:8-59), ``whiten_channel`` and the complex <-> real-valued representation
 helpers (mimo/utils.py:11-356) and ``lmmse_matrix`` (mimo/equalization.py:11-99) under the NumPy stand-in for TensorFlow
 (tools/ref_exec), in double precision, on random well-conditioned problems.  Run here (needs /root/reference); the fixture
 travels.  tests/test_oracle_ref_exec_linalg.py holds oracle/linalg.py to it."""

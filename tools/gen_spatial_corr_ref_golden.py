@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates tests/golden/spatial_corr_ref_golden.npz by EXECUTING the reference's ``exp_corr_mat`` / ``one_ring_corr_mat``
-(channel/utils.py:1490-1652) and ``KroneckerModel`` / ``PerColumnModel`` (channel/spatial_correlation.py:41-200) under the
+(channel/utils.py:1490-1652) and ``KroneckerModel`` / ``PerColumnModel`` (channel/spatial_correlation.py:41-195) under the
 NumPy stand-in for TensorFlow: the correlation matrices and the models' outputs on fixed channel matrices (4 x 16 as in
 Simple_MIMO_Simulation.ipynb cell 44, and 3 x 5 with complex correlation).  Run here (needs /root/reference)."""
 import os

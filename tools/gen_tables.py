@@ -43,7 +43,7 @@ print("wrote", os.path.normpath(dst))
 
 # ---- TDL power-delay profiles (3GPP TR 38.901 Tables 7.7.2-1..5 and the A30/B100/C300 variants
 # of TS 38.101/38.104), shipped by the reference as channel/tr38901/models/TDL-*.json
-# (parsed at channel/tr38901/tdl.py:539-600).  Re-packed into one JSON.
+# (parsed at channel/tr38901/tdl.py:539-592).  Re-packed into one JSON.
 import json
 tdl = {}
 mdir = os.path.join(ref, "src/sionna/phy/channel/tr38901/models")
