@@ -196,3 +196,11 @@ def test_integration_stubs_match_the_abi():
             assert len(parts) == len(_ffi._SIGNATURES[name][1]), f"INTEGRATION.md: {name} is written with {len(parts)} arguments, the ABI has {len(_ffi._SIGNATURES[name][1])}"
         seen += 1
     assert seen >= 15
+
+
+def test_readme_states_the_number_of_entry_points():
+    import os
+    import re
+    with open(os.path.join(os.path.dirname(__file__), "..", "README.md")) as f:
+        m = re.search(r"the C-ABI \((\d+) entry points\)", f.read())
+    assert m and int(m.group(1)) == len(_ffi.declared_symbols())
