@@ -44,3 +44,22 @@ def test_cited_lines_exist():
             if all(length[c] < last for c in cands):
                 bad.append(f"{src}: {m.group(0)} (the file has {max(length[c] for c in cands)} lines)")
     assert checked > 500 and not bad, "\n".join(bad[:20])
+
+
+def test_tests_named_in_the_documents_exist():
+    """every ``::test_name`` that COVERAGE.md / DESIGN.md / README.md quote is a test function of this suite (a name ending in ``_`` or
+    followed by an ellipsis is a prefix)"""
+    defined = set()
+    for p in glob.glob(os.path.join(ROOT, "tests", "*.py")):
+        with open(p) as f:
+            defined |= set(re.findall(r"^def (test_\w+)", f.read(), re.M))
+    missing, seen = [], 0
+    for doc in ("COVERAGE.md", "DESIGN.md", "README.md"):
+        with open(os.path.join(ROOT, doc)) as f:
+            text = f.read()
+        for m in re.finditer(r"::(test_\w+)(…|\.\.\.)?", text):
+            name, prefix = m.group(1), bool(m.group(2)) or m.group(1).endswith("_")
+            seen += 1
+            if not (name in defined or (prefix and any(d.startswith(name) for d in defined))):
+                missing.append(f"{doc}: {name}")
+    assert seen > 50 and not missing, missing
