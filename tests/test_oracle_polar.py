@@ -92,3 +92,25 @@ def test_polar_transform_matrix_and_dense_polar():
         generate_dense_polar(np.arange(3), 48, verbose=False)
     with pytest.raises(TypeError):
         generate_dense_polar(np.array([0.0, 1.0]), 8, verbose=False)
+
+
+def test_polar_utils_match_reference_execution():
+    """generate_polar_transform_mat / generate_dense_polar / generate_rm_code against the reference's own functions EXECUTED
+    (tests/golden/polar_utils_ref_golden.npz, tools/gen_polar_utils_golden.py): bit for bit"""
+    from sionna_amd.phy.fec.polar.utils import generate_polar_transform_mat, generate_dense_polar, generate_5g_ranking, generate_rm_code
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "polar_utils_ref_golden.npz"))
+    for n_lift in range(0, 9):
+        shape = tuple(int(v) for v in g[f"tm{n_lift}_shape"])
+        ref = np.unpackbits(g[f"tm{n_lift}"])[:shape[0] * shape[1]].reshape(shape)
+        got = generate_polar_transform_mat(n_lift)
+        assert got.shape == shape and np.array_equal(got, ref)
+    for i, (n, k) in enumerate(g["dense_cases"]):
+        n, k = int(n), int(k)
+        frozen, _ = generate_5g_ranking(k, n)
+        pcm, gm = generate_dense_polar(frozen, n, verbose=False)
+        assert np.array_equal(pcm, np.unpackbits(g[f"dp{i}_pcm"])[:(n - k) * n].reshape(n - k, n))
+        assert np.array_equal(gm, np.unpackbits(g[f"dp{i}_gm"])[:k * n].reshape(k, n))
+    for i, (r, m) in enumerate(g["rm_cases"]):
+        f, inf, n, k, d = generate_rm_code(int(r), int(m))
+        assert np.array_equal(f, g[f"rm{i}_frozen"]) and np.array_equal(inf, g[f"rm{i}_info"])
+        assert [n, k, d] == [int(v) for v in g[f"rm{i}_nkd"]]
