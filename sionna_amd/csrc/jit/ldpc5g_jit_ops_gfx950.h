@@ -27,6 +27,18 @@ JIT_DEV void lds_st2(U32 a, unsigned off, F32 x0, F32 x1) { *(jit_lds_f32x2*)(un
 typedef bool M64;                                                      // one bit per lane (an SGPR pair)
 JIT_DEV M64 u_testbit(U32 x, unsigned mask) { return (x & mask) != 0u; }
 JIT_DEV F32 f_sel(M64 m, F32 a, F32 b) { return m ? a : b; }
+// lane index, lane masks and per-lane integers of the any-lifting-size programs (jit/ldpc5g_jit_templates.h, JIT_GENERAL)
+JIT_DEV unsigned jit_lane() { return threadIdx.x & 63u; }
+#define JIT_IF(m) if (m) {                                             // lanes outside m execute nothing up to JIT_END
+#define JIT_END }
+JIT_DEV M64 u_lt(unsigned a, unsigned b) { return a < b; }
+JIT_DEV M64 u_ge(unsigned a, unsigned b) { return a >= b; }
+JIT_DEV M64 u_eq(unsigned a, unsigned b) { return a == b; }
+JIT_DEV M64 m_and(M64 a, M64 b) { return (bool)((int)a & (int)b); }
+JIT_DEV M64 m_not(M64 a) { return !a; }
+JIT_DEV M64 m_xor_c(M64 a, bool c) { return a != c; }
+JIT_DEV unsigned u_sel(M64 m, unsigned a, unsigned b) { return m ? a : b; }
+JIT_DEV unsigned u_div(unsigned a, unsigned d) { return a / d; }
 // f_eq / f_sel_m: a comparison whose lane mask is consumed several instructions later.  Written as volatile assembly so that the
 // order of the generated text is the order of the instructions: the compiler's scheduler moves a v_cmp next to the v_cndmask that
 // reads its mask (shortest scalar live range) and then has to pad the two wait states gfx950 wants between them with s_nop.
@@ -45,6 +57,10 @@ JIT_DEV U32 u_shl(U32 a, int n) { return a << n; }
 JIT_DEV U32 u_shr(U32 a, int n) { return a >> n; }
 JIT_DEV F32 g_ld(const float* row, U32 voff, unsigned coff) { return *(const float*)((const char*)row + (voff + coff)); }
 JIT_DEV void g_st(float* row, U32 voff, unsigned coff, F32 v) { *(float*)((char*)row + (voff + coff)) = v; }
+JIT_DEV F32 g_ld_m(const float* row, U32 voff, M64 m) { return m ? *(const float*)((const char*)row + voff) : 0.f; }
+JIT_DEV void g_st_m(float* row, U32 voff, M64 m, F32 v) {
+  if (m) *(float*)((char*)row + voff) = v;
+}
 JIT_DEV F32 jit_bcast(float x) { return x; }
 JIT_DEV F32 f_med3(F32 a, F32 b, F32 c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 JIT_DEV F32 f_abs(F32 a) { return __builtin_fabsf(a); }

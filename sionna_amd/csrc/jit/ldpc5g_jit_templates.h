@@ -59,6 +59,62 @@ JIT_DEV U32 jit_vn_addr_b1(U32 l4, unsigned k, unsigned base) {
   return u_shl(zc4 & 255u, 1) + u_shl(u_shr(zc4, 8), 2) + base;
 }
 
+// ---------------------------------------------------------------------------------------------- any even lifting size
+// JIT_GENERAL = 1: the interleaved layout for EVERY even Z and several codewords per workgroup.  A lane owns the lifted
+// copies (z, z + H), H = Z / 2, of ONE codeword; lane position p = 64 chunk + lane = g H + z runs over the JIT_G codewords
+// of the workgroup's group (JIT_P = G H lanes; the lanes beyond it in the last chunk are switched off around every item:
+// JIT_IF / JIT_END).  An edge block has JIT_P slots of 8 bytes, slot p = the pair (copy z, copy z + H) of codeword g's check
+// node.  A rotation by s maps the pair {z, z + H} onto the pair {z - s, z - s + H} mod Z - one slot, in this order or
+// swapped - so both phases move 8 bytes per lane and instruction as at Z = 128 (which is G = 1, H = 64).
+// Where a lane's channel values come from and its marginals go is a function of the lane (k, n, fillers and the pruned
+// tail are not multiples of 64): byte offsets computed once per launch, or a sentinel.
+#ifndef JIT_GENERAL
+#define JIT_GENERAL 0
+#endif
+#if JIT_GENERAL
+#define JIT_OFF_NONE 0xFFFFFFFFu                 // no element: channel LLR 0 (punctured / pruned / padding), nothing to store
+#define JIT_OFF_FILL 0xFFFFFFFEu                 // filler bit: logit -llr_max (decoding.py:1455-1463)
+// slot of the check-node pair a variable-node lane reads through an edge with shift s (sh = s mod H): bytes from the block start
+JIT_DEV U32 jit_vn_addr_g(U32 p, U32 z, unsigned sh, unsigned blk) {
+  const U32 t = z - sh;                                  // wraps for z < sh
+  const U32 zc = u_min(t, t + (unsigned)JIT_H);          // (z - sh) mod H
+  return u_shl((p - z) + zc, 3) + blk;
+}
+// lanes whose own node z sits in the HIGH half of that slot: (z - s) mod Z >= H
+JIT_DEV M64 jit_vn_swap_g(U32 z, unsigned sh, bool hi) { return m_xor_c(u_lt(z, sh), hi); }
+// rate recovery (decoding.py:1438-1475, encoding.py:238-244) for VN v of the group's codeword g: byte offset of its element
+// in the group's received rows, or a sentinel
+JIT_DEV U32 jit_in_off(U32 v, U32 g, M64 act) {
+  const M64 info = u_lt(v, (unsigned)JIT_K);
+  const U32 u = u_sel(info, v, v - (unsigned)JIT_FILLERS);
+  const M64 fill = m_and(m_not(info), u_lt(v, (unsigned)JIT_KLDPC));
+  const U32 t = u - (unsigned)(2 * JIT_Z);               // wraps for the punctured first columns
+  const M64 ok = u_lt(t, (unsigned)JIT_N);
+  U32 o = t;
+  if (JIT_M > 1u) {
+    const U32 tq = u_div(t, (unsigned)JIT_Q);
+    o = tq + (t - tq * (unsigned)JIT_Q) * (unsigned)JIT_M;
+  }
+  U32 r = u_shl(o + g * (unsigned)JIT_N, 2);
+  r = u_sel(ok, r, JIT_OFF_NONE);
+  r = u_sel(fill, JIT_OFF_FILL, r);
+  return u_sel(act, r, JIT_OFF_NONE);
+}
+// where VN v's marginal goes (decoding.py:1486-1531): information bits in place, or the codeword in the received order
+JIT_DEV U32 jit_out_off(U32 v, U32 g, M64 act, U32 in_off) {
+  if (!JIT_RIB) return u_sel(u_lt(in_off, JIT_OFF_FILL), in_off, JIT_OFF_NONE);
+  return u_sel(m_and(act, u_lt(v, (unsigned)JIT_K)), u_shl(v + g * (unsigned)JIT_NOUT, 2), JIT_OFF_NONE);
+}
+// received value of a lane (rem = codewords of this group that exist)
+JIT_DEV F32 jit_ld_raw(const float* rows, U32 off, U32 g, int rem, float llr_max) {
+  const F32 r = g_ld_m(rows, off, m_and(u_lt(off, JIT_OFF_FILL), u_lt(g, (unsigned)rem)));
+  return f_sel(u_eq(off, JIT_OFF_FILL), jit_bcast(-llr_max), r);
+}
+JIT_DEV void jit_st_out(float* orows, U32 off, U32 g, int rem, F32 x, float llr_max, int hard_out) {
+  g_st_m(orows, off, m_and(u_lt(off, JIT_OFF_FILL), u_lt(g, (unsigned)rem)), jit_outval(x, llr_max, hard_out));
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------- check node row
 // a0 = byte address of the lane's slot in the row's first block (chunk 0 of the item); NCH chunks of 64 lifted copies
 template <int D, int NCH>
@@ -86,12 +142,16 @@ JIT_DEV void jit_cn_store(U32 a0, unsigned off, const F32 (&c)[NCH]) {
 #ifndef JIT_CMP_AHEAD
 #define JIT_CMP_AHEAD 0
 #endif
-template <int D, int NCH, bool FUSE>
-JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, float offset, bool last,
-                           float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
+// xo[h] (FUSE): total of the fused degree-1 VN, for the generated code's output store after the last iteration.
+// PRUNE: lanes of pm[h] are check nodes the rate matching pruned (decoding.py:1344-1373) - they send 0 on every edge.
+template <int D, int NCH, bool FUSE, bool PRUNE = false>
+JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, float offset, F32 (&xo)[NCH],
+                           const M64 (&pm)[NCH]) {
   if (JIT_ABL & 1) {
 #pragma unroll
     for (int i = 0; i < D; ++i) jit_cn_store<NCH>(a0, (unsigned)i * JIT_Z4, v[i]);
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) xo[h] = 0.f;
     return;
   }
   F32 m1[NCH], m2[NCH];
@@ -157,12 +217,10 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
       const F32 mag = f_sel_eq(f_abs(v[i][h]), m1[h], a2[h], a1[h]);
 #endif
       c2v[h] = u_float(u_xor_and(f_bits(mag), f_bits(v[i][h]), 0x80000000u));   // mag ^ (v & msb)
+      if (PRUNE) c2v[h] = f_sel(pm[h], jit_bcast(0.f), c2v[h]);
       if (FUSE && i == D - 1) {
         const F32 x = c2v[h] + lf[h];                // (0 + c2v) + llr
-        const unsigned oc = h ? oc1 : oc0;
-        if (oc != JIT_NOOUT) {
-          if (last) g_st(orow, u_here(ovoff), oc, jit_outval(x, llr_max, hard_out));
-        }
+        xo[h] = x;
         c2v[h] = f_med3(x - c2v[h], -llr_max, llr_max);   // the slot now holds the next v2c
       }
     }
@@ -234,9 +292,9 @@ JIT_DEV void jit_phi_stage(U32 l4) {
 }
 // the check-node update of bp_math.h's cn_update_col (boxplus-phi branch).  NCH = 2: the two chunks of an edge share every
 // packed operation; NCH = 1 (rows of high degree, one chunk per item: registers): two EDGES share them.
-template <int D, int NCH, bool FUSE>
-JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, bool last, float* orow, U32 ovoff,
-                               unsigned oc0, unsigned oc1, int hard_out) {
+template <int D, int NCH, bool FUSE, bool PRUNE = false>
+JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, F32 (&xo)[NCH],
+                               const M64 (&pm)[NCH]) {
   U32 sg[D][NCH], node[NCH];
   F32 sum[NCH];
 #pragma unroll
@@ -286,12 +344,10 @@ JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], f
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
       c2v[h] = u_float(f_bits(f_min(q[i][h], llr_max)) ^ (sg[i][h] ^ node[h]));
+      if (PRUNE) c2v[h] = f_sel(pm[h], jit_bcast(0.f), c2v[h]);
       if (FUSE && i == D - 1) {
         const F32 x = c2v[h] + lf[h];
-        const unsigned oc = h ? oc1 : oc0;
-        if (oc != JIT_NOOUT) {
-          if (last) g_st(orow, u_here(ovoff), oc, jit_outval(x, llr_max, hard_out));
-        }
+        xo[h] = x;
         c2v[h] = f_med3(x - c2v[h], -llr_max, llr_max);
       }
     }
@@ -339,11 +395,11 @@ JIT_DEV void jit_vnb_init(const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[
   for (int i = 0; i < D; ++i) lds_st2(a[i], 0u, f_sel(sw[i], l[1], l[0]), f_sel(sw[i], l[0], l[1]));
 }
 template <int D>
-JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2], float llr_max, bool last,
-                            float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
+JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2], float llr_max, F32 (&xo)[2]) {
   if (JIT_ABL & 2) {
 #pragma unroll
     for (int i = 0; i < D; ++i) lds_st2(a[i], 0u, c[i][0], c[i][1]);
+    xo[0] = 0.f; xo[1] = 0.f;
     return;
   }
   F32 x0 = 0.f, x1 = 0.f;
@@ -363,21 +419,18 @@ JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D
     e1 = f_med3(e1, -llr_max, llr_max);
     lds_st2(a[i], 0u, f_sel(sw[i], e1, e0), f_sel(sw[i], e0, e1));     // node order -> slot order
   }
-  if (last) {
-    if (oc0 != JIT_NOOUT) g_st(orow, u_here(ovoff), oc0, jit_outval(x0, llr_max, hard_out));
-    if (oc1 != JIT_NOOUT) g_st(orow, u_here(ovoff), oc1, jit_outval(x1, llr_max, hard_out));
-  }
+  xo[0] = x0; xo[1] = x1;
 }
 
 template <int D, int NCH>
-JIT_DEV void jit_vn_update(F32 (&c)[D][NCH], const U32 (&a)[D][NCH], const F32 (&l)[NCH], float llr_max, bool last,
-                           float* orow, U32 ovoff, unsigned oc0, unsigned oc1, int hard_out) {
-  F32 x[NCH];
+JIT_DEV void jit_vn_update(F32 (&c)[D][NCH], const U32 (&a)[D][NCH], const F32 (&l)[NCH], float llr_max, F32 (&x)[NCH]) {
   if (JIT_ABL & 2) {
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
       for (int h = 0; h < NCH; ++h) lds_st(a[i][h], 0u, c[i][h]);
+#pragma unroll
+    for (int h = 0; h < NCH; ++h) x[h] = 0.f;
     return;
   }
   if (NCH == 2) {
@@ -403,13 +456,6 @@ JIT_DEV void jit_vn_update(F32 (&c)[D][NCH], const U32 (&a)[D][NCH], const F32 (
       x[h] = x[h] + l[h];
 #pragma unroll
       for (int i = 0; i < D; ++i) lds_st(a[i][h], 0u, f_med3(x[h] - c[i][h], -llr_max, llr_max));
-    }
-  }
-  if (last) {
-#pragma unroll
-    for (int h = 0; h < NCH; ++h) {
-      const unsigned oc = h ? oc1 : oc0;
-      if (oc != JIT_NOOUT) g_st(orow, u_here(ovoff), oc, jit_outval(x[h], llr_max, hard_out));
     }
   }
 }

@@ -452,6 +452,7 @@ extern "C" int samd_ldpc5g_create(int bg, int z, const int16_t* rows, const int1
   if (rc == SAMD_OK) rc = build_onchip_mss_tables(h, by_row);
   if (rc == SAMD_OK) rc = build_onchip_ly_tables(h, by_row);
   if (rc != SAMD_OK) { samd_ldpc5g_destroy(h); return rc; }
+  build_jit_plan_general(h, by_row);                       // graph data for the generated kernel of any other code
   if (h->jit_plan) h->jit_state = new_jit_state();
   *out = h;
   return SAMD_OK;
@@ -603,6 +604,10 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
   if (use_explicit_minsum(h)) {
     const int rc = launch_onchip_ms(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits,
                                     workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc != SAMD_ERR_UNSUPPORTED) return rc;
+  } else {
+    // the kernel generated for this code (ldpc5g_jit.cpp: any even lifting size whose messages fit LDS)
+    const int rc = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, stream);
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
   if (use_spill_minsum(h)) {

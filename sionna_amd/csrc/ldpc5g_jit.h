@@ -26,6 +26,20 @@ struct JitPlan {
   std::vector<std::vector<std::pair<int32_t, int32_t>>> col_edges;  // [nbu] (edge block byte offset, 4 shift), rows ascending
   std::vector<char> col_fused;                                      // [nbu]
   std::vector<std::vector<JitItem>> cn, vn;                         // [16 waves], in issue order
+  // general = 1: built for any code by build_jit_plan_general (graph data only: the generator makes its own schedule)
+  int general = 0;
+  int prune_row = -1, prune_z0 = 0;   // base row whose lifted copies z >= prune_z0 the rate matching pruned (decoding.py:1344-1373)
+};
+
+// how the any-lifting-size programs map lifted copies onto lanes (jit/ldpc5g_jit_templates.h, JIT_GENERAL)
+struct JitGeometry {
+  int G = 1;        // codewords per workgroup
+  int H = 0;        // Z / 2: a lane owns copies (z, z + H)
+  int P = 0;        // G H lanes in use
+  int chunks = 0;   // 64-lane chunks per edge block
+  int blk = 0;      // bytes per edge block (512 per chunk)
+  int nw = 16;      // waves per workgroup
+  int wgs = 1;      // workgroups per CU
 };
 
 // development knobs of the generator (SAMD_JIT_* options, read when the source is generated)
@@ -47,6 +61,8 @@ struct JitKnobs {
   int cn_pair_max = 32;   // rows of higher degree are two single-chunk items
   int waves = 0;          // own schedule (sched = 1): waves per workgroup, 0 = the generic kernel's 16
   int cmp_ahead = 0;      // min-sum check node: comparisons issued this many edges ahead of the selections that read them
+  int general = 0;        // 1: the any-lifting-size programs also for the codes of the Z = 128 class (A/B)
+  int group = 0, wgs = 0; // any-lifting-size programs: codewords per workgroup / workgroups per CU (0: chosen by the generator)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
 };
@@ -60,6 +76,11 @@ std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, int r
 // SAMD_OK, SAMD_ERR_UNSUPPORTED (caller runs the generic kernel) or an error
 int launch_onchip_jit(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                       float llr_max, float offset, int hard_out, int return_infobits, void* stream);
+// graph data of the generator for a code that build_onchip_bp_tables left without a plan (any even lifting size)
+void build_jit_plan_general(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
+// 0: no generated kernel; 1: the Z = 128 k class (whole chunks of one kind, constants); 2: any-lifting-size programs
+int jit_class(const samd_ldpc5g* h, const JitKnobs& kn, bool phi);
+bool jit_geometry(const samd_ldpc5g* h, const JitKnobs& kn, bool phi, JitGeometry* g);
 JitState* new_jit_state();
 void free_jit(samd_ldpc5g* h);
 

@@ -39,6 +39,10 @@ struct JitEmuCtx {
   int block, grid;
 };
 static thread_local JitEmuCtx jit_emu_ctx;
+// execution mask: JIT_IF(m) ... JIT_END switches the lanes outside m off for every memory access in between (their
+// register values are don't-cares, as on the GPU)
+static thread_local bool jit_emu_exec[64] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                                             1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
 
 #define JIT_DEV static inline
 #define JIT_INF std::numeric_limits<float>::infinity()
@@ -53,6 +57,8 @@ JIT_DEV U32 jit_lane4() {
 JIT_DEV F32 lds_ld(const U32& a, unsigned off) {
   F32 r;
   for (int i = 0; i < 64; ++i) {
+    r.v[i] = 0.f;
+    if (!jit_emu_exec[i]) continue;
     const size_t p = (size_t)a.v[i] + off;
     if (p + 4 > jit_emu_ctx.lds_bytes || (p & 3)) __builtin_trap();
     memcpy(&r.v[i], jit_emu_ctx.lds + p, 4);
@@ -61,6 +67,7 @@ JIT_DEV F32 lds_ld(const U32& a, unsigned off) {
 }
 JIT_DEV void lds_st(const U32& a, unsigned off, const F32& x) {
   for (int i = 0; i < 64; ++i) {
+    if (!jit_emu_exec[i]) continue;
     const size_t p = (size_t)a.v[i] + off;
     if (p + 4 > jit_emu_ctx.lds_bytes || (p & 3)) __builtin_trap();
     memcpy(jit_emu_ctx.lds + p, &x.v[i], 4);
@@ -68,6 +75,8 @@ JIT_DEV void lds_st(const U32& a, unsigned off, const F32& x) {
 }
 JIT_DEV void lds_ld2(const U32& a, unsigned off, F32& x0, F32& x1) {
   for (int i = 0; i < 64; ++i) {
+    x0.v[i] = x1.v[i] = 0.f;
+    if (!jit_emu_exec[i]) continue;
     const size_t p = (size_t)a.v[i] + off;
     if (p + 8 > jit_emu_ctx.lds_bytes || (p & 7)) __builtin_trap();
     memcpy(&x0.v[i], jit_emu_ctx.lds + p, 4);
@@ -76,6 +85,7 @@ JIT_DEV void lds_ld2(const U32& a, unsigned off, F32& x0, F32& x1) {
 }
 JIT_DEV void lds_st2(const U32& a, unsigned off, const F32& x0, const F32& x1) {
   for (int i = 0; i < 64; ++i) {
+    if (!jit_emu_exec[i]) continue;
     const size_t p = (size_t)a.v[i] + off;
     if (p + 8 > jit_emu_ctx.lds_bytes || (p & 7)) __builtin_trap();
     memcpy(jit_emu_ctx.lds + p, &x0.v[i], 4);
@@ -94,6 +104,53 @@ JIT_DEV F32 f_sel(const M64& m, const F32& a, const F32& b) {
   return r;
 }
 typedef M64 M64S;
+struct JitEmuExec {
+  bool saved[64];
+  explicit JitEmuExec(const M64& m) {
+    for (int i = 0; i < 64; ++i) { saved[i] = jit_emu_exec[i]; jit_emu_exec[i] = saved[i] && m.v[i]; }
+  }
+  ~JitEmuExec() { for (int i = 0; i < 64; ++i) jit_emu_exec[i] = saved[i]; }
+};
+#define JIT_IF(m) { JitEmuExec jit_emu_scope(m);
+#define JIT_END }
+JIT_DEV U32 jit_lane() {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = (unsigned)i;
+  return r;
+}
+#define JIT_EMU_CMP(name, op)                                \
+  JIT_DEV M64 name(const U32& a, const U32& b) {             \
+    M64 r;                                                   \
+    for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] op b.v[i];  \
+    return r;                                                \
+  }
+JIT_EMU_CMP(u_lt, <) JIT_EMU_CMP(u_ge, >=) JIT_EMU_CMP(u_eq, ==)
+#undef JIT_EMU_CMP
+JIT_DEV M64 m_and(const M64& a, const M64& b) {
+  M64 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] && b.v[i];
+  return r;
+}
+JIT_DEV M64 m_not(const M64& a) {
+  M64 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = !a.v[i];
+  return r;
+}
+JIT_DEV M64 m_xor_c(const M64& a, bool c) {
+  M64 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] != c;
+  return r;
+}
+JIT_DEV U32 u_sel(const M64& m, const U32& a, const U32& b) {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i];
+  return r;
+}
+JIT_DEV U32 u_div(const U32& a, unsigned d) {
+  U32 r;
+  for (int i = 0; i < 64; ++i) r.v[i] = a.v[i] / d;
+  return r;
+}
 JIT_DEV M64S f_eq_abs(const F32& a, const F32& b) {
   M64 r;
   for (int i = 0; i < 64; ++i) r.v[i] = fabsf(a.v[i]) == b.v[i];
@@ -117,6 +174,18 @@ JIT_DEV F32 g_ld(const float* row, const U32& voff, unsigned coff) {
 }
 JIT_DEV void g_st(float* row, const U32& voff, unsigned coff, const F32& x) {
   for (int i = 0; i < 64; ++i) memcpy((char*)row + (voff.v[i] + coff), &x.v[i], 4);
+}
+JIT_DEV F32 g_ld_m(const float* row, const U32& voff, const M64& m) {
+  F32 r;
+  for (int i = 0; i < 64; ++i) {
+    r.v[i] = 0.f;
+    if (m.v[i] && jit_emu_exec[i]) memcpy(&r.v[i], (const char*)row + voff.v[i], 4);
+  }
+  return r;
+}
+JIT_DEV void g_st_m(float* row, const U32& voff, const M64& m, const F32& x) {
+  for (int i = 0; i < 64; ++i)
+    if (m.v[i] && jit_emu_exec[i]) memcpy((char*)row + voff.v[i], &x.v[i], 4);
 }
 JIT_DEV F32 jit_bcast(float x) { return F32(x); }
 JIT_DEV float jit_emu_med3(float a, float b, float c) {      // v_med3_f32 on ordinary values: the middle operand itself
