@@ -53,15 +53,19 @@ def _reference(code, llr, cn, it, infobits, m):
 
 
 CODES = [(2816, 8448, "bg1", 6), (2816, 8448, "bg1", None), (2816, 5632, "bg1", 2), (5632, 8448, "bg1", None)]
+# codes of the any-lifting-size programs (round 6): BASELINE C4's code (BG2, Z = 80, six codewords per workgroup) and C1's (BG1,
+# Z = 48), fillers / k, n not multiples of 64 / pruned tail of the last base row / a partly filled last chunk / tiny Z
+GENERAL_CODES = [(768, 1536, None, 2), (1024, 2048, "bg1", None), (100, 200, None, None), (4000, 6000, None, 4),
+                 (3000, 4500, "bg1", 6), (20, 60, None, None), (2816, 8436, "bg1", 6), (1234, 2468, None, 4)]
 
 
-@pytest.mark.parametrize("k,n,bg,m", CODES)
+@pytest.mark.parametrize("k,n,bg,m", CODES + GENERAL_CODES)
 @pytest.mark.parametrize("grid", [None, "2"])
 def test_specialised_kernel_bit_exact_vs_oracle(phy, k, n, bg, m, grid):
     """small batches through the specialised kernel (SAMD_LDPC_JIT=2: any batch size); grid = 2 workgroups: each decodes
     several codewords in sequence (the codeword loop with its prefetch of the next codeword's channel values)"""
     code = LDPC5GCode(k, n, m, bg)
-    llr = _noisy_llr(code, 7, k + n)
+    llr = _noisy_llr(code, 7 if (k, n, bg, m) in CODES else 150, k + n)    # (several groups of codewords per workgroup)
     llr[0, :7] = 0
     llr[1] = np.round(llr[1])
     llr[2, ::5] *= 40

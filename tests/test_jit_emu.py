@@ -113,10 +113,45 @@ def _run_generated(tmp_path, code, h, k, n, m, full=True):
                                              f"{np.mean(out != ref):.3e} differ, nan {np.isnan(out).sum()}"
 
 
-def test_jit_class_boundaries():
-    """codes outside the class keep the generic kernel: odd lifting sizes, k / n / interleaver rows not multiples of 64"""
+# round 6: the any-lifting-size programs.  BASELINE C4's code (BG2, Z = 80: six codewords per workgroup, pruned tail, fillers,
+# interleaver), C1's (BG1, Z = 48), a partly filled last chunk with k / n not multiples of anything, tiny Z (35 codewords per
+# workgroup), a Z = 128 code outside the constant-offset class
+GENERAL = [(768, 1536, None, 2, ("minsum", "offset-minsum", "boxplus-phi")), (1024, 2048, "bg1", None, ("minsum", "boxplus-phi")),
+           (1234, 2468, None, 4, ("offset-minsum",)), (100, 200, None, None, ("minsum",)), (2816, 8436, "bg1", 6, ("minsum",))]
+
+
+@pytest.mark.parametrize("k,n,bg,m,rules", GENERAL)
+def test_generated_programs_any_lifting_size_match_oracle(tmp_path, k, n, bg, m, rules):
     from sionna_amd import _ffi
-    for k, n, bg, m in ((1024, 2048, "bg1", None), (2816, 8436, "bg1", 6), (2800, 8400, "bg1", None), (768, 1536, None, 2)):
-        h = jit_dump.host_only_handle(k, n, m, bg)
-        assert _ffi.lib().samd_ldpc5g_jit_supported(h) == 0, (k, n, bg, m)
+    h, enc, _ = jit_dump.host_only_handle(k, n, m, bg, return_obj=True)
+    code = LDPC5GCode(k, n, m, enc._bg)
+    assert _ffi.lib().samd_ldpc5g_jit_supported(h) == 1
+    for infobits in (1, 0):
+        for rule in rules:
+            if infobits == 0 and rule != rules[0]:
+                continue
+            lib, src = _build_emu(tmp_path, h, infobits, f"g{k}_{n}_{infobits}_{rule}", rule)
+            assert "#define JIT_GENERAL 1" in src
+            group = int(src.split("// JIT_GROUP ")[1].split()[0])
+            batch, grid = 2 * group + 1, 2                            # workgroup 0: two groups (the second one not full), workgroup 1: one
+            llr = _noisy_llr(code, batch, k + n)
+            llr[0, :7] = 0
+            llr[1] = np.round(llr[1])
+            llr[2, ::5] *= 40
+            for it, hard in ((1, 0), (4, 0), (3, 1)):
+                out = np.full((batch, k if infobits else n), np.nan, np.float32)
+                x = np.ascontiguousarray(llr)
+                lib.jit_emu_decode(x.ctypes.data, out.ctypes.data, batch, it, 20.0, 0.5 if rule == "offset-minsum" else 0.0, hard, grid)
+                ref = _reference(code, llr, rule, it, bool(infobits), m, hard)
+                assert np.array_equal(out, ref), f"{rule} it={it} infobits={infobits} hard={hard}: {np.mean(out != ref):.3e} differ"
+    _ffi.lib().samd_ldpc5g_destroy(h)
+
+
+def test_jit_class_boundaries():
+    """odd lifting sizes and codes whose messages exceed LDS keep the generic kernels; every other code has a generated one"""
+    from sionna_amd import _ffi
+    for k, n, bg, m, want in ((1024, 2048, "bg1", None, 1), (2816, 8436, "bg1", 6, 1), (768, 1536, None, 2, 1), (30, 90, None, None, 0),
+                              (8448, 25344, "bg1", None, 0)):
+        h, enc, _ = jit_dump.host_only_handle(k, n, m, bg, return_obj=True)
+        assert _ffi.lib().samd_ldpc5g_jit_supported(h) == want, (k, n, bg, m, enc._z)
         _ffi.lib().samd_ldpc5g_destroy(h)
