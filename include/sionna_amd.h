@@ -66,6 +66,8 @@ int samd_device_count(void);
 int samd_debug_set_option(const char* key, const char* value);
 /* incremented by every samd_debug_set_option (host-side caches of handles key on it) */
 int samd_debug_options_generation(void);
+/* value of a switch: its length (copied NUL-terminated into buf when cap suffices), -1 when it is not set */
+long samd_debug_get_option(const char* key, char* buf, size_t cap);
 
 /* ------------------------------------------------------------------------------------
  * Generic LDPC flooding BP decoder (any parity-check matrix).
@@ -199,6 +201,11 @@ int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
  *                  entry - what tests/jit_emu runs on the CPU); returns its length, copies at most cap - 1 bytes.
  *   ..._code:      the compiled code object (for llvm-objdump); returns its size, copies when cap suffices.
  *   ..._launches:  how many decode calls of this handle ran on a specialised kernel so far.
+ *   ..._cache_stats: process-wide counters of the code-object cache, what[0] = hipRTC compilations, what[1] = code objects
+ *                  read from disk (<cache dir>/<sha256(source | hipRTC version | target)>.co; cache dir = option
+ *                  SAMD_JIT_CACHE_DIR, else $XDG_CACHE_HOME/sionna_amd, else $HOME/.cache/sionna_amd; SAMD_JIT_CACHE=0: off).
+ * Round 6: the class is every even lifting size whose messages fit LDS (lanes own the copy pair (z, z + Z/2) of one of several
+ * codewords of a workgroup); the reference decodes every (k, n) through one path (encoding.py:248-282, decoding.py:1302-1403).
  * ..._source works on a handle created under the development option SAMD_HOST_ONLY=1 (no device needed; such a handle
  * builds tables and schedules only and refuses every launch). */
 int samd_ldpc5g_jit_supported(const samd_ldpc5g_t* h);
@@ -206,6 +213,7 @@ int samd_ldpc5g_jit_prepare(const samd_ldpc5g_t* h, int return_infobits, int cn_
 long samd_ldpc5g_jit_source(const samd_ldpc5g_t* h, int return_infobits, int cn_mode, int with_ops, char* buf, size_t cap);
 long samd_ldpc5g_jit_code(const samd_ldpc5g_t* h, int return_infobits, int cn_mode, char* buf, size_t cap);
 long samd_ldpc5g_jit_launches(const samd_ldpc5g_t* h);
+int samd_ldpc5g_jit_cache_stats(long* what);
 
 /* ------------------------------------------------------------------------------------
  * Mapping.  points: DEVICE complex64[2^m] (interleaved re,im), label of point i = binary

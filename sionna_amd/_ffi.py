@@ -87,6 +87,7 @@ _SIGNATURES = {
     "samd_ldpc5g_jit_source": (C.c_long, [_vp, _i32, _i32, _i32, _vp, _sz]),
     "samd_ldpc5g_jit_code": (C.c_long, [_vp, _i32, _i32, _vp, _sz]),
     "samd_ldpc5g_jit_launches": (C.c_long, [_vp]),
+    "samd_ldpc5g_jit_cache_stats": (_i32, [_vp]),
     "samd_ldpc5g_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, _sz, _vp]),
     "samd_qam_map_c64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "samd_qam_demap_f32": (_i32, [_vp, _vp, _i64, _vp, _i32, _i64, _i32, _i32, _vp, _vp]),
@@ -165,6 +166,7 @@ _SIGNATURES = {
                                         _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "samd_debug_set_option": (_i32, [C.c_char_p, C.c_char_p]),
     "samd_debug_options_generation": (_i32, []),
+    "samd_debug_get_option": (C.c_long, [C.c_char_p, C.c_char_p, _sz]),
 }
 
 
@@ -203,6 +205,16 @@ def set_option(key, value=None):
     check(lib().samd_debug_set_option(key.encode(), None if value is None else str(value).encode()), "samd_debug_set_option")
 
 
+def get_option(key):
+    """Current value of a development switch (str), or None when it is not set."""
+    n = lib().samd_debug_get_option(key.encode(), None, 0)
+    if n < 0:
+        return None
+    buf = C.create_string_buffer(n + 1)
+    lib().samd_debug_get_option(key.encode(), buf, n + 1)
+    return buf.value.decode()
+
+
 class option:
     """``with _ffi.option("SAMD_X", 1): ...`` - set a development switch for the duration of a block."""
 
@@ -210,11 +222,12 @@ class option:
         self.key, self.value = key, value
 
     def __enter__(self):
+        self.previous = get_option(self.key)                     # nested / pre-set switches come back as they were
         set_option(self.key, self.value)
         return self
 
     def __exit__(self, *exc):
-        set_option(self.key, None)
+        set_option(self.key, self.previous)
         return False
 
 

@@ -20,6 +20,9 @@ struct Registry {
   std::atomic<int> generation{0};
   Registry() {                                   // the ONE read of the process environment (library load)
     for (char** e = environ; e && *e; ++e) {
+      // (where the code-object cache of the generated kernels lives, ldpc5g_jit.cpp: kept under internal keys)
+      if (strncmp(*e, "XDG_CACHE_HOME=", 15) == 0) kv.emplace("SAMD__XDG_CACHE_HOME", std::string(*e + 15));
+      if (strncmp(*e, "HOME=", 5) == 0) kv.emplace("SAMD__HOME", std::string(*e + 5));
       if (strncmp(*e, "SAMD_", 5) != 0) continue;
       const char* eq = strchr(*e, '=');
       if (eq) kv.emplace(std::string(*e, eq - *e), std::string(eq + 1));
@@ -62,7 +65,7 @@ extern "C" int samd_device_count(void) {
 }
 
 extern "C" int samd_debug_set_option(const char* key, const char* value) {
-  if (!key || strncmp(key, "SAMD_", 5) != 0) {
+  if (!key || strncmp(key, "SAMD_", 5) != 0 || strncmp(key, "SAMD__", 6) == 0) {
     samd::set_error("samd_debug_set_option: key must start with SAMD_");
     return SAMD_ERR_INVALID;
   }
@@ -76,3 +79,11 @@ extern "C" int samd_debug_set_option(const char* key, const char* value) {
   return SAMD_OK;
 }
 extern "C" int samd_debug_options_generation(void) { return samd::opt_generation(); }
+// value of a development switch: its length (copied, NUL-terminated, when cap suffices) or -1 when it is not set
+extern "C" long samd_debug_get_option(const char* key, char* buf, size_t cap) {
+  if (!key || strncmp(key, "SAMD_", 5) != 0 || strncmp(key, "SAMD__", 6) == 0) return -1;
+  if (!samd::opt_set(key)) return -1;
+  const std::string v = samd::opt_str(key);
+  if (buf && cap > v.size()) memcpy(buf, v.c_str(), v.size() + 1);
+  return (long)v.size();
+}

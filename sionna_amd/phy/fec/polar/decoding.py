@@ -130,7 +130,8 @@ class _PolarListDecoderBase(Block):
     llr_max = property(lambda self: self._llr_max)
 
     def _decode_2d(self, llr, want_status=False):
-        if self._dev is None:
+        if self._dev is None or self._dev_gen != _ffi.options_generation():   # (a development switch changed: rebuild)
+            self._dev_gen = _ffi.options_generation()
             i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
             # the engine that will run says which stages it keeps in registers: it decodes a whole node one stage above
             # them (f / g from memory around two register-stage subtrees) without further schedule dispatch
@@ -315,7 +316,8 @@ class PolarBPDecoder(Block):
             raise ValueError("Invalid input shape")
         if self._num_iter < 1:
             raise ValueError("num_iter must be a positive value.")
-        if self._dev is None:
+        if self._dev is None or self._dev_gen != _ffi.options_generation():   # (a development switch changed: rebuild)
+            self._dev_gen = _ffi.options_generation()
             prior = np.zeros(self._n, np.float64 if dbl else np.float32)
             prior[self._frozen_pos] = np.float32(self._llr_max)        # decoding.py:1632-1636 (19.3 as a float32, cast)
             self._dev = (_ffi.to_device(prior, self.rdtype),
@@ -422,7 +424,8 @@ class Polar5GDecoder(Block):
             raise ValueError("Invalid input shape.")
         lead = tuple(llr.shape[:-1])
         x = llr.reshape(-1, self._n_target)
-        if self._dev is None:
+        if self._dev is None or self._dev_gen != _ffi.options_generation():   # (a development switch changed: rebuild)
+            self._dev_gen = _ffi.options_generation()
             dev = x.device
             t = lambda a: torch.from_numpy(np.asarray(a, np.int64)).to(dev)
             self._dev = (t(np.clip(self._src_a, 0, None)), torch.from_numpy(self._src_a >= 0).to(dev),

@@ -33,7 +33,6 @@ def _check_binary_flag(binary):
 
 
 class Scrambler(Block):
-    _io_rdtype = None          # set by a Descrambler of another precision around its call
     """``Scrambler(seed=None, keep_batch_constant=False, binary=True, sequence=None,
     keep_state=True)(x, seed=None, binary=None)``."""
 
@@ -75,8 +74,13 @@ class Scrambler(Block):
         return seq, n
 
     def call(self, x, seed=None, binary=None):
+        return self._run(x, seed, binary, self.rdtype)
+
+    def _run(self, x, seed, binary, rdtype):
+        """the scrambling itself in the I/O precision `rdtype` - a Descrambler of another precision hands in its own
+        (scrambling.py:573-579 casts to it) instead of changing anything on this block, which an encoder may share"""
         binary = self._binary if binary is None else _check_binary_flag(binary)
-        x = _ffi.to_device(x, self._io_rdtype or self.rdtype)
+        x = _ffi.to_device(x, rdtype)
         if seed is not None:
             s = int(seed)
         elif self._keep_state:
@@ -91,9 +95,9 @@ class Scrambler(Block):
                 raise ValueError("sequence has more dimensions than the input")
             seq = np.broadcast_to(seq, tuple(x.shape)[x.dim() - seq.ndim:]) if seq.ndim else seq.reshape(1)
             seq_d = _ffi.to_device(np.ascontiguousarray(seq, np.float32).reshape(-1), torch.float32)
-            return _apply(x, seq_d, seq_d.numel(), binary, self._io_rdtype or self.rdtype)
+            return _apply(x, seq_d, seq_d.numel(), binary, rdtype)
         seq_d, period = self._random_sequence(x.shape, s)
-        return _apply(x, seq_d, period, binary, self._io_rdtype or self.rdtype)
+        return _apply(x, seq_d, period, binary, rdtype)
 
 
 class TB5GScrambler(Block):
@@ -139,7 +143,6 @@ class TB5GScrambler(Block):
         self._sequence = None
 
     keep_state = property(lambda self: True)
-    _io_rdtype = None
 
     def _build_sequence(self, n):
         seq = torch.empty((len(self._c_init), n), dtype=torch.float32, device=_ffi.device())
@@ -148,14 +151,17 @@ class TB5GScrambler(Block):
         self._sequence, self._seq_len = seq, n
 
     def call(self, x, /, *, binary=None):
+        return self._run(x, None, binary, self.rdtype)
+
+    def _run(self, x, seed, binary, rdtype):               # (see Scrambler._run; the sequence of 38.211 has no seed)
         binary = self._binary if binary is None else _check_binary_flag(binary)
-        x = _ffi.to_device(x, self._io_rdtype or self.rdtype)
+        x = _ffi.to_device(x, rdtype)
         if self._multi_stream:
             assert x.dim() >= 2 and x.shape[-2] == len(self._c_init), \
                 "Dimension of axis=-2 must be equal to len(n_rnti)."
         if self._seq_len != x.shape[-1]:
             self._build_sequence(int(x.shape[-1]))
-        return _apply(x, self._sequence, self._sequence.numel(), binary, self._io_rdtype or self.rdtype)
+        return _apply(x, self._sequence, self._sequence.numel(), binary, rdtype)
 
 
 class Descrambler(Block):
@@ -175,11 +181,7 @@ class Descrambler(Block):
 
     def call(self, x, /, *, seed=None):
         scr = self._scrambler
-        scr._io_rdtype = self.rdtype               # the descrambler's own precision (scrambling.py:573-579 casts to it)
-        try:
-            if isinstance(scr, Scrambler):
-                s = seed if seed is not None else scr.seed
-                return scr(x, seed=s, binary=self._binary)
-            return scr(x, binary=self._binary)
-        finally:
-            scr._io_rdtype = None
+        s = (seed if seed is not None else scr.seed) if isinstance(scr, Scrambler) else None
+        if isinstance(s, torch.Tensor):
+            s = int(s)
+        return scr._run(x, s, self._binary, self.rdtype)   # the descrambler's own precision (scrambling.py:573-579 casts to it)

@@ -504,6 +504,20 @@ def test_5g_random_codes_all_engines(phy, k, n):
         assert np.array_equal(_np(dec2(llr)), ref)
     dec._onchip_ok = False
     assert np.array_equal(_np(dec(llr)), ref)
+    # the kernel generated for the code (round 6: any even lifting size whose messages fit LDS), small batch forced onto it
+    from sionna_amd import _ffi
+    with _ffi_option("SAMD_LDPC_JIT", "2"):
+        enc3 = phy.fec.ldpc.LDPC5GEncoder(k, n)
+        dec3 = phy.fec.ldpc.LDPC5GDecoder(enc3, cn_update="minsum", hard_out=False, num_iter=6)
+        h3 = enc3._handle(dec3._nb_pruned_nodes)
+        if _ffi.lib().samd_ldpc5g_jit_supported(h3):
+            assert np.array_equal(_np(dec3(llr)), ref)
+            assert _ffi.lib().samd_ldpc5g_jit_launches(h3) > 0, "generated kernel did not run"
+            dec4 = phy.fec.ldpc.LDPC5GDecoder(enc3, cn_update="offset-minsum", hard_out=True, return_infobits=False, num_iter=3)
+            od4 = obp.LDPC5GDecoder(code, cn_update="offset-minsum", hard_out=True, return_infobits=False, num_iter=3)
+            assert np.array_equal(_np(dec4(llr)), od4.decode5g(llr))
+        else:
+            assert enc3.z % 2 == 1 or enc3.z > 192, (k, n, enc3.z)     # odd lifting size, or messages beyond LDS
     for cn, infobits in (("boxplus-phi", True), ("boxplus", False)):
         decp = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, hard_out=False, return_infobits=infobits, num_iter=4)
         a = _np(decp(llr))
@@ -891,9 +905,10 @@ def test_5g_chain_matches_reference_execution(phy, tag):
             # (tanh rule on the device library's tanhf / atanhf: measured 95.9 ... 98.0 % on the GPU)
             assert np.mean(np.isclose(got, ref, rtol=1e-5, atol=1e-4)) >= 0.93, rule
             assert np.max(np.abs(got - ref)) <= 2.5 and np.array_equal((got > 0)[np.abs(ref) > 1e-2], (ref > 0)[np.abs(ref) > 1e-2]), rule
-    if tag == "c2":
-        # BASELINE config C2 itself (round-4 verdict, missing #2): the kernel GENERATED for this code (csrc/ldpc5g_jit.cpp;
-        # SAMD_LDPC_JIT=2 = also for this batch of 4) against the executed reference, both output forms, both rules
+    if True:
+        # BASELINE's own codes (C1, C2, C4) and the other fixtures: the kernel GENERATED for the code (csrc/ldpc5g_jit.cpp;
+        # SAMD_LDPC_JIT=2 = also for this batch of 4; round 6: every even lifting size) against the executed reference, both
+        # output forms, both rules
         from sionna_amd import _ffi
         with _ffi_option("SAMD_LDPC_JIT", "2"):
             enc_j = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=(m or None), bg=f"bg{bg}")
