@@ -771,6 +771,44 @@ def main():
     out["end_to_end"] = {"codewords_per_s_per_gpu": round(B / t_e2e, 1), "ms_per_batch": round(t_e2e * 1e3, 2),
                          "stages": "BinarySource, LDPC5GEncoder, Mapper, AWGN, Demapper(app), LDPC5GDecoder, count_errors"}
 
+    if not args.no_extra:
+        # The Monte-Carlo driver itself (north_star's use case; reference utils/misc.py:694-784): the same chain as mc_fun of
+        # sim_ber over three Eb/N0 points.  With num_target_block_errors the driver must read the counters after EVERY iteration
+        # (one device synchronisation - and, for N > 1, one all-reduce of 4 x int64 - per iteration), exactly where the reference
+        # evaluates its stopping rules; without a target the counters stay on the device until the point ends.
+        def mc_fun(batch_size, ebno_db):
+            ub = src([batch_size, k])
+            no_p = phy.utils.ebnodb2no(float(ebno_db), m, k / n)
+            return ub, dec(demap(awgn(mapper(enc(ub)), no_p), no_p))
+        n_mc, points = 4, [0.0, 0.5, 1.0]              # block error rate 1 at these points: no early stop, every iteration runs
+        sims = {}
+        flushes = {"n": 0}
+        orig_cpu = torch.Tensor.cpu
+        def counting_cpu(self_, *a, **kw):              # device -> host reads inside sim_ber = its synchronisations
+            flushes["n"] += 1
+            return orig_cpu(self_, *a, **kw)
+        for tag, kw in (("target_block_errors", {"num_target_block_errors": 10 ** 12}), ("no_target", {})):
+            phy.utils.sim_ber(mc_fun, points[:1], B, 1, verbose=False, distribute=("all" if world > 1 else None), **kw)   # warm
+            barrier(world, torch.cuda.synchronize)
+            flushes["n"] = 0
+            torch.Tensor.cpu = counting_cpu
+            try:
+                t0 = time.perf_counter()
+                ber_s, bler_s = phy.utils.sim_ber(mc_fun, points, B, n_mc * world, early_stop=True, verbose=False,
+                                                  distribute=("all" if world > 1 else None), **kw)
+                barrier(world, torch.cuda.synchronize)
+                t_s = time.perf_counter() - t0
+            finally:
+                torch.Tensor.cpu = orig_cpu
+            sims[tag] = {"codewords_per_s_per_gpu": round(len(points) * n_mc * B / t_s, 1),
+                         "ms_per_iteration": round(t_s / (len(points) * n_mc) * 1e3, 2),
+                         "host_syncs_per_iteration": round(flushes["n"] / (len(points) * n_mc), 3),
+                         "fraction_of_raw_chain": round((len(points) * n_mc * B / t_s) / (B / t_e2e), 4),
+                         "bler": [float(v) for v in np.asarray(bler_s)]}
+        out["sim_ber"] = {"what": f"sim_ber(mc_fun = the end_to_end chain, ebno_dbs = {points}, batch_size = {B}, max_mc_iter = {n_mc} per rank, "
+                                  "early_stop = True) - codewords per second THROUGH the Monte-Carlo driver, beside end_to_end (the raw chain)",
+                          **sims}
+
     dec2 = None
     if args.also and args.also != "none" and args.also != args.cn_update:
         dec2 = make_dec(args.also)
