@@ -154,6 +154,22 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
     for (int h = 0; h < NCH; ++h) xo[h] = 0.f;
     return;
   }
+  if ((JIT_ABL & 8) && JIT_LAYOUT_B && NCH == 2) {
+    // estimate of "one total per variable node" (DESIGN section 7 item 1): the check node also reads a second 8-byte slot
+    // per edge and forms clip(total - own c2v) itself (two selections, one packed subtraction, two clips); the variable node
+    // stores one pair per node instead of one per edge.  Results are WRONG; the traffic and instruction counts are the plan's.
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      F32 x0, x1;
+      lds_ld2(u_here(a0) ^ 8u, (unsigned)i * JIT_Z4, x0, x1);
+      const M64 sw = u_testbit(f_bits(x0), 0x00800000u);
+      const F32 y0 = f_sel(sw, x1, x0), y1 = f_sel(sw, x0, x1);
+      F32 e0, e1;
+      f_pk_sub(e0, e1, y0, y1, v[i][0], v[i][NCH - 1]);
+      v[i][0] = f_med3(e0, -llr_max, llr_max);
+      v[i][NCH - 1] = f_med3(e1, -llr_max, llr_max);
+    }
+  }
   F32 m1[NCH], m2[NCH];
   U32 sx[NCH];
 #pragma unroll
@@ -411,6 +427,11 @@ JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D
     f_pk_add(x0, x1, v0[i], v1[i]);
   }
   f_pk_add(x0, x1, l[0], l[1]);
+  if (JIT_ABL & 8) {
+    lds_st2(a[0], 0u, x0, x1);
+    xo[0] = x0; xo[1] = x1;
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < D; ++i) {
     F32 e0, e1;
