@@ -358,6 +358,17 @@ int samd_cir_to_ofdm_c64(const float* a, const float* tau, const float* frequenc
                          int num_time_steps, int num_freqs, int normalize, float* h_freq,
                          void* stream);
 
+/* OFDMChannel.call  channel/ofdm_channel.py:109-115 = cir_to_ofdm_channel (channel/utils.py:180-253) + ApplyOFDMChannel
+ * (channel/apply_ofdm_channel.py:70-80) + AWGN (channel/awgn.py:63-78) in ONE launch, for the case that h_freq itself is not
+ * read (return_channel = False, or the returned tensor never used): a [B,rx,ra,1,ta,P,T], tau [B,rx,1,P], x [B,1,ta,T,F]
+ * -> y [B,rx,ra,T,F]; no: DEVICE float[1] or NULL (no noise); (seed, call): the stream samd_awgn_c64 would be given.  The same
+ * bits as the three separate entries; the link's frequency response never reaches memory.  SAMD_ERR_UNSUPPORTED (several
+ * transmitters, shapes outside the staged-register kernel): run the separate entries. */
+int samd_ofdm_channel_fused_c64(const float* a, const float* tau, const float* frequencies, const float* x, const float* no,
+                                uint64_t seed, uint64_t call, int batch, int num_rx, int num_rx_ant, int num_tx,
+                                int num_tx_ant, int num_paths, int num_time_steps, int num_freqs, int normalize, float* y,
+                                void* stream);
+
 /* ApplyOFDMChannel.call (noise-free part)  channel/apply_ofdm_channel.py:70-80.
  * x [B, num_tx*num_tx_ant, num_re], h_freq [B, num_rx*num_rx_ant, num_tx*num_tx_ant, num_re]
  * -> y [B, num_rx*num_rx_ant, num_re]. */

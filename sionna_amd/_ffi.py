@@ -113,6 +113,7 @@ _SIGNATURES = {
                                 _vp, _f64, _f64, _f64, _f64, _vp, _sz, _vp, _vp]),
     "samd_cir_to_ofdm_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_apply_ofdm_channel_c64": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "samd_ofdm_channel_fused_c64": (_i32, [_vp, _vp, _vp, _vp, _vp, _u64, _u64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_ls_gather_scale_c64": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "samd_gf2_encode_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "samd_scramble_f32": (_i32, [_vp, _vp, _i64, _i64, _i32, _vp, _vp]),

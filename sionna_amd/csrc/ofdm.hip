@@ -360,6 +360,16 @@ __global__ __launch_bounds__(512) void cir_to_ofdm_reg_kernel(const float2* __re
   }
 }
 
+// Box-Muller on two uniforms in (0,1): channel.hip's box_muller, operation for operation (the fused channel kernel adds the noise
+// awgn_kernel would add)
+__device__ __forceinline__ float2 c2o_box_muller(uint32_t a, uint32_t b) {
+  const float r = sqrtf(-2.0f * logf(u01(a)));
+  const float t = 6.283185307179586f * u01(b);
+  float sn, cs;
+  sincosf(t, &sn, &cs);
+  return make_float2(r * cs, r * sn);
+}
+
 // The same kernel with the paths walked in passes of PW: only PW phases (and the PW taps of a row, and with PF those of the
 // next row, requested a row ahead) are live beside the RPT staged results, so the kernel needs 80-94 instead of 164 vector
 // registers and three to four workgroups instead of two (at 384 threads) share a CU.  History on the C4 shapes (8192 links
@@ -376,11 +386,24 @@ __global__ __launch_bounds__(512) void cir_to_ofdm_reg_kernel(const float2* __re
 // the staging loops decompose indices with multiply-high, the energy is reduced with wave shuffles.  Sum over the paths in
 // ascending order, pass by pass (the same chain for every PW: the variants are bit-identical to each other); held to 1e-4 of
 // the float64 oracle like the kernels above.
-template <int MAXP, int RPT, int PW, bool PF>
-__global__ __launch_bounds__(512) void cir_to_ofdm_pass_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
-                                                               const float* __restrict__ freqs, int RX, int RA, int TX,
-                                                               int TA, int P, int T, int F, int normalize,
-                                                               float2* __restrict__ out) {
+//
+// FUSED (round 6; OFDMChannel.call channel/ofdm_channel.py:109-115 when nobody reads h_freq): the link's frequency response
+// never leaves the workgroup - ApplyOFDMChannel (apply_ofdm_channel.py:70-80) and the AWGN of channel/awgn.py:63-78 happen on
+// the staged registers: y[b, rx, ra, t, f] = sum_ta h x[b, 0, ta, t, f] + sqrt(no) w, one transmitter (TX = 1; the sum over
+// transmit antennas runs inside the workgroup through the LDS of the dead phase / tap tables, ascending ta like
+// apply_ofdm_channel_kernel), the noise of element i from Philox block i / 2 like awgn_kernel: the same bits as the three
+// separate kernels, without the 558 MB of h_freq written and read back at config C4.
+struct C2oFuse {
+  const float2* x;       // [B, 1, TA, T, F] transmitted grid
+  const float* no;       // one noise variance, or null: no noise
+  uint64_t seed, call;   // the AWGN block's Philox stream
+  float2* y;             // [B, RX, RA, T, F]
+};
+template <int MAXP, int RPT, int PW, bool PF, bool FUSED>
+__device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__ a, const float* __restrict__ tau,
+                                                      const float* __restrict__ freqs, int RX, int RA, int TX,
+                                                      int TA, int P, int T, int F, int normalize,
+                                                      float2* __restrict__ out, C2oFuse fu) {
   static_assert(MAXP % PW == 0, "pass width must divide the padded path count");
   extern __shared__ __attribute__((aligned(16))) float2 tab[];   // [MAXP][F] phases, taps [RPT * G][MAXP] (zero rows behind the link), red[8]
   const int nt = blockDim.x, tid = threadIdx.x;
@@ -519,6 +542,58 @@ __global__ __launch_bounds__(512) void cir_to_ofdm_pass_kernel(const float2* __r
     const float c = sqrtf(e / (float)(rows * F));
     inv = c > 0.f ? 1.f / c : 0.f;                               // divide_no_nan
   }
+  if constexpr (FUSED) {
+    // products h x of the rows with ta >= 1 into the LDS of the (dead) tables: [(ra (TA - 1) + ta - 1) T + t][f]
+    float2* stage = tab;
+    const float2* xb = fu.x + (size_t)b * TA * T * F;
+    __syncthreads();                                              // every wave is through its FMA loop
+    {
+      int t = g % T, lk = g / T;
+      int ta = lk % TA, ra = lk / TA;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        if (act && ra < RA && ta >= 1) {
+          const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);          // the value cir_to_ofdm stores
+          stage[(unsigned)(((ra * (TA - 1) + ta - 1) * T + t) * F + f)] = cmul(hv, xb[(unsigned)((ta * T + t) * F + f)]);
+        }
+        t += G;
+        while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
+      }
+    }
+    __syncthreads();
+    const float sh = sqrtf(1.0f / 2.0f);
+    const float sn = fu.no ? sqrtf(fu.no[0]) : 0.f;
+    float2* yb = fu.y + ((size_t)(b * RX + rx) * RA) * (size_t)T * F;
+    const uint64_t i0 = ((uint64_t)(b * RX + rx) * RA) * (uint64_t)T * F;
+    {
+      int t = g % T, lk = g / T;
+      int ta = lk % TA, ra = lk / TA;
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        if (act && ra < RA && ta == 0) {
+          const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);
+          float2 v = cmul(hv, xb[(unsigned)(t * F + f)]);
+          float2 s = make_float2(0.f, 0.f);                       // apply_ofdm_channel_kernel: acc = 0; acc += v_k, k ascending
+          s.x += v.x; s.y += v.y;
+          for (int k = 1; k < TA; ++k) {
+            v = stage[(unsigned)(((ra * (TA - 1) + k - 1) * T + t) * F + f)];
+            s.x += v.x; s.y += v.y;
+          }
+          const unsigned rel = (unsigned)((ra * T + t) * F + f);
+          if (fu.no) {                                            // awgn_kernel: element i takes half (i & 1) of Philox block i / 2
+            const uint64_t i = i0 + rel;
+            const uint4 rr = philox_block(fu.seed, fu.call, i >> 1);
+            const float2 w = (i & 1) ? c2o_box_muller(rr.z, rr.w) : c2o_box_muller(rr.x, rr.y);
+            s = make_float2(s.x + (w.x * sh) * sn, s.y + (w.y * sh) * sn);
+          }
+          yb[rel] = s;
+        }
+        t += G;
+        while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
+      }
+    }
+    return;
+  }
   float2* ob = out + ((size_t)(b * RX + rx) * RA) * TX * TA * (size_t)T * F;
   {
     int t = g % T, lk = g / T;
@@ -531,6 +606,22 @@ __global__ __launch_bounds__(512) void cir_to_ofdm_pass_kernel(const float2* __r
       while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
     }
   }
+}
+
+template <int MAXP, int RPT, int PW, bool PF>
+__global__ __launch_bounds__(512) void cir_to_ofdm_pass_kernel(const float2* __restrict__ a, const float* __restrict__ tau,
+                                                               const float* __restrict__ freqs, int RX, int RA, int TX,
+                                                               int TA, int P, int T, int F, int normalize,
+                                                               float2* __restrict__ out, C2oFuse fu) {
+  cir_to_ofdm_pass_body<MAXP, RPT, PW, PF, false>(a, tau, freqs, RX, RA, TX, TA, P, T, F, normalize, out, fu);
+}
+// the fused form keeps the occupancy of the plain one (5 waves per SIMD = three workgroups of 384 threads per CU - two were
+// measured 30 % slower, profiles/r05w): the Philox / Box-Muller epilogue may spill around the 48 staged result registers
+template <int MAXP, int RPT, int PW, bool PF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(5, 5)))
+void cir_to_ofdm_fused_kernel(const float2* __restrict__ a, const float* __restrict__ tau, const float* __restrict__ freqs, int RX,
+                              int RA, int TX, int TA, int P, int T, int F, int normalize, float2* __restrict__ out, C2oFuse fu) {
+  cir_to_ofdm_pass_body<MAXP, RPT, PW, PF, true>(a, tau, freqs, RX, RA, TX, TA, P, T, F, normalize, out, fu);
 }
 
 // y[b,rx,ra,t,f] = sum_{tx,ta} h[b,rx,ra,tx,ta,t,f] * x[b,tx,ta,t,f]
@@ -663,6 +754,48 @@ extern "C" int samd_spatial_corr_c128(const double* a, const double* mat, int ba
   return launch_status();
 }
 
+// OFDMChannel.call (channel/ofdm_channel.py:109-115) = cir_to_ofdm_channel + ApplyOFDMChannel (+ AWGN) in ONE launch for the case
+// that h_freq itself is not needed: a [B,rx,ra,1,ta,P,T], tau [B,rx,1,P], x [B,1,ta,T,F] -> y [B,rx,ra,T,F].  no: DEVICE float[1]
+// or null (no noise); (seed, call): the Philox stream samd_awgn_c64 would be given.  Bit-identical to the three separate entries.
+// SAMD_ERR_UNSUPPORTED (several transmitters, shapes outside the staged-register kernel): the caller runs the separate entries.
+extern "C" int samd_ofdm_channel_fused_c64(const float* a, const float* tau, const float* frequencies, const float* x, const float* no,
+                                           uint64_t seed, uint64_t call, int batch, int num_rx, int num_rx_ant, int num_tx,
+                                           int num_tx_ant, int num_paths, int num_time_steps, int num_freqs, int normalize, float* y,
+                                           void* stream) {
+  SAMD_REQUIRE(a && tau && frequencies && x && y && batch > 0, "bad argument");
+  SAMD_REQUIRE(num_paths >= 1 && num_freqs >= 1 && num_time_steps >= 1, "bad size");
+  static samd::CachedOpt opt_off("SAMD_NO_FUSED_CHANNEL");
+  if (num_tx != 1 || opt_off.is_set()) { set_error("fused OFDM channel: one transmitter only"); return SAMD_ERR_UNSUPPORTED; }
+  const int rows = num_rx_ant * num_tx_ant * num_time_steps;
+  int best_nt = 0, best_rpt = 0;
+  double best_u = 0.0;
+  for (int nt = 256; nt <= 512 && num_freqs <= 512; nt += 64) {
+    if (num_freqs > nt) continue;
+    const int gq = nt / num_freqs, rpt = (rows + gq - 1) / gq;
+    const double u = (double)(gq * num_freqs) / nt;
+    if (rpt <= 40 && u > best_u + 1e-9) { best_u = u; best_nt = nt; best_rpt = rpt; }
+  }
+  const int mp = num_paths <= 8 ? 8 : num_paths <= 16 ? 16 : num_paths <= 24 ? 24 : num_paths <= 32 ? 32 : 0;
+  if (!best_nt || !mp) { set_error("fused OFDM channel: shape outside the staged-register kernel"); return SAMD_ERR_UNSUPPORTED; }
+  const size_t lds_p = ((size_t)mp * num_freqs + (size_t)(((best_rpt + 7) / 8) * 8) * (best_nt / num_freqs) * mp) * sizeof(float2) + 64;
+  const size_t stage_b = (size_t)num_rx_ant * (num_tx_ant - 1) * num_time_steps * num_freqs * sizeof(float2);
+  if (lds_p > 64 * 1024 || stage_b + 64 > lds_p || (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant >= 8192) {
+    set_error("fused OFDM channel: shape outside the staged-register kernel");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  typedef void (*kern_t)(const float2*, const float*, const float*, int, int, int, int, int, int, int, int, float2*, C2oFuse);
+#define SAMD_C2F_K(MP) {cir_to_ofdm_fused_kernel<MP, 8, 4, true>, cir_to_ofdm_fused_kernel<MP, 16, 4, true>, \
+                        cir_to_ofdm_fused_kernel<MP, 24, 4, true>, cir_to_ofdm_fused_kernel<MP, 32, 4, true>, \
+                        cir_to_ofdm_fused_kernel<MP, 40, 4, true>}
+  static const kern_t fk[4][5] = {SAMD_C2F_K(8), SAMD_C2F_K(16), SAMD_C2F_K(24), SAMD_C2F_K(32)};
+#undef SAMD_C2F_K
+  const C2oFuse fu{(const float2*)x, no, seed, call, (float2*)y};
+  hipLaunchKernelGGL(fk[mp / 8 - 1][(best_rpt + 7) / 8 - 1], dim3(batch * num_rx), dim3(best_nt), lds_p, (hipStream_t)stream,
+                     (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs,
+                     normalize, (float2*)nullptr, fu);
+  return launch_status();
+}
+
 extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const float* frequencies, int batch, int num_rx,
                                     int num_rx_ant, int num_tx, int num_tx_ant, int num_paths, int num_time_steps,
                                     int num_freqs, int normalize, float* h_freq, void* stream) {
@@ -698,15 +831,20 @@ extern "C" int samd_cir_to_ofdm_c64(const float* a, const float* tau, const floa
       const long pw = opt_pass.get(4);
 #define SAMD_C2P_K(MP, PW, PF) {cir_to_ofdm_pass_kernel<MP, 8, PW, PF>, cir_to_ofdm_pass_kernel<MP, 16, PW, PF>, cir_to_ofdm_pass_kernel<MP, 24, PW, PF>, \
                                 cir_to_ofdm_pass_kernel<MP, 32, PW, PF>, cir_to_ofdm_pass_kernel<MP, 40, PW, PF>}
-      static const kern_t pk4[4][5] = {SAMD_C2P_K(8, 4, true), SAMD_C2P_K(16, 4, true), SAMD_C2P_K(24, 4, true), SAMD_C2P_K(32, 4, true)};
-      static const kern_t pk2[4][5] = {SAMD_C2P_K(8, 2, true), SAMD_C2P_K(16, 2, true), SAMD_C2P_K(24, 2, true), SAMD_C2P_K(32, 2, true)};
-      static const kern_t pk8n[4][5] = {SAMD_C2P_K(8, 8, false), SAMD_C2P_K(16, 8, false), SAMD_C2P_K(24, 8, false), SAMD_C2P_K(32, 8, false)};
+      typedef void (*pkern_t)(const float2*, const float*, const float*, int, int, int, int, int, int, int, int, float2*, C2oFuse);
+      static const pkern_t pk4[4][5] = {SAMD_C2P_K(8, 4, true), SAMD_C2P_K(16, 4, true), SAMD_C2P_K(24, 4, true), SAMD_C2P_K(32, 4, true)};
+      static const pkern_t pk2[4][5] = {SAMD_C2P_K(8, 2, true), SAMD_C2P_K(16, 2, true), SAMD_C2P_K(24, 2, true), SAMD_C2P_K(32, 2, true)};
+      static const pkern_t pk8n[4][5] = {SAMD_C2P_K(8, 8, false), SAMD_C2P_K(16, 8, false), SAMD_C2P_K(24, 8, false), SAMD_C2P_K(32, 8, false)};
 #undef SAMD_C2P_K
       const size_t lds_p = ((size_t)mp * num_freqs + (size_t)(((best_rpt + 7) / 8) * 8) * (best_nt / num_freqs) * mp) * sizeof(float2) + 64;
       const bool pass = (pw == 8 || pw == 4 || pw == 2) && lds_p <= 64 * 1024 && (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant < 8192;
-      const kern_t kern = !pass ? rk[mp / 8 - 1][(best_rpt + 7) / 8 - 1] : (pw == 8 ? pk8n : pw == 4 ? pk4 : pk2)[mp / 8 - 1][(best_rpt + 7) / 8 - 1];
-      hipLaunchKernelGGL(kern, grid, dim3(best_nt), pass ? lds_p : lds_r, st, (const float2*)a, tau, frequencies, num_rx, num_rx_ant,
-                         num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq);
+      if (pass)
+        hipLaunchKernelGGL((pw == 8 ? pk8n : pw == 4 ? pk4 : pk2)[mp / 8 - 1][(best_rpt + 7) / 8 - 1], grid, dim3(best_nt), lds_p, st,
+                           (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs,
+                           normalize, (float2*)h_freq, C2oFuse{});
+      else
+        hipLaunchKernelGGL(rk[mp / 8 - 1][(best_rpt + 7) / 8 - 1], grid, dim3(best_nt), lds_r, st, (const float2*)a, tau, frequencies, num_rx,
+                           num_rx_ant, num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs, normalize, (float2*)h_freq);
       return launch_status();
     }
   }

@@ -23,8 +23,11 @@ class AWGN(Block):
             while no.dim() < x.dim():
                 no = no.unsqueeze(-1)
             no = torch.broadcast_to(no, x.shape).contiguous()
+        return self._add(x, no, config.rng.next_call())
+
+    def _add(self, x, no, call_id):
+        """the launch with a given call id of the Philox stream (OFDMChannel hands in the one it drew for its fused kernel)"""
         y = torch.empty_like(x)
-        rng = config.rng
-        fn = _ffi.lib().samd_awgn_c128 if dbl else _ffi.lib().samd_awgn_c64
-        _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(no), no.numel(), rng.seed, rng.next_call(), x.numel(), _ffi.ptr(y), _ffi.stream()), "AWGN")
+        fn = _ffi.lib().samd_awgn_c128 if self.precision == "double" else _ffi.lib().samd_awgn_c64
+        _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(no), no.numel(), config.rng.seed, call_id, x.numel(), _ffi.ptr(y), _ffi.stream()), "AWGN")
         return y
