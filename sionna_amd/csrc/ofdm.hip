@@ -779,7 +779,8 @@ extern "C" int samd_ofdm_channel_fused_c64(const float* a, const float* tau, con
   if (!best_nt || !mp) { set_error("fused OFDM channel: shape outside the staged-register kernel"); return SAMD_ERR_UNSUPPORTED; }
   const size_t lds_p = ((size_t)mp * num_freqs + (size_t)(((best_rpt + 7) / 8) * 8) * (best_nt / num_freqs) * mp) * sizeof(float2) + 64;
   const size_t stage_b = (size_t)num_rx_ant * (num_tx_ant - 1) * num_time_steps * num_freqs * sizeof(float2);
-  if (lds_p > 64 * 1024 || stage_b + 64 > lds_p || (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant >= 8192) {
+  const size_t lds_f = std::max(lds_p, stage_b + 64);          // (few paths: the staged products need more than the tables)
+  if (lds_f > 64 * 1024 || (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant >= 8192) {
     set_error("fused OFDM channel: shape outside the staged-register kernel");
     return SAMD_ERR_UNSUPPORTED;
   }
@@ -790,7 +791,7 @@ extern "C" int samd_ofdm_channel_fused_c64(const float* a, const float* tau, con
   static const kern_t fk[4][5] = {SAMD_C2F_K(8), SAMD_C2F_K(16), SAMD_C2F_K(24), SAMD_C2F_K(32)};
 #undef SAMD_C2F_K
   const C2oFuse fu{(const float2*)x, no, seed, call, (float2*)y};
-  hipLaunchKernelGGL(fk[mp / 8 - 1][(best_rpt + 7) / 8 - 1], dim3(batch * num_rx), dim3(best_nt), lds_p, (hipStream_t)stream,
+  hipLaunchKernelGGL(fk[mp / 8 - 1][(best_rpt + 7) / 8 - 1], dim3(batch * num_rx), dim3(best_nt), lds_f, (hipStream_t)stream,
                      (const float2*)a, tau, frequencies, num_rx, num_rx_ant, num_tx, num_tx_ant, num_paths, num_time_steps, num_freqs,
                      normalize, (float2*)nullptr, fu);
   return launch_status();

@@ -2,6 +2,7 @@
 and ``RayleighBlockFading`` - mirrors of reference src/sionna/phy/channel/
 generate_ofdm_channel.py:9-85, apply_ofdm_channel.py:14-80, ofdm_channel.py:13-115,
 rayleigh_block_fading.py:10-110."""
+import numpy as np
 import torch
 
 from ... import _ffi
@@ -81,8 +82,8 @@ class OFDMChannel(Block):
         gen = self._generate_channel
         if self.precision != "single" or not isinstance(x, torch.Tensor) or x.dim() != 5 or x.shape[1] != 1:
             return None
-        if no is not None and (not isinstance(no, (int, float, torch.Tensor)) or (isinstance(no, torch.Tensor) and no.numel() != 1)):
-            return None
+        if no is not None and int(np.size(no.detach().cpu() if isinstance(no, torch.Tensor) else no)) != 1:
+            return None                                     # per-element noise variances: the separate blocks
         x = _ffi.to_device(x, self.cdtype)
         a, tau = gen._cir_sampler(x.shape[0], gen._num_ofdm_symbols, gen._sampling_frequency)
         a_t, tau_t = _ffi.to_device(a, self.cdtype), _ffi.to_device(tau, self.rdtype)
