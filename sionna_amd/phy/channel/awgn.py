@@ -25,9 +25,9 @@ class AWGN(Block):
             no = torch.broadcast_to(no, x.shape).contiguous()
         return self._add(x, no, config.rng.next_call())
 
-    def _add(self, x, no, call_id):
-        """the launch with a given call id of the Philox stream (OFDMChannel hands in the one it drew for its fused kernel)"""
-        y = torch.empty_like(x)
+    def _add(self, x, no, call_id, out=None):
+        """the launch with a given call id of the Philox stream (OFDMChannel hands in the one it drew); out = x: in place"""
+        y = torch.empty_like(x) if out is None else out
         fn = _ffi.lib().samd_awgn_c128 if self.precision == "double" else _ffi.lib().samd_awgn_c64
         _ffi.check(fn(_ffi.ptr(x), _ffi.ptr(no), no.numel(), config.rng.seed, call_id, x.numel(), _ffi.ptr(y), _ffi.stream()), "AWGN")
         return y

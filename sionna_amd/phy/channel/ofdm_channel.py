@@ -102,9 +102,11 @@ class OFDMChannel(Block):
         no_t = None if no is None else _ffi.to_device(no, self.rdtype).reshape(1)
         rng = config.rng
         call_id = rng.next_call() if no is not None else 0
-        rc = _ffi.lib().samd_ofdm_channel_fused_c64(_ffi.ptr(a_t), _ffi.ptr(tau_t), _ffi.ptr(fr), _ffi.ptr(x),
-                                                    None if no_t is None else _ffi.ptr(no_t), rng.seed, call_id, b, rx, ra, tx, ta, p, t,
-                                                    fr.numel(), int(bool(norm)), _ffi.ptr(y), _ffi.stream())
+        # The noise is NOT added inside the launch although the entry can do it (bit-identical): Philox + Box-Muller per element
+        # on top of the 48 staged result registers of a thread ran at 5 waves per SIMD with spills - 747 us against 343 us for
+        # the noise-free launch at config C4 (profiles/r06g_kernel_stats_c4.txt); awgn_kernel in place on y costs ~150 us.
+        rc = _ffi.lib().samd_ofdm_channel_fused_c64(_ffi.ptr(a_t), _ffi.ptr(tau_t), _ffi.ptr(fr), _ffi.ptr(x), None, rng.seed, call_id,
+                                                    b, rx, ra, tx, ta, p, t, fr.numel(), int(bool(norm)), _ffi.ptr(y), _ffi.stream())
         if rc == _ffi.ERR_UNSUPPORTED:
             h = cir_to_ofdm_channel(fr, a_t, tau_t, norm)
             yy = self._apply_channel._apply(x, h)
@@ -112,6 +114,8 @@ class OFDMChannel(Block):
                 yy = self._apply_channel._awgn._add(yy, no_t, call_id)
             return (wrap(yy), h) if self._return_channel else wrap(yy)
         _ffi.check(rc, "OFDMChannel")
+        if no is not None:
+            y = self._apply_channel._awgn._add(y, no_t, call_id, out=y)
         if not self._return_channel:
             return wrap(y)
         h = torch.empty((b, rx, ra, tx, ta, t, fr.numel()), dtype=self.cdtype, device=x.device)
