@@ -393,6 +393,11 @@ __device__ __forceinline__ float2 c2o_box_muller(uint32_t a, uint32_t b) {
 // transmit antennas runs inside the workgroup through the LDS of the dead phase / tap tables, ascending ta like
 // apply_ofdm_channel_kernel), the noise of element i from Philox block i / 2 like awgn_kernel: the same bits as the three
 // separate kernels, without the 558 MB of h_freq written and read back at config C4.
+// 0: the fused kernel is built without the in-kernel noise (measured slower than awgn_kernel in place on y, profiles/r06g): the
+// host adds it with samd_awgn_c64; the entry refuses a noise variance then.  1 keeps the bit-identical in-kernel form.
+#ifndef C2O_FUSED_NOISE
+#define C2O_FUSED_NOISE 0
+#endif
 struct C2oFuse {
   const float2* x;       // [B, 1, TA, T, F] transmitted grid
   const float* no;       // one noise variance, or null: no noise
@@ -543,36 +548,69 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
     inv = c > 0.f ? 1.f / c : 0.f;                               // divide_no_nan
   }
   if constexpr (FUSED) {
-    // products h x of the rows with ta >= 1 into the LDS of the (dead) tables: [(ra (TA - 1) + ta - 1) T + t][f]
+    // products h x: the rows with ta >= 1 into the LDS of the (dead) tables, [(ra (TA - 1) + ta - 1) T + t][f]; the rows with
+    // ta = 0 stay in their result registers.  The x values are requested in batches of 8 rows before the first is used (one
+    // round trip per batch: row by row, a workgroup's life grew by two thirds - 562 against 343 us, profiles/r06h).
     float2* stage = tab;
     const float2* xb = fu.x + (size_t)b * TA * T * F;
     __syncthreads();                                              // every wave is through its FMA loop
+    // row g + r G -> (ra, ta, t) as a running state advanced with selections (G <= T, host-checked: at most one wrap per step):
+    // the x loads of a batch must not sit behind data-dependent control flow, or each one waits for the one before
+    struct RowPos {
+      int t, ta, ra;
+      __device__ __forceinline__ void step(int G_, int T_, int TA_) {
+        t += G_;
+        const bool w = t >= T_;
+        t -= w ? T_ : 0;
+        ta += w ? 1 : 0;
+        const bool w2 = ta >= TA_;
+        ta = w2 ? 0 : ta;
+        ra += w2 ? 1 : 0;
+      }
+    };
+    const RowPos pos0{g % T, (g / T) % TA, (g / T) / TA};
     {
-      int t = g % T, lk = g / T;
-      int ta = lk % TA, ra = lk / TA;
+      RowPos pl = pos0, pc = pos0;
+      // (the three walks over the rows are the same sequence: left visible, the compiler keeps all 24 positions of one walk
+      // alive for the others - 121 spilled registers)
+      asm volatile("" : "+v"(pc.t), "+v"(pc.ta), "+v"(pc.ra));
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        if (act && ra < RA && ta >= 1) {
-          const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);          // the value cir_to_ofdm stores
-          stage[(unsigned)(((ra * (TA - 1) + ta - 1) * T + t) * F + f)] = cmul(hv, xb[(unsigned)((ta * T + t) * F + f)]);
+      for (int r0 = 0; r0 < RPT; r0 += 8) {
+        float2 xv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const bool ok = act && pl.ra < RA;
+          xv[k] = xb[ok ? (unsigned)((pl.ta * T + pl.t) * F + f) : 0u];
+          pl.step(G, T, TA);
         }
-        t += G;
-        while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int r = r0 + k;
+          const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);          // the value cir_to_ofdm stores
+          const float2 pr = cmul(hv, xv[k]);
+          if (act && pc.ra < RA && pc.ta >= 1) stage[(unsigned)(((pc.ra * (TA - 1) + pc.ta - 1) * T + pc.t) * F + f)] = pr;
+          acc[r] = c2o_f32x2{pr.x, pr.y};
+          pc.step(G, T, TA);
+        }
+        asm volatile("" ::: "memory");                           // (the next batch's loads stay behind this batch: registers)
       }
     }
     __syncthreads();
     const float sh = sqrtf(1.0f / 2.0f);
-    const float sn = fu.no ? sqrtf(fu.no[0]) : 0.f;
+    const float sn = (C2O_FUSED_NOISE && fu.no) ? sqrtf(fu.no[0]) : 0.f;
+    (void)sh; (void)sn;
     float2* yb = fu.y + ((size_t)(b * RX + rx) * RA) * (size_t)T * F;
     const uint64_t i0 = ((uint64_t)(b * RX + rx) * RA) * (uint64_t)T * F;
+    (void)i0;
     {
-      int t = g % T, lk = g / T;
-      int ta = lk % TA, ra = lk / TA;
+      RowPos ps = pos0;
+      asm volatile("" : "+v"(ps.t), "+v"(ps.ta), "+v"(ps.ra));
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
+        const int t = ps.t, ta = ps.ta, ra = ps.ra;
+        ps.step(G, T, TA);
         if (act && ra < RA && ta == 0) {
-          const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);
-          float2 v = cmul(hv, xb[(unsigned)(t * F + f)]);
+          float2 v = make_float2(acc[r].x, acc[r].y);
           float2 s = make_float2(0.f, 0.f);                       // apply_ofdm_channel_kernel: acc = 0; acc += v_k, k ascending
           s.x += v.x; s.y += v.y;
           for (int k = 1; k < TA; ++k) {
@@ -580,7 +618,7 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
             s.x += v.x; s.y += v.y;
           }
           const unsigned rel = (unsigned)((ra * T + t) * F + f);
-          if (fu.no) {                                            // awgn_kernel: element i takes half (i & 1) of Philox block i / 2
+          if (C2O_FUSED_NOISE && fu.no) {                         // awgn_kernel: element i takes half (i & 1) of Philox block i / 2
             const uint64_t i = i0 + rel;
             const uint4 rr = philox_block(fu.seed, fu.call, i >> 1);
             const float2 w = (i & 1) ? c2o_box_muller(rr.z, rr.w) : c2o_box_muller(rr.x, rr.y);
@@ -588,8 +626,6 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
           }
           yb[rel] = s;
         }
-        t += G;
-        while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
       }
     }
     return;
@@ -766,6 +802,7 @@ extern "C" int samd_ofdm_channel_fused_c64(const float* a, const float* tau, con
   SAMD_REQUIRE(num_paths >= 1 && num_freqs >= 1 && num_time_steps >= 1, "bad size");
   static samd::CachedOpt opt_off("SAMD_NO_FUSED_CHANNEL");
   if (num_tx != 1 || opt_off.is_set()) { set_error("fused OFDM channel: one transmitter only"); return SAMD_ERR_UNSUPPORTED; }
+  if (no && !C2O_FUSED_NOISE) { set_error("fused OFDM channel: built without in-kernel noise (add it with samd_awgn_c64)"); return SAMD_ERR_UNSUPPORTED; }
   const int rows = num_rx_ant * num_tx_ant * num_time_steps;
   int best_nt = 0, best_rpt = 0;
   double best_u = 0.0;
@@ -780,7 +817,7 @@ extern "C" int samd_ofdm_channel_fused_c64(const float* a, const float* tau, con
   const size_t lds_p = ((size_t)mp * num_freqs + (size_t)(((best_rpt + 7) / 8) * 8) * (best_nt / num_freqs) * mp) * sizeof(float2) + 64;
   const size_t stage_b = (size_t)num_rx_ant * (num_tx_ant - 1) * num_time_steps * num_freqs * sizeof(float2);
   const size_t lds_f = std::max(lds_p, stage_b + 64);          // (few paths: the staged products need more than the tables)
-  if (lds_f > 64 * 1024 || (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant >= 8192) {
+  if (lds_f > 64 * 1024 || (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant >= 8192 || best_nt / num_freqs > num_time_steps) {
     set_error("fused OFDM channel: shape outside the staged-register kernel");
     return SAMD_ERR_UNSUPPORTED;
   }
