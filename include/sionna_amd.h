@@ -186,14 +186,15 @@ int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
                            float offset, int hard_out, int return_infobits,
                            void* workspace, size_t workspace_bytes, void* stream);
 
-/* Specialised decoders (csrc/ldpc5g_jit.cpp).  For codes whose schedule is static and whose messages fit in LDS (lifting
- * size a multiple of 128, whole base rows / columns, k, n and the interleaver's row length multiples of 64 - BASELINE
- * config C2), samd_ldpc5g_decode_f32 with SAMD_CN_MINSUM / SAMD_CN_OFFSET_MINSUM runs a kernel GENERATED for that one code:
+/* Specialised decoders (csrc/ldpc5g_jit.cpp).  For codes whose messages fit in LDS (round 5: lifting size a multiple of 128,
+ * whole base rows / columns, k, n and the interleaver's row length multiples of 64 - BASELINE config C2; round 6: every even
+ * lifting size, any k / n / pruning - BASELINE C4's and C1's codes), samd_ldpc5g_decode_f32 with SAMD_CN_MINSUM /
+ * SAMD_CN_OFFSET_MINSUM runs a kernel GENERATED for that one code:
  * the per-wave work lists written out as straight-line source (block offsets, shifts and rate-matching offsets as
- * constants), compiled once per process and code with hipRTC (libhiprtc.so, bound with dlopen) for gfx950.  Same
+ * constants), compiled once per machine and code with hipRTC (libhiprtc.so, bound with dlopen) for gfx950.  Same
  * reference path (decoding.py:1427-1536, 416-524, 681-953), same bits as the generic kernel.  One kernel per (code,
  * return_infobits, rule): cn_mode below is SAMD_CN_MINSUM or SAMD_CN_OFFSET_MINSUM.  Compilation happens at the
- * first decode of at least 1024 codewords (development options SAMD_LDPC_JIT = 0 off / 1 default / 2 any batch,
+ * first decode of at least 256 codewords (development options SAMD_LDPC_JIT = 0 off / 1 default / 2 any batch,
  * SAMD_LDPC_JIT_MIN_BATCH); whenever it is not possible the generic kernel runs.
  *   ..._supported: 1 when the handle's code is in that class.
  *   ..._prepare:   compile now; 1 ready, 0 not in the class / switched off, < 0 failed (samd_last_error = compiler log).

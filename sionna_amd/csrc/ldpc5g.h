@@ -19,7 +19,11 @@ struct samd_ldpc5g_opt {
   // phi evaluations make 437 KB of code for 16 wave programs (64 KB instruction cache) and 1076 spilled registers: 144.7 ms
   // against 119.9 ms per 65536 C2 codewords (profiles/r05l_phi_generated_vs_generic.txt).  Off unless SAMD_LDPC_JIT_PHI=1.
   int jit_phi = 0;
-  int jit = 1, jit_min_batch = 1024;     // specialised kernels (ldpc5g_jit.cpp): 0 off, 1 from jit_min_batch codewords, 2 always
+  // specialised kernels (ldpc5g_jit.cpp): 0 off, 1 from jit_min_batch codewords, 2 always.  The generated kernel is the faster
+  // one at EVERY batch size (16 ... 4096 codewords, five codes: profiles/r06k_jit_small_batch.json); the threshold only keeps
+  // one-off small decodes (unit tests over dozens of codes) from paying ~3 s of hipRTC each the first time a machine sees a
+  // code - later processes load the cached code object (256 since round 6, 1024 before the disk cache)
+  int jit = 1, jit_min_batch = 256;
   void capture() {
     using samd::opt_set; using samd::opt_int;
     enc_bytes = opt_set("SAMD_ENC_BYTES"); enc_persist = opt_set("SAMD_ENC_PERSIST");
@@ -31,7 +35,7 @@ struct samd_ldpc5g_opt {
     onchip_grid = (int)opt_int("SAMD_ONCHIP_GRID", 0);
     ms_dataflow = (int)opt_int("SAMD_MS_DATAFLOW", 0);
     jit_phi = (int)opt_int("SAMD_LDPC_JIT_PHI", 0);
-    jit = (int)opt_int("SAMD_LDPC_JIT", 1); jit_min_batch = (int)opt_int("SAMD_LDPC_JIT_MIN_BATCH", 1024);
+    jit = (int)opt_int("SAMD_LDPC_JIT", 1); jit_min_batch = (int)opt_int("SAMD_LDPC_JIT_MIN_BATCH", 256);
 #ifdef SAMD_DEV
     enc_dbg = (int)opt_int("SAMD_ENC_DBG", 0);        // skips encoder phases: wrong results, development builds only
 #endif
