@@ -370,6 +370,46 @@ JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], f
     jit_cn_store<NCH>(a0, (unsigned)i * JIT_Z4, c2v);
   }
 }
+// The same update with the loops over the row's edges ROLLED (round 6): D is a wave-uniform run-time value, each pass has ONE
+// phi body, the phi(|v2c|) of the first pass wait in the row's own message slots (read back by the second pass), the signs in
+// one bit per edge.  Unrolled, the 16 wave programs of C2 were 437 KB of code against a 64 KB instruction cache with 1076
+// spilled registers (profiles/r05l); rolled they are a tenth.  Same operations on the same values in the same order: same bits.
+template <bool FUSE, bool PRUNE>
+JIT_DEV void jit_cn_phi_rolled(U32 a0, int D, const F32 (&lf)[2], float llr_max, F32 (&xo)[2], const M64 (&pm)[2]) {
+  U32 sg0 = 0u, sg1 = 0u, node0 = 0u, node1 = 0u;          // sg: bit i = sign of edge i's v2c; node: their parity in the msb
+  F32 sum0 = 0.f, sum1 = 0.f;
+  U32 a = a0;
+#pragma unroll 1
+  for (int i = 0; i < D; ++i) {
+    F32 v0, v1, p0, p1;
+    lds_ld2(a, 0u, v0, v1);
+    const U32 s0 = u_msb_if_neg(v0), s1 = u_msb_if_neg(v1);
+    node0 = node0 ^ s0; node1 = node1 ^ s1;
+    sg0 = sg0 | u_shr(s0, 31 - i); sg1 = sg1 | u_shr(s1, 31 - i);
+    jit_phi2(p0, p1, f_abs(v0), f_abs(v1));
+    sum0 = sum0 + p0; sum1 = sum1 + p1;
+    lds_st2(a, 0u, p0, p1);
+    a = a + (unsigned)JIT_Z4;
+  }
+  a = a0;
+#pragma unroll 1
+  for (int i = 0; i < D; ++i) {
+    F32 p0, p1, q0, q1;
+    lds_ld2(a, 0u, p0, p1);
+    jit_phi2(q0, q1, f_neg(p0) + sum0, f_neg(p1) + sum1);
+    F32 c0 = u_float(f_bits(f_min(q0, llr_max)) ^ (u_shl(u_shr(sg0, i), 31) ^ node0));
+    F32 c1 = u_float(f_bits(f_min(q1, llr_max)) ^ (u_shl(u_shr(sg1, i), 31) ^ node1));
+    if (PRUNE) { c0 = f_sel(pm[0], jit_bcast(0.f), c0); c1 = f_sel(pm[1], jit_bcast(0.f), c1); }
+    if (FUSE && i == D - 1) {
+      const F32 x0 = c0 + lf[0], x1 = c1 + lf[1];
+      xo[0] = x0; xo[1] = x1;
+      c0 = f_med3(x0 - c0, -llr_max, llr_max);
+      c1 = f_med3(x1 - c1, -llr_max, llr_max);
+    }
+    lds_st2(a, 0u, c0, c1);
+    a = a + (unsigned)JIT_Z4;
+  }
+}
 #endif
 
 // v2c of iteration 0 for the fused degree-1 column of a row: its channel LLR

@@ -61,6 +61,7 @@ struct JitKnobs {
   int cn_pair_max = 32;   // rows of higher degree are two single-chunk items
   int waves = 0;          // own schedule (sched = 1): waves per workgroup, 0 = the generic kernel's 16
   int cmp_ahead = 0;      // min-sum check node: comparisons issued this many edges ahead of the selections that read them
+  int phi_rolled = 1;     // boxplus-phi: the check-node loops over a row's edges rolled (one phi body per pass) instead of unrolled
   int general = 0;        // 1: the any-lifting-size programs also for the codes of the Z = 128 class (A/B)
   int group = 0, wgs = 0; // any-lifting-size programs: codewords per workgroup / workgroups per CU (0: chosen by the generator)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
