@@ -15,10 +15,13 @@ struct samd_ldpc5g_opt {
   bool enc_bytes = false, enc_persist = false, onchip_compressed = false, force_spill = false, no_spill = false;
   bool no_onchip_layered = false, bp_engine = false, onchip_v1 = false, ms_nogroup = false, ms_noz128 = false;
   int ms_var = 1, ms_ldsbar = 0, onchip_grid = 0, enc_dbg = 0, ms_dataflow = 0;
-  // boxplus-phi on the generated kernel: bit-identical, but SLOWER than the generic explicit-message kernel - fully unrolled
-  // phi evaluations make 437 KB of code for 16 wave programs (64 KB instruction cache) and 1076 spilled registers: 144.7 ms
-  // against 119.9 ms per 65536 C2 codewords (profiles/r05l_phi_generated_vs_generic.txt).  Off unless SAMD_LDPC_JIT_PHI=1.
-  int jit_phi = 0;
+  // boxplus-phi on the generated kernel (bit-identical).  Round 5, loops unrolled: SLOWER than the generic explicit-message
+  // kernel (437 KB of code for 16 wave programs, 1076 spilled registers: 144.7 against 119.9 ms per 65536 C2 codewords).
+  // Round 6, check-node loops rolled (jit_cn_phi_rolled): 113.0 ms at C2 (0.580 M against 0.546 M decodes/s), 1.5 - 2 x the
+  // generic engines on the codes that pack several codewords per workgroup (C4's code 3.45 M against 1.75 M), but 0.91 x where
+  // ONE codeword leaves a quarter of the lanes of its only chunk idle (Z = 96: the rule is bound by the vector pipe, idle
+  // lanes cost their full share) - profiles/r06m.  -1 (default): on, except for that geometry; 0 off; 1 on.
+  int jit_phi = -1;
   // specialised kernels (ldpc5g_jit.cpp): 0 off, 1 from jit_min_batch codewords, 2 always.  The generated kernel is the faster
   // one at EVERY batch size (16 ... 4096 codewords, five codes: profiles/r06k_jit_small_batch.json); the threshold only keeps
   // one-off small decodes (unit tests over dozens of codes) from paying ~3 s of hipRTC each the first time a machine sees a
@@ -34,7 +37,7 @@ struct samd_ldpc5g_opt {
     ms_var = (int)opt_int("SAMD_MS_VAR", 1) & 1; ms_ldsbar = (int)opt_int("SAMD_MS_LDSBAR", 0);
     onchip_grid = (int)opt_int("SAMD_ONCHIP_GRID", 0);
     ms_dataflow = (int)opt_int("SAMD_MS_DATAFLOW", 0);
-    jit_phi = (int)opt_int("SAMD_LDPC_JIT_PHI", 0);
+    jit_phi = (int)opt_int("SAMD_LDPC_JIT_PHI", -1);
     jit = (int)opt_int("SAMD_LDPC_JIT", 1); jit_min_batch = (int)opt_int("SAMD_LDPC_JIT_MIN_BATCH", 256);
 #ifdef SAMD_DEV
     enc_dbg = (int)opt_int("SAMD_ENC_DBG", 0);        // skips encoder phases: wrong results, development builds only

@@ -109,16 +109,17 @@ def test_generator_variants_bit_exact(phy, opts):
             assert np.array_equal(got, _reference(code, llr, cn, it, infobits, m)), (cn, opts)
 
 
-def test_boxplus_phi_on_the_generated_kernel_bit_exact(phy):
-    """the defined phi of round 5 inside a generated kernel (SAMD_LDPC_JIT_PHI=1; off by default - measured slower than the
-    generic explicit-message kernel): soft outputs array_equal to the oracle, both output forms"""
+@pytest.mark.parametrize("k,n,bg,m,rolled", [(2816, 8448, "bg1", 6, "1"), (2816, 8448, "bg1", 6, "0"), (768, 1536, None, 2, "1"),
+                                             (1024, 2048, "bg1", None, "1"), (1234, 2468, None, 4, "0")])
+def test_boxplus_phi_on_the_generated_kernel_bit_exact(phy, k, n, bg, m, rolled):
+    """the defined phi of round 5 inside a generated kernel - round 6: check-node loops rolled (the default; the unrolled form
+    stays selectable), every even lifting size: soft outputs array_equal to the oracle, both output forms"""
     import contextlib
-    k, n, m, bg = 2816, 8448, 6, "bg1"
     code = LDPC5GCode(k, n, m, bg)
-    llr = _noisy_llr(code, 6, 7, sigma=0.7)
+    llr = _noisy_llr(code, 6 if k == 2816 else 50, 7, sigma=0.7)
     llr[0, :9] = 0
     with contextlib.ExitStack() as st:
-        for kk, vv in (("SAMD_LDPC_JIT", "2"), ("SAMD_LDPC_JIT_PHI", "1"), ("SAMD_ONCHIP_GRID", "2")):
+        for kk, vv in (("SAMD_LDPC_JIT", "2"), ("SAMD_JIT_PHI_ROLLED", rolled), ("SAMD_ONCHIP_GRID", "2")):
             st.enter_context(_opt(kk, vv))
         enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
         for it, infobits in ((1, True), (6, False)):
