@@ -118,7 +118,9 @@ def onchip_roofline(kernel_key, kernel_name, units, ms, extra=None):
             out["barrier_frac"] = rec["ablation"].get("barrier_frac")
             out["ablation"] = {k_: rec["ablation"][k_] for k_ in ("node_arithmetic_frac", "lds_frac_of_time", "lds_plus_barriers_frac",
                                                                   "fixed_per_codeword_frac", "from") if k_ in rec["ablation"]}
-        if rec.get("mix"):
+        # (the static mix of profiles/r03_valu_mix.json was taken on the round-3 kernels: the boxplus-phi kernels changed their
+        # arithmetic in round 5 - a busy share above 1 came out of the old mix - and have no current one)
+        if rec.get("mix") and kernel_key not in ("ldpc5g_bp", "ldpc5g_bp_fast", "ldpc5g_jit_phi"):
             ns = rec["mix"]["ns_per_valu_inst_est"]
             out["valu_busy_est"] = round(rec["valu_insts_per_unit"] * units * ns * 1e-9 / (NUM_SIMD * ms * 1e-3), 4)
             out["valu_mix"] = {"ns_per_inst_est": ns, "class_counts": rec["mix"]["class_counts"],
@@ -579,6 +581,7 @@ def cpu_baseline_c2(llr, k, n, m, cn_update, num_iter, dec, seconds, max_cw):
 
 
 def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms, specialised=False):
+    """specialised: the kernel generated for the code ran (csrc/ldpc5g_jit.cpp) - min-sum family or, since round 6, boxplus-phi"""
     bytes_alg = b_msg(num_iter, k) * B
     equiv = {"algorithmic_bytes_per_decode": b_msg(num_iter, k), "gbps": round(bytes_alg / (dec_ms * 1e-3) / 1e9, 1),
              "frac_of_hbm_peak": round(bytes_alg / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -590,10 +593,14 @@ def c2_roofline(cn_update, onchip, B, k, num_iter, dec_ms, specialised=False):
         name = ("ldpc5g_decode_msg_kernel (on-chip min-sum, one float per edge in LDS, channel LLRs in an L2 workspace row, "
                 "grouped dispatch)" if minsum else
                 "ldpc5g_decode_msg_kernel<..., boxplus> (the same engine with bp_math's boxplus node update)")
-        if specialised:
+        if specialised and minsum:
             key = "ldpc5g_jit"
             name = ("samd_ldpc5g_jit (generated for this code and compiled with hipRTC at the first decode: one straight-line "
                     "program per wave, messages in LDS, channel LLRs and block positions in registers; csrc/ldpc5g_jit.cpp)")
+        elif specialised and cn_update == "boxplus-phi":
+            key = "ldpc5g_jit_phi"
+            name = ("samd_ldpc5g_jit_phi (generated for this code: the defined phi with the check-node loops over a row's edges "
+                    "rolled, one phi body per pass, values through the row's own LDS slots; csrc/ldpc5g_jit.cpp)")
         return onchip_roofline(key, name, B, dec_ms, {"hbm_resident_equiv": equiv, **io})
     ach = bytes_alg / (dec_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
@@ -813,14 +820,17 @@ def main():
     if args.also and args.also != "none" and args.also != args.cn_update:
         dec2 = make_dec(args.also)
         steps2 = max(2, args.steps // 3)
+        n_before = int(_ffi.lib().samd_ldpc5g_jit_launches(enc._handle(dec2._nb_pruned_nodes)))
         t2, ms2, c2 = run(dec2, steps2, 1)
         on2 = bool(dec2._onchip_ok)
-        out["also"] = {"cn_update": args.also, "engine": "on-chip" if on2 else "generic-hbm",
+        jit2 = on2 and int(_ffi.lib().samd_ldpc5g_jit_launches(enc._handle(dec2._nb_pruned_nodes))) > n_before
+        out["also"] = {"cn_update": args.also,
+                       "engine": ("on-chip, kernel specialised for the code (hipRTC)" if jit2 else "on-chip") if on2 else "generic-hbm",
                        "note": "the reference's default check-node rule",
                        "value": round(B * world * steps2 / t2, 1), "unit": "codewords/s", "steps": steps2,
                        "ms_per_step": round(t2 / steps2 * 1e3, 3), "ber": float(c2[0] / max(c2[2], 1)),
                        "bler": float(c2[1] / max(c2[3], 1)),
-                       "roofline": c2_roofline(args.also, on2, B, k, args.num_iter, ms2)}
+                       "roofline": c2_roofline(args.also, on2, B, k, args.num_iter, ms2, jit2)}
 
         if args.also == "boxplus-phi":
             # the same rule on the GPU's transcendental unit (SAMD_CN_BOXPLUS_PHI_FAST): not bit-defined, reported beside

@@ -93,7 +93,7 @@ LDS_CYCLES = {"ds_read_b32": 2, "ds_read_b64": 2, "ds_read2_b32": 4, "ds_read2st
 def per_iteration_stats(asm):
     """The kernel is 16 wave programs, each [prologue + init | barrier | CN phase | barrier | VN phase | barrier]: instruction
     classes and LDS-pipeline cycles of ONE iteration summed over the waves (what a CU executes per iteration and codeword)."""
-    body = asm[asm.index("<samd_ldpc5g_jit>:"):]
+    body = asm[re.search(r"<samd_ldpc5g_jit\w*>:", asm).start():]
     segs = [[]]
     for line in body.splitlines():
         mm = re.match(r"\s+([a-z_0-9]+)\s", line)
@@ -149,7 +149,7 @@ def main():
                 ".group_segment_fixed_size", ".private_segment_fixed_size"):
         mm = re.search(re.escape(key) + r":\s+(\d+)", notes)
         print(f"  {key[1:]:28s} {mm.group(1) if mm else '?'}")
-    body = asm[asm.index("<samd_ldpc5g_jit>:"):]
+    body = asm[re.search(r"<samd_ldpc5g_jit\w*>:", asm).start():]
     print(f"  code bytes                   {4 * sum(len(l.split('//')[1].split(':')[1].split()) for l in body.splitlines() if '//' in l and ':' in l.split('//')[1])}")
     st = isa_stats(body)
     print("  instructions:", dict(st))

@@ -23,8 +23,14 @@ KERNELS = {   # key -> (substring of the kernel name, unit, source file(s): the 
     # defined exp / log, 4 boxplus-phi on the hardware transcendentals)
     # the kernel GENERATED for the code (csrc/ldpc5g_jit.cpp, compiled by hipRTC at run time): generator, node updates,
     # operation definitions; the schedule it writes out comes from the table builder in ldpc5g_onchip_bp.hip
-    "ldpc5g_jit": ("samd_ldpc5g_jit", "decode", ["sionna_amd/csrc/ldpc5g_jit.cpp", "sionna_amd/csrc/jit/ldpc5g_jit_templates.h",
-                                                 "sionna_amd/csrc/jit/ldpc5g_jit_ops_gfx950.h", "sionna_amd/csrc/ldpc5g_onchip_bp.hip"]),
+    # (a trailing $: the kernel's exact name - the generated kernels carry the rule and the code in theirs)
+    "ldpc5g_jit": ("samd_ldpc5g_jit$", "decode", ["sionna_amd/csrc/ldpc5g_jit.cpp", "sionna_amd/csrc/jit/ldpc5g_jit_templates.h",
+                                                  "sionna_amd/csrc/jit/ldpc5g_jit_ops_gfx950.h", "sionna_amd/csrc/ldpc5g_onchip_bp.hip"]),
+    # round 6: boxplus-phi on the generated kernel (rolled check-node loops) at C2, and the any-lifting-size programs at C4's code
+    "ldpc5g_jit_phi": ("samd_ldpc5g_jit_phi$", "decode", ["sionna_amd/csrc/ldpc5g_jit.cpp", "sionna_amd/csrc/jit/ldpc5g_jit_templates.h",
+                                                          "sionna_amd/csrc/jit/ldpc5g_jit_ops_gfx950.h", "sionna_amd/csrc/ldpc5g_onchip_bp.hip"]),
+    "ldpc5g_jit_c4": ("samd_ldpc5g_jit_ms_bg2z80k768n1536$", "decode", ["sionna_amd/csrc/ldpc5g_jit.cpp", "sionna_amd/csrc/jit/ldpc5g_jit_templates.h",
+                                                                        "sionna_amd/csrc/jit/ldpc5g_jit_ops_gfx950.h"]),
     "ldpc5g_ms": ("ldpc5g_decode_msg_kernel<2, true, 2, 1>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
     "ldpc5g_bp": ("ldpc5g_decode_msg_kernel<2, true, 1, 0>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
     "ldpc5g_bp_fast": ("ldpc5g_decode_msg_kernel<2, true, 4, 0>", "decode", "sionna_amd/csrc/ldpc5g_onchip_ms.inc"),
@@ -106,7 +112,7 @@ def main():
     for key, (sub, unit, src) in KERNELS.items():
         if key not in units:
             continue
-        match = [k for k in means if sub in k]
+        match = [k for k in means if (k.split("(")[0].strip() == sub[:-1] if sub.endswith("$") else sub in k)]
         if not match:
             print(f"no kernel matching {sub}", file=sys.stderr)
             continue
