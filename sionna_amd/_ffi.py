@@ -149,6 +149,8 @@ _SIGNATURES = {
     "samd_polar_scl_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "samd_polar_scl_decode_f32": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i32, _vp, _vp,
                                          _vp, _sz, _vp]),
+    "samd_polar5g_scl_decode_f32": (_i32, [_vp, _i32, _vp, _vp, _f32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i32,
+                                           _vp, _vp, _vp, _sz, _vp]),
     "samd_polar_scl_decode_f64": (_i32, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_uint32, _i32, _vp, _vp,
                                          _vp, _sz, _vp]),
     "samd_polar_scl_workspace_bytes_f64": (_sz, [_i32, _i32, _i32]),

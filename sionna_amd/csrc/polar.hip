@@ -493,10 +493,41 @@ extern "C" size_t samd_polar_scl_workspace_bytes(int batch, int n, int list_size
   return (size_t)grid * list_size * (size_t)n * (sizeof(float) + 1) + 512 + (size_t)n * sizeof(uint32_t) + 256;   // + CRC table
 }
 
+static int polar_scl_decode_f32(const float* llr, const int32_t* src_a, const int32_t* src_b, int n_in, float rm_fill, const int32_t* ops,
+                                int num_ops, const int32_t* info_pos, const int32_t* iil_inv, int batch, int n, int k, int list_size,
+                                int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat, float* crc_status, void* workspace,
+                                size_t workspace_bytes, void* stream);
+
 extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops, const int32_t* info_pos,
                                          const int32_t* iil_inv, int batch, int n, int k, int list_size, int sc_mode,
                                          uint32_t crc_poly, int crc_len, float* u_hat, float* crc_status,
                                          void* workspace, size_t workspace_bytes, void* stream) {
+  return polar_scl_decode_f32(llr, nullptr, nullptr, 0, 0.f, ops, num_ops, info_pos, iil_inv, batch, n, k, list_size, sc_mode, crc_poly,
+                              crc_len, u_hat, crc_status, workspace, workspace_bytes, stream);
+}
+
+// Polar5GDecoder.call (polar/decoding.py:1947-2100) with its rate recovery (:2018-2052) INSIDE the decoder's channel-LLR load:
+// llr [batch, n_in] as received; src_a / src_b DEVICE int32[n] (src_b nullable): position i of the mother code of length n reads
+// llr[src_a[i]] (-1: 0, punctured; -2: -rm_fill, shortened) + llr[src_b[i]] (repetition; -1: nothing).  Everything else as
+// samd_polar_scl_decode_f32.  SAMD_ERR_UNSUPPORTED when the (n, list_size, sc_mode) runs the generic engine (the host then
+// gathers and calls samd_polar_scl_decode_f32).
+extern "C" int samd_polar5g_scl_decode_f32(const float* llr, int n_in, const int32_t* src_a, const int32_t* src_b, float rm_fill,
+                                           const int32_t* ops, int num_ops, const int32_t* info_pos, const int32_t* iil_inv, int batch,
+                                           int n, int k, int list_size, int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat,
+                                           float* crc_status, void* workspace, size_t workspace_bytes, void* stream) {
+  SAMD_REQUIRE(src_a && n_in > 0, "bad argument");
+  if (!scl_reg_supported(n, list_size, sc_mode)) {
+    set_error("rate recovery inside the decoder: register engine only");
+    return SAMD_ERR_UNSUPPORTED;
+  }
+  return polar_scl_decode_f32(llr, src_a, src_b, n_in, rm_fill, ops, num_ops, info_pos, iil_inv, batch, n, k, list_size, sc_mode, crc_poly,
+                              crc_len, u_hat, crc_status, workspace, workspace_bytes, stream);
+}
+
+static int polar_scl_decode_f32(const float* llr, const int32_t* src_a, const int32_t* src_b, int n_in, float rm_fill, const int32_t* ops,
+                                int num_ops, const int32_t* info_pos, const int32_t* iil_inv, int batch, int n, int k, int list_size,
+                                int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat, float* crc_status, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   SAMD_REQUIRE(llr && ops && info_pos && u_hat && batch > 0, "bad argument");
   if (!workspace || workspace_bytes < samd_polar_scl_workspace_bytes(batch, n, list_size)) {
     set_error("workspace too small");
@@ -524,6 +555,7 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
   SclArgs p{llr, u_hat, crc_status, ops, num_ops, info_pos, iil_inv, gs, gb, (reg_engine && crc_len > 0) ? crc_tab : nullptr,
             scl_gstages(n, reg_engine), batch, n, m, k, list_size,
             sc_mode, crc_len, crc_poly};
+  p.src_a = src_a; p.src_b = src_b; p.n_in = n_in; p.rm_fill = rm_fill;
   // SC and list decoding with 1..32 paths of codes with n >= 64: the engine whose low stages live in registers (polar_scl_reg.hip)
   // (samd_polar_scl_register_stages() tells the host which engine runs, i.e. which subtree stage its schedule may use)
   if (reg_engine) return scl_reg_launch(p, grid, (hipStream_t)stream);

@@ -48,6 +48,13 @@ struct SclArgsT {          // R = float (both engines) or double (precision = "d
   int gstages;             // G
   int batch, n, m, k, L, sc_mode, crc_len;
   uint32_t crc_poly;
+  // Polar5GDecoder's rate recovery (decoding.py:2018-2052) as an index in the channel-LLR load (register engine; round 6):
+  // llr_in rows then have n_in values, position i of the mother code reads src_a[i] (>= 0: that received value, -1: 0 =
+  // punctured, -2: -rm_fill = shortened, known zero) and adds src_b[i] (repetition; null: none).  src_a null: llr_in is [B, n].
+  const int32_t* src_a = nullptr;
+  const int32_t* src_b = nullptr;
+  int n_in = 0;
+  R rm_fill = 0;
 };
 using SclArgs = SclArgsT<float>;
 

@@ -119,10 +119,23 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
   __syncthreads();
 
   for (int b = blockIdx.x; b < p.batch; b += gridDim.x) {
-    const float* llr_ch = p.llr_in + (size_t)b * n;    // logits: negated where they are read (LLR = -logit)
+    const float* llr_ch = p.llr_in + (size_t)b * (p.src_a ? p.n_in : n);    // logits: negated where they are read (LLR = -logit)
+    // channel value of mother-code position idx: the received row itself, or Polar5GDecoder's rate recovery as an index
+    // (the torch gathers in front of the kernel were four launches, ~3 % of a C5 step; decoding.py:2018-2052)
+    auto ch_val = [&](int idx) __attribute__((always_inline)) -> float {
+      if (!p.src_a) return llr_ch[idx];
+      const int ia = p.src_a[idx];
+      float v = ia >= 0 ? llr_ch[ia] : 0.f;
+      v = ia == -2 ? -p.rm_fill : v;
+      if (p.src_b) {
+        const int ib = p.src_b[idx];
+        v = v + (ib >= 0 ? llr_ch[ib] : 0.f);
+      }
+      return v;
+    };
     // value idx of the stage-s LLRs held by slot sl; every branch is wave-uniform and has its own address space
     auto ld_llr = [&](int sl, int s, int idx) __attribute__((always_inline)) -> float {
-      if (s == m) return -llr_ch[idx];
+      if (s == m) return -ch_val(idx);
       if (s < top) return llr3[sl * hn + (1 << s) + idx];
       return gsc[(size_t)sl * (n - hn) + ((1 << s) - hn) + idx];
     };
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
     // four consecutive values (idx a multiple of 4) - the upper stages hold >= 4 values per half
     auto ld_llr4 = [&](int sl, int s, int idx) __attribute__((always_inline)) -> float4 {
       if (s == m) {
-        if (!ch_aligned) return make_float4(-llr_ch[idx], -llr_ch[idx + 1], -llr_ch[idx + 2], -llr_ch[idx + 3]);
+        if (p.src_a || !ch_aligned) return make_float4(-ch_val(idx), -ch_val(idx + 1), -ch_val(idx + 2), -ch_val(idx + 3));
         const float4 v = *reinterpret_cast<const float4*>(llr_ch + idx);
         return make_float4(-v.x, -v.y, -v.z, -v.w);
       }

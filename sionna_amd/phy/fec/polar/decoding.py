@@ -129,7 +129,9 @@ class _PolarListDecoderBase(Block):
     info_pos = property(lambda self: self._info_pos)
     llr_max = property(lambda self: self._llr_max)
 
-    def _decode_2d(self, llr, want_status=False):
+    def _decode_2d(self, llr, want_status=False, rm=None):
+        """rm = (src_a, src_b or None, fill): Polar5GDecoder's rate recovery as an index inside the kernel's channel-LLR load
+        (samd_polar5g_scl_decode_f32; ``llr`` then has the received length) - the caller checked ``_rm_in_kernel()``"""
         if self._dev is None or self._dev_gen != _ffi.options_generation():   # (a development switch changed: rebuild)
             self._dev_gen = _ffi.options_generation()
             i32 = lambda a: _ffi.to_device(np.ascontiguousarray(a, np.int32), torch.int32)
@@ -152,11 +154,21 @@ class _PolarListDecoderBase(Block):
                 self._ws = _ffi.Workspace()
             ws, ws_bytes = self._ws.get((lib.samd_polar_scl_workspace_bytes_f64 if dbl else lib.samd_polar_scl_workspace_bytes)(
                 b, self._n, self._list_size))
-            _ffi.check((lib.samd_polar_scl_decode_f64 if dbl else lib.samd_polar_scl_decode_f32)(
-                _ffi.ptr(llr), _ffi.ptr(ops), ops.numel(), _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size,
-                self._sc_mode, self._crc_mask, self._crc_len, _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.ptr(ws), ws_bytes,
-                _ffi.stream()), type(self).__name__)
+            if rm is not None:
+                _ffi.check(lib.samd_polar5g_scl_decode_f32(
+                    _ffi.ptr(llr), int(llr.shape[1]), _ffi.ptr(rm[0]), _ffi.ptr(rm[1]), float(rm[2]), _ffi.ptr(ops), ops.numel(),
+                    _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size, self._sc_mode, self._crc_mask, self._crc_len,
+                    _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.ptr(ws), ws_bytes, _ffi.stream()), type(self).__name__)
+            else:
+                _ffi.check((lib.samd_polar_scl_decode_f64 if dbl else lib.samd_polar_scl_decode_f32)(
+                    _ffi.ptr(llr), _ffi.ptr(ops), ops.numel(), _ffi.ptr(info), _ffi.ptr(iil), b, self._n, self._k, self._list_size,
+                    self._sc_mode, self._crc_mask, self._crc_len, _ffi.ptr(u_hat), _ffi.ptr(status), _ffi.ptr(ws), ws_bytes,
+                    _ffi.stream()), type(self).__name__)
         return u_hat, status
+
+    def _rm_in_kernel(self):
+        """the register engine takes Polar5GDecoder's rate recovery as an index table (single precision)"""
+        return self.precision != "double" and _ffi.lib().samd_polar_scl_register_stages(self._n, self._list_size, self._sc_mode) >= 0
 
     def build(self, input_shape):
         if input_shape[-1] != self._n:
@@ -432,12 +444,21 @@ class Polar5GDecoder(Block):
                          torch.from_numpy(self._src_a == -2).to(dev), t(np.clip(self._src_b, 0, None)),
                          torch.from_numpy(self._src_b >= 0).to(dev), bool((self._src_b >= 0).any()))
         ia, ma, sa, ib, mb, has_b = self._dev
-        # index plumbing of the rate recovery (gathers only; decoding.py:2018-2052)
-        dec_in = torch.where(ma, x.index_select(1, ia), torch.zeros((), dtype=x.dtype, device=x.device))
-        dec_in = torch.where(sa, torch.full((), -self._llr_max, dtype=x.dtype, device=x.device), dec_in)
-        if has_b:
-            dec_in = dec_in + torch.where(mb, x.index_select(1, ib), torch.zeros((), dtype=x.dtype, device=x.device))
-        u_crc = self._polar_dec(dec_in.contiguous()).as_subclass(torch.Tensor)
+        pd = self._polar_dec
+        if isinstance(pd, _PolarListDecoderBase) and not getattr(pd, "_use_hybrid_sc", False) and pd._rm_in_kernel() and x.shape[0] > 0:
+            # the rate recovery (decoding.py:2018-2052) as an index inside the decoder's channel-LLR load: no gather launches
+            if getattr(self, "_rm_dev", None) is None or self._rm_gen != _ffi.options_generation():
+                self._rm_gen = _ffi.options_generation()
+                i32 = lambda a_: _ffi.to_device(np.ascontiguousarray(a_, np.int32), torch.int32)
+                self._rm_dev = (i32(self._src_a), i32(self._src_b) if has_b else None)
+            u_crc, _ = pd._decode_2d(x.contiguous(), False, rm=(self._rm_dev[0], self._rm_dev[1], self._llr_max))
+        else:
+            # index plumbing of the rate recovery (gathers only)
+            dec_in = torch.where(ma, x.index_select(1, ia), torch.zeros((), dtype=x.dtype, device=x.device))
+            dec_in = torch.where(sa, torch.full((), -self._llr_max, dtype=x.dtype, device=x.device), dec_in)
+            if has_b:
+                dec_in = dec_in + torch.where(mb, x.index_select(1, ib), torch.zeros((), dtype=x.dtype, device=x.device))
+            u_crc = self._polar_dec(dec_in.contiguous()).as_subclass(torch.Tensor)
         if self._iil:
             u_crc = u_crc.index_select(1, torch.from_numpy(self._ind_iil_inv.astype(np.int64)).to(u_crc.device))
         if self._return_crc_status:
