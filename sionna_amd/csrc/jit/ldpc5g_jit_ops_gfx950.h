@@ -61,6 +61,7 @@ JIT_DEV F32 g_ld_m(const float* row, U32 voff, M64 m) { return m ? *(const float
 JIT_DEV void g_st_m(float* row, U32 voff, M64 m, F32 v) {
   if (m) *(float*)((char*)row + voff) = v;
 }
+JIT_DEV unsigned jit_bcast_u(unsigned x) { return x; }
 JIT_DEV F32 jit_bcast(float x) { return x; }
 JIT_DEV F32 f_med3(F32 a, F32 b, F32 c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 JIT_DEV F32 f_abs(F32 a) { return __builtin_fabsf(a); }

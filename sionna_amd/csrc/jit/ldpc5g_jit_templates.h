@@ -82,6 +82,8 @@ JIT_DEV U32 jit_vn_addr_g(U32 p, U32 z, unsigned sh, unsigned blk) {
 }
 // lanes whose own node z sits in the HIGH half of that slot: (z - s) mod Z >= H
 JIT_DEV M64 jit_vn_swap_g(U32 z, unsigned sh, bool hi) { return m_xor_c(u_lt(z, sh), hi); }
+// a slot = copy z of two codewords: a rotation moves both alike, the pair is never swapped (the selections fold away)
+JIT_DEV M64 jit_no_swap() { return u_lt(jit_bcast_u(1u), 0u); }
 // rate recovery (decoding.py:1438-1475, encoding.py:238-244) for VN v of the group's codeword g: byte offset of its element
 // in the group's received rows, or a sentinel
 JIT_DEV U32 jit_in_off(U32 v, U32 g, M64 act) {

@@ -33,8 +33,10 @@ struct JitPlan {
 
 // how the any-lifting-size programs map lifted copies onto lanes (jit/ldpc5g_jit_templates.h, JIT_GENERAL)
 struct JitGeometry {
-  int G = 1;        // codewords per workgroup
-  int H = 0;        // Z / 2: a lane owns copies (z, z + H)
+  int G = 1;        // codewords per workgroup (pairx: PAIRS of codewords)
+  int pairx = 0;    // 1: a slot's two values are copy z of TWO codewords (2 g, 2 g + 1) - any Z, odd ones too, a rotation never
+                    // swaps the pair (no selections in the variable-node phase); 0: copies (z, z + Z / 2) of ONE codeword
+  int H = 0;        // the rotation's period in lanes: Z / 2 (a lane owns copies (z, z + H)), or Z with pairx
   int P = 0;        // G H lanes in use
   int chunks = 0;   // 64-lane chunks per edge block
   int blk = 0;      // bytes per edge block (512 per chunk)
@@ -64,6 +66,7 @@ struct JitKnobs {
   int phi_rolled = 1;     // boxplus-phi: the check-node loops over a row's edges rolled (one phi body per pass) instead of unrolled
   int general = 0;        // 1: the any-lifting-size programs also for the codes of the Z = 128 class (A/B)
   int group = 0, wgs = 0; // any-lifting-size programs: codewords per workgroup / workgroups per CU (0: chosen by the generator)
+  int pairx = -1;         // -1: by the generator; 0 / 1: pairs inside a codeword / across two codewords
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
 };

@@ -77,7 +77,9 @@ struct UniStream {
   }
 };
 
-__global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t call, int B, int RA, int TA, int P,
+typedef float tdl_f32x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void tdl_cir_kernel(uint64_t seed, uint64_t call, int B, int RA, int TA, int P,
                                                       int T, int N, float sampling_frequency,
                                                       const float* __restrict__ mean_powers, float min_doppler,
                                                       float max_doppler, int los, float los_power, float los_aoa,
@@ -114,18 +116,26 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
         }
     }
     for (int t0 = 0; t0 < T; t0 += kChunk) {
-      float accx[kChunk], accy[kChunk];
+      // (cos, sin) pairs in packed registers (round 6): accumulate = one v_pk_add_f32, rotate = two v_pk_mul_f32 + one
+      // v_pk_add_f32 - (c, s) cw + (-s, c) sw, the same products and the same sum as c cw - s sw / s cw + c sw, no contraction -
+      // instead of eight scalar operations per step; the steps beyond T of the last chunk are not computed
+      tdl_f32x2 acc[kChunk];
 #pragma unroll
-      for (int k = 0; k < kChunk; ++k) accx[k] = accy[k] = 0.f;
+      for (int k = 0; k < kChunk; ++k) acc[k] = tdl_f32x2{0.f, 0.f};
+      const int kmax = T - t0 < kChunk ? T - t0 : kChunk;
       auto one = [&](float ca, float phi) {
         float sn, cs, sw, cw;
         sincosf(doppler * ((float)t0 / sampling_frequency) * ca + phi, &sn, &cs);
         sincosf(doppler * (1.f / sampling_frequency) * ca, &sw, &cw);
+        tdl_f32x2 v = {cs, sn};
+        const tdl_f32x2 cw2 = {cw, cw}, sw2 = {sw, sw};
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
-          accx[k] += cs; accy[k] += sn;
-          const float c2 = cs * cw - sn * sw, s2 = sn * cw + cs * sw;
-          cs = c2; sn = s2;
+          if (k < kmax) {
+            acc[k] += v;
+            const tdl_f32x2 rot = {-v.y, v.x};
+            v = v * cw2 + rot * sw2;
+          }
         }
       };
       if (cached) {
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256) void tdl_cir_kernel(uint64_t seed, uint64_t ca
       for (int k = 0; k < kChunk; ++k) {
         const int t = t0 + k;
         if (t < T) {
-          float2 h = make_float2(amp * (accx[k] * norm), amp * (accy[k] * norm));
+          float2 h = make_float2(amp * (acc[k].x * norm), amp * (acc[k].y * norm));
           if (los && p == 0) {
             const float arg = doppler * ((float)t / sampling_frequency) * cosf(los_aoa) + phi0;
             float sn, cs;

@@ -187,6 +187,7 @@ JIT_DEV void g_st_m(float* row, const U32& voff, const M64& m, const F32& x) {
   for (int i = 0; i < 64; ++i)
     if (m.v[i] && jit_emu_exec[i]) memcpy((char*)row + voff.v[i], &x.v[i], 4);
 }
+JIT_DEV U32 jit_bcast_u(unsigned x) { return U32(x); }
 JIT_DEV F32 jit_bcast(float x) { return F32(x); }
 JIT_DEV float jit_emu_med3(float a, float b, float c) {      // v_med3_f32 on ordinary values: the middle operand itself
   if (a <= b) return b <= c ? b : (a <= c ? c : a);

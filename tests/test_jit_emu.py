@@ -150,7 +150,7 @@ def test_generated_programs_any_lifting_size_match_oracle(tmp_path, k, n, bg, m,
 def test_jit_class_boundaries():
     """odd lifting sizes and codes whose messages exceed LDS keep the generic kernels; every other code has a generated one"""
     from sionna_amd import _ffi
-    for k, n, bg, m, want in ((1024, 2048, "bg1", None, 1), (2816, 8436, "bg1", 6, 1), (768, 1536, None, 2, 1), (30, 90, None, None, 0),
+    for k, n, bg, m, want in ((1024, 2048, "bg1", None, 1), (2816, 8436, "bg1", 6, 1), (768, 1536, None, 2, 1), (30, 90, None, None, 1),
                               (8448, 25344, "bg1", None, 0)):
         h, enc, _ = jit_dump.host_only_handle(k, n, m, bg, return_obj=True)
         assert _ffi.lib().samd_ldpc5g_jit_supported(h) == want, (k, n, bg, m, enc._z)
