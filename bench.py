@@ -371,6 +371,17 @@ def bench_c4(args, short=False):
                                  "traffic": int(rec_tdl["hbm_bytes_per_unit"] * rec_tdl["units_per_launch"]) if rec_tdl else None,
                                  "output_bytes": int(a_t.numel()) * 8}}}
     del a_t, tau_t
+    # the channel stage as the chain runs it (round 6): OFDMChannel = tdl_cir + ONE launch for cir_to_ofdm_channel + ApplyOFDMChannel
+    # (cir_to_ofdm_fused_kernel: h_freq, 558 MB here, is deferred and never written) + awgn_kernel in place on y
+    x_rg = rgm(mapper(enc(src([B, 1, 2, k]))))
+    ms_stage = timed(lambda: ch(x_rg, no), 5)
+    with _ffi.option("SAMD_NO_FUSED_CHANNEL"):
+        ms_stage_sep = timed(lambda: ch(x_rg, no), 5)
+    channel_kernels["ofdm_channel_stage"] = {
+        "what": "OFDMChannel(TDL-A, normalize_channel, return_channel=True)(x, no): tdl_cir + cir_to_ofdm_fused (h_freq deferred) + awgn",
+        "ms_per_call": round(ms_stage, 4), "ms_per_call_separate_kernels": round(ms_stage_sep, 4),
+        "note": "separate = cir_to_ofdm_pass + apply_ofdm_channel + awgn with h_freq materialised (SAMD_NO_FUSED_CHANNEL)"}
+    del x_rg
     n_data_re = B * rg.num_data_symbols
     ach = n_data_re * 120 / (ms * 1e-3) / 1e9
     t0 = time.perf_counter()

@@ -459,10 +459,19 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
       }
     }
   }
+  // Which rows a thread owns (round 6).  grouped: group g owns the UNITS u = (ra, t) with u mod G = g and of each all TA transmit
+  // antennas, local row r = (u / G) TA + ta - the sum over the transmit antennas of ApplyOFDMChannel then stays inside a thread
+  // (the fused kernel needs no exchange of products).  Needs RPT a multiple of TA; else rows g, g + G, ... of (ra, ta, t) order.
+  const bool grouped = (RPT % TA) == 0;
+  if (grouped) {
+    for (int i = tid; i < rows_pad * MAXP; i += nt) taps[i] = make_float2(0.f, 0.f);
+    __syncthreads();
+  }
   {
     // taps: source order (ra | ta, p, t) with t fastest - consecutive lanes on consecutive addresses - transposed into [row][p]
     const unsigned pt = (unsigned)(P * T), lpt = (unsigned)TA * pt, total = (unsigned)RA * lpt;
     const unsigned m_lpt = magic(lpt), m_pt = magic(pt), m_t = magic((unsigned)T);
+    const unsigned m_ta = magic((unsigned)TA), m_g = magic((unsigned)G);
     const float2* src = a + (((size_t)(b * RX + rx) * RA) * TX + tx) * (size_t)lpt;
     const size_t ra_stride = (size_t)TX * lpt;
     for (unsigned i0 = (unsigned)tid; i0 < total; i0 += (unsigned)(KB * nt)) {
@@ -481,16 +490,24 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
         if (i < total) {
           const unsigned lk = divu(i, pt, m_pt), q = i - lk * pt;
           const unsigned pp = divu(q, (unsigned)T, m_t), t = q - pp * (unsigned)T;
-          taps[(lk * (unsigned)T + t) * MAXP + pp] = v[k];
+          unsigned row = lk * (unsigned)T + t;
+          if (grouped) {                                          // unit u = (ra, t) -> group u mod G, local rows (u / G) TA + ta
+            const unsigned ra = divu(lk, (unsigned)TA, m_ta), ta = lk - ra * (unsigned)TA;
+            const unsigned u = ra * (unsigned)T + t, j = divu(u, (unsigned)G, m_g);
+            row = (u - j * (unsigned)G) + (j * (unsigned)TA + ta) * (unsigned)G;
+          }
+          taps[row * MAXP + pp] = v[k];
         }
       }
     }
-    const int zp = MAXP - P;                                      // zero columns of the real rows, zero rows behind them
-    for (int i = tid; i < rows * zp; i += nt) {
-      const int row = i / zp;
-      taps[(unsigned)(row * MAXP + P + (i - row * zp))] = make_float2(0.f, 0.f);
+    if (!grouped) {
+      const int zp = MAXP - P;                                    // zero columns of the real rows, zero rows behind them
+      for (int i = tid; i < rows * zp; i += nt) {
+        const int row = i / zp;
+        taps[(unsigned)(row * MAXP + P + (i - row * zp))] = make_float2(0.f, 0.f);
+      }
+      for (int i = rows * MAXP + tid; i < rows_pad * MAXP; i += nt) taps[i] = make_float2(0.f, 0.f);
     }
-    for (int i = rows * MAXP + tid; i < rows_pad * MAXP; i += nt) taps[i] = make_float2(0.f, 0.f);
   }
   __syncthreads();
   c2o_f32x2 acc[RPT];
@@ -557,52 +574,47 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
     const float c = sqrtf(e / (float)(rows * F));
     inv = c > 0.f ? 1.f / c : 0.f;                               // divide_no_nan
   }
+  // local row r of group g -> (ra, ta, t): a running state (r is a compile-time index of the result registers, TA is not)
+  struct RowWalk {
+    int u, ta, t, ra;          // grouped: unit, antenna;  else: (t, ta, ra) of row g + r G
+    bool grouped;
+    int G_, T_, TA_;
+    unsigned mT;
+    __device__ __forceinline__ void init(int g_, bool gr, int Gq, int Tq, int TAq, unsigned m) {
+      grouped = gr; G_ = Gq; T_ = Tq; TA_ = TAq; mT = m;
+      if (gr) { u = g_; ta = 0; ra = (int)(Tq > 1 ? __umulhi((unsigned)g_, m) : (unsigned)g_); t = g_ - ra * Tq; }
+      else { u = 0; t = g_ % Tq; ta = (g_ / Tq) % TAq; ra = (g_ / Tq) / TAq; }
+    }
+    __device__ __forceinline__ void step() {
+      if (grouped) {
+        const bool w = ++ta == TA_;                               // wave-uniform
+        if (w) {
+          ta = 0; u += G_;
+          ra = (int)(T_ > 1 ? __umulhi((unsigned)u, mT) : (unsigned)u); t = u - ra * T_;
+        }
+      } else {
+        t += G_;
+        while (t >= T_) { t -= T_; if (++ta == TA_) { ta = 0; ++ra; } }
+      }
+    }
+  };
+  const unsigned m_T = magic((unsigned)T);
   if constexpr (FUSED) {
-    // products h x: the rows with ta >= 1 into the LDS of the (dead) tables, [(ra (TA - 1) + ta - 1) T + t][f]; the rows with
-    // ta = 0 stay in their result registers.  The x values are requested in batches of 8 rows before the first is used (one
-    // round trip per batch: row by row, a workgroup's life grew by two thirds - 562 against 343 us, profiles/r06h).
-    float2* stage = tab;
+    // y = sum over the transmit antennas of h x (+ noise): the group's units keep their TA rows in this thread's registers, x of
+    // this batch item (TA T F values, the same for every receive antenna) comes through the LDS of the dead phase / tap tables -
+    // one coalesced load per workgroup instead of 24 scattered ones per thread (host: grouped, x fits the tables' LDS)
+    float2* xs = tab;
     const float2* xb = fu.x + (size_t)b * TA * T * F;
     __syncthreads();                                              // every wave is through its FMA loop
-    // row g + r G -> (ra, ta, t) as a running state advanced with selections (G <= T, host-checked: at most one wrap per step):
-    // the x loads of a batch must not sit behind data-dependent control flow, or each one waits for the one before
-    struct RowPos {
-      int t, ta, ra;
-      __device__ __forceinline__ void step(int G_, int T_, int TA_) {
-        t += G_;
-        const bool w = t >= T_;
-        t -= w ? T_ : 0;
-        ta += w ? 1 : 0;
-        const bool w2 = ta >= TA_;
-        ta = w2 ? 0 : ta;
-        ra += w2 ? 1 : 0;
-      }
-    };
-    const RowPos pos0{g % T, (g / T) % TA, (g / T) / TA};
     {
-      RowPos pl = pos0, pc = pos0;
-      // (the three walks over the rows are the same sequence: left visible, the compiler keeps all 24 positions of one walk
-      // alive for the others - 121 spilled registers)
-      asm volatile("" : "+v"(pc.t), "+v"(pc.ta), "+v"(pc.ra));
+      const int nx = TA * T * F;
+      for (int i0x = tid; i0x < nx; i0x += KB * nt) {
+        float2 xv[KB];
 #pragma unroll
-      for (int r0 = 0; r0 < RPT; r0 += 8) {
-        float2 xv[8];
+        for (int k = 0; k < KB; ++k) xv[k] = xb[min(i0x + k * nt, nx - 1)];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const bool ok = act && pl.ra < RA;
-          xv[k] = xb[ok ? (unsigned)((pl.ta * T + pl.t) * F + f) : 0u];
-          pl.step(G, T, TA);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const int r = r0 + k;
-          const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);          // the value cir_to_ofdm stores
-          const float2 pr = cmul(hv, xv[k]);
-          if (act && pc.ra < RA && pc.ta >= 1) stage[(unsigned)(((pc.ra * (TA - 1) + pc.ta - 1) * T + pc.t) * F + f)] = pr;
-          acc[r] = c2o_f32x2{pr.x, pr.y};
-          pc.step(G, T, TA);
-        }
-        asm volatile("" ::: "memory");                           // (the next batch's loads stay behind this batch: registers)
+        for (int k = 0; k < KB; ++k)
+          if (i0x + k * nt < nx) xs[i0x + k * nt] = xv[k];
       }
     }
     __syncthreads();
@@ -612,44 +624,39 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
     float2* yb = fu.y + ((size_t)(b * RX + rx) * RA) * (size_t)T * F;
     const uint64_t i0 = ((uint64_t)(b * RX + rx) * RA) * (uint64_t)T * F;
     (void)i0;
-    {
-      RowPos ps = pos0;
-      asm volatile("" : "+v"(ps.t), "+v"(ps.ta), "+v"(ps.ra));
+    RowWalk w;
+    w.init(g, true, G, T, TA, m_T);
+    float2 sy = make_float2(0.f, 0.f);
 #pragma unroll
-      for (int r = 0; r < RPT; ++r) {
-        const int t = ps.t, ta = ps.ta, ra = ps.ra;
-        ps.step(G, T, TA);
-        if (act && ra < RA && ta == 0) {
-          float2 v = make_float2(acc[r].x, acc[r].y);
-          float2 s = make_float2(0.f, 0.f);                       // apply_ofdm_channel_kernel: acc = 0; acc += v_k, k ascending
-          s.x += v.x; s.y += v.y;
-          for (int k = 1; k < TA; ++k) {
-            v = stage[(unsigned)(((ra * (TA - 1) + k - 1) * T + t) * F + f)];
-            s.x += v.x; s.y += v.y;
-          }
-          const unsigned rel = (unsigned)((ra * T + t) * F + f);
-          if (C2O_FUSED_NOISE && fu.no) {                         // awgn_kernel: element i takes half (i & 1) of Philox block i / 2
-            const uint64_t i = i0 + rel;
-            const uint4 rr = philox_block(fu.seed, fu.call, i >> 1);
-            const float2 w = (i & 1) ? c2o_box_muller(rr.z, rr.w) : c2o_box_muller(rr.x, rr.y);
-            s = make_float2(s.x + (w.x * sh) * sn, s.y + (w.y * sh) * sn);
-          }
-          yb[rel] = s;
+    for (int r = 0; r < RPT; ++r) {
+      const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);            // the value cir_to_ofdm stores
+      const float2 v = cmul(hv, xs[(unsigned)((w.ta * T + w.t) * F + f)]);
+      if (w.ta == 0) sy = make_float2(0.f, 0.f);                  // apply_ofdm_channel_kernel: acc = 0; acc += v_k, k ascending
+      sy.x += v.x; sy.y += v.y;
+      if (w.ta == TA - 1 && act && w.ra < RA) {
+        const unsigned rel = (unsigned)((w.ra * T + w.t) * F + f);
+        float2 so = sy;
+        if (C2O_FUSED_NOISE && fu.no) {                           // awgn_kernel: element i takes half (i & 1) of Philox block i / 2
+          const uint64_t i = i0 + rel;
+          const uint4 rr = philox_block(fu.seed, fu.call, i >> 1);
+          const float2 wn = (i & 1) ? c2o_box_muller(rr.z, rr.w) : c2o_box_muller(rr.x, rr.y);
+          so = make_float2(so.x + (wn.x * sh) * sn, so.y + (wn.y * sh) * sn);
         }
+        yb[rel] = so;
       }
+      w.step();
     }
     return;
   }
   float2* ob = out + ((size_t)(b * RX + rx) * RA) * TX * TA * (size_t)T * F;
   {
-    int t = g % T, lk = g / T;
-    int ta = lk % TA, ra = lk / TA;
+    RowWalk w;
+    w.init(g, grouped, G, T, TA, m_T);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
-      if (act && ra < RA)
-        ob[(unsigned)((((ra * TX + tx) * TA + ta) * T + t) * F + f)] = make_float2(acc[r].x * inv, acc[r].y * inv);
-      t += G;
-      while (t >= T) { t -= T; if (++ta == TA) { ta = 0; ++ra; } }
+      if (act && w.ra < RA)
+        ob[(unsigned)((((w.ra * TX + tx) * TA + w.ta) * T + w.t) * F + f)] = make_float2(acc[r].x * inv, acc[r].y * inv);
+      w.step();
     }
   }
 }
@@ -825,9 +832,11 @@ extern "C" int samd_ofdm_channel_fused_c64(const float* a, const float* tau, con
   const int mp = num_paths <= 8 ? 8 : num_paths <= 16 ? 16 : num_paths <= 24 ? 24 : num_paths <= 32 ? 32 : 0;
   if (!best_nt || !mp) { set_error("fused OFDM channel: shape outside the staged-register kernel"); return SAMD_ERR_UNSUPPORTED; }
   const size_t lds_p = ((size_t)mp * num_freqs + (size_t)(((best_rpt + 7) / 8) * 8) * (best_nt / num_freqs) * mp) * sizeof(float2) + 64;
-  const size_t stage_b = (size_t)num_rx_ant * (num_tx_ant - 1) * num_time_steps * num_freqs * sizeof(float2);
-  const size_t lds_f = std::max(lds_p, stage_b + 64);          // (few paths: the staged products need more than the tables)
-  if (lds_f > 64 * 1024 || (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant >= 8192 || best_nt / num_freqs > num_time_steps) {
+  const size_t stage_b = (size_t)num_tx_ant * num_time_steps * num_freqs * sizeof(float2);   // x of one batch item, staged in LDS
+  const size_t lds_f = std::max(lds_p, stage_b + 64);          // (few paths: x needs more than the tables)
+  const int rpt_pad = ((best_rpt + 7) / 8) * 8;
+  if (lds_f > 64 * 1024 || (size_t)num_paths * num_time_steps * num_rx_ant * num_tx_ant >= 8192 || rpt_pad % num_tx_ant != 0 ||
+      (size_t)(rpt_pad / num_tx_ant) * (best_nt / num_freqs) < (size_t)num_rx_ant * num_time_steps) {
     set_error("fused OFDM channel: shape outside the staged-register kernel");
     return SAMD_ERR_UNSUPPORTED;
   }
