@@ -384,6 +384,8 @@ def bench_c4(args, short=False):
     del x_rg
     n_data_re = B * rg.num_data_symbols
     ach = n_data_re * 120 / (ms * 1e-3) / 1e9
+    chain()                                   # (handles rebuilt after the development switch above: not part of the timing)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     reps = 2 if short else 3
     for _ in range(reps):
