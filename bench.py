@@ -139,7 +139,7 @@ def onchip_roofline(kernel_key, kernel_name, units, ms, extra=None):
                         "lds_pipe": {"cycles_per_decode": rec["lds_pipe_cycles_per_unit"], "static": rec.get("static")},
                         "icache": rec.get("icache")})
     else:
-        out["note"] = "profiles/counters.json has no entry for this kernel: run tools/gpu_pmc.sh + tools/pmc_counters.py"
+        out["note"] = "profiles/counters.json has no entry for this kernel: run `bash tools/gpu_trip.sh <tag> pmc` (tools/pmc_counters.py)"
     if extra:
         out.update(extra)
     return out

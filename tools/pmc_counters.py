@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""rocprofv3 --pmc output (tools/gpu_pmc.sh) -> profiles/counters.json: per-UNIT counters of the dominant kernels, which
+"""rocprofv3 --pmc output (tools/gpu_trip.sh <tag> pmc) -> profiles/counters.json: per-UNIT counters of the dominant kernels, which
 bench.py combines with the launch duration it measures live (roofline.achieved = instructions per unit x units / time).
 
     python tools/pmc_counters.py gpurun_out/pmc_<tag> --tag <tag> ldpc5g_ms=65536 ldpc5g_bp=65536 polar_scl=32768 ofdm_lmmse=6291456
