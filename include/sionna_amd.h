@@ -734,7 +734,7 @@ int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, int num_ops,
                               int sc_mode, uint32_t crc_poly, int crc_len, float* u_hat,
                               float* crc_status, void* workspace, size_t workspace_bytes,
                               void* stream);
-/* Polar5GDecoder.call (polar/decoding.py:1947-2100) with its rate recovery (:2018-2052) inside the decoder's channel-LLR load:
+/* Polar5GDecoder.call (polar/decoding.py:1999-2086) with its rate recovery (:2018-2052) inside the decoder's channel-LLR load:
  * llr [batch,n_in] as received; src_a / src_b DEVICE int32[n] (src_b nullable): position i of the mother code reads llr[src_a[i]]
  * (-1: 0 = punctured, -2: -rm_fill = shortened) + llr[src_b[i]] (repetition; -1: nothing).  The rest as samd_polar_scl_decode_f32.
  * SAMD_ERR_UNSUPPORTED when (n, list_size, sc_mode) runs the generic engine: gather on the host side and call that entry. */

@@ -506,7 +506,7 @@ extern "C" int samd_polar_scl_decode_f32(const float* llr, const int32_t* ops, i
                               crc_len, u_hat, crc_status, workspace, workspace_bytes, stream);
 }
 
-// Polar5GDecoder.call (polar/decoding.py:1947-2100) with its rate recovery (:2018-2052) INSIDE the decoder's channel-LLR load:
+// Polar5GDecoder.call (polar/decoding.py:1999-2086) with its rate recovery (:2018-2052) INSIDE the decoder's channel-LLR load:
 // llr [batch, n_in] as received; src_a / src_b DEVICE int32[n] (src_b nullable): position i of the mother code of length n reads
 // llr[src_a[i]] (-1: 0, punctured; -2: -rm_fill, shortened) + llr[src_b[i]] (repetition; -1: nothing).  Everything else as
 // samd_polar_scl_decode_f32.  SAMD_ERR_UNSUPPORTED when the (n, list_size, sc_mode) runs the generic engine (the host then
