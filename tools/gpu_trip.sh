@@ -16,7 +16,7 @@ for step in "$@"; do
     sweep) timeout 1500 python tools/ldpc_size_sweep.py --out $OUT/ldpc_size_sweep.json 2>&1 | tee $OUT/ldpc_size_sweep.txt ;;
     sweep_quick) timeout 900 python tools/ldpc_size_sweep.py --quick --out $OUT/ldpc_size_sweep_quick.json 2>&1 | tee $OUT/ldpc_size_sweep_quick.txt ;;
     bench) timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; tail -c 6000 $OUT/bench.json ;;
-    bench_prof) (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 > $OUT/bench_prof.json 2> $OUT/bench_prof.err); python tools/prof_summary.py $OUT/prof > $OUT/kernel_stats.txt 2>&1; head -40 $OUT/kernel_stats.txt ;;
+    bench_prof) (cd /tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 > $OUT/bench_prof.json 2> $OUT/bench_prof.err); python tools/prof_summary.py $OUT/prof/bench_results.db > $OUT/kernel_stats.txt 2>&1; head -40 $OUT/kernel_stats.txt ;;
     pmc)  # PMC passes for the kernels of the default bench command (separate runs, --pmc with --kernel-trace only), then the
           # per-unit counters file bench.py reads (copy $OUT/pmc/counters.json to profiles/counters.json, summary to profiles/)
       mkdir -p $OUT/pmc
