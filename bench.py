@@ -807,15 +807,20 @@ def main():
         def counting_cpu(self_, *a, **kw):              # device -> host reads inside sim_ber = its synchronisations
             flushes["n"] += 1
             return orig_cpu(self_, *a, **kw)
+        import contextlib
+        import io
+        quiet = contextlib.redirect_stdout(io.StringIO())           # (sim_ber announces the distribution on stdout: this file prints ONE line)
         for tag, kw in (("target_block_errors", {"num_target_block_errors": 10 ** 12}), ("no_target", {})):
-            phy.utils.sim_ber(mc_fun, points[:1], B, 1, verbose=False, distribute=("all" if world > 1 else None), **kw)   # warm
+            with quiet:
+                phy.utils.sim_ber(mc_fun, points[:1], B, world, verbose=False, distribute=("all" if world > 1 else None), **kw)   # warm
             barrier(world, torch.cuda.synchronize)
             flushes["n"] = 0
             torch.Tensor.cpu = counting_cpu
             try:
                 t0 = time.perf_counter()
-                ber_s, bler_s = phy.utils.sim_ber(mc_fun, points, B, n_mc * world, early_stop=True, verbose=False,
-                                                  distribute=("all" if world > 1 else None), **kw)
+                with quiet:
+                    ber_s, bler_s = phy.utils.sim_ber(mc_fun, points, B, n_mc * world, early_stop=True, verbose=False,
+                                                      distribute=("all" if world > 1 else None), **kw)
                 barrier(world, torch.cuda.synchronize)
                 t_s = time.perf_counter() - t0
             finally:
