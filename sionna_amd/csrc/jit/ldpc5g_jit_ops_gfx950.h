@@ -57,6 +57,14 @@ JIT_DEV U32 u_shl(U32 a, int n) { return a << n; }
 JIT_DEV U32 u_shr(U32 a, int n) { return a >> n; }
 JIT_DEV F32 g_ld(const float* row, U32 voff, unsigned coff) { return *(const float*)((const char*)row + (voff + coff)); }
 JIT_DEV void g_st(float* row, U32 voff, unsigned coff, F32 v) { *(float*)((char*)row + (voff + coff)) = v; }
+// a message pair in the workgroup's row of the workspace (L2): 8-byte access at a per-lane byte offset
+JIT_DEV void gm_ld2(const float* ws, U32 a, unsigned off, F32& x0, F32& x1) {
+  const jit_f32x2 v = *(const jit_f32x2*)((const char*)ws + (a + off));
+  x0 = v.x; x1 = v.y;
+}
+JIT_DEV void gm_st2(float* ws, U32 a, unsigned off, F32 x0, F32 x1) { *(jit_f32x2*)((char*)ws + (a + off)) = jit_f32x2{x0, x1}; }
+// ... a phase then exchanges data through L2 as well: wait for the vector memory operations too
+JIT_DEV void jit_barrier_g() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 JIT_DEV F32 g_ld_m(const float* row, U32 voff, M64 m) { return m ? *(const float*)((const char*)row + voff) : 0.f; }
 JIT_DEV void g_st_m(float* row, U32 voff, M64 m, F32 v) {
   if (m) *(float*)((char*)row + voff) = v;

@@ -117,22 +117,37 @@ JIT_DEV void jit_st_out(float* orows, U32 off, U32 g, int rem, F32 x, float llr_
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------- where a message pair lives
+// Codes whose messages exceed LDS (Z >= 256 at low rate; round 6): the edge blocks of the LAST base rows live in the workgroup's
+// row of a caller-owned workspace (it stays in L2) instead of LDS.  SP = the block is there: the address is a byte offset into
+// that row.  A column's edges to those rows are its last ones (rows ascending), so the order of every sum is unchanged.
+template <bool SP>
+JIT_DEV void msg_ld2(const float* ws, U32 a, unsigned off, F32& x0, F32& x1) {
+  if (SP) gm_ld2(ws, a, off, x0, x1);
+  else lds_ld2(a, off, x0, x1);
+}
+template <bool SP>
+JIT_DEV void msg_st2(float* ws, U32 a, unsigned off, F32 x0, F32 x1) {
+  if (SP) gm_st2(ws, a, off, x0, x1);
+  else lds_st2(a, off, x0, x1);
+}
+
 // ---------------------------------------------------------------------------------------------- check node row
 // a0 = byte address of the lane's slot in the row's first block (chunk 0 of the item); NCH chunks of 64 lifted copies
-template <int D, int NCH>
-JIT_DEV void jit_cn_load(F32 (&v)[D][NCH], U32 a0) {
+template <int D, int NCH, bool SP = false>
+JIT_DEV void jit_cn_load(F32 (&v)[D][NCH], U32 a0, float* ws = nullptr) {
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    if (JIT_LAYOUT_B && NCH == 2) lds_ld2(a0, (unsigned)i * JIT_Z4, v[i][0], v[i][NCH - 1]);
+    if (JIT_LAYOUT_B && NCH == 2) msg_ld2<SP>(ws, a0, (unsigned)i * JIT_Z4, v[i][0], v[i][NCH - 1]);
     else {
 #pragma unroll
       for (int h = 0; h < NCH; ++h) v[i][h] = lds_ld(a0, (unsigned)i * JIT_Z4 + JIT_CH * h);
     }
   }
 }
-template <int NCH>
-JIT_DEV void jit_cn_store(U32 a0, unsigned off, const F32 (&c)[NCH]) {
-  if (JIT_LAYOUT_B && NCH == 2) lds_st2(a0, off, c[0], c[NCH - 1]);
+template <int NCH, bool SP = false>
+JIT_DEV void jit_cn_store(U32 a0, unsigned off, const F32 (&c)[NCH], float* ws = nullptr) {
+  if (JIT_LAYOUT_B && NCH == 2) msg_st2<SP>(ws, a0, off, c[0], c[NCH - 1]);
   else {
 #pragma unroll
     for (int h = 0; h < NCH; ++h) lds_st(a0, off + JIT_CH * h, c[h]);
@@ -146,12 +161,12 @@ JIT_DEV void jit_cn_store(U32 a0, unsigned off, const F32 (&c)[NCH]) {
 #endif
 // xo[h] (FUSE): total of the fused degree-1 VN, for the generated code's output store after the last iteration.
 // PRUNE: lanes of pm[h] are check nodes the rate matching pruned (decoding.py:1344-1373) - they send 0 on every edge.
-template <int D, int NCH, bool FUSE, bool PRUNE = false>
+template <int D, int NCH, bool FUSE, bool PRUNE = false, bool SP = false>
 JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float llr_max, float offset, F32 (&xo)[NCH],
-                           const M64 (&pm)[NCH]) {
+                           const M64 (&pm)[NCH], float* ws = nullptr) {
   if (JIT_ABL & 1) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) jit_cn_store<NCH>(a0, (unsigned)i * JIT_Z4, v[i]);
+    for (int i = 0; i < D; ++i) jit_cn_store<NCH, SP>(a0, (unsigned)i * JIT_Z4, v[i], ws);
 #pragma unroll
     for (int h = 0; h < NCH; ++h) xo[h] = 0.f;
     return;
@@ -242,7 +257,7 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
         c2v[h] = f_med3(x - c2v[h], -llr_max, llr_max);   // the slot now holds the next v2c
       }
     }
-    jit_cn_store<NCH>(a0, (unsigned)i * JIT_Z4, c2v);
+    jit_cn_store<NCH, SP>(a0, (unsigned)i * JIT_Z4, c2v, ws);
   }
 }
 
@@ -415,9 +430,9 @@ JIT_DEV void jit_cn_phi_rolled(U32 a0, int D, const F32 (&lf)[2], float llr_max,
 #endif
 
 // v2c of iteration 0 for the fused degree-1 column of a row: its channel LLR
-template <int D, int NCH>
-JIT_DEV void jit_cn_init_fused(U32 a0, const F32 (&lf)[NCH]) {
-  jit_cn_store<NCH>(a0, (unsigned)(D - 1) * JIT_Z4, lf);
+template <int D, int NCH, bool SP = false>
+JIT_DEV void jit_cn_init_fused(U32 a0, const F32 (&lf)[NCH], float* ws = nullptr) {
+  jit_cn_store<NCH, SP>(a0, (unsigned)(D - 1) * JIT_Z4, lf, ws);
 }
 
 // ---------------------------------------------------------------------------------------------- variable node column
@@ -442,21 +457,27 @@ JIT_DEV void jit_vn_init(const U32 (&a)[D][NCH], const F32 (&l)[NCH]) {
 
 // ---- interleaved layout, pair items: a[i] = byte address of slot (lane - shift_i) mod 64 in the block of edge i, sw[i] = the
 // lanes whose node `lane` (chunk 0) sits in the HIGH half of that slot (then node lane + 64 sits in the low half)
-template <int D>
-JIT_DEV void jit_vnb_load(F32 (&c)[D][2], const U32 (&a)[D]) {
+// SPM: bit i = the block of edge i lives in the workspace row (see msg_ld2)
+#define JIT_VN_EDGE(i, CALL_SP, CALL_LDS) do { if ((SPM >> (i)) & 1u) { CALL_SP; } else { CALL_LDS; } } while (0)
+template <int D, unsigned SPM = 0u>
+JIT_DEV void jit_vnb_load(F32 (&c)[D][2], const U32 (&a)[D], float* ws = nullptr) {
 #pragma unroll
-  for (int i = 0; i < D; ++i) lds_ld2(a[i], 0u, c[i][0], c[i][1]);
+  for (int i = 0; i < D; ++i) JIT_VN_EDGE(i, gm_ld2(ws, a[i], 0u, c[i][0], c[i][1]), lds_ld2(a[i], 0u, c[i][0], c[i][1]));
 }
-template <int D>
-JIT_DEV void jit_vnb_init(const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2]) {
+template <int D, unsigned SPM = 0u>
+JIT_DEV void jit_vnb_init(const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2], float* ws = nullptr) {
 #pragma unroll
-  for (int i = 0; i < D; ++i) lds_st2(a[i], 0u, f_sel(sw[i], l[1], l[0]), f_sel(sw[i], l[0], l[1]));
+  for (int i = 0; i < D; ++i) {
+    const F32 s0 = f_sel(sw[i], l[1], l[0]), s1 = f_sel(sw[i], l[0], l[1]);
+    JIT_VN_EDGE(i, gm_st2(ws, a[i], 0u, s0, s1), lds_st2(a[i], 0u, s0, s1));
+  }
 }
-template <int D>
-JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2], float llr_max, F32 (&xo)[2]) {
+template <int D, unsigned SPM = 0u>
+JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2], float llr_max, F32 (&xo)[2],
+                            float* ws = nullptr) {
   if (JIT_ABL & 2) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) lds_st2(a[i], 0u, c[i][0], c[i][1]);
+    for (int i = 0; i < D; ++i) JIT_VN_EDGE(i, gm_st2(ws, a[i], 0u, c[i][0], c[i][1]), lds_st2(a[i], 0u, c[i][0], c[i][1]));
     xo[0] = 0.f; xo[1] = 0.f;
     return;
   }
@@ -480,7 +501,8 @@ JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D
     f_pk_sub(e0, e1, x0, x1, v0[i], v1[i]);
     e0 = f_med3(e0, -llr_max, llr_max);
     e1 = f_med3(e1, -llr_max, llr_max);
-    lds_st2(a[i], 0u, f_sel(sw[i], e1, e0), f_sel(sw[i], e0, e1));     // node order -> slot order
+    const F32 o0 = f_sel(sw[i], e1, e0), o1 = f_sel(sw[i], e0, e1);    // node order -> slot order
+    JIT_VN_EDGE(i, gm_st2(ws, a[i], 0u, o0, o1), lds_st2(a[i], 0u, o0, o1));
   }
   xo[0] = x0; xo[1] = x1;
 }

@@ -536,8 +536,11 @@ extern "C" size_t samd_ldpc5g_decode_workspace_bytes(const samd_ldpc5g_t* h, int
   const bool boxplus = cn_mode == SAMD_CN_BOXPLUS || cn_mode == SAMD_CN_BOXPLUS_PHI || cn_mode == SAMD_CN_BOXPLUS_PHI_FAST;
   if (boxplus && use_spill_boxplus(h)) return onchip_mss_workspace_bytes(h, batch);
   if (boxplus || use_explicit_minsum(h)) return onchip_bp_workspace_bytes(h, batch);
-  if (use_spill_minsum(h)) return onchip_mss_workspace_bytes(h, batch);
-  return onchip_workspace_bytes(h, batch);
+  // (the kernel generated for a code beyond LDS keeps its last base rows' messages in a workspace row per workgroup; the
+  // generic engine behind it - the fall-back - has its own need: the larger of the two)
+  const size_t jw = jit_workspace_bytes(h, batch, cn_mode);
+  if (use_spill_minsum(h)) return std::max(jw, onchip_mss_workspace_bytes(h, batch));
+  return std::max(jw, onchip_workspace_bytes(h, batch));
 }
 
 // ---- layered schedule (one sub-iteration per base row) on chip: ldpc5g_onchip_ly.hip
@@ -607,7 +610,7 @@ extern "C" int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, 
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   } else {
     // the kernel generated for this code (ldpc5g_jit.cpp: any even lifting size whose messages fit LDS)
-    const int rc = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, stream);
+    const int rc = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, workspace, workspace_bytes, stream);
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
   if (use_spill_minsum(h)) {

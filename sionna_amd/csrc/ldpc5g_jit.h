@@ -42,6 +42,10 @@ struct JitGeometry {
   int blk = 0;      // bytes per edge block (512 per chunk)
   int nw = 16;      // waves per workgroup
   int wgs = 1;      // workgroups per CU
+  // codes whose messages exceed LDS: the edge blocks of the base rows >= spill_row live in the workgroup's row of a
+  // caller-owned workspace (L2); e_lds = edges whose blocks stay in LDS (all of them without spill)
+  int spill_row = -1, e_lds = 0;
+  size_t ws_bytes = 0;   // bytes of one workgroup's workspace row
 };
 
 // development knobs of the generator (SAMD_JIT_* options, read when the source is generated)
@@ -67,6 +71,7 @@ struct JitKnobs {
   int general = 0;        // 1: the any-lifting-size programs also for the codes of the Z = 128 class (A/B)
   int group = 0, wgs = 0; // any-lifting-size programs: codewords per workgroup / workgroups per CU (0: chosen by the generator)
   int pairx = -1;         // -1: by the generator; 0 / 1: pairs inside a codeword / across two codewords
+  int spill = 1;          // codes beyond LDS: the last base rows' blocks in an L2 workspace row (0: such codes keep the generic engines)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
 };
@@ -79,7 +84,10 @@ bool jit_eligible(const samd_ldpc5g* h);
 std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, int rule, bool with_ops, const JitKnobs& knobs);
 // SAMD_OK, SAMD_ERR_UNSUPPORTED (caller runs the generic kernel) or an error
 int launch_onchip_jit(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
-                      float llr_max, float offset, int hard_out, int return_infobits, void* stream);
+                      float llr_max, float offset, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes,
+                      void* stream);
+// workspace the generated kernel of this code needs for `batch` codewords (0: none - the messages fit LDS - or no such kernel)
+size_t jit_workspace_bytes(const samd_ldpc5g* h, int batch, int cn_mode);
 // graph data of the generator for a code that build_onchip_bp_tables left without a plan (any even lifting size)
 void build_jit_plan_general(samd_ldpc5g* h, const std::vector<std::vector<std::pair<int, int>>>& by_row);
 // 0: no generated kernel; 1: the Z = 128 k class (whole chunks of one kind, constants); 2: any-lifting-size programs

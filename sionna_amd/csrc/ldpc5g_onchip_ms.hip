@@ -38,7 +38,7 @@ int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int bat
                      size_t workspace_bytes, hipStream_t st) {
   if (cn_mode == SAMD_CN_BOXPLUS_PHI) {
     // the kernel generated for this code (ldpc5g_jit.cpp) when there is one - the same defined phi, the same bits
-    const int rcj = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, st);
+    const int rcj = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, workspace, workspace_bytes, st);
     if (rcj != SAMD_ERR_UNSUPPORTED) return rcj;
   }
   if (cn_mode == SAMD_CN_BOXPLUS_PHI)
@@ -55,7 +55,7 @@ int launch_onchip_ms(const samd_ldpc5g* h, const float* llr, float* out, int bat
   }
   {
     // the kernel generated for this code (ldpc5g_jit.cpp) when there is one; else the lists below
-    const int rc = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, st);
+    const int rc = launch_onchip_jit(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out, return_infobits, workspace, workspace_bytes, st);
     if (rc != SAMD_ERR_UNSUPPORTED) return rc;
   }
   return launch_onchip_ms_mode<SAMD_CN_MINSUM>(h, llr, out, batch, num_iter, cn_mode, llr_max, offset, hard_out,

@@ -7,9 +7,13 @@
 #include <thread>
 #include <vector>
 
+#ifndef JIT_WS_FLOATS
+#define JIT_WS_FLOATS 0
+#endif
 extern "C" int jit_emu_decode(const float* llr_in, float* out, int batch, int num_iter, float llr_max, float offset,
                               int hard_out, int grid) {
   std::vector<unsigned char> lds((size_t)JIT_LDS_FLOATS * 4);
+  std::vector<float> ws((size_t)JIT_WS_FLOATS * grid + 16, std::numeric_limits<float>::quiet_NaN());   // one row per workgroup
   for (int blk = 0; blk < grid; ++blk) {
     memset(lds.data(), 0xFF, lds.size());                    // NaN pattern: a slot read before it was written shows up
     pthread_barrier_t bar;
@@ -17,8 +21,8 @@ extern "C" int jit_emu_decode(const float* llr_in, float* out, int batch, int nu
     std::vector<std::thread> th;
     for (int w = 0; w < JIT_NWAVES; ++w)
       th.emplace_back([&, w]() {
-        jit_emu_ctx = JitEmuCtx{lds.data(), lds.size(), &bar, blk, grid};
-#define JIT_EMU_CASE(W) case W: jit_wave_##W(llr_in, out, batch, num_iter, llr_max, offset, hard_out); break;
+        jit_emu_ctx = JitEmuCtx{lds.data(), lds.size(), &bar, blk, grid, (size_t)JIT_WS_FLOATS * 4};
+#define JIT_EMU_CASE(W) case W: jit_wave_##W(llr_in, out, batch, num_iter, llr_max, offset, hard_out, ws.data()); break;
         switch (w) {
 #if JIT_NWAVES > 0
           JIT_EMU_CASE(0)

@@ -37,6 +37,7 @@ struct JitEmuCtx {
   size_t lds_bytes;
   pthread_barrier_t* bar;
   int block, grid;
+  size_t ws_bytes;      // bytes of ONE workgroup's row of the workspace
 };
 static thread_local JitEmuCtx jit_emu_ctx;
 // execution mask: JIT_IF(m) ... JIT_END switches the lanes outside m off for every memory access in between (their
@@ -175,6 +176,25 @@ JIT_DEV F32 g_ld(const float* row, const U32& voff, unsigned coff) {
 JIT_DEV void g_st(float* row, const U32& voff, unsigned coff, const F32& x) {
   for (int i = 0; i < 64; ++i) memcpy((char*)row + (voff.v[i] + coff), &x.v[i], 4);
 }
+JIT_DEV void gm_ld2(const float* ws, const U32& a, unsigned off, F32& x0, F32& x1) {
+  for (int i = 0; i < 64; ++i) {
+    x0.v[i] = x1.v[i] = 0.f;
+    if (!jit_emu_exec[i]) continue;
+    const size_t p = (size_t)a.v[i] + off;
+    if (p + 8 > jit_emu_ctx.ws_bytes || (p & 7)) __builtin_trap();
+    memcpy(&x0.v[i], (const char*)ws + p, 4);
+    memcpy(&x1.v[i], (const char*)ws + p + 4, 4);
+  }
+}
+JIT_DEV void gm_st2(float* ws, const U32& a, unsigned off, const F32& x0, const F32& x1) {
+  for (int i = 0; i < 64; ++i) {
+    if (!jit_emu_exec[i]) continue;
+    const size_t p = (size_t)a.v[i] + off;
+    if (p + 8 > jit_emu_ctx.ws_bytes || (p & 7)) __builtin_trap();
+    memcpy((char*)ws + p, &x0.v[i], 4);
+    memcpy((char*)ws + p + 4, &x1.v[i], 4);
+  }
+}
 JIT_DEV F32 g_ld_m(const float* row, const U32& voff, const M64& m) {
   F32 r;
   for (int i = 0; i < 64; ++i) {
@@ -282,5 +302,6 @@ JIT_DEV U32 u_msb_if_neg(const F32& v) {
   return r;
 }
 JIT_DEV void jit_barrier() { pthread_barrier_wait(jit_emu_ctx.bar); }
+JIT_DEV void jit_barrier_g() { pthread_barrier_wait(jit_emu_ctx.bar); }
 template <int P>
 JIT_DEV void jit_setprio() {}

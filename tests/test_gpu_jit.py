@@ -56,7 +56,9 @@ CODES = [(2816, 8448, "bg1", 6), (2816, 8448, "bg1", None), (2816, 5632, "bg1", 
 # codes of the any-lifting-size programs (round 6): BASELINE C4's code (BG2, Z = 80, six codewords per workgroup) and C1's (BG1,
 # Z = 48), fillers / k, n not multiples of 64 / pruned tail of the last base row / a partly filled last chunk / tiny Z
 GENERAL_CODES = [(768, 1536, None, 2), (1024, 2048, "bg1", None), (100, 200, None, None), (4000, 6000, None, 4),
-                 (3000, 4500, "bg1", 6), (20, 60, None, None), (2816, 8436, "bg1", 6), (1234, 2468, None, 4)]
+                 (3000, 4500, "bg1", 6), (20, 60, None, None), (2816, 8436, "bg1", 6), (1234, 2468, None, 4),
+                 # messages beyond LDS: the last base rows' blocks in the L2 workspace row of the workgroup, odd lifting size
+                 (6144, 9216, "bg1", None), (5632, 11264, "bg1", 2), (64, 128, None, None)]
 
 
 @pytest.mark.parametrize("k,n,bg,m", CODES + GENERAL_CODES)

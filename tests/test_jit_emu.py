@@ -117,7 +117,8 @@ def _run_generated(tmp_path, code, h, k, n, m, full=True):
 # interleaver), C1's (BG1, Z = 48), a partly filled last chunk with k / n not multiples of anything, tiny Z (35 codewords per
 # workgroup), a Z = 128 code outside the constant-offset class
 GENERAL = [(768, 1536, None, 2, ("minsum", "offset-minsum", "boxplus-phi")), (1024, 2048, "bg1", None, ("minsum", "boxplus-phi")),
-           (1234, 2468, None, 4, ("offset-minsum",)), (100, 200, None, None, ("minsum",)), (2816, 8436, "bg1", 6, ("minsum",))]
+           (1234, 2468, None, 4, ("offset-minsum",)), (100, 200, None, None, ("minsum",)), (2816, 8436, "bg1", 6, ("minsum",)),
+           (6144, 9216, "bg1", None, ("minsum",))]     # (messages beyond LDS: the last base rows' blocks in the workspace row)
 
 
 @pytest.mark.parametrize("k,n,bg,m,rules", GENERAL)
