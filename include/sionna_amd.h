@@ -205,8 +205,9 @@ int samd_ldpc5g_decode_f32(const samd_ldpc5g_t* h, const float* llr, float* out,
  *   ..._cache_stats: process-wide counters of the code-object cache, what[0] = hipRTC compilations, what[1] = code objects
  *                  read from disk (<cache dir>/<sha256(source | hipRTC version | target)>.co; cache dir = option
  *                  SAMD_JIT_CACHE_DIR, else $XDG_CACHE_HOME/sionna_amd, else $HOME/.cache/sionna_amd; SAMD_JIT_CACHE=0: off).
- * Round 6: the class is every even lifting size whose messages fit LDS (lanes own the copy pair (z, z + Z/2) of one of several
- * codewords of a workgroup); the reference decodes every (k, n) through one path (encoding.py:248-282, decoding.py:1302-1403).
+ * Round 6: the class is every lifting size whose messages fit LDS (an 8-byte slot holds copy z of two codewords, or the copies
+ * (z, z + Z/2) of one; several codewords per workgroup) and the codes with up to 30 % of their messages beyond it (the last base
+ * rows' blocks in the caller's workspace: samd_ldpc5g_decode_workspace_bytes); the reference decodes every (k, n) through one path (encoding.py:248-282, decoding.py:1302-1403).
  * ..._source works on a handle created under the development option SAMD_HOST_ONLY=1 (no device needed; such a handle
  * builds tables and schedules only and refuses every launch). */
 int samd_ldpc5g_jit_supported(const samd_ldpc5g_t* h);
