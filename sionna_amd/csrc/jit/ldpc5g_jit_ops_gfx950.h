@@ -27,14 +27,6 @@ JIT_DEV void lds_st2(U32 a, unsigned off, F32 x0, F32 x1) { *(jit_lds_f32x2*)(un
 typedef bool M64;                                                      // one bit per lane (an SGPR pair)
 JIT_DEV M64 u_testbit(U32 x, unsigned mask) { return (x & mask) != 0u; }
 JIT_DEV F32 f_sel(M64 m, F32 a, F32 b) { return m ? a : b; }
-// exchange a and b in the lanes of m: v_swap_b32 under that execution mask (saved and restored: the programs of partly filled
-// chunks run inside a divergent region)
-JIT_DEV void f_swap_if(M64 m, F32& a, F32& b) {
-  const unsigned long long mk = __builtin_amdgcn_ballot_w64(m);
-  unsigned long long saved;
-  asm volatile("s_mov_b64 %2, exec\n\ts_and_b64 exec, %2, %3\n\tv_swap_b32 %0, %1\n\ts_mov_b64 exec, %2"
-               : "+v"(a), "+v"(b), "=&s"(saved) : "s"(mk));
-}
 // lane index, lane masks and per-lane integers of the any-lifting-size programs (jit/ldpc5g_jit_templates.h, JIT_GENERAL)
 JIT_DEV unsigned jit_lane() { return threadIdx.x & 63u; }
 #define JIT_IF(m) if (m) {                                             // lanes outside m execute nothing up to JIT_END

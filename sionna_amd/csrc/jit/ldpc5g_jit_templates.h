@@ -30,11 +30,6 @@
 #define JIT_LAYOUT_B 0
 #endif
 #define JIT_CH (JIT_LAYOUT_B ? 4u : 256u)
-// JIT_SWAP = 1: the slot-order <-> node-order exchange of a variable-node lane's pair as ONE v_swap_b32 executed under the edge's
-// lane mask (two scalar moves of the execution mask around it) instead of two v_cndmask_b32
-#ifndef JIT_SWAP
-#define JIT_SWAP 0
-#endif
 
 // value written to the output tensor for a VN total x (decoding.py:620-626): clip, then hard decision or the logit
 JIT_DEV F32 jit_outval(F32 x, float llr_max, int hard_out) {
@@ -490,13 +485,8 @@ JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D
   F32 v0[D], v1[D];
 #pragma unroll
   for (int i = 0; i < D; ++i) {                          // slot order -> node order
-#if JIT_SWAP
-    v0[i] = c[i][0]; v1[i] = c[i][1];
-    f_swap_if(sw[i], v0[i], v1[i]);                      // one v_swap_b32 under the edge's lane mask instead of two selections
-#else
     v0[i] = f_sel(sw[i], c[i][1], c[i][0]);
     v1[i] = f_sel(sw[i], c[i][0], c[i][1]);
-#endif
     f_pk_add(x0, x1, v0[i], v1[i]);
   }
   f_pk_add(x0, x1, l[0], l[1]);
@@ -511,12 +501,7 @@ JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D
     f_pk_sub(e0, e1, x0, x1, v0[i], v1[i]);
     e0 = f_med3(e0, -llr_max, llr_max);
     e1 = f_med3(e1, -llr_max, llr_max);
-#if JIT_SWAP
-    F32 o0 = e0, o1 = e1;
-    f_swap_if(sw[i], o0, o1);                                          // node order -> slot order
-#else
     const F32 o0 = f_sel(sw[i], e1, e0), o1 = f_sel(sw[i], e0, e1);    // node order -> slot order
-#endif
     JIT_VN_EDGE(i, gm_st2(ws, a[i], 0u, o0, o1), lds_st2(a[i], 0u, o0, o1));
   }
   xo[0] = x0; xo[1] = x1;

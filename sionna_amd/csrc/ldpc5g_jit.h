@@ -71,7 +71,6 @@ struct JitKnobs {
   int general = 0;        // 1: the any-lifting-size programs also for the codes of the Z = 128 class (A/B)
   int group = 0, wgs = 0; // any-lifting-size programs: codewords per workgroup / workgroups per CU (0: chosen by the generator)
   int pairx = -1;         // -1: by the generator; 0 / 1: pairs inside a codeword / across two codewords
-  int swap = 0;           // variable-node pair exchange by v_swap_b32 under the lane mask instead of two selections
   int spill = 1;          // codes beyond LDS: the last base rows' blocks in an L2 workspace row (0: such codes keep the generic engines)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();

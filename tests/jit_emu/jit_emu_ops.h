@@ -104,10 +104,6 @@ JIT_DEV F32 f_sel(const M64& m, const F32& a, const F32& b) {
   for (int i = 0; i < 64; ++i) r.v[i] = m.v[i] ? a.v[i] : b.v[i];
   return r;
 }
-JIT_DEV void f_swap_if(const M64& m, F32& a, F32& b) {
-  for (int i = 0; i < 64; ++i)
-    if (m.v[i]) { const float t = a.v[i]; a.v[i] = b.v[i]; b.v[i] = t; }
-}
 typedef M64 M64S;
 struct JitEmuExec {
   bool saved[64];
