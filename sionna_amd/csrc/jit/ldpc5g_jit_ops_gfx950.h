@@ -93,6 +93,17 @@ JIT_DEV U32 u_xor256_here(U32 a) {
   asm volatile("v_xor_b32_e32 %0, 0x100, %1" : "=v"(r) : "v"(a));
   return r;
 }
+// a ^ 4 / a & ~4 (the other half of an 8-byte slot / the slot itself), computed where written
+JIT_DEV U32 u_xor4_here(U32 a) {
+  U32 r;
+  asm volatile("v_xor_b32_e32 %0, 4, %1" : "=v"(r) : "v"(a));
+  return r;
+}
+JIT_DEV U32 u_andn4_here(U32 a) {
+  U32 r;
+  asm volatile("v_and_b32_e32 %0, 0xfffffffb, %1" : "=v"(r) : "v"(a));
+  return r;
+}
 JIT_DEV U32 u_xor3(U32 a, U32 b, U32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 JIT_DEV U32 u_xor_and(U32 m, U32 v, unsigned k) { return __builtin_amdgcn_bitop3_b32(m, v, k, 0x78); }   // m ^ (v & k)
 // two IEEE additions / subtractions in one issue slot (v_pk_add_f32)
@@ -125,6 +136,7 @@ JIT_DEV F32 f_frexp_exp(F32 x) { return (float)__builtin_amdgcn_frexp_expf(x); }
 JIT_DEV F32 f_min(F32 a, float b) { return __builtin_fminf(a, b); }
 JIT_DEV U32 u_and_or(U32 a, unsigned m, unsigned o) { return (a & m) | o; }
 JIT_DEV U32 u_msb_if_neg(F32 v) { return (v < 0.f) ? 0x80000000u : 0u; }
+JIT_DEV U32 u_msb_nonzero(F32 v) { return __builtin_bit_cast(unsigned, v) & 0x80000000u; }   // = u_msb_if_neg for every v but -0
 // a phase exchanges LDS data only: wait for this wave's LDS operations, then the workgroup barrier
 JIT_DEV void jit_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int P>

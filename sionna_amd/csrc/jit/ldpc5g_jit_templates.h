@@ -159,6 +159,9 @@ JIT_DEV void jit_cn_store(U32 a0, unsigned off, const F32 (&c)[NCH], float* ws =
 #ifndef JIT_CMP_AHEAD
 #define JIT_CMP_AHEAD 0
 #endif
+#ifndef JIT_A1_NOCLIP
+#define JIT_A1_NOCLIP 0
+#endif
 // xo[h] (FUSE): total of the fused degree-1 VN, for the generated code's output store after the last iteration.
 // PRUNE: lanes of pm[h] are check nodes the rate matching pruned (decoding.py:1344-1373) - they send 0 on every edge.
 template <int D, int NCH, bool FUSE, bool PRUNE = false, bool SP = false>
@@ -213,7 +216,9 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
     // expression returns m1 (0 + m1), so no selection is needed
     const F32 min_e = (m2[h] - m1[h]) + m1[h];
     if (JIT_OFFSET0) {                               // plain min-sum: clip(m - 0, 0, llr_max) = min(m, llr_max), m >= 0
-      a1[h] = f_med3(m1[h], llr_max, 0.f);
+      // JIT_A1_NOCLIP: every v2c was clipped to +-llr_max by its sender (jit_chan, the variable node's med3, the fused column),
+      // so m1 <= llr_max and min(m1, llr_max) is m1 itself; (m2 - m1) + m1 can round ONE ulp above m2 and keeps its clip
+      a1[h] = JIT_A1_NOCLIP ? m1[h] : f_med3(m1[h], llr_max, 0.f);
       a2[h] = f_med3(min_e, llr_max, 0.f);
     } else {
       a1[h] = f_med3(m1[h] - offset, 0.f, llr_max);
@@ -270,6 +275,9 @@ JIT_DEV void jit_cn_update(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], float
 #define JIT_RULE_PHI 0
 #endif
 #if JIT_RULE_PHI
+#ifndef JIT_PHI_LEAN
+#define JIT_PHI_LEAN 0
+#endif
 static JIT_TABLE float jit_phi_tab[64][2] = {
 JIT_PHI_TAB_ROWS
 };
@@ -293,7 +301,11 @@ JIT_DEV void jit_phi_exp2(F32& e0, F32& e1, F32 x0, F32 x1) {
 }
 JIT_DEV void jit_phi_log2(F32& l0, F32& l1, F32 x0, F32 x1) {      // normal positive arguments
   const U32 b0 = f_bits(x0), b1 = f_bits(x1);
-  const F32 ef0 = f_frexp_exp(x0), ef1 = f_frexp_exp(x1);          // e + 1 as a float
+  // e + 1 as a float.  JIT_PHI_LEAN: the biased exponent under the mantissa of 2^23 is the float 2^23 + (e + 127); minus
+  // (2^23 + 126) - exact, small integers - gives the same e + 1 with three full-rate operations (v_lshrrev, v_or, v_sub_f32:
+  // ~7.4 cycles per wave) instead of v_frexp_exp_i32_f32 + v_cvt_f32_i32 (~8.7)
+  const F32 ef0 = JIT_PHI_LEAN ? u_float(u_shr(b0, 23) | 0x4B000000u) - 8388734.0f : f_frexp_exp(x0);
+  const F32 ef1 = JIT_PHI_LEAN ? u_float(u_shr(b1, 23) | 0x4B000000u) - 8388734.0f : f_frexp_exp(x1);
   F32 i0, c0, i1, c1, r0, r1, t0, t1;
   lds_ld2(u_and_or(u_shr(b0, 14), 0x1F8u, JIT_PHI_TAB), 0u, i0, c0);
   lds_ld2(u_and_or(u_shr(b1, 14), 0x1F8u, JIT_PHI_TAB), 0u, i1, c1);
@@ -304,10 +316,20 @@ JIT_DEV void jit_phi_log2(F32& l0, F32& l1, F32 x0, F32 x1) {      // normal pos
   f_pk_fma(t0, t1, t0, t1, r0, r1, c0, c1);
   f_pk_fma(l0, l1, ef0, ef1, 0.69314718055994530942f, t0, t1);
 }
+// JIT_PHI_LEAN (round 6): the clamp as ONE v_med3_f32 that takes |x| as a source modifier (fminf(fmaxf()) compiles to a
+// canonicalising v_max_f32 |x|, |x| in front of it; the same value for every non-NaN x), and the sign of a v2c read from its
+// sign bit: a v2c is never -0 (a variable node's total starts from +0 and x - c is +0 when x == c; jit_chan adds +0), so the
+// bit is exactly "v < 0" - one v_and_b32 instead of v_cmp + v_cndmask.  tests/jit_emu traps if a -0 ever reaches jit_sign_msb.
+JIT_DEV U32 jit_sign_msb(F32 v) { return JIT_PHI_LEAN ? u_msb_nonzero(v) : u_msb_if_neg(v); }
 JIT_DEV void jit_phi2(F32& y0, F32& y1, F32 x0, F32 x1) {
   F32 e0, e1, a0, a1, b0, b1, p0, p1, q0, q1;
-  x0 = f_clamp(x0, 8.5e-8f, 16.635532f);
-  x1 = f_clamp(x1, 8.5e-8f, 16.635532f);
+  if (JIT_PHI_LEAN) {
+    x0 = f_med3(x0, 8.5e-8f, 16.635532f);
+    x1 = f_med3(x1, 8.5e-8f, 16.635532f);
+  } else {
+    x0 = f_clamp(x0, 8.5e-8f, 16.635532f);
+    x1 = f_clamp(x1, 8.5e-8f, 16.635532f);
+  }
   jit_phi_exp2(e0, e1, x0, x1);
   f_pk_addc(a0, a1, e0, e1, 1.0f);
   f_pk_addc(b0, b1, e0, e1, -1.0f);
@@ -336,7 +358,7 @@ JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], f
   for (int i = 0; i < D; ++i)
 #pragma unroll
     for (int h = 0; h < NCH; ++h) {
-      sg[i][h] = u_msb_if_neg(v[i][h]);                      // sign_nz(v) = -1 <=> v < 0 (a -0 counts as +)
+      sg[i][h] = jit_sign_msb(v[i][h]);                      // sign_nz(v) = -1 <=> v < 0 (a -0 counts as +)
       node[h] = node[h] ^ sg[i][h];
     }
   if (NCH == 2) {
@@ -400,7 +422,7 @@ JIT_DEV void jit_cn_phi_rolled(U32 a0, int D, const F32 (&lf)[2], float llr_max,
   for (int i = 0; i < D; ++i) {
     F32 v0, v1, p0, p1;
     lds_ld2(a, 0u, v0, v1);
-    const U32 s0 = u_msb_if_neg(v0), s1 = u_msb_if_neg(v1);
+    const U32 s0 = jit_sign_msb(v0), s1 = jit_sign_msb(v1);
     node0 = node0 ^ s0; node1 = node1 ^ s1;
     sg0 = sg0 | u_shr(s0, 31 - i); sg1 = sg1 | u_shr(s1, 31 - i);
     jit_phi2(p0, p1, f_abs(v0), f_abs(v1));
@@ -503,6 +525,43 @@ JIT_DEV void jit_vnb_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D
     e1 = f_med3(e1, -llr_max, llr_max);
     const F32 o0 = f_sel(sw[i], e1, e0), o1 = f_sel(sw[i], e0, e1);    // node order -> slot order
     JIT_VN_EDGE(i, gm_st2(ws, a[i], 0u, o0, o1), lds_st2(a[i], 0u, o0, o1));
+  }
+  xo[0] = x0; xo[1] = x1;
+}
+
+// ---- the same pair items with 4-byte STORES (round 6, JIT_VN_ST32): a[i] = the slot's byte address + 4 for the lanes whose
+// pair is swapped = where the lane's node `lane` lives; node lane + 64 lives at a[i] ^ 4.  The two results of an edge go out in
+// NODE order through those two addresses (ds_write_b32 x 2: 8 LDS-pipeline cycles against 6, two-way bank conflicts that a 4-byte
+// store hides) instead of two selections into slot order and one ds_write_b64: a v_cndmask_b32 with its lane mask in an SGPR pair
+// issues in ~4.5 cycles per wave, the v_xor_b32 that forms the second address in ~2.5 (profiles/r06w_valu_rate2.txt).  Loads keep the
+// 8-byte form (a[i] & ~4) and their two selections: 4-byte loads would meet two-way conflicts that loads do pay for.
+template <int D>
+JIT_DEV void jit_vnc_load(F32 (&c)[D][2], const U32 (&a)[D]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) lds_ld2(u_andn4_here(a[i]), 0u, c[i][0], c[i][1]);
+}
+template <int D>
+JIT_DEV void jit_vnc_init(const U32 (&a)[D], const F32 (&l)[2]) {
+#pragma unroll
+  for (int i = 0; i < D; ++i) { lds_st(a[i], 0u, l[0]); lds_st(u_xor4_here(a[i]), 0u, l[1]); }
+}
+template <int D>
+JIT_DEV void jit_vnc_update(F32 (&c)[D][2], const U32 (&a)[D], const M64 (&sw)[D], const F32 (&l)[2], float llr_max, F32 (&xo)[2]) {
+  F32 x0 = 0.f, x1 = 0.f;
+  F32 v0[D], v1[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {                          // slot order -> node order
+    v0[i] = f_sel(sw[i], c[i][1], c[i][0]);
+    v1[i] = f_sel(sw[i], c[i][0], c[i][1]);
+    f_pk_add(x0, x1, v0[i], v1[i]);
+  }
+  f_pk_add(x0, x1, l[0], l[1]);
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    F32 e0, e1;
+    f_pk_sub(e0, e1, x0, x1, v0[i], v1[i]);
+    lds_st(a[i], 0u, f_med3(e0, -llr_max, llr_max));
+    lds_st(u_xor4_here(a[i]), 0u, f_med3(e1, -llr_max, llr_max));
   }
   xo[0] = x0; xo[1] = x1;
 }

@@ -72,6 +72,10 @@ struct JitKnobs {
   int group = 0, wgs = 0; // any-lifting-size programs: codewords per workgroup / workgroups per CU (0: chosen by the generator)
   int pairx = -1;         // -1: by the generator; 0 / 1: pairs inside a codeword / across two codewords
   int spill = 1;          // codes beyond LDS: the last base rows' blocks in an L2 workspace row (0: such codes keep the generic engines)
+  int a1 = 1;             // plain min-sum: no clip of the smallest magnitude (it cannot exceed llr_max; JIT_A1_NOCLIP)
+  int phi_tab0 = 1;       // boxplus-phi: table of the logarithm at LDS address 0 (no v_or per lookup)
+  int phi_lean = 1;       // boxplus-phi: clamp as one v_med3 with |x| folded, sign of a v2c from its sign bit (a v2c is never -0)
+  int vst32 = 0;          // Z = 128 class: variable-node results stored in node order by two 4-byte stores (JIT_VN_ST32, templates)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
 };

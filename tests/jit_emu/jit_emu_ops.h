@@ -261,6 +261,8 @@ JIT_DEV U32 u_min(const U32& a, const U32& b) {
 }
 JIT_DEV U32 u_here(const U32& a) { return a; }
 JIT_DEV U32 u_xor256_here(const U32& a) { return a ^ U32(256u); }
+JIT_DEV U32 u_xor4_here(const U32& a) { return a ^ U32(4u); }
+JIT_DEV U32 u_andn4_here(const U32& a) { return a & U32(0xfffffffbu); }
 JIT_DEV U32 u_xor3(const U32& a, const U32& b, const U32& c) { return a ^ b ^ c; }
 JIT_DEV U32 u_xor_and(const U32& m, const U32& v, unsigned k) { return m ^ (v & U32(k)); }
 JIT_DEV void f_pk_add(F32& x0, F32& x1, const F32& c0, const F32& c1) { x0 = x0 + c0; x1 = x1 + c1; }
@@ -299,6 +301,16 @@ JIT_DEV U32 u_and_or(const U32& a, unsigned m, unsigned o) { return (a & U32(m))
 JIT_DEV U32 u_msb_if_neg(const F32& v) {
   U32 r;
   for (int i = 0; i < 64; ++i) r.v[i] = (v.v[i] < 0.f) ? 0x80000000u : 0u;
+  return r;
+}
+JIT_DEV U32 u_msb_nonzero(const F32& v) {                      // the sign bit; the generated code relies on "never -0": checked here
+  U32 r;
+  for (int i = 0; i < 64; ++i) {
+    unsigned b;
+    memcpy(&b, &v.v[i], 4);
+    if (b == 0x80000000u && jit_emu_exec[i]) __builtin_trap();
+    r.v[i] = b & 0x80000000u;
+  }
   return r;
 }
 JIT_DEV void jit_barrier() { pthread_barrier_wait(jit_emu_ctx.bar); }
