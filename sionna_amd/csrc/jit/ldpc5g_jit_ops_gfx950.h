@@ -104,6 +104,9 @@ JIT_DEV U32 u_andn4_here(U32 a) {
   asm volatile("v_and_b32_e32 %0, 0xfffffffb, %1" : "=v"(r) : "v"(a));
   return r;
 }
+// inside an if-block on a wave-uniform condition: keeps it a branch (the optimiser would turn the block into selections
+// executed on every path)
+#define JIT_KEEP_BRANCH() asm volatile("" ::: "memory")
 JIT_DEV U32 u_xor3(U32 a, U32 b, U32 c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
 JIT_DEV U32 u_xor_and(U32 m, U32 v, unsigned k) { return __builtin_amdgcn_bitop3_b32(m, v, k, 0x78); }   // m ^ (v & k)
 // two IEEE additions / subtractions in one issue slot (v_pk_add_f32)

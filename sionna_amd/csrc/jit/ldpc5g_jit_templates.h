@@ -415,7 +415,10 @@ JIT_DEV void jit_cn_update_phi(F32 (&v)[D][NCH], U32 a0, const F32 (&lf)[NCH], f
 // spilled registers (profiles/r05l); rolled they are a tenth.  Same operations on the same values in the same order: same bits.
 template <bool FUSE, bool PRUNE>
 JIT_DEV void jit_cn_phi_rolled(U32 a0, int D, const F32 (&lf)[2], float llr_max, F32 (&xo)[2], const M64 (&pm)[2]) {
-  U32 sg0 = 0u, sg1 = 0u, node0 = 0u, node1 = 0u;          // sg: bit i = sign of edge i's v2c; node: their parity in the msb
+  // the sign of edge i's v2c waits, with phi(|v2c|), in the row's own slot: phi >= 0, so its sign bit is free (the second pass
+  // takes |.| as a source modifier).  Until round 6 the signs were collected in one bit per edge of a register (v_and,
+  // v_lshrrev by a scalar count, v_or in the first pass; two shifts and a v_xor in the second).  node: their parity in the msb.
+  U32 node0 = 0u, node1 = 0u;
   F32 sum0 = 0.f, sum1 = 0.f;
   U32 a = a0;
 #pragma unroll 1
@@ -424,10 +427,9 @@ JIT_DEV void jit_cn_phi_rolled(U32 a0, int D, const F32 (&lf)[2], float llr_max,
     lds_ld2(a, 0u, v0, v1);
     const U32 s0 = jit_sign_msb(v0), s1 = jit_sign_msb(v1);
     node0 = node0 ^ s0; node1 = node1 ^ s1;
-    sg0 = sg0 | u_shr(s0, 31 - i); sg1 = sg1 | u_shr(s1, 31 - i);
     jit_phi2(p0, p1, f_abs(v0), f_abs(v1));
     sum0 = sum0 + p0; sum1 = sum1 + p1;
-    lds_st2(a, 0u, p0, p1);
+    lds_st2(a, 0u, u_float(f_bits(p0) | s0), u_float(f_bits(p1) | s1));
     a = a + (unsigned)JIT_Z4;
   }
   a = a0;
@@ -435,11 +437,15 @@ JIT_DEV void jit_cn_phi_rolled(U32 a0, int D, const F32 (&lf)[2], float llr_max,
   for (int i = 0; i < D; ++i) {
     F32 p0, p1, q0, q1;
     lds_ld2(a, 0u, p0, p1);
-    jit_phi2(q0, q1, f_neg(p0) + sum0, f_neg(p1) + sum1);
-    F32 c0 = u_float(f_bits(f_min(q0, llr_max)) ^ (u_shl(u_shr(sg0, i), 31) ^ node0));
-    F32 c1 = u_float(f_bits(f_min(q1, llr_max)) ^ (u_shl(u_shr(sg1, i), 31) ^ node1));
+    jit_phi2(q0, q1, sum0 - f_abs(p0), sum1 - f_abs(p1));                       // = (-phi) + sum, decoding.py:1147-1152
+    F32 c0 = u_float(u_xor_and(f_bits(f_min(q0, llr_max)) ^ node0, f_bits(p0), 0x80000000u));
+    F32 c1 = u_float(u_xor_and(f_bits(f_min(q1, llr_max)) ^ node1, f_bits(p1), 0x80000000u));
     if (PRUNE) { c0 = f_sel(pm[0], jit_bcast(0.f), c0); c1 = f_sel(pm[1], jit_bcast(0.f), c1); }
     if (FUSE && i == D - 1) {
+      // a BRANCH on the (wave-uniform) trip count: converted to selections, this block ran on every trip and its two
+      // v_cndmask_b32 read a lane mask that a SCALAR instruction wrote (s_cselect_b64 vcc) - ~24 cycles each on gfx950
+      // (profiles/r06w_valu_rate2.txt) against ~2.5 behind a vector comparison
+      JIT_KEEP_BRANCH();
       const F32 x0 = c0 + lf[0], x1 = c1 + lf[1];
       xo[0] = x0; xo[1] = x1;
       c0 = f_med3(x0 - c0, -llr_max, llr_max);

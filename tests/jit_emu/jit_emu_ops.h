@@ -263,6 +263,7 @@ JIT_DEV U32 u_here(const U32& a) { return a; }
 JIT_DEV U32 u_xor256_here(const U32& a) { return a ^ U32(256u); }
 JIT_DEV U32 u_xor4_here(const U32& a) { return a ^ U32(4u); }
 JIT_DEV U32 u_andn4_here(const U32& a) { return a & U32(0xfffffffbu); }
+#define JIT_KEEP_BRANCH() do { } while (0)
 JIT_DEV U32 u_xor3(const U32& a, const U32& b, const U32& c) { return a ^ b ^ c; }
 JIT_DEV U32 u_xor_and(const U32& m, const U32& v, unsigned k) { return m ^ (v & U32(k)); }
 JIT_DEV void f_pk_add(F32& x0, F32& x1, const F32& c0, const F32& c1) { x0 = x0 + c0; x1 = x1 + c1; }
