@@ -14,6 +14,9 @@ JIT_DEV U32 jit_lane4() { return 4u * (threadIdx.x & 63u); }
 JIT_DEV int jit_wave() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 // LDS is addressed by plain byte offsets: the kernel's only __shared__ object starts at offset 0 (checked at entry)
 JIT_DEV F32 lds_ld(U32 a, unsigned off) { return *(jit_lds_f32*)(unsigned long)(a + off); }
+// a 4-byte load the backend must not merge with a neighbour into a two-address form (ds_read2_b32: the two values would
+// come back in neighbouring registers)
+JIT_DEV F32 lds_ld_single(U32 a, unsigned off) { return *(volatile jit_lds_f32*)(unsigned long)(a + off); }
 JIT_DEV void lds_st(U32 a, unsigned off, F32 v) { *(jit_lds_f32*)(unsigned long)(a + off) = v; }
 // both values of an 8-byte slot with one DS instruction (interleaved layout).  volatile: the backend would merge two such
 // accesses 512 bytes apart into ds_read2st64_b64 / ds_write2st64_b64, which move 16 bytes per lane at HALF the rate of two

@@ -299,6 +299,13 @@ JIT_DEV void jit_phi_exp2(F32& e0, F32& e1, F32 x0, F32 x1) {
   e0 = u_float(f_bits(y0) + u_shl(f_bits(t0), 23));          // 2^m through the exponent field, m = low bits of t
   e1 = u_float(f_bits(y1) + u_shl(f_bits(t1), 23));
 }
+// JIT_PHI_TAB32 (round 6): the table as two 256-byte planes (factor, then constant) read with FOUR 4-byte loads per pair: each
+// value lands in the register its packed operation wants.  The 8-byte entry (factor, constant) of ONE lookup came back in two
+// neighbouring registers and the pair (factor of lane value 0, factor of lane value 1) took three v_mov_b32 per logarithm pair to
+// assemble.  LDS has the room (0.26 busy); the plain 4-byte loads may meet bank conflicts (64 entries on 32 banks).
+#ifndef JIT_PHI_TAB32
+#define JIT_PHI_TAB32 0
+#endif
 JIT_DEV void jit_phi_log2(F32& l0, F32& l1, F32 x0, F32 x1) {      // normal positive arguments
   const U32 b0 = f_bits(x0), b1 = f_bits(x1);
   // e + 1 as a float.  JIT_PHI_LEAN: the biased exponent under the mantissa of 2^23 is the float 2^23 + (e + 127); minus
@@ -307,8 +314,14 @@ JIT_DEV void jit_phi_log2(F32& l0, F32& l1, F32 x0, F32 x1) {      // normal pos
   const F32 ef0 = JIT_PHI_LEAN ? u_float(u_shr(b0, 23) | 0x4B000000u) - 8388734.0f : f_frexp_exp(x0);
   const F32 ef1 = JIT_PHI_LEAN ? u_float(u_shr(b1, 23) | 0x4B000000u) - 8388734.0f : f_frexp_exp(x1);
   F32 i0, c0, i1, c1, r0, r1, t0, t1;
-  lds_ld2(u_and_or(u_shr(b0, 14), 0x1F8u, JIT_PHI_TAB), 0u, i0, c0);
-  lds_ld2(u_and_or(u_shr(b1, 14), 0x1F8u, JIT_PHI_TAB), 0u, i1, c1);
+  if (JIT_PHI_TAB32) {
+    const U32 a0 = u_and_or(u_shr(b0, 15), 0xFCu, JIT_PHI_TAB), a1 = u_and_or(u_shr(b1, 15), 0xFCu, JIT_PHI_TAB);
+    i0 = lds_ld_single(a0, 0u); i1 = lds_ld_single(a1, 0u);
+    c0 = lds_ld_single(a0, 256u); c1 = lds_ld_single(a1, 256u);
+  } else {
+    lds_ld2(u_and_or(u_shr(b0, 14), 0x1F8u, JIT_PHI_TAB), 0u, i0, c0);
+    lds_ld2(u_and_or(u_shr(b1, 14), 0x1F8u, JIT_PHI_TAB), 0u, i1, c1);
+  }
   const F32 p0 = u_float(u_and_or(b0, 0x007FFFFFu, 0x3F800000u)), p1 = u_float(u_and_or(b1, 0x007FFFFFu, 0x3F800000u));
   f_pk_fma(r0, r1, p0, p1, i0, i1, -1.0f, -1.0f);
   f_pk_fma(t0, t1, r0, r1, 0.333333343f, -0.5f, -0.5f);
@@ -343,7 +356,8 @@ JIT_DEV void jit_phi2(F32& y0, F32& y1, F32 x0, F32 x1) {
 JIT_DEV void jit_phi_stage(U32 l4) {
   F32 a, b;
   jit_tab_lane(a, b, jit_phi_tab);
-  lds_st2(l4 + l4, JIT_PHI_TAB, a, b);
+  if (JIT_PHI_TAB32) { lds_st(l4, JIT_PHI_TAB, a); lds_st(l4, JIT_PHI_TAB + 256u, b); }
+  else lds_st2(l4 + l4, JIT_PHI_TAB, a, b);
 }
 // the check-node update of bp_math.h's cn_update_col (boxplus-phi branch).  NCH = 2: the two chunks of an edge share every
 // packed operation; NCH = 1 (rows of high degree, one chunk per item: registers): two EDGES share them.
@@ -438,8 +452,11 @@ JIT_DEV void jit_cn_phi_rolled(U32 a0, int D, const F32 (&lf)[2], float llr_max,
     F32 p0, p1, q0, q1;
     lds_ld2(a, 0u, p0, p1);
     jit_phi2(q0, q1, sum0 - f_abs(p0), sum1 - f_abs(p1));                       // = (-phi) + sum, decoding.py:1147-1152
-    F32 c0 = u_float(u_xor_and(f_bits(f_min(q0, llr_max)) ^ node0, f_bits(p0), 0x80000000u));
-    F32 c1 = u_float(u_xor_and(f_bits(f_min(q1, llr_max)) ^ node1, f_bits(p1), 0x80000000u));
+    // min(q, llr_max): the defined phi never exceeds phi(8.5e-8) = 16.635532 (all 231.6 M floats of its domain evaluated,
+    // tests/test_oracle_pins.py), so the clip can only act below that bound - a branch on the launch parameter
+    if (llr_max < 16.635532f) { JIT_KEEP_BRANCH(); q0 = f_min(q0, llr_max); q1 = f_min(q1, llr_max); }
+    F32 c0 = u_float(u_xor_and(f_bits(q0) ^ node0, f_bits(p0), 0x80000000u));
+    F32 c1 = u_float(u_xor_and(f_bits(q1) ^ node1, f_bits(p1), 0x80000000u));
     if (PRUNE) { c0 = f_sel(pm[0], jit_bcast(0.f), c0); c1 = f_sel(pm[1], jit_bcast(0.f), c1); }
     if (FUSE && i == D - 1) {
       // a BRANCH on the (wave-uniform) trip count: converted to selections, this block ran on every trip and its two

@@ -66,6 +66,7 @@ JIT_DEV F32 lds_ld(const U32& a, unsigned off) {
   }
   return r;
 }
+JIT_DEV F32 lds_ld_single(const U32& a, unsigned off) { return lds_ld(a, off); }
 JIT_DEV void lds_st(const U32& a, unsigned off, const F32& x) {
   for (int i = 0; i < 64; ++i) {
     if (!jit_emu_exec[i]) continue;

@@ -141,6 +141,22 @@ def test_phi_round5_exp_log_accuracy():
     assert np.mean(new == old) > 0.85 and np.mean(np.abs(new - old) <= 1e-5 * np.abs(old) + 1e-7) > 0.99
 
 
+def test_phi_defined_range_over_its_whole_domain():
+    """Two facts the generated boxplus-phi kernel (csrc/jit/ldpc5g_jit_templates.h, jit_cn_phi_rolled) builds on, checked on EVERY
+    float of the clamped domain [8.5e-8, 16.635532] (231.6 M arguments, ~8 s of the C oracle): the defined phi is never negative
+    (nor -0) - its sign bit is free to carry the edge's sign between the two passes - and never exceeds phi(8.5e-8) = 16.635532,
+    so min(phi, llr_max) can only act for llr_max below that value."""
+    lo, hi = int(np.float32(8.5e-8).view(np.uint32)), int(np.float32(16.635532).view(np.uint32))
+    top = np.float32(16.635532)
+    step = 1 << 24
+    for s0 in range(lo, hi + 1, step):
+        u = np.arange(s0, min(s0 + step, hi + 1), dtype=np.uint32)
+        y = cbind.phi_f32(u.view(np.float32))
+        assert not np.any(y.view(np.uint32) >> 31), "a negative (or -0) phi value"
+        assert y.max() <= top
+    assert cbind.phi_f32(np.array([8.5e-8], np.float32))[0] == top
+
+
 @pytest.mark.parametrize("k,n,m,bg,batch,iters,ebno", [(1024, 2048, 2, "bg1", 19, 10, 1.5), (2816, 8448, 6, "bg1", 9, 20, 4.5)])
 def test_simd_c_baseline_equals_scalar_c_oracle(k, n, m, bg, batch, iters, ebno):
     """bench.py's CPU baseline (8 codewords per vector, oracle_ldpc_bp_decode_simd) returns the scalar C oracle's soft
