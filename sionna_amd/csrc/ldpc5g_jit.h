@@ -76,6 +76,7 @@ struct JitKnobs {
   int phi_tab0 = 1;       // boxplus-phi: table of the logarithm at LDS address 0 (no v_or per lookup)
   int phi_tab32 = 1;      // boxplus-phi: the table as two planes read with 4-byte loads (no register moves; JIT_PHI_TAB32)
   int phi_lean = 1;       // boxplus-phi: clamp as one v_med3 with |x| folded, sign of a v2c from its sign bit (a v2c is never -0)
+  int simdbal = 0;        // Z = 128 class: items exchanged between waves of different SIMDs to level the per-SIMD instruction sums
   int vst32 = 0;          // Z = 128 class: variable-node results stored in node order by two 4-byte stores (JIT_VN_ST32, templates)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
