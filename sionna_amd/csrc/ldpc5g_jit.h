@@ -57,7 +57,7 @@ struct JitKnobs {
   int layout = 1;      // 1 (Z = 128 only): the two chunks of an edge block interleaved (8-byte DS instructions in both phases)
   int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
   int prio = 1;        // s_setprio per item
-  int vnrev = 1;       // VN lists assigned to the waves in reverse order
+  int vnrev = -1;      // VN lists assigned to the waves in reverse order (-1: by generator - 0 for the levelled Z = 128 schedule, else 1)
   int sched = -1;      // -1: by layout (interleaved 1, planar 0).  0: the generic kernel's lists (tuned on hardware over rounds 2-3: cut items, SIMD-aware order);
                        // 1: an own longest-processing-time assignment by instruction counts - measured 4-7 % slower
                        // for every cost model tried (profiles/r05c_jit_sched_sweep.txt): an item's cost is its latency
@@ -76,7 +76,7 @@ struct JitKnobs {
   int phi_tab0 = 1;       // boxplus-phi: table of the logarithm at LDS address 0 (no v_or per lookup)
   int phi_tab32 = 1;      // boxplus-phi: the table as two planes read with 4-byte loads (no register moves; JIT_PHI_TAB32)
   int phi_lean = 1;       // boxplus-phi: clamp as one v_med3 with |x| folded, sign of a v2c from its sign bit (a v2c is never -0)
-  int simdbal = 0;        // Z = 128 class: items exchanged between waves of different SIMDs to level the per-SIMD instruction sums
+  int simdbal = 1;        // Z = 128 class: items exchanged between waves of different SIMDs to level the per-SIMD instruction sums
   int vst32 = 0;          // Z = 128 class: variable-node results stored in node order by two 4-byte stores (JIT_VN_ST32, templates)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
