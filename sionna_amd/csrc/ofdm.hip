@@ -631,7 +631,10 @@ __device__ __forceinline__ void cir_to_ofdm_pass_body(const float2* __restrict__
     for (int r = 0; r < RPT; ++r) {
       const float2 hv = make_float2(acc[r].x * inv, acc[r].y * inv);            // the value cir_to_ofdm stores
       const float2 v = cmul(hv, xs[(unsigned)((w.ta * T + w.t) * F + f)]);
-      if (w.ta == 0) sy = make_float2(0.f, 0.f);                  // apply_ofdm_channel_kernel: acc = 0; acc += v_k, k ascending
+      // apply_ofdm_channel_kernel: acc = 0; acc += v_k, k ascending.  A BRANCH on the wave-uniform antenna index (the empty asm
+      // keeps it one): as two selections it read a vcc written by s_cselect_b64 - ~24 cycles of the vector pipe each on gfx950
+      // (profiles/r06w_valu_rate2.txt), 48 per staged result
+      if (w.ta == 0) { asm volatile(""); sy = make_float2(0.f, 0.f); }
       sy.x += v.x; sy.y += v.y;
       if (w.ta == TA - 1 && act && w.ra < RA) {
         const unsigned rel = (unsigned)((w.ra * T + w.t) * F + f);

@@ -188,14 +188,30 @@ __global__ __launch_bounds__(64, 8) void polar_scl_reg_kernel(SclArgs p) {
     // LLRs of the register stages: separate scalars selected by the wave-uniform stage (an indexed array, or
     // references captured by a lambda, would be placed in scratch memory)
     float A0 = 0.f, A1 = 0.f, A2 = 0.f, A3 = 0.f, A4 = 0.f;
-#define SCL_GETA(s_) ((R >= 4 && (s_) == 4) ? A4 : (R >= 3 && (s_) == 3) ? A3 : (R >= 2 && (s_) == 2) ? A2 : ((s_) == 1) ? A1 : A0)
-#define SCL_SETA(s_, r_)                  \
-  do {                                    \
-    A0 = (s_) == 0 ? (r_) : A0;           \
-    A1 = (s_) == 1 ? (r_) : A1;           \
-    if (R >= 2) A2 = (s_) == 2 ? (r_) : A2; \
-    if (R >= 3) A3 = (s_) == 3 ? (r_) : A3; \
-    if (R >= 4) A4 = (s_) == 4 ? (r_) : A4; \
+    // (round 6: BRANCHES on the wave-uniform stage.  Written as selections - `A0 = s == 0 ? r : A0` - each became s_cmp +
+    // s_cselect_b64 vcc + v_cndmask_b32_e32, and a v_cndmask_b32_e32 that reads a vcc written by a SCALAR instruction takes ~24
+    // cycles of the SIMD's vector pipe on gfx950 against ~2.5 behind a vector comparison (profiles/r06w_valu_rate2.txt); the empty
+    // asm statements keep the optimiser from converting the branches back)
+#define SCL_GETA(s_)                                                                     \
+  ({                                                                                     \
+    const int gs_ = (s_);                                                                \
+    float gx_;                                                                           \
+    if (R >= 4 && gs_ == 4) { asm volatile(""); gx_ = A4; }                              \
+    else if (R >= 3 && gs_ == 3) { asm volatile(""); gx_ = A3; }                         \
+    else if (R >= 2 && gs_ == 2) { asm volatile(""); gx_ = A2; }                         \
+    else if (gs_ == 1) { asm volatile(""); gx_ = A1; }                                   \
+    else { asm volatile(""); gx_ = A0; }                                                 \
+    gx_;                                                                                 \
+  })
+#define SCL_SETA(s_, r_)                                                                 \
+  do {                                                                                   \
+    const int ss_ = (s_);                                                                \
+    const float sr_ = (r_);                                                              \
+    if (ss_ == 0) { asm volatile(""); A0 = sr_; }                                        \
+    else if (ss_ == 1) { asm volatile(""); A1 = sr_; }                                   \
+    else if (R >= 2 && ss_ == 2) { asm volatile(""); A2 = sr_; }                         \
+    else if (R >= 3 && ss_ == 3) { asm volatile(""); A3 = sr_; }                         \
+    else if (R >= 4 && ss_ == 4) { asm volatile(""); A4 = sr_; }                         \
   } while (0)
     uint32_t bb = 0u;                                   // bit 2s / 2s+1: left / right child result at stage s, position j
     float pm = lane0 / W == 0 ? 0.f : kPolarLlrMax;     // decoding.py:1029-1033 (first lane of the slot)
