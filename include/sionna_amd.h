@@ -217,6 +217,25 @@ long samd_ldpc5g_jit_code(const samd_ldpc5g_t* h, int return_infobits, int cn_mo
 long samd_ldpc5g_jit_launches(const samd_ldpc5g_t* h);
 int samd_ldpc5g_jit_cache_stats(long* what);
 
+/* LDPC5GDecoder.call with return_state=True / msg_v2c (fec/ldpc/decoding.py:573, 636-637; 5G wrapper :1427-1536) on the
+ * generated kernels (round 6).  The kernel moves the message image of one workgroup pass - the LDS copy of the edge blocks of
+ * the codeword(s) a workgroup decodes side by side - to and from image buffers, DEVICE float[ceil(batch / cw_per_pass)][img_floats]:
+ * samd_ldpc5g_state_layout gives the two numbers (SAMD_ERR_UNSUPPORTED: the code's messages exceed LDS - use
+ * samd_ldpc_bp_decode_f32 with its [num_edges, batch] state); samd_ldpc5g_state_map fills three HOST int32[img_floats] arrays:
+ * for every float of the image the codeword of the pass, the check node and the variable node of the lifted (pruned) graph it
+ * belongs to, or -1 (padding, pruned check nodes); the host sorts them into a DEVICE table int32[img_floats] =
+ * codeword << 24 | edge index in the reference's order (edges sorted by variable node, then check node), or -1, and
+ * samd_ldpc5g_state_convert_f32 moves image <-> the reference's state [num_edges, batch] (logit sign) with it.
+ * samd_ldpc5g_decode_state_f32: image_in == NULL starts from the channel values, image_out == NULL returns no state;
+ * llr / out as samd_ldpc5g_decode_f32. */
+int samd_ldpc5g_state_layout(const samd_ldpc5g_t* h, int cn_mode, int* img_floats, int* cw_per_pass);
+int samd_ldpc5g_state_map(const samd_ldpc5g_t* h, int cn_mode, int32_t* cw, int32_t* cn, int32_t* vn);
+int samd_ldpc5g_state_convert_f32(const int32_t* table, int img_floats, int cw_per_pass, long batch, float* image, float* canonical,
+                                  int to_canonical, void* stream);
+int samd_ldpc5g_decode_state_f32(const samd_ldpc5g_t* h, const float* llr, float* out, const float* image_in, float* image_out,
+                                 int batch, int num_iter, int cn_mode, float llr_max, float offset, int hard_out,
+                                 int return_infobits, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Mapping.  points: DEVICE complex64[2^m] (interleaved re,im), label of point i = binary
  * representation of i, MSB first (mapping.py:486-514).

@@ -143,6 +143,20 @@ JIT_DEV F32 f_min(F32 a, float b) { return __builtin_fminf(a, b); }
 JIT_DEV U32 u_and_or(U32 a, unsigned m, unsigned o) { return (a & m) | o; }
 JIT_DEV U32 u_msb_if_neg(F32 v) { return (v < 0.f) ? 0x80000000u : 0u; }
 JIT_DEV U32 u_msb_nonzero(F32 v) { return __builtin_bit_cast(unsigned, v) & 0x80000000u; }   // = u_msb_if_neg for every v but -0
+// the message image of a workgroup pass between LDS and a caller's buffer (state variant): the calling wave's share, 8 bytes
+// per lane and step; rank / nranks = this wave among the waves that copy
+JIT_DEV void jit_copy_g2l(const float* g, unsigned lds_byte, unsigned nbytes, int rank, int nranks) {
+  for (unsigned off = ((unsigned)rank * 64u + (threadIdx.x & 63u)) * 8u; off < nbytes; off += (unsigned)nranks * 512u) {
+    const jit_f32x2 v = *(const jit_f32x2*)((const char*)g + off);
+    *(jit_lds_f32x2*)(unsigned long)(lds_byte + off) = v;
+  }
+}
+JIT_DEV void jit_copy_l2g(float* g, unsigned lds_byte, unsigned nbytes, int rank, int nranks) {
+  for (unsigned off = ((unsigned)rank * 64u + (threadIdx.x & 63u)) * 8u; off < nbytes; off += (unsigned)nranks * 512u) {
+    const jit_f32x2 v = *(jit_lds_f32x2*)(unsigned long)(lds_byte + off);
+    *(jit_f32x2*)((char*)g + off) = v;
+  }
+}
 // a phase exchanges LDS data only: wait for this wave's LDS operations, then the workgroup barrier
 JIT_DEV void jit_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int P>

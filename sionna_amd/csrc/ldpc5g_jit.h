@@ -77,6 +77,7 @@ struct JitKnobs {
   int phi_tab32 = 1;      // boxplus-phi: the table as two planes read with 4-byte loads (no register moves; JIT_PHI_TAB32)
   int phi_lean = 1;       // boxplus-phi: clamp as one v_med3 with |x| folded, sign of a v2c from its sign bit (a v2c is never -0)
   int simdbal = 1;        // Z = 128 class: items exchanged between waves of different SIMDs to level the per-SIMD instruction sums
+  int state = 0;          // the variant that takes / returns the message image of a workgroup pass (return_state / msg_v2c; set by the caller)
   int vst32 = 0;          // Z = 128 class: variable-node results stored in node order by two 4-byte stores (JIT_VN_ST32, templates)
   int abl = 0;         // -DSAMD_DEV builds: SAMD_JIT_ABL (see jit/ldpc5g_jit_templates.h)
   void capture();
@@ -91,7 +92,7 @@ std::string jit_generate_source(const samd_ldpc5g* h, int return_infobits, int r
 // SAMD_OK, SAMD_ERR_UNSUPPORTED (caller runs the generic kernel) or an error
 int launch_onchip_jit(const samd_ldpc5g* h, const float* llr, float* out, int batch, int num_iter, int cn_mode,
                       float llr_max, float offset, int hard_out, int return_infobits, void* workspace, size_t workspace_bytes,
-                      void* stream);
+                      void* stream, const float* state_in = nullptr, float* state_out = nullptr);
 // workspace the generated kernel of this code needs for `batch` codewords (0: none - the messages fit LDS - or no such kernel)
 size_t jit_workspace_bytes(const samd_ldpc5g* h, int batch, int cn_mode);
 // graph data of the generator for a code that build_onchip_bp_tables left without a plan (any even lifting size)

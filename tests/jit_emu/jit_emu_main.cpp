@@ -10,8 +10,9 @@
 #ifndef JIT_WS_FLOATS
 #define JIT_WS_FLOATS 0
 #endif
-extern "C" int jit_emu_decode(const float* llr_in, float* out, int batch, int num_iter, float llr_max, float offset,
-                              int hard_out, int grid) {
+// st_in / st_out (state variant of the generated source, SAMD_JIT_STATE=1): the message images, [passes][JIT image bytes]
+extern "C" int jit_emu_decode_state(const float* llr_in, float* out, int batch, int num_iter, float llr_max, float offset,
+                                    int hard_out, int grid, const float* st_in, float* st_out) {
   std::vector<unsigned char> lds((size_t)JIT_LDS_FLOATS * 4);
   std::vector<float> ws((size_t)JIT_WS_FLOATS * grid + 16, std::numeric_limits<float>::quiet_NaN());   // one row per workgroup
   for (int blk = 0; blk < grid; ++blk) {
@@ -22,7 +23,7 @@ extern "C" int jit_emu_decode(const float* llr_in, float* out, int batch, int nu
     for (int w = 0; w < JIT_NWAVES; ++w)
       th.emplace_back([&, w]() {
         jit_emu_ctx = JitEmuCtx{lds.data(), lds.size(), &bar, blk, grid, (size_t)JIT_WS_FLOATS * 4};
-#define JIT_EMU_CASE(W) case W: jit_wave_##W(llr_in, out, batch, num_iter, llr_max, offset, hard_out, ws.data()); break;
+#define JIT_EMU_CASE(W) case W: jit_wave_##W(llr_in, out, batch, num_iter, llr_max, offset, hard_out, ws.data(), st_in, st_out); break;
         switch (w) {
 #if JIT_NWAVES > 0
           JIT_EMU_CASE(0)
@@ -78,4 +79,9 @@ extern "C" int jit_emu_decode(const float* llr_in, float* out, int batch, int nu
     pthread_barrier_destroy(&bar);
   }
   return 0;
+}
+
+extern "C" int jit_emu_decode(const float* llr_in, float* out, int batch, int num_iter, float llr_max, float offset,
+                              int hard_out, int grid) {
+  return jit_emu_decode_state(llr_in, out, batch, num_iter, llr_max, offset, hard_out, grid, nullptr, nullptr);
 }

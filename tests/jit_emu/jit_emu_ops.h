@@ -315,6 +315,20 @@ JIT_DEV U32 u_msb_nonzero(const F32& v) {                      // the sign bit; 
   }
   return r;
 }
+JIT_DEV void jit_copy_g2l(const float* g, unsigned lds_byte, unsigned nbytes, int rank, int nranks) {
+  for (int lane = 0; lane < 64; ++lane)
+    for (unsigned off = ((unsigned)rank * 64u + lane) * 8u; off < nbytes; off += (unsigned)nranks * 512u) {
+      if ((size_t)lds_byte + off + 8 > jit_emu_ctx.lds_bytes) __builtin_trap();
+      memcpy(jit_emu_ctx.lds + lds_byte + off, (const char*)g + off, 8);
+    }
+}
+JIT_DEV void jit_copy_l2g(float* g, unsigned lds_byte, unsigned nbytes, int rank, int nranks) {
+  for (int lane = 0; lane < 64; ++lane)
+    for (unsigned off = ((unsigned)rank * 64u + lane) * 8u; off < nbytes; off += (unsigned)nranks * 512u) {
+      if ((size_t)lds_byte + off + 8 > jit_emu_ctx.lds_bytes) __builtin_trap();
+      memcpy((char*)g + off, jit_emu_ctx.lds + lds_byte + off, 8);
+    }
+}
 JIT_DEV void jit_barrier() { pthread_barrier_wait(jit_emu_ctx.bar); }
 JIT_DEV void jit_barrier_g() { pthread_barrier_wait(jit_emu_ctx.bar); }
 template <int P>

@@ -158,3 +158,72 @@ def test_jit_class_boundaries():
         h, enc, _ = jit_dump.host_only_handle(k, n, m, bg, return_obj=True)
         assert _ffi.lib().samd_ldpc5g_jit_supported(h) == want, (k, n, bg, m, enc._z)
         _ffi.lib().samd_ldpc5g_destroy(h)
+
+
+# round 6: the state variant (return_state / msg_v2c on the generated kernels).  The image a workgroup pass writes, mapped with
+# samd_ldpc5g_state_map, must be the oracle's msg_v2c; decoding on from an image must equal decoding in one go.
+STATE_CODES = [(2816, 8448, "bg1", 6, "minsum"), (2816, 8448, "bg1", 6, "boxplus-phi"), (768, 1536, None, 2, "minsum"),
+               (1024, 2048, "bg1", None, "minsum"), (1234, 2468, None, 4, "offset-minsum")]
+
+
+@pytest.mark.parametrize("k,n,bg,m,rule", STATE_CODES)
+def test_generated_state_variant_matches_oracle_state(tmp_path, k, n, bg, m, rule):
+    from sionna_amd import _ffi
+    lib0 = _ffi.lib()
+    h, enc, _ = jit_dump.host_only_handle(k, n, m, bg, return_obj=True)
+    code = LDPC5GCode(k, n, m, enc._bg)
+    mode = _ffi.CN_MODES[rule]
+    img, cwpp = C.c_int(), C.c_int()
+    rc = lib0.samd_ldpc5g_state_layout(h, mode, C.byref(img), C.byref(cwpp))
+    assert rc == 0, lib0.samd_last_error().decode()
+    img, cwpp = img.value, cwpp.value
+    cw, cn, vn = (np.empty(img, np.int32) for _ in range(3))
+    assert lib0.samd_ldpc5g_state_map(h, mode, cw.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(C.c_void_p),
+                                      vn.ctypes.data_as(C.c_void_p)) == 0
+    _ffi.set_option("SAMD_JIT_STATE", "1")
+    try:
+        lib, src = _build_emu(tmp_path, h, 1, f"st{k}_{n}_{rule}", rule)
+    finally:
+        _ffi.set_option("SAMD_JIT_STATE", None)
+    assert "jit_copy_l2g" in src and f"// JIT_IMG_BYTES {4 * img}" in src
+    lib.jit_emu_decode_state.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p]
+    batch, grid = 2 * cwpp + 1, 2
+    passes = -(-batch // cwpp)
+    llr = _noisy_llr(code, batch, k + n + 1)
+    llr[1] = np.round(llr[1])
+    off = 0.5 if rule == "offset-minsum" else 0.0
+
+    def run(it, st_in, want):
+        out = np.full((batch, k), np.nan, np.float32)
+        st_out = np.full((passes, img), np.nan, np.float32) if want else None
+        lib.jit_emu_decode_state(llr.ctypes.data, out.ctypes.data, batch, it, 20.0, off, 0, grid,
+                                 None if st_in is None else st_in.ctypes.data, None if st_out is None else st_out.ctypes.data)
+        return out, st_out
+
+    out5, im5 = run(5, None, True)
+    _, im2 = run(2, None, True)
+    out23, im23 = run(3, im2, True)
+    assert np.array_equal(out5, out23) and np.array_equal(im5, im23)
+    assert np.array_equal(run(5, None, False)[0], out5)
+    # the oracle's state (VN-major edge order, logit sign) against the mapped image
+    odec = obp.LDPC5GDecoder(code, cn_update=rule, hard_out=False, return_infobits=True, num_iter=2, return_state=True)
+    key = odec.vn_idx.astype(np.int64) * odec.num_cns + odec.cn_idx
+    assert np.all(np.diff(key) > 0)
+    live = cw >= 0
+    e = np.searchsorted(key, vn[live].astype(np.int64) * odec.num_cns + cn[live])
+    assert np.array_equal(key[e], vn[live].astype(np.int64) * odec.num_cns + cn[live])
+    assert len(np.unique(np.stack([cw[live], e]), axis=1).T) == live.sum() == cwpp * odec.num_edges
+    if rule != "offset-minsum":                                  # (the NumPy oracle's offset rule takes its default offset)
+        _, st = odec.decode(odec.rate_recover(llr), num_iter=2)      # [E, B]
+        got = np.full_like(st, np.nan)
+        q = np.nonzero(live)[0]
+        for p_ in range(passes):
+            b = p_ * cwpp + cw[q]
+            ok = b < batch
+            got[e[ok], b[ok]] = -im2[p_, q[ok]]
+        if rule == "minsum":
+            assert np.array_equal(got, st)
+        else:
+            assert np.mean(np.isclose(got, st, rtol=1e-4, atol=1e-3)) > 0.999
+    lib0.samd_ldpc5g_destroy(h)
