@@ -876,6 +876,44 @@ def main():
             "ms_per_step": round(tl / stepsl * 1e3, 3), "ber": float(cl[0] / max(cl[2], 1)), "bler": float(cl[1] / max(cl[3], 1))}
         del decl
 
+    if args.also and args.also != "none" and world == 1:
+        # return_state / msg_v2c (the iterative detection-and-decoding use): the same 20 iterations as four calls
+        # of five with the decoder state handed from call to call; a quarter of the batch (an image and its deferred tensor per call)
+        Bs = max(1024, B // 4)
+        decs = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=args.cn_update, num_iter=max(1, args.num_iter // 4), hard_out=True,
+                                          return_infobits=True, return_state=True)
+        llrs = llr[:Bs]
+
+        def idd():
+            x, st = decs(llrs)
+            for _ in range(3):
+                x, st = decs(llrs, msg_v2c=st)
+            return x
+        x = idd()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(x.as_subclass(torch.Tensor), dec(llrs).as_subclass(torch.Tensor)))
+        t0 = time.perf_counter()
+        for _ in range(3):
+            idd()
+        torch.cuda.synchronize()
+        ts = (time.perf_counter() - t0) / 3
+        decs._onchip_ok = False                      # the HBM-resident engine (two launches per iteration), the path of rounds 1-5
+        idd()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idd()
+        torch.cuda.synchronize()
+        th = time.perf_counter() - t0
+        out.setdefault("also", {})["return_state"] = {
+            "what": f"LDPC5GDecoder(return_state=True): 4 calls x {max(1, args.num_iter // 4)} iterations, msg_v2c handed from call to call, "
+                    f"batch {Bs}", "cn_update": args.cn_update,
+            "engine": "on-chip, state variant of the generated kernel (message image in / out, [num_edges, batch] tensor deferred)"
+                      if getattr(decs, "_state_lay", (None, None))[1] is not None else "generic-hbm",
+            "value": round(Bs / ts, 1), "unit": "codewords/s", "ms_per_call": round(ts / 4 * 1e3, 3),
+            "same_decisions_as_one_call": same,
+            "hbm_resident_engine": {"value": round(Bs / th, 1), "unit": "codewords/s", "ms_per_call": round(th / 4 * 1e3, 3)}}
+        del decs, llrs
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c2(llr, k, n, m, args.cn_update, args.num_iter, dec, 12.0, B)
         out["speedup_vs_cpu_baseline"] = round(value / out["cpu_baseline"]["value"], 1)

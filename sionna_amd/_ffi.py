@@ -87,6 +87,10 @@ _SIGNATURES = {
     "samd_ldpc5g_jit_source": (C.c_long, [_vp, _i32, _i32, _i32, _vp, _sz]),
     "samd_ldpc5g_jit_code": (C.c_long, [_vp, _i32, _i32, _vp, _sz]),
     "samd_ldpc5g_jit_launches": (C.c_long, [_vp]),
+    "samd_ldpc5g_state_layout": (_i32, [_vp, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
+    "samd_ldpc5g_state_map": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "samd_ldpc5g_state_convert_f32": (_i32, [_vp, _i32, _i32, C.c_long, _vp, _vp, _i32, _vp]),
+    "samd_ldpc5g_decode_state_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp]),
     "samd_ldpc5g_jit_cache_stats": (_i32, [_vp]),
     "samd_ldpc5g_decode_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _i32, _i32, _vp, _sz, _vp]),
     "samd_qam_map_c64": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),

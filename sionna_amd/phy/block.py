@@ -95,6 +95,10 @@ class Tensor(torch.Tensor):
         materialize(self)
         return self.as_subclass(torch.Tensor).detach().cpu().numpy(*args, **kwargs)
 
+    def as_subclass(self, cls):  # pylint: disable=arguments-differ
+        materialize(self)               # (as_subclass does not pass through __torch_function__: the alias would show unfilled storage)
+        return super().as_subclass(cls)
+
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         if _PENDING:                                   # some tensor somewhere is deferred: is one of the operands?

@@ -20,13 +20,14 @@ as padded device tensors): same interface as the reference's, slower than the bu
 """
 import ctypes as C
 import types
+import weakref
 
 import numpy as np
 import scipy.sparse as sp
 import torch
 
 from .... import _ffi
-from ...block import Block
+from ...block import Block, wrap, defer, Pending, pending_of
 from .encoding import LDPC5GEncoder
 
 # workspace cap of one generic-decoder launch; larger batches are processed in slices
@@ -396,6 +397,99 @@ class LDPC5GDecoder(LDPCBPDecoder):
         _ffi.check(rc, "LDPC5GDecoder(on-chip)")
         return out
 
+    _defer_state = True      # return_state on the generated kernels: the [num_edges, batch] tensor is formed on first use
+    _state_last = None
+    _state_kept = None
+
+    def _state_layout(self):
+        """(img_floats, cw_per_pass, device table) of the generated kernel's message image for this code and rule, or None:
+        samd_ldpc5g_state_layout / samd_ldpc5g_state_map (include/sionna_amd.h) sorted into the reference's edge order
+        (edges by variable node, then check node: decoding.py:282-288 = self._cn_idx / self._vn_idx)."""
+        key = (self._cn_mode, _ffi.options_generation())
+        if getattr(self, "_state_lay", (None,))[0] == key:
+            return self._state_lay[1]
+        lib, h = _ffi.lib(), self._encoder._handle(self._nb_pruned_nodes)
+        img, cwpp = C.c_int(), C.c_int()
+        lay = None
+        if lib.samd_ldpc5g_state_layout(h, self._cn_mode, C.byref(img), C.byref(cwpp)) == 0:
+            img, cwpp = img.value, cwpp.value
+            cw, cn, vn = (np.empty(img, np.int32) for _ in range(3))
+            _ffi.check(lib.samd_ldpc5g_state_map(h, self._cn_mode, cw.ctypes.data_as(C.c_void_p), cn.ctypes.data_as(C.c_void_p),
+                                                 vn.ctypes.data_as(C.c_void_p)), "samd_ldpc5g_state_map")
+            key_e = self._vn_idx.astype(np.int64) * self._num_cns + self._cn_idx           # ascending: the reference's order
+            live = cw >= 0
+            want = vn[live].astype(np.int64) * self._num_cns + cn[live]
+            e = np.searchsorted(key_e, want)
+            if (cwpp < 128 and self._num_edges < (1 << 24) and int(live.sum()) == cwpp * self._num_edges
+                    and np.array_equal(key_e[np.minimum(e, self._num_edges - 1)], want)):
+                table = np.full(img, -1, np.int32)
+                table[live] = (cw[live].astype(np.int64) << 24 | e).astype(np.int32)
+                lay = (img, cwpp, torch.from_numpy(table).to(_ffi.device()))
+        self._state_lay = (key, lay)
+        return lay
+
+    def _try_onchip_state(self, llr2d, num_iter, msg_v2c):
+        """return_state / msg_v2c on the generated kernel (decoding.py:573, 636-637): the kernel keeps the messages on chip for
+        the whole call and moves their image in and out once; the [num_edges, batch] tensor of the reference's interface is
+        formed from the image by one more launch - and NOT re-read when the caller hands back the very tensor a previous call
+        returned, unmodified (the iterative detection-and-decoding loop): its image is still here.  None: not covered."""
+        lay = self._state_layout()
+        if lay is None or num_iter < 1:
+            return None
+        img, cwpp, table = lay
+        enc, lib = self._encoder, _ffi.lib()
+        batch = llr2d.shape[0]
+        passes = -(-batch // cwpp)
+        image_in = None
+        if msg_v2c is not None:
+            if not isinstance(msg_v2c, torch.Tensor):
+                msg_v2c = _ffi.to_device(msg_v2c, torch.float32)
+            if tuple(msg_v2c.shape) != (self._num_edges, batch):
+                raise ValueError("msg_v2c must have shape [num_edges, batch_size]")
+            pend, kept = pending_of(msg_v2c), getattr(self, "_state_kept", None)
+            if pend is not None and pend.kind == "ldpc5g_state" and pend.layout is table and pend.image.shape[0] == passes:
+                image_in = pend.image                   # a state this decoder returned and nobody has looked at: never formed
+            elif kept is not None and kept[0]() is msg_v2c and kept[1] == msg_v2c._version and kept[2].shape[0] == passes:
+                image_in = kept[2]                      # formed, but not modified since
+            else:
+                state = _ffi.to_device(msg_v2c, torch.float32)
+                image_in = torch.empty((passes, img), dtype=torch.float32, device=llr2d.device)
+                _ffi.check(lib.samd_ldpc5g_state_convert_f32(_ffi.ptr(table), img, cwpp, batch, _ffi.ptr(image_in), _ffi.ptr(state),
+                                                             0, _ffi.stream()), "state_convert")
+        image_out = torch.empty((passes, img), dtype=torch.float32, device=llr2d.device) if self._return_state else None
+        out_cols = enc.k if self._return_infobits else enc.n
+        out = torch.empty((batch, out_cols), dtype=torch.float32, device=llr2d.device)
+        rc = lib.samd_ldpc5g_decode_state_f32(
+            enc._handle(self._nb_pruned_nodes), _ffi.ptr(llr2d), _ffi.ptr(out), _ffi.ptr(image_in), _ffi.ptr(image_out), batch,
+            int(num_iter), self._cn_mode, self._llr_max, self._offset, int(self._hard_out), int(self._return_infobits), _ffi.stream())
+        if rc == _ffi.ERR_UNSUPPORTED:
+            self._state_lay = (self._state_lay[0], None)
+            return None
+        _ffi.check(rc, "LDPC5GDecoder(on-chip, state)")
+        state_out = None
+        if self._return_state:
+            # the reference's [num_edges, batch] tensor is DEFERRED (phy/block.py): one launch forms it from the image when somebody
+            # reads it; handed back to this decoder untouched, it never exists
+            state_out = torch.empty((self._num_edges, batch), dtype=torch.float32, device=llr2d.device)
+            dec_ref = weakref.ref(self)
+
+            def fill(plain, image=image_out, table=table, img=img, cwpp=cwpp, batch=batch):
+                _ffi.check(_ffi.lib().samd_ldpc5g_state_convert_f32(_ffi.ptr(table), img, cwpp, batch, _ffi.ptr(image), _ffi.ptr(plain),
+                                                                    1, _ffi.stream()), "state_convert")
+                d = dec_ref()
+                if d is not None and d._state_last is not None and d._state_last[0]() is not None:
+                    t = d._state_last[0]()
+                    if t.data_ptr() == plain.data_ptr():
+                        d._state_kept = (d._state_last[0], t._version, image)
+            if self._defer_state:
+                state_out = defer(state_out, Pending("ldpc5g_state", fill, image=image_out, layout=table))
+                self._state_last = (weakref.ref(state_out),)
+            else:
+                state_out = wrap(state_out)
+                self._state_last = (weakref.ref(state_out),)
+                fill(state_out.as_subclass(torch.Tensor))
+        return out, state_out
+
     def _try_onchip_layered(self, llr2d, num_iter):
         """Whole layered decode in one kernel (csrc/ldpc5g_onchip_ly.hip); None when the code is not covered."""
         enc = self._encoder
@@ -432,6 +526,11 @@ class LDPC5GDecoder(LDPCBPDecoder):
             out = self._try_onchip(llr2d, num_iter)
             if out is not None:
                 return out.reshape(out_shape)
+        if (self._onchip_ok and not double and not self._custom and self._cn_mode in (0, 1, 2, 3, 4) and batch > 0
+                and self._scheduling == "flooding" and (self._return_state or msg_v2c is not None)):
+            res = self._try_onchip_state(llr2d, int(num_iter), msg_v2c)
+            if res is not None:
+                return (res[0].reshape(out_shape), res[1]) if self._return_state else res[0].reshape(out_shape)
         # cn_schedule="layered" (one sub-iteration per base row): the on-chip layered engine when the code is covered
         if (self._layered5g and self._onchip_ok and not double and not self._custom and self._cn_mode in (1, 2, 3, 4)
                 and not self._return_state and msg_v2c is None and batch > 0):

@@ -126,3 +126,69 @@ def test_idd_chain_matches_the_reference_executed_chain():
     assert np.mean(np.isclose(kb, g["llr_kbest"], rtol=1e-4, atol=1e-3)) > 0.995
     ep = phy.ofdm.EPDetector("bit", rg, sm, m, l=10, hard_out=False)(y, hf, ev, no).cpu().numpy()
     assert np.mean(np.isclose(ep, g["llr_ep"], rtol=1e-3, atol=1e-2)) > 0.995
+
+
+# round 6: return_state / msg_v2c on the GENERATED kernels (message image in / out, the [num_edges, batch] tensor deferred)
+@pytest.mark.parametrize("k,n,m,bg", [(2816, 8448, 6, "bg1"), (768, 1536, 2, None), (1024, 2048, None, "bg1"), (1234, 2468, 4, None),
+                                     (100, 200, None, None)])
+def test_return_state_on_generated_kernels(k, n, m, bg):
+    """Every code class of the generator (Z = 128 constants; several codewords per workgroup with the pair across two codewords;
+    pairs inside a codeword; partly filled last chunk; tiny Z), the three rules, both output forms: outputs and states of
+    chained calls equal the HBM-resident engine's bit for bit (min-sum family) and the oracle's msg_v2c, whether the state comes
+    back untouched (never formed), as a copy (converted in) or was read in between (formed, image kept)."""
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    from sionna_amd.phy.block import pending_of
+    from oracle.ldpc5g import LDPC5GCode
+    from oracle import ldpc_bp as obp
+    _ffi.device()
+    T = lambda x: x.as_subclass(torch.Tensor)
+    B = 37
+    phy.config.seed = 5
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg=bg)
+    mm = m or 2
+    no = phy.utils.ebnodb2no(2.0, mm, k / n)
+    u = phy.mapping.BinarySource()([B, k])
+    llr = phy.mapping.Demapper("app", "qam", mm)(phy.channel.AWGN()(phy.mapping.Mapper("qam", mm)(enc(u)), no), no)
+    for cn in ("minsum", "offset-minsum", "boxplus-phi"):
+        for rib in (True, False):
+            dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=3, hard_out=False, return_state=True, return_infobits=rib)
+            ref = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update=cn, num_iter=3, hard_out=False, return_state=True, return_infobits=rib)
+            ref._onchip_ok = False
+            x1, s1 = dec(llr)
+            assert dec._state_lay[1] is not None, "the generated kernel with state did not run"
+            assert pending_of(s1) is not None
+            x2, s2 = dec(llr, msg_v2c=s1)                          # untouched: the image goes straight back
+            assert pending_of(s1) is not None
+            s1c = T(s1).clone()                                     # reading forms it ...
+            assert pending_of(s1) is None
+            x2b, _ = dec(llr, msg_v2c=s1)                           # ... formed, not modified: the kept image
+            x3, s3 = dec(llr, msg_v2c=s1c)                          # a copy: converted in
+            y1, t1 = ref(llr)
+            y2, t2 = ref(llr, msg_v2c=t1)
+            pairs = ((x1, y1), (s1, t1), (x2, y2), (s2, t2), (x2b, y2), (x3, y2), (s3, t2))
+            if cn == "boxplus-phi":
+                assert all(torch.allclose(T(a), T(b), rtol=1e-4, atol=1e-3) for a, b in pairs), (cn, rib)
+            else:
+                assert all(torch.equal(T(a), T(b)) for a, b in pairs), (cn, rib)
+            s1.mul_(1.0)                                            # an in-place operation: the kept image no longer counts
+            x4, _ = dec(llr, msg_v2c=s1)
+            assert torch.equal(T(x4), T(x2))
+    code = LDPC5GCode(k, n, m, enc._bg)
+    od = obp.LDPC5GDecoder(code, cn_update="minsum", hard_out=False, return_infobits=True, num_iter=3, return_state=True)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=3, hard_out=False, return_state=True)
+    x, s = dec(llr[:5])
+    xo, so = od.decode(od.rate_recover(T(llr[:5]).cpu().numpy()))
+    assert np.array_equal(T(x).cpu().numpy(), xo[:, :k]) and np.array_equal(T(s).cpu().numpy(), so)
+
+
+def test_return_state_shape_errors_on_generated_kernels():
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    _ffi.device()
+    enc = phy.fec.ldpc.LDPC5GEncoder(768, 1536)
+    dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=2, hard_out=False, return_state=True)
+    llr = torch.randn(8, 1536, device="cuda")
+    _, s = dec(llr)
+    with pytest.raises(ValueError):
+        dec(llr[:4], msg_v2c=s)
