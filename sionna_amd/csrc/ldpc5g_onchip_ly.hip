@@ -319,8 +319,11 @@ __global__ __launch_bounds__(1024) void ldpc5g_decode_ly_kernel(
         } else if (is_vn) {
           const unsigned ax = (unsigned)cy + zq4;
           if ((cx >> 14) & 1) {                                          // the column's first edge: the prefix restarts
+            // (a branch on the wave-uniform record - the empty asm keeps it one: as selections the two resets read a vcc
+            // written by s_cselect_b64, ~24 cycles of the vector pipe each on gfx950, profiles/r06w_valu_rate2.txt)
+            asm volatile("");
             s0 = 0.f;
-            if ((cx >> 6) & 1) s1 = 0.f;
+            if ((cx >> 6) & 1) { asm volatile(""); s1 = 0.f; }
           }
 #define SAMD_LY_VN(KEY, NL, NCHV) case KEY: ly_vn_col<NL, NCHV, POW2>(ent, zq4, zwv, ax, s0, s1, s2, s3, tm); break;
           switch ((cx >> 2) & 63) {
