@@ -62,7 +62,7 @@ struct JitKnobs {
                        // 1: an own longest-processing-time assignment by instruction counts - measured 4-7 % slower
                        // for every cost model tried (profiles/r05c_jit_sched_sweep.txt): an item's cost is its latency
                        // chain, not its instruction count
-  int rotate = 1;      // a wave's item order rotated by its index on its SIMD
+  int rotate = -1;     // a wave's item order rotated by its index on its SIMD (-1: by generator - 0 for the levelled Z = 128 schedule, else 1)
   int cn_slope = 10, cn_ovh = -1, cn_fused = 6, vn_slope = 8, vn_ovh = 10, vn_pair_max = -1;   // cost model (-1: by layout)
   int cn_pair_max = 32;   // rows of higher degree are two single-chunk items
   int waves = 0;          // own schedule (sched = 1): waves per workgroup, 0 = the generic kernel's 16
