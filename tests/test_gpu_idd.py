@@ -192,3 +192,29 @@ def test_return_state_shape_errors_on_generated_kernels():
     _, s = dec(llr)
     with pytest.raises(ValueError):
         dec(llr[:4], msg_v2c=s)
+
+
+def test_state_conversion_float4_path():
+    """one codeword per pass, a batch of whole float4s and full 64-pass tiles: samd_ldpc5g_state_convert_f32 moves 16 bytes per
+    lane on the reference's side (both directions), plus a ragged last tile"""
+    import sionna_amd.phy as phy
+    from sionna_amd import _ffi
+    _ffi.device()
+    T = lambda x: x.as_subclass(torch.Tensor)
+    k, n, m = 2816, 8448, 6
+    phy.config.seed = 9
+    enc = phy.fec.ldpc.LDPC5GEncoder(k, n, num_bits_per_symbol=m, bg="bg1")
+    no = phy.utils.ebnodb2no(3.0, m, k / n)
+    for B in (128, 200):
+        u = phy.mapping.BinarySource()([B, k])
+        llr = phy.mapping.Demapper("app", "qam", m)(phy.channel.AWGN()(phy.mapping.Mapper("qam", m)(enc(u)), no), no)
+        dec = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=2, hard_out=False, return_state=True)
+        ref = phy.fec.ldpc.LDPC5GDecoder(enc, cn_update="minsum", num_iter=2, hard_out=False, return_state=True)
+        ref._onchip_ok = False
+        x1, s1 = dec(llr)
+        y1, t1 = ref(llr)
+        assert dec._state_lay[1] is not None and dec._state_lay[1][1] == 1
+        assert torch.equal(T(s1), T(t1)) and torch.equal(T(x1), T(y1))
+        x2, s2 = dec(llr, msg_v2c=T(t1).clone())                  # a foreign tensor: converted in
+        y2, t2 = ref(llr, msg_v2c=t1)
+        assert torch.equal(T(x2), T(y2)) and torch.equal(T(s2), T(t2))
