@@ -55,7 +55,9 @@ struct JitKnobs {
   int pipe = 1;        // items whose loads are in flight (1: load - update - store per item)
   int xor128 = 0;      // Z = 128: second chunk's block position recomputed in the loop (v_xor) instead of a register
   int layout = 1;      // 1 (Z = 128 only): the two chunks of an edge block interleaved (8-byte DS instructions in both phases)
-  int prefetch = 1;    // next codeword's channel LLRs requested one codeword ahead
+  int prefetch = 0;    // next codeword's channel LLRs requested one codeword ahead.  Round 5: on (+).  End of round 6: OFF - the
+                       // values wait in ~40 registers through a whole decode (23 -> 4 spilled registers without them); C2 min-sum
+                       // 15.58 -> 15.28 ms, boxplus-phi unchanged, the other codes of the sweep -0.5 ... +4.5 % (profiles/r06zy)
   int prio = 1;        // s_setprio per item
   int vnrev = -1;      // VN lists assigned to the waves in reverse order (-1: by generator - 0 for the levelled Z = 128 schedule, else 1)
   int sched = -1;      // -1: by layout (interleaved 1, planar 0).  0: the generic kernel's lists (tuned on hardware over rounds 2-3: cut items, SIMD-aware order);

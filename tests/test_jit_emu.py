@@ -68,7 +68,7 @@ CODES = [(2816, 8448, "bg1", 6), (2816, 8448, "bg1", None), (2816, 5632, "bg1", 
 VARIANTS = [{}, {"SAMD_JIT_LAYOUT": "1"}, {"SAMD_JIT_SCHED": "1", "SAMD_JIT_PIPE": "2", "SAMD_JIT_XOR128": "1", "SAMD_JIT_PREFETCH": "0"},
             {"SAMD_JIT_CMP_AHEAD": "2"}, {"SAMD_JIT_WAVES": "12"}, {"SAMD_JIT_PHI_ROLLED": "0"},
             {"SAMD_JIT_VST32": "1"}, {"SAMD_JIT_A1": "0"}, {"SAMD_JIT_PHI_TAB32": "1"},
-            {"SAMD_JIT_PHI_TAB0": "0", "SAMD_JIT_PHI_LEAN": "0"}]
+            {"SAMD_JIT_PHI_TAB0": "0", "SAMD_JIT_PHI_LEAN": "0"}, {"SAMD_JIT_PREFETCH": "1"}]
 
 
 @pytest.mark.parametrize("k,n,bg,m", CODES)
