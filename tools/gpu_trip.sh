@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parametrised GPU trip (replaces the per-trip tools/gpu_r0*.sh scripts of rounds 3-5).
 #   bash tools/gpurun.sh --timeout S -- 'bash tools/gpu_trip.sh TAG step [step ...]'
-# steps: jit_tests | parity | all_tests | sweep | sweep_quick | bench | bench_prof | pmc | sh:<command>
+# steps: jit_tests | parity | all_tests | sweep | sweep_quick | bench | bench_prof | pmc | idd_rate | pic_rate | ubench2 | sh:<command>
 TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -31,6 +31,9 @@ for step in "$@"; do
       python tools/pmc_counters.py $OUT/pmc --tag $TAG ldpc5g_jit=65536 ldpc5g_jit_phi=65536 ldpc5g_jit_c4=16384 ldpc5g_ms=65536 ldpc5g_bp=65536 ldpc5g_bp_fast=65536 \
         ldpc5g_layered=65536 polar_scl=32768 polar_bp=32768 ofdm_lmmse=6291456 ofdm_lsnn_lmmse=6291456 cir_to_ofdm=69730304 tdl_cir=21102592 > $OUT/pmc/counters.json
       head -c 600 $OUT/pmc/counters.json ;;
+    idd_rate) timeout 600 python tools/idd_rate.py 2>&1 | tee $OUT/idd_rate.txt ;;          # return_state / msg_v2c chain
+    pic_rate) timeout 600 python tools/pic_rate.py 2>&1 | tee $OUT/pic_rate.txt ;;          # MMSE-PIC against the LMMSE detector
+    ubench2) hipcc --offload-arch=gfx950 -O3 -w -o /tmp/valu_rate2 tools/ubench/valu_rate2.hip && timeout 300 /tmp/valu_rate2 2>&1 | tee $OUT/valu_rate2.txt ;;   # issue classes
     sh:*) bash -c "${step#sh:}" 2>&1 | tee -a $OUT/sh.txt ;;
     *) echo "unknown step $step" ;;
   esac
