@@ -749,6 +749,199 @@ __device__ void mmse_pic_solve(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], floa
     }
 }
 
+// The same detector with every array that is indexed by the bit position addressed STATICALLY (round 6; the launchers take it
+// for more than four bits per symbol - 64-QAM: 4.37 -> 3.10 ms per 307 k elements at 8 x 4, the same bits; for up to four bits
+// the guarded loops to kMaxBits cost more than the scratch accesses they remove: 16-QAM 2.02 -> 2.50 ms, QPSK 0.17 -> 0.40 ms,
+// profiles/r06_pic_static_bits.txt - those keep mmse_pic_solve above).
+template <int M, int K>
+__device__ void mmse_pic_solve_bits8(c32 (&y)[M], c32 (&h)[M][K], c32 (&s)[M][M], float (&llr)[K][kMaxBits],
+                               const PicParams& q) {
+  constexpr int N2 = 2 * K;
+  const int nb = q.nb, P = 1 << nb;
+  // whiten_channel(y, h, s, return_s=False): L = chol(S), y <- L^-1 y, H <- L^-1 H
+  cholesky<M>(s);
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    c32 v = y[i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) v = v - s[i][k] * y[k];
+    y[i] = scale(v, 1.f / s[i][i].re);
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      c32 w = h[i][c];
+#pragma unroll
+      for (int k = 0; k < i; ++k) w = w - s[i][k] * h[k][c];
+      h[i][c] = scale(w, 1.f / s[i][i].re);
+    }
+  }
+  c32 ymf[K], g[K][K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    c32 v = C(0.f, 0.f);
+#pragma unroll
+    for (int m = 0; m < M; ++m) v = v + mulc(y[m], h[m][k]);            // conj(h[m][k]) * y[m]
+    ymf[k] = v;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      c32 w = C(0.f, 0.f);
+#pragma unroll
+      for (int m = 0; m < M; ++m) w = w + mulc(h[m][j], h[m][k]);       // conj(h[m][k]) * h[m][j]
+      g[k][j] = w;
+    }
+  }
+  float gr[N2][N2];                                                     // real form of G (complex2real_matrix)
+#pragma unroll
+  for (int r = 0; r < K; ++r)
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      gr[r][c] = g[r][c].re; gr[r][K + c] = -g[r][c].im;
+      gr[K + r][c] = g[r][c].im; gr[K + r][K + c] = g[r][c].re;
+    }
+  // (round 6) every array indexed by the bit position is addressed with STATIC indices: the loops over b run to kMaxBits with a
+  // wave-uniform guard b < nb kept as a branch (PIC_BITS).  With a run-time bound the arrays (priors, log-sigmoids, the running
+  // maxima and sums of the demapper) lived in scratch memory - ~1 KB per thread, read in the innermost loops over the
+  // constellation points at two waves per SIMD.  A point's bit is tested on a per-lane copy of the point index so that the
+  // selection's lane mask comes from a vector comparison (scalar-written vcc: ~24 cycles).  Same operations in the
+  // same order: the same bits (profiles/r06_pic_static_bits.txt).
+#define PIC_BITS(b) _Pragma("unroll") for (int b = 0; b < kMaxBits; ++b) if (b < nb)
+  unsigned lane_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(lane_zero));
+  const int up = kMaxBits - nb;                                           // point index aligned at bit kMaxBits - 1
+  float llr_a[K][kMaxBits];
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+#pragma unroll
+    for (int b = 0; b < kMaxBits; ++b) llr_a[k][b] = 0.f;
+
+  for (int it = 0; it < q.num_iter; ++it) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      PIC_BITS(b) { asm volatile(""); llr_a[k][b] = llr[k][b]; }
+    // soft symbols and their variances from the a-priori LLRs
+    c32 xh[K];
+    float var[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float ls0[kMaxBits], ls1[kMaxBits];
+      PIC_BITS(b) { asm volatile(""); ls1[b] = log_sigmoid(llr_a[k][b]); ls0[b] = log_sigmoid(-llr_a[k][b]); }
+      float mx = -INFINITY;
+      for (int pt = 0; pt < P; ++pt) {
+        const unsigned pv = ((unsigned)pt << up) + lane_zero;
+        float lg = 0.f;
+        PIC_BITS(b) { asm volatile(""); lg += ((pv >> (kMaxBits - 1 - b)) & 1u) ? ls1[b] : ls0[b]; }
+        mx = fmaxf(mx, lg);
+      }
+      float den = 0.f, mr = 0.f, mi = 0.f;
+      for (int pt = 0; pt < P; ++pt) {
+        const unsigned pv = ((unsigned)pt << up) + lane_zero;
+        float lg = 0.f;
+        PIC_BITS(b) { asm volatile(""); lg += ((pv >> (kMaxBits - 1 - b)) & 1u) ? ls1[b] : ls0[b]; }
+        const float e = expf(lg - mx);
+        den += e; mr += e * q.points[pt].x; mi += e * q.points[pt].y;
+      }
+      mr /= den; mi /= den;
+      float vv = 0.f;
+      for (int pt = 0; pt < P; ++pt) {
+        const unsigned pv = ((unsigned)pt << up) + lane_zero;
+        float lg = 0.f;
+        PIC_BITS(b) { asm volatile(""); lg += ((pv >> (kMaxBits - 1 - b)) & 1u) ? ls1[b] : ls0[b]; }
+        const float dr = q.points[pt].x - mr, di = q.points[pt].y - mi;
+        vv += (expf(lg - mx) / den) * (dr * dr + di * di);
+      }
+      xh[k] = C(mr, mi);
+      var[k] = vv;
+    }
+    // parallel interference cancellation: ypic[k][j] = y_mf[k] + g[k][j] xh[j] - sum_i g[k][i] xh[i]
+    c32 ypic[K][K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      c32 gx = C(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < K; ++i) gx = gx + g[k][i] * xh[i];
+#pragma unroll
+      for (int j = 0; j < K; ++j) ypic[k][j] = ymf[k] + g[k][j] * xh[j] - gx;
+    }
+    // A = G_r * diag(v, v) + I, inverted by Gauss-Jordan elimination with partial pivoting
+    float a[N2][N2], ai[N2][N2];
+#pragma unroll
+    for (int r = 0; r < N2; ++r)
+#pragma unroll
+      for (int c = 0; c < N2; ++c) {
+        a[r][c] = gr[r][c] * var[c % K] + (r == c ? 1.f : 0.f);
+        ai[r][c] = r == c ? 1.f : 0.f;
+      }
+    for (int c = 0; c < N2; ++c) {
+      int piv = c;
+      float best = fabsf(a[c][c]);
+      for (int r = c + 1; r < N2; ++r)
+        if (fabsf(a[r][c]) > best) { best = fabsf(a[r][c]); piv = r; }
+      if (piv != c)
+        for (int j = 0; j < N2; ++j) {
+          float t = a[c][j]; a[c][j] = a[piv][j]; a[piv][j] = t;
+          t = ai[c][j]; ai[c][j] = ai[piv][j]; ai[piv][j] = t;
+        }
+      const float inv = 1.f / a[c][c];
+      for (int j = 0; j < N2; ++j) { a[c][j] *= inv; ai[c][j] *= inv; }
+      for (int r = 0; r < N2; ++r)
+        if (r != c) {
+          const float fct = a[r][c];
+          for (int j = 0; j < N2; ++j) { a[r][j] -= fct * a[c][j]; ai[r][j] -= fct * ai[c][j]; }
+        }
+    }
+    // bias mu, unbiased estimates and post-filter variance (detection.py:1580-1606)
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float mu0 = 0.f, mu1 = 0.f, x0 = 0.f, x1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < N2; ++c) {
+        const float v = c < K ? ypic[c < K ? c : 0][k].re : ypic[c < K ? 0 : c - K][k].im;   // real vector of column k of ypic
+        mu0 += ai[k][c] * gr[c][k];
+        mu1 += ai[K + k][c] * gr[c][K + k];
+        x0 += ai[k][c] * v;
+        x1 += ai[K + k][c] * v;
+      }
+      const float xr = x0 / mu0, xi = x1 / mu1;
+      const float vx = mu0 / fmaxf(1.f - var[k] * mu0, 1e-4f);
+      const float no_eff = fmaxf(1.f / vx, 1.17549435e-38f);
+      // demapping with priors llr_a (app: logsumexp, maxlog: max) over the points with bit b = 1 / 0
+      float ls0[kMaxBits], ls1[kMaxBits], m1[kMaxBits], m0[kMaxBits], s1[kMaxBits], s0[kMaxBits];
+      PIC_BITS(b) {
+        asm volatile("");
+        ls1[b] = log_sigmoid(llr_a[k][b]); ls0[b] = log_sigmoid(-llr_a[k][b]);
+        m1[b] = m0[b] = -INFINITY; s1[b] = s0[b] = 0.f;
+      }
+      for (int pass = 0; pass < (q.maxlog ? 1 : 2); ++pass)
+        for (int pt = 0; pt < P; ++pt) {
+          const unsigned pv = ((unsigned)pt << up) + lane_zero;
+          const float dr = xr - q.points[pt].x, di = xi - q.points[pt].y;
+          float tl = -(dr * dr + di * di) / no_eff;
+          float ps = 0.f;
+          PIC_BITS(b) { asm volatile(""); ps += ((pv >> (kMaxBits - 1 - b)) & 1u) ? ls1[b] : ls0[b]; }
+          tl += ps;
+          PIC_BITS(b) {
+            asm volatile("");
+            const bool one = (pv >> (kMaxBits - 1 - b)) & 1u;
+            const float mo = one ? m1[b] : m0[b];                       // (one fmaxf / expf per point and bit, as before)
+            if (pass == 0) { const float mn = fmaxf(mo, tl); m1[b] = one ? mn : m1[b]; m0[b] = one ? m0[b] : mn; }
+            else { const float e = expf(tl - mo); s1[b] = one ? s1[b] + e : s1[b]; s0[b] = one ? s0[b] : s0[b] + e; }
+          }
+        }
+      PIC_BITS(b) {
+        asm volatile("");
+        llr[k][b] = q.maxlog ? (m1[b] - m0[b]) : ((m1[b] + logf(s1[b])) - (m0[b] + logf(s0[b])));
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    PIC_BITS(b) {
+      asm volatile("");
+      const float e = llr[k][b] - llr_a[k][b];
+      llr[k][b] = q.hard_out ? (e > 0.f ? 1.f : 0.f) : e;
+    }
+#undef PIC_BITS
+}
+
 // ------------------------------------------------------------------ EP detector
 // EPDetector.call  mimo/detection.py:1229-1312 (expectation propagation of [EP2014], bit output):
 // whitening, real-valued decomposition (2M x 2K, noise variance 1/2 per real dimension), l iterations
@@ -1191,7 +1384,7 @@ __global__ __launch_bounds__(64) void ofdm_kbest_real_kernel(OfdmEqArgs p, KBest
 }
 
 // ---- standalone detector on n problems: y [n,M], h [n,M,K], s [n,M,M], prior [n,K,nb] -> out [n,K,nb]
-template <int M, int K>
+template <int M, int K, bool B8>
 __global__ __launch_bounds__(64) void mmse_pic_items_kernel(const float2* __restrict__ y, const float2* __restrict__ h,
                                                             const float2* __restrict__ s, const float* __restrict__ prior,
                                                             int64_t n, PicParams q, float* __restrict__ out) {
@@ -1209,14 +1402,15 @@ __global__ __launch_bounds__(64) void mmse_pic_items_kernel(const float2* __rest
   }
   for (int k = 0; k < K; ++k)
     for (int b = 0; b < q.nb; ++b) llr[k][b] = prior[(i * K + k) * q.nb + b];
-  mmse_pic_solve<M, K>(yy, hh, ss, llr, q);
+  if constexpr (B8) mmse_pic_solve_bits8<M, K>(yy, hh, ss, llr, q);
+  else mmse_pic_solve<M, K>(yy, hh, ss, llr, q);
   for (int k = 0; k < K; ++k)
     for (int b = 0; b < q.nb; ++b) out[(i * K + k) * q.nb + b] = llr[k][b];
 }
 
 // ---- fused OFDM MMSE-PIC detector (ofdm/detection.py:1062-1173 + OFDMDetectorWithPrior :320-560):
 // prior / out [B, S, ND * nb]; REs without data for a stream enter with a zero prior.
-template <int M, int K>
+template <int M, int K, bool B8>
 __global__ __launch_bounds__(64) void ofdm_mmse_pic_kernel(OfdmEqArgs p, const float* __restrict__ prior, PicParams q,
                                                            float* __restrict__ out) {
   const int re_i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1231,7 +1425,8 @@ __global__ __launch_bounds__(64) void ofdm_mmse_pic_kernel(OfdmEqArgs p, const f
     const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + (dpos[k] >= 0 ? dpos[k] : 0)) * q.nb;
     for (int bb = 0; bb < q.nb; ++bb) llr[k][bb] = dpos[k] >= 0 ? prior[o + bb] : 0.f;
   }
-  mmse_pic_solve<M, K>(y, h, s, llr, q);
+  if constexpr (B8) mmse_pic_solve_bits8<M, K>(y, h, s, llr, q);
+  else mmse_pic_solve<M, K>(y, h, s, llr, q);
   for (int k = 0; k < K; ++k)
     if (dpos[k] >= 0) {
       const int64_t o = ((b * p.S + p.desired[rx * K + k]) * p.ND + dpos[k]) * q.nb;
@@ -1614,7 +1809,11 @@ extern "C" int samd_mmse_pic_f32(const float* y, const float* h, const float* s,
   const dim3 grid((unsigned)((n + 63) / 64));
 #define X(M, K)                                                                                                   \
   if (m == M && k == K) {                                                                                         \
-    hipLaunchKernelGGL((mmse_pic_items_kernel<M, K>), grid, dim3(64), 0, (hipStream_t)stream, (const float2*)y,  \
+    if (num_bits_per_symbol > 4)                                                                                  \
+      hipLaunchKernelGGL((mmse_pic_items_kernel<M, K, true>), grid, dim3(64), 0, (hipStream_t)stream, (const float2*)y,  \
+                         (const float2*)h, (const float2*)s, prior, n, q, out);                                   \
+    else                                                                                                          \
+    hipLaunchKernelGGL((mmse_pic_items_kernel<M, K, false>), grid, dim3(64), 0, (hipStream_t)stream, (const float2*)y,  \
                        (const float2*)h, (const float2*)s, prior, n, q, out);                                     \
     return launch_status();                                                                                       \
   }
@@ -1645,7 +1844,11 @@ extern "C" int samd_ofdm_mmse_pic_f32(const float* y, const float* h_hat, const 
 #define X(M, K)                                                                                              \
   if (num_rx_ant == M && streams_per_rx == K) {                                                              \
     for (p.brx0 = 0; p.brx0 < brx_total; p.brx0 += 65535)                                                   \
-      hipLaunchKernelGGL((ofdm_mmse_pic_kernel<M, K>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(64), 0,     \
+      if (q.nb > 4)                                                                                          \
+        hipLaunchKernelGGL((ofdm_mmse_pic_kernel<M, K, true>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(64), 0,     \
+                           (hipStream_t)stream, p, prior, q, out); \
+      else                                                                                                   \
+      hipLaunchKernelGGL((ofdm_mmse_pic_kernel<M, K, false>), dim3(tf_blocks, std::min(brx_total - p.brx0, 65535)), dim3(64), 0,     \
                          (hipStream_t)stream, p, prior, q, out); \
     return launch_status();                                                                                  \
   }
